@@ -1,0 +1,635 @@
+// forge3d_amd/csrc/f3d_host.hip -- host side of libf3dhip.so (C ABI in include/f3d_terrain_pt.h).
+//
+// Mirrors, for the one hot path, what the reference does in Rust:
+//   validate_desc                       src/path_tracing/hybrid_compute/render_terrain.rs:474-557
+//   TerrainPtScene::new / pyramid       .../terrain_heightfield.rs:132-202, :390-494
+//   EarthCurvatureUniforms::new         .../terrain_heightfield.rs:52-84 + src/geo/refraction.rs
+//   HybridPathTracer::render_terrain_reference   .../render_terrain.rs:563-1434
+// with a different runtime: no per-frame host synchronisation (frames are enqueued
+// back to back on one HIP stream; the host reads ONE 16-byte record per 32-frame window
+// instead of 8 B/pixel), packed 16-byte reservoirs, and acceleration tables built on the
+// GPU.  There is no CPU fallback: every entry point that computes needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <new>
+
+#include "f3d_launch.h"
+#include "f3d_setup.h"
+
+using namespace f3d;
+
+namespace {
+
+void hip_check(hipError_t e, const char *what) {
+    if (e != hipSuccess) fail(F3D_STATUS_DEVICE, "HIP failure in %s: %s", what, hipGetErrorString(e));
+}
+
+}  // namespace
+
+namespace {
+
+// ---- device memory ledger (the reference's TrackedGpu / global memory tracker) ----
+struct Ledger {
+    std::vector<void *> owned;
+    uint64_t device_bytes = 0;
+    uint64_t host_visible_peak = 0;
+    void *alloc(size_t bytes, const char *what) {
+        void *p = nullptr;
+        hip_check(hipMalloc(&p, bytes ? bytes : 16), what);
+        owned.push_back(p);
+        device_bytes += bytes;
+        return p;
+    }
+    void note_host_visible(uint64_t bytes) {
+        if (bytes > host_visible_peak) host_visible_peak = bytes;
+    }
+    void release() {
+        for (void *p : owned) (void)hipFree(p);
+        owned.clear();
+    }
+};
+
+// ---- acceleration tables, built on the GPU ----
+struct TerrainTables {
+    TerrainDev dev{};
+    TableLayout layout;
+    uint64_t bytes = 0;  // leaf + node tables
+    LeafRec *leaves = nullptr;
+    NodeRec *nodes = nullptr;
+};
+
+TerrainTables build_tables(Ledger &mem, const float *d_heights, uint32_t w, uint32_t h, float exaggeration,
+                           hipStream_t stream) {
+    TerrainTables t;
+    t.layout = table_layout(w, h);
+    const TableLayout &L = t.layout;
+    t.leaves = (LeafRec *)mem.alloc(L.leaf_count * sizeof(LeafRec), "leaf table");
+    t.nodes = (NodeRec *)mem.alloc((L.node_count ? L.node_count : 1) * sizeof(NodeRec), "node table");
+    t.bytes = L.leaf_count * sizeof(LeafRec) + L.node_count * sizeof(NodeRec);
+    hip_check(launch_leaf_build(leaf_build_params(L, d_heights, w, h, exaggeration, t.leaves), stream),
+              "leaf table build");
+    for (uint32_t l = 1; l < L.levels; l++)
+        hip_check(launch_level_build(level_build_params(L, l, t.leaves, t.nodes), stream), "node table build");
+    apply_layout(L, t.dev);
+    t.dev.leaves = t.leaves;
+    t.dev.nodes = t.nodes;
+    return t;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// session
+// ---------------------------------------------------------------------------------------
+struct f3d_session {
+    Ledger mem;
+    hipStream_t stream = nullptr;
+    int device = 0;
+    FrameParams params{};
+    TerrainTables tables;
+    uint32_t width = 0, height = 0, row_begin = 0, row_end = 0, rows = 0;
+    PackedReservoir *res[2] = {nullptr, nullptr};
+    float4 *gbuffer_n = nullptr;
+    float *depth = nullptr;
+    uint32_t *stats = nullptr;
+    uint32_t *host_stats = nullptr;  // pinned
+    uint8_t *d_rgba = nullptr;
+    float *d_albedo = nullptr, *d_normal = nullptr;
+    int variant = 0;
+    bool require_valid_reservoirs = false;
+    uint64_t budget = 0;
+    // per-launch timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    ~f3d_session() {
+        for (auto &e : events) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+        if (host_stats) (void)hipHostFree(host_stats);
+        mem.release();
+    }
+};
+
+namespace {
+
+void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_session_opts *opts) {
+    validate_desc(d);
+    validate_scene(d);
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        fail(F3D_STATUS_DEVICE, "no HIP device available: libf3dhip has no CPU fallback");
+    s.device = (opts && opts->device >= 0) ? opts->device : -1;
+    if (s.device >= 0) hip_check(hipSetDevice(s.device), "hipSetDevice");
+    else hip_check(hipGetDevice(&s.device), "hipGetDevice");
+    s.stream = opts ? (hipStream_t)opts->stream : nullptr;
+    s.variant = opts ? opts->kernel_variant : 0;
+    s.budget = (opts && opts->memory_budget_bytes) ? opts->memory_budget_bytes : (512ull << 20);
+    s.width = d.width;
+    s.height = d.height;
+    s.row_begin = opts ? opts->row_begin : 0u;
+    s.row_end = (opts && opts->row_end) ? opts->row_end : d.height;
+    if (s.row_begin >= s.row_end || s.row_end > d.height)
+        fail(F3D_STATUS_VALUE, "invalid row strip [%u, %u) for image height %u", s.row_begin, s.row_end, d.height);
+    s.rows = s.row_end - s.row_begin;
+
+    FrameParams &P = s.params;
+    s.require_valid_reservoirs = fill_uniforms(d, P);  // curvature, camera, lighting
+
+    // DEM upload + GPU table build (reference: CPU build + per-level write_texture)
+    const size_t dem_n = (size_t)d.dem_width * d.dem_height;
+    float *d_heights = (float *)s.mem.alloc(dem_n * sizeof(float), "DEM upload");
+    hip_check(hipMemcpy(d_heights, d.heights, dem_n * sizeof(float), hipMemcpyHostToDevice), "DEM upload");
+    s.tables = build_tables(s.mem, d_heights, d.dem_width, d.dem_height, d.exaggeration, s.stream);
+    apply_layout(s.tables.layout, P.terrain);
+    P.terrain.leaves = s.tables.leaves;
+    P.terrain.nodes = s.tables.nodes;
+
+    // environment map as rgb+pad texels (the reference uploads RGBA32F, terrain_heightfield.rs:443-482)
+    if (d.env_map) {
+        const size_t n = (size_t)d.env_width * d.env_height;
+        const std::vector<float> rgba = pad_rgb_to_rgba(d.env_map, n, 1.0f);
+        float4 *tex = (float4 *)s.mem.alloc(n * sizeof(float4), "env map");
+        hip_check(hipMemcpy(tex, rgba.data(), n * sizeof(float4), hipMemcpyHostToDevice), "env upload");
+        P.env.texels = tex;
+        P.env.width = d.env_width;
+        P.env.height = d.env_height;
+    }
+    // mesh (HybridScene::mesh_only + upload, src/sdf/hybrid.rs:285-366: vec4-padded vertices)
+    if (d.mesh_vertices) {
+        const std::vector<float> v4 = pad_rgb_to_rgba(d.mesh_vertices, d.mesh_vertex_count, 0.0f);
+        float4 *dv = (float4 *)s.mem.alloc(v4.size() * sizeof(float), "mesh vertices");
+        uint32_t *di = (uint32_t *)s.mem.alloc((size_t)d.mesh_index_count * sizeof(uint32_t), "mesh indices");
+        hip_check(hipMemcpy(dv, v4.data(), v4.size() * sizeof(float), hipMemcpyHostToDevice), "mesh upload");
+        hip_check(hipMemcpy(di, d.mesh_indices, (size_t)d.mesh_index_count * sizeof(uint32_t), hipMemcpyHostToDevice),
+                  "mesh upload");
+        P.mesh.vertices = dv;
+        P.mesh.indices = di;
+        P.mesh.vertex_count = d.mesh_vertex_count;
+        P.mesh.index_count = d.mesh_index_count;
+        P.mesh.traversal_mode = 0u;
+    }
+    P.row_begin = s.row_begin;
+    P.row_end = s.row_end;
+
+    // per-pixel state
+    const size_t px = (size_t)s.rows * s.width;
+    const size_t res_n = (size_t)(s.rows + 2 * kHaloRows) * s.width;
+    {
+        // memory-budget gate, render_terrain.rs:875-888 -- evaluated on the planned working
+        // set BEFORE the large allocations are made (the reference allocates, then checks).
+        const uint64_t planned = s.mem.device_bytes + 2 * (uint64_t)res_n * sizeof(PackedReservoir) +
+                                 (uint64_t)px * (sizeof(float4) + sizeof(float) + sizeof(float4) + sizeof(float) + 4 +
+                                                 3 * sizeof(float) + 3 * sizeof(float)) + 16;
+        if (planned > s.budget)
+            fail(F3D_STATUS_RENDER,
+                 "terrain PT exceeds the memory budget before rendering: tracked total %llu (host-visible %llu) > "
+                 "limit %llu",
+                 (unsigned long long)planned, (unsigned long long)s.mem.host_visible_peak,
+                 (unsigned long long)s.budget);
+    }
+    for (int i = 0; i < 2; i++) {
+        if (opts && opts->ext_reservoirs[i]) {
+            s.res[i] = (PackedReservoir *)opts->ext_reservoirs[i];
+            s.mem.device_bytes += res_n * sizeof(PackedReservoir);  // caller-owned, still part of the working set
+        } else {
+            s.res[i] = (PackedReservoir *)s.mem.alloc(res_n * sizeof(PackedReservoir), "reservoirs");
+        }
+        hip_check(hipMemsetAsync(s.res[i], 0, res_n * sizeof(PackedReservoir), s.stream), "reservoir clear");
+    }
+    P.accum_mean = (float4 *)s.mem.alloc(px * sizeof(float4), "accumulation");
+    P.welford_m2 = (float *)s.mem.alloc(px * sizeof(float), "welford");
+    s.gbuffer_n = (float4 *)s.mem.alloc(px * sizeof(float4), "g-buffer");
+    s.depth = (float *)s.mem.alloc(px * sizeof(float), "depth AOV");
+    s.d_rgba = (uint8_t *)s.mem.alloc(px * 4, "rgba8 output");
+    s.d_albedo = (float *)s.mem.alloc(px * 3 * sizeof(float), "albedo AOV");
+    s.d_normal = (float *)s.mem.alloc(px * 3 * sizeof(float), "normal AOV");
+    if (opts && opts->ext_stats) s.stats = (uint32_t *)opts->ext_stats;
+    else s.stats = (uint32_t *)s.mem.alloc(4 * sizeof(uint32_t), "stats");
+    hip_check(hipMemsetAsync(P.accum_mean, 0, px * sizeof(float4), s.stream), "accum clear");
+    hip_check(hipMemsetAsync(P.welford_m2, 0, px * sizeof(float), s.stream), "welford clear");
+    hip_check(hipMemsetAsync(s.stats, 0, 4 * sizeof(uint32_t), s.stream), "stats clear");
+    hip_check(hipHostMalloc((void **)&s.host_stats, 4 * sizeof(uint32_t), hipHostMallocDefault), "pinned stats");
+    s.mem.note_host_visible(4 * sizeof(uint32_t));
+    P.gbuffer_n = s.gbuffer_n;
+    P.stats = s.stats;
+
+    // memory-budget gate, render_terrain.rs:875-888
+    if (s.mem.device_bytes > s.budget)
+        fail(F3D_STATUS_RENDER,
+             "terrain PT exceeds the memory budget before rendering: tracked total %llu (host-visible %llu) > limit %llu",
+             (unsigned long long)s.mem.device_bytes, (unsigned long long)s.mem.host_visible_peak,
+             (unsigned long long)s.budget);
+
+    // one-shot G-buffer + AOV pass, render_terrain.rs:1091-1121
+    P.frame_index = 0;
+    P.res_in = s.res[1];
+    P.res_out = s.res[0];
+    P.collect_stats = 0;
+    hip_check(launch_gbuffer(P, s.gbuffer_n, s.depth, s.stream), "g-buffer pass");
+}
+
+void enqueue_frame(f3d_session &s, uint32_t frame, bool collect) {
+    FrameParams &P = s.params;
+    P.frame_index = frame;
+    P.res_out = s.res[frame & 1u];
+    P.res_in = s.res[(frame & 1u) ^ 1u];
+    P.collect_stats = collect ? 1u : 0u;
+    if (collect) hip_check(hipMemsetAsync(s.stats, 0, 2 * sizeof(uint32_t), s.stream), "stats clear");
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (s.timing) {
+        hip_check(hipEventCreate(&e0), "event");
+        hip_check(hipEventCreate(&e1), "event");
+        hip_check(hipEventRecord(e0, s.stream), "event record");
+    }
+    hip_check(launch_frame(P, s.variant, s.stream), "frame kernel");
+    if (s.timing) {
+        hip_check(hipEventRecord(e1, s.stream), "event record");
+        s.events.emplace_back(e0, e1);
+    }
+}
+
+bool closes_window(uint32_t frame, uint32_t max_frames) {
+    const uint32_t frames = frame + 1u;
+    return frames % kWelfordWindow == 0u || frames == max_frames;
+}
+
+void resolve(f3d_session &s, uint32_t frames, uint8_t *d_rgba, float *d_albedo, float *d_normal) {
+    ResolveParams R{};
+    R.frame = s.params;
+    R.frame.res_in = s.res[(frames - 1u) & 1u];
+    R.frames = frames;
+    R.rgba = d_rgba;
+    R.albedo = d_albedo;
+    R.normal = d_normal;
+    hip_check(hipMemsetAsync(s.stats + 2, 0, 2 * sizeof(uint32_t), s.stream), "stats clear");
+    hip_check(launch_resolve(R, s.stream), "resolve kernel");
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+int f3d_session_create(const f3d_terrain_ref_desc *desc, const f3d_session_opts *opts, f3d_session **session,
+                       char *err, size_t errlen) {
+    if (err && errlen) err[0] = 0;
+    if (!desc || !session) return F3D_STATUS_VALUE;
+    f3d_session *s = new (std::nothrow) f3d_session();
+    if (!s) return F3D_STATUS_DEVICE;
+    try {
+        session_init(*s, *desc, opts);
+    } catch (const Failure &f) {
+        delete s;
+        return report(f, err, errlen);
+    }
+    *session = s;
+    return F3D_STATUS_OK;
+}
+
+void f3d_session_destroy(f3d_session *session) {
+    if (!session) return;
+    (void)hipStreamSynchronize(session->stream);
+    delete session;
+}
+
+int f3d_session_enqueue_frames(f3d_session *s, uint32_t first_frame, uint32_t count, int32_t collect_stats_on_last,
+                               char *err, size_t errlen) {
+    try {
+        for (uint32_t i = 0; i < count; i++)
+            enqueue_frame(*s, first_frame + i, collect_stats_on_last != 0 && i + 1 == count);
+    } catch (const Failure &f) {
+        return report(f, err, errlen);
+    }
+    return F3D_STATUS_OK;
+}
+
+int f3d_session_window_stats(f3d_session *s, float *max_m2, int32_t *nonfinite, char *err, size_t errlen) {
+    try {
+        hip_check(hipMemcpyAsync(s->host_stats, s->stats, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream),
+                  "stats readback");
+        hip_check(hipStreamSynchronize(s->stream), "stream sync");
+        if (max_m2) *max_m2 = f_from_bits(s->host_stats[0]);
+        if (nonfinite) *nonfinite = s->host_stats[1] != 0u;
+    } catch (const Failure &f) {
+        return report(f, err, errlen);
+    }
+    return F3D_STATUS_OK;
+}
+
+int f3d_session_halo(f3d_session *s, int32_t which, int32_t side, void **ptr, uint64_t *bytes) {
+    if (!s || which < 0 || which > 1 || side < 0 || side > 3) return F3D_STATUS_VALUE;
+    const size_t row = (size_t)s->width;
+    size_t first;
+    switch (side) {
+        case 0: first = kHaloRows; break;                 // top owned rows
+        case 1: first = s->rows; break;                   // bottom owned rows
+        case 2: first = 0; break;                         // halo above
+        default: first = (size_t)s->rows + kHaloRows; break;  // halo below
+    }
+    *ptr = (void *)(s->res[which] + first * row);
+    *bytes = (uint64_t)kHaloRows * row * sizeof(PackedReservoir);
+    return F3D_STATUS_OK;
+}
+
+int f3d_session_resolve_device(f3d_session *s, uint32_t frames, void *d_rgba, void *d_albedo, void *d_normal,
+                               void *d_depth, char *err, size_t errlen) {
+    try {
+        if (frames == 0) fail(F3D_STATUS_VALUE, "resolve needs at least one accumulated frame");
+        resolve(*s, frames, d_rgba ? (uint8_t *)d_rgba : s->d_rgba, d_albedo ? (float *)d_albedo : s->d_albedo,
+                d_normal ? (float *)d_normal : s->d_normal);
+        if (d_depth)
+            hip_check(hipMemcpyAsync(d_depth, s->depth, (size_t)s->rows * s->width * sizeof(float),
+                                     hipMemcpyDeviceToDevice, s->stream), "depth copy");
+    } catch (const Failure &f) {
+        return report(f, err, errlen);
+    }
+    return F3D_STATUS_OK;
+}
+
+int f3d_session_resolve(f3d_session *s, uint32_t frames, uint8_t *rgba, float *albedo, float *normal, float *depth,
+                        int32_t *any_valid_reservoir, char *err, size_t errlen) {
+    try {
+        if (frames == 0) fail(F3D_STATUS_VALUE, "resolve needs at least one accumulated frame");
+        resolve(*s, frames, s->d_rgba, s->d_albedo, s->d_normal);
+        const size_t px = (size_t)s->rows * s->width;
+        hip_check(hipMemcpyAsync(s->host_stats, s->stats, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream),
+                  "stats readback");
+        if (rgba) hip_check(hipMemcpyAsync(rgba, s->d_rgba, px * 4, hipMemcpyDeviceToHost, s->stream), "rgba readback");
+        if (albedo)
+            hip_check(hipMemcpyAsync(albedo, s->d_albedo, px * 3 * sizeof(float), hipMemcpyDeviceToHost, s->stream),
+                      "albedo readback");
+        if (normal)
+            hip_check(hipMemcpyAsync(normal, s->d_normal, px * 3 * sizeof(float), hipMemcpyDeviceToHost, s->stream),
+                      "normal readback");
+        if (depth)
+            hip_check(hipMemcpyAsync(depth, s->depth, px * sizeof(float), hipMemcpyDeviceToHost, s->stream),
+                      "depth readback");
+        hip_check(hipStreamSynchronize(s->stream), "stream sync");
+        s->mem.note_host_visible(px * 3 * sizeof(float));
+        if (s->host_stats[3] != 0u)
+            fail(F3D_STATUS_RENDER, "terrain PT reservoir bookkeeping produced non-finite values");
+        if (any_valid_reservoir) *any_valid_reservoir = s->host_stats[2] != 0u;
+    } catch (const Failure &f) {
+        return report(f, err, errlen);
+    }
+    return F3D_STATUS_OK;
+}
+
+int f3d_session_info(f3d_session *s, uint64_t *gpu_resource_bytes, uint64_t *minmax_pyramid_bytes,
+                     uint64_t *peak_host_visible_bytes, uint32_t *rows, uint32_t *width) {
+    if (!s) return F3D_STATUS_VALUE;
+    if (gpu_resource_bytes) *gpu_resource_bytes = s->mem.device_bytes;
+    if (minmax_pyramid_bytes) *minmax_pyramid_bytes = s->tables.bytes;
+    if (peak_host_visible_bytes) *peak_host_visible_bytes = s->mem.host_visible_peak;
+    if (rows) *rows = s->rows;
+    if (width) *width = s->width;
+    return F3D_STATUS_OK;
+}
+
+int f3d_session_kernel_timing(f3d_session *s, int32_t enable, double *avg_ms, uint32_t *launches) {
+    if (!s) return F3D_STATUS_VALUE;
+    if (enable) {
+        for (auto &e : s->events) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+        s->events.clear();
+        s->timing = true;
+        return F3D_STATUS_OK;
+    }
+    s->timing = false;
+    if (hipStreamSynchronize(s->stream) != hipSuccess) return F3D_STATUS_DEVICE;
+    double total = 0.0;
+    for (auto &e : s->events) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, e.first, e.second) != hipSuccess) return F3D_STATUS_DEVICE;
+        total += ms;
+    }
+    if (launches) *launches = (uint32_t)s->events.size();
+    if (avg_ms) *avg_ms = s->events.empty() ? 0.0 : total / (double)s->events.size();
+    return F3D_STATUS_OK;
+}
+
+int f3d_terrain_ref_render(const f3d_terrain_ref_desc *desc, f3d_terrain_ref_out *out, char *err, size_t errlen) {
+    if (err && errlen) err[0] = 0;
+    if (!desc || !out) return F3D_STATUS_VALUE;
+    f3d_session *s = new (std::nothrow) f3d_session();
+    if (!s) return F3D_STATUS_DEVICE;
+    int rc = F3D_STATUS_OK;
+    try {
+        const double t_setup = now_s();
+        session_init(*s, *desc, nullptr);
+        hip_check(hipStreamSynchronize(s->stream), "setup sync");
+        out->setup_seconds = now_s() - t_setup;
+
+        // accumulate until converged or capped, render_terrain.rs:1123-1244.  The reference
+        // checks after every frame whether a 32-frame window just closed; here whole windows
+        // are enqueued without touching the host and only the closing frame reports.
+        uint32_t frames = 0;
+        float variance = INFINITY;
+        bool converged = false;
+        const double t_loop = now_s();
+        while (frames < desc->max_frames) {
+            uint32_t stop = (frames / kWelfordWindow + 1u) * kWelfordWindow;
+            if (stop > desc->max_frames) stop = desc->max_frames;
+            for (uint32_t f = frames; f < stop; f++) enqueue_frame(*s, f, f + 1 == stop);
+            frames = stop;
+            const uint32_t n_window = ((frames - 1u) % kWelfordWindow) + 1u;
+            if (n_window >= 2u) {
+                float m2 = 0.0f;
+                int32_t nonfinite = 0;
+                char e2[256];
+                if (f3d_session_window_stats(s, &m2, &nonfinite, e2, sizeof(e2)) != 0) fail(F3D_STATUS_DEVICE, "%s", e2);
+                if (nonfinite) fail(F3D_STATUS_RENDER, "terrain PT produced non-finite variance (NaN in accumulation)");
+                variance = f_max(0.0f, m2 / ((float)n_window - 1.0f));
+                if (frames >= desc->min_frames && variance < desc->variance_threshold) {
+                    converged = true;
+                    break;
+                }
+            }
+        }
+        hip_check(hipStreamSynchronize(s->stream), "loop sync");
+        out->loop_seconds = now_s() - t_loop;
+        out->frames = frames;
+        out->variance = variance;
+        out->converged = converged ? 1 : 0;
+        if (!converged)
+            fail(F3D_STATUS_RENDER,
+                 "terrain PT did not converge: per-pixel luminance variance %s over the last %u-frame window after "
+                 "%u frames (threshold %s); raise max_frames or simplify the scene \xe2\x80\x94 refusing to return a "
+                 "fake reference",
+                 rust_exp(variance, 3).c_str(), kWelfordWindow, frames, rust_exp(desc->variance_threshold, 1).c_str());
+
+        const double t_read = now_s();
+        int32_t any_valid = 0;
+        char e2[256];
+        rc = f3d_session_resolve(s, frames, out->rgba, out->albedo, out->normal, out->depth, &any_valid, e2, sizeof(e2));
+        if (rc != 0) fail(rc, "%s", e2);
+        if (s->require_valid_reservoirs && !any_valid)
+            fail(F3D_STATUS_RENDER,
+                 "terrain PT ReSTIR reuse chain produced no valid reservoirs for a sun-lit scene \xe2\x80\x94 "
+                 "temporal/spatial reuse is broken");
+        out->readback_seconds = now_s() - t_read;
+        out->gpu_resource_bytes = s->mem.device_bytes;
+        out->minmax_pyramid_bytes = s->tables.bytes;
+        out->peak_host_visible_bytes = s->mem.host_visible_peak;
+        // budget guardrail on the host-visible peak, render_terrain.rs:1397-1404
+        if (out->peak_host_visible_bytes > s->budget)
+            fail(F3D_STATUS_RENDER, "terrain PT exceeded the host-visible budget: peak %llu > limit %llu",
+                 (unsigned long long)out->peak_host_visible_bytes, (unsigned long long)s->budget);
+    } catch (const Failure &f) {
+        rc = report(f, err, errlen);
+    }
+    f3d_session_destroy(s);
+    return rc;
+}
+
+int f3d_build_minmax_mips(const float *heights, uint32_t width, uint32_t height, float *levels_out, uint32_t *dims_out,
+                          uint32_t max_levels, uint64_t *total_floats, char *err, size_t errlen) {
+    if (err && errlen) err[0] = 0;
+    Ledger mem;
+    int rc = F3D_STATUS_OK;
+    try {
+        if (width < 2 || height < 2)
+            fail(F3D_STATUS_UPLOAD, "terrain heightfield must be at least 2x2 texels, got %ux%u", width, height);
+        const size_t n = (size_t)width * height;
+        for (size_t i = 0; i < n; i++)
+            if (!std::isfinite(heights[i])) fail(F3D_STATUS_UPLOAD, "terrain heightfield contains non-finite samples");
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+            fail(F3D_STATUS_DEVICE, "no HIP device available: libf3dhip has no CPU fallback");
+        float *d_h = (float *)mem.alloc(n * sizeof(float), "DEM upload");
+        hip_check(hipMemcpy(d_h, heights, n * sizeof(float), hipMemcpyHostToDevice), "DEM upload");
+        TerrainTables t = build_tables(mem, d_h, width, height, 1.0f, nullptr);
+        hip_check(hipDeviceSynchronize(), "table build");
+        const TableLayout &L = t.layout;
+        const uint32_t levels = L.levels;
+        uint64_t tot = 0;
+        for (uint32_t l = 0; l < levels; l++) tot += (uint64_t)L.level_w[l] * L.level_h[l] * 2;
+        if (total_floats) *total_floats = tot;
+        if (dims_out)
+            for (uint32_t l = 0; l < levels && l < max_levels; l++) {
+                dims_out[2 * l] = L.level_w[l];
+                dims_out[2 * l + 1] = L.level_h[l];
+            }
+        if (levels_out) {
+            std::vector<LeafRec> leaves(L.leaf_count);
+            std::vector<NodeRec> nodes(L.node_count ? L.node_count : 1);
+            hip_check(hipMemcpy(leaves.data(), t.leaves, L.leaf_count * sizeof(LeafRec), hipMemcpyDeviceToHost), "readback");
+            if (L.node_count)
+                hip_check(hipMemcpy(nodes.data(), t.nodes, L.node_count * sizeof(NodeRec), hipMemcpyDeviceToHost), "readback");
+            uint64_t off = 0;
+            for (uint32_t l = 0; l < levels; l++) {
+                for (uint32_t y = 0; y < L.level_h[l]; y++)
+                    for (uint32_t x = 0; x < L.level_w[l]; x++) {
+                        float mn, mx;
+                        if (l == 0) {
+                            if (x < t.dev.cell_w && y < t.dev.cell_h) {
+                                const LeafRec &h = leaves[tiled_index(x, y, t.dev.tiles_x[0])];
+                                mn = min4(h);
+                                mx = max4(h);
+                            } else {
+                                mn = INFINITY;
+                                mx = -INFINITY;
+                            }
+                        } else {
+                            const NodeRec &r = nodes[t.dev.node_offset[l] + tiled_index(x, y, t.dev.tiles_x[l])];
+                            mn = r.mn;
+                            mx = r.mx;
+                        }
+                        levels_out[off++] = mn;
+                        levels_out[off++] = mx;
+                    }
+            }
+        }
+        rc = (int)levels;
+    } catch (const Failure &f) {
+        rc = -report(f, err, errlen);
+    }
+    mem.release();
+    return rc;
+}
+
+int f3d_terrain_trace_batch(const float *heights, uint32_t width, uint32_t height, float origin_x, float origin_z,
+                            float spacing_x, float spacing_z, float exaggeration, float inv_two_r_prime,
+                            uint32_t curvature_enabled, const float *rays, uint32_t n, int32_t any_hit,
+                            int32_t apply_curvature, uint32_t *out_hit, float *out_t, float *out_normal, char *err,
+                            size_t errlen) {
+    if (err && errlen) err[0] = 0;
+    Ledger mem;
+    int rc = F3D_STATUS_OK;
+    try {
+        if (width < 2 || height < 2)
+            fail(F3D_STATUS_UPLOAD, "terrain heightfield must be at least 2x2 texels, got %ux%u", width, height);
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+            fail(F3D_STATUS_DEVICE, "no HIP device available: libf3dhip has no CPU fallback");
+        const size_t dem_n = (size_t)width * height;
+        float *d_h = (float *)mem.alloc(dem_n * sizeof(float), "DEM upload");
+        hip_check(hipMemcpy(d_h, heights, dem_n * sizeof(float), hipMemcpyHostToDevice), "DEM upload");
+        TerrainTables t = build_tables(mem, d_h, width, height, exaggeration, nullptr);
+        RayBatchParams B{};
+        B.terrain = t.dev;
+        B.terrain.origin_x = origin_x;
+        B.terrain.origin_z = origin_z;
+        B.terrain.spacing_x = spacing_x;
+        B.terrain.spacing_z = spacing_z;
+        B.terrain.inv_spacing_x = 1.0f / spacing_x;
+        B.terrain.inv_spacing_z = 1.0f / spacing_z;
+        B.terrain.inv_two_r_prime = inv_two_r_prime;
+        B.terrain.curvature_enabled = curvature_enabled;
+        float4 *d_rays = (float4 *)mem.alloc((size_t)n * 32, "rays");
+        hip_check(hipMemcpy(d_rays, rays, (size_t)n * 32, hipMemcpyHostToDevice), "ray upload");
+        B.rays = d_rays;
+        B.n = n;
+        B.any_hit = any_hit != 0;
+        B.apply_curvature = apply_curvature != 0;
+        B.out_hit = (uint32_t *)mem.alloc((size_t)n * 4, "hits");
+        B.out_t = (float *)mem.alloc((size_t)n * 4, "t");
+        B.out_normal = (float *)mem.alloc((size_t)n * 12, "normals");
+        hip_check(launch_ray_batch(B, nullptr), "ray batch kernel");
+        hip_check(hipDeviceSynchronize(), "ray batch");
+        hip_check(hipMemcpy(out_hit, B.out_hit, (size_t)n * 4, hipMemcpyDeviceToHost), "readback");
+        if (out_t) hip_check(hipMemcpy(out_t, B.out_t, (size_t)n * 4, hipMemcpyDeviceToHost), "readback");
+        if (out_normal) hip_check(hipMemcpy(out_normal, B.out_normal, (size_t)n * 12, hipMemcpyDeviceToHost), "readback");
+    } catch (const Failure &f) {
+        rc = report(f, err, errlen);
+    }
+    mem.release();
+    return rc;
+}
+
+int f3d_effective_radius_m(int32_t earth_model, double latitude_deg, double sphere_radius_m, int32_t refraction_model,
+                           double pressure_mbar, double temperature_c, double refraction_k, double azimuth_deg,
+                           double *radius_out, char *err, size_t errlen) {
+    if (err && errlen) err[0] = 0;
+    try {
+        *radius_out = effective_radius(earth_model, latitude_deg, sphere_radius_m, refraction_model, pressure_mbar,
+                                       temperature_c, refraction_k, azimuth_deg);
+    } catch (const Failure &f) {
+        return report(f, err, errlen);
+    }
+    return F3D_STATUS_OK;
+}
+
+int f3d_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *f3d_device_name(int32_t device) {
+    static thread_local char name[256];
+    name[0] = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) snprintf(name, sizeof(name), "%s", prop.gcnArchName);
+    return name;
+}
+
+const char *f3d_version(void) { return "forge3d_amd 0.1.0 (gfx950 terrain path tracer)"; }
+
+}  // extern "C"

@@ -1,0 +1,154 @@
+// forge3d_amd/csrc/f3d_kernels.hip -- gfx950 kernels of the terrain path tracer.
+//
+// Launch shape: one wave (64 lanes) per workgroup = one 8x8 pixel tile, like the
+// reference's @workgroup_size(8,8,1) (hybrid_terrain_traversal.wgsl:445), so primary rays
+// of a wave stay coherent.  Workgroup b runs on XCD b % 8 (observed dispatch order,
+// MI355X_MICROARCH.md), so tile ids are dealt to XCDs in contiguous bands: each XCD's
+// private 4 MiB L2 then caches one horizontal band of the image and the slice of the
+// terrain tables its rays actually walk.  No MFMA anywhere: there is no dense
+// contraction on this path.
+#include "f3d_launch.h"
+#include "f3d_shade.h"
+
+namespace f3d {
+
+constexpr int kWave = 64;
+constexpr int kNumXcd = 8;
+
+// Pending-sibling words: [level][lane] column in LDS, 4 KiB per wave; bank = lane.
+struct LdsPending {
+    uint32_t *col;
+    __device__ __forceinline__ void put(uint32_t level, uint32_t word) { col[level * kWave] = word; }
+    __device__ __forceinline__ uint32_t get(uint32_t level) const { return col[level * kWave]; }
+};
+
+__device__ __forceinline__ bool tile_pixel(const FrameParams &P, uint32_t &gx, uint32_t &gy) {
+    const uint32_t rows = P.row_end - P.row_begin;
+    const uint32_t tiles_x = (P.cam.width + 7u) >> 3, tiles_y = (rows + 7u) >> 3;
+    const uint32_t ntiles = tiles_x * tiles_y;
+    const uint32_t per_xcd = (ntiles + kNumXcd - 1u) / kNumXcd;
+    const uint32_t tile = (blockIdx.x % kNumXcd) * per_xcd + blockIdx.x / kNumXcd;
+    if (tile >= ntiles) return false;
+    const uint32_t lane = threadIdx.x;
+    gx = (tile % tiles_x) * 8u + (lane & 7u);
+    gy = P.row_begin + (tile / tiles_x) * 8u + (lane >> 3);
+    return gx < P.cam.width && gy < P.row_end;
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        uint32_t o = (uint32_t)__shfl_xor((int)v, off, kWave);
+        v = v > o ? v : o;
+    }
+    return v;
+}
+
+template <int VARIANT>
+__global__ __launch_bounds__(kWave) void k_frame(const FrameParams P) {
+    __shared__ uint32_t lds[kMaxLevels * kWave];
+    LdsPending pend{lds + threadIdx.x};
+    uint32_t gx, gy;
+    const bool active = tile_pixel(P, gx, gy);
+    float m2 = 0.0f;
+    if (active) m2 = frame_pixel(P, gx, gy, pend);
+    if (P.collect_stats != 0u) {
+        // max over pixels of the Welford m2 (render_terrain.rs:1211-1226); m2 >= 0 so the
+        // bit pattern orders like the value; non-finite values are flagged separately.
+        const bool bad = active && !f_finite(m2);
+        uint32_t bits = (active && !bad) ? f_bits(f_max(m2, 0.0f)) : 0u;
+        bits = wave_max_u32(bits);
+        const unsigned long long any_bad = __ballot(bad);
+        if (threadIdx.x == 0) {
+            // most waves lose the race for the maximum: look before paying for the atomic
+            if (bits > __hip_atomic_load(&P.stats[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(&P.stats[0], bits);
+            if (any_bad) atomicOr(&P.stats[1], 1u);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kWave) void k_gbuffer(const FrameParams P, float4 *gbuffer_n, float *depth) {
+    __shared__ uint32_t lds[kMaxLevels * kWave];
+    LdsPending pend{lds + threadIdx.x};
+    uint32_t gx, gy;
+    if (tile_pixel(P, gx, gy)) gbuffer_pixel(P, gx, gy, gbuffer_n, depth, pend);
+}
+
+__global__ __launch_bounds__(kWave) void k_resolve(const ResolveParams R) {
+    uint32_t gx, gy;
+    const bool active = tile_pixel(R.frame, gx, gy);
+    uint32_t flags = 0u;
+    if (active) flags = resolve_pixel(R.frame, R.frames, gx, gy, R.rgba, R.albedo, R.normal);
+    const unsigned long long valid = __ballot((flags & 1u) != 0u), bad = __ballot((flags & 2u) != 0u);
+    if (threadIdx.x == 0) {
+        if (valid) atomicOr(&R.frame.stats[2], 1u);
+        if (bad) atomicOr(&R.frame.stats[3], 1u);
+    }
+}
+
+__global__ __launch_bounds__(kWave) void k_ray_batch(const RayBatchParams B) {
+    __shared__ uint32_t lds[kMaxLevels * kWave];
+    LdsPending pend{lds + threadIdx.x};
+    const uint32_t i = blockIdx.x * kWave + threadIdx.x;
+    if (i >= B.n) return;
+    const float4 a = B.rays[2 * i], b = B.rays[2 * i + 1];
+    const RayCtx r = make_ray(B.terrain, V3{a.x, a.y, a.z}, a.w, V3{b.x, b.y, b.z}, b.w, B.apply_curvature != 0u);
+    const TraceHit h = trace_terrain(B.terrain, r, B.any_hit != 0u, pend);
+    B.out_hit[i] = h.hit ? 1u : 0u;
+    if (B.out_t) B.out_t[i] = h.t;
+    if (B.out_normal) {
+        B.out_normal[3 * i + 0] = h.hit ? h.n.x : 0.0f;
+        B.out_normal[3 * i + 1] = h.hit ? h.n.y : 0.0f;
+        B.out_normal[3 * i + 2] = h.hit ? h.n.z : 0.0f;
+    }
+}
+
+// ---- acceleration-table builders (reference build_minmax_mips,
+// terrain_heightfield.rs:132-202, runs single-threaded on the CPU) -------------------
+__global__ void k_leaf_build(const PyramidBuildParams B) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x < B.leaf_dim_x && y < B.leaf_dim_y) leaf_build_at(B, x, y);
+}
+
+__global__ void k_level_build(const LevelBuildParams B) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x < B.dst_dim_x && y < B.dst_dim_y) level_build_at(B, x, y);
+}
+
+// ---- launchers ---------------------------------------------------------------------
+static inline uint32_t frame_grid(const FrameParams &p) {
+    const uint32_t rows = p.row_end - p.row_begin;
+    const uint32_t ntiles = ((p.cam.width + 7u) >> 3) * ((rows + 7u) >> 3);
+    return ((ntiles + kNumXcd - 1u) / kNumXcd) * kNumXcd;
+}
+
+hipError_t launch_frame(const FrameParams &p, int variant, hipStream_t stream) {
+    (void)variant;
+    hipLaunchKernelGGL(k_frame<0>, dim3(frame_grid(p)), dim3(kWave), 0, stream, p);
+    return hipGetLastError();
+}
+hipError_t launch_gbuffer(const FrameParams &p, float4 *gbuffer_n, float *depth, hipStream_t stream) {
+    hipLaunchKernelGGL(k_gbuffer, dim3(frame_grid(p)), dim3(kWave), 0, stream, p, gbuffer_n, depth);
+    return hipGetLastError();
+}
+hipError_t launch_resolve(const ResolveParams &p, hipStream_t stream) {
+    hipLaunchKernelGGL(k_resolve, dim3(frame_grid(p.frame)), dim3(kWave), 0, stream, p);
+    return hipGetLastError();
+}
+hipError_t launch_ray_batch(const RayBatchParams &p, hipStream_t stream) {
+    hipLaunchKernelGGL(k_ray_batch, dim3((p.n + kWave - 1) / kWave), dim3(kWave), 0, stream, p);
+    return hipGetLastError();
+}
+hipError_t launch_leaf_build(const PyramidBuildParams &p, hipStream_t stream) {
+    dim3 block(16, 16), grid((p.leaf_dim_x + 15) / 16, (p.leaf_dim_y + 15) / 16);
+    hipLaunchKernelGGL(k_leaf_build, grid, block, 0, stream, p);
+    return hipGetLastError();
+}
+hipError_t launch_level_build(const LevelBuildParams &p, hipStream_t stream) {
+    dim3 block(16, 16), grid((p.dst_dim_x + 15) / 16, (p.dst_dim_y + 15) / 16);
+    hipLaunchKernelGGL(k_level_build, grid, block, 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace f3d

@@ -1,0 +1,35 @@
+// forge3d_amd/csrc/f3d_launch.h -- host-callable launchers of the gfx950 kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "f3d_build.h"
+#include "f3d_scene.h"
+
+namespace f3d {
+
+struct RayBatchParams {
+    TerrainDev terrain;
+    const float4 *rays;  // 2 float4 per ray: (origin, tmin), (direction, tmax)
+    uint32_t n;
+    uint32_t any_hit, apply_curvature;
+    uint32_t *out_hit;
+    float *out_t;
+    float *out_normal;  // 3 per ray
+};
+
+struct ResolveParams {
+    FrameParams frame;  // res_in = final temporal output, frame_index unused
+    uint32_t frames;
+    uint8_t *rgba;
+    float *albedo, *normal;
+};
+
+hipError_t launch_frame(const FrameParams &p, int variant, hipStream_t stream);
+hipError_t launch_gbuffer(const FrameParams &p, float4 *gbuffer_n, float *depth, hipStream_t stream);
+hipError_t launch_resolve(const ResolveParams &p, hipStream_t stream);
+hipError_t launch_ray_batch(const RayBatchParams &p, hipStream_t stream);
+hipError_t launch_leaf_build(const PyramidBuildParams &p, hipStream_t stream);
+hipError_t launch_level_build(const LevelBuildParams &p, hipStream_t stream);
+
+}  // namespace f3d

@@ -1,0 +1,194 @@
+// forge3d_amd/csrc/f3d_math.h
+// Scalar / vec3 arithmetic shared by every kernel of the terrain path tracer.
+//
+// Numerics contract (DESIGN.md "Numerics"): IEEE f32, RNE, denormals kept, the whole
+// library is compiled with -ffp-contract=off, and fused multiply-adds appear ONLY where
+// this code spells fmaf().  Division and sqrt are the correctly rounded forms (hipcc's
+// default).  sin/cos/atan2/acos are fixed polynomials, not the libm/ocml ones, so every
+// device and host evaluates the same bits.  That makes the HIP path comparable
+// bit-for-bit with the CPU oracle under tests/.
+#pragma once
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define F3D_HD __host__ __device__ __forceinline__
+#else
+#include <cmath>
+#include <cstring>
+#define F3D_HD inline
+// Host-only builds (tests/emul) have no HIP vector types.
+struct alignas(16) float4 {
+    float x, y, z, w;
+};
+#endif
+
+namespace f3d {
+
+struct V3 {
+    float x, y, z;
+};
+
+F3D_HD float f_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+F3D_HD float f_min(float a, float b) { return __builtin_fminf(a, b); }
+F3D_HD float f_max(float a, float b) { return __builtin_fmaxf(a, b); }
+F3D_HD float f_abs(float a) { return __builtin_fabsf(a); }
+F3D_HD float f_sqrt(float a) { return __builtin_sqrtf(a); }
+F3D_HD float f_rint(float a) { return __builtin_rintf(a); }
+F3D_HD float f_floor(float a) { return __builtin_floorf(a); }
+F3D_HD float f_clamp(float x, float lo, float hi) { return f_min(f_max(x, lo), hi); }
+
+F3D_HD uint32_t f_bits(float f) { return __builtin_bit_cast(uint32_t, f); }
+F3D_HD float f_from_bits(uint32_t u) { return __builtin_bit_cast(float, u); }
+F3D_HD bool f_finite(float f) { return (f_bits(f) & 0x7F800000u) != 0x7F800000u; }
+
+F3D_HD V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+F3D_HD V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+F3D_HD V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+F3D_HD V3 operator*(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+F3D_HD V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
+F3D_HD V3 neg(V3 a) { return V3{-a.x, -a.y, -a.z}; }
+F3D_HD float dot(V3 a, V3 b) { return f_fma(a.z, b.z, f_fma(a.y, b.y, a.x * b.x)); }
+F3D_HD float dot2(float ax, float az, float bx, float bz) { return f_fma(az, bz, ax * bx); }
+F3D_HD V3 cross(V3 a, V3 b) {
+    return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+F3D_HD V3 normalize(V3 a) {
+    float inv = 1.0f / f_sqrt(dot(a, a));
+    return a * inv;
+}
+// o + t * d
+F3D_HD V3 along(V3 o, float t, V3 d) {
+    return V3{f_fma(t, d.x, o.x), f_fma(t, d.y, o.y), f_fma(t, d.z, o.z)};
+}
+// a*x + b*y + c*z for three basis vectors
+F3D_HD V3 combine(float a, V3 x, float b, V3 y, float c, V3 z) {
+    return V3{f_fma(c, z.x, f_fma(b, y.x, a * x.x)), f_fma(c, z.y, f_fma(b, y.y, a * x.y)),
+              f_fma(c, z.z, f_fma(b, y.z, a * x.z))};
+}
+// WGSL mix(a, b, t) = a * (1 - t) + b * t
+F3D_HD float mix(float a, float b, float t) { return f_fma(b, t, a * (1.0f - t)); }
+// Rec.709 luminance (reference hybrid_terrain_traversal.wgsl:416-418)
+F3D_HD float luminance(V3 c) { return dot(c, V3{0.2126f, 0.7152f, 0.0722f}); }
+
+// WGSL u32(f32): saturating conversion
+F3D_HD uint32_t sat_u32(float f) {
+    if (!(f > 0.0f)) return 0u;
+    if (f >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)f;
+}
+
+// xorshift32 (reference hybrid_kernel.wgsl:78-85); returns the float draw in [0, 1].
+F3D_HD float rng_next(uint32_t &s) {
+    uint32_t x = s;
+    x ^= x << 13;
+    x ^= x >> 17;
+    x ^= x << 5;
+    s = x;
+    return (float)x / 4294967296.0f;
+}
+
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kHalfPi = 1.57079632679489661923f;
+constexpr float kQuarterPi = 0.78539816339744830962f;
+
+// ---- fixed-polynomial transcendentals (single-precision cephes coefficients) ----
+F3D_HD float sin_quarter(float x) {  // |x| <= pi/4
+    float z = x * x;
+    float p = f_fma(f_fma(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    return f_fma(p * z, x, x);
+}
+F3D_HD float cos_quarter(float x) {  // |x| <= pi/4
+    float z = x * x;
+    float p = f_fma(f_fma(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    return f_fma(p, z * z, f_fma(-0.5f, z, 1.0f));
+}
+// sin, cos of 2*pi*u for u in [0, 1]
+F3D_HD void sincos_turn(float u, float &s_out, float &c_out) {
+    float a = 4.0f * u;
+    float k = f_rint(a);
+    float x = (a - k) * kHalfPi;
+    float s = sin_quarter(x), c = cos_quarter(x);
+    int q = ((int)k) & 3;
+    s_out = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
+    c_out = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
+}
+F3D_HD float atan_det(float v) {
+    float sign = 1.0f, x = v;
+    if (v < 0.0f) {
+        sign = -1.0f;
+        x = -v;
+    }
+    float y;
+    if (x > 2.414213562373095f) {
+        y = kHalfPi;
+        x = -(1.0f / x);
+    } else if (x > 0.4142135623730950f) {
+        y = kQuarterPi;
+        x = (x - 1.0f) / (x + 1.0f);
+    } else {
+        y = 0.0f;
+    }
+    float z = x * x;
+    float p = f_fma(f_fma(f_fma(8.05374449538e-2f, z, -1.38776856032e-1f), z, 1.99777106478e-1f), z,
+                    -3.33329491539e-1f);
+    y = y + f_fma(p * z, x, x);
+    return sign * y;
+}
+F3D_HD float atan2_det(float y, float x) {
+    if (x > 0.0f) return atan_det(y / x);
+    if (x < 0.0f) {
+        float a = atan_det(y / x);
+        return (y >= 0.0f) ? a + kPi : a - kPi;
+    }
+    if (y > 0.0f) return kHalfPi;
+    if (y < 0.0f) return -kHalfPi;
+    return 0.0f;
+}
+F3D_HD float asin_half(float x) {  // |x| <= 0.5
+    float z = x * x;
+    float p = f_fma(
+        f_fma(f_fma(f_fma(4.2163199048e-2f, z, 2.4181311049e-2f), z, 4.5470025998e-2f), z, 7.4953002686e-2f),
+        z, 1.6666752422e-1f);
+    return f_fma(x * z, p, x);
+}
+F3D_HD float acos_det(float x) {  // x in [-1, 1]
+    if (x < -0.5f) return kPi - 2.0f * asin_half(f_sqrt(0.5f * (1.0f + x)));
+    if (x > 0.5f) return 2.0f * asin_half(f_sqrt(0.5f * (1.0f - x)));
+    return kHalfPi - asin_half(x);
+}
+
+// ---- IEEE binary16 storage rounding (RGBA16F targets of the reference) ----
+F3D_HD uint16_t half_bits(float f) {
+    uint32_t x = f_bits(f);
+    uint32_t sign = (x >> 16) & 0x8000u;
+    uint32_t mag = x & 0x7FFFFFFFu;
+    if (mag >= 0x7F800000u) return (uint16_t)(sign | 0x7C00u | (mag > 0x7F800000u ? 0x0200u : 0u));
+    if (mag >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);  // >= 65520 rounds to inf
+    if (mag <= 0x33000000u) return (uint16_t)sign;              // <= 2^-25 rounds to zero
+    int32_t e = (int32_t)(mag >> 23) - 127;
+    uint32_t m = (mag & 0x007FFFFFu) | 0x00800000u;
+    uint32_t drop = (e < -14) ? (uint32_t)(13 + (-14 - e)) : 13u;
+    uint32_t q = m >> drop;
+    uint32_t rem = m & ((1u << drop) - 1u);
+    uint32_t halfway = 1u << (drop - 1u);
+    if (e >= -14) q = ((uint32_t)(e + 15) << 10) | (q & 0x3FFu);
+    if (rem > halfway || (rem == halfway && (q & 1u))) q++;
+    return (uint16_t)(sign | q);
+}
+F3D_HD float half_value(uint16_t h) {
+    uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1Fu;
+    uint32_t m = h & 0x3FFu;
+    if (e == 0u) {
+        // subnormal or zero: value = m * 2^-24 (exact in f32)
+        float v = (float)m * 5.9604644775390625e-8f;
+        return f_from_bits(f_bits(v) | sign);
+    }
+    if (e == 31u) return f_from_bits(sign | 0x7F800000u | (m << 13));
+    return f_from_bits(sign | ((e + 112u) << 23) | (m << 13));
+}
+F3D_HD float round_to_half(float v) { return half_value(half_bits(v)); }
+
+}  // namespace f3d

@@ -1,0 +1,128 @@
+// forge3d_amd/csrc/f3d_scene.h
+// Kernel-side scene description and the HBM layout of the terrain acceleration data.
+//
+// Reference data (terrain_heightfield.rs:132-202, :204-336): an R32F DEM texture plus an
+// RG32F min-max mip chain, fetched one texel per visited node and 4 + 4 texels per leaf.
+// MI355X layout (no texture units; everything is plain 16-byte-vector loads):
+//
+//  * leaf table  : one 16-byte record per DEM cell = its four corner heights already
+//                  multiplied by `exaggeration` (h00, h10, h01, h11).  Level 0 of the
+//                  min-max chain is NOT stored: min/max of a cell are the min/max of
+//                  those four values, exactly what build_minmax_mips stores for level 0.
+//  * node table  : levels >= 1 of the chain, (min, max) * exaggeration, 8 bytes a node.
+//  * both tables are tiled 8x8 with a Z-order inside the tile, so the 2x2 children of a
+//    node are 4 consecutive records (64 B of leaves = one cache line, 32 B of nodes) and
+//    the 4x4 grandchildren share a 256 B / 128 B run.  A visited node therefore costs ONE
+//    dependent round trip that returns all four children, instead of one per child.
+//  * padded records (outside the cell grid, or added to round a level up to 8x8) hold
+//    (+inf, -inf) / zeros; the traversal never uses them because the cell-range test
+//    (reference hybrid_terrain_traversal.wgsl:284, :332) comes first.
+#pragma once
+
+#include "f3d_math.h"
+
+namespace f3d {
+
+constexpr uint32_t kMaxLevels = 16;       // 8192-cell DEMs need 14
+constexpr uint32_t kRestirMCap = 512;     // TERRAIN_RESTIR_M_CAP, hybrid_terrain_traversal.wgsl:77
+constexpr uint32_t kWelfordWindow = 32;   // WELFORD_WINDOW, render_terrain.rs:236
+constexpr uint32_t kHaloRows = 3;         // spatial reuse radius R, pt_restir_spatial.wgsl:171
+
+struct alignas(16) LeafRec {
+    float h00, h10, h01, h11;
+};
+struct alignas(8) NodeRec {
+    float mn, mx;
+};
+
+// Index of the first of the four child records of parent (px, py); tiles_x = number of
+// 8x8 tiles per row of the CHILD level.  Children follow in (cx, cy) = (0,0),(1,0),(0,1),(1,1)
+// order = the reference's scan order (cy outer, cx inner).
+F3D_HD uint32_t child_group_index(uint32_t px, uint32_t py, uint32_t tiles_x) {
+    uint32_t tile = (py >> 2) * tiles_x + (px >> 2);
+    uint32_t g = (px & 1u) | ((py & 1u) << 1) | ((px & 2u) << 1) | ((py & 2u) << 2);
+    return (tile << 6) | (g << 2);
+}
+// Index of record (x, y) in a tiled level (used by the builders).
+F3D_HD uint32_t tiled_index(uint32_t x, uint32_t y, uint32_t tiles_x) {
+    return child_group_index(x >> 1, y >> 1, tiles_x) | (x & 1u) | ((y & 1u) << 1);
+}
+
+// Everything the traversal needs; passed to kernels by value (kernarg -> SGPRs).
+struct TerrainDev {
+    const LeafRec *leaves;  // tiled, dims padded to multiples of 8
+    const NodeRec *nodes;   // levels 1.. back to back, each tiled
+    uint32_t node_offset[kMaxLevels];  // record offset of level l (l >= 1) inside `nodes`
+    uint32_t tiles_x[kMaxLevels];      // tiles per row of level l (l = 0 -> leaf table)
+    uint32_t mip_count;                // levels of the reference chain (incl. level 0)
+    uint32_t cell_w, cell_h;
+    float origin_x, origin_z, spacing_x, spacing_z, inv_spacing_x, inv_spacing_z;
+    float inv_two_r_prime;  // EarthCurvatureUniforms, terrain_heightfield.rs:42-84
+    uint32_t curvature_enabled;
+};
+
+struct MeshDev {  // HybridUniforms mesh part, hybrid_traversal.wgsl:9-17
+    const float4 *vertices;  // xyz + pad (reference MeshVertex)
+    const uint32_t *indices;
+    uint32_t vertex_count, index_count;
+    uint32_t traversal_mode;  // 0 hybrid (mesh + terrain), 3 terrain only
+};
+
+struct EnvDev {  // equirect environment, hybrid_terrain_traversal.wgsl:392-405
+    const float4 *texels;  // rgb + pad, row-major
+    uint32_t width, height;  // 0 -> constant white
+    float intensity;
+};
+
+struct CameraDev {  // Uniforms, hybrid_kernel.wgsl:8-23 (+ derived constants)
+    V3 origin, right, up, forward;
+    float half_w, half_h;  // aspect * tan(fov/2), tan(fov/2)
+    float exposure;
+    uint32_t width, height;  // FULL image size
+    uint32_t seed_hi, seed_lo;
+};
+
+struct LightDev {  // LightingUniforms, hybrid_kernel.wgsl:27-38 (+ derived constants)
+    V3 wi;         // normalize(light_dir): candidate sample direction
+    V3 wi_reuse;   // normalize(wi): what the kernels get from a stored reservoir direction
+    V3 color;      // light_color = intensity * colour
+    V3 albedo;     // terrain albedo
+    uint32_t shadows_enabled;
+};
+
+// Packed reservoir (16 B) replacing the reference's 80-byte Reservoir
+// (src/path_tracing/restir/types.rs:6-37).  The sun is the only light, so
+// sample.direction / intensity / light_index are render constants and
+// sample.position never influences a result; what the three reference passes read is
+// w_sum, m, weight, target_pdf and whether sample.light_type == 1, kept in bit 31 of m
+// (m <= 9 * (512 + 64) by construction).
+struct alignas(16) PackedReservoir {
+    float w_sum;
+    uint32_t m_lt;  // bit 31: sample.light_type == 1; bits 0..30: m
+    float weight;
+    float target_pdf;
+};
+constexpr uint32_t kLightTypeBit = 0x80000000u;
+
+// Per-frame kernel parameters.
+struct FrameParams {
+    TerrainDev terrain;
+    MeshDev mesh;
+    EnvDev env;
+    CameraDev cam;
+    LightDev light;
+    uint32_t spp;
+    uint32_t frame_index;
+    uint32_t row_begin, row_end;  // owned image rows
+    // state (strip-local): pixel (gx, gy) lives at (gy - row_begin) * width + gx, the
+    // reservoir buffers have kHaloRows extra rows above and below.
+    const PackedReservoir *res_in;  // temporal output of frame-1 (incl. halos)
+    PackedReservoir *res_out;       // temporal output of this frame
+    float4 *accum_mean;             // rgb = sum of per-frame means, w = Welford mean
+    float *welford_m2;
+    const float4 *gbuffer_n;        // xyz = centre-ray normal ((0,0,1) on sky), w = hit code
+    uint32_t *stats;                // [0] max m2 bits, [1] nonfinite, [2] any_valid, [3] bad
+    uint32_t collect_stats;         // this frame closes a convergence window
+};
+
+}  // namespace f3d

@@ -1,0 +1,402 @@
+// forge3d_amd/csrc/f3d_shade.h
+// Per-pixel work of the terrain path tracer: camera rays, mesh/terrain closest and any
+// hit, sun + IBL shading, the ReSTIR reservoir chain and progressive accumulation.
+//
+// The reference runs three dispatches per frame over 80-byte reservoirs:
+//   main_terrain (hybrid_terrain_traversal.wgsl:445-610) -> pt_restir_temporal
+//   (pt_restir_temporal.wgsl:54-109) -> pt_restir_spatial (pt_restir_spatial.wgsl:158-222).
+// Here ONE kernel per frame does, for its pixel:  spatial reuse of the previous frame's
+// temporal output (the only cross-pixel step, so it moves to the head of the next frame),
+// M-clamp, the spp camera samples, candidate generation and the temporal merge -- with the
+// merged history held in registers and 16-byte packed reservoirs in HBM (f3d_scene.h).
+// Frame-0 AOVs come from the G-buffer pass: the reference's AOV centre ray (:583-609) and
+// its G-buffer centre ray (:619-644) are the same ray.
+#pragma once
+
+#include "f3d_trace.h"
+
+namespace f3d {
+
+struct SurfaceHit {
+    float t;
+    V3 p, n;
+    uint32_t kind;  // 0 miss, 1 terrain (reference hit_type 3), 2 mesh (hit_type 0)
+};
+
+// ray_triangle_intersect, hybrid_traversal.wgsl:86-132
+F3D_HD bool ray_triangle(V3 o, float tmin, V3 d, float tmax, V3 v0, V3 v1, V3 v2, float &t_out, V3 &n_out) {
+    V3 e1 = v1 - v0, e2 = v2 - v0;
+    V3 h = cross(d, e2);
+    float a = dot(e1, h);
+    if (f_abs(a) < 1e-7f) return false;
+    float f = 1.0f / a;
+    V3 s = o - v0;
+    float u = f * dot(s, h);
+    if (u < 0.0f || u > 1.0f) return false;
+    V3 q = cross(s, e1);
+    float v = f * dot(d, q);
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float t = f * dot(e2, q);
+    if (t > tmin && t < tmax) {
+        t_out = t;
+        n_out = normalize(cross(e1, e2));
+        return true;
+    }
+    return false;
+}
+
+// intersect_mesh, hybrid_traversal.wgsl:137-172: the reference sweeps every triangle
+// (its BVH buffer is bound but never read); triangle data is wave-uniform here.
+F3D_HD bool mesh_closest(const MeshDev &M, V3 o, float tmin, V3 d, float tmax, float &t_best, V3 &n_best) {
+    bool any = false;
+    t_best = tmax;
+    if (M.index_count < 3u) return false;
+    for (uint32_t tri = 0u; tri + 2u < M.index_count; tri += 3u) {
+        uint32_t i0 = M.indices[tri], i1 = M.indices[tri + 1u], i2 = M.indices[tri + 2u];
+        if (i0 >= M.vertex_count || i1 >= M.vertex_count || i2 >= M.vertex_count) continue;
+        float4 a = M.vertices[i0], b = M.vertices[i1], c = M.vertices[i2];
+        float t;
+        V3 n;
+        if (ray_triangle(o, tmin, d, tmax, V3{a.x, a.y, a.z}, V3{b.x, b.y, b.z}, V3{c.x, c.y, c.z}, t, n) &&
+            t < t_best) {
+            t_best = t;
+            n_best = n;
+            any = true;
+        }
+    }
+    return any;
+}
+
+// intersect_hybrid, hybrid_traversal.wgsl:175-201 (closest hit, curvature off)
+template <class Pending>
+F3D_HD SurfaceHit closest_hit(const FrameParams &P, V3 o, float tmin, V3 d, float tmax, Pending &pend) {
+    SurfaceHit best;
+    best.kind = 0u;
+    best.t = tmax;
+    best.p = V3{0, 0, 0};
+    best.n = V3{0, 0, 0};
+    if (P.mesh.traversal_mode == 0u) {
+        float t;
+        V3 n;
+        if (mesh_closest(P.mesh, o, tmin, d, tmax, t, n) && t < best.t) {
+            best.kind = 2u;
+            best.t = t;
+            best.n = n;
+            best.p = along(o, t, d);
+        }
+    }
+    RayCtx r = make_ray(P.terrain, o, tmin, d, best.t, false);
+    TraceHit th = trace_terrain(P.terrain, r, false, pend);
+    if (th.hit && th.t < best.t) {
+        best.kind = 1u;
+        best.t = th.t;
+        best.n = th.n;
+        best.p = along(o, th.t, d);
+    }
+    return best;
+}
+
+// intersect_hybrid_optimized + intersect_shadow_ray / intersect_ibl_occlusion_ray,
+// hybrid_traversal.wgsl:204-259 (any hit; early_exit 0.01; max_distance 1e30)
+template <class Pending>
+F3D_HD bool occluded(const FrameParams &P, V3 o, float tmin, V3 d, float tmax, bool apply_curvature,
+                     Pending &pend) {
+    float best_t = tmax;
+    bool hit = false;
+    if (P.mesh.traversal_mode == 0u) {
+        float t;
+        V3 n;
+        if (mesh_closest(P.mesh, o, tmin, d, tmax, t, n)) {
+            if (t < 0.01f) return t < 1e30f;
+            if (t < best_t) {
+                best_t = t;
+                hit = true;
+            }
+        }
+    }
+    RayCtx r = make_ray(P.terrain, o, tmin, d, best_t, apply_curvature);
+    TraceHit th = trace_terrain(P.terrain, r, true, pend);
+    if (th.hit && th.t < best_t) {
+        best_t = th.t;
+        hit = true;
+    }
+    return hit && best_t < 1e30f;
+}
+
+// terrain_env_radiance, hybrid_terrain_traversal.wgsl:392-405
+F3D_HD V3 env_radiance(const EnvDev &E, V3 dir) {
+    if (E.width == 0u || E.height == 0u) return V3{E.intensity, E.intensity, E.intensity};
+    V3 d = normalize(dir);
+    float uu = atan2_det(d.z, d.x) / (2.0f * kPi) + 0.5f;
+    float vv = acos_det(f_clamp(d.y, -1.0f, 1.0f)) / kPi;
+    uint32_t px = sat_u32(uu * (float)E.width), py = sat_u32(vv * (float)E.height);
+    px = px < E.width - 1u ? px : E.width - 1u;
+    py = py < E.height - 1u ? py : E.height - 1u;
+    float4 t = E.texels[(size_t)py * E.width + px];
+    return V3{t.x * E.intensity, t.y * E.intensity, t.z * E.intensity};
+}
+
+// terrain_tent_offset, :409-414
+F3D_HD float tent_offset(float u) {
+    if (u < 0.5f) return f_sqrt(2.0f * u) - 1.0f;
+    return 1.0f - f_sqrt(2.0f * (1.0f - u));
+}
+
+// terrain_cosine_dir, :421-431
+F3D_HD V3 cosine_dir(V3 n, float u1, float u2) {
+    float sign = n.z < 0.0f ? -1.0f : 1.0f;
+    float a = -1.0f / (sign + n.z);
+    float b = n.x * n.y * a;
+    V3 t = V3{1.0f + sign * n.x * n.x * a, sign * b, -sign * n.x};
+    V3 bt = V3{b, sign + n.y * n.y * a, -n.y};
+    float rr = f_sqrt(u1);
+    float sn, cs;
+    sincos_turn(u2, sn, cs);
+    return normalize(combine(rr * cs, t, rr * sn, bt, f_sqrt(f_max(0.0f, 1.0f - u1)), n));
+}
+
+// Camera ray through pixel (gx, gy) + sub-pixel offset, :481-485
+F3D_HD V3 camera_dir(const CameraDev &C, uint32_t gx, uint32_t gy, float jx, float jy) {
+    float ndc_x = (((float)gx + 0.5f + jx) / (float)C.width) * 2.0f - 1.0f;
+    float ndc_y = (1.0f - ((float)gy + 0.5f + jy) / (float)C.height) * 2.0f - 1.0f;
+    V3 rd = normalize(V3{ndc_x * C.half_w, ndc_y * C.half_h, -1.0f});
+    return normalize(combine(rd.x, C.right, rd.y, C.up, rd.z, neg(C.forward)));
+}
+
+// ---- reservoirs -------------------------------------------------------------------
+struct Reservoir {  // register form of PackedReservoir
+    float w_sum;
+    uint32_t m;
+    float weight;
+    float target_pdf;
+    bool directional;  // sample.light_type == 1
+};
+F3D_HD Reservoir unpack(const PackedReservoir &p) {
+    return Reservoir{p.w_sum, p.m_lt & ~kLightTypeBit, p.weight, p.target_pdf, (p.m_lt & kLightTypeBit) != 0u};
+}
+F3D_HD PackedReservoir pack(const Reservoir &r) {
+    return PackedReservoir{r.w_sum, r.m | (r.directional ? kLightTypeBit : 0u), r.weight, r.target_pdf};
+}
+F3D_HD Reservoir empty_reservoir() { return Reservoir{0.0f, 0u, 0.0f, 0.0f, false}; }
+
+// Address of image pixel (x, y) in a strip-local reservoir buffer (halo rows included).
+F3D_HD size_t reservoir_index(const FrameParams &P, uint32_t x, uint32_t y) {
+    return (size_t)(y + kHaloRows - P.row_begin) * P.cam.width + x;
+}
+
+// pt_restir_spatial (pt_restir_spatial.wgsl:158-222 with consider_candidate :45-111)
+// specialised to the light table the driver binds (render_terrain.rs:756-781): one
+// directional light of importance 1 => p_sel = 1; one zeroed area light, never selected.
+// `frame` is the frame whose spatial pass this is.  n_raw = G-buffer normal record.
+F3D_HD Reservoir spatial_reuse(const FrameParams &P, const PackedReservoir *res, uint32_t gx, uint32_t gy,
+                               uint32_t frame, V3 n_raw) {
+    const uint32_t W = P.cam.width, H = P.cam.height;
+    const uint32_t idx = gy * W + gx;
+    uint32_t seed = (P.cam.seed_hi ^ frame) + idx * 1664525u + 1013904223u;
+    const Reservoir self = unpack(res[reservoir_index(P, gx, gy)]);
+    const bool facing = f_max(dot(normalize(n_raw), P.light.wi_reuse), 0.0f) > 0.0f;
+
+    bool chosen_directional = self.directional;
+    float chosen_pdf = self.target_pdf;
+    float wsum = 0.0f;
+    uint32_t m_total = 0u;
+    auto consider = [&](const Reservoir &r) {
+        if (r.m == 0u) return;
+        if (!r.directional) return;  // light_type 0: no sample ever stored
+        if (!facing) return;
+        const float p_curr = 1.0f;
+        if (r.target_pdf <= 0.0f) return;
+        const float w = r.w_sum * (p_curr / f_max(r.target_pdf, 1e-6f));
+        if (w <= 0.0f) return;
+        wsum = wsum + w;
+        const float u = rng_next(seed);
+        if (u < w / wsum) {
+            chosen_directional = true;
+            chosen_pdf = p_curr;
+        }
+    };
+    consider(self);
+    m_total += self.m;
+    for (uint32_t i = 0u; i < 8u; i++) {
+        const int rx = (int)f_floor(rng_next(seed) * 7.0f) - 3;
+        const int ry = (int)f_floor(rng_next(seed) * 7.0f) - 3;
+        if (rx == 0 && ry == 0) continue;
+        int qx = (int)gx + rx, qy = (int)gy + ry;
+        qx = qx < 0 ? 0 : (qx > (int)W - 1 ? (int)W - 1 : qx);
+        qy = qy < 0 ? 0 : (qy > (int)H - 1 ? (int)H - 1 : qy);
+        const Reservoir rn = unpack(res[reservoir_index(P, (uint32_t)qx, (uint32_t)qy)]);
+        consider(rn);
+        m_total += rn.m;
+    }
+    Reservoir out;
+    out.directional = chosen_directional;
+    out.target_pdf = chosen_pdf;
+    out.w_sum = wsum;
+    out.m = m_total;
+    out.weight = (out.w_sum > 0.0f && out.target_pdf > 0.0f) ? out.w_sum / ((float)out.m * out.target_pdf) : 0.0f;
+    return out;
+}
+
+// pt_restir_temporal.wgsl:54-109
+F3D_HD Reservoir temporal_merge(const Reservoir &rp, const Reservoir &rc) {
+    const bool pv = rp.m > 0u && rp.weight > 0.0f && rp.target_pdf > 0.0f;
+    const bool cv = rc.m > 0u && rc.weight > 0.0f && rc.target_pdf > 0.0f;
+    if (!pv) return rc;
+    if (!cv) return rp;
+    Reservoir ro = (rp.weight > rc.weight) ? rp : rc;
+    ro.m = rp.m + rc.m;
+    ro.w_sum = rp.w_sum + rc.w_sum;
+    ro.weight = (ro.w_sum > 0.0f && ro.target_pdf > 0.0f) ? ro.w_sum / ((float)ro.m * ro.target_pdf) : 0.0f;
+    return ro;
+}
+
+// ---- one accumulation frame of one pixel ---------------------------------------------
+// Returns the pixel's Welford m2 (for the convergence statistic).
+template <class Pending>
+F3D_HD float frame_pixel(const FrameParams &P, uint32_t gx, uint32_t gy, Pending &pend) {
+    const uint32_t W = P.cam.width;
+    const size_t lp = (size_t)(gy - P.row_begin) * W + gx;  // strip-local pixel
+    const float4 g = P.gbuffer_n[lp];
+
+    // merged history: last frame's spatial pass, evaluated lazily here
+    Reservoir prev = empty_reservoir();
+    if (P.frame_index > 0u) prev = spatial_reuse(P, P.res_in, gx, gy, P.frame_index - 1u, V3{g.x, g.y, g.z});
+    // M-clamp, hybrid_terrain_traversal.wgsl:452-462
+    if (prev.m > kRestirMCap) {
+        const float scale = (float)kRestirMCap / (float)prev.m;
+        prev.w_sum = prev.w_sum * scale;
+        prev.m = kRestirMCap;
+        if (prev.target_pdf > 0.0f) prev.weight = prev.w_sum / ((float)prev.m * prev.target_pdf);
+    }
+    const bool prev_valid = P.frame_index > 0u && prev.m > 0u && prev.weight > 0.0f && prev.target_pdf > 0.0f &&
+                            prev.directional;
+    const V3 sun_dir = prev_valid ? P.light.wi_reuse : P.light.wi;
+    const float reuse_w = prev_valid ? f_clamp(prev.weight, 0.0f, 4.0f) : 1.0f;
+
+    uint32_t rng = P.cam.seed_hi ^ (gx * 1664525u) ^ (gy * 1013904223u) ^ (P.frame_index * 92837111u) ^
+                   P.cam.seed_lo;
+    V3 radiance = V3{0.0f, 0.0f, 0.0f};
+    Reservoir cand = empty_reservoir();
+
+    for (uint32_t s = 0u; s < P.spp; s++) {
+        const float jx = tent_offset(rng_next(rng)) * 0.5f;
+        const float jy = tent_offset(rng_next(rng)) * 0.5f;
+        const V3 rd = camera_dir(P.cam, gx, gy, jx, jy);
+        const SurfaceHit hit = closest_hit(P, P.cam.origin, 1e-3f, rd, 1e30f, pend);
+        if (hit.kind == 0u) {
+            radiance = radiance + env_radiance(P.env, rd);
+            continue;
+        }
+        const V3 n = hit.n;
+        const V3 albedo = hit.kind == 1u ? P.light.albedo : V3{0.7f, 0.7f, 0.8f};
+
+        // candidate generation, :500-512
+        const float ndotl = f_max(dot(n, P.light.wi), 0.0f);
+        const float target_pdf = luminance((albedo * P.light.color) * ndotl);
+        if (target_pdf > 0.0f) {
+            cand.directional = true;
+            cand.w_sum = cand.w_sum + target_pdf;
+            cand.m = cand.m + 1u;
+            cand.target_pdf = target_pdf;
+        }
+
+        // sun through the merged reservoir, :517-532
+        V3 sun = V3{0.0f, 0.0f, 0.0f};
+        const float nd = f_max(dot(n, sun_dir), 0.0f);
+        const V3 so = along(hit.p, 1e-3f, n);
+        if (nd > 0.0f) {
+            float vis = 1.0f;
+            if (P.light.shadows_enabled != 0u && occluded(P, so, 1e-3f, sun_dir, 1e30f, true, pend)) vis = 0.0f;
+            sun = (((albedo * P.light.color) * nd) * vis) * reuse_w;
+        }
+
+        // one cosine-weighted IBL sample, :537-545
+        const float u1 = rng_next(rng);
+        const float u2 = rng_next(rng);
+        const V3 ei = cosine_dir(n, u1, u2);
+        const float env_vis = occluded(P, so, 1e-3f, ei, 1e30f, false, pend) ? 0.0f : 1.0f;
+        const V3 ibl = (albedo * env_radiance(P.env, ei)) * env_vis;
+
+        radiance = (radiance + sun) + ibl;
+    }
+    const float fspp = (float)P.spp;
+    radiance = V3{radiance.x / fspp, radiance.y / fspp, radiance.z / fspp};
+
+    // finalize the candidate (:552-555) and merge with the history (temporal pass)
+    if (cand.m > 0u && cand.w_sum > 0.0f && cand.target_pdf > 0.0f)
+        cand.weight = cand.w_sum / ((float)cand.m * cand.target_pdf);
+    P.res_out[reservoir_index(P, gx, gy)] = pack(temporal_merge(prev, cand));
+
+    // accumulate + windowed Welford of the running-mean luminance, :557-574
+    float4 am = P.accum_mean[lp];
+    float wf_m2 = P.welford_m2[lp];
+    float wf_mean = am.w;
+    const V3 acc = V3{am.x + radiance.x, am.y + radiance.y, am.z + radiance.z};
+    const float count = (float)(P.frame_index + 1u);  // accum.a: one per frame, exact
+    const uint32_t phase = P.frame_index % kWelfordWindow;
+    if (phase == 0u) {
+        wf_mean = 0.0f;
+        wf_m2 = 0.0f;
+    }
+    const float mean_lum = luminance(V3{acc.x / count, acc.y / count, acc.z / count});
+    const float k = (float)phase + 1.0f;
+    const float delta = mean_lum - wf_mean;
+    const float mean = wf_mean + delta / k;
+    const float m2 = f_fma(delta, mean_lum - mean, wf_m2);
+    P.accum_mean[lp] = float4{acc.x, acc.y, acc.z, mean};
+    P.welford_m2[lp] = m2;
+    return m2;
+}
+
+// ---- G-buffer + frame-0 AOVs: unjittered centre ray (:583-609, :619-644) ---------------
+template <class Pending>
+F3D_HD void gbuffer_pixel(const FrameParams &P, uint32_t gx, uint32_t gy, float4 *gbuffer_n, float *depth,
+                          Pending &pend) {
+    const size_t lp = (size_t)(gy - P.row_begin) * P.cam.width + gx;
+    const V3 rd = camera_dir(P.cam, gx, gy, 0.0f, 0.0f);
+    const SurfaceHit hit = closest_hit(P, P.cam.origin, 1e-3f, rd, 1e30f, pend);
+    if (hit.kind != 0u) {
+        gbuffer_n[lp] = float4{hit.n.x, hit.n.y, hit.n.z, (float)hit.kind};
+        depth[lp] = hit.t;
+    } else {
+        gbuffer_n[lp] = float4{0.0f, 0.0f, 1.0f, 0.0f};
+        depth[lp] = f_from_bits(0x7fc00000u);
+    }
+}
+
+// ---- final resolve: last spatial pass + validity (render_terrain.rs:1313-1337),
+// Reinhard -> RGBA16F -> u8 (hybrid_kernel.wgsl:109-112, render_terrain.rs:1358-1366),
+// AOVs through RGBA16F (render_terrain.rs:438-447, :1367-1393). flags: bit0 valid, bit1 bad.
+F3D_HD uint32_t resolve_pixel(const FrameParams &P, uint32_t frames, uint32_t gx, uint32_t gy, uint8_t *rgba,
+                              float *albedo, float *normal) {
+    const size_t lp = (size_t)(gy - P.row_begin) * P.cam.width + gx;
+    const float4 g = P.gbuffer_n[lp];
+    const Reservoir r = spatial_reuse(P, P.res_in, gx, gy, frames - 1u, V3{g.x, g.y, g.z});
+    uint32_t flags = 0u;
+    if (!(f_finite(r.w_sum) && f_finite(r.weight) && f_finite(r.target_pdf))) flags |= 2u;
+    if (r.m > 0u && r.weight > 0.0f && r.target_pdf > 0.0f) flags |= 1u;
+
+    const float4 am = P.accum_mean[lp];
+    const float count = (float)frames;
+    const V3 e = V3{am.x / count, am.y / count, am.z / count} * P.cam.exposure;
+    const float ldr[3] = {e.x / (1.0f + e.x), e.y / (1.0f + e.y), e.z / (1.0f + e.z)};
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float v = round_to_half(ldr[c]);
+        rgba[4 * lp + c] = (uint8_t)(f_clamp(v, 0.0f, 1.0f) * 255.0f + 0.5f);
+    }
+    rgba[4 * lp + 3] = 255;
+
+    const uint32_t kind = (uint32_t)g.w;
+    const V3 a = kind == 1u ? P.light.albedo : (kind == 2u ? V3{0.7f, 0.7f, 0.8f} : V3{0.0f, 0.0f, 0.0f});
+    const V3 n = kind != 0u ? V3{g.x, g.y, g.z} : V3{0.0f, 0.0f, 0.0f};
+    albedo[3 * lp + 0] = round_to_half(a.x);
+    albedo[3 * lp + 1] = round_to_half(a.y);
+    albedo[3 * lp + 2] = round_to_half(a.z);
+    normal[3 * lp + 0] = round_to_half(n.x);
+    normal[3 * lp + 1] = round_to_half(n.y);
+    normal[3 * lp + 2] = round_to_half(n.z);
+    return flags;
+}
+
+}  // namespace f3d

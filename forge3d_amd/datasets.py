@@ -1,0 +1,93 @@
+"""Synthetic stand-ins for the DEMs BASELINE.json names.
+
+The reference ships Rainier / Shasta / ... as git-LFS objects fetched over the network
+(reference python/forge3d/datasets.py:53-61, 287-300); none of that is reachable here, so
+the benchmark configuration runs on a procedurally generated proxy with pinned seeds
+(input "S2").  Everything produced here is labelled synthetic.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+RAINIER_PROXY_SEED = 20260926
+
+
+def _lattice(ix: np.ndarray, iy: np.ndarray, seed: int) -> np.ndarray:
+    """Integer lattice hash -> uniform [0, 1) (32-bit avalanche mix)."""
+    h = (ix.astype(np.uint64) * np.uint64(0x9E3779B1) + iy.astype(np.uint64) * np.uint64(0x85EBCA77)
+         + np.uint64(seed)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(15)
+    h = (h * np.uint64(0x2C1B3C6D)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(12)
+    h = (h * np.uint64(0x297A2D39)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(15)
+    return h.astype(np.float64) / 4294967296.0
+
+
+def _value_noise(u: np.ndarray, v: np.ndarray, seed: int) -> np.ndarray:
+    x0, y0 = np.floor(u), np.floor(v)
+    fx, fy = u - x0, v - y0
+    sx, sy = fx * fx * (3 - 2 * fx), fy * fy * (3 - 2 * fy)
+    ix, iy = x0.astype(np.int64), y0.astype(np.int64)
+    a = _lattice(ix, iy, seed)
+    b = _lattice(ix + 1, iy, seed)
+    c = _lattice(ix, iy + 1, seed)
+    d = _lattice(ix + 1, iy + 1, seed)
+    return (a * (1 - sx) + b * sx) * (1 - sy) + (c * (1 - sx) + d * sx) * sy
+
+
+def rainier_proxy(size: int = 2048, seed: int = RAINIER_PROXY_SEED) -> np.ndarray:
+    """"rainier-proxy": a 4392 m cone + 6-octave value-noise fBm (600 m), float32 metres."""
+    t = (np.arange(size, dtype=np.float64) + 0.5) / size
+    u, v = np.meshgrid(t, t)
+    r = np.hypot(u - 0.5, v - 0.5)
+    cone = 4392.0 * np.maximum(0.0, 1.0 - r / 0.45) ** 1.3
+    fbm = np.zeros_like(cone)
+    amp, freq, norm = 1.0, 8.0, 0.0
+    for octave in range(6):
+        fbm += amp * (_value_noise(u * freq, v * freq, seed + 101 * octave) - 0.5)
+        norm += amp
+        amp *= 0.5
+        freq *= 2.0
+    dem = cone + 600.0 * 2.0 * fbm / norm
+    dem -= dem.min()
+    return dem.astype(np.float32)
+
+
+def orbit_camera(target, radius: float, phi_deg: float, theta_deg: float, fov_y_deg: float, exposure: float = 1.0):
+    """Orbit-camera mapping of the reference viewer (src/viewer/terrain/scene.rs:110-139):
+    eye = target + r (sin(theta) cos(phi), cos(theta), sin(theta) sin(phi))."""
+    th, ph = math.radians(theta_deg), math.radians(phi_deg)
+    eye = (target[0] + radius * math.sin(th) * math.cos(ph), target[1] + radius * math.cos(th),
+           target[2] + radius * math.sin(th) * math.sin(ph))
+    return {"origin": eye, "look_at": tuple(target), "up": (0.0, 1.0, 0.0), "fov_y": fov_y_deg,
+            "exposure": exposure}
+
+
+def rainier_proxy_scene(size: int = 2048):
+    """BASELINE.json config 2 on the proxy DEM: returns (dem, camera, kwargs)."""
+    dem = rainier_proxy(size)
+    spacing = 10.0 * 2048.0 / size
+    span = (size - 1) * spacing
+    target = (0.0, 0.5 * float(dem.max()), 0.0)
+    cam = orbit_camera(target, 1.25 * span, 28.0, 49.0, 42.0)
+    kw = dict(spacing=(spacing, spacing), exaggeration=1.0, albedo=(0.6, 0.6, 0.6), sun_azimuth_deg=302.0,
+              sun_elevation_deg=24.0, sun_intensity=2.5, env_intensity=0.35, seed=7)
+    return dem, cam, kw
+
+
+def mini_dem_scene(dem_256: np.ndarray):
+    """The reference's locked golden scene (tests/test_hybrid_terrain_pt.py:30-76) from the
+    shipped 256x256 mini DEM: returns (dem, camera, kwargs)."""
+    dem = np.asarray(dem_256)[::2, ::2].astype(np.float32)
+    dem -= dem.min()
+    dem /= max(float(dem.max()), 1e-6)
+    spacing = 100.0 / (dem.shape[1] - 1)
+    cam = {"origin": (0.0, 35.0, 90.0), "look_at": (0.0, 5.0, 0.0), "up": (0.0, 1.0, 0.0), "fov_y": 45.0,
+           "exposure": 1.0}
+    kw = dict(spacing=(spacing, spacing), exaggeration=20.0, albedo=(0.55, 0.52, 0.48), sun_azimuth_deg=225.0,
+              sun_elevation_deg=35.0, sun_intensity=2.5, env_intensity=0.35, max_frames=512, min_frames=32,
+              variance_threshold=1e-3, seed=7)
+    return dem, cam, kw

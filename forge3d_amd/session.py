@@ -1,0 +1,138 @@
+"""Steppable, device-resident form of the terrain render (C ABI ``f3d_session_*``).
+
+Used by bench.py (inputs resident in HBM before the timed region) and by the row-strip
+multi-GPU driver (forge3d_amd/distributed.py).  One TerrainSession owns the image rows
+[row_begin, row_end); RNG and all state are keyed by full-image coordinates.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native
+
+HALO_ROWS = 3
+RESERVOIR_BYTES = 16
+WELFORD_WINDOW = 32
+
+
+class TerrainSession:
+    def __init__(self, heightmap, width, height, camera=None, *, row_begin=0, row_end=0, device=-1, stream=0,
+                 memory_budget_bytes=0, kernel_variant=0, ext_reservoirs=(None, None), ext_stats=None,
+                 spacing=(1.0, 1.0), exaggeration=1.0, albedo=(0.6, 0.6, 0.6), sun_azimuth_deg=315.0,
+                 sun_elevation_deg=45.0, sun_intensity=2.5, sun_color=(1.0, 0.97, 0.92), env_map=None,
+                 env_intensity=0.35, mesh_vertices=None, mesh_indices=None, spp=1, max_frames=512, min_frames=32,
+                 variance_threshold=1e-3, seed=7, observer_latitude_deg=0.0, observer_longitude_deg=0.0,
+                 earth_model="ellipsoid", sphere_radius_m=6_371_008.8, refraction_model="bennett",
+                 refraction_k=0.13, pressure_mbar=1013.25, temperature_c=15.0):
+        self._lib = _native.lib()
+        self._handle = C.c_void_p(None)
+        desc, keep = _native.make_desc(heightmap, width, height, dict(camera or {}), spacing, exaggeration, albedo,
+                                       sun_azimuth_deg, sun_elevation_deg, sun_intensity, env_map, env_intensity,
+                                       mesh_vertices, mesh_indices, spp, max_frames, min_frames,
+                                       variance_threshold, seed, sun_color, observer_latitude_deg,
+                                       observer_longitude_deg, earth_model, sphere_radius_m, refraction_model,
+                                       refraction_k, pressure_mbar, temperature_c)
+        opts = _native.SessionOpts()
+        opts.device = int(device)
+        opts.stream = C.c_void_p(int(stream) or None)
+        opts.row_begin, opts.row_end = int(row_begin), int(row_end)
+        opts.memory_budget_bytes = int(memory_budget_bytes)
+        opts.kernel_variant = int(kernel_variant)
+        opts.ext_reservoirs[0] = C.c_void_p(ext_reservoirs[0] or None)
+        opts.ext_reservoirs[1] = C.c_void_p(ext_reservoirs[1] or None)
+        opts.ext_stats = C.c_void_p(ext_stats or None)
+        err = C.create_string_buffer(1024)
+        rc = self._lib.f3d_session_create(C.byref(desc), C.byref(opts), C.byref(self._handle), err, len(err))
+        del keep
+        if rc != 0:
+            self._handle = C.c_void_p(None)
+            _native.raise_status(rc, err.value.decode("utf-8", "replace"))
+        self.width, self.height = int(width), int(height)
+        self.row_begin = int(row_begin)
+        self.row_end = int(row_end) or int(height)
+        self.rows = self.row_end - self.row_begin
+        self.spp = int(spp)
+        self._err = err
+
+    # -- lifecycle --------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            self._lib.f3d_session_destroy(self._handle)
+            self._handle = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            _native.raise_status(rc, self._err.value.decode("utf-8", "replace"))
+
+    # -- stepping ---------------------------------------------------------------------
+    def enqueue_frames(self, first_frame: int, count: int, collect_stats: bool = False):
+        """Asynchronously enqueue accumulation frames on the session stream."""
+        self._check(self._lib.f3d_session_enqueue_frames(self._handle, int(first_frame), int(count),
+                                                         1 if collect_stats else 0, self._err, len(self._err)))
+
+    def window_stats(self):
+        """(max Welford m2 over the owned pixels, saw non-finite) -- synchronises the stream."""
+        m2, bad = C.c_float(0.0), C.c_int32(0)
+        self._check(self._lib.f3d_session_window_stats(self._handle, C.byref(m2), C.byref(bad), self._err,
+                                                       len(self._err)))
+        return float(m2.value), bool(bad.value)
+
+    def halo(self, which: int, side: int):
+        """(device pointer, bytes) of a 3-row halo block of reservoir buffer `which`."""
+        ptr, nbytes = C.c_void_p(None), C.c_uint64(0)
+        rc = self._lib.f3d_session_halo(self._handle, int(which), int(side), C.byref(ptr), C.byref(nbytes))
+        if rc != 0:
+            raise ValueError("invalid halo query")
+        return int(ptr.value), int(nbytes.value)
+
+    def resolve(self, frames: int):
+        """Final resolve of the owned rows into host arrays."""
+        rows, w = self.rows, self.width
+        rgba = np.zeros((rows, w, 4), np.uint8)
+        alb = np.zeros((rows, w, 3), np.float32)
+        nrm = np.zeros((rows, w, 3), np.float32)
+        dep = np.zeros((rows, w), np.float32)
+        valid = C.c_int32(0)
+        self._check(self._lib.f3d_session_resolve(self._handle, int(frames), rgba.ctypes.data, alb.ctypes.data,
+                                                  nrm.ctypes.data, dep.ctypes.data, C.byref(valid), self._err,
+                                                  len(self._err)))
+        return {"rgba": rgba, "albedo": alb, "normal": nrm, "depth": dep, "any_valid_reservoir": bool(valid.value)}
+
+    def resolve_device(self, frames: int, d_rgba=0, d_albedo=0, d_normal=0, d_depth=0):
+        self._check(self._lib.f3d_session_resolve_device(self._handle, int(frames), C.c_void_p(d_rgba or None),
+                                                         C.c_void_p(d_albedo or None), C.c_void_p(d_normal or None),
+                                                         C.c_void_p(d_depth or None), self._err, len(self._err)))
+
+    def info(self):
+        g, p, h = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        rows, width = C.c_uint32(0), C.c_uint32(0)
+        self._lib.f3d_session_info(self._handle, C.byref(g), C.byref(p), C.byref(h), C.byref(rows), C.byref(width))
+        return {"gpu_resource_bytes": int(g.value), "minmax_pyramid_bytes": int(p.value),
+                "peak_host_visible_bytes": int(h.value), "rows": int(rows.value), "width": int(width.value)}
+
+    def kernel_timing(self, enable: bool):
+        """enable=True starts recording a hipEvent pair around every frame launch;
+        enable=False stops and returns (average ms per launch, launches)."""
+        avg, n = C.c_double(0.0), C.c_uint32(0)
+        rc = self._lib.f3d_session_kernel_timing(self._handle, 1 if enable else 0, C.byref(avg), C.byref(n))
+        if rc != 0:
+            raise RuntimeError("kernel timing failed")
+        return float(avg.value), int(n.value)
+
+
+def reservoir_buffer_bytes(rows: int, width: int) -> int:
+    return (rows + 2 * HALO_ROWS) * width * RESERVOIR_BYTES

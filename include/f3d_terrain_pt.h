@@ -1,0 +1,187 @@
+/* include/f3d_terrain_pt.h -- C ABI of libf3dhip.so
+ *
+ * MI355X-native (gfx950, HIP) replacement for ONE path of forge3d: the PROMETHEUS
+ * terrain path tracer behind `forge3d.hybrid_render_terrain_reference`.  These entry
+ * points are what the reference's FFI for this path would bind (INTEGRATION.md shows
+ * the Rust `extern "C"` block and the PyO3 shim a forge3d maintainer would add).
+ * Plain pointers and sizes only; no torch / HIP types in any signature (streams and
+ * device buffers travel as `void*`).  All functions are blocking unless stated and
+ * thread-compatible (no hidden process-wide state besides the HIP primary context).
+ *
+ * Status codes: 0 ok; 1 value error (-> Python ValueError); 2 render error
+ * (reference RenderError::Render -> RuntimeError "[Render] Render error: ...");
+ * 3 upload error (RenderError::Upload); 4 device error (no GPU / HIP failure --
+ * there is NO CPU fallback: without a usable gfx950 device every compute entry
+ * point fails with status 4).
+ */
+#ifndef F3D_TERRAIN_PT_H
+#define F3D_TERRAIN_PT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define F3D_STATUS_OK 0
+#define F3D_STATUS_VALUE 1
+#define F3D_STATUS_RENDER 2
+#define F3D_STATUS_UPLOAD 3
+#define F3D_STATUS_DEVICE 4
+
+/* EarthModel / RefractionModel of reference src/geo/refraction.rs:15-43 */
+#define F3D_EARTH_FLAT 0
+#define F3D_EARTH_SPHERE 1
+#define F3D_EARTH_ELLIPSOID 2
+#define F3D_REFRACTION_NONE 0
+#define F3D_REFRACTION_BENNETT 1
+#define F3D_REFRACTION_SAEMUNDSSON 2
+#define F3D_REFRACTION_EFFECTIVE_RADIUS 3
+
+/* Mirrors TerrainReferenceDesc (reference
+ * src/path_tracing/hybrid_compute/render_terrain.rs:239-282) plus the earth /
+ * refraction parameters the PyO3 seam parses (src/py_functions/path_tracing/
+ * terrain_reference.rs:295-312).  All pointers are HOST pointers that are only read
+ * during the call. */
+typedef struct f3d_terrain_ref_desc {
+    const float *heights; /* (dem_height, dem_width) row-major f32 */
+    uint32_t dem_width, dem_height;
+    float spacing_x, spacing_z;
+    float exaggeration;
+    float albedo[3];
+    float cam_origin[3], cam_look_at[3], cam_up[3];
+    float fov_y_deg, exposure;
+    float sun_azimuth_deg, sun_elevation_deg, sun_intensity;
+    float sun_color[3];
+    double observer_latitude_deg, observer_longitude_deg;
+    int32_t earth_model;      /* F3D_EARTH_* */
+    int32_t refraction_model; /* F3D_REFRACTION_* */
+    double sphere_radius_m, refraction_k, pressure_mbar, temperature_c;
+    const float *env_map; /* (env_height, env_width, 3) or NULL */
+    uint32_t env_width, env_height;
+    float env_intensity;
+    const float *mesh_vertices; /* (mesh_vertex_count, 3) or NULL */
+    uint32_t mesh_vertex_count;
+    const uint32_t *mesh_indices; /* mesh_index_count entries, 3 per triangle, or NULL */
+    uint32_t mesh_index_count;
+    uint32_t width, height;
+    uint32_t seed, spp, max_frames, min_frames;
+    float variance_threshold;
+} f3d_terrain_ref_desc;
+
+/* Mirrors TerrainReferenceOutput (render_terrain.rs:285-299).  The four image
+ * buffers are CALLER-allocated host memory; the library never frees or retains
+ * them. */
+typedef struct f3d_terrain_ref_out {
+    uint8_t *rgba; /* (height, width, 4) */
+    float *albedo; /* (height, width, 3) */
+    float *normal; /* (height, width, 3) */
+    float *depth;  /* (height, width), qNaN on miss */
+    uint32_t frames;
+    float variance;
+    int32_t converged;
+    uint64_t peak_host_visible_bytes;
+    uint64_t minmax_pyramid_bytes;
+    uint64_t gpu_resource_bytes;
+    double loop_seconds;     /* accumulation loop only (device time, host clock) */
+    double setup_seconds;    /* pyramid build + uploads + G-buffer pass */
+    double readback_seconds; /* resolve + copies back */
+} f3d_terrain_ref_out;
+
+/* Replaces `_forge3d.hybrid_render_terrain_reference`
+ * (reference src/py_functions/path_tracing/terrain_reference.rs:221-457 ->
+ * HybridPathTracer::render_terrain_reference, render_terrain.rs:563-1434). */
+int f3d_terrain_ref_render(const f3d_terrain_ref_desc *desc, f3d_terrain_ref_out *out, char *err,
+                           size_t errlen);
+
+/* ---- session API: the same render, device-resident and steppable -------------
+ * Used by bench.py (inputs resident in HBM before the timed region) and by the
+ * row-strip multi-GPU driver (forge3d_amd/distributed.py).  A session owns the
+ * pixel rows [row_begin, row_end) of the full width x height image; RNG and all
+ * state are keyed by full-image coordinates, so any partition reproduces the
+ * single-GPU image. */
+typedef struct f3d_session f3d_session;
+
+typedef struct f3d_session_opts {
+    int32_t device;      /* HIP device ordinal, -1 = current */
+    void *stream;        /* hipStream_t to enqueue on, NULL = the null stream */
+    uint32_t row_begin;  /* first owned image row */
+    uint32_t row_end;    /* one past the last owned row; 0 = height */
+    uint64_t memory_budget_bytes; /* 0 = 512 MiB (reference MEMORY_BUDGET_LIMIT) */
+    int32_t kernel_variant;       /* 0 = default; others are A/B variants for profiling */
+    /* Optional caller-owned DEVICE buffers (NULL -> the library allocates).  The
+     * strip driver allocates these as torch tensors so RCCL can move them.
+     *   reservoirs[2]: ping-pong packed reservoirs, each (rows + 6) * width * 16 B,
+     *                  local row r holds image row row_begin - 3 + r;
+     *   stats:         4 x u32 {max m2 bits, nonfinite flag, any_valid flag, bad_reservoir flag}. */
+    void *ext_reservoirs[2];
+    void *ext_stats;
+} f3d_session_opts;
+
+int f3d_session_create(const f3d_terrain_ref_desc *desc, const f3d_session_opts *opts,
+                       f3d_session **session, char *err, size_t errlen);
+void f3d_session_destroy(f3d_session *session);
+
+/* Enqueue accumulation frames [first_frame, first_frame + count) on the session
+ * stream; asynchronous.  Multi-strip callers enqueue one frame at a time and
+ * exchange the 3-row halos of reservoir buffer (frame & 1) between frames.  When
+ * collect_stats_on_last != 0 the last frame of the batch also publishes the
+ * convergence statistic read by f3d_session_window_stats. */
+int f3d_session_enqueue_frames(f3d_session *session, uint32_t first_frame, uint32_t count,
+                               int32_t collect_stats_on_last, char *err, size_t errlen);
+/* Variance gate input for the window that ends after `frames` frames
+ * (render_terrain.rs:1206-1231): synchronises the stream, returns max m2 over the
+ * owned pixels (NOT yet divided by n-1) and whether a non-finite m2 was seen. */
+int f3d_session_window_stats(f3d_session *session, float *max_m2, int32_t *nonfinite, char *err,
+                             size_t errlen);
+/* Device pointer + byte size of the halo rows of reservoir buffer `which` (0/1):
+ * side 0 = the 3 owned rows at the top (to send up), 1 = the 3 owned rows at the
+ * bottom (to send down), 2 = halo above the strip (to receive), 3 = halo below. */
+int f3d_session_halo(f3d_session *session, int32_t which, int32_t side, void **ptr, uint64_t *bytes);
+/* Final resolve (last spatial reuse pass, reservoir validity, Reinhard + f16 + u8
+ * quantisation, AOV conversion) and copy of the owned rows into host buffers that
+ * cover ONLY the strip ((rows, width, C) each).  frames = accumulated frame count. */
+int f3d_session_resolve(f3d_session *session, uint32_t frames, uint8_t *rgba, float *albedo,
+                        float *normal, float *depth, int32_t *any_valid_reservoir, char *err,
+                        size_t errlen);
+/* Same, but leaves the results in caller-owned DEVICE buffers (for an RCCL gather). */
+int f3d_session_resolve_device(f3d_session *session, uint32_t frames, void *d_rgba, void *d_albedo,
+                               void *d_normal, void *d_depth, char *err, size_t errlen);
+/* Memory / layout diagnostics of a session. */
+int f3d_session_info(f3d_session *session, uint64_t *gpu_resource_bytes, uint64_t *minmax_pyramid_bytes,
+                     uint64_t *peak_host_visible_bytes, uint32_t *rows, uint32_t *width);
+/* Average device time in ms of the `count` most recent frame-kernel launches,
+ * measured with hipEvents recorded on the session stream around every launch when
+ * timing is enabled (bench.py's roofline leg).  enable: 1 start, 0 stop. */
+int f3d_session_kernel_timing(f3d_session *session, int32_t enable, double *avg_ms, uint32_t *launches);
+
+/* ---- test hooks (KATs restated from the reference's Rust unit tests) ----------- */
+/* build_minmax_mips on the GPU (reference terrain_heightfield.rs:132-202); output in
+ * the reference's layout: levels back to back, finest first, each (ph, pw, 2) f32;
+ * dims_out (pw, ph) pairs.  levels_out may be NULL to query level count / size. */
+int f3d_build_minmax_mips(const float *heights, uint32_t width, uint32_t height, float *levels_out,
+                          uint32_t *dims_out, uint32_t max_levels, uint64_t *total_floats, char *err,
+                          size_t errlen);
+/* terrain_trace over a ray batch (reference test seam
+ * main_helios_production_terrain_trace_proof, terrain_heightfield.rs:1646-1671).
+ * rays: n x 8 f32 (origin xyz, tmin, direction xyz, tmax). */
+int f3d_terrain_trace_batch(const float *heights, uint32_t width, uint32_t height, float origin_x,
+                            float origin_z, float spacing_x, float spacing_z, float exaggeration,
+                            float inv_two_r_prime, uint32_t curvature_enabled, const float *rays,
+                            uint32_t n, int32_t any_hit, int32_t apply_curvature, uint32_t *out_hit,
+                            float *out_t, float *out_normal, char *err, size_t errlen);
+/* geo::refraction::effective_radius_m (reference src/geo/refraction.rs:137-148). */
+int f3d_effective_radius_m(int32_t earth_model, double latitude_deg, double sphere_radius_m,
+                           int32_t refraction_model, double pressure_mbar, double temperature_c,
+                           double refraction_k, double azimuth_deg, double *radius_out, char *err,
+                           size_t errlen);
+
+int f3d_device_count(void);
+const char *f3d_device_name(int32_t device); /* gcnArchName, "" when unavailable */
+const char *f3d_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* F3D_TERRAIN_PT_H */

@@ -1,0 +1,112 @@
+"""ctypes front-end of tests/emul/libf3d_emul.so -- TEST INFRASTRUCTURE ONLY.
+
+The emulator compiles the product's kernel headers (forge3d_amd/csrc/f3d_{trace,shade,
+build,setup}.h) for the host and runs them one lane at a time, so the kernel LOGIC can be
+compared bit-for-bit with the oracle in the GPU-less container.  The `-m gpu` tests repeat
+the comparison on the real device through libf3dhip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+from forge3d_amd import _native
+
+_HERE = Path(__file__).resolve().parent
+_LIB = _HERE / "libf3d_emul.so"
+_CSRC = _HERE.parent.parent / "forge3d_amd" / "csrc"
+
+
+def build(force=False):
+    srcs = [_HERE / "f3d_emul.cpp"] + sorted(_CSRC.glob("*.h"))
+    if force or not _LIB.exists() or _LIB.stat().st_mtime < max(s.stat().st_mtime for s in srcs):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-march=x86-64-v3",
+                        "-ffp-contract=off", str(_HERE / "f3d_emul.cpp"), "-o", str(_LIB)],
+                       check=True, capture_output=True)
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(str(_LIB))
+        _lib.emul_render.restype = C.c_int
+        _lib.emul_trace_batch.restype = C.c_int
+        _lib.emul_build_minmax_mips.restype = C.c_int
+    return _lib
+
+
+def render(heightmap, width, height, camera=None, *, spacing=(1.0, 1.0), exaggeration=1.0,
+           albedo=(0.6, 0.6, 0.6), sun_azimuth_deg=315.0, sun_elevation_deg=45.0, sun_intensity=2.5,
+           sun_color=(1.0, 0.97, 0.92), env_map=None, env_intensity=0.35, mesh_vertices=None,
+           mesh_indices=None, spp=1, max_frames=512, min_frames=32, variance_threshold=1e-3, seed=7,
+           observer_latitude_deg=0.0, observer_longitude_deg=0.0, earth_model="ellipsoid",
+           sphere_radius_m=6_371_008.8, refraction_model="bennett", refraction_k=0.13,
+           pressure_mbar=1013.25, temperature_c=15.0):
+    d, keep = _native.make_desc(heightmap, width, height, dict(camera or {}), spacing, exaggeration, albedo,
+                                sun_azimuth_deg, sun_elevation_deg, sun_intensity, env_map, env_intensity,
+                                mesh_vertices, mesh_indices, spp, max_frames, min_frames, variance_threshold,
+                                seed, sun_color, observer_latitude_deg, observer_longitude_deg, earth_model,
+                                sphere_radius_m, refraction_model, refraction_k, pressure_mbar, temperature_c)
+    P = width * height
+    rgba = np.zeros((height, width, 4), np.uint8)
+    alb = np.zeros((height, width, 3), np.float32)
+    nrm = np.zeros((height, width, 3), np.float32)
+    dep = np.zeros((height, width), np.float32)
+    accum = np.zeros((P, 4), np.float32)
+    m2 = np.zeros(P, np.float32)
+    res = np.zeros((P, 4), np.uint32)
+    frames, conv, var = C.c_uint32(0), C.c_int32(0), C.c_float(0)
+    err = C.create_string_buffer(512)
+    rc = lib().emul_render(C.byref(d), C.c_uint32(0), C.c_uint32(0), C.c_void_p(rgba.ctypes.data),
+                           C.c_void_p(alb.ctypes.data), C.c_void_p(nrm.ctypes.data), C.c_void_p(dep.ctypes.data),
+                           C.byref(frames), C.byref(var), C.byref(conv), C.c_void_p(accum.ctypes.data),
+                           C.c_void_p(m2.ctypes.data), C.c_void_p(res.ctypes.data), err, C.c_size_t(len(err)))
+    if rc != 0:
+        raise RuntimeError(f"emul status {rc}: {err.value.decode()}")
+    return {"rgba": rgba, "albedo": alb, "normal": nrm, "depth": dep, "frames": frames.value,
+            "variance": var.value, "converged": bool(conv.value), "accum": accum, "m2": m2, "res": res}
+
+
+def terrain_trace_batch(heights, rays, *, origin=(0.0, 0.0), spacing=(1.0, 1.0), exaggeration=1.0,
+                        inv_two_r_prime=0.0, curvature_enabled=False, any_hit=True, apply_curvature=True):
+    dem = np.ascontiguousarray(heights, np.float32)
+    r = np.ascontiguousarray(rays, np.float32)
+    n = r.shape[0]
+    hit = np.zeros(n, np.uint32)
+    t = np.zeros(n, np.float32)
+    nrm = np.zeros((n, 3), np.float32)
+    rc = lib().emul_trace_batch(C.c_void_p(dem.ctypes.data), C.c_uint32(dem.shape[1]), C.c_uint32(dem.shape[0]),
+                                C.c_float(origin[0]), C.c_float(origin[1]), C.c_float(spacing[0]),
+                                C.c_float(spacing[1]), C.c_float(exaggeration), C.c_float(inv_two_r_prime),
+                                C.c_uint32(1 if curvature_enabled else 0), C.c_void_p(r.ctypes.data), C.c_uint32(n),
+                                C.c_int32(1 if any_hit else 0), C.c_int32(1 if apply_curvature else 0),
+                                C.c_void_p(hit.ctypes.data), C.c_void_p(t.ctypes.data), C.c_void_p(nrm.ctypes.data))
+    if rc != 0:
+        raise RuntimeError(f"emul status {rc}")
+    return {"hit": hit, "t": t, "normal": nrm}
+
+
+def build_minmax_mips(heights):
+    dem = np.ascontiguousarray(heights, np.float32)
+    h, w = dem.shape
+    tot = C.c_uint64(0)
+    dims = np.zeros(32, np.uint32)
+    n = lib().emul_build_minmax_mips(C.c_void_p(dem.ctypes.data), C.c_uint32(w), C.c_uint32(h), None,
+                                     C.c_void_p(dims.ctypes.data), C.byref(tot))
+    flat = np.zeros(tot.value, np.float32)
+    lib().emul_build_minmax_mips(C.c_void_p(dem.ctypes.data), C.c_uint32(w), C.c_uint32(h),
+                                 C.c_void_p(flat.ctypes.data), C.c_void_p(dims.ctypes.data), C.byref(tot))
+    levels, off = [], 0
+    for l in range(n):
+        pw, ph = int(dims[2 * l]), int(dims[2 * l + 1])
+        levels.append(flat[off:off + pw * ph * 2].reshape(ph, pw, 2))
+        off += pw * ph * 2
+    return levels

@@ -1,0 +1,227 @@
+// tests/emul/f3d_emul.cpp -- TEST INFRASTRUCTURE ONLY.
+// Runs the product's kernel bodies (forge3d_amd/csrc/f3d_{trace,shade,build}.h, the same
+// source the gfx950 kernels are compiled from) on the host, one "lane" at a time, so that
+// the kernel logic can be compared bit-for-bit with the CPU oracle in the GPU-less
+// container.  It is never shipped, never imported by forge3d_amd, and proves nothing about
+// the GPU build by itself -- the `-m gpu` tests repeat the comparison through libf3dhip.so.
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../forge3d_amd/csrc/f3d_setup.h"
+#include "../../forge3d_amd/csrc/f3d_shade.h"
+
+using namespace f3d;
+
+namespace {
+struct ArrayPending {
+    uint32_t w[kMaxLevels];
+    void put(uint32_t l, uint32_t v) { w[l] = v; }
+    uint32_t get(uint32_t l) const { return w[l]; }
+};
+
+struct HostTables {
+    TableLayout L;
+    std::vector<LeafRec> leaves;
+    std::vector<NodeRec> nodes;
+};
+
+HostTables build_tables_host(const float *heights, uint32_t w, uint32_t h, float exaggeration) {
+    HostTables t;
+    t.L = table_layout(w, h);
+    t.leaves.resize(t.L.leaf_count);
+    t.nodes.resize(t.L.node_count ? t.L.node_count : 1);
+    PyramidBuildParams lb = leaf_build_params(t.L, heights, w, h, exaggeration, t.leaves.data());
+    for (uint32_t y = 0; y < lb.leaf_dim_y; y++)
+        for (uint32_t x = 0; x < lb.leaf_dim_x; x++) leaf_build_at(lb, x, y);
+    for (uint32_t l = 1; l < t.L.levels; l++) {
+        LevelBuildParams b = level_build_params(t.L, l, t.leaves.data(), t.nodes.data());
+        for (uint32_t y = 0; y < b.dst_dim_y; y++)
+            for (uint32_t x = 0; x < b.dst_dim_x; x++) level_build_at(b, x, y);
+    }
+    return t;
+}
+}  // namespace
+
+extern "C" {
+
+int emul_trace_batch(const float *heights, uint32_t w, uint32_t h, float origin_x, float origin_z, float spacing_x,
+                     float spacing_z, float exaggeration, float inv_two_r_prime, uint32_t curvature_enabled,
+                     const float *rays, uint32_t n, int32_t any_hit, int32_t apply_curvature, uint32_t *out_hit,
+                     float *out_t, float *out_normal) {
+    try {
+        HostTables t = build_tables_host(heights, w, h, exaggeration);
+        TerrainDev T{};
+        apply_layout(t.L, T);
+        T.leaves = t.leaves.data();
+        T.nodes = t.nodes.data();
+        T.origin_x = origin_x;
+        T.origin_z = origin_z;
+        T.spacing_x = spacing_x;
+        T.spacing_z = spacing_z;
+        T.inv_spacing_x = 1.0f / spacing_x;
+        T.inv_spacing_z = 1.0f / spacing_z;
+        T.inv_two_r_prime = inv_two_r_prime;
+        T.curvature_enabled = curvature_enabled;
+#pragma omp parallel for schedule(dynamic, 64)
+        for (long i = 0; i < (long)n; i++) {
+            const float *r = rays + 8 * (size_t)i;
+            ArrayPending pend;
+            RayCtx rc = make_ray(T, V3{r[0], r[1], r[2]}, r[3], V3{r[4], r[5], r[6]}, r[7], apply_curvature != 0);
+            TraceHit hit = trace_terrain(T, rc, any_hit != 0, pend);
+            out_hit[i] = hit.hit ? 1u : 0u;
+            if (out_t) out_t[i] = hit.t;
+            if (out_normal) {
+                out_normal[3 * i] = hit.hit ? hit.n.x : 0.0f;
+                out_normal[3 * i + 1] = hit.hit ? hit.n.y : 0.0f;
+                out_normal[3 * i + 2] = hit.hit ? hit.n.z : 0.0f;
+            }
+        }
+    } catch (const Failure &f) {
+        return f.status;
+    }
+    return 0;
+}
+
+// levels_out in the reference layout (see f3d_build_minmax_mips)
+int emul_build_minmax_mips(const float *heights, uint32_t w, uint32_t h, float *levels_out, uint32_t *dims_out,
+                           uint64_t *total_floats) {
+    try {
+        HostTables t = build_tables_host(heights, w, h, 1.0f);
+        uint64_t off = 0;
+        for (uint32_t l = 0; l < t.L.levels; l++) {
+            if (dims_out) {
+                dims_out[2 * l] = t.L.level_w[l];
+                dims_out[2 * l + 1] = t.L.level_h[l];
+            }
+            for (uint32_t y = 0; y < t.L.level_h[l]; y++)
+                for (uint32_t x = 0; x < t.L.level_w[l]; x++) {
+                    float mn = INFINITY, mx = -INFINITY;
+                    if (l == 0) {
+                        if (x < t.L.cell_w && y < t.L.cell_h) {
+                            const LeafRec &r = t.leaves[tiled_index(x, y, t.L.tiles_x[0])];
+                            mn = min4(r);
+                            mx = max4(r);
+                        }
+                    } else {
+                        const NodeRec &r = t.nodes[t.L.node_offset[l] + tiled_index(x, y, t.L.tiles_x[l])];
+                        mn = r.mn;
+                        mx = r.mx;
+                    }
+                    if (levels_out) {
+                        levels_out[off] = mn;
+                        levels_out[off + 1] = mx;
+                    }
+                    off += 2;
+                }
+        }
+        if (total_floats) *total_floats = off;
+        return (int)t.L.levels;
+    } catch (const Failure &f) {
+        return -f.status;
+    }
+}
+
+// Full render with the product's per-pixel code; fixed-frame or converging, like the C ABI.
+// state dumps: accum (P x 4: rgb + welford mean), m2 (P), res (P x 4 u32 words, final temporal output)
+int emul_render(const f3d_terrain_ref_desc *d, uint32_t row_begin, uint32_t row_end, uint8_t *rgba, float *albedo,
+                float *normal, float *depth, uint32_t *frames_out, float *variance_out, int32_t *converged_out,
+                float *accum_dump, float *m2_dump, uint32_t *res_dump, char *err, size_t errlen) {
+    try {
+        validate_desc(*d);
+        validate_scene(*d);
+        FrameParams P{};
+        const bool require_valid = fill_uniforms(*d, P);
+        HostTables t = build_tables_host(d->heights, d->dem_width, d->dem_height, d->exaggeration);
+        apply_layout(t.L, P.terrain);
+        P.terrain.leaves = t.leaves.data();
+        P.terrain.nodes = t.nodes.data();
+        std::vector<float> env4, mesh4;
+        if (d->env_map) {
+            env4 = pad_rgb_to_rgba(d->env_map, (size_t)d->env_width * d->env_height, 1.0f);
+            P.env.texels = (const float4 *)env4.data();
+            P.env.width = d->env_width;
+            P.env.height = d->env_height;
+        }
+        if (d->mesh_vertices) {
+            mesh4 = pad_rgb_to_rgba(d->mesh_vertices, d->mesh_vertex_count, 0.0f);
+            P.mesh.vertices = (const float4 *)mesh4.data();
+            P.mesh.indices = d->mesh_indices;
+            P.mesh.vertex_count = d->mesh_vertex_count;
+            P.mesh.index_count = d->mesh_index_count;
+            P.mesh.traversal_mode = 0u;
+        }
+        if (row_end == 0) row_end = d->height;
+        P.row_begin = row_begin;
+        P.row_end = row_end;
+        const uint32_t W = d->width, rows = row_end - row_begin;
+        const size_t px = (size_t)rows * W, res_n = (size_t)(rows + 2 * kHaloRows) * W;
+        std::vector<PackedReservoir> res[2] = {std::vector<PackedReservoir>(res_n), std::vector<PackedReservoir>(res_n)};
+        std::vector<float4> accum(px), gbuf(px);
+        std::vector<float> m2(px, 0.0f), dep(px);
+        memset(accum.data(), 0, px * sizeof(float4));
+        memset(res[0].data(), 0, res_n * sizeof(PackedReservoir));
+        memset(res[1].data(), 0, res_n * sizeof(PackedReservoir));
+        P.accum_mean = accum.data();
+        P.welford_m2 = m2.data();
+        P.gbuffer_n = gbuf.data();
+#pragma omp parallel for schedule(dynamic, 4)
+        for (long y = row_begin; y < (long)row_end; y++) {
+            ArrayPending pend;
+            for (uint32_t x = 0; x < W; x++) gbuffer_pixel(P, x, (uint32_t)y, gbuf.data(), dep.data(), pend);
+        }
+        uint32_t frames = 0;
+        float variance = INFINITY;
+        bool converged = false;
+        while (frames < d->max_frames) {
+            P.frame_index = frames;
+            P.res_out = res[frames & 1u].data();
+            P.res_in = res[(frames & 1u) ^ 1u].data();
+            float vmax_m2 = 0.0f;
+            bool nonfinite = false;
+#pragma omp parallel for schedule(dynamic, 4) reduction(max : vmax_m2) reduction(|| : nonfinite)
+            for (long y = row_begin; y < (long)row_end; y++) {
+                ArrayPending pend;
+                for (uint32_t x = 0; x < W; x++) {
+                    const float v = frame_pixel(P, x, (uint32_t)y, pend);
+                    if (!f_finite(v)) nonfinite = true;
+                    else vmax_m2 = f_max(vmax_m2, f_max(v, 0.0f));
+                }
+            }
+            frames++;
+            if (frames % kWelfordWindow == 0u || frames == d->max_frames) {
+                const uint32_t n_window = ((frames - 1u) % kWelfordWindow) + 1u;
+                if (n_window >= 2u) {
+                    if (nonfinite) fail(F3D_STATUS_RENDER, "terrain PT produced non-finite variance (NaN in accumulation)");
+                    variance = f_max(0.0f, vmax_m2 / ((float)n_window - 1.0f));
+                    if (frames >= d->min_frames && variance < d->variance_threshold) {
+                        converged = true;
+                        break;
+                    }
+                }
+            }
+        }
+        *frames_out = frames;
+        *variance_out = variance;
+        *converged_out = converged ? 1 : 0;
+        if (!converged) fail(F3D_STATUS_RENDER, "terrain PT did not converge");
+        P.res_in = res[(frames - 1u) & 1u].data();
+        uint32_t flags_or = 0;
+        for (uint32_t y = row_begin; y < row_end; y++)
+            for (uint32_t x = 0; x < W; x++) flags_or |= resolve_pixel(P, frames, x, y, rgba, albedo, normal);
+        memcpy(depth, dep.data(), px * sizeof(float));
+        if (flags_or & 2u) fail(F3D_STATUS_RENDER, "terrain PT reservoir bookkeeping produced non-finite values");
+        if (require_valid && !(flags_or & 1u)) fail(F3D_STATUS_RENDER, "no valid reservoirs");
+        if (accum_dump) memcpy(accum_dump, accum.data(), px * sizeof(float4));
+        if (m2_dump) memcpy(m2_dump, m2.data(), px * sizeof(float));
+        if (res_dump) memcpy(res_dump, res[(frames - 1u) & 1u].data() + (size_t)kHaloRows * W, px * sizeof(PackedReservoir));
+    } catch (const Failure &f) {
+        if (err && errlen) snprintf(err, errlen, "%s", f.message.c_str());
+        return f.status;
+    }
+    return 0;
+}
+
+}  // extern "C"

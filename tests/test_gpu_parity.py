@@ -1,0 +1,393 @@
+"""`-m gpu` parity tests: the HIP path (through the C ABI) against the CPU oracle, the
+reference's committed golden image, and the behaviours the reference's own hot-path tests
+pin (reference tests/test_hybrid_terrain_pt.py).  Integer/byte outputs and -- because the
+numerics contract fixes every rounding (DESIGN.md "Numerics") -- the float AOVs are compared
+bit-for-bit; the golden gate uses the reference's tolerance SSIM >= 0.995, mean-abs <= 2.0.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import pytest
+
+import scenes
+from metrics import mean_abs, ssim
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def f3d():
+    import forge3d_amd
+    from forge3d_amd import _native
+
+    assert _native.device_count() >= 1, "no HIP device: the GPU tests must run on the MI355X box"
+    name = _native.lib().f3d_device_name(0).decode()
+    assert "gfx950" in name, f"expected gfx950, got {name!r}"
+    return forge3d_amd
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as o
+
+    o.build()
+    return o
+
+
+def _same(a, b):
+    assert np.array_equal(a["rgba"], b["rgba"]), f"rgba differs in {(a['rgba'] != b['rgba']).any(-1).sum()} pixels"
+    assert np.array_equal(a["depth"], b["depth"], equal_nan=True)
+    assert np.array_equal(a["normal"], b["normal"])
+    assert np.array_equal(a["albedo"], b["albedo"])
+    assert a["frames"] == b["frames"]
+    assert np.float32(a["variance"]) == np.float32(b["variance"])
+
+
+# ---------------------------------------------------------------------------------------
+# bit-exact parity with the oracle on seeded inputs
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("size,spp,frames,step", [((64, 64), 1, 2, 4), ((96, 64), 3, 5, 2), ((128, 128), 2, 34, 2),
+                                                  ((200, 120), 8, 3, 2), ((61, 47), 64, 2, 4)])
+def test_hip_matches_oracle_bit_exact(f3d, oracle, size, spp, frames, step):
+    dem = scenes.golden_dem(step)
+    kw = scenes.fixed_frames(scenes.scene_kwargs(dem), frames, spp=spp)
+    got = f3d.hybrid_render_terrain_reference(dem, size[0], size[1], scenes.CAM, **kw)
+    want = oracle.render(dem, size[0], size[1], scenes.CAM, **kw)
+    _same(got, want)
+
+
+def test_ragged_nonsquare_dem_and_sun_colour(f3d, oracle):
+    dem = scenes.golden_dem(2)[:37, :100].copy()  # 100 x 37 texels -> 128 x 64 padded pyramid
+    kw = scenes.fixed_frames(scenes.scene_kwargs(dem), 6, spp=2, sun_color=(0.2, 0.3, 1.5), seed=12345,
+                             earth_model="sphere", refraction_model="none")
+    cam = {**scenes.CAM, "origin": (10.0, 30.0, 60.0), "fov_y": 60.0, "exposure": 1.7}
+    _same(f3d.hybrid_render_terrain_reference(dem, 80, 72, cam, **kw), oracle.render(dem, 80, 72, cam, **kw))
+
+
+def test_env_map_and_flat_earth(f3d, oracle):
+    dem = scenes.golden_dem(4)
+    rng = np.random.default_rng(5)
+    env = rng.uniform(0.1, 2.0, size=(16, 32, 3)).astype(np.float32)
+    kw = scenes.fixed_frames(scenes.scene_kwargs(dem), 4, spp=2, env_map=env, earth_model="flat",
+                             refraction_model="none")
+    _same(f3d.hybrid_render_terrain_reference(dem, 72, 56, scenes.CAM, **kw),
+          oracle.render(dem, 72, 56, scenes.CAM, **kw))
+
+
+def test_mixed_scene_mesh_and_terrain(f3d, oracle):
+    """reference test_mixed_scene_mesh_and_terrain (:735-769) + bit parity with the oracle."""
+    dem = scenes.golden_dem()
+    kw = scenes.fixed_frames(scenes.scene_kwargs(dem), 8)
+    quad_v = np.array([[-18.0, 22.0, -6.0], [18.0, 22.0, -6.0], [18.0, 40.0, -6.0], [-18.0, 40.0, -6.0]], np.float32)
+    quad_i = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+    base = f3d.hybrid_render_terrain_reference(dem, 128, 128, scenes.CAM, **kw)
+    mixed = f3d.hybrid_render_terrain_reference(dem, 128, 128, scenes.CAM, mesh_vertices=quad_v,
+                                                mesh_indices=quad_i, **kw)
+    _same(mixed, oracle.render(dem, 128, 128, scenes.CAM, mesh_vertices=quad_v, mesh_indices=quad_i, **kw))
+    d0, d1 = base["depth"], mixed["depth"]
+    closer = np.isfinite(d1) & (~np.isfinite(d0) | (d1 < d0 - 1.0))
+    assert closer.mean() > 0.01
+    assert np.allclose(mixed["albedo"][closer], [0.7, 0.7, 0.8], atol=2e-2)
+    terr = np.isfinite(d1) & ~closer
+    assert terr.mean() > 0.3
+    assert np.allclose(mixed["albedo"][terr], np.array(scenes.ALBEDO), atol=2e-2)
+
+
+def test_terrain_trace_batch_matches_oracle_and_kat_gates(f3d, oracle):
+    """The reference's production-kernel proof (terrain_heightfield.rs:2129-2285): 10 000
+    xorshift rays + 255^2 grazing shadow mask, any-hit with curvature; here the HIP
+    traversal must reproduce the oracle's hit bits, t and normals exactly."""
+    import ctypes as C
+
+    from forge3d_amd import _native
+
+    heights, rays = scenes.proof_rays()
+    inv2r = np.float32(1.0 / 14_650_000.0)
+    want = oracle.terrain_trace_batch(heights, rays, spacing=(500.0, 500.0), inv_two_r_prime=float(inv2r),
+                                      curvature_enabled=True, any_hit=True, apply_curvature=True)
+    n = rays.shape[0]
+    hit, t, nrm = np.zeros(n, np.uint32), np.zeros(n, np.float32), np.zeros((n, 3), np.float32)
+    err = C.create_string_buffer(256)
+    rc = _native.lib().f3d_terrain_trace_batch(heights.ctypes.data, 256, 256, 0.0, 0.0, 500.0, 500.0, 1.0,
+                                               float(inv2r), 1, rays.ctypes.data, n, 1, 1, hit.ctypes.data,
+                                               t.ctypes.data, nrm.ctypes.data, err, len(err))
+    assert rc == 0, err.value
+    assert np.array_equal(hit, want["hit"])
+    assert np.array_equal(t, want["t"])
+    assert np.array_equal(nrm, want["normal"])
+    # closest-hit mode as well
+    want2 = oracle.terrain_trace_batch(heights, rays, spacing=(500.0, 500.0), any_hit=False, apply_curvature=False)
+    rc = _native.lib().f3d_terrain_trace_batch(heights.ctypes.data, 256, 256, 0.0, 0.0, 500.0, 500.0, 1.0, 0.0, 0,
+                                               rays.ctypes.data, n, 0, 0, hit.ctypes.data, t.ctypes.data,
+                                               nrm.ctypes.data, err, len(err))
+    assert rc == 0, err.value
+    assert np.array_equal(hit, want2["hit"]) and np.array_equal(t, want2["t"]) and np.array_equal(nrm, want2["normal"])
+
+
+@pytest.mark.parametrize("shape", [(256, 256), (37, 100), (2, 2), (3, 9), (130, 65)])
+def test_gpu_built_minmax_pyramid_matches_oracle(f3d, oracle, shape):
+    import ctypes as C
+
+    from forge3d_amd import _native
+
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    dem = rng.normal(1000.0, 300.0, size=shape).astype(np.float32)
+    levels, dims = oracle.build_minmax_mips(dem)
+    tot = C.c_uint64(0)
+    d = np.zeros(32, np.uint32)
+    err = C.create_string_buffer(256)
+    L = _native.lib()
+    n = L.f3d_build_minmax_mips(dem.ctypes.data, shape[1], shape[0], None, d.ctypes.data, 16, C.byref(tot), err, 256)
+    assert n == len(levels), err.value
+    flat = np.zeros(tot.value, np.float32)
+    L.f3d_build_minmax_mips(dem.ctypes.data, shape[1], shape[0], flat.ctypes.data, d.ctypes.data, 16, C.byref(tot),
+                            err, 256)
+    off = 0
+    for l, lvl in enumerate(levels):
+        assert (int(d[2 * l]), int(d[2 * l + 1])) == dims[l]
+        assert np.array_equal(flat[off:off + lvl.size].reshape(lvl.shape), lvl)
+        off += lvl.size
+
+
+# ---------------------------------------------------------------------------------------
+# the reference's golden and its own hot-path gates, on the HIP path
+# ---------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def reference(f3d):
+    dem = scenes.golden_dem()
+    out = f3d.hybrid_render_terrain_reference(dem, scenes.SIZE, scenes.SIZE, scenes.CAM, **scenes.scene_kwargs(dem))
+    return dem, out
+
+
+def test_terrain_reference_golden(reference, oracle):
+    """reference test_terrain_reference_golden (:822-859): SSIM >= 0.995, mean-abs <= 2.0 vs
+    the committed golden; plus bit equality with the oracle's converged image."""
+    dem, out = reference
+    golden = scenes.golden_png()
+    assert out["rgba"].shape == golden.shape
+    score = ssim(out["rgba"][..., :3], golden[..., :3], data_range=255.0)
+    drift = mean_abs(out["rgba"][..., :3], golden[..., :3])
+    print(f"\nHIP terrain PT vs reference golden: SSIM {score:.6f}, mean abs {drift:.4f}, frames {out['frames']}")
+    assert score >= 0.995
+    assert drift <= 2.0
+    want = oracle.render(dem, scenes.SIZE, scenes.SIZE, scenes.CAM, **scenes.scene_kwargs(dem))
+    _same(out, want)
+
+
+def test_converged_variance_under_threshold(reference):
+    _, out = reference
+    assert out["converged"] is True
+    assert out["variance"] < 1e-3
+    rgba = out["rgba"]
+    assert rgba.shape == (scenes.SIZE, scenes.SIZE, 4) and rgba.dtype == np.uint8
+    assert rgba[..., :3].astype(np.float32).mean() > 5.0
+    magenta = (rgba[..., 0] > 250) & (rgba[..., 1] < 5) & (rgba[..., 2] > 250)
+    assert magenta.mean() < 0.01
+    assert (rgba[..., 3] == 255).all()
+
+
+def test_terrain_hits_and_aov_consistency(reference):
+    _, out = reference
+    depth, normal, albedo = out["depth"], out["normal"], out["albedo"]
+    hits = np.isfinite(depth)
+    assert hits.mean() > 0.3
+    cam_dist = np.linalg.norm(np.array(scenes.CAM["origin"]) - np.array(scenes.CAM["look_at"]))
+    assert depth[hits].min() > 1.0
+    assert depth[hits].max() < cam_dist + scenes.SPAN * 2.0
+    assert np.abs(np.linalg.norm(normal[hits], axis=-1) - 1.0).max() < 1e-2
+    assert normal[hits][:, 1].mean() > 0.5
+    assert np.allclose(albedo[hits], np.array(scenes.ALBEDO), atol=2e-3)
+    assert np.allclose(albedo[~hits], 0.0, atol=1e-6)
+    assert np.isnan(depth[~hits]).all()
+    # sky pixels: env 0.35 -> Reinhard -> f16 -> 66
+    assert (out["rgba"][~hits][:, :3] == 66).all()
+
+
+def test_normals_match_analytic_gradient(reference):
+    """tier 1 of reference test_aov_parity_with_rasterizer (:313-381)."""
+    dem, out = reference
+    depth, normal = out["depth"], out["normal"]
+    hits = np.isfinite(depth)
+    spacing = scenes.SPAN / (dem.shape[1] - 1)
+    hz = dem * scenes.RELIEF
+    n_ref = np.stack([-np.gradient(hz, spacing, axis=1), np.ones_like(hz), -np.gradient(hz, spacing, axis=0)], -1)
+    n_ref /= np.linalg.norm(n_ref, axis=-1, keepdims=True)
+    origin = np.array(scenes.CAM["origin"], np.float64)
+    fwd = np.array(scenes.CAM["look_at"], np.float64) - origin
+    fwd /= np.linalg.norm(fwd)
+    right = np.cross(fwd, [0.0, 1.0, 0.0])
+    right /= np.linalg.norm(right)
+    up = np.cross(right, fwd)
+    half_h = np.tan(np.radians(scenes.CAM["fov_y"]) / 2.0)
+    ox = -0.5 * (dem.shape[1] - 1) * spacing
+    oz = -0.5 * (dem.shape[0] - 1) * spacing
+    ys, xs = np.nonzero(hits)
+    ndc_x = (xs + 0.5) / scenes.SIZE * 2 - 1
+    ndc_y = 1 - (ys + 0.5) / scenes.SIZE * 2
+    dirs = ndc_x[:, None] * half_h * right + ndc_y[:, None] * half_h * up + fwd
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    pts = origin[None, :] + depth[ys, xs][:, None] * dirs
+    gx = np.clip((pts[:, 0] - ox) / spacing, 0, dem.shape[1] - 1.001).astype(int)
+    gz = np.clip((pts[:, 2] - oz) / spacing, 0, dem.shape[0] - 1.001).astype(int)
+    inner = (gx > 1) & (gx < dem.shape[1] - 2) & (gz > 1) & (gz < dem.shape[0] - 2)
+    ang = np.degrees(np.arccos(np.clip((n_ref[gz[inner], gx[inner]] * normal[ys[inner], xs[inner]]).sum(-1), -1, 1)))
+    assert ang.mean() < 5.0
+    assert np.percentile(ang, 95) < 15.0
+
+
+def test_memory_within_budget(reference):
+    from forge3d_amd import _native
+
+    _, out = reference
+    limit = _native.global_memory_metrics()["limit_bytes"]
+    assert out["peak_host_visible_bytes"] < limit
+    assert out["minmax_pyramid_bytes"] < limit
+    assert out["gpu_resource_bytes"] > out["minmax_pyramid_bytes"]
+    assert out["gpu_resource_bytes"] < limit
+
+
+def test_no_silent_fallback(f3d):
+    bad = np.full((16, 16), np.nan, dtype=np.float32)
+    with pytest.raises(Exception, match="non-finite"):
+        f3d.hybrid_render_terrain_reference(bad, 64, 64, scenes.CAM, max_frames=8)
+    with pytest.raises(Exception, match="at least 2x2"):
+        f3d.hybrid_render_terrain_reference(np.zeros((1, 1), np.float32), 64, 64, scenes.CAM, max_frames=8)
+    dem = scenes.golden_dem()
+    with pytest.raises(RuntimeError, match="did not converge"):
+        f3d.hybrid_render_terrain_reference(dem, 128, 128, scenes.CAM,
+                                            **{**scenes.scene_kwargs(dem), "max_frames": 8, "min_frames": 2,
+                                               "variance_threshold": 1e-12})
+
+
+def test_native_trust_boundary_validation(f3d):
+    """validate_desc messages raised by the C ABI itself (render_terrain.rs:474-557)."""
+    from forge3d_amd import _native
+
+    dem = scenes.golden_dem()
+    base = dict(spacing=(1.0, 1.0), max_frames=4, min_frames=2, variance_threshold=1e30)
+    cases = [
+        (dict(base, max_frames=4, min_frames=8), "min_frames"),
+        (dict(base, spacing=(0.0, 1.0)), "spacing"),
+        (dict(base, spp=0), "spp"),
+        (dict(base, spp=65), "spp"),
+        (dict(base, exaggeration=-1.0), "exaggeration"),
+        (dict(base, sun_intensity=-1.0), "sun intensity"),
+        (dict(base, variance_threshold=0.0), "variance threshold"),
+        (dict(base, earth_model="flat"), "flat earth"),
+        (dict(base, observer_latitude_deg=91.0), "latitude"),
+    ]
+    for kw, needle in cases:
+        with pytest.raises(RuntimeError, match=needle):
+            _native.hybrid_render_terrain_reference(dem, 64, 64, dict(scenes.CAM), **kw)
+    for cam, needle in [({**scenes.CAM, "look_at": scenes.CAM["origin"]}, "look_at"),
+                        ({**scenes.CAM, "fov_y": 0.0}, "fov"),
+                        ({**scenes.CAM, "up": (0.0, -30.0, -90.0)}, "parallel"),
+                        ({**scenes.CAM, "exposure": 0.0}, "exposure")]:
+        with pytest.raises(RuntimeError, match=needle):
+            _native.hybrid_render_terrain_reference(dem, 64, 64, cam, **base)
+    with pytest.raises(ValueError, match="earth_model"):
+        _native.hybrid_render_terrain_reference(dem, 64, 64, dict(scenes.CAM), earth_model="mean-earth", **base)
+    with pytest.raises(RuntimeError, match="memory budget"):
+        _native.hybrid_render_terrain_reference(dem, 4096, 4096, dict(scenes.CAM), **base)
+
+
+def test_zero_sun_color_render_succeeds_and_removes_direct_sun(f3d):
+    dem = scenes.golden_dem()
+    kw = scenes.fixed_frames(scenes.scene_kwargs(dem), 32)
+    default = f3d.hybrid_render_terrain_reference(dem, 128, 128, scenes.CAM, **kw)
+    zero = f3d.hybrid_render_terrain_reference(dem, 128, 128, scenes.CAM, **{**kw, "sun_color": (0.0, 0.0, 0.0)})
+    assert np.isfinite(zero["depth"]).any()
+    a, b = default["rgba"][..., :3].astype(np.float64), zero["rgba"][..., :3].astype(np.float64)
+    assert np.abs(a - b).mean() > 0.5
+    assert b.mean() < a.mean()
+    blue = f3d.hybrid_render_terrain_reference(dem, 128, 128, scenes.CAM, **{**kw, "sun_color": (0.2, 0.3, 1.5)})
+    assert np.abs(a - blue["rgba"][..., :3].astype(np.float64)).mean() > 1.0
+
+
+def test_scaling_no_per_spp_blowup(f3d):
+    """reference test_scaling_no_per_spp_blowup (:772-813) on the accumulation-loop time."""
+    dem = scenes.golden_dem()
+    kw = scenes.scene_kwargs(dem)
+
+    def loop(spp, frames):
+        k = scenes.fixed_frames(kw, frames, spp=spp)
+        return min(f3d.hybrid_render_terrain_reference(dem, 128, 128, scenes.CAM, **k)["loop_seconds"] for _ in range(3))
+
+    loop(1, 32)
+    t1, t8 = loop(1, 32), loop(8, 32)
+    assert t8 / max(t1, 1e-9) < 12.0
+    tf1, tf8 = loop(1, 16), loop(1, 128)
+    assert tf8 / max(tf1, 1e-9) < 16.0
+
+
+# ---------------------------------------------------------------------------------------
+# size-independent properties at larger sizes
+# ---------------------------------------------------------------------------------------
+def test_strips_reproduce_the_full_image(f3d):
+    """Any row partition must reproduce the single-strip image exactly once the 3-row
+    reservoir halos are exchanged after every frame (here: device-to-device copies on one
+    GPU standing in for the RCCL point-to-point exchange)."""
+    import torch
+
+    from forge3d_amd.session import TerrainSession, reservoir_buffer_bytes
+
+    dem = scenes.golden_dem()
+    W, H, frames, spp = 160, 96, 6, 2
+    kw = scenes.fixed_frames(scenes.scene_kwargs(dem), frames, spp=spp)
+    full = f3d.hybrid_render_terrain_reference(dem, W, H, scenes.CAM, **kw)
+    bounds = [(0, 29), (29, 64), (64, 96)]
+    dev = torch.device("cuda", 0)
+    sessions, bufs = [], []
+    for b, e in bounds:
+        res = [torch.zeros(reservoir_buffer_bytes(e - b, W), dtype=torch.uint8, device=dev) for _ in range(2)]
+        bufs.append(res)
+        sessions.append(TerrainSession(dem, W, H, scenes.CAM, row_begin=b, row_end=e,
+                                       ext_reservoirs=(res[0].data_ptr(), res[1].data_ptr()), **kw))
+    row = W * 16
+    for f in range(frames):
+        for s in sessions:
+            s.enqueue_frames(f, 1, False)
+        torch.cuda.synchronize()
+        which = f & 1
+        for i in range(len(bounds) - 1):
+            up, dn = bufs[i][which], bufs[i + 1][which]
+            rows_up = bounds[i][1] - bounds[i][0]
+            dn[0:3 * row] = up[rows_up * row:(rows_up + 3) * row]          # my bottom rows -> their top halo
+            up[(rows_up + 3) * row:(rows_up + 6) * row] = dn[3 * row:6 * row]  # their top rows -> my bottom halo
+        torch.cuda.synchronize()
+    parts = [s.resolve(frames) for s in sessions]
+    for key in ("rgba", "albedo", "normal", "depth"):
+        stitched = np.concatenate([p[key] for p in parts], axis=0)
+        assert np.array_equal(stitched, full[key], equal_nan=True), key
+    for s in sessions:
+        s.close()
+
+
+def test_full_size_properties(f3d):
+    """BASELINE.json config 2 size (1920x1080, 8 spp) on the proxy DEM: determinism,
+    frame-additivity of the accumulation, finite outputs, AOV/hit-mask consistency."""
+    from forge3d_amd import datasets
+    from forge3d_amd.session import TerrainSession
+
+    dem, cam, kw = datasets.rainier_proxy_scene(1024)
+    k = dict(kw, spp=8, max_frames=4, min_frames=4, variance_threshold=1e30)
+    W, H = 1920, 1080
+    with TerrainSession(dem, W, H, cam, memory_budget_bytes=4 << 30, **k) as s:
+        s.enqueue_frames(0, 4, True)
+        m2, bad = s.window_stats()
+        a = s.resolve(4)
+    with TerrainSession(dem, W, H, cam, memory_budget_bytes=4 << 30, **k) as s:
+        for f in range(4):  # same frames, enqueued one by one
+            s.enqueue_frames(f, 1, f == 3)
+        m2b, _ = s.window_stats()
+        b = s.resolve(4)
+    assert not bad and np.isfinite(m2) and m2 == m2b
+    for key in ("rgba", "albedo", "normal", "depth"):
+        assert np.array_equal(a[key], b[key], equal_nan=True), key
+    hits = np.isfinite(a["depth"])
+    assert 0.2 < hits.mean() <= 1.0
+    assert np.abs(np.linalg.norm(a["normal"][hits], axis=-1) - 1.0).max() < 1e-2
+    assert (a["albedo"][~hits] == 0).all()
+    assert a["any_valid_reservoir"]
