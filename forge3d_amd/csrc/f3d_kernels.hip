@@ -15,12 +15,30 @@ namespace f3d {
 constexpr int kWave = 64;
 constexpr int kNumXcd = 8;
 
-// Pending-sibling words: [level][lane] column in LDS, 4 KiB per wave; bank = lane.
+// Per-wave LDS scratch of the traversal: the pending-sibling words as a [level][lane] column
+// (bank = lane, conflict-free) and a copy of the per-level layout table, so that a lane can
+// look its level up with one ds_read_b64 instead of a vector load from the kernarg segment.
+constexpr int kLdsWords = kMaxLevels * kWave + 2 * kMaxLevels;
 struct LdsPending {
-    uint32_t *col;
+    uint32_t *col;          // lds + lane
+    const uint32_t *table;  // lds + kMaxLevels * kWave: {node_offset, tiles_x} per level
     __device__ __forceinline__ void put(uint32_t level, uint32_t word) { col[level * kWave] = word; }
     __device__ __forceinline__ uint32_t get(uint32_t level) const { return col[level * kWave]; }
+    __device__ __forceinline__ void level_entry(const TerrainDev &, uint32_t level, uint32_t &offset,
+                                                uint32_t &tiles_x) const {
+        const uint2 e = *reinterpret_cast<const uint2 *>(table + 2u * level);
+        offset = e.x;
+        tiles_x = e.y;
+    }
 };
+__device__ __forceinline__ LdsPending make_pending(uint32_t *lds, const TerrainDev &T) {
+    if (threadIdx.x < kMaxLevels) {
+        lds[kMaxLevels * kWave + 2 * threadIdx.x] = T.node_offset[threadIdx.x];
+        lds[kMaxLevels * kWave + 2 * threadIdx.x + 1] = T.tiles_x[threadIdx.x];
+    }
+    __syncthreads();
+    return LdsPending{lds + threadIdx.x, lds + kMaxLevels * kWave};
+}
 
 __device__ __forceinline__ bool tile_pixel(const FrameParams &P, uint32_t &gx, uint32_t &gy) {
     const uint32_t rows = P.row_end - P.row_begin;
@@ -44,33 +62,53 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return v;
 }
 
-template <int VARIANT>
-__global__ __launch_bounds__(kWave) void k_frame(const FrameParams P) {
-    __shared__ uint32_t lds[kMaxLevels * kWave];
-    LdsPending pend{lds + threadIdx.x};
-    uint32_t gx, gy;
-    const bool active = tile_pixel(P, gx, gy);
-    float m2 = 0.0f;
-    if (active) m2 = frame_pixel(P, gx, gy, pend);
-    if (P.collect_stats != 0u) {
-        // max over pixels of the Welford m2 (render_terrain.rs:1211-1226); m2 >= 0 so the
-        // bit pattern orders like the value; non-finite values are flagged separately.
-        const bool bad = active && !f_finite(m2);
-        uint32_t bits = (active && !bad) ? f_bits(f_max(m2, 0.0f)) : 0u;
-        bits = wave_max_u32(bits);
-        const unsigned long long any_bad = __ballot(bad);
-        if (threadIdx.x == 0) {
-            // most waves lose the race for the maximum: look before paying for the atomic
-            if (bits > __hip_atomic_load(&P.stats[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                atomicMax(&P.stats[0], bits);
-            if (any_bad) atomicOr(&P.stats[1], 1u);
-        }
+// Wave-ballot gate of the ray state machine (f3d_shade.h): run the shading transition only
+// when at least MIN_WAITING lanes are waiting for one, or nobody is traversing any more.
+template <int MIN_WAITING>
+struct DeviceWave {
+    __device__ __forceinline__ bool gate(bool need, bool traversing) const {
+        const unsigned long long n = __ballot(need), t = __ballot(traversing);
+        return n != 0ull && (__popcll(n) >= MIN_WAITING || t == 0ull);
+    }
+    __device__ __forceinline__ bool all_finished(bool finished) const { return __ballot(!finished) == 0ull; }
+};
+
+__device__ __forceinline__ void publish_window_stats(const FrameParams &P, bool active, float m2) {
+    // max over pixels of the Welford m2 (render_terrain.rs:1211-1226); m2 >= 0 so the bit
+    // pattern orders like the value; non-finite values are flagged separately.
+    const bool bad = active && !f_finite(m2);
+    uint32_t bits = (active && !bad) ? f_bits(f_max(m2, 0.0f)) : 0u;
+    bits = wave_max_u32(bits);
+    const unsigned long long any_bad = __ballot(bad);
+    if (threadIdx.x == 0) {
+        // most waves lose the race for the maximum: look before paying for the atomic
+        if (bits > __hip_atomic_load(&P.stats[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(&P.stats[0], bits);
+        if (any_bad) atomicOr(&P.stats[1], 1u);
     }
 }
 
+// VARIANT 0: reference-shaped nested sample loop.  VARIANT n > 0: per-lane ray state
+// machine whose transition gate waits for n lanes (n = 64: fully synchronous).
+template <int VARIANT>
+__global__ __launch_bounds__(kWave) void k_frame(const FrameParams P) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kLdsWords];
+    LdsPending pend = make_pending(lds, P.terrain);
+    uint32_t gx = 0u, gy = 0u;
+    const bool active = tile_pixel(P, gx, gy);
+    float m2 = 0.0f;
+    if constexpr (VARIANT == 0) {
+        if (active) m2 = frame_pixel(P, gx, gy, pend);
+    } else {
+        DeviceWave<VARIANT> wave;
+        m2 = frame_pixel_sm(P, gx, gy, active, pend, wave);
+    }
+    if (P.collect_stats != 0u) publish_window_stats(P, active, m2);
+}
+
 __global__ __launch_bounds__(kWave) void k_gbuffer(const FrameParams P, float4 *gbuffer_n, float *depth) {
-    __shared__ uint32_t lds[kMaxLevels * kWave];
-    LdsPending pend{lds + threadIdx.x};
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kLdsWords];
+    LdsPending pend = make_pending(lds, P.terrain);
     uint32_t gx, gy;
     if (tile_pixel(P, gx, gy)) gbuffer_pixel(P, gx, gy, gbuffer_n, depth, pend);
 }
@@ -88,8 +126,8 @@ __global__ __launch_bounds__(kWave) void k_resolve(const ResolveParams R) {
 }
 
 __global__ __launch_bounds__(kWave) void k_ray_batch(const RayBatchParams B) {
-    __shared__ uint32_t lds[kMaxLevels * kWave];
-    LdsPending pend{lds + threadIdx.x};
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kLdsWords];
+    LdsPending pend = make_pending(lds, B.terrain);
     const uint32_t i = blockIdx.x * kWave + threadIdx.x;
     if (i >= B.n) return;
     const float4 a = B.rays[2 * i], b = B.rays[2 * i + 1];
@@ -124,8 +162,16 @@ static inline uint32_t frame_grid(const FrameParams &p) {
 }
 
 hipError_t launch_frame(const FrameParams &p, int variant, hipStream_t stream) {
-    (void)variant;
-    hipLaunchKernelGGL(k_frame<0>, dim3(frame_grid(p)), dim3(kWave), 0, stream, p);
+    const dim3 grid(frame_grid(p)), block(kWave);
+    switch (variant) {
+        case 0: hipLaunchKernelGGL(k_frame<0>, grid, block, 0, stream, p); break;
+        case 1: hipLaunchKernelGGL(k_frame<1>, grid, block, 0, stream, p); break;
+        case 8: hipLaunchKernelGGL(k_frame<8>, grid, block, 0, stream, p); break;
+        case 16: hipLaunchKernelGGL(k_frame<16>, grid, block, 0, stream, p); break;
+        case 32: hipLaunchKernelGGL(k_frame<32>, grid, block, 0, stream, p); break;
+        case 64: hipLaunchKernelGGL(k_frame<64>, grid, block, 0, stream, p); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 hipError_t launch_gbuffer(const FrameParams &p, float4 *gbuffer_n, float *depth, hipStream_t stream) {

@@ -14,10 +14,12 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define F3D_HD __host__ __device__ __forceinline__
+#define F3D_LAMBDA __attribute__((always_inline))
 #else
 #include <cmath>
 #include <cstring>
 #define F3D_HD inline
+#define F3D_LAMBDA __attribute__((always_inline))
 // Host-only builds (tests/emul) have no HIP vector types.
 struct alignas(16) float4 {
     float x, y, z, w;

@@ -27,6 +27,7 @@
 //    (The reference's 64-entry private u32 stack would be 16 KiB per wave.)
 #pragma once
 
+#include "f3d_build.h"
 #include "f3d_scene.h"
 
 namespace f3d {
@@ -205,140 +206,168 @@ struct TraceHit {
     bool hit;
 };
 
-// LDS (device) or array (host) column holding the pending-sibling word of each level.
-// put/get are only called with 1 <= level < kMaxLevels.
-template <class Pending>
-F3D_HD TraceHit trace_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit, Pending &pend) {
+// Resumable traversal: trace_begin applies the root tests, every trace_step visits one node
+// (inner node or fat leaf).  The frame kernel interleaves steps of rays in different
+// phases (primary / sun shadow / IBL) across the lanes of a wave.
+struct TraceState {
     TraceHit res;
-    res.hit = false;
-    res.t = r.tmax;
-    res.n = V3{0.0f, 0.0f, 0.0f};
+    uint32_t level, nx, nz;  // node being visited / last visited (path for sibling decoding)
+    uint32_t remaining;      // 2 bits per level: siblings still queued
+    float t_lo, t_hi;        // clipped interval of the node to visit
+    bool have;               // (level, nx, nz) with [t_lo, t_hi] is ready to visit
+    bool done;
+};
 
+template <class Pending>
+F3D_HD void trace_begin(const TerrainDev &T, const RayCtx &r, bool any_hit, TraceState &st, Pending &pend) {
+    (void)pend;
+    st.res.hit = false;
+    st.res.t = r.tmax;
+    st.res.n = V3{0.0f, 0.0f, 0.0f};
+    st.done = true;
+    st.have = false;
+    st.remaining = 0u;
     const uint32_t top = T.mip_count - 1u;
+    st.level = top;
+    st.nx = 0u;
+    st.nz = 0u;
     // ---- root: the reference pops it first and applies :284-304 ----
-    float t_lo, t_hi;
     {
         const float ax = (plane_at(T.origin_x, 0u, T.spacing_x) - r.o.x) * r.inv_x;
         const float bx = (plane_at(T.origin_x, T.cell_w, T.spacing_x) - r.o.x) * r.inv_x;
         const float az = (plane_at(T.origin_z, 0u, T.spacing_z) - r.o.z) * r.inv_z;
         const float bz = (plane_at(T.origin_z, T.cell_h, T.spacing_z) - r.o.z) * r.inv_z;
-        t_lo = f_max(f_max(f_min(ax, bx), f_min(az, bz)), r.tmin);
-        t_hi = f_min(f_min(f_max(ax, bx), f_max(az, bz)), f_min(r.tmax, res.t));
-        if (t_lo > t_hi) return res;
+        st.t_lo = f_max(f_max(f_min(ax, bx), f_min(az, bz)), r.tmin);
+        st.t_hi = f_min(f_min(f_max(ax, bx), f_max(az, bz)), f_min(r.tmax, st.res.t));
+        if (st.t_lo > st.t_hi) return;
     }
     if (top == 0u) {  // 2x2 DEM: the root is the single cell
         const LeafRec h = T.leaves[0];
-        const float mn = f_min(f_min(f_min(h.h00, h.h10), h.h01), h.h11);
-        const float mx = f_max(f_max(f_max(h.h00, h.h10), h.h01), h.h11);
-        if (band_rejects(r, t_lo, t_hi, mn, mx)) return res;
+        if (band_rejects(r, st.t_lo, st.t_hi, min4(h), max4(h))) return;
         float t;
-        if (leaf_solve(T, r, h, 0u, 0u, t_lo, t_hi, any_hit, t) && t < res.t) {
-            res.hit = true;
-            res.t = t;
-            res.n = leaf_normal(T, h, along(r.o, t, r.d), 0u, 0u);
+        if (leaf_solve(T, r, h, 0u, 0u, st.t_lo, st.t_hi, any_hit, t) && t < st.res.t) {
+            st.res.hit = true;
+            st.res.t = t;
+            st.res.n = leaf_normal(T, h, along(r.o, t, r.d), 0u, 0u);
         }
-        return res;
+        return;
     }
-    {
-        const NodeRec root = T.nodes[T.node_offset[top]];
-        if (band_rejects(r, t_lo, t_hi, root.mn, root.mx)) return res;
-    }
+    const NodeRec root = T.nodes[T.node_offset[top]];
+    if (band_rejects(r, st.t_lo, st.t_hi, root.mn, root.mx)) return;
+    st.have = true;
+    st.done = false;
+}
 
-    uint32_t level = top, nx = 0u, nz = 0u;  // node being visited
-    uint32_t remaining = 0u;                  // 2 bits per level: siblings still queued
-    bool have = true;                         // (level, nx, nz) with [t_lo, t_hi] is ready to visit
-    for (;;) {
-        if (!have) {
-            if (remaining == 0u) break;
-            // deepest level with queued siblings
-            const uint32_t l = (uint32_t)__builtin_ctz(remaining) >> 1;
-            const uint32_t left = (remaining >> (2u * l)) & 3u;
-            const uint32_t word = pend.get(l);
-            const uint32_t total = word >> 6;
-            const uint32_t code = (word >> (2u * (total - left))) & 3u;
-            remaining -= 1u << (2u * l);
-            const uint32_t up = l + 1u - level;  // levels between the current node and the parent
-            nx = ((nx >> up) << 1) | (code & 1u);
-            nz = ((nz >> up) << 1) | (code >> 1);
-            level = l;
-            // pop-time slab/interval test with the CURRENT best t (:288-297)
-            const uint32_t cx0 = nx << level, cz0 = nz << level;
-            uint32_t cx1 = (nx + 1u) << level, cz1 = (nz + 1u) << level;
-            cx1 = cx1 < T.cell_w ? cx1 : T.cell_w;
-            cz1 = cz1 < T.cell_h ? cz1 : T.cell_h;
-            const float ax = (plane_at(T.origin_x, cx0, T.spacing_x) - r.o.x) * r.inv_x;
-            const float bx = (plane_at(T.origin_x, cx1, T.spacing_x) - r.o.x) * r.inv_x;
-            const float az = (plane_at(T.origin_z, cz0, T.spacing_z) - r.o.z) * r.inv_z;
-            const float bz = (plane_at(T.origin_z, cz1, T.spacing_z) - r.o.z) * r.inv_z;
-            t_lo = f_max(f_max(f_min(ax, bx), f_min(az, bz)), r.tmin);
-            t_hi = f_min(f_min(f_max(ax, bx), f_max(az, bz)), f_min(r.tmax, res.t));
-            if (t_lo > t_hi) continue;
+template <class Pending>
+F3D_HD void trace_step(const TerrainDev &T, const RayCtx &r, bool any_hit, TraceState &st, Pending &pend) {
+    if (!st.have) {
+        if (st.remaining == 0u) {
+            st.done = true;
+            return;
         }
-        have = false;
-        const uint32_t cl = level - 1u;
-        const ChildSlabs k = child_slabs(T, r, level, nx, nz, t_lo, t_hi);
+        // deepest level with queued siblings
+        const uint32_t l = (uint32_t)__builtin_ctz(st.remaining) >> 1;
+        const uint32_t left = (st.remaining >> (2u * l)) & 3u;
+        const uint32_t word = pend.get(l);
+        const uint32_t total = word >> 6;
+        const uint32_t code = (word >> (2u * (total - left))) & 3u;
+        st.remaining -= 1u << (2u * l);
+        const uint32_t up = l + 1u - st.level;  // levels between the current node and the parent
+        st.nx = ((st.nx >> up) << 1) | (code & 1u);
+        st.nz = ((st.nz >> up) << 1) | (code >> 1);
+        st.level = l;
+        // pop-time slab/interval test with the CURRENT best t (:288-297)
+        const uint32_t cx0 = st.nx << l, cz0 = st.nz << l;
+        uint32_t cx1 = (st.nx + 1u) << l, cz1 = (st.nz + 1u) << l;
+        cx1 = cx1 < T.cell_w ? cx1 : T.cell_w;
+        cz1 = cz1 < T.cell_h ? cz1 : T.cell_h;
+        const float ax = (plane_at(T.origin_x, cx0, T.spacing_x) - r.o.x) * r.inv_x;
+        const float bx = (plane_at(T.origin_x, cx1, T.spacing_x) - r.o.x) * r.inv_x;
+        const float az = (plane_at(T.origin_z, cz0, T.spacing_z) - r.o.z) * r.inv_z;
+        const float bz = (plane_at(T.origin_z, cz1, T.spacing_z) - r.o.z) * r.inv_z;
+        st.t_lo = f_max(f_max(f_min(ax, bx), f_min(az, bz)), r.tmin);
+        st.t_hi = f_min(f_min(f_max(ax, bx), f_max(az, bz)), f_min(r.tmax, st.res.t));
+        if (st.t_lo > st.t_hi) return;  // culled; next step pops again
+    }
+    st.have = false;
+    const uint32_t level = st.level, nx = st.nx, nz = st.nz;
+    const uint32_t cl = level - 1u;
+    const ChildSlabs k = child_slabs(T, r, level, nx, nz, st.t_lo, st.t_hi);
 
-        if (cl == 0u) {
-            // ---- fat leaf: solve the queued cells near-to-far (:306-318) ----
-            const uint32_t g = child_group_index(nx, nz, T.tiles_x[0]);
-            const LeafRec h0 = T.leaves[g], h1 = T.leaves[g + 1u], h2 = T.leaves[g + 2u], h3 = T.leaves[g + 3u];
-            uint32_t count;
-            const uint32_t order = visit_order(k.key, k.queued, count);
-            for (uint32_t i = 0u; i < count; i++) {
-                const uint32_t code = (order >> (2u * i)) & 3u;
-                const float en = pick4(code, k.enter[0], k.enter[1], k.enter[2], k.enter[3]);
-                const float ex = pick4(code, k.exit[0], k.exit[1], k.exit[2], k.exit[3]);
-                const float lo = f_max(en, r.tmin);
-                const float hi = f_min(ex, f_min(r.tmax, res.t));
-                if (lo > hi) continue;
-                LeafRec h;
-                h.h00 = pick4(code, h0.h00, h1.h00, h2.h00, h3.h00);
-                h.h10 = pick4(code, h0.h10, h1.h10, h2.h10, h3.h10);
-                h.h01 = pick4(code, h0.h01, h1.h01, h2.h01, h3.h01);
-                h.h11 = pick4(code, h0.h11, h1.h11, h2.h11, h3.h11);
-                const float mn = f_min(f_min(f_min(h.h00, h.h10), h.h01), h.h11);
-                const float mx = f_max(f_max(f_max(h.h00, h.h10), h.h01), h.h11);
-                if (band_rejects(r, lo, hi, mn, mx)) continue;
-                const uint32_t cx = 2u * nx + (code & 1u), cz = 2u * nz + (code >> 1);
-                float t;
-                if (leaf_solve(T, r, h, cx, cz, lo, hi, any_hit, t) && t < res.t) {
-                    res.hit = true;
-                    res.t = t;
-                    res.n = leaf_normal(T, h, along(r.o, t, r.d), cx, cz);
-                    if (any_hit) return res;
+    if (cl == 0u) {
+        // ---- fat leaf: solve the queued cells near-to-far (:306-318) ----
+        const uint32_t g = child_group_index(nx, nz, T.tiles_x[0]);
+        const LeafRec h0 = T.leaves[g], h1 = T.leaves[g + 1u], h2 = T.leaves[g + 2u], h3 = T.leaves[g + 3u];
+        uint32_t count;
+        const uint32_t order = visit_order(k.key, k.queued, count);
+        for (uint32_t i = 0u; i < count; i++) {
+            const uint32_t code = (order >> (2u * i)) & 3u;
+            const float en = pick4(code, k.enter[0], k.enter[1], k.enter[2], k.enter[3]);
+            const float ex = pick4(code, k.exit[0], k.exit[1], k.exit[2], k.exit[3]);
+            const float lo = f_max(en, r.tmin);
+            const float hi = f_min(ex, f_min(r.tmax, st.res.t));
+            if (lo > hi) continue;
+            LeafRec h;
+            h.h00 = pick4(code, h0.h00, h1.h00, h2.h00, h3.h00);
+            h.h10 = pick4(code, h0.h10, h1.h10, h2.h10, h3.h10);
+            h.h01 = pick4(code, h0.h01, h1.h01, h2.h01, h3.h01);
+            h.h11 = pick4(code, h0.h11, h1.h11, h2.h11, h3.h11);
+            if (band_rejects(r, lo, hi, min4(h), max4(h))) continue;
+            const uint32_t cx = 2u * nx + (code & 1u), cz = 2u * nz + (code >> 1);
+            float t;
+            if (leaf_solve(T, r, h, cx, cz, lo, hi, any_hit, t) && t < st.res.t) {
+                st.res.hit = true;
+                st.res.t = t;
+                st.res.n = leaf_normal(T, h, along(r.o, t, r.d), cx, cz);
+                if (any_hit) {
+                    st.done = true;
+                    return;
                 }
             }
-            continue;
         }
-
-        // ---- inner node: test the four children now, keep the survivors (:320-369) ----
-        const uint32_t g = T.node_offset[cl] + child_group_index(nx, nz, T.tiles_x[cl]);
-        const NodeRec m0 = T.nodes[g], m1 = T.nodes[g + 1u], m2 = T.nodes[g + 2u], m3 = T.nodes[g + 3u];
-        const float cmn[4] = {m0.mn, m1.mn, m2.mn, m3.mn}, cmx[4] = {m0.mx, m1.mx, m2.mx, m3.mx};
-        bool keep[4];
-        const float cap = f_min(r.tmax, res.t);
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const float lo = f_max(k.enter[c], r.tmin), hi = f_min(k.exit[c], cap);
-            keep[c] = k.queued[c] && !(lo > hi) && !band_rejects(r, lo, hi, cmn[c], cmx[c]);
-        }
-        uint32_t count;
-        const uint32_t order = visit_order(k.key, keep, count);
-        if (count == 0u) continue;
-        // nearest survivor is visited next; the rest wait in the level's pending word
-        const uint32_t first = order & 3u;
-        if (count > 1u) {
-            pend.put(cl, (order >> 2) | ((count - 1u) << 6));
-            remaining |= (count - 1u) << (2u * cl);
-        }
-        t_lo = f_max(pick4(first, k.enter[0], k.enter[1], k.enter[2], k.enter[3]), r.tmin);
-        t_hi = f_min(pick4(first, k.exit[0], k.exit[1], k.exit[2], k.exit[3]), cap);
-        nx = 2u * nx + (first & 1u);
-        nz = 2u * nz + (first >> 1);
-        level = cl;
-        have = true;
+        return;
     }
-    return res;
+
+    // ---- inner node: test the four children now, keep the survivors (:320-369) ----
+    uint32_t level_offset, level_tiles_x;
+    pend.level_entry(T, cl, level_offset, level_tiles_x);
+    const uint32_t g = level_offset + child_group_index(nx, nz, level_tiles_x);
+    // four (min, max) records = 32 contiguous, 32-byte aligned bytes: two 16-byte loads
+    const float4 *pair = reinterpret_cast<const float4 *>(T.nodes + g);
+    const float4 q0 = pair[0], q1 = pair[1];
+    const float cmn[4] = {q0.x, q0.z, q1.x, q1.z}, cmx[4] = {q0.y, q0.w, q1.y, q1.w};
+    bool keep[4];
+    const float cap = f_min(r.tmax, st.res.t);
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const float lo = f_max(k.enter[c], r.tmin), hi = f_min(k.exit[c], cap);
+        keep[c] = k.queued[c] && !(lo > hi) && !band_rejects(r, lo, hi, cmn[c], cmx[c]);
+    }
+    uint32_t count;
+    const uint32_t order = visit_order(k.key, keep, count);
+    if (count == 0u) return;
+    // nearest survivor is visited next; the rest wait in the level's pending word
+    const uint32_t first = order & 3u;
+    if (count > 1u) {
+        pend.put(cl, (order >> 2) | ((count - 1u) << 6));
+        st.remaining |= (count - 1u) << (2u * cl);
+    }
+    st.t_lo = f_max(pick4(first, k.enter[0], k.enter[1], k.enter[2], k.enter[3]), r.tmin);
+    st.t_hi = f_min(pick4(first, k.exit[0], k.exit[1], k.exit[2], k.exit[3]), cap);
+    st.nx = 2u * nx + (first & 1u);
+    st.nz = 2u * nz + (first >> 1);
+    st.level = cl;
+    st.have = true;
+}
+
+// LDS (device) or array (host) column holding the pending-sibling word of each level.
+// put/get are only called with 1 <= level < kMaxLevels.
+template <class Pending>
+F3D_HD TraceHit trace_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit, Pending &pend) {
+    TraceState st;
+    trace_begin(T, r, any_hit, st, pend);
+    while (!st.done) trace_step(T, r, any_hit, st, pend);
+    return st.res;
 }
 
 }  // namespace f3d

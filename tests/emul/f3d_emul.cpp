@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -20,6 +21,10 @@ struct ArrayPending {
     uint32_t w[kMaxLevels];
     void put(uint32_t l, uint32_t v) { w[l] = v; }
     uint32_t get(uint32_t l) const { return w[l]; }
+    void level_entry(const TerrainDev &T, uint32_t l, uint32_t &offset, uint32_t &tiles_x) const {
+        offset = T.node_offset[l];
+        tiles_x = T.tiles_x[l];
+    }
 };
 
 struct HostTables {
@@ -175,6 +180,8 @@ int emul_render(const f3d_terrain_ref_desc *d, uint32_t row_begin, uint32_t row_
         uint32_t frames = 0;
         float variance = INFINITY;
         bool converged = false;
+        const char *sm_env = getenv("F3D_EMUL_STATE_MACHINE");
+        const bool sm = sm_env && sm_env[0] == '1';
         while (frames < d->max_frames) {
             P.frame_index = frames;
             P.res_out = res[frames & 1u].data();
@@ -185,7 +192,9 @@ int emul_render(const f3d_terrain_ref_desc *d, uint32_t row_begin, uint32_t row_
             for (long y = row_begin; y < (long)row_end; y++) {
                 ArrayPending pend;
                 for (uint32_t x = 0; x < W; x++) {
-                    const float v = frame_pixel(P, x, (uint32_t)y, pend);
+                    HostWave wave;
+                    const float v = sm ? frame_pixel_sm(P, x, (uint32_t)y, true, pend, wave)
+                                       : frame_pixel(P, x, (uint32_t)y, pend);
                     if (!f_finite(v)) nonfinite = true;
                     else vmax_m2 = f_max(vmax_m2, f_max(v, 0.0f));
                 }

@@ -58,6 +58,28 @@ def test_hip_matches_oracle_bit_exact(f3d, oracle, size, spp, frames, step):
     _same(got, want)
 
 
+@pytest.mark.parametrize("variant", [0, 1, 8, 16, 32, 64])
+def test_every_kernel_variant_is_bit_identical(f3d, oracle, variant):
+    """The nested-loop kernel and the ray-state-machine kernels (any gate width) must agree
+    with the oracle bit for bit -- with and without a mesh in the scene."""
+    from forge3d_amd.session import TerrainSession
+
+    dem = scenes.golden_dem()
+    quad_v = np.array([[-18.0, 22.0, -6.0], [18.0, 22.0, -6.0], [18.0, 40.0, -6.0], [-18.0, 40.0, -6.0]], np.float32)
+    quad_i = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+    for extra in ({}, {"mesh_vertices": quad_v, "mesh_indices": quad_i}):
+        kw = scenes.fixed_frames(scenes.scene_kwargs(dem), 5, spp=3, **extra)
+        want = oracle.render(dem, 112, 80, scenes.CAM, **kw)
+        with TerrainSession(dem, 112, 80, scenes.CAM, kernel_variant=variant, **kw) as s:
+            s.enqueue_frames(0, 5, True)
+            m2, bad = s.window_stats()
+            got = s.resolve(5)
+        assert not bad
+        assert np.float32(max(0.0, m2) / np.float32(4.0)) == np.float32(want["variance"])
+        for key in ("rgba", "albedo", "normal", "depth"):
+            assert np.array_equal(got[key], want[key], equal_nan=True), (variant, key)
+
+
 def test_ragged_nonsquare_dem_and_sun_colour(f3d, oracle):
     dem = scenes.golden_dem(2)[:37, :100].copy()  # 100 x 37 texels -> 128 x 64 padded pyramid
     kw = scenes.fixed_frames(scenes.scene_kwargs(dem), 6, spp=2, sun_color=(0.2, 0.3, 1.5), seed=12345,
@@ -201,8 +223,12 @@ def test_terrain_hits_and_aov_consistency(reference):
     assert np.allclose(albedo[hits], np.array(scenes.ALBEDO), atol=2e-3)
     assert np.allclose(albedo[~hits], 0.0, atol=1e-6)
     assert np.isnan(depth[~hits]).all()
-    # sky pixels: env 0.35 -> Reinhard -> f16 -> 66
-    assert (out["rgba"][~hits][:, :3] == 66).all()
+    # sky pixels: env 0.35 -> Reinhard -> f16 -> 66; a centre-ray miss
+    # can still catch terrain with jittered samples along the silhouette
+    sky66 = (out["rgba"][~hits][:, :3] == 66).all(-1)
+    assert sky66.mean() > 0.97
+    golden = scenes.golden_png()
+    assert abs((golden[..., :3] == 66).all(-1).mean() - (out["rgba"][..., :3] == 66).all(-1).mean()) < 2e-3
 
 
 def test_normals_match_analytic_gradient(reference):
