@@ -90,8 +90,9 @@ __device__ __forceinline__ void publish_window_stats(const FrameParams &P, bool 
 
 // VARIANT 0: reference-shaped nested sample loop.  VARIANT n > 0: per-lane ray state
 // machine whose transition gate waits for n lanes (n = 64: fully synchronous).
-template <int VARIANT>
-__global__ __launch_bounds__(kWave) void k_frame(const FrameParams P) {
+// MIN_WAVES: waves per SIMD the register allocator must leave room for (1 = unconstrained).
+template <int VARIANT, int MIN_WAVES = 1>
+__global__ __launch_bounds__(kWave, MIN_WAVES) void k_frame(const FrameParams P) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[kLdsWords];
     LdsPending pend = make_pending(lds, P.terrain);
     uint32_t gx = 0u, gy = 0u;
@@ -170,6 +171,9 @@ hipError_t launch_frame(const FrameParams &p, int variant, hipStream_t stream) {
         case 16: hipLaunchKernelGGL(k_frame<16>, grid, block, 0, stream, p); break;
         case 32: hipLaunchKernelGGL(k_frame<32>, grid, block, 0, stream, p); break;
         case 64: hipLaunchKernelGGL(k_frame<64>, grid, block, 0, stream, p); break;
+        case 104: hipLaunchKernelGGL((k_frame<0, 4>), grid, block, 0, stream, p); break;
+        case 105: hipLaunchKernelGGL((k_frame<0, 5>), grid, block, 0, stream, p); break;
+        case 106: hipLaunchKernelGGL((k_frame<0, 6>), grid, block, 0, stream, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -258,9 +258,14 @@ F3D_HD void trace_begin(const TerrainDev &T, const RayCtx &r, bool any_hit, Trac
     st.done = false;
 }
 
-template <class Pending>
+// MODE 0: visit whatever node is next.  MODE 1: inner nodes only (the caller guarantees the
+// next node is not a fat leaf, or that a sibling has to be popped first).  MODE 2: the fat
+// leaf that is ready (st.have && st.level == 1).  Modes 1/2 let trace_terrain run all lanes
+// of a wave through their inner-node descents together and then through their leaf solves
+// together ("while-while"), instead of serialising the two divergent bodies every step.
+template <int MODE = 0, class Pending>
 F3D_HD void trace_step(const TerrainDev &T, const RayCtx &r, bool any_hit, TraceState &st, Pending &pend) {
-    if (!st.have) {
+    if (MODE != 2 && !st.have) {
         if (st.remaining == 0u) {
             st.done = true;
             return;
@@ -288,13 +293,17 @@ F3D_HD void trace_step(const TerrainDev &T, const RayCtx &r, bool any_hit, Trace
         st.t_lo = f_max(f_max(f_min(ax, bx), f_min(az, bz)), r.tmin);
         st.t_hi = f_min(f_min(f_max(ax, bx), f_max(az, bz)), f_min(r.tmax, st.res.t));
         if (st.t_lo > st.t_hi) return;  // culled; next step pops again
+        if (MODE == 1 && l == 1u) {     // a fat leaf surfaced: leave it for the leaf phase
+            st.have = true;
+            return;
+        }
     }
     st.have = false;
     const uint32_t level = st.level, nx = st.nx, nz = st.nz;
     const uint32_t cl = level - 1u;
     const ChildSlabs k = child_slabs(T, r, level, nx, nz, st.t_lo, st.t_hi);
 
-    if (cl == 0u) {
+    if (MODE != 1 && (MODE == 2 || cl == 0u)) {
         // ---- fat leaf: solve the queued cells near-to-far (:306-318) ----
         const uint32_t g = child_group_index(nx, nz, T.tiles_x[0]);
         const LeafRec h0 = T.leaves[g], h1 = T.leaves[g + 1u], h2 = T.leaves[g + 2u], h3 = T.leaves[g + 3u];
@@ -366,7 +375,12 @@ template <class Pending>
 F3D_HD TraceHit trace_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit, Pending &pend) {
     TraceState st;
     trace_begin(T, r, any_hit, st, pend);
-    while (!st.done) trace_step(T, r, any_hit, st, pend);
+    while (!st.done) {
+        // all lanes descend through inner nodes until each holds a fat leaf (or is done) ...
+        while (!st.done && !(st.have && st.level == 1u)) trace_step<1>(T, r, any_hit, st, pend);
+        // ... then the lanes that hold one solve their leaves together
+        if (!st.done) trace_step<2>(T, r, any_hit, st, pend);
+    }
     return st.res;
 }
 

@@ -483,6 +483,8 @@ static inline float plane(float origin, uint32_t c, float spacing) {
     return fmaf((float)c, spacing, origin);
 }
 
+static float span_root(float d0, float dm, float d1, int any_hit);
+
 /* terrain_leaf_intersect, :167-235 */
 static inline int leaf_intersect(const scene_t *sc, const ray_t *ray, uint32_t cx, uint32_t cz,
                                  float t0, float t1, float c2, int any_hit, float *t_out) {
@@ -499,10 +501,23 @@ static inline int leaf_intersect(const scene_t *sc, const ray_t *ray, uint32_t c
         float hh = mixf(mixf(h[0], h[1], u), mixf(h[2], h[3], u), v);
         d3[i] = curved_height(ray, t, c2) - hh;
     }
-    float c = d3[0];
-    float a = 2.0f * d3[2] + 2.0f * d3[0] - 4.0f * d3[1];
-    float b = d3[2] - d3[0] - a;
+    float s_hit = span_root(d3[0], d3[1], d3[2], any_hit);
+    if (s_hit <= 1.0f) {
+        float t = fmaf(s_hit, t1 - t0, t0);
+        if (t > ray->tmin && t < ray->tmax) {
+            *t_out = t;
+            return 1;
+        }
+    }
+    return 0;
+}
 
+/* The quadratic part of terrain_leaf_intersect (:197-226): smallest root s in [0,1] of the
+ * parabola through d(0)=d0, d(1/2)=dm, d(1)=d1, or 1e30 when there is none. */
+static float span_root(float d0, float dm, float d1, int any_hit) {
+    float c = d0;
+    float a = 2.0f * d1 + 2.0f * d0 - 4.0f * dm;
+    float b = d1 - d0 - a;
     float s_hit = 1e30f;
     if (any_hit && c <= 0.0f) {
         s_hit = 0.0f;
@@ -524,14 +539,10 @@ static inline int leaf_intersect(const scene_t *sc, const ray_t *ray, uint32_t c
             else if (r1 >= 0.0f && r1 <= 1.0f) s_hit = r1;
         }
     }
-    if (s_hit <= 1.0f) {
-        float t = fmaf(s_hit, t1 - t0, t0);
-        if (t > ray->tmin && t < ray->tmax) {
-            *t_out = t;
-            return 1;
-        }
-    }
-    return 0;
+    return s_hit;
+}
+int f3do_deviation_span_hit(float d0, float dm, float d1, int32_t any_hit) {
+    return span_root(d0, dm, d1, any_hit != 0) <= 1.0f;
 }
 
 /* terrain_normal_at, :239-248 */

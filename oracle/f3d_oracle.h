@@ -117,6 +117,11 @@ int f3do_effective_radius_m(int32_t earth_model, double latitude_deg, double sph
                             double temperature_c, double k, double azimuth_deg,
                             double *radius_out, char *err, size_t errlen);
 
+/* The leaf quadratic alone: does the parabola through d(0)=d0, d(1/2)=dm, d(1)=d1 have a
+ * root in [0,1] (or, for any_hit, start at/below the surface)?  Mirrors the reference's
+ * unit-test helper deviation_span_hit (terrain_heightfield.rs:722-729). */
+int f3do_deviation_span_hit(float d0, float dm, float d1, int32_t any_hit);
+
 /* f32 -> f16 (RNE) -> f32 round trip, exposed for tests. */
 float f3do_f16_round(float v);
 

@@ -309,7 +309,7 @@ def test_native_trust_boundary_validation(f3d):
             _native.hybrid_render_terrain_reference(dem, 64, 64, dict(scenes.CAM), **kw)
     for cam, needle in [({**scenes.CAM, "look_at": scenes.CAM["origin"]}, "look_at"),
                         ({**scenes.CAM, "fov_y": 0.0}, "fov"),
-                        ({**scenes.CAM, "up": (0.0, -30.0, -90.0)}, "parallel"),
+                        ({**scenes.CAM, "look_at": (0.0, 35.0, 0.0), "up": (0.0, 0.0, 1.0)}, "parallel"),
                         ({**scenes.CAM, "exposure": 0.0}, "exposure")]:
         with pytest.raises(RuntimeError, match=needle):
             _native.hybrid_render_terrain_reference(dem, 64, 64, cam, **base)

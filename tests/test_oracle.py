@@ -1,0 +1,299 @@
+"""Pinning the CPU oracle (oracle/f3d_oracle.c) against the reference's own evidence:
+
+* the committed golden image of the locked scene with the reference's gate
+  (tests/test_hybrid_terrain_pt.py:818-859: SSIM >= 0.995, mean-abs <= 2.0);
+* the Rust known-answer tests of the traversal restated here
+  (src/path_tracing/hybrid_compute/terrain_heightfield.rs:516-616, :1971-2127);
+* src/geo/refraction.rs:147-186 and render_terrain.rs:1441-1498.
+No GPU involved.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import scenes
+from metrics import mean_abs, ssim
+from oracle import oracle
+
+
+@pytest.fixture(scope="module")
+def golden_render():
+    dem = scenes.golden_dem()
+    return dem, oracle.render(dem, scenes.SIZE, scenes.SIZE, scenes.CAM, **scenes.scene_kwargs(dem))
+
+
+def test_oracle_passes_the_reference_golden_gate(golden_render):
+    _, out = golden_render
+    golden = scenes.golden_png()
+    assert golden.shape == (256, 256, 4)
+    score = ssim(out["rgba"][..., :3], golden[..., :3], data_range=255.0)
+    drift = mean_abs(out["rgba"][..., :3], golden[..., :3])
+    print(f"\noracle vs reference golden: SSIM {score:.6f}, mean abs {drift:.4f}, frames {out['frames']}")
+    assert score >= 0.995
+    assert drift <= 2.0
+    assert out["converged"] and out["variance"] < 1e-3 and out["frames"] % 32 == 0
+
+
+def test_oracle_sky_value_and_coverage_match_the_golden(golden_render):
+    """env 0.35 -> Reinhard 0.35/1.35 -> f16 -> u8 = 66, on the same 42.3 % of pixels."""
+    _, out = golden_render
+    golden = scenes.golden_png()
+    ours = (out["rgba"][..., :3] == 66).all(-1)
+    theirs = (golden[..., :3] == 66).all(-1)
+    assert abs(ours.mean() - theirs.mean()) < 1e-3
+    assert (ours ^ theirs).mean() < 2e-3
+    assert (out["rgba"][..., 3] == 255).all()
+
+
+def test_oracle_aov_consistency(golden_render):
+    """reference test_terrain_hits_and_aov_consistency (:290-310)."""
+    _, out = golden_render
+    depth, normal, albedo = out["depth"], out["normal"], out["albedo"]
+    hits = np.isfinite(depth)
+    assert hits.mean() > 0.3
+    assert depth[hits].min() > 1.0 and depth[hits].max() < 85.0 + 200.0 + 10.0
+    assert np.abs(np.linalg.norm(normal[hits], axis=-1) - 1.0).max() < 1e-2
+    assert normal[hits][:, 1].mean() > 0.5
+    assert np.allclose(albedo[hits], np.array(scenes.ALBEDO), atol=2e-3)
+    assert (albedo[~hits] == 0).all() and np.isnan(depth[~hits]).all()
+
+
+# ---- build_minmax_mips KATs (terrain_heightfield.rs:522-612) -------------------------------
+def _ramp(w, h):
+    i = np.arange(w * h)
+    return ((i % w).astype(np.float32) * np.float32(0.5) + (i // w).astype(np.float32) * np.float32(0.25)).reshape(h, w)
+
+
+def test_minmax_invariant_per_node():
+    levels, _ = oracle.build_minmax_mips(_ramp(256, 256))
+    for lvl in levels:
+        real = np.isfinite(lvl[..., 0]) | np.isfinite(lvl[..., 1])
+        assert (lvl[..., 0][real] <= lvl[..., 1][real]).all()
+
+
+def test_mip_count_and_dims():
+    levels, dims = oracle.build_minmax_mips(_ramp(256, 256))
+    assert dims[0] == (256, 256) and dims[-1] == (1, 1) and len(levels) == 9
+    levels, dims = oracle.build_minmax_mips(_ramp(100, 37))
+    assert dims[0] == (128, 64) and dims[-1] == (1, 1) and len(levels) == 8
+
+
+def test_parent_covers_children():
+    levels, dims = oracle.build_minmax_mips(_ramp(64, 64))
+    for l in range(1, len(levels)):
+        (pw, ph), (cw, ch) = dims[l], dims[l - 1]
+        for y in range(ph):
+            for x in range(pw):
+                for dy in (0, 1):
+                    for dx in (0, 1):
+                        c = levels[l - 1][min(2 * y + dy, ch - 1), min(2 * x + dx, cw - 1)]
+                        assert levels[l][y, x, 0] <= c[0] and levels[l][y, x, 1] >= c[1]
+
+
+def test_root_covers_full_range_and_flat_dem():
+    h = _ramp(33, 17)
+    levels, _ = oracle.build_minmax_mips(h)
+    assert levels[-1][0, 0, 0] == h.min() and levels[-1][0, 0, 1] == h.max()
+    levels, _ = oracle.build_minmax_mips(np.full((16, 16), 5.0, np.float32))
+    for lvl in levels:
+        real = np.isfinite(lvl[..., 0])
+        assert (lvl[real] == 5.0).all()
+    assert tuple(levels[-1][0, 0]) == (5.0, 5.0)
+    # sentinel padding is (+inf, -inf)
+    levels, _ = oracle.build_minmax_mips(_ramp(100, 37))
+    assert levels[0][40, 0, 0] == np.inf and levels[0][40, 0, 1] == -np.inf
+
+
+def test_degenerate_dems_error():
+    with pytest.raises(oracle.OracleError, match="at least 2x2"):
+        oracle.build_minmax_mips(np.ones((1, 1), np.float32))
+    with pytest.raises(oracle.OracleError, match="non-finite"):
+        oracle.build_minmax_mips(np.full((2, 2), np.nan, np.float32))
+
+
+# ---- leaf semantics (terrain_heightfield.rs:1971-2000) -----------------------------------
+def test_leaf_any_hit_semantics():
+    hit = oracle.lib().f3do_deviation_span_hit
+    hit.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int32]
+    hit.restype = C.c_int
+    assert hit(-0.000061035, -0.6636963, -1.3182983, 1) == 1   # captured NVIDIA boundary-rounding case
+    assert hit(-1.0, -2.0, -3.0, 0) == 0                        # below entry, no crossing: not a primary hit
+    assert hit(-1.0, 0.0, 1.0, 0) == 1                          # below entry, upward exit keeps the exact root
+    assert hit(1.0, 2.0, 3.0, 1) == 0
+    assert hit(1.0, -0.5, 1.0, 0) == 1                          # dips through the surface mid-span
+
+
+# ---- f64 brute force vs min-max descent (terrain_heightfield.rs:659-821, :2078-2127) -------
+def _brute_hits(heights, rays, inv_two_r):
+    """Independent f64 cell-by-cell march: expand the bilinear patch and the curved ray
+    analytically in every crossed cell and look for a root of the exact quadratic."""
+    h = heights.astype(np.float64)
+    S = 500.0
+    o = rays[:, 0:3].astype(np.float64)
+    d = rays[:, 4:7].astype(np.float64)
+    n = len(rays)
+    extent = 255 * S
+
+    def axis(o_, d_):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            a, b = (0.0 - o_) / d_, (extent - o_) / d_
+        lo, hi = np.minimum(a, b), np.maximum(a, b)
+        par = np.abs(d_) < 1e-12
+        inside = (o_ >= 0.0) & (o_ <= extent)
+        lo = np.where(par, np.where(inside, -np.inf, np.inf), lo)
+        hi = np.where(par, np.where(inside, np.inf, -np.inf), hi)
+        return lo, hi
+
+    xl, xh = axis(o[:, 0], d[:, 0])
+    zl, zh = axis(o[:, 2], d[:, 2])
+    enter, exit_ = np.maximum(xl, zl), np.minimum(xh, zh)
+    alive = enter <= exit_
+    t = np.maximum(enter, 1e-3)
+    end = np.minimum(exit_, 200_000.0)
+    alive &= t <= end
+    hit = np.zeros(n, bool)
+    hsq = d[:, 0] ** 2 + d[:, 2] ** 2
+
+    def root_in_span(a, b, c, t0, t1):
+        lin = np.abs(a) < 1e-15
+        with np.errstate(divide="ignore", invalid="ignore"):
+            r_lin = -c / b
+            disc = b * b - 4 * a * c
+            sq = np.sqrt(np.maximum(disc, 0.0))
+            q = -0.5 * (b + np.copysign(sq, b))
+            r1 = q / a
+            r2 = np.where(np.abs(q) < 1e-30, np.inf, c / q)
+        ok_lin = lin & (np.abs(b) >= 1e-15) & (r_lin >= t0) & (r_lin <= t1)
+        ok_quad = ~lin & (disc >= 0) & (((r1 >= t0) & (r1 <= t1)) | ((r2 >= t0) & (r2 <= t1)))
+        return ok_lin | ok_quad
+
+    for _ in range(600):
+        if not alive.any():
+            break
+        idx = np.nonzero(alive)[0]
+        ti, ei = t[idx], end[idx]
+        probe = np.minimum(ti + 1e-5, ei)
+        x = o[idx, 0] + probe * d[idx, 0]
+        z = o[idx, 2] + probe * d[idx, 2]
+        cx = np.clip(np.floor(x / S), 0, 254).astype(int)
+        cz = np.clip(np.floor(z / S), 0, 254).astype(int)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            nx = np.where(d[idx, 0] > 0, ((cx + 1) * S - o[idx, 0]) / d[idx, 0],
+                          np.where(d[idx, 0] < 0, (cx * S - o[idx, 0]) / d[idx, 0], np.inf))
+            nz = np.where(d[idx, 2] > 0, ((cz + 1) * S - o[idx, 2]) / d[idx, 2],
+                          np.where(d[idx, 2] < 0, (cz * S - o[idx, 2]) / d[idx, 2], np.inf))
+        nxt = np.minimum(np.minimum(nx, nz), ei)
+        h00 = h[cz, cx]
+        hx = h[cz, cx + 1] - h00
+        hz = h[cz + 1, cx] - h00
+        hxz = h[cz + 1, cx + 1] - h00 - hx - hz
+        u0 = o[idx, 0] / S - cx
+        v0 = o[idx, 2] / S - cz
+        du, dv = d[idx, 0] / S, d[idx, 2] / S
+        ta = hxz * du * dv
+        tb = hx * du + hz * dv + hxz * (u0 * dv + v0 * du)
+        tc = h00 + hx * u0 + hz * v0 + hxz * u0 * v0
+        found = root_in_span(hsq[idx] * inv_two_r - ta, d[idx, 1] - tb, o[idx, 1] - tc, ti, nxt)
+        hit[idx[found]] = True
+        alive[idx[found]] = False
+        done = nxt >= ei
+        alive[idx[done & ~found]] = False
+        t[idx] = nxt + 1e-7
+    return hit
+
+
+def test_descent_is_conservative_vs_f64_brute_force():
+    heights, rays = scenes.proof_rays()
+    inv2r = float(np.float32(1.0 / 14_650_000.0))
+    got = oracle.terrain_trace_batch(heights, rays, spacing=(500.0, 500.0), inv_two_r_prime=inv2r,
+                                     curvature_enabled=True, any_hit=True, apply_curvature=True)["hit"].astype(bool)
+    brute = _brute_hits(heights, rays, inv2r)
+    rnd_b, rnd_g = brute[:10_000], got[:10_000]
+    false_misses = int((rnd_b & ~rnd_g).sum())
+    false_hit_rate = float((~rnd_b & rnd_g).sum()) / 10_000.0
+    mask_b, mask_g = brute[10_000:], got[10_000:]
+    agreement = float((mask_b == mask_g).mean())
+    print(f"\n10000 rays: false misses {false_misses}, false-hit rate {false_hit_rate:.5f}; "
+          f"shadow-mask agreement {agreement:.5f} (hit fraction {mask_b.mean():.3f})")
+    assert false_misses == 0
+    assert false_hit_rate < 0.001
+    assert agreement >= 0.999
+
+
+def test_captured_physical_mask_ray_is_a_hit():
+    """terrain_heightfield.rs:1971-1989: the ray NVIDIA Vulkan once missed."""
+    heights = scenes.curvature_fixture()
+    ray = np.array([[125_750.0, 870.54614, 67_750.0, 1e-3, 0.79859173, 0.010471784, 0.60178196, 200_000.0]], np.float32)
+    inv2r = float(np.float32(6.8259382e-8))
+    assert _brute_hits(heights, ray, inv2r)[0]
+    out = oracle.terrain_trace_batch(heights, ray, spacing=(500.0, 500.0), inv_two_r_prime=inv2r,
+                                     curvature_enabled=True, any_hit=True, apply_curvature=True)
+    assert out["hit"][0] == 1
+
+
+def test_curvature_drop_f32_vs_f64():
+    """terrain_heightfield.rs:2072-2076"""
+    distance, inv_two_r = 100_000.0, 1.0 / 14_650_000.0
+    assert abs(distance * distance * inv_two_r - float(np.float32(distance) ** 2 * np.float32(inv_two_r))) < 1.0
+
+
+# ---- geo::refraction (src/geo/refraction.rs:147-186) --------------------------------------
+def test_effective_radius_models():
+    r0 = oracle.effective_radius_m("ellipsoid", "none", 0.0, latitude_deg=45.0)
+    r90 = oracle.effective_radius_m("ellipsoid", "none", 90.0, latitude_deg=45.0)
+    assert r90 > r0
+    assert oracle.effective_radius_m("ellipsoid", "effective_radius", 0.0, latitude_deg=45.0, k=0.13) > r0
+    with pytest.raises(oracle.OracleError, match="flat earth"):
+        oracle.effective_radius_m("flat", "effective_radius", 0.0, k=1.0)
+    with pytest.raises(oracle.OracleError, match="flat earth"):
+        oracle.effective_radius_m("flat", "bennett", 0.0)
+    assert np.isinf(oracle.effective_radius_m("flat", "none", 0.0))
+    # default model of the hot path: ellipsoid + bennett at the equator, sun azimuth 225
+    r = oracle.effective_radius_m("ellipsoid", "bennett", 225.0)
+    assert abs(0.5 / r - 6.8e-8) < 0.2e-8  # inv_two_r_prime ~ 6.8e-8
+    with pytest.raises(oracle.OracleError, match="less than 1"):
+        oracle.effective_radius_m("sphere", "effective_radius", 0.0, k=1.5)
+
+
+# ---- storage / transcendental helpers -------------------------------------------------------
+def test_f16_round_trip_matches_ieee_half():
+    rng = np.random.default_rng(0)
+    vals = np.concatenate([rng.uniform(-2, 2, 4000), rng.uniform(-1e-6, 1e-6, 500), 10.0 ** rng.uniform(-9, 5, 1500),
+                           [0.0, 65504.0, 65519.9, 65520.0, 1e9, 5.96e-8, 2.98e-8, 2.9803e-8, 6.1e-5, 0.35 / 1.35]])
+    f = oracle.lib().f3do_f16_round
+    for v in vals.astype(np.float32):
+        want = np.float32(np.float16(v))
+        got = np.float32(f(float(v)))
+        assert got == want or (np.isinf(got) and np.isinf(want)), (v, got, want)
+
+
+def test_deterministic_sincos_accuracy():
+    s, c = C.c_float(), C.c_float()
+    f = oracle.lib().f3do_sincos_2pi
+    worst = 0.0
+    for u in np.linspace(0.0, 1.0, 4001, dtype=np.float32):
+        f(float(u), C.byref(s), C.byref(c))
+        a = 2.0 * np.pi * float(u)
+        worst = max(worst, abs(s.value - np.sin(a)), abs(c.value - np.cos(a)))
+    assert worst < 4e-7  # WGSL allows 2^-11 absolute error for sin/cos
+
+
+def test_zero_sun_colour_disables_direct_light():
+    """render_terrain.rs:1461-1472 semantics through the renderer."""
+    dem = scenes.golden_dem(4)
+    kw = scenes.fixed_frames(scenes.scene_kwargs(dem), 8)
+    lit = oracle.render(dem, 64, 64, scenes.CAM, **kw)
+    dark = oracle.render(dem, 64, 64, scenes.CAM, **{**kw, "sun_color": (0.0, 0.0, 0.0)})
+    assert dark["rgba"][..., :3].astype(float).mean() < lit["rgba"][..., :3].astype(float).mean()
+
+
+def test_not_converged_is_an_error_never_an_image():
+    dem = scenes.golden_dem(4)
+    kw = {**scenes.scene_kwargs(dem), "max_frames": 8, "min_frames": 2, "variance_threshold": 1e-12}
+    with pytest.raises(oracle.OracleError, match="did not converge"):
+        oracle.render(dem, 64, 64, scenes.CAM, **kw)
+    with pytest.raises(oracle.OracleError, match="did not converge"):  # a 1-frame window has no variance
+        oracle.render(dem, 32, 32, scenes.CAM, **scenes.fixed_frames(scenes.scene_kwargs(dem), 1))
