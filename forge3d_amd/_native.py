@@ -114,6 +114,14 @@ def lib() -> C.CDLL:
                 f"forge3d_amd: HIP library {path} is missing -- run `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc --offload-arch=gfx950); there is no CPU fallback"
             )
+        # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64; if this
+        # library pulled in /opt/rocm's copy first, a later `import torch` would find no GPUs.
+        # Importing torch first makes both resolve to the same runtime (torch is plumbing for
+        # device memory / streams / RCCL here, not part of the render path).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(str(path))
         for name, restype, argtypes in ABI:
             fn = getattr(L, name)  # AttributeError if the export is missing

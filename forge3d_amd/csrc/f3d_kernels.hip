@@ -44,8 +44,25 @@ __device__ __forceinline__ bool tile_pixel(const FrameParams &P, uint32_t &gx, u
     const uint32_t rows = P.row_end - P.row_begin;
     const uint32_t tiles_x = (P.cam.width + 7u) >> 3, tiles_y = (rows + 7u) >> 3;
     const uint32_t ntiles = tiles_x * tiles_y;
-    const uint32_t per_xcd = (ntiles + kNumXcd - 1u) / kNumXcd;
-    const uint32_t tile = (blockIdx.x % kNumXcd) * per_xcd + blockIdx.x / kNumXcd;
+    // Workgroup b is observed to run on XCD b % 8.  tile_map picks how tiles are dealt to XCDs:
+    //   1  tile id = workgroup id (consecutive tiles on different XCDs)
+    //   2  tile ROWS dealt round-robin to XCDs (row r -> XCD r % 8) -- the default: the load
+    //      balance of 1 with each XCD's L2 still seeing whole rows of coherent rays
+    //   3  contiguous image bands per XCD (best L2 locality, but a sky band idles its XCD:
+    //      measured 1.77x slower on the headline scene)
+    uint32_t tile;
+    if (P.tile_map == 1u) {
+        tile = blockIdx.x;
+    } else if (P.tile_map == 2u) {
+        const uint32_t xcd = blockIdx.x % kNumXcd, i = blockIdx.x / kNumXcd;
+        const uint32_t rows_per_xcd = (tiles_y + kNumXcd - 1u) / kNumXcd;
+        const uint32_t ty = (i / tiles_x) * kNumXcd + xcd;
+        if (i >= rows_per_xcd * tiles_x || ty >= tiles_y) return false;
+        tile = ty * tiles_x + (i % tiles_x);
+    } else {  // 3 (and anything else): contiguous bands
+        const uint32_t per_xcd = (ntiles + kNumXcd - 1u) / kNumXcd;
+        tile = (blockIdx.x % kNumXcd) * per_xcd + blockIdx.x / kNumXcd;
+    }
     if (tile >= ntiles) return false;
     const uint32_t lane = threadIdx.x;
     gx = (tile % tiles_x) * 8u + (lane & 7u);
@@ -158,14 +175,16 @@ __global__ void k_level_build(const LevelBuildParams B) {
 // ---- launchers ---------------------------------------------------------------------
 static inline uint32_t frame_grid(const FrameParams &p) {
     const uint32_t rows = p.row_end - p.row_begin;
-    const uint32_t ntiles = ((p.cam.width + 7u) >> 3) * ((rows + 7u) >> 3);
-    return ((ntiles + kNumXcd - 1u) / kNumXcd) * kNumXcd;
+    const uint32_t tiles_x = (p.cam.width + 7u) >> 3, tiles_y = (rows + 7u) >> 3;
+    if (p.tile_map == 2u) return ((tiles_y + kNumXcd - 1u) / kNumXcd) * tiles_x * kNumXcd;
+    return ((tiles_x * tiles_y + kNumXcd - 1u) / kNumXcd) * kNumXcd;
 }
 
 hipError_t launch_frame(const FrameParams &p, int variant, hipStream_t stream) {
     const dim3 grid(frame_grid(p)), block(kWave);
-    switch (variant) {
-        case 0: hipLaunchKernelGGL(k_frame<0>, grid, block, 0, stream, p); break;
+    switch (variant % 1000) {
+        case 0: hipLaunchKernelGGL((k_frame<0, 4>), grid, block, 0, stream, p); break;  // default
+        case 101: hipLaunchKernelGGL((k_frame<0, 1>), grid, block, 0, stream, p); break;
         case 1: hipLaunchKernelGGL(k_frame<1>, grid, block, 0, stream, p); break;
         case 8: hipLaunchKernelGGL(k_frame<8>, grid, block, 0, stream, p); break;
         case 16: hipLaunchKernelGGL(k_frame<16>, grid, block, 0, stream, p); break;

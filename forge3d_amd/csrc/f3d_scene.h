@@ -123,6 +123,7 @@ struct FrameParams {
     const float4 *gbuffer_n;        // xyz = centre-ray normal ((0,0,1) on sky), w = hit code
     uint32_t *stats;                // [0] max m2 bits, [1] nonfinite, [2] any_valid, [3] bad
     uint32_t collect_stats;         // this frame closes a convergence window
+    uint32_t tile_map;              // workgroup -> tile mapping (f3d_kernels.hip tile_pixel)
 };
 
 }  // namespace f3d

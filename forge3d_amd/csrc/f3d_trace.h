@@ -375,12 +375,17 @@ template <class Pending>
 F3D_HD TraceHit trace_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit, Pending &pend) {
     TraceState st;
     trace_begin(T, r, any_hit, st, pend);
+#if defined(F3D_TRACE_WHILE_WHILE)
+    // Measured on MI355X (profiles/README.md): batching the leaf solves ("while-while") is
+    // 1.5x SLOWER than visiting whatever comes next -- lanes holding a leaf idle through the
+    // other lanes' descents -- so it is kept only as an A/B switch.
     while (!st.done) {
-        // all lanes descend through inner nodes until each holds a fat leaf (or is done) ...
         while (!st.done && !(st.have && st.level == 1u)) trace_step<1>(T, r, any_hit, st, pend);
-        // ... then the lanes that hold one solve their leaves together
         if (!st.done) trace_step<2>(T, r, any_hit, st, pend);
     }
+#else
+    while (!st.done) trace_step<0>(T, r, any_hit, st, pend);
+#endif
     return st.res;
 }
 
