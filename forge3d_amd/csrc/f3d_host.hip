@@ -175,7 +175,9 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
     // variant = kernel variant + 1000 * tile map; map 0 = default (tile rows dealt round-robin
     // to the XCDs: 1.77x faster than contiguous bands on the headline scene, whose sky bands
     // left whole XCDs idle -- profiles/README.md)
-    P.tile_map = s.variant >= 1000 ? (uint32_t)(s.variant / 1000) : 2u;
+    P.tile_map = (s.variant / 1000) % 10 ? (uint32_t)((s.variant / 1000) % 10) : 2u;
+    // + 10000 * leaf quorum (f3d_trace.h "leaf gating"); 0 = default
+    P.terrain.leaf_quorum = s.variant / 10000 ? (uint32_t)(s.variant / 10000) : kDefaultLeafQuorum;
 
     // per-pixel state
     const size_t px = (size_t)s.rows * s.width;

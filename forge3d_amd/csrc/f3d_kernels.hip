@@ -24,6 +24,13 @@ struct LdsPending {
     const uint32_t *table;  // lds + kMaxLevels * kWave: {node_offset, tiles_x} per level
     __device__ __forceinline__ void put(uint32_t level, uint32_t word) { col[level * kWave] = word; }
     __device__ __forceinline__ uint32_t get(uint32_t level) const { return col[level * kWave]; }
+    __device__ __forceinline__ void note(int) const {}  // step-statistics hook (host emulator only)
+    // Called by every lane still traversing: may the lanes that hold a fat leaf solve it now?
+    uint32_t leaf_quorum;
+    __device__ __forceinline__ bool leaf_gate(bool at_leaf) const {
+        const unsigned long long leaf = __ballot(at_leaf), inner = __ballot(!at_leaf);
+        return (uint32_t)__popcll(leaf) >= leaf_quorum || inner == 0ull;
+    }
     __device__ __forceinline__ void level_entry(const TerrainDev &, uint32_t level, uint32_t &offset,
                                                 uint32_t &tiles_x) const {
         const uint2 e = *reinterpret_cast<const uint2 *>(table + 2u * level);
@@ -37,7 +44,7 @@ __device__ __forceinline__ LdsPending make_pending(uint32_t *lds, const TerrainD
         lds[kMaxLevels * kWave + 2 * threadIdx.x + 1] = T.tiles_x[threadIdx.x];
     }
     __syncthreads();
-    return LdsPending{lds + threadIdx.x, lds + kMaxLevels * kWave};
+    return LdsPending{lds + threadIdx.x, lds + kMaxLevels * kWave, T.leaf_quorum ? T.leaf_quorum : 1u};
 }
 
 __device__ __forceinline__ bool tile_pixel(const FrameParams &P, uint32_t &gx, uint32_t &gy) {

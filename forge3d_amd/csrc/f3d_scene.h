@@ -27,6 +27,7 @@ constexpr uint32_t kMaxLevels = 16;       // 8192-cell DEMs need 14
 constexpr uint32_t kRestirMCap = 512;     // TERRAIN_RESTIR_M_CAP, hybrid_terrain_traversal.wgsl:77
 constexpr uint32_t kWelfordWindow = 32;   // WELFORD_WINDOW, render_terrain.rs:236
 constexpr uint32_t kHaloRows = 3;         // spatial reuse radius R, pt_restir_spatial.wgsl:171
+constexpr uint32_t kDefaultLeafQuorum = 1;  // tuned on MI355X, see profiles/README.md
 
 struct alignas(16) LeafRec {
     float h00, h10, h01, h11;
@@ -59,6 +60,7 @@ struct TerrainDev {
     float origin_x, origin_z, spacing_x, spacing_z, inv_spacing_x, inv_spacing_z;
     float inv_two_r_prime;  // EarthCurvatureUniforms, terrain_heightfield.rs:42-84
     uint32_t curvature_enabled;
+    uint32_t leaf_quorum;   // lanes of a wave that must hold a fat leaf before the leaf body runs
 };
 
 struct MeshDev {  // HybridUniforms mesh part, hybrid_traversal.wgsl:9-17

@@ -220,7 +220,7 @@ struct TraceState {
 
 template <class Pending>
 F3D_HD void trace_begin(const TerrainDev &T, const RayCtx &r, bool any_hit, TraceState &st, Pending &pend) {
-    (void)pend;
+    pend.note(2 | (any_hit ? 1 : 0) | (r.c2 != 0.0f ? 4 : 0));  // statistics hook: a new ray starts
     st.res.hit = false;
     st.res.t = r.tmax;
     st.res.n = V3{0.0f, 0.0f, 0.0f};
@@ -305,6 +305,7 @@ F3D_HD void trace_step(const TerrainDev &T, const RayCtx &r, bool any_hit, Trace
 
     if (MODE != 1 && (MODE == 2 || cl == 0u)) {
         // ---- fat leaf: solve the queued cells near-to-far (:306-318) ----
+        pend.note(1);
         const uint32_t g = child_group_index(nx, nz, T.tiles_x[0]);
         const LeafRec h0 = T.leaves[g], h1 = T.leaves[g + 1u], h2 = T.leaves[g + 2u], h3 = T.leaves[g + 3u];
         uint32_t count;
@@ -338,6 +339,7 @@ F3D_HD void trace_step(const TerrainDev &T, const RayCtx &r, bool any_hit, Trace
     }
 
     // ---- inner node: test the four children now, keep the survivors (:320-369) ----
+    pend.note(0);
     uint32_t level_offset, level_tiles_x;
     pend.level_entry(T, cl, level_offset, level_tiles_x);
     const uint32_t g = level_offset + child_group_index(nx, nz, level_tiles_x);
@@ -382,6 +384,16 @@ F3D_HD TraceHit trace_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit
     while (!st.done) {
         while (!st.done && !(st.have && st.level == 1u)) trace_step<1>(T, r, any_hit, st, pend);
         if (!st.done) trace_step<2>(T, r, any_hit, st, pend);
+    }
+#elif defined(F3D_TRACE_LEAF_GATE)
+    // Leaf gating (A/B switch, measured SLOWER: 2312 -> 1603 Msamples/s as the quorum goes
+    // 1 -> 32, profiles/README.md): a lane holding a fat leaf waits until `leaf_quorum` lanes
+    // of its wave hold one too, or no lane has inner-node work left.
+    while (!st.done) {
+        const bool at_leaf = st.have && st.level == 1u;
+        const bool open = pend.leaf_gate(at_leaf);
+        if (!at_leaf) trace_step<1>(T, r, any_hit, st, pend);
+        else if (open) trace_step<2>(T, r, any_hit, st, pend);
     }
 #else
     while (!st.done) trace_step<0>(T, r, any_hit, st, pend);

@@ -17,8 +17,26 @@
 using namespace f3d;
 
 namespace {
+// Per-ray step log for the SIMT-utilisation model (tools/utilisation_model.py): kind
+// 2 = primary, 3 = IBL occlusion, 7 = sun shadow; bit k of leaf_mask = step k was a fat leaf.
+struct RayLog {
+    uint32_t kind, steps;
+    uint64_t leaf_mask;
+};
 struct ArrayPending {
     uint32_t w[kMaxLevels];
+    std::vector<RayLog> *log = nullptr;
+    void note(int kind) {
+        if (!log) return;
+        if (kind >= 2) {
+            log->push_back(RayLog{(uint32_t)kind, 0u, 0ull});
+        } else if (!log->empty()) {
+            RayLog &r = log->back();
+            if (kind == 1 && r.steps < 64u) r.leaf_mask |= 1ull << r.steps;
+            r.steps++;
+        }
+    }
+    bool leaf_gate(bool) const { return true; }  // one lane at a time: the gate is always open
     void put(uint32_t l, uint32_t v) { w[l] = v; }
     uint32_t get(uint32_t l) const { return w[l]; }
     void level_entry(const TerrainDev &T, uint32_t l, uint32_t &offset, uint32_t &tiles_x) const {
@@ -188,15 +206,32 @@ int emul_render(const f3d_terrain_ref_desc *d, uint32_t row_begin, uint32_t row_
             P.res_in = res[(frames & 1u) ^ 1u].data();
             float vmax_m2 = 0.0f;
             bool nonfinite = false;
+            // F3D_EMUL_RAYLOG=<file>: dump the per-ray step log of the LAST frame
+            const char *log_path = getenv("F3D_EMUL_RAYLOG");
+            const bool logging = log_path && log_path[0] && frames + 1 == d->max_frames;
+            std::vector<std::vector<RayLog>> pixel_logs(logging ? px : 0);
 #pragma omp parallel for schedule(dynamic, 4) reduction(max : vmax_m2) reduction(|| : nonfinite)
             for (long y = row_begin; y < (long)row_end; y++) {
                 ArrayPending pend;
                 for (uint32_t x = 0; x < W; x++) {
                     HostWave wave;
+                    if (logging) pend.log = &pixel_logs[(size_t)(y - row_begin) * W + x];
                     const float v = sm ? frame_pixel_sm(P, x, (uint32_t)y, true, pend, wave)
                                        : frame_pixel(P, x, (uint32_t)y, pend);
                     if (!f_finite(v)) nonfinite = true;
                     else vmax_m2 = f_max(vmax_m2, f_max(v, 0.0f));
+                }
+            }
+            if (logging) {
+                if (FILE *f = fopen(log_path, "wb")) {
+                    const uint32_t hdr[4] = {W, rows, P.spp, 0u};
+                    fwrite(hdr, 4, 4, f);
+                    for (const auto &pl : pixel_logs) {
+                        const uint32_t n = (uint32_t)pl.size();
+                        fwrite(&n, 4, 1, f);
+                        if (n) fwrite(pl.data(), sizeof(RayLog), n, f);
+                    }
+                    fclose(f);
                 }
             }
             frames++;
