@@ -142,9 +142,19 @@ def main():
                      + 16.0 * counts["n_hit"])
             per_launch = b_alg * samples_per_step / world
             achieved = per_launch / (kernel_ms * 1e-3) / 1e9
+            # HBM bytes per launch from the rocprofv3 PMC passes of the SAME command (committed
+            # under profiles/; bench.py cannot run the profiler itself): only quoted when the
+            # run matches the profiled configuration.
+            traffic = None
+            try:
+                pmc = json.loads((ROOT / "profiles" / "r01_pmc_traffic.json").read_text())
+                if world == 1 and (args.width, args.height, args.spp, args.dem) == (1920, 1080, 8, 2048):
+                    traffic = pmc["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
             result["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_frame",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_frame",
                 "kernel_ms": kernel_ms, "launches": launches, "bytes_per_sample": b_alg,
                 "per_sample_counts": counts,
             }

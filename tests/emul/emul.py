@@ -110,3 +110,82 @@ def build_minmax_mips(heights):
         levels.append(flat[off:off + pw * ph * 2].reshape(ph, pw, 2))
         off += pw * ph * 2
     return levels
+
+
+# ---- strip backend for forge3d_amd.distributed.StripRenderer (gloo CPU tests) -----------------
+class _EmulStripSession:
+    def __init__(self, handle, rows, width, stats):
+        self._h, self.rows, self.width, self._stats = handle, rows, width, stats
+
+    def enqueue_frames(self, first, count, collect=False):
+        L = lib()
+        for i in range(count):
+            last = collect and i + 1 == count
+            L.emul_session_frame(C.c_void_p(self._h), C.c_uint32(first + i), C.c_int32(1 if last else 0),
+                                 C.c_void_p(self._stats.data_ptr()))
+
+    def window_stats(self):
+        host = self._stats.numpy().astype(np.uint32)
+        return float(host[:1].view(np.float32)[0]), bool(host[1])
+
+    def resolve(self, frames):
+        rows, w = self.rows, self.width
+        rgba = np.zeros((rows, w, 4), np.uint8)
+        alb = np.zeros((rows, w, 3), np.float32)
+        nrm = np.zeros((rows, w, 3), np.float32)
+        dep = np.zeros((rows, w), np.float32)
+        valid = C.c_int32(0)
+        rc = lib().emul_session_resolve(C.c_void_p(self._h), C.c_uint32(frames), C.c_void_p(rgba.ctypes.data),
+                                        C.c_void_p(alb.ctypes.data), C.c_void_p(nrm.ctypes.data),
+                                        C.c_void_p(dep.ctypes.data), C.byref(valid))
+        if rc != 0:
+            raise RuntimeError("emul resolve failed")
+        return {"rgba": rgba, "albedo": alb, "normal": nrm, "depth": dep, "any_valid_reservoir": bool(valid.value)}
+
+    def kernel_timing(self, enable):
+        return 0.0, 0
+
+    def close(self):
+        if self._h:
+            lib().emul_session_destroy(C.c_void_p(self._h))
+            self._h = None
+
+
+class EmulBackend:
+    """CPU stand-in for forge3d_amd.distributed.HipBackend (same kernel code, host-compiled)."""
+
+    def __init__(self):
+        import torch
+
+        self.torch = torch
+
+    def empty_bytes(self, n):
+        return self.torch.zeros(n, dtype=self.torch.uint8)
+
+    def empty_i32(self, n):
+        return self.torch.zeros(n, dtype=self.torch.int32)
+
+    def make_session(self, dem, width, height, cam, row_begin, row_end, res, stats, kw):
+        kw = dict(kw)
+        for k in ("memory_budget_bytes", "kernel_variant", "device", "stream"):
+            kw.pop(k, None)
+        defaults = dict(spacing=(1.0, 1.0), exaggeration=1.0, albedo=(0.6, 0.6, 0.6), sun_azimuth_deg=315.0,
+                        sun_elevation_deg=45.0, sun_intensity=2.5, env_map=None, env_intensity=0.35,
+                        mesh_vertices=None, mesh_indices=None, spp=1, max_frames=512, min_frames=32,
+                        variance_threshold=1e-3, seed=7, sun_color=(1.0, 0.97, 0.92), observer_latitude_deg=0.0,
+                        observer_longitude_deg=0.0, earth_model="ellipsoid", sphere_radius_m=6_371_008.8,
+                        refraction_model="bennett", refraction_k=0.13, pressure_mbar=1013.25, temperature_c=15.0)
+        defaults.update(kw)
+        d, keep = _native.make_desc(dem, width, height, dict(cam or {}), **defaults)
+        L = lib()
+        L.emul_session_create.restype = C.c_void_p
+        err = C.create_string_buffer(512)
+        h = L.emul_session_create(C.byref(d), C.c_uint32(row_begin), C.c_uint32(row_end),
+                                  C.c_void_p(res[0].data_ptr()), C.c_void_p(res[1].data_ptr()), err,
+                                  C.c_size_t(len(err)))
+        if not h:
+            raise RuntimeError(err.value.decode())
+        return _EmulStripSession(h, row_end - row_begin, width, stats)
+
+    def sync(self):
+        pass

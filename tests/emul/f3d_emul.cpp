@@ -268,4 +268,104 @@ int emul_render(const f3d_terrain_ref_desc *d, uint32_t row_begin, uint32_t row_
     return 0;
 }
 
+// ---- strip session on the host: the subset of f3d_session_* the row-strip driver
+// (forge3d_amd/distributed.py) needs, so its halo exchange / all-reduce / gather logic can be
+// tested with world_size-2 gloo on the CPU.  Reservoir buffers are caller-owned.
+struct EmulSession {
+    FrameParams P{};
+    HostTables tables;
+    std::vector<float> env4, mesh4;
+    std::vector<uint32_t> mesh_idx;
+    std::vector<float4> accum, gbuf;
+    std::vector<float> m2, depth;
+    PackedReservoir *res[2] = {nullptr, nullptr};
+    uint32_t rows = 0, width = 0;
+    bool require_valid = false;
+};
+
+void *emul_session_create(const f3d_terrain_ref_desc *d, uint32_t row_begin, uint32_t row_end, void *res0, void *res1,
+                          char *err, size_t errlen) {
+    EmulSession *s = new EmulSession();
+    try {
+        validate_desc(*d);
+        validate_scene(*d);
+        s->require_valid = fill_uniforms(*d, s->P);
+        s->tables = build_tables_host(d->heights, d->dem_width, d->dem_height, d->exaggeration);
+        apply_layout(s->tables.L, s->P.terrain);
+        s->P.terrain.leaves = s->tables.leaves.data();
+        s->P.terrain.nodes = s->tables.nodes.data();
+        if (d->mesh_vertices) {
+            s->mesh4 = pad_rgb_to_rgba(d->mesh_vertices, d->mesh_vertex_count, 0.0f);
+            s->mesh_idx.assign(d->mesh_indices, d->mesh_indices + d->mesh_index_count);
+            s->P.mesh.vertices = (const float4 *)s->mesh4.data();
+            s->P.mesh.indices = s->mesh_idx.data();
+            s->P.mesh.vertex_count = d->mesh_vertex_count;
+            s->P.mesh.index_count = d->mesh_index_count;
+            s->P.mesh.traversal_mode = 0u;
+        }
+        if (row_end == 0) row_end = d->height;
+        s->P.row_begin = row_begin;
+        s->P.row_end = row_end;
+        s->rows = row_end - row_begin;
+        s->width = d->width;
+        const size_t px = (size_t)s->rows * s->width;
+        s->accum.assign(px, float4{0, 0, 0, 0});
+        s->gbuf.resize(px);
+        s->m2.assign(px, 0.0f);
+        s->depth.resize(px);
+        s->res[0] = (PackedReservoir *)res0;
+        s->res[1] = (PackedReservoir *)res1;
+        s->P.accum_mean = s->accum.data();
+        s->P.welford_m2 = s->m2.data();
+        s->P.gbuffer_n = s->gbuf.data();
+        for (uint32_t y = row_begin; y < row_end; y++) {
+            ArrayPending pend;
+            for (uint32_t x = 0; x < s->width; x++) gbuffer_pixel(s->P, x, y, s->gbuf.data(), s->depth.data(), pend);
+        }
+    } catch (const Failure &f) {
+        if (err && errlen) snprintf(err, errlen, "%s", f.message.c_str());
+        delete s;
+        return nullptr;
+    }
+    return s;
+}
+
+// one frame; stats[0] = max m2 bits, stats[1] = nonfinite (same record as the device writes)
+void emul_session_frame(void *h, uint32_t frame, int32_t collect, uint32_t *stats) {
+    EmulSession *s = (EmulSession *)h;
+    FrameParams &P = s->P;
+    P.frame_index = frame;
+    P.res_out = s->res[frame & 1u];
+    P.res_in = s->res[(frame & 1u) ^ 1u];
+    float vmax = 0.0f;
+    bool bad = false;
+    for (uint32_t y = P.row_begin; y < P.row_end; y++) {
+        ArrayPending pend;
+        for (uint32_t x = 0; x < s->width; x++) {
+            const float v = frame_pixel(P, x, y, pend);
+            if (!f_finite(v)) bad = true;
+            else vmax = f_max(vmax, f_max(v, 0.0f));
+        }
+    }
+    if (collect && stats) {
+        stats[0] = f_bits(vmax);
+        stats[1] = bad ? 1u : 0u;
+    }
+}
+
+int emul_session_resolve(void *h, uint32_t frames, uint8_t *rgba, float *albedo, float *normal, float *depth,
+                         int32_t *any_valid) {
+    EmulSession *s = (EmulSession *)h;
+    FrameParams P = s->P;
+    P.res_in = s->res[(frames - 1u) & 1u];
+    uint32_t flags = 0;
+    for (uint32_t y = P.row_begin; y < P.row_end; y++)
+        for (uint32_t x = 0; x < s->width; x++) flags |= resolve_pixel(P, frames, x, y, rgba, albedo, normal);
+    memcpy(depth, s->depth.data(), s->depth.size() * sizeof(float));
+    if (any_valid) *any_valid = (flags & 1u) != 0u;
+    return (flags & 2u) ? F3D_STATUS_RENDER : 0;
+}
+
+void emul_session_destroy(void *h) { delete (EmulSession *)h; }
+
 }  // extern "C"

@@ -1,0 +1,131 @@
+"""The C-ABI shared library: loads, exports every symbol include/f3d_terrain_pt.h declares,
+agrees with the ctypes mirror on struct layout, and fails LOUDLY (status 4, no CPU fallback)
+when asked to compute without a HIP device.  No compute calls are made when a GPU is absent.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import re
+import subprocess
+import tempfile
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import scenes
+
+ROOT = Path(__file__).resolve().parent.parent
+HEADER = ROOT / "include" / "f3d_terrain_pt.h"
+
+
+@pytest.fixture(scope="module")
+def native():
+    import __graft_entry__ as g
+
+    g.build_hip()
+    from forge3d_amd import _native
+
+    return _native
+
+
+def _declared_functions():
+    text = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
+    return sorted(set(re.findall(r"\b(f3d_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(native):
+    L = native.lib()
+    declared = _declared_functions()
+    assert len(declared) >= 16
+    for name in declared:
+        assert hasattr(L, name), f"libf3dhip.so does not export {name}"
+    assert sorted(n for n, _, _ in native.ABI) == declared  # the ctypes table covers the whole header
+    out = subprocess.run(["nm", "-D", "--defined-only", str(native.library_path())], capture_output=True, text=True)
+    exported = {line.split()[-1] for line in out.stdout.splitlines() if " T " in line}
+    assert set(declared) <= exported
+
+
+def test_struct_layouts_match_the_header(native):
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "f3d_terrain_pt.h"
+int main(void) {
+  printf("%zu %zu %zu\n", sizeof(f3d_terrain_ref_desc), sizeof(f3d_terrain_ref_out), sizeof(f3d_session_opts));
+  printf("%zu %zu %zu %zu\n", offsetof(f3d_terrain_ref_desc, observer_latitude_deg),
+         offsetof(f3d_terrain_ref_desc, env_map), offsetof(f3d_terrain_ref_desc, variance_threshold),
+         offsetof(f3d_terrain_ref_out, gpu_resource_bytes));
+  return 0; }
+'''
+    with tempfile.TemporaryDirectory() as tmp:
+        c = Path(tmp) / "layout.c"
+        c.write_text(src)
+        exe = Path(tmp) / "layout"
+        subprocess.run(["gcc", "-I", str(ROOT / "include"), str(c), "-o", str(exe)], check=True)
+        sizes, offsets = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines()
+    assert [int(x) for x in sizes.split()] == [C.sizeof(native.Desc), C.sizeof(native.Out), C.sizeof(native.SessionOpts)]
+    assert [int(x) for x in offsets.split()] == [native.Desc.observer_latitude_deg.offset, native.Desc.env_map.offset,
+                                                 native.Desc.variance_threshold.offset,
+                                                 native.Out.gpu_resource_bytes.offset]
+
+
+def test_version_and_device_probe(native):
+    L = native.lib()
+    assert b"gfx950" in L.f3d_version()
+    assert L.f3d_device_count() >= 0
+
+
+def test_host_side_earth_model_through_the_abi(native):
+    """f3d_effective_radius_m is pure host arithmetic (src/geo/refraction.rs): no GPU needed."""
+    from oracle import oracle
+
+    L = native.lib()
+    out = C.c_double(0.0)
+    err = C.create_string_buffer(256)
+    for earth, refr, az in ((2, 1, 225.0), (2, 0, 0.0), (1, 2, 90.0), (2, 3, 302.0)):
+        rc = L.f3d_effective_radius_m(earth, 12.5, 6371008.8, refr, 1013.25, 15.0, 0.13, az, C.byref(out), err, 256)
+        assert rc == 0
+        want = oracle.effective_radius_m({1: "sphere", 2: "ellipsoid"}[earth],
+                                         {0: "none", 1: "bennett", 2: "saemundsson", 3: "effective_radius"}[refr], az,
+                                         latitude_deg=12.5)
+        assert out.value == want
+    assert L.f3d_effective_radius_m(0, 0.0, 6371008.8, 1, 1013.25, 15.0, 0.13, 0.0, C.byref(out), err, 256) == 2
+    assert b"flat earth" in err.value
+
+
+def test_compute_entry_points_fail_loudly_without_a_gpu(native):
+    if native.device_count() > 0:
+        pytest.skip("a HIP device is present; the no-device behaviour is checked in the CPU container")
+    import forge3d_amd
+
+    dem = scenes.golden_dem(4)
+    with pytest.raises(RuntimeError, match=r"\[Device\].*no CPU fallback"):
+        forge3d_amd.hybrid_render_terrain_reference(dem, 32, 32, scenes.CAM, max_frames=4, min_frames=2)
+    L = native.lib()
+    err = C.create_string_buffer(256)
+    hit = np.zeros(1, np.uint32)
+    rays = np.zeros((1, 8), np.float32)
+    rc = L.f3d_terrain_trace_batch(dem.ctypes.data, dem.shape[1], dem.shape[0], 0.0, 0.0, 1.0, 1.0, 1.0, 0.0, 0,
+                                   rays.ctypes.data, 1, 1, 1, hit.ctypes.data, None, None, err, 256)
+    assert rc == native.STATUS_DEVICE and b"no CPU fallback" in err.value
+    tot = C.c_uint64(0)
+    rc = L.f3d_build_minmax_mips(dem.ctypes.data, dem.shape[1], dem.shape[0], None, None, 0, C.byref(tot), err, 256)
+    assert rc == -native.STATUS_DEVICE
+
+
+def test_product_package_never_imports_the_oracle():
+    """The oracle and the emulator are test infrastructure: nothing under forge3d_amd/ may
+    reference them."""
+    forbidden = re.compile(r"(import\s+oracle|from\s+oracle|from\s+emul|import\s+emul|#include\s+\"[^\"]*(oracle|emul)"
+                           r"|libf3d_oracle|libf3d_emul|f3do_|emul_render|emul_session)")
+    checked = 0
+    for path in (ROOT / "forge3d_amd").rglob("*"):
+        if path.suffix in (".py", ".h", ".hip", ".cpp"):
+            checked += 1
+            hit = forbidden.search(path.read_text())
+            assert hit is None, f"{path} references test infrastructure: {hit.group(0)!r}"
+    assert checked >= 10
+    # and the shared library links nothing but the HIP runtime / libstdc++
+    out = subprocess.run(["ldd", str(ROOT / "forge3d_amd" / "libf3dhip.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out and "emul" not in out

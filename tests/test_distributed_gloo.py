@@ -1,0 +1,117 @@
+"""world_size-2 (and 3) `gloo` tests of the row-strip driver on the CPU.
+
+forge3d_amd.distributed.StripRenderer is exercised exactly as bench.py / a multi-GPU job
+uses it -- per-frame 3-row reservoir halo exchange (batch_isend_irecv), per-window
+all-reduce(MAX) of the statistics record, final gather of the strips -- with the kernel
+emulator standing in for the HIP session.  The stitched image must equal the single-strip
+image bit for bit, because RNG and state are keyed by full-image coordinates.
+"""
+from __future__ import annotations
+
+import os
+import pickle
+import socket
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_path, mode):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    import scenes
+    from emul import emul
+    from forge3d_amd.distributed import StripRenderer, init_process_group
+
+    init_process_group(world, rank, backend="gloo")
+    dem = scenes.golden_dem(4)
+    kw = scenes.scene_kwargs(dem)
+    if mode == "fixed":
+        kw = scenes.fixed_frames(kw, 6, spp=2)
+    else:  # converge through two Welford windows
+        kw = {**kw, "variance_threshold": 5e-3, "max_frames": 256, "spp": 1}
+    r = StripRenderer(dem, 72, 50, scenes.CAM, rank=rank, world=world, backend=emul.EmulBackend(), **kw)
+    image = r.render() if mode == "converge" else None
+    if mode == "fixed":
+        r.run_frames(0, 6, collect_last=True)
+        var = r.window_variance(6)
+        image = r.gather_image(6)
+        if image is not None:
+            image["variance"] = var
+    t = r.max_over_ranks(float(rank))
+    assert t == float(world - 1)
+    r.close()
+    if rank == 0:
+        with open(out_path, "wb") as f:
+            pickle.dump(image, f)
+    else:
+        assert image is None
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _run(world, mode):
+    import torch.multiprocessing as mp
+
+    out = tempfile.mktemp(suffix=".pkl")
+    port = _free_port()
+    if world == 1:
+        _worker(0, 1, port, out, mode)
+    else:
+        mp.spawn(_worker, args=(world, port, out, mode), nprocs=world, join=True)
+    with open(out, "rb") as f:
+        image = pickle.load(f)
+    os.unlink(out)
+    return image
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_strips_over_gloo_reproduce_the_single_strip_image(world):
+    single = _run(1, "fixed")
+    multi = _run(world, "fixed")
+    for key in ("rgba", "albedo", "normal", "depth"):
+        assert np.array_equal(single[key], multi[key], equal_nan=True), key
+    assert single["variance"] == multi["variance"]
+
+
+def test_distributed_convergence_gate_matches_single_process():
+    import scenes
+    from oracle import oracle
+
+    multi = _run(2, "converge")
+    dem = scenes.golden_dem(4)
+    want = oracle.render(dem, 72, 50, scenes.CAM, **{**scenes.scene_kwargs(dem), "variance_threshold": 5e-3,
+                                                     "max_frames": 256, "spp": 1})
+    assert multi["frames"] == want["frames"] and multi["converged"]
+    assert np.float32(multi["variance"]) == np.float32(want["variance"])
+    for key in ("rgba", "albedo", "normal", "depth"):
+        assert np.array_equal(multi[key], want[key], equal_nan=True), key
+
+
+def test_strip_rows_partition_the_image():
+    from forge3d_amd.distributed import strip_rows
+
+    for h, n in ((1080, 8), (50, 3), (7, 2), (4096, 8)):
+        bounds = [strip_rows(h, n, r) for r in range(n)]
+        assert bounds[0][0] == 0 and bounds[-1][1] == h
+        assert all(bounds[i][1] == bounds[i + 1][0] for i in range(n - 1))
+        sizes = [e - b for b, e in bounds]
+        assert max(sizes) - min(sizes) <= 1

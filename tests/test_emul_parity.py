@@ -1,0 +1,90 @@
+"""CPU-side parity of the product's KERNEL CODE (host-compiled by tests/emul, test
+infrastructure) against the oracle: the restructured traversal (push-time culling, fat
+leaves, path-coded pending siblings), the packed 16-byte reservoirs and the single fused
+pass per frame must reproduce the literal three-pass restatement bit for bit.  The `-m gpu`
+tests repeat every comparison on the device through libf3dhip.so.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import pytest
+
+import scenes
+from emul import emul
+from oracle import oracle
+
+QUAD_V = np.array([[-18.0, 22.0, -6.0], [18.0, 22.0, -6.0], [18.0, 40.0, -6.0], [-18.0, 40.0, -6.0]], np.float32)
+QUAD_I = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+
+
+def _same(a, b):
+    for key in ("rgba", "albedo", "normal"):
+        assert np.array_equal(a[key], b[key]), key
+    assert np.array_equal(a["depth"], b["depth"], equal_nan=True)
+    assert a["frames"] == b["frames"] and np.float32(a["variance"]) == np.float32(b["variance"])
+
+
+@pytest.mark.parametrize("state_machine", ["0", "1"])
+@pytest.mark.parametrize("size,spp,frames,extra", [
+    ((64, 64), 1, 3, {}),
+    ((96, 64), 3, 5, {}),
+    ((80, 80), 2, 4, {"mesh_vertices": QUAD_V, "mesh_indices": QUAD_I}),
+    ((128, 96), 2, 34, {}),                       # crosses a Welford window + the M-clamp
+    ((72, 56), 2, 4, {"earth_model": "flat", "refraction_model": "none", "sun_color": (0.2, 0.3, 1.5)}),
+])
+def test_kernel_code_matches_oracle(monkeypatch, state_machine, size, spp, frames, extra):
+    monkeypatch.setenv("F3D_EMUL_STATE_MACHINE", state_machine)
+    dem = scenes.golden_dem()
+    kw = scenes.fixed_frames(scenes.scene_kwargs(dem), frames, spp=spp, **extra)
+    want = oracle.render(dem, size[0], size[1], scenes.CAM, dump_state=True, **kw)
+    got = emul.render(dem, size[0], size[1], scenes.CAM, **kw)
+    _same(got, want)
+    assert np.array_equal(got["accum"][:, :3], want["accum"][:, :3])          # accumulated radiance
+    assert np.array_equal(got["accum"][:, 3], want["welford"][:, 0])          # Welford mean
+    assert np.array_equal(got["m2"], want["welford"][:, 1])                   # Welford m2
+
+
+def test_env_map_and_ragged_dem():
+    dem = scenes.golden_dem(2)[:37, :100].copy()
+    env = np.random.default_rng(5).uniform(0.1, 2.0, size=(16, 32, 3)).astype(np.float32)
+    kw = scenes.fixed_frames(scenes.scene_kwargs(dem), 4, spp=2, env_map=env, seed=99)
+    cam = {**scenes.CAM, "origin": (10.0, 30.0, 60.0), "fov_y": 60.0, "exposure": 1.7}
+    _same(emul.render(dem, 80, 72, cam, **kw), oracle.render(dem, 80, 72, cam, **kw))
+
+
+def test_two_by_two_dem_root_is_the_leaf():
+    dem = np.array([[0.0, 1.0], [2.0, 0.5]], np.float32)
+    kw = dict(spacing=(40.0, 40.0), exaggeration=10.0, max_frames=4, min_frames=4, variance_threshold=1e30, spp=2)
+    _same(emul.render(dem, 48, 40, scenes.CAM, **kw), oracle.render(dem, 48, 40, scenes.CAM, **kw))
+
+
+def test_converging_render_stops_at_the_same_frame():
+    dem = scenes.golden_dem(4)
+    kw = {**scenes.scene_kwargs(dem), "variance_threshold": 5e-3, "max_frames": 256}
+    a, b = emul.render(dem, 64, 64, scenes.CAM, **kw), oracle.render(dem, 64, 64, scenes.CAM, **kw)
+    _same(a, b)
+    assert a["frames"] % 32 == 0 and a["frames"] < 256
+
+
+def test_traversal_matches_oracle_on_the_reference_proof_rays():
+    heights, rays = scenes.proof_rays(n_random=4000, mask=True)
+    inv2r = float(np.float32(1.0 / 14_650_000.0))
+    for any_hit, curv in ((True, True), (False, False), (True, False)):
+        kw = dict(spacing=(500.0, 500.0), inv_two_r_prime=inv2r, curvature_enabled=True, any_hit=any_hit,
+                  apply_curvature=curv)
+        want, got = oracle.terrain_trace_batch(heights, rays, **kw), emul.terrain_trace_batch(heights, rays, **kw)
+        assert np.array_equal(got["hit"], want["hit"])
+        assert np.array_equal(got["t"], want["t"])
+        assert np.array_equal(got["normal"], want["normal"])
+
+
+@pytest.mark.parametrize("shape", [(256, 256), (37, 100), (2, 2), (3, 9), (130, 65), (9, 3)])
+def test_table_builder_matches_build_minmax_mips(shape):
+    dem = np.random.default_rng(shape[0] * 1000 + shape[1]).normal(1000.0, 300.0, size=shape).astype(np.float32)
+    want, _ = oracle.build_minmax_mips(dem)
+    got = emul.build_minmax_mips(dem)
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and np.array_equal(a, b)
