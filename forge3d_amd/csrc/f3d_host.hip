@@ -592,7 +592,7 @@ int f3d_terrain_trace_batch(const float *heights, uint32_t width, uint32_t heigh
         hip_check(hipMemcpy(d_rays, rays, (size_t)n * 32, hipMemcpyHostToDevice), "ray upload");
         B.rays = d_rays;
         B.n = n;
-        B.any_hit = any_hit != 0;
+        B.any_hit = (uint32_t)any_hit;  // 0 closest, 1 any-hit descent, 2 occlusion march (boolean only)
         B.apply_curvature = apply_curvature != 0;
         B.out_hit = (uint32_t *)mem.alloc((size_t)n * 4, "hits");
         B.out_t = (float *)mem.alloc((size_t)n * 4, "t");

@@ -157,7 +157,14 @@ __global__ __launch_bounds__(kWave) void k_ray_batch(const RayBatchParams B) {
     if (i >= B.n) return;
     const float4 a = B.rays[2 * i], b = B.rays[2 * i + 1];
     const RayCtx r = make_ray(B.terrain, V3{a.x, a.y, a.z}, a.w, V3{b.x, b.y, b.z}, b.w, B.apply_curvature != 0u);
-    const TraceHit h = trace_terrain(B.terrain, r, B.any_hit != 0u, pend);
+    TraceHit h;
+    if (B.any_hit == 2u) {  // the frame kernel's occlusion march: boolean only
+        h.hit = terrain_occluded_march(B.terrain, r, pend);
+        h.t = 0.0f;
+        h.n = V3{0.0f, 0.0f, 0.0f};
+    } else {
+        h = trace_terrain(B.terrain, r, B.any_hit != 0u, pend);
+    }
     B.out_hit[i] = h.hit ? 1u : 0u;
     if (B.out_t) B.out_t[i] = h.t;
     if (B.out_normal) {

@@ -13,6 +13,7 @@
 // its G-buffer centre ray (:619-644) are the same ray.
 #pragma once
 
+#include "f3d_march.h"
 #include "f3d_trace.h"
 
 namespace f3d {
@@ -115,12 +116,18 @@ F3D_HD bool occluded(const FrameParams &P, V3 o, float tmin, V3 d, float tmax, b
         }
     }
     RayCtx r = make_ray(P.terrain, o, tmin, d, best_t, apply_curvature);
-    TraceHit th = trace_terrain(P.terrain, r, true, pend);
+#if defined(F3D_OCCLUSION_DESCENT)
+    TraceHit th = trace_terrain(P.terrain, r, true, pend);  // the reference-shaped sorted descent
     if (th.hit && th.t < best_t) {
         best_t = th.t;
         hit = true;
     }
     return hit && best_t < 1e30f;
+#else
+    // only the boolean is needed, and for any-hit rays it does not depend on the visiting order:
+    // stackless min-max march (f3d_march.h); a terrain hit implies t < best_t <= tmax
+    return hit || terrain_occluded_march(P.terrain, r, pend);
+#endif
 }
 
 // terrain_env_radiance, hybrid_terrain_traversal.wgsl:392-405

@@ -87,7 +87,7 @@ def terrain_trace_batch(heights, rays, *, origin=(0.0, 0.0), spacing=(1.0, 1.0),
                                 C.c_float(origin[0]), C.c_float(origin[1]), C.c_float(spacing[0]),
                                 C.c_float(spacing[1]), C.c_float(exaggeration), C.c_float(inv_two_r_prime),
                                 C.c_uint32(1 if curvature_enabled else 0), C.c_void_p(r.ctypes.data), C.c_uint32(n),
-                                C.c_int32(1 if any_hit else 0), C.c_int32(1 if apply_curvature else 0),
+                                C.c_int32(int(any_hit)), C.c_int32(1 if apply_curvature else 0),
                                 C.c_void_p(hit.ctypes.data), C.c_void_p(t.ctypes.data), C.c_void_p(nrm.ctypes.data))
     if rc != 0:
         raise RuntimeError(f"emul status {rc}")

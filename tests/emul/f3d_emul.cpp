@@ -93,7 +93,14 @@ int emul_trace_batch(const float *heights, uint32_t w, uint32_t h, float origin_
             const float *r = rays + 8 * (size_t)i;
             ArrayPending pend;
             RayCtx rc = make_ray(T, V3{r[0], r[1], r[2]}, r[3], V3{r[4], r[5], r[6]}, r[7], apply_curvature != 0);
-            TraceHit hit = trace_terrain(T, rc, any_hit != 0, pend);
+            TraceHit hit;
+            if (any_hit == 2) {  // stackless occlusion march: boolean only
+                hit.hit = terrain_occluded_march(T, rc, pend);
+                hit.t = 0.0f;
+                hit.n = V3{0.0f, 0.0f, 0.0f};
+            } else {
+                hit = trace_terrain(T, rc, any_hit != 0, pend);
+            }
             out_hit[i] = hit.hit ? 1u : 0u;
             if (out_t) out_t[i] = hit.t;
             if (out_normal) {
