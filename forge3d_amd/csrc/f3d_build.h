@@ -29,6 +29,19 @@ struct LevelBuildParams {
     uint32_t cell_w, cell_h;
 };
 
+struct BandBuildParams {
+    // row-major (min,max) copy of one level for the march: level 0 from the corner records,
+    // level >= 1 from the tiled node table
+    const LeafRec *leaves;
+    const NodeRec *src;  // tiled records of this level (level >= 1)
+    NodeRec *dst;        // bands + band_offset[level]
+    uint32_t level;
+    uint32_t width, height;  // logical pow2 dims of the level (= row pitch and row count)
+    uint32_t shift;          // log2(width)
+    uint32_t src_tiles_x;
+    uint32_t cell_w, cell_h;
+};
+
 F3D_HD float min4(const LeafRec &h) { return f_min(f_min(f_min(h.h00, h.h10), h.h01), h.h11); }
 F3D_HD float max4(const LeafRec &h) { return f_max(f_max(f_max(h.h00, h.h10), h.h01), h.h11); }
 
@@ -72,6 +85,19 @@ F3D_HD void level_build_at(const LevelBuildParams &B, uint32_t x, uint32_t y) {
         }
     }
     B.dst[tiled_index(x, y, B.dst_tiles_x)] = NodeRec{mn, mx};
+}
+
+F3D_HD void band_build_at(const BandBuildParams &B, uint32_t x, uint32_t z) {
+    NodeRec out{__builtin_inff(), -__builtin_inff()};
+    if (B.level == 0u) {
+        if (x < B.cell_w && z < B.cell_h) {
+            const LeafRec h = B.leaves[tiled_index(x, z, B.src_tiles_x)];
+            out = NodeRec{min4(h), max4(h)};
+        }
+    } else {
+        out = B.src[tiled_index(x, z, B.src_tiles_x)];
+    }
+    B.dst[((size_t)z << B.shift) + x] = out;
 }
 
 }  // namespace f3d

@@ -56,6 +56,7 @@ struct TerrainTables {
     uint64_t bytes = 0;  // leaf + node tables
     LeafRec *leaves = nullptr;
     NodeRec *nodes = nullptr;
+    NodeRec *bands = nullptr;  // row-major (min,max) of every level (the march's table)
 };
 
 TerrainTables build_tables(Ledger &mem, const float *d_heights, uint32_t w, uint32_t h, float exaggeration,
@@ -65,14 +66,18 @@ TerrainTables build_tables(Ledger &mem, const float *d_heights, uint32_t w, uint
     const TableLayout &L = t.layout;
     t.leaves = (LeafRec *)mem.alloc(L.leaf_count * sizeof(LeafRec), "leaf table");
     t.nodes = (NodeRec *)mem.alloc((L.node_count ? L.node_count : 1) * sizeof(NodeRec), "node table");
-    t.bytes = L.leaf_count * sizeof(LeafRec) + L.node_count * sizeof(NodeRec);
+    t.bands = (NodeRec *)mem.alloc(L.band_count * sizeof(NodeRec), "band tables");
+    t.bytes = L.leaf_count * sizeof(LeafRec) + (L.node_count + L.band_count) * sizeof(NodeRec);
     hip_check(launch_leaf_build(leaf_build_params(L, d_heights, w, h, exaggeration, t.leaves), stream),
               "leaf table build");
     for (uint32_t l = 1; l < L.levels; l++)
         hip_check(launch_level_build(level_build_params(L, l, t.leaves, t.nodes), stream), "node table build");
+    for (uint32_t l = 0; l < L.levels; l++)
+        hip_check(launch_band_build(band_build_params(L, l, t.leaves, t.nodes, t.bands), stream), "band table build");
     apply_layout(L, t.dev);
     t.dev.leaves = t.leaves;
     t.dev.nodes = t.nodes;
+    t.dev.bands = t.bands;
     return t;
 }
 
@@ -145,6 +150,7 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
     apply_layout(s.tables.layout, P.terrain);
     P.terrain.leaves = s.tables.leaves;
     P.terrain.nodes = s.tables.nodes;
+    P.terrain.bands = s.tables.bands;
 
     // environment map as rgb+pad texels (the reference uploads RGBA32F, terrain_heightfield.rs:443-482)
     if (d.env_map) {
@@ -592,7 +598,10 @@ int f3d_terrain_trace_batch(const float *heights, uint32_t width, uint32_t heigh
         hip_check(hipMemcpy(d_rays, rays, (size_t)n * 32, hipMemcpyHostToDevice), "ray upload");
         B.rays = d_rays;
         B.n = n;
-        B.any_hit = (uint32_t)any_hit;  // 0 closest, 1 any-hit descent, 2 occlusion march (boolean only)
+        // 0 closest / 1 any-hit through the sorted descent; 2 any / 3 closest through the march,
+        // +4: the march starts in the origin cell (secondary rays) instead of at the root
+        B.any_hit = (uint32_t)any_hit & 3u;
+        B.start_in_cell = ((uint32_t)any_hit >> 2) & 1u;
         B.apply_curvature = apply_curvature != 0;
         B.out_hit = (uint32_t *)mem.alloc((size_t)n * 4, "hits");
         B.out_t = (float *)mem.alloc((size_t)n * 4, "t");

@@ -15,33 +15,43 @@ namespace f3d {
 constexpr int kWave = 64;
 constexpr int kNumXcd = 8;
 
-// Per-wave LDS scratch of the traversal: the pending-sibling words as a [level][lane] column
-// (bank = lane, conflict-free) and a copy of the per-level layout table, so that a lane can
-// look its level up with one ds_read_b64 instead of a vector load from the kernarg segment.
-constexpr int kLdsWords = kMaxLevels * kWave + 2 * kMaxLevels;
+// Per-wave LDS scratch of the traversal: a copy of the per-level layout tables, so that a lane
+// can look its (per-lane) level up with one ds_read_b64 instead of a vector load from the kernarg
+// segment, and -- only for the sorted descent kept for the test hook / A-B builds -- the
+// pending-sibling words as a [level][lane] column (bank = lane, conflict-free).
+constexpr int kLdsWords = kMaxLevels * kWave + 4 * kMaxLevels;
 struct LdsPending {
     uint32_t *col;          // lds + lane
-    const uint32_t *table;  // lds + kMaxLevels * kWave: {node_offset, tiles_x} per level
+    const uint32_t *table;  // lds + kMaxLevels * kWave: {band_offset, band_shift, node_offset, tiles_x} per level
+    uint32_t leaf_quorum;
     __device__ __forceinline__ void put(uint32_t level, uint32_t word) { col[level * kWave] = word; }
     __device__ __forceinline__ uint32_t get(uint32_t level) const { return col[level * kWave]; }
     __device__ __forceinline__ void note(int) const {}  // step-statistics hook (host emulator only)
-    // Called by every lane still traversing: may the lanes that hold a fat leaf solve it now?
-    uint32_t leaf_quorum;
+    // (leaf-gate A/B build only) may the lanes that hold a fat leaf solve it now?
     __device__ __forceinline__ bool leaf_gate(bool at_leaf) const {
         const unsigned long long leaf = __ballot(at_leaf), inner = __ballot(!at_leaf);
         return (uint32_t)__popcll(leaf) >= leaf_quorum || inner == 0ull;
     }
+    __device__ __forceinline__ void band_entry(const TerrainDev &, uint32_t level, uint32_t &offset,
+                                               uint32_t &shift) const {
+        const uint2 e = *reinterpret_cast<const uint2 *>(table + 4u * level);
+        offset = e.x;
+        shift = e.y;
+    }
     __device__ __forceinline__ void level_entry(const TerrainDev &, uint32_t level, uint32_t &offset,
                                                 uint32_t &tiles_x) const {
-        const uint2 e = *reinterpret_cast<const uint2 *>(table + 2u * level);
+        const uint2 e = *reinterpret_cast<const uint2 *>(table + 4u * level + 2u);
         offset = e.x;
         tiles_x = e.y;
     }
 };
 __device__ __forceinline__ LdsPending make_pending(uint32_t *lds, const TerrainDev &T) {
     if (threadIdx.x < kMaxLevels) {
-        lds[kMaxLevels * kWave + 2 * threadIdx.x] = T.node_offset[threadIdx.x];
-        lds[kMaxLevels * kWave + 2 * threadIdx.x + 1] = T.tiles_x[threadIdx.x];
+        uint32_t *e = lds + kMaxLevels * kWave + 4 * threadIdx.x;
+        e[0] = T.band_offset[threadIdx.x];
+        e[1] = T.band_shift[threadIdx.x];
+        e[2] = T.node_offset[threadIdx.x];
+        e[3] = T.tiles_x[threadIdx.x];
     }
     __syncthreads();
     return LdsPending{lds + threadIdx.x, lds + kMaxLevels * kWave, T.leaf_quorum ? T.leaf_quorum : 1u};
@@ -158,10 +168,8 @@ __global__ __launch_bounds__(kWave) void k_ray_batch(const RayBatchParams B) {
     const float4 a = B.rays[2 * i], b = B.rays[2 * i + 1];
     const RayCtx r = make_ray(B.terrain, V3{a.x, a.y, a.z}, a.w, V3{b.x, b.y, b.z}, b.w, B.apply_curvature != 0u);
     TraceHit h;
-    if (B.any_hit == 2u) {  // the frame kernel's occlusion march: boolean only
-        h.hit = terrain_occluded_march(B.terrain, r, pend);
-        h.t = 0.0f;
-        h.n = V3{0.0f, 0.0f, 0.0f};
+    if (B.any_hit >= 2u) {  // the frame kernel's stackless march: 2 = any hit, 3 = closest hit
+        h = march_ray(B.terrain, r, B.any_hit == 2u, B.start_in_cell != 0u, pend);
     } else {
         h = trace_terrain(B.terrain, r, B.any_hit != 0u, pend);
     }
@@ -179,6 +187,11 @@ __global__ __launch_bounds__(kWave) void k_ray_batch(const RayBatchParams B) {
 __global__ void k_leaf_build(const PyramidBuildParams B) {
     const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x < B.leaf_dim_x && y < B.leaf_dim_y) leaf_build_at(B, x, y);
+}
+
+__global__ void k_band_build(const BandBuildParams B) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, z = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x < B.width && z < B.height) band_build_at(B, x, z);
 }
 
 __global__ void k_level_build(const LevelBuildParams B) {
@@ -226,6 +239,11 @@ hipError_t launch_ray_batch(const RayBatchParams &p, hipStream_t stream) {
 hipError_t launch_leaf_build(const PyramidBuildParams &p, hipStream_t stream) {
     dim3 block(16, 16), grid((p.leaf_dim_x + 15) / 16, (p.leaf_dim_y + 15) / 16);
     hipLaunchKernelGGL(k_leaf_build, grid, block, 0, stream, p);
+    return hipGetLastError();
+}
+hipError_t launch_band_build(const BandBuildParams &p, hipStream_t stream) {
+    dim3 block(16, 16), grid((p.width + 15) / 16, (p.height + 15) / 16);
+    hipLaunchKernelGGL(k_band_build, grid, block, 0, stream, p);
     return hipGetLastError();
 }
 hipError_t launch_level_build(const LevelBuildParams &p, hipStream_t stream) {

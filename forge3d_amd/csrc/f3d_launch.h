@@ -12,7 +12,8 @@ struct RayBatchParams {
     TerrainDev terrain;
     const float4 *rays;  // 2 float4 per ray: (origin, tmin), (direction, tmax)
     uint32_t n;
-    uint32_t any_hit, apply_curvature;
+    uint32_t any_hit, apply_curvature;  // any_hit: 0 closest / 1 any-hit (sorted descent), 2 any / 3 closest (march)
+    uint32_t start_in_cell;             // march only: start in the origin cell instead of at the root
     uint32_t *out_hit;
     float *out_t;
     float *out_normal;  // 3 per ray
@@ -31,5 +32,6 @@ hipError_t launch_resolve(const ResolveParams &p, hipStream_t stream);
 hipError_t launch_ray_batch(const RayBatchParams &p, hipStream_t stream);
 hipError_t launch_leaf_build(const PyramidBuildParams &p, hipStream_t stream);
 hipError_t launch_level_build(const LevelBuildParams &p, hipStream_t stream);
+hipError_t launch_band_build(const BandBuildParams &p, hipStream_t stream);
 
 }  // namespace f3d

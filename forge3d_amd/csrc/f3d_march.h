@@ -1,64 +1,67 @@
 // forge3d_amd/csrc/f3d_march.h
-// Occlusion (any-hit) rays: stackless min-max march along the ray.
+// Stackless min-max march: the traversal the frame kernel uses for every ray.
 //
-// The reference answers "is anything in the way?" with the same sorted quadtree descent it
-// uses for closest hits (`terrain_trace(ray, any_hit = true, ...)`,
-// hybrid_terrain_traversal.wgsl:254-372, called by intersect_shadow_ray /
-// intersect_ibl_occlusion_ray, hybrid_traversal.wgsl:248-259).  For an any-hit ray best-t never
-// changes before the function returns, so every node and every leaf is judged by a test that
-// depends on the node and the ray only -- the answer is the OR over all leaves of
-// "passes its slab interval, its height band and the leaf solve", whatever the visiting order.
-// That freedom is used here: two thirds of all rays (sun shadow + IBL occlusion) and ~80 % of the
-// traversal steps are any-hit.
+// The reference answers both "what does this ray hit first?" and "is anything in the way?" with a
+// sorted quadtree descent over an explicit stack (`terrain_trace`,
+// hybrid_terrain_traversal.wgsl:254-372).  Its RESULT, however, is a function of per-node and
+// per-leaf tests that depend on the node and the ray only:
+//   * a node is entered iff its own slab interval [max(enter,tmin), min(exit,tmax,best)] is not
+//     empty (:288-297) and the ray's height range over it meets the node's (min,max) band (:301-304);
+//   * a leaf inside entered nodes is solved over its own interval (:167-235);
+//   * any-hit rays return at the first hit (best-t never changes before that, so the answer is the
+//     OR over all leaves, whatever the order); closest-hit rays visit leaves near-to-far (children are
+//     sorted by entry parameter, :351-369), so the first hit along the ray is final -- a later leaf
+//     starts where the earlier one ended and `t < best` is strict.
+// So any enumeration that walks the nodes ALONG THE RAY, applies those same tests with the same
+// plane parameters, and stops at the first hit, returns the same hit/t/normal.  The march does that
+// with ONE current node (level, x, z) and no stack:
+//   band test fails -> step across the node's exit boundary to the neighbour of the same level, and
+//                      one level UP whenever that crossing also leaves the parent;
+//   band test passes -> level > 0: DOWN into the child the ray is in (the child boundary's plane
+//                      parameter against the current ray parameter); level 0: solve the leaf.
+// A step costs one 8-byte (min,max) fetch from a row-major per-level table and a few dozen VALU
+// instructions; the descent's four-children expansion, sorting network and LDS sibling lists are gone.
+// Secondary rays start in the cell their origin is in (validated by that cell's own slab interval)
+// instead of walking ~11 levels down from the root.
 //
-// The march keeps ONE current node (level, x, z) -- the node of that level the ray is in -- and
-// applies to it exactly the reference's per-node tests with the node's own slab interval
-// (:288-304):
-//   * band test fails  -> nothing in this node can be hit: step across its far boundary to the
-//                         neighbour at the same level, and move one level UP whenever that
-//                         crossing also leaves the parent (bigger steps while the ray is clear);
-//   * band test passes -> level > 0: go DOWN into the child the ray is in (chosen by comparing
-//                         the ray parameter with the child boundary's plane parameter);
-//                         level 0: solve the leaf (:167-235); a hit ends the ray.
-// No stack, no sorting, no four-children expansion: a step costs one 8-byte (min,max) fetch (or one
-// 16-byte leaf record) and a few dozen VALU instructions, against ~200 for a descent step.
-//
-// Completeness (every leaf the descent would accept is reached): a node is skipped only when the
-// reference's own band test for that node rejects it (which rejects every leaf inside it, because
-// children are bounded by their parent in interval and height range); lateral moves follow the
-// ray's exit boundary, so consecutive nodes tile the ray's path.  Two measure-zero deviations from
-// the reference's enumeration are accepted and documented in DESIGN.md: a ray that leaves a node
-// EXACTLY through a corner (both axis parameters equal in f32) skips the two cells it touches in
-// that single point, and the node containing the ray's start is located from its slab
-// parameters.  tests/ compare the boolean against the oracle on 75 000 proof rays and whole
-// images bit for bit.
+// Deviations from the reference's enumeration, both measure-zero and documented in DESIGN.md:
+// a ray leaving a node EXACTLY through a corner (equal f32 plane parameters) skips the two cells it
+// touches in that single point; the start cell is located from the ray position.  tests/ compare
+// hit, t and normal with the oracle on 75 000 proof rays and whole renders bit for bit.
 #pragma once
 
 #include "f3d_trace.h"
 
 namespace f3d {
 
-// (min,max)*exaggeration of node (level, x, z); level 0 comes from the corner record.
-template <class Pending>
-F3D_HD void node_band(const TerrainDev &T, uint32_t level, uint32_t x, uint32_t z, Pending &pend, float &mn, float &mx,
-                      LeafRec &leaf) {
-    if (level == 0u) {
-        leaf = T.leaves[tiled_index(x, z, T.tiles_x[0])];
-        mn = min4(leaf);
-        mx = max4(leaf);
-    } else {
-        uint32_t offset, tiles_x;
-        pend.level_entry(T, level, offset, tiles_x);
-        const NodeRec r = T.nodes[offset + tiled_index(x, z, tiles_x)];
-        mn = r.mn;
-        mx = r.mx;
-    }
+template <bool CURVED>
+F3D_HD float march_height(const RayCtx &r, float t) {
+    const float lin = f_fma(t, r.d.y, r.o.y);
+    // non-curved rays have c2 == 0: fma(t*t, 0, lin) == lin exactly, so the term is dropped
+    return CURVED ? f_fma(t * t, r.c2, lin) : lin;
 }
 
-template <class Pending>
-F3D_HD bool terrain_occluded_march(const TerrainDev &T, const RayCtx &r, Pending &pend) {
+template <bool CURVED>
+F3D_HD bool march_band_rejects(const RayCtx &r, float t0, float t1, float mn, float mx) {
+    const float y0 = march_height<CURVED>(r, t0), y1 = march_height<CURVED>(r, t1);
+    float lo = f_min(y0, y1);
+    if (CURVED) {
+        if (r.has_vertex && r.vertex >= t0 && r.vertex <= t1) lo = f_min(lo, march_height<true>(r, r.vertex));
+    }
+    return lo > mx || f_max(y0, y1) < mn;
+}
+
+// CURVED: the sun-ray curvature policy is active for this ray (compile-time so that the other
+// two thirds of the rays do not carry the parabola arithmetic).  start_in_cell: begin in the cell
+// the ray is in (secondary rays) instead of at the root (camera rays entering from outside).
+template <bool CURVED, class Pending>
+F3D_HD TraceHit march_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit, bool start_in_cell, Pending &pend) {
+    TraceHit res;
+    res.hit = false;
+    res.t = r.tmax;
+    res.n = V3{0.0f, 0.0f, 0.0f};
+    pend.note(2 | (any_hit ? 1 : 0) | (CURVED ? 4 : 0));  // statistics hook: a new ray starts
     const uint32_t top = T.mip_count - 1u;
-    pend.note(3 | (r.c2 != 0.0f ? 4 : 0));  // statistics hook: a new any-hit ray starts
     // root slab interval (:288-297 for the root node)
     float t_cur;
     {
@@ -68,28 +71,25 @@ F3D_HD bool terrain_occluded_march(const TerrainDev &T, const RayCtx &r, Pending
         const float bz = (plane_at(T.origin_z, T.cell_h, T.spacing_z) - r.o.z) * r.inv_z;
         const float lo = f_max(f_max(f_min(ax, bx), f_min(az, bz)), r.tmin);
         const float hi = f_min(f_min(f_max(ax, bx), f_max(az, bz)), r.tmax);
-        if (lo > hi) return false;
+        if (lo > hi) return res;
         t_cur = lo;
     }
     const bool x_forward = !(r.d.x < 0.0f), z_forward = !(r.d.z < 0.0f);
-    // Start in the CELL the ray is in at t_cur instead of walking down from the root: for a
-    // secondary ray (origin on the surface) the ~11 levels above its cell would all pass their
-    // band tests anyway.  The cell is located from the position and then validated by its own
-    // slab interval in the first iteration; if it does not contain t_cur (position rounded across
-    // a cell boundary) the march restarts from the root.
-    uint32_t level = 0u, nx, nz;
-    {
+    uint32_t level = top, nx = 0u, nz = 0u;
+    bool unverified_start = false;
+    if (start_in_cell) {
         const float fx = f_floor((f_fma(t_cur, r.d.x, r.o.x) - T.origin_x) * T.inv_spacing_x);
         const float fz = f_floor((f_fma(t_cur, r.d.z, r.o.z) - T.origin_z) * T.inv_spacing_z);
         nx = sat_u32(fx);
         nz = sat_u32(fz);
         nx = nx < T.cell_w - 1u ? nx : T.cell_w - 1u;
         nz = nz < T.cell_h - 1u ? nz : T.cell_h - 1u;
+        level = 0u;
+        unverified_start = true;
     }
-    bool unverified_start = true;
     for (;;) {
         pend.note(0);
-        // node extent in cells, clamped at ragged edges (:282-286)
+        // node extent in cells, clamped at ragged edges (:282-286), and its four plane parameters
         const uint32_t cx0 = nx << level, cz0 = nz << level;
         uint32_t cx1 = (nx + 1u) << level, cz1 = (nz + 1u) << level;
         cx1 = cx1 < T.cell_w ? cx1 : T.cell_w;
@@ -99,78 +99,73 @@ F3D_HD bool terrain_occluded_march(const TerrainDev &T, const RayCtx &r, Pending
         const float tz0 = (plane_at(T.origin_z, cz0, T.spacing_z) - r.o.z) * r.inv_z;
         const float tz1 = (plane_at(T.origin_z, cz1, T.spacing_z) - r.o.z) * r.inv_z;
         const float x_out = f_max(tx0, tx1), z_out = f_max(tz0, tz1);
+        const float enter = f_max(f_min(tx0, tx1), f_min(tz0, tz1)), exit = f_min(x_out, z_out);
         if (unverified_start) {
             unverified_start = false;
-            const float enter = f_max(f_min(tx0, tx1), f_min(tz0, tz1));
-            if (!(enter <= t_cur && t_cur <= f_min(x_out, z_out))) {  // not the cell the ray is in
+            if (!(enter <= t_cur && t_cur <= exit)) {  // position rounded across a cell boundary
                 level = top;
                 nx = 0u;
                 nz = 0u;
                 continue;
             }
         }
-        const float lo = f_max(f_max(f_min(tx0, tx1), f_min(tz0, tz1)), r.tmin);
-        const float hi = f_min(f_min(x_out, z_out), r.tmax);
-        bool skip = lo > hi;  // the ray misses this node altogether (:297)
-        float mn, mx;
-        LeafRec leaf{};
-        if (!skip) {
-            node_band(T, level, nx, nz, pend, mn, mx, leaf);
-            skip = band_rejects(r, lo, hi, mn, mx);  // :301-304
-        }
-        if (!skip) {
-            if (level == 0u) {
-                float t;
-                if (leaf_solve(T, r, leaf, nx, nz, lo, hi, true, t) && t < r.tmax) return true;
-                skip = true;  // leaf done: move on along the ray
-            } else {
-                // descend into the child the ray is in at t_cur: it has crossed the child boundary
-                // plane iff that plane's parameter is <= t_cur
-                const uint32_t cl = level - 1u;
-                const uint32_t xm = (2u * nx + 1u) << cl, zm = (2u * nz + 1u) << cl;
-                uint32_t ix = x_forward ? 0u : 1u, iz = z_forward ? 0u : 1u;  // entry-side child
-                if (xm < T.cell_w) {
-                    const float txm = (plane_at(T.origin_x, xm, T.spacing_x) - r.o.x) * r.inv_x;
-                    if (txm <= t_cur) ix ^= 1u;
-                } else {
-                    ix = 0u;  // the far half is outside the cell grid
-                }
-                if (zm < T.cell_h) {
-                    const float tzm = (plane_at(T.origin_z, zm, T.spacing_z) - r.o.z) * r.inv_z;
-                    if (tzm <= t_cur) iz ^= 1u;
-                } else {
-                    iz = 0u;
-                }
-                nx = 2u * nx + ix;
-                nz = 2u * nz + iz;
-                level = cl;
-                continue;
+        const float lo = f_max(enter, r.tmin), hi = f_min(exit, r.tmax);
+        // the node's (min,max) band: one 8-byte record of the row-major table of its level
+        uint32_t band_offset, band_shift;
+        pend.band_entry(T, level, band_offset, band_shift);
+        const NodeRec band = T.bands[band_offset + (nz << band_shift) + nx];
+        bool skip = lo > hi || march_band_rejects<CURVED>(r, lo, hi, band.mn, band.mx);  // :297, :301-304
+        if (!skip && level == 0u) {
+            pend.note(1);
+            const LeafRec leaf = T.leaves[tiled_index(nx, nz, T.tiles_x[0])];
+            float t;
+            if (leaf_solve(T, r, leaf, nx, nz, lo, hi, any_hit, t) && t < res.t) {
+                res.hit = true;
+                res.t = t;
+                res.n = leaf_normal(T, leaf, along(r.o, t, r.d), nx, nz);
+                return res;  // first hit along the ray is final (see the header)
             }
+            skip = true;  // leaf done: move on along the ray
         }
-        // ---- step across the exit boundary of this node ----
-        const float t_exit = f_min(x_out, z_out);
-        if (!(t_exit < r.tmax)) return false;
+        if (!skip) {
+            // DOWN into the child the ray is in at t_cur: it has passed the child boundary plane iff
+            // that plane's parameter is <= t_cur
+            const uint32_t cl = level - 1u;
+            const uint32_t xm = (2u * nx + 1u) << cl, zm = (2u * nz + 1u) << cl;
+            const float txm = (plane_at(T.origin_x, xm, T.spacing_x) - r.o.x) * r.inv_x;
+            const float tzm = (plane_at(T.origin_z, zm, T.spacing_z) - r.o.z) * r.inv_z;
+            uint32_t ix = (x_forward != (txm <= t_cur)) ? 0u : 1u;  // forward & not passed, or backward & passed
+            uint32_t iz = (z_forward != (tzm <= t_cur)) ? 0u : 1u;
+            if (!(xm < T.cell_w)) ix = 0u;  // the far half lies outside the cell grid
+            if (!(zm < T.cell_h)) iz = 0u;
+            nx = 2u * nx + ix;
+            nz = 2u * nz + iz;
+            level = cl;
+            continue;
+        }
+        // ---- across the exit boundary of this node ----
+        if (!(exit < r.tmax)) return res;
         const bool cross_x = x_out <= z_out, cross_z = z_out <= x_out;
         const uint32_t px = nx, pz = nz;
         if (cross_x) {
             if (x_forward) {
                 nx = nx + 1u;
-                if ((nx << level) >= T.cell_w) return false;
+                if ((nx << level) >= T.cell_w) return res;
             } else {
-                if (nx == 0u) return false;
+                if (nx == 0u) return res;
                 nx = nx - 1u;
             }
         }
         if (cross_z) {
             if (z_forward) {
                 nz = nz + 1u;
-                if ((nz << level) >= T.cell_h) return false;
+                if ((nz << level) >= T.cell_h) return res;
             } else {
-                if (nz == 0u) return false;
+                if (nz == 0u) return res;
                 nz = nz - 1u;
             }
         }
-        t_cur = f_max(t_cur, t_exit);
+        t_cur = f_max(t_cur, exit);
         // leaving the parent as well: continue one level up (the parent-level neighbour is new)
         if (level < top && ((nx >> 1) != (px >> 1) || (nz >> 1) != (pz >> 1))) {
             nx >>= 1;
@@ -178,6 +173,13 @@ F3D_HD bool terrain_occluded_march(const TerrainDev &T, const RayCtx &r, Pending
             level = level + 1u;
         }
     }
+}
+
+// Curvature is a per-ray policy AND a per-render switch (wave-uniform): pick the instantiation.
+template <class Pending>
+F3D_HD TraceHit march_ray(const TerrainDev &T, const RayCtx &r, bool any_hit, bool start_in_cell, Pending &pend) {
+    if (r.c2 != 0.0f || r.has_vertex) return march_terrain<true>(T, r, any_hit, start_in_cell, pend);
+    return march_terrain<false>(T, r, any_hit, start_in_cell, pend);
 }
 
 }  // namespace f3d

@@ -55,6 +55,12 @@ struct TerrainDev {
     const NodeRec *nodes;   // levels 1.. back to back, each tiled
     uint32_t node_offset[kMaxLevels];  // record offset of level l (l >= 1) inside `nodes`
     uint32_t tiles_x[kMaxLevels];      // tiles per row of level l (l = 0 -> leaf table)
+    // (min,max)*exaggeration of EVERY level (0 = per cell), row-major with a power-of-two pitch:
+    // record (x, z) of level l is bands[band_offset[l] + (z << band_shift[l]) + x].  This is the
+    // table the stackless march reads (one 8-byte record per step, 2-instruction address).
+    const NodeRec *bands;
+    uint32_t band_offset[kMaxLevels];
+    uint32_t band_shift[kMaxLevels];
     uint32_t mip_count;                // levels of the reference chain (incl. level 0)
     uint32_t cell_w, cell_h;
     float origin_x, origin_z, spacing_x, spacing_z, inv_spacing_x, inv_spacing_z;

@@ -191,6 +191,9 @@ struct TableLayout {
     uint32_t node_offset[kMaxLevels]{};
     uint64_t leaf_count = 0, node_count = 0;
     uint32_t cell_w = 0, cell_h = 0;
+    // row-major band tables of the march (all levels, pitch = level_w = 2^band_shift)
+    uint32_t band_offset[kMaxLevels]{}, band_shift[kMaxLevels]{};
+    uint64_t band_count = 0;
 };
 
 inline TableLayout table_layout(uint32_t w, uint32_t h) {
@@ -217,6 +220,13 @@ inline TableLayout table_layout(uint32_t w, uint32_t h) {
         lh = lh / 2 > 1 ? lh / 2 : 1;
     }
     t.leaf_count = (uint64_t)t.dim_x[0] * t.dim_y[0];
+    for (uint32_t l = 0; l < t.levels; l++) {
+        uint32_t shift = 0;
+        while ((1u << shift) < t.level_w[l]) shift++;
+        t.band_offset[l] = (uint32_t)t.band_count;
+        t.band_shift[l] = shift;
+        t.band_count += (uint64_t)t.level_w[l] * t.level_h[l];
+    }
     return t;
 }
 
@@ -224,10 +234,28 @@ inline void apply_layout(const TableLayout &t, TerrainDev &dev) {
     for (uint32_t l = 0; l < kMaxLevels; l++) {
         dev.node_offset[l] = t.node_offset[l];
         dev.tiles_x[l] = t.tiles_x[l];
+        dev.band_offset[l] = t.band_offset[l];
+        dev.band_shift[l] = t.band_shift[l];
     }
     dev.mip_count = t.levels;
     dev.cell_w = t.cell_w;
     dev.cell_h = t.cell_h;
+}
+
+inline BandBuildParams band_build_params(const TableLayout &t, uint32_t l, const LeafRec *leaves, const NodeRec *nodes,
+                                         NodeRec *bands) {
+    BandBuildParams b{};
+    b.leaves = leaves;
+    b.src = l >= 1 ? nodes + t.node_offset[l] : nullptr;
+    b.dst = bands + t.band_offset[l];
+    b.level = l;
+    b.width = t.level_w[l];
+    b.height = t.level_h[l];
+    b.shift = t.band_shift[l];
+    b.src_tiles_x = t.tiles_x[l];
+    b.cell_w = t.cell_w;
+    b.cell_h = t.cell_h;
+    return b;
 }
 
 inline PyramidBuildParams leaf_build_params(const TableLayout &t, const float *heights, uint32_t w, uint32_t h,

@@ -87,7 +87,12 @@ F3D_HD SurfaceHit closest_hit(const FrameParams &P, V3 o, float tmin, V3 d, floa
         }
     }
     RayCtx r = make_ray(P.terrain, o, tmin, d, best.t, false);
-    TraceHit th = trace_terrain(P.terrain, r, false, pend);
+#if defined(F3D_TRAVERSAL_DESCENT)
+    TraceHit th = trace_terrain(P.terrain, r, false, pend);  // the reference-shaped sorted descent
+#else
+    // camera rays enter the footprint from outside: the march starts at the root
+    TraceHit th = march_terrain<false>(P.terrain, r, false, false, pend);
+#endif
     if (th.hit && th.t < best.t) {
         best.kind = 1u;
         best.t = th.t;
@@ -116,18 +121,19 @@ F3D_HD bool occluded(const FrameParams &P, V3 o, float tmin, V3 d, float tmax, b
         }
     }
     RayCtx r = make_ray(P.terrain, o, tmin, d, best_t, apply_curvature);
-#if defined(F3D_OCCLUSION_DESCENT)
+#if defined(F3D_TRAVERSAL_DESCENT)
     TraceHit th = trace_terrain(P.terrain, r, true, pend);  // the reference-shaped sorted descent
+#else
+    // occlusion rays start on the surface: the march starts in the origin's cell.  Only sun
+    // rays carry the curvature policy (apply_curvature is a compile-time constant per call site).
+    TraceHit th = apply_curvature ? march_ray(P.terrain, r, true, true, pend)
+                                  : march_terrain<false>(P.terrain, r, true, true, pend);
+#endif
     if (th.hit && th.t < best_t) {
         best_t = th.t;
         hit = true;
     }
     return hit && best_t < 1e30f;
-#else
-    // only the boolean is needed, and for any-hit rays it does not depend on the visiting order:
-    // stackless min-max march (f3d_march.h); a terrain hit implies t < best_t <= tmax
-    return hit || terrain_occluded_march(P.terrain, r, pend);
-#endif
 }
 
 // terrain_env_radiance, hybrid_terrain_traversal.wgsl:392-405

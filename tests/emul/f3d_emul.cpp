@@ -39,6 +39,10 @@ struct ArrayPending {
     bool leaf_gate(bool) const { return true; }  // one lane at a time: the gate is always open
     void put(uint32_t l, uint32_t v) { w[l] = v; }
     uint32_t get(uint32_t l) const { return w[l]; }
+    void band_entry(const TerrainDev &T, uint32_t l, uint32_t &offset, uint32_t &shift) const {
+        offset = T.band_offset[l];
+        shift = T.band_shift[l];
+    }
     void level_entry(const TerrainDev &T, uint32_t l, uint32_t &offset, uint32_t &tiles_x) const {
         offset = T.node_offset[l];
         tiles_x = T.tiles_x[l];
@@ -48,7 +52,13 @@ struct ArrayPending {
 struct HostTables {
     TableLayout L;
     std::vector<LeafRec> leaves;
-    std::vector<NodeRec> nodes;
+    std::vector<NodeRec> nodes, bands;
+    void attach(TerrainDev &T) const {
+        apply_layout(L, T);
+        T.leaves = leaves.data();
+        T.nodes = nodes.data();
+        T.bands = bands.data();
+    }
 };
 
 HostTables build_tables_host(const float *heights, uint32_t w, uint32_t h, float exaggeration) {
@@ -64,6 +74,12 @@ HostTables build_tables_host(const float *heights, uint32_t w, uint32_t h, float
         for (uint32_t y = 0; y < b.dst_dim_y; y++)
             for (uint32_t x = 0; x < b.dst_dim_x; x++) level_build_at(b, x, y);
     }
+    t.bands.resize(t.L.band_count);
+    for (uint32_t l = 0; l < t.L.levels; l++) {
+        BandBuildParams b = band_build_params(t.L, l, t.leaves.data(), t.nodes.data(), t.bands.data());
+        for (uint32_t z = 0; z < b.height; z++)
+            for (uint32_t x = 0; x < b.width; x++) band_build_at(b, x, z);
+    }
     return t;
 }
 }  // namespace
@@ -77,9 +93,7 @@ int emul_trace_batch(const float *heights, uint32_t w, uint32_t h, float origin_
     try {
         HostTables t = build_tables_host(heights, w, h, exaggeration);
         TerrainDev T{};
-        apply_layout(t.L, T);
-        T.leaves = t.leaves.data();
-        T.nodes = t.nodes.data();
+        t.attach(T);
         T.origin_x = origin_x;
         T.origin_z = origin_z;
         T.spacing_x = spacing_x;
@@ -94,10 +108,8 @@ int emul_trace_batch(const float *heights, uint32_t w, uint32_t h, float origin_
             ArrayPending pend;
             RayCtx rc = make_ray(T, V3{r[0], r[1], r[2]}, r[3], V3{r[4], r[5], r[6]}, r[7], apply_curvature != 0);
             TraceHit hit;
-            if (any_hit == 2) {  // stackless occlusion march: boolean only
-                hit.hit = terrain_occluded_march(T, rc, pend);
-                hit.t = 0.0f;
-                hit.n = V3{0.0f, 0.0f, 0.0f};
+            if ((any_hit & 3) >= 2) {  // stackless march: 2 any hit, 3 closest; +4 start in the origin cell
+                hit = march_ray(T, rc, (any_hit & 3) == 2, (any_hit & 4) != 0, pend);
             } else {
                 hit = trace_terrain(T, rc, any_hit != 0, pend);
             }
@@ -165,9 +177,7 @@ int emul_render(const f3d_terrain_ref_desc *d, uint32_t row_begin, uint32_t row_
         FrameParams P{};
         const bool require_valid = fill_uniforms(*d, P);
         HostTables t = build_tables_host(d->heights, d->dem_width, d->dem_height, d->exaggeration);
-        apply_layout(t.L, P.terrain);
-        P.terrain.leaves = t.leaves.data();
-        P.terrain.nodes = t.nodes.data();
+        t.attach(P.terrain);
         std::vector<float> env4, mesh4;
         if (d->env_map) {
             env4 = pad_rgb_to_rgba(d->env_map, (size_t)d->env_width * d->env_height, 1.0f);
@@ -298,9 +308,7 @@ void *emul_session_create(const f3d_terrain_ref_desc *d, uint32_t row_begin, uin
         validate_scene(*d);
         s->require_valid = fill_uniforms(*d, s->P);
         s->tables = build_tables_host(d->heights, d->dem_width, d->dem_height, d->exaggeration);
-        apply_layout(s->tables.L, s->P.terrain);
-        s->P.terrain.leaves = s->tables.leaves.data();
-        s->P.terrain.nodes = s->tables.nodes.data();
+        s->tables.attach(s->P.terrain);
         if (d->mesh_vertices) {
             s->mesh4 = pad_rgb_to_rgba(d->mesh_vertices, d->mesh_vertex_count, 0.0f);
             s->mesh_idx.assign(d->mesh_indices, d->mesh_indices + d->mesh_index_count);
