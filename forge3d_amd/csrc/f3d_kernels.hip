@@ -32,6 +32,25 @@ struct LdsPending {
         const unsigned long long leaf = __ballot(at_leaf), inner = __ballot(!at_leaf);
         return (uint32_t)__popcll(leaf) >= leaf_quorum || inner == 0ull;
     }
+    // ---- deferred leaf FIFO of the march (f3d_march.h): 3 words per entry in the lane's column ----
+    __device__ __forceinline__ void fifo_put(uint32_t k, uint32_t cell, float lo, float hi) {
+        col[(3u * k) * kWave] = cell;
+        col[(3u * k + 1u) * kWave] = f_bits(lo);
+        col[(3u * k + 2u) * kWave] = f_bits(hi);
+    }
+    __device__ __forceinline__ void fifo_get(uint32_t k, uint32_t &cell, float &lo, float &hi) const {
+        cell = col[(3u * k) * kWave];
+        lo = f_from_bits(col[(3u * k + 1u) * kWave]);
+        hi = f_from_bits(col[(3u * k + 2u) * kWave]);
+    }
+    // drain now?  enough lanes have a leaf queued, or a FIFO is full, or nobody marches any more
+    __device__ __forceinline__ bool flush_now(uint32_t queued, bool marching) const {
+        const unsigned long long have = __ballot(queued != 0u);
+        if (have == 0ull) return false;
+        return (uint32_t)__popcll(have) >= leaf_quorum || __ballot(queued >= kLeafFifo) != 0ull ||
+               __ballot(marching) == 0ull;
+    }
+    __device__ __forceinline__ bool any(bool pred) const { return __ballot(pred) != 0ull; }
     __device__ __forceinline__ void band_entry(const TerrainDev &, uint32_t level, uint32_t &offset,
                                                uint32_t &shift) const {
         const uint2 e = *reinterpret_cast<const uint2 *>(table + 4u * level);
@@ -54,7 +73,7 @@ __device__ __forceinline__ LdsPending make_pending(uint32_t *lds, const TerrainD
         e[3] = T.tiles_x[threadIdx.x];
     }
     __syncthreads();
-    return LdsPending{lds + threadIdx.x, lds + kMaxLevels * kWave, T.leaf_quorum ? T.leaf_quorum : 1u};
+    return LdsPending{lds + threadIdx.x, lds + kMaxLevels * kWave, T.leaf_quorum ? T.leaf_quorum : kDefaultLeafQuorum};
 }
 
 __device__ __forceinline__ bool tile_pixel(const FrameParams &P, uint32_t &gx, uint32_t &gy) {

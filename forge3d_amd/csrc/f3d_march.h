@@ -51,19 +51,34 @@ F3D_HD bool march_band_rejects(const RayCtx &r, float t0, float t1, float mn, fl
     return lo > mx || f_max(y0, y1) < mn;
 }
 
+// Leaf solves are DEFERRED.  The solve (~170 VALU instructions with its divisions and square
+// root) is wanted by ~5 % of the lane-steps, but in a 64-lane wave some lane wants it in almost every
+// iteration, so an in-line solve makes every iteration pay for it at 1-3 active lanes.  Instead a lane
+// that reaches a leaf whose band test passes appends (cell, lo, hi) to a small per-lane FIFO and keeps
+// marching as if the leaf had missed; the wave drains the FIFOs together when enough lanes have
+// something queued (Ctx::flush_now, a ballot), when a FIFO is full, or when nobody marches any more.
+// This is exact: before the first hit every leaf is judged with best-t = tmax, so its verdict does
+// not depend on when it is evaluated; any-hit rays need the OR, closest-hit rays the FIRST queued
+// leaf (ray order = FIFO order) that hits.  The price is a few extra march steps for rays whose hit
+// is sitting in the FIFO.
+constexpr uint32_t kLeafFifo = 4;  // entries per lane
+
 // CURVED: the sun-ray curvature policy is active for this ray (compile-time so that the other
 // two thirds of the rays do not carry the parabola arithmetic).  start_in_cell: begin in the cell
 // the ray is in (secondary rays) instead of at the root (camera rays entering from outside).
-template <bool CURVED, class Pending>
-F3D_HD TraceHit march_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit, bool start_in_cell, Pending &pend) {
+// Ctx provides: note(), band_entry(), the FIFO storage fifo_put/fifo_get, and the wave votes
+// flush_now(queued, marching) / any(pred).
+template <bool CURVED, class Ctx>
+F3D_HD TraceHit march_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit, bool start_in_cell, Ctx &ctx) {
     TraceHit res;
     res.hit = false;
     res.t = r.tmax;
     res.n = V3{0.0f, 0.0f, 0.0f};
-    pend.note(2 | (any_hit ? 1 : 0) | (CURVED ? 4 : 0));  // statistics hook: a new ray starts
+    ctx.note(2 | (any_hit ? 1 : 0) | (CURVED ? 4 : 0));  // statistics hook: a new ray starts
     const uint32_t top = T.mip_count - 1u;
+    bool marching = true;
     // root slab interval (:288-297 for the root node)
-    float t_cur;
+    float t_cur = 0.0f;
     {
         const float ax = (plane_at(T.origin_x, 0u, T.spacing_x) - r.o.x) * r.inv_x;
         const float bx = (plane_at(T.origin_x, T.cell_w, T.spacing_x) - r.o.x) * r.inv_x;
@@ -71,7 +86,7 @@ F3D_HD TraceHit march_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit
         const float bz = (plane_at(T.origin_z, T.cell_h, T.spacing_z) - r.o.z) * r.inv_z;
         const float lo = f_max(f_max(f_min(ax, bx), f_min(az, bz)), r.tmin);
         const float hi = f_min(f_min(f_max(ax, bx), f_max(az, bz)), r.tmax);
-        if (lo > hi) return res;
+        if (lo > hi) marching = false;
         t_cur = lo;
     }
     const bool x_forward = !(r.d.x < 0.0f), z_forward = !(r.d.z < 0.0f);
@@ -87,92 +102,113 @@ F3D_HD TraceHit march_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit
         level = 0u;
         unverified_start = true;
     }
+    uint32_t queued = 0u;
     for (;;) {
-        pend.note(0);
-        // node extent in cells, clamped at ragged edges (:282-286), and its four plane parameters
-        const uint32_t cx0 = nx << level, cz0 = nz << level;
-        uint32_t cx1 = (nx + 1u) << level, cz1 = (nz + 1u) << level;
-        cx1 = cx1 < T.cell_w ? cx1 : T.cell_w;
-        cz1 = cz1 < T.cell_h ? cz1 : T.cell_h;
-        const float tx0 = (plane_at(T.origin_x, cx0, T.spacing_x) - r.o.x) * r.inv_x;
-        const float tx1 = (plane_at(T.origin_x, cx1, T.spacing_x) - r.o.x) * r.inv_x;
-        const float tz0 = (plane_at(T.origin_z, cz0, T.spacing_z) - r.o.z) * r.inv_z;
-        const float tz1 = (plane_at(T.origin_z, cz1, T.spacing_z) - r.o.z) * r.inv_z;
-        const float x_out = f_max(tx0, tx1), z_out = f_max(tz0, tz1);
-        const float enter = f_max(f_min(tx0, tx1), f_min(tz0, tz1)), exit = f_min(x_out, z_out);
-        if (unverified_start) {
-            unverified_start = false;
-            if (!(enter <= t_cur && t_cur <= exit)) {  // position rounded across a cell boundary
+        if (marching) {
+            ctx.note(0);
+            // node extent in cells, clamped at ragged edges (:282-286), and its four plane parameters
+            const uint32_t cx0 = nx << level, cz0 = nz << level;
+            uint32_t cx1 = (nx + 1u) << level, cz1 = (nz + 1u) << level;
+            cx1 = cx1 < T.cell_w ? cx1 : T.cell_w;
+            cz1 = cz1 < T.cell_h ? cz1 : T.cell_h;
+            const float tx0 = (plane_at(T.origin_x, cx0, T.spacing_x) - r.o.x) * r.inv_x;
+            const float tx1 = (plane_at(T.origin_x, cx1, T.spacing_x) - r.o.x) * r.inv_x;
+            const float tz0 = (plane_at(T.origin_z, cz0, T.spacing_z) - r.o.z) * r.inv_z;
+            const float tz1 = (plane_at(T.origin_z, cz1, T.spacing_z) - r.o.z) * r.inv_z;
+            const float x_out = f_max(tx0, tx1), z_out = f_max(tz0, tz1);
+            const float enter = f_max(f_min(tx0, tx1), f_min(tz0, tz1)), exit = f_min(x_out, z_out);
+            if (unverified_start && !(enter <= t_cur && t_cur <= exit)) {
+                // the position was rounded across a cell boundary: walk down from the root instead
                 level = top;
                 nx = 0u;
                 nz = 0u;
-                continue;
-            }
-        }
-        const float lo = f_max(enter, r.tmin), hi = f_min(exit, r.tmax);
-        // the node's (min,max) band: one 8-byte record of the row-major table of its level
-        uint32_t band_offset, band_shift;
-        pend.band_entry(T, level, band_offset, band_shift);
-        const NodeRec band = T.bands[band_offset + (nz << band_shift) + nx];
-        bool skip = lo > hi || march_band_rejects<CURVED>(r, lo, hi, band.mn, band.mx);  // :297, :301-304
-        if (!skip && level == 0u) {
-            pend.note(1);
-            const LeafRec leaf = T.leaves[tiled_index(nx, nz, T.tiles_x[0])];
-            float t;
-            if (leaf_solve(T, r, leaf, nx, nz, lo, hi, any_hit, t) && t < res.t) {
-                res.hit = true;
-                res.t = t;
-                res.n = leaf_normal(T, leaf, along(r.o, t, r.d), nx, nz);
-                return res;  // first hit along the ray is final (see the header)
-            }
-            skip = true;  // leaf done: move on along the ray
-        }
-        if (!skip) {
-            // DOWN into the child the ray is in at t_cur: it has passed the child boundary plane iff
-            // that plane's parameter is <= t_cur
-            const uint32_t cl = level - 1u;
-            const uint32_t xm = (2u * nx + 1u) << cl, zm = (2u * nz + 1u) << cl;
-            const float txm = (plane_at(T.origin_x, xm, T.spacing_x) - r.o.x) * r.inv_x;
-            const float tzm = (plane_at(T.origin_z, zm, T.spacing_z) - r.o.z) * r.inv_z;
-            uint32_t ix = (x_forward != (txm <= t_cur)) ? 0u : 1u;  // forward & not passed, or backward & passed
-            uint32_t iz = (z_forward != (tzm <= t_cur)) ? 0u : 1u;
-            if (!(xm < T.cell_w)) ix = 0u;  // the far half lies outside the cell grid
-            if (!(zm < T.cell_h)) iz = 0u;
-            nx = 2u * nx + ix;
-            nz = 2u * nz + iz;
-            level = cl;
-            continue;
-        }
-        // ---- across the exit boundary of this node ----
-        if (!(exit < r.tmax)) return res;
-        const bool cross_x = x_out <= z_out, cross_z = z_out <= x_out;
-        const uint32_t px = nx, pz = nz;
-        if (cross_x) {
-            if (x_forward) {
-                nx = nx + 1u;
-                if ((nx << level) >= T.cell_w) return res;
             } else {
-                if (nx == 0u) return res;
-                nx = nx - 1u;
+                const float lo = f_max(enter, r.tmin), hi = f_min(exit, r.tmax);
+                // the node's (min,max) band: one 8-byte record of the row-major table of its level
+                uint32_t band_offset, band_shift;
+                ctx.band_entry(T, level, band_offset, band_shift);
+                const NodeRec band = T.bands[band_offset + (nz << band_shift) + nx];
+                const bool pass = !(lo > hi) && !march_band_rejects<CURVED>(r, lo, hi, band.mn, band.mx);  // :297-304
+                if (pass && level > 0u) {
+                    // DOWN into the child the ray is in at t_cur: it has passed the child boundary plane
+                    // iff that plane's parameter is <= t_cur
+                    const uint32_t cl = level - 1u;
+                    const uint32_t xm = (2u * nx + 1u) << cl, zm = (2u * nz + 1u) << cl;
+                    const float txm = (plane_at(T.origin_x, xm, T.spacing_x) - r.o.x) * r.inv_x;
+                    const float tzm = (plane_at(T.origin_z, zm, T.spacing_z) - r.o.z) * r.inv_z;
+                    uint32_t ix = (x_forward != (txm <= t_cur)) ? 0u : 1u;
+                    uint32_t iz = (z_forward != (tzm <= t_cur)) ? 0u : 1u;
+                    if (!(xm < T.cell_w)) ix = 0u;  // the far half lies outside the cell grid
+                    if (!(zm < T.cell_h)) iz = 0u;
+                    nx = 2u * nx + ix;
+                    nz = 2u * nz + iz;
+                    level = cl;
+                } else {
+                    if (pass) {  // a leaf to solve: queue it and march on as if it had missed
+                        ctx.note(1);
+                        ctx.fifo_put(queued, nx | (nz << 16), lo, hi);
+                        queued++;
+                    }
+                    // ---- across the exit boundary of this node ----
+                    const bool cross_x = x_out <= z_out, cross_z = z_out <= x_out;
+                    const uint32_t px = nx, pz = nz;
+                    bool left = !(exit < r.tmax);
+                    if (cross_x) {
+                        if (x_forward) {
+                            nx = nx + 1u;
+                            left = left || (nx << level) >= T.cell_w;
+                        } else {
+                            left = left || nx == 0u;
+                            nx = nx - 1u;
+                        }
+                    }
+                    if (cross_z) {
+                        if (z_forward) {
+                            nz = nz + 1u;
+                            left = left || (nz << level) >= T.cell_h;
+                        } else {
+                            left = left || nz == 0u;
+                            nz = nz - 1u;
+                        }
+                    }
+                    if (left) {
+                        marching = false;  // the ray is out of the footprint (or past tmax)
+                    } else {
+                        t_cur = f_max(t_cur, exit);
+                        // leaving the parent as well: continue one level up
+                        if (level < top && ((nx >> 1) != (px >> 1) || (nz >> 1) != (pz >> 1))) {
+                            nx >>= 1;
+                            nz >>= 1;
+                            level = level + 1u;
+                        }
+                    }
+                }
             }
+            unverified_start = false;
         }
-        if (cross_z) {
-            if (z_forward) {
-                nz = nz + 1u;
-                if ((nz << level) >= T.cell_h) return res;
-            } else {
-                if (nz == 0u) return res;
-                nz = nz - 1u;
+        // ---- drain the leaf FIFOs when the wave says so ----
+        if (ctx.flush_now(queued, marching)) {
+            for (uint32_t k = 0u; ctx.any(k < queued && !res.hit); k++) {
+                if (k < queued && !res.hit) {
+                    uint32_t cell;
+                    float lo, hi;
+                    ctx.fifo_get(k, cell, lo, hi);
+                    const uint32_t cx = cell & 0xFFFFu, cz = cell >> 16;
+                    const LeafRec leaf = T.leaves[tiled_index(cx, cz, T.tiles_x[0])];
+                    float t;
+                    if (leaf_solve(T, r, leaf, cx, cz, lo, hi, any_hit, t) && t < res.t) {
+                        res.hit = true;  // first hit in ray order is final (see the header)
+                        res.t = t;
+                        res.n = leaf_normal(T, leaf, along(r.o, t, r.d), cx, cz);
+                        marching = false;
+                    }
+                }
             }
+            queued = 0u;
         }
-        t_cur = f_max(t_cur, exit);
-        // leaving the parent as well: continue one level up (the parent-level neighbour is new)
-        if (level < top && ((nx >> 1) != (px >> 1) || (nz >> 1) != (pz >> 1))) {
-            nx >>= 1;
-            nz >>= 1;
-            level = level + 1u;
-        }
+        if (!ctx.any(marching || queued != 0u)) break;
     }
+    return res;
 }
 
 // Curvature is a per-ray policy AND a per-render switch (wave-uniform): pick the instantiation.

@@ -37,6 +37,23 @@ struct ArrayPending {
         }
     }
     bool leaf_gate(bool) const { return true; }  // one lane at a time: the gate is always open
+    // deferred leaf FIFO of the march: a single lane drains only when its FIFO is full or its march
+    // has ended, i.e. as LATE as possible -- the opposite extreme of the device's wave vote, so the
+    // order-independence the deferral relies on is exercised by every CPU parity test
+    uint32_t q_cell[kLeafFifo];
+    float q_lo[kLeafFifo], q_hi[kLeafFifo];
+    void fifo_put(uint32_t k, uint32_t cell, float lo, float hi) {
+        q_cell[k] = cell;
+        q_lo[k] = lo;
+        q_hi[k] = hi;
+    }
+    void fifo_get(uint32_t k, uint32_t &cell, float &lo, float &hi) const {
+        cell = q_cell[k];
+        lo = q_lo[k];
+        hi = q_hi[k];
+    }
+    bool flush_now(uint32_t queued, bool marching) const { return queued >= kLeafFifo || (!marching && queued != 0u); }
+    bool any(bool pred) const { return pred; }
     void put(uint32_t l, uint32_t v) { w[l] = v; }
     uint32_t get(uint32_t l) const { return w[l]; }
     void band_entry(const TerrainDev &T, uint32_t l, uint32_t &offset, uint32_t &shift) const {
