@@ -115,17 +115,6 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return v;
 }
 
-// Wave-ballot gate of the ray state machine (f3d_shade.h): run the shading transition only
-// when at least MIN_WAITING lanes are waiting for one, or nobody is traversing any more.
-template <int MIN_WAITING>
-struct DeviceWave {
-    __device__ __forceinline__ bool gate(bool need, bool traversing) const {
-        const unsigned long long n = __ballot(need), t = __ballot(traversing);
-        return n != 0ull && (__popcll(n) >= MIN_WAITING || t == 0ull);
-    }
-    __device__ __forceinline__ bool all_finished(bool finished) const { return __ballot(!finished) == 0ull; }
-};
-
 __device__ __forceinline__ void publish_window_stats(const FrameParams &P, bool active, float m2) {
     // max over pixels of the Welford m2 (render_terrain.rs:1211-1226); m2 >= 0 so the bit
     // pattern orders like the value; non-finite values are flagged separately.
@@ -141,8 +130,7 @@ __device__ __forceinline__ void publish_window_stats(const FrameParams &P, bool 
     }
 }
 
-// VARIANT 0: reference-shaped nested sample loop.  VARIANT n > 0: per-lane ray state
-// machine whose transition gate waits for n lanes (n = 64: fully synchronous).
+// VARIANT is reserved for A/B builds (0 = the shipped kernel).
 // MIN_WAVES: waves per SIMD the register allocator must leave room for (1 = unconstrained).
 template <int VARIANT, int MIN_WAVES = 1>
 __global__ __launch_bounds__(kWave, MIN_WAVES) void k_frame(const FrameParams P) {
@@ -151,12 +139,7 @@ __global__ __launch_bounds__(kWave, MIN_WAVES) void k_frame(const FrameParams P)
     uint32_t gx = 0u, gy = 0u;
     const bool active = tile_pixel(P, gx, gy);
     float m2 = 0.0f;
-    if constexpr (VARIANT == 0) {
-        if (active) m2 = frame_pixel(P, gx, gy, pend);
-    } else {
-        DeviceWave<VARIANT> wave;
-        m2 = frame_pixel_sm(P, gx, gy, active, pend, wave);
-    }
+    if (active) m2 = frame_pixel(P, gx, gy, pend);
     if (P.collect_stats != 0u) publish_window_stats(P, active, m2);
 }
 
@@ -231,14 +214,11 @@ hipError_t launch_frame(const FrameParams &p, int variant, hipStream_t stream) {
     switch (variant % 1000) {
         case 0: hipLaunchKernelGGL((k_frame<0, 4>), grid, block, 0, stream, p); break;  // default
         case 101: hipLaunchKernelGGL((k_frame<0, 1>), grid, block, 0, stream, p); break;
-        case 1: hipLaunchKernelGGL(k_frame<1>, grid, block, 0, stream, p); break;
-        case 8: hipLaunchKernelGGL(k_frame<8>, grid, block, 0, stream, p); break;
-        case 16: hipLaunchKernelGGL(k_frame<16>, grid, block, 0, stream, p); break;
-        case 32: hipLaunchKernelGGL(k_frame<32>, grid, block, 0, stream, p); break;
-        case 64: hipLaunchKernelGGL(k_frame<64>, grid, block, 0, stream, p); break;
         case 104: hipLaunchKernelGGL((k_frame<0, 4>), grid, block, 0, stream, p); break;
         case 105: hipLaunchKernelGGL((k_frame<0, 5>), grid, block, 0, stream, p); break;
         case 106: hipLaunchKernelGGL((k_frame<0, 6>), grid, block, 0, stream, p); break;
+        case 107: hipLaunchKernelGGL((k_frame<0, 7>), grid, block, 0, stream, p); break;
+        case 108: hipLaunchKernelGGL((k_frame<0, 8>), grid, block, 0, stream, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

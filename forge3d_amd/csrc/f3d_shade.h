@@ -265,31 +265,33 @@ F3D_HD Reservoir temporal_merge(const Reservoir &rp, const Reservoir &rc) {
 
 // ---- one accumulation frame of one pixel ---------------------------------------------
 struct FrameHead {
-    Reservoir prev;  // merged + M-clamped history this frame shades from
-    V3 sun_dir;
-    float reuse_w;
+    bool prev_valid;  // the merged history carries a usable sun sample (:463-465)
+    float reuse_w;    // clamp(prev.weight, 0, 4) or 1
     uint32_t rng;
 };
 
-// Everything main_terrain does before its sample loop (:452-471), with the previous
-// frame's spatial reuse pass evaluated lazily for this pixel.
+// Everything main_terrain does before its sample loop (:452-471), with the previous frame's
+// spatial reuse pass evaluated lazily for this pixel.  The merged, M-clamped history is needed
+// again only by the temporal merge at the very end of the frame, so it is parked in this pixel's
+// slot of the OUTPUT reservoir buffer (which the same lane overwrites in frame_tail) instead of
+// occupying five registers across the whole sample loop.
 F3D_HD FrameHead frame_head(const FrameParams &P, uint32_t gx, uint32_t gy) {
     const size_t lp = (size_t)(gy - P.row_begin) * P.cam.width + gx;  // strip-local pixel
     const float4 g = P.gbuffer_n[lp];
-    FrameHead h;
-    h.prev = empty_reservoir();
-    if (P.frame_index > 0u) h.prev = spatial_reuse(P, P.res_in, gx, gy, P.frame_index - 1u, V3{g.x, g.y, g.z});
+    Reservoir prev = empty_reservoir();
+    if (P.frame_index > 0u) prev = spatial_reuse(P, P.res_in, gx, gy, P.frame_index - 1u, V3{g.x, g.y, g.z});
     // M-clamp, hybrid_terrain_traversal.wgsl:452-462
-    if (h.prev.m > kRestirMCap) {
-        const float scale = (float)kRestirMCap / (float)h.prev.m;
-        h.prev.w_sum = h.prev.w_sum * scale;
-        h.prev.m = kRestirMCap;
-        if (h.prev.target_pdf > 0.0f) h.prev.weight = h.prev.w_sum / ((float)h.prev.m * h.prev.target_pdf);
+    if (prev.m > kRestirMCap) {
+        const float scale = (float)kRestirMCap / (float)prev.m;
+        prev.w_sum = prev.w_sum * scale;
+        prev.m = kRestirMCap;
+        if (prev.target_pdf > 0.0f) prev.weight = prev.w_sum / ((float)prev.m * prev.target_pdf);
     }
-    const bool prev_valid = P.frame_index > 0u && h.prev.m > 0u && h.prev.weight > 0.0f &&
-                            h.prev.target_pdf > 0.0f && h.prev.directional;
-    h.sun_dir = prev_valid ? P.light.wi_reuse : P.light.wi;
-    h.reuse_w = prev_valid ? f_clamp(h.prev.weight, 0.0f, 4.0f) : 1.0f;
+    P.res_out[reservoir_index(P, gx, gy)] = pack(prev);
+    FrameHead h;
+    h.prev_valid = P.frame_index > 0u && prev.m > 0u && prev.weight > 0.0f && prev.target_pdf > 0.0f &&
+                   prev.directional;
+    h.reuse_w = h.prev_valid ? f_clamp(prev.weight, 0.0f, 4.0f) : 1.0f;
     h.rng = P.cam.seed_hi ^ (gx * 1664525u) ^ (gy * 1013904223u) ^ (P.frame_index * 92837111u) ^ P.cam.seed_lo;
     return h;
 }
@@ -307,14 +309,15 @@ F3D_HD void candidate_update(const FrameParams &P, Reservoir &cand, V3 n, V3 alb
 }
 
 // Everything after the sample loop (:549-574) plus the temporal pass; returns Welford m2.
-F3D_HD float frame_tail(const FrameParams &P, uint32_t gx, uint32_t gy, const Reservoir &prev, Reservoir cand,
-                        V3 radiance) {
+F3D_HD float frame_tail(const FrameParams &P, uint32_t gx, uint32_t gy, Reservoir cand, V3 radiance) {
     const size_t lp = (size_t)(gy - P.row_begin) * P.cam.width + gx;
     const float fspp = (float)P.spp;
     radiance = V3{radiance.x / fspp, radiance.y / fspp, radiance.z / fspp};
     if (cand.m > 0u && cand.w_sum > 0.0f && cand.target_pdf > 0.0f)
         cand.weight = cand.w_sum / ((float)cand.m * cand.target_pdf);
-    P.res_out[reservoir_index(P, gx, gy)] = pack(temporal_merge(prev, cand));
+    const size_t ri = reservoir_index(P, gx, gy);
+    const Reservoir prev = unpack(P.res_out[ri]);  // parked by frame_head
+    P.res_out[ri] = pack(temporal_merge(prev, cand));
 
     float4 am = P.accum_mean[lp];
     float wf_m2 = P.welford_m2[lp];
@@ -336,10 +339,12 @@ F3D_HD float frame_tail(const FrameParams &P, uint32_t gx, uint32_t gy, const Re
     return m2;
 }
 
-// Reference-shaped sample loop: primary, shadow and IBL traversals nested per sample.
+// The sample loop of main_terrain (:476-548): primary, sun-shadow and IBL-occlusion rays per sample.
+// (A per-lane ray state machine with ballot-gated shading transitions was measured at 0.5-0.7x of
+// this nested form on MI355X and removed -- profiles/README.md.)
 template <class Pending>
 F3D_HD float frame_pixel(const FrameParams &P, uint32_t gx, uint32_t gy, Pending &pend) {
-    FrameHead h = frame_head(P, gx, gy);
+    const FrameHead h = frame_head(P, gx, gy);
     uint32_t rng = h.rng;
     V3 radiance = V3{0.0f, 0.0f, 0.0f};
     Reservoir cand = empty_reservoir();
@@ -353,187 +358,33 @@ F3D_HD float frame_pixel(const FrameParams &P, uint32_t gx, uint32_t gy, Pending
             continue;
         }
         const V3 n = hit.n;
-        const V3 albedo = hit.kind == 1u ? P.light.albedo : V3{0.7f, 0.7f, 0.8f};
-        candidate_update(P, cand, n, albedo);
-
-        // sun through the merged reservoir, :517-532
-        V3 sun = V3{0.0f, 0.0f, 0.0f};
-        const float nd = f_max(dot(n, h.sun_dir), 0.0f);
+        const bool on_terrain = hit.kind == 1u;
         const V3 so = along(hit.p, 1e-3f, n);
-        if (nd > 0.0f) {
-            float vis = 1.0f;
-            if (P.light.shadows_enabled != 0u && occluded(P, so, 1e-3f, h.sun_dir, 1e30f, true, pend)) vis = 0.0f;
-            sun = (((albedo * P.light.color) * nd) * vis) * h.reuse_w;
+        {
+            const V3 albedo = on_terrain ? P.light.albedo : V3{0.7f, 0.7f, 0.8f};
+            candidate_update(P, cand, n, albedo);
+            // sun through the merged reservoir, :517-532.  (radiance + sun) + ibl is evaluated in
+            // that order, so the sun term can be added as soon as its shadow ray is back.
+            const V3 sun_dir = h.prev_valid ? P.light.wi_reuse : P.light.wi;
+            const float nd = f_max(dot(n, sun_dir), 0.0f);
+            V3 sun = V3{0.0f, 0.0f, 0.0f};
+            if (nd > 0.0f) {
+                float vis = 1.0f;
+                if (P.light.shadows_enabled != 0u && occluded(P, so, 1e-3f, sun_dir, 1e30f, true, pend)) vis = 0.0f;
+                sun = (((albedo * P.light.color) * nd) * vis) * h.reuse_w;
+            }
+            radiance = radiance + sun;
         }
         // one cosine-weighted IBL sample, :537-545
         const float u1 = rng_next(rng);
         const float u2 = rng_next(rng);
         const V3 ei = cosine_dir(n, u1, u2);
         const float env_vis = occluded(P, so, 1e-3f, ei, 1e30f, false, pend) ? 0.0f : 1.0f;
+        const V3 albedo = on_terrain ? P.light.albedo : V3{0.7f, 0.7f, 0.8f};
         const V3 ibl = (albedo * env_radiance(P.env, ei)) * env_vis;
-        radiance = (radiance + sun) + ibl;
+        radiance = radiance + ibl;
     }
-    return frame_tail(P, gx, gy, h.prev, cand, radiance);
-}
-
-// ---- the same frame as a per-lane ray state machine -----------------------------------
-// The nested form above makes every lane of a wave wait at each of the 3*spp phase
-// boundaries for the slowest traversal of that phase.  Here each lane owns ONE resumable
-// traversal (TraceState) and a small phase word; all lanes execute trace_step together no
-// matter which ray (primary / sun shadow / IBL occlusion, of whichever sample) they are on,
-// and the shading "transition" between two rays runs only when the wave decides enough
-// lanes are waiting for one (Wave::gate) -- a wave-ballot form of ray compaction.  Per-lane
-// arithmetic and RNG order are unchanged, so results are bit-identical to frame_pixel.
-struct HostWave {  // one lane at a time (tests/emul)
-    bool gate(bool need, bool traversing) const {
-        (void)traversing;
-        return need;
-    }
-    bool all_finished(bool finished) const { return finished; }
-};
-
-template <class Pending, class Wave>
-F3D_HD float frame_pixel_sm(const FrameParams &P, uint32_t gx, uint32_t gy, bool active, Pending &pend, Wave &wave) {
-    enum : uint32_t { kStart = 0u, kPrimary = 1u, kShadow = 2u, kIbl = 3u };
-    FrameHead h{};
-    if (active) h = frame_head(P, gx, gy);
-    uint32_t rng = h.rng;
-    V3 radiance = V3{0.0f, 0.0f, 0.0f};
-    Reservoir cand = empty_reservoir();
-    uint32_t s = 0u, phase = kStart;
-    bool finished = !active;
-    float m2 = 0.0f;
-    // per-ray state
-    TraceState st;
-    st.done = true;
-    RayCtx ray{};
-    bool any_hit = false;
-    bool mesh_hit = false, forced = false;  // mesh closest/any hit found; result decided without the terrain
-    float mesh_t = 0.0f;
-    V3 mesh_n = V3{0.0f, 0.0f, 0.0f};
-    // per-sample state
-    V3 rd = V3{0.0f, 0.0f, 0.0f}, n = V3{0.0f, 0.0f, 0.0f}, so = V3{0.0f, 0.0f, 0.0f};
-    V3 albedo = V3{0.0f, 0.0f, 0.0f}, sun = V3{0.0f, 0.0f, 0.0f}, ibl_dir = V3{0.0f, 0.0f, 0.0f};
-    float nd = 0.0f;
-
-    auto start_ray = [&](V3 o, V3 d, bool anyhit, bool curvature) F3D_LAMBDA {
-        // intersect_hybrid / intersect_hybrid_optimized prologue: the mesh sweep bounds tmax
-        any_hit = anyhit;
-        mesh_hit = false;
-        forced = false;
-        float tmax = 1e30f;
-        if (P.mesh.traversal_mode == 0u) {
-            float t;
-            V3 mn;
-            if (mesh_closest(P.mesh, o, 1e-3f, d, 1e30f, t, mn)) {
-                if (anyhit && t < 0.01f) {  // early exit, hybrid_traversal.wgsl:215-217
-                    mesh_hit = true;
-                    mesh_t = t;
-                    forced = true;
-                } else if (t < tmax) {
-                    mesh_hit = true;
-                    mesh_t = t;
-                    mesh_n = mn;
-                    tmax = t;
-                }
-            }
-        }
-        ray = make_ray(P.terrain, o, 1e-3f, d, tmax, curvature);
-        if (forced) {
-            st.done = true;
-            st.res.hit = false;
-        } else {
-            trace_begin(P.terrain, ray, anyhit, st, pend);
-        }
-    };
-    auto ray_occluded = [&]() F3D_LAMBDA -> bool {
-        if (forced) return mesh_t < 1e30f;
-        float best = mesh_hit ? mesh_t : 1e30f;
-        bool hit = mesh_hit;
-        if (st.res.hit && st.res.t < best) {
-            best = st.res.t;
-            hit = true;
-        }
-        return hit && best < 1e30f;
-    };
-
-    for (;;) {
-        const bool need = st.done && !finished;
-        if (wave.gate(need, !st.done) && need) {
-            // ---- transition: consume the finished ray, set up the next one ----
-            bool new_sample = false;
-            if (phase == kStart) {
-                new_sample = true;
-            } else if (phase == kPrimary) {
-                uint32_t kind = 0u;
-                float t_best = 1e30f;
-                if (mesh_hit) {
-                    kind = 2u;
-                    t_best = mesh_t;
-                    n = mesh_n;
-                }
-                if (st.res.hit && st.res.t < t_best) {
-                    kind = 1u;
-                    t_best = st.res.t;
-                    n = st.res.n;
-                }
-                if (kind == 0u) {
-                    radiance = radiance + env_radiance(P.env, rd);
-                    new_sample = true;
-                } else {
-                    const V3 p = along(P.cam.origin, t_best, rd);
-                    albedo = kind == 1u ? P.light.albedo : V3{0.7f, 0.7f, 0.8f};
-                    candidate_update(P, cand, n, albedo);
-                    sun = V3{0.0f, 0.0f, 0.0f};
-                    nd = f_max(dot(n, h.sun_dir), 0.0f);
-                    so = along(p, 1e-3f, n);
-                    if (nd > 0.0f && P.light.shadows_enabled != 0u) {
-                        phase = kShadow;
-                        start_ray(so, h.sun_dir, true, true);
-                    } else {
-                        if (nd > 0.0f) sun = (((albedo * P.light.color) * nd) * 1.0f) * h.reuse_w;
-                        phase = kShadow;  // fall through to the IBL set-up below
-                        forced = false;
-                        mesh_hit = false;
-                        st.res.hit = false;
-                        nd = 0.0f;
-                    }
-                }
-            }
-            if (phase == kShadow && st.done && !new_sample) {
-                if (nd > 0.0f) {
-                    const float vis = ray_occluded() ? 0.0f : 1.0f;
-                    sun = (((albedo * P.light.color) * nd) * vis) * h.reuse_w;
-                }
-                const float u1 = rng_next(rng);
-                const float u2 = rng_next(rng);
-                ibl_dir = cosine_dir(n, u1, u2);
-                phase = kIbl;
-                start_ray(so, ibl_dir, true, false);
-            } else if (phase == kIbl && st.done && !new_sample) {
-                const float env_vis = ray_occluded() ? 0.0f : 1.0f;
-                const V3 ibl = (albedo * env_radiance(P.env, ibl_dir)) * env_vis;
-                radiance = (radiance + sun) + ibl;
-                new_sample = true;
-            }
-            if (new_sample) {
-                if (s == P.spp) {
-                    m2 = frame_tail(P, gx, gy, h.prev, cand, radiance);
-                    finished = true;
-                } else {
-                    s++;
-                    const float jx = tent_offset(rng_next(rng)) * 0.5f;
-                    const float jy = tent_offset(rng_next(rng)) * 0.5f;
-                    rd = camera_dir(P.cam, gx, gy, jx, jy);
-                    phase = kPrimary;
-                    start_ray(P.cam.origin, rd, false, false);
-                }
-            }
-        }
-        if (wave.all_finished(finished)) break;
-        if (!st.done) trace_step(P.terrain, ray, any_hit, st, pend);
-    }
-    return m2;
+    return frame_tail(P, gx, gy, cand, radiance);
 }
 
 // ---- G-buffer + frame-0 AOVs: unjittered centre ray (:583-609, :619-644) ---------------

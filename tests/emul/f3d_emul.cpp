@@ -232,8 +232,6 @@ int emul_render(const f3d_terrain_ref_desc *d, uint32_t row_begin, uint32_t row_
         uint32_t frames = 0;
         float variance = INFINITY;
         bool converged = false;
-        const char *sm_env = getenv("F3D_EMUL_STATE_MACHINE");
-        const bool sm = sm_env && sm_env[0] == '1';
         while (frames < d->max_frames) {
             P.frame_index = frames;
             P.res_out = res[frames & 1u].data();
@@ -248,10 +246,8 @@ int emul_render(const f3d_terrain_ref_desc *d, uint32_t row_begin, uint32_t row_
             for (long y = row_begin; y < (long)row_end; y++) {
                 ArrayPending pend;
                 for (uint32_t x = 0; x < W; x++) {
-                    HostWave wave;
                     if (logging) pend.log = &pixel_logs[(size_t)(y - row_begin) * W + x];
-                    const float v = sm ? frame_pixel_sm(P, x, (uint32_t)y, true, pend, wave)
-                                       : frame_pixel(P, x, (uint32_t)y, pend);
+                    const float v = frame_pixel(P, x, (uint32_t)y, pend);
                     if (!f_finite(v)) nonfinite = true;
                     else vmax_m2 = f_max(vmax_m2, f_max(v, 0.0f));
                 }
