@@ -212,7 +212,7 @@ static inline uint32_t frame_grid(const FrameParams &p) {
 hipError_t launch_frame(const FrameParams &p, int variant, hipStream_t stream) {
     const dim3 grid(frame_grid(p)), block(kWave);
     switch (variant % 1000) {
-        case 0: hipLaunchKernelGGL((k_frame<0, 4>), grid, block, 0, stream, p); break;  // default
+        case 0: hipLaunchKernelGGL((k_frame<0, 6>), grid, block, 0, stream, p); break;  // default: 80 VGPRs, 6 waves/SIMD
         case 101: hipLaunchKernelGGL((k_frame<0, 1>), grid, block, 0, stream, p); break;
         case 104: hipLaunchKernelGGL((k_frame<0, 4>), grid, block, 0, stream, p); break;
         case 105: hipLaunchKernelGGL((k_frame<0, 5>), grid, block, 0, stream, p); break;

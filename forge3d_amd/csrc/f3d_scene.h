@@ -27,7 +27,8 @@ constexpr uint32_t kMaxLevels = 16;       // 8192-cell DEMs need 14
 constexpr uint32_t kRestirMCap = 512;     // TERRAIN_RESTIR_M_CAP, hybrid_terrain_traversal.wgsl:77
 constexpr uint32_t kWelfordWindow = 32;   // WELFORD_WINDOW, render_terrain.rs:236
 constexpr uint32_t kHaloRows = 3;         // spatial reuse radius R, pt_restir_spatial.wgsl:171
-constexpr uint32_t kDefaultLeafQuorum = 16;  // lanes with a queued leaf that trigger a wave drain
+constexpr uint32_t kDefaultLeafQuorum = 64;  // lanes with a queued leaf that trigger a wave drain
+                                             // (64 = only when a FIFO is full or nobody marches; measured best)
 
 struct alignas(16) LeafRec {
     float h00, h10, h01, h11;
