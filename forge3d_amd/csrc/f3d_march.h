@@ -76,38 +76,23 @@ F3D_HD TraceHit march_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit
     res.n = V3{0.0f, 0.0f, 0.0f};
     ctx.note(2 | (any_hit ? 1 : 0) | (CURVED ? 4 : 0));  // statistics hook: a new ray starts
     const uint32_t top = T.mip_count - 1u;
-    // ray parameter of the plane x = origin_x + cell * spacing_x (resp. z): the reference's slab
-    // arithmetic (:131-141, :290-293); a pure function of the cell index, so values carried from
-    // node to node are the values the reference would recompute.
-    auto plane_tx = [&](uint32_t cell) F3D_LAMBDA { return (plane_at(T.origin_x, cell, T.spacing_x) - r.o.x) * r.inv_x; };
-    auto plane_tz = [&](uint32_t cell) F3D_LAMBDA { return (plane_at(T.origin_z, cell, T.spacing_z) - r.o.z) * r.inv_z; };
-    const bool x_forward = !(r.d.x < 0.0f), z_forward = !(r.d.z < 0.0f);
-    // far / near boundary cell of node (level, n) along one axis, clamped at the ragged edge
-    auto far_cell = [&](uint32_t n, uint32_t level, bool forward, uint32_t cells) F3D_LAMBDA {
-        const uint32_t hi = (n + 1u) << level;
-        return forward ? (hi < cells ? hi : cells) : (n << level);
-    };
-    auto near_cell = [&](uint32_t n, uint32_t level, bool forward, uint32_t cells) F3D_LAMBDA {
-        const uint32_t hi = (n + 1u) << level;
-        return forward ? (n << level) : (hi < cells ? hi : cells);
-    };
-
     bool marching = true;
-    uint32_t level = top, nx = 0u, nz = 0u;
-    // entry / exit parameters of the CURRENT node per axis (min / max of its two plane parameters)
-    float x_in, x_out, z_in, z_out;
+    // root slab interval (:288-297 for the root node)
+    float t_cur = 0.0f;
     {
-        const float ax = plane_tx(0u), bx = plane_tx(T.cell_w), az = plane_tz(0u), bz = plane_tz(T.cell_h);
-        x_in = f_min(ax, bx);
-        x_out = f_max(ax, bx);
-        z_in = f_min(az, bz);
-        z_out = f_max(az, bz);
+        const float ax = (plane_at(T.origin_x, 0u, T.spacing_x) - r.o.x) * r.inv_x;
+        const float bx = (plane_at(T.origin_x, T.cell_w, T.spacing_x) - r.o.x) * r.inv_x;
+        const float az = (plane_at(T.origin_z, 0u, T.spacing_z) - r.o.z) * r.inv_z;
+        const float bz = (plane_at(T.origin_z, T.cell_h, T.spacing_z) - r.o.z) * r.inv_z;
+        const float lo = f_max(f_max(f_min(ax, bx), f_min(az, bz)), r.tmin);
+        const float hi = f_min(f_min(f_max(ax, bx), f_max(az, bz)), r.tmax);
+        if (lo > hi) marching = false;
+        t_cur = lo;
     }
-    float t_cur = f_max(f_max(x_in, z_in), r.tmin);
-    if (t_cur > f_min(f_min(x_out, z_out), r.tmax)) marching = false;  // misses the footprint (:297)
+    const bool x_forward = !(r.d.x < 0.0f), z_forward = !(r.d.z < 0.0f);
+    uint32_t level = top, nx = 0u, nz = 0u;
     bool unverified_start = false;
-    if (start_in_cell && marching) {
-        // start in the cell the ray is in at t_cur, located from the position
+    if (start_in_cell) {
         const float fx = f_floor((f_fma(t_cur, r.d.x, r.o.x) - T.origin_x) * T.inv_spacing_x);
         const float fz = f_floor((f_fma(t_cur, r.d.z, r.o.z) - T.origin_z) * T.inv_spacing_z);
         nx = sat_u32(fx);
@@ -115,28 +100,28 @@ F3D_HD TraceHit march_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit
         nx = nx < T.cell_w - 1u ? nx : T.cell_w - 1u;
         nz = nz < T.cell_h - 1u ? nz : T.cell_h - 1u;
         level = 0u;
-        const float ax = plane_tx(nx), bx = plane_tx(nx + 1u), az = plane_tz(nz), bz = plane_tz(nz + 1u);
-        x_in = f_min(ax, bx);
-        x_out = f_max(ax, bx);
-        z_in = f_min(az, bz);
-        z_out = f_max(az, bz);
         unverified_start = true;
     }
     uint32_t queued = 0u;
     for (;;) {
         if (marching) {
             ctx.note(0);
-            const float enter = f_max(x_in, z_in), exit = f_min(x_out, z_out);
+            // node extent in cells, clamped at ragged edges (:282-286), and its four plane parameters
+            const uint32_t cx0 = nx << level, cz0 = nz << level;
+            uint32_t cx1 = (nx + 1u) << level, cz1 = (nz + 1u) << level;
+            cx1 = cx1 < T.cell_w ? cx1 : T.cell_w;
+            cz1 = cz1 < T.cell_h ? cz1 : T.cell_h;
+            const float tx0 = (plane_at(T.origin_x, cx0, T.spacing_x) - r.o.x) * r.inv_x;
+            const float tx1 = (plane_at(T.origin_x, cx1, T.spacing_x) - r.o.x) * r.inv_x;
+            const float tz0 = (plane_at(T.origin_z, cz0, T.spacing_z) - r.o.z) * r.inv_z;
+            const float tz1 = (plane_at(T.origin_z, cz1, T.spacing_z) - r.o.z) * r.inv_z;
+            const float x_out = f_max(tx0, tx1), z_out = f_max(tz0, tz1);
+            const float enter = f_max(f_min(tx0, tx1), f_min(tz0, tz1)), exit = f_min(x_out, z_out);
             if (unverified_start && !(enter <= t_cur && t_cur <= exit)) {
                 // the position was rounded across a cell boundary: walk down from the root instead
                 level = top;
                 nx = 0u;
                 nz = 0u;
-                const float ax = plane_tx(0u), bx = plane_tx(T.cell_w), az = plane_tz(0u), bz = plane_tz(T.cell_h);
-                x_in = f_min(ax, bx);
-                x_out = f_max(ax, bx);
-                z_in = f_min(az, bz);
-                z_out = f_max(az, bz);
             } else {
                 const float lo = f_max(enter, r.tmin), hi = f_min(exit, r.tmax);
                 // the node's (min,max) band: one 8-byte record of the row-major table of its level
@@ -146,25 +131,15 @@ F3D_HD TraceHit march_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit
                 const bool pass = !(lo > hi) && !march_band_rejects<CURVED>(r, lo, hi, band.mn, band.mx);  // :297-304
                 if (pass && level > 0u) {
                     // DOWN into the child the ray is in at t_cur: it has passed the child boundary plane
-                    // iff that plane's parameter is <= t_cur.  In parameter space the entry-side child
-                    // is [in, mid] and the far one [mid, out], whichever way the ray runs.
+                    // iff that plane's parameter is <= t_cur
                     const uint32_t cl = level - 1u;
                     const uint32_t xm = (2u * nx + 1u) << cl, zm = (2u * nz + 1u) << cl;
-                    uint32_t ix = 0u, iz = 0u;
-                    if (xm < T.cell_w) {  // otherwise the far half lies outside the cell grid
-                        const float txm = plane_tx(xm);
-                        const bool passed = txm <= t_cur;
-                        x_in = passed ? txm : x_in;
-                        x_out = passed ? x_out : txm;
-                        ix = (x_forward == passed) ? 1u : 0u;
-                    }
-                    if (zm < T.cell_h) {
-                        const float tzm = plane_tz(zm);
-                        const bool passed = tzm <= t_cur;
-                        z_in = passed ? tzm : z_in;
-                        z_out = passed ? z_out : tzm;
-                        iz = (z_forward == passed) ? 1u : 0u;
-                    }
+                    const float txm = (plane_at(T.origin_x, xm, T.spacing_x) - r.o.x) * r.inv_x;
+                    const float tzm = (plane_at(T.origin_z, zm, T.spacing_z) - r.o.z) * r.inv_z;
+                    uint32_t ix = (x_forward != (txm <= t_cur)) ? 0u : 1u;
+                    uint32_t iz = (z_forward != (tzm <= t_cur)) ? 0u : 1u;
+                    if (!(xm < T.cell_w)) ix = 0u;  // the far half lies outside the cell grid
+                    if (!(zm < T.cell_h)) iz = 0u;
                     nx = 2u * nx + ix;
                     nz = 2u * nz + iz;
                     level = cl;
@@ -200,35 +175,12 @@ F3D_HD TraceHit march_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit
                         marching = false;  // the ray is out of the footprint (or past tmax)
                     } else {
                         t_cur = f_max(t_cur, exit);
-                        // leaving the parent as well: continue one level up (that ancestor is
-                        // entirely ahead of the ray)
-                        const bool up = level < top && ((nx >> 1) != (px >> 1) || (nz >> 1) != (pz >> 1));
-                        const uint32_t old = level;
-                        if (up) {
+                        // leaving the parent as well: continue one level up
+                        if (level < top && ((nx >> 1) != (px >> 1) || (nz >> 1) != (pz >> 1))) {
                             nx >>= 1;
                             nz >>= 1;
                             level = level + 1u;
                         }
-                        // plane parameters of the new node: the crossed plane becomes its entry; other
-                        // planes are kept when they coincide with the old node's and recomputed when
-                        // the node grew by going up.
-                        if (cross_x) {
-                            x_in = x_out;
-                            x_out = plane_tx(far_cell(nx, level, x_forward, T.cell_w));
-                        } else if (up) {
-                            const bool was_entry_child = ((px & 1u) == 0u) == x_forward;
-                            if (was_entry_child) x_out = plane_tx(far_cell(nx, level, x_forward, T.cell_w));
-                            else x_in = plane_tx(near_cell(nx, level, x_forward, T.cell_w));
-                        }
-                        if (cross_z) {
-                            z_in = z_out;
-                            z_out = plane_tz(far_cell(nz, level, z_forward, T.cell_h));
-                        } else if (up) {
-                            const bool was_entry_child = ((pz & 1u) == 0u) == z_forward;
-                            if (was_entry_child) z_out = plane_tz(far_cell(nz, level, z_forward, T.cell_h));
-                            else z_in = plane_tz(near_cell(nz, level, z_forward, T.cell_h));
-                        }
-                        (void)old;
                     }
                 }
             }
