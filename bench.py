@@ -62,13 +62,16 @@ def cpu_baseline(dem, cam, kw, args):
     w, h = 240, 135
     probe = oracle.render(dem, w, h, cam, **k)
     rate = probe["n_samples"] / max(probe["loop_seconds"], 1e-9)
-    scale = max(1.0, (args.cpu_seconds * rate / probe["n_samples"]) ** 0.5)
+    budget = args.cpu_seconds * rate  # samples the host can trace in the target time
+    scale = min(args.width / w, max(1.0, (budget / probe["n_samples"]) ** 0.5))
     w2, h2 = min(args.width, int(w * scale) // 8 * 8), min(args.height, int(h * scale) // 8 * 8)
-    out = oracle.render(dem, w2, h2, cam, **k) if (w2, h2) != (w, h) else probe
+    frames = int(max(2, min(32, budget // (w2 * h2 * args.spp))))
+    k.update(max_frames=frames, min_frames=frames)
+    out = oracle.render(dem, w2, h2, cam, **k)
     n = out["n_samples"]
     return {
         "value": n / out["loop_seconds"] / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-        "sample": f"CPU oracle (C, OpenMP), same DEM/camera/sun, {w2}x{h2}, {args.spp} spp x 2 frames "
+        "sample": f"CPU oracle (C, OpenMP), same DEM/camera/sun, {w2}x{h2}, {args.spp} spp x {frames} frames "
                   f"= {n / 1e6:.2f} Msamples in {out['loop_seconds']:.1f} s",
     }, {"n_node": out["n_node"] / n, "n_leaf": out["n_leaf"] / n, "n_hit": out["n_hit"] / n}
 
