@@ -12,7 +12,8 @@ state) are resident in HBM before the timed region.
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the image is split into N
-row strips, the 3-row reservoir halos move over RCCL after every frame, the variance
+load-balanced row strips (measured before the timed region, forge3d_amd/distributed.py),
+the 3-row reservoir halos move over RCCL after every frame, the variance
 statistic is all-reduced per window and the RGBA8/AOV strips are gathered to rank 0 at the
 end (strong scaling: the 1080p frame is fixed).
 """
@@ -130,6 +131,8 @@ def main():
                             f"= {args.spp * args.steps} spp, sun az302/el24, orbit phi28/theta49 fov42",
                 "parallelism": "1 GPU" if world == 1 else f"{world} row strips, RCCL halo exchange + gather",
                 "kernel_variant": args.variant,
+                **({"strip_row_bounds": r.bounds, "strip_probe_ms": r.balance_log[-1]["ms"] if r.balance_log else None}
+                   if world > 1 else {}),
             },
         }
         counts = None

@@ -183,7 +183,25 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
     // left whole XCDs idle -- profiles/README.md)
     P.tile_map = (s.variant / 1000) % 10 ? (uint32_t)((s.variant / 1000) % 10) : 2u;
     // + 10000 * leaf quorum (f3d_trace.h "leaf gating"); 0 = default
-    P.terrain.leaf_quorum = s.variant / 10000 ? (uint32_t)(s.variant / 10000) : kDefaultLeafQuorum;
+    P.terrain.leaf_quorum = (s.variant / 10000) % 100 ? (uint32_t)((s.variant / 10000) % 100) : kDefaultLeafQuorum;
+    // + 1000000 * sample lanes per pixel (f3d_kernels.hip frame_lanes): 1, 2, 4, 8; 0 = automatic.
+    // A wave of the 1-lane kernel lasts spp x 3 traversals whatever the image size, so small images
+    // and thin multi-GPU strips are latency-bound and even a 1080p frame ends in a ~1 ms tail of
+    // half-empty SIMDs; trading pixels per wave for sample lanes keeps ~16 waves per wave slot
+    // (measured at 1080p / 8 spp: 3881, 4866, 5024, 4898 Msamples/s for 1, 2, 4, 8 lanes).
+    {
+        uint32_t lanes = (uint32_t)((s.variant / 1000000) % 10);
+        if (lanes == 0u && s.variant % 1000 != 0) lanes = 1u;  // register-budget A/B kernels exist for 1 lane only
+        if (lanes == 0u) {
+            constexpr uint64_t kTargetWaves = 98304;  // 16 x (256 CUs x 4 SIMDs x 6 waves)
+            lanes = 1u;
+            while (lanes < 8u && lanes * 2u <= P.spp && ((uint64_t)s.rows * s.width * lanes + 63u) / 64u < kTargetWaves)
+                lanes *= 2u;
+        }
+        if (lanes != 1u && lanes != 2u && lanes != 4u && lanes != 8u)
+            fail(F3D_STATUS_VALUE, "kernel_variant: sample lanes must be 1, 2, 4 or 8 (got %u)", lanes);
+        P.sample_lanes = lanes;
+    }
 
     // per-pixel state
     const size_t px = (size_t)s.rows * s.width;

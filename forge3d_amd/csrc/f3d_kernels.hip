@@ -1,12 +1,11 @@
 // forge3d_amd/csrc/f3d_kernels.hip -- gfx950 kernels of the terrain path tracer.
 //
-// Launch shape: one wave (64 lanes) per workgroup = one 8x8 pixel tile, like the
-// reference's @workgroup_size(8,8,1) (hybrid_terrain_traversal.wgsl:445), so primary rays
-// of a wave stay coherent.  Workgroup b runs on XCD b % 8 (observed dispatch order,
-// MI355X_MICROARCH.md), so tile ids are dealt to XCDs in contiguous bands: each XCD's
-// private 4 MiB L2 then caches one horizontal band of the image and the slice of the
-// terrain tables its rays actually walk.  No MFMA anywhere: there is no dense
-// contraction on this path.
+// Launch shape: one wave (64 lanes) per workgroup = one pixel tile (8x8 pixels like the
+// reference's @workgroup_size(8,8,1), hybrid_terrain_traversal.wgsl:445, or fewer pixels with
+// several sample lanes each -- frame_lanes below), so primary rays of a wave stay coherent.
+// Workgroup b runs on XCD b % 8 (observed dispatch order, MI355X_MICROARCH.md); tile ROWS are
+// dealt round-robin to the XCDs (tile_pixel).  No MFMA anywhere: there is no dense contraction
+// on this path.
 #include "f3d_launch.h"
 #include "f3d_shade.h"
 
@@ -76,9 +75,20 @@ __device__ __forceinline__ LdsPending make_pending(uint32_t *lds, const TerrainD
     return LdsPending{lds + threadIdx.x, lds + kMaxLevels * kWave, T.leaf_quorum ? T.leaf_quorum : kDefaultLeafQuorum};
 }
 
+// Pixel tile of a wave with S sample lanes per pixel: 64 / S pixels, TW x TH.
+template <uint32_t S>
+struct TileShape {
+    static constexpr uint32_t kLogS = S == 1u ? 0u : (S == 2u ? 1u : (S == 4u ? 2u : 3u));
+    static constexpr uint32_t kLogW = S <= 2u ? 3u : 2u;      // 8, 8, 4, 4 pixels wide
+    static constexpr uint32_t kLogH = 6u - kLogS - kLogW;     // 8, 4, 4, 2 pixels high
+};
+
+template <uint32_t S = 1u>
 __device__ __forceinline__ bool tile_pixel(const FrameParams &P, uint32_t &gx, uint32_t &gy) {
+    using Shape = TileShape<S>;
+    constexpr uint32_t TW = 1u << Shape::kLogW, TH = 1u << Shape::kLogH;
     const uint32_t rows = P.row_end - P.row_begin;
-    const uint32_t tiles_x = (P.cam.width + 7u) >> 3, tiles_y = (rows + 7u) >> 3;
+    const uint32_t tiles_x = (P.cam.width + TW - 1u) >> Shape::kLogW, tiles_y = (rows + TH - 1u) >> Shape::kLogH;
     const uint32_t ntiles = tiles_x * tiles_y;
     // Workgroup b is observed to run on XCD b % 8.  tile_map picks how tiles are dealt to XCDs:
     //   1  tile id = workgroup id (consecutive tiles on different XCDs)
@@ -100,9 +110,9 @@ __device__ __forceinline__ bool tile_pixel(const FrameParams &P, uint32_t &gx, u
         tile = (blockIdx.x % kNumXcd) * per_xcd + blockIdx.x / kNumXcd;
     }
     if (tile >= ntiles) return false;
-    const uint32_t lane = threadIdx.x;
-    gx = (tile % tiles_x) * 8u + (lane & 7u);
-    gy = P.row_begin + (tile / tiles_x) * 8u + (lane >> 3);
+    const uint32_t pixel = threadIdx.x >> Shape::kLogS;  // the S sample lanes of a pixel are neighbours
+    gx = (tile % tiles_x) * TW + (pixel & (TW - 1u));
+    gy = P.row_begin + (tile / tiles_x) * TH + (pixel >> Shape::kLogW);
     return gx < P.cam.width && gy < P.row_end;
 }
 
@@ -130,17 +140,88 @@ __device__ __forceinline__ void publish_window_stats(const FrameParams &P, bool 
     }
 }
 
+// ---- sample-lane form of the frame ---------------------------------------------------------
+// A lane of frame_pixel walks its pixel's spp samples one after the other, so a wave lasts
+// spp x 3 traversals (~3 ms at 8 spp on the headline scene) however few waves there are: a strip of
+// one eighth of a 1080p frame (4 080 waves for 6 144 wave slots) takes as long as half the frame,
+// and a 512 x 512 image cannot fill the chip.  Here S neighbouring lanes trace S samples of the
+// SAME pixel at once (tile = 64 / S pixels), which needs the two couplings between samples
+// (f3d_shade.h) resolved:
+//   (a) RNG stream: the state at the start of sample s depends on how many earlier samples hit.
+//       The hit flags are PREDICTED (G-buffer centre ray: right for every pixel that is not on a
+//       silhouette), every lane traces its primary ray from the predicted state, the group compares
+//       flags (one ballot) and lanes whose start state was wrong trace again; sample 0 is always
+//       right, so this settles in at most S rounds and in one for almost every pixel.
+//   (b) radiance sum and candidate reservoir: every lane of the group replays all S contributions in
+//       sample order (7 ds_bpermute per sample), so each holds the exact running values.
+// Results are bit-identical to frame_pixel; frame head and tail run redundantly on the S lanes
+// (only sample lane 0 writes), which costs S x their ~4 % share -- the price of S x shorter waves.
+template <uint32_t S>
+__device__ __forceinline__ float frame_lanes(const FrameParams &P, uint32_t gx, uint32_t gy, LdsPending &pend) {
+    const uint32_t lane = threadIdx.x, j = lane & (S - 1u), base = lane & ~(S - 1u);
+    constexpr uint32_t kGroup = (1u << S) - 1u;
+    const FrameHead h = frame_head(P, gx, gy);  // identical on the S lanes of the pixel
+    uint32_t stream = h.rng;                    // state at the start of the current round
+    V3 radiance = V3{0.0f, 0.0f, 0.0f};
+    Reservoir cand = empty_reservoir();
+    for (uint32_t s0 = 0u; s0 < P.spp; s0 += S) {  // wave-uniform
+        const uint32_t n_act = P.spp - s0 < S ? P.spp - s0 : S;
+        const bool act = j < n_act;
+        uint32_t pred = h.centre_hit ? kGroup : 0u;  // predicted hit flags of this round's samples
+        uint32_t traced = 0xFFFFFFFFu;               // draws in front of my sample when I last traced it
+        PrimaryHit ph;
+        ph.hit.kind = 0u;
+        ph.rng = 0u;
+        for (;;) {
+            const uint32_t draws = 2u * j + 2u * (uint32_t)__popc(pred & ((1u << j) - 1u));
+            const bool need = act && draws != traced;
+            if (__ballot(need) == 0ull) break;
+            if (need) {
+                uint32_t st = stream;
+                rng_skip(st, draws);
+                ph = sample_primary(P, gx, gy, st, pend);
+                traced = draws;
+            }
+            pred = (uint32_t)(__ballot(act && ph.hit.kind != 0u) >> base) & kGroup;
+        }
+        SampleOut o;
+        o.a = V3{0.0f, 0.0f, 0.0f};
+        o.b = V3{0.0f, 0.0f, 0.0f};
+        o.target_pdf = 0.0f;
+        if (act) {
+            uint32_t rng = ph.rng;
+            o = sample_shade(P, h, ph, rng, pend);
+        }
+#pragma unroll
+        for (uint32_t k = 0u; k < S; k++) {
+            const int src = (int)(base + k);
+            const V3 a = V3{__shfl(o.a.x, src, kWave), __shfl(o.a.y, src, kWave), __shfl(o.a.z, src, kWave)};
+            const V3 b = V3{__shfl(o.b.x, src, kWave), __shfl(o.b.y, src, kWave), __shfl(o.b.z, src, kWave)};
+            const float tp = __shfl(o.target_pdf, src, kWave);
+            if (k < n_act) accumulate_sample(cand, radiance, a, b, tp);
+        }
+        rng_skip(stream, 2u * n_act + 2u * (uint32_t)__popc(pred));
+    }
+    return j == 0u ? frame_tail(P, gx, gy, cand, radiance) : 0.0f;
+}
+
 // VARIANT is reserved for A/B builds (0 = the shipped kernel).
 // MIN_WAVES: waves per SIMD the register allocator must leave room for (1 = unconstrained).
-template <int VARIANT, int MIN_WAVES = 1>
+// S: sample lanes per pixel (1 = frame_pixel; 2, 4, 8 = frame_lanes).
+template <int VARIANT, int MIN_WAVES = 1, uint32_t S = 1u>
 __global__ __launch_bounds__(kWave, MIN_WAVES) void k_frame(const FrameParams P) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[kLdsWords];
     LdsPending pend = make_pending(lds, P.terrain);
     uint32_t gx = 0u, gy = 0u;
-    const bool active = tile_pixel(P, gx, gy);
+    const bool active = tile_pixel<S>(P, gx, gy);
     float m2 = 0.0f;
-    if (active) m2 = frame_pixel(P, gx, gy, pend);
-    if (P.collect_stats != 0u) publish_window_stats(P, active, m2);
+    if constexpr (S == 1u) {
+        if (active) m2 = frame_pixel(P, gx, gy, pend);
+        if (P.collect_stats != 0u) publish_window_stats(P, active, m2);
+    } else {
+        if (active) m2 = frame_lanes<S>(P, gx, gy, pend);
+        if (P.collect_stats != 0u) publish_window_stats(P, active && (threadIdx.x & (S - 1u)) == 0u, m2);
+    }
 }
 
 __global__ __launch_bounds__(kWave) void k_gbuffer(const FrameParams P, float4 *gbuffer_n, float *depth) {
@@ -202,22 +283,32 @@ __global__ void k_level_build(const LevelBuildParams B) {
 }
 
 // ---- launchers ---------------------------------------------------------------------
-static inline uint32_t frame_grid(const FrameParams &p) {
+static inline uint32_t frame_grid(const FrameParams &p, uint32_t lanes = 1u) {
+    const uint32_t log_s = lanes == 1u ? 0u : (lanes == 2u ? 1u : (lanes == 4u ? 2u : 3u));
+    const uint32_t log_w = lanes <= 2u ? 3u : 2u, log_h = 6u - log_s - log_w;  // TileShape<S>
     const uint32_t rows = p.row_end - p.row_begin;
-    const uint32_t tiles_x = (p.cam.width + 7u) >> 3, tiles_y = (rows + 7u) >> 3;
+    const uint32_t tiles_x = (p.cam.width + (1u << log_w) - 1u) >> log_w, tiles_y = (rows + (1u << log_h) - 1u) >> log_h;
     if (p.tile_map == 2u) return ((tiles_y + kNumXcd - 1u) / kNumXcd) * tiles_x * kNumXcd;
     return ((tiles_x * tiles_y + kNumXcd - 1u) / kNumXcd) * kNumXcd;
 }
 
 hipError_t launch_frame(const FrameParams &p, int variant, hipStream_t stream) {
-    const dim3 grid(frame_grid(p)), block(kWave);
+    const uint32_t lanes = p.sample_lanes ? p.sample_lanes : 1u;
+    const dim3 grid(frame_grid(p, lanes)), block(kWave);
+    if (lanes != 1u) {  // sample-lane kernels: one register budget (6 waves/SIMD)
+        switch (lanes) {
+            case 2: hipLaunchKernelGGL((k_frame<0, 6, 2>), grid, block, 0, stream, p); break;
+            case 4: hipLaunchKernelGGL((k_frame<0, 6, 4>), grid, block, 0, stream, p); break;
+            case 8: hipLaunchKernelGGL((k_frame<0, 6, 8>), grid, block, 0, stream, p); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (variant % 1000) {
         case 0: hipLaunchKernelGGL((k_frame<0, 6>), grid, block, 0, stream, p); break;  // default: 80 VGPRs, 6 waves/SIMD
         case 101: hipLaunchKernelGGL((k_frame<0, 1>), grid, block, 0, stream, p); break;
         case 104: hipLaunchKernelGGL((k_frame<0, 4>), grid, block, 0, stream, p); break;
         case 105: hipLaunchKernelGGL((k_frame<0, 5>), grid, block, 0, stream, p); break;
-        case 106: hipLaunchKernelGGL((k_frame<0, 6>), grid, block, 0, stream, p); break;
-        case 107: hipLaunchKernelGGL((k_frame<0, 7>), grid, block, 0, stream, p); break;
         case 108: hipLaunchKernelGGL((k_frame<0, 8>), grid, block, 0, stream, p); break;
         default: return hipErrorInvalidValue;
     }

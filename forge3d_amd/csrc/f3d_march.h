@@ -149,39 +149,21 @@ F3D_HD TraceHit march_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit
                         ctx.fifo_put(queued, nx | (nz << 16), lo, hi);
                         queued++;
                     }
-                    // ---- across the exit boundary of this node ----
+                    // ---- across the exit boundary of this node (straight-line: no nested divergence) ----
                     const bool cross_x = x_out <= z_out, cross_z = z_out <= x_out;
                     const uint32_t px = nx, pz = nz;
-                    bool left = !(exit < r.tmax);
-                    if (cross_x) {
-                        if (x_forward) {
-                            nx = nx + 1u;
-                            left = left || (nx << level) >= T.cell_w;
-                        } else {
-                            left = left || nx == 0u;
-                            nx = nx - 1u;
-                        }
-                    }
-                    if (cross_z) {
-                        if (z_forward) {
-                            nz = nz + 1u;
-                            left = left || (nz << level) >= T.cell_h;
-                        } else {
-                            left = left || nz == 0u;
-                            nz = nz - 1u;
-                        }
-                    }
-                    if (left) {
-                        marching = false;  // the ray is out of the footprint (or past tmax)
-                    } else {
-                        t_cur = f_max(t_cur, exit);
-                        // leaving the parent as well: continue one level up
-                        if (level < top && ((nx >> 1) != (px >> 1) || (nz >> 1) != (pz >> 1))) {
-                            nx >>= 1;
-                            nz >>= 1;
-                            level = level + 1u;
-                        }
-                    }
+                    // a backward step from column 0 wraps to 0xFFFFFFFF, whose shifted value is >= cell_w too
+                    // (cell_w <= 2^13, level <= 15), so one unsigned comparison covers both directions
+                    nx = nx + ((cross_x && x_forward) ? 1u : 0u) - ((cross_x && !x_forward) ? 1u : 0u);
+                    nz = nz + ((cross_z && z_forward) ? 1u : 0u) - ((cross_z && !z_forward) ? 1u : 0u);
+                    const bool left = !(exit < r.tmax) || (nx << level) >= T.cell_w || (nz << level) >= T.cell_h;
+                    // leaving the parent as well: continue one level up
+                    const bool up = level < top && (((nx ^ px) | (nz ^ pz)) > 1u);
+                    nx = up ? nx >> 1 : nx;
+                    nz = up ? nz >> 1 : nz;
+                    level = up ? level + 1u : level;
+                    t_cur = f_max(t_cur, exit);
+                    marching = !left;  // out of the footprint, or past tmax
                 }
             }
             unverified_start = false;

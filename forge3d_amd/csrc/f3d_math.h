@@ -91,6 +91,17 @@ F3D_HD float rng_next(uint32_t &s) {
     return (float)x / 4294967296.0f;
 }
 
+// advance the stream by `draws` draws without producing them
+F3D_HD void rng_skip(uint32_t &s, uint32_t draws) {
+    uint32_t x = s;
+    for (uint32_t k = 0u; k < draws; k++) {
+        x ^= x << 13;
+        x ^= x >> 17;
+        x ^= x << 5;
+    }
+    s = x;
+}
+
 constexpr float kPi = 3.14159265358979323846f;
 constexpr float kHalfPi = 1.57079632679489661923f;
 constexpr float kQuarterPi = 0.78539816339744830962f;

@@ -133,6 +133,7 @@ struct FrameParams {
     uint32_t *stats;                // [0] max m2 bits, [1] nonfinite, [2] any_valid, [3] bad
     uint32_t collect_stats;         // this frame closes a convergence window
     uint32_t tile_map;              // workgroup -> tile mapping (f3d_kernels.hip tile_pixel)
+    uint32_t sample_lanes;          // lanes per pixel in the frame kernel: 1 (frame_pixel), 2, 4, 8 (frame_lanes)
 };
 
 }  // namespace f3d

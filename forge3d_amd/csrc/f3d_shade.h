@@ -265,6 +265,7 @@ F3D_HD Reservoir temporal_merge(const Reservoir &rp, const Reservoir &rc) {
 
 // ---- one accumulation frame of one pixel ---------------------------------------------
 struct FrameHead {
+    bool centre_hit;  // the G-buffer's centre ray hit a surface (hit-flag prediction of frame_lanes)
     bool prev_valid;  // the merged history carries a usable sun sample (:463-465)
     float reuse_w;    // clamp(prev.weight, 0, 4) or 1
     uint32_t rng;
@@ -289,6 +290,7 @@ F3D_HD FrameHead frame_head(const FrameParams &P, uint32_t gx, uint32_t gy) {
     }
     P.res_out[reservoir_index(P, gx, gy)] = pack(prev);
     FrameHead h;
+    h.centre_hit = g.w != 0.0f;
     h.prev_valid = P.frame_index > 0u && prev.m > 0u && prev.weight > 0.0f && prev.target_pdf > 0.0f &&
                    prev.directional;
     h.reuse_w = h.prev_valid ? f_clamp(prev.weight, 0.0f, 4.0f) : 1.0f;
@@ -296,16 +298,80 @@ F3D_HD FrameHead frame_head(const FrameParams &P, uint32_t gx, uint32_t gy) {
     return h;
 }
 
-// Candidate generation for one terrain/mesh hit (:500-512)
-F3D_HD void candidate_update(const FrameParams &P, Reservoir &cand, V3 n, V3 albedo) {
-    const float ndotl = f_max(dot(n, P.light.wi), 0.0f);
-    const float target_pdf = luminance((albedo * P.light.color) * ndotl);
+// ---- one camera sample, cut where the samples of a pixel depend on one another -----------
+// Samples of a pixel-frame are chained only through (a) the RNG stream -- a sample draws 2 numbers
+// for its jitter and 2 more for the IBL direction IF its primary ray hit (:477-478, :537-538), so
+// the state at the start of sample s depends on the hit flags of samples < s -- and (b) two
+// order-sensitive accumulations: the radiance sum and the candidate reservoir (:500-512).  The
+// tracing in between is independent.  frame_pixel below walks the samples one after the other;
+// the sample-lane form of the frame kernel (f3d_kernels.hip) traces several samples of a pixel on
+// neighbouring lanes and replays (b) in sample order.
+struct PrimaryHit {
+    SurfaceHit hit;
+    V3 rd;
+    uint32_t rng;  // stream state after the two jitter draws
+};
+
+template <class Pending>
+F3D_HD PrimaryHit sample_primary(const FrameParams &P, uint32_t gx, uint32_t gy, uint32_t rng, Pending &pend) {
+    PrimaryHit ph;
+    const float jx = tent_offset(rng_next(rng)) * 0.5f;
+    const float jy = tent_offset(rng_next(rng)) * 0.5f;
+    ph.rd = camera_dir(P.cam, gx, gy, jx, jy);
+    ph.hit = closest_hit(P, P.cam.origin, 1e-3f, ph.rd, 1e30f, pend);
+    ph.rng = rng;
+    return ph;
+}
+
+struct SampleOut {
+    V3 a, b;           // radiance = (radiance + a) + b: hit -> (sun, ibl); miss -> (env, 0)
+    float target_pdf;  // candidate weight of the hit (:500-512); 0 = no candidate
+};
+
+// Shading of one sample whose primary hit is known (:486-548); draws u1, u2 from `rng` on a hit.
+template <class Pending>
+F3D_HD SampleOut sample_shade(const FrameParams &P, const FrameHead &h, const PrimaryHit &ph, uint32_t &rng,
+                              Pending &pend) {
+    SampleOut o;
+    o.b = V3{0.0f, 0.0f, 0.0f};
+    o.target_pdf = 0.0f;
+    if (ph.hit.kind == 0u) {
+        o.a = env_radiance(P.env, ph.rd);
+        return o;
+    }
+    const V3 n = ph.hit.n;
+    const V3 albedo = ph.hit.kind == 1u ? P.light.albedo : V3{0.7f, 0.7f, 0.8f};
+    const V3 so = along(ph.hit.p, 1e-3f, n);
+    // candidate generation for this hit (:500-512)
+    o.target_pdf = luminance((albedo * P.light.color) * f_max(dot(n, P.light.wi), 0.0f));
+    // sun through the merged reservoir, :517-532
+    const V3 sun_dir = h.prev_valid ? P.light.wi_reuse : P.light.wi;
+    const float nd = f_max(dot(n, sun_dir), 0.0f);
+    o.a = V3{0.0f, 0.0f, 0.0f};
+    if (nd > 0.0f) {
+        float vis = 1.0f;
+        if (P.light.shadows_enabled != 0u && occluded(P, so, 1e-3f, sun_dir, 1e30f, true, pend)) vis = 0.0f;
+        o.a = (((albedo * P.light.color) * nd) * vis) * h.reuse_w;
+    }
+    // one cosine-weighted IBL sample, :537-545
+    const float u1 = rng_next(rng);
+    const float u2 = rng_next(rng);
+    const V3 ei = cosine_dir(n, u1, u2);
+    const float env_vis = occluded(P, so, 1e-3f, ei, 1e30f, false, pend) ? 0.0f : 1.0f;
+    o.b = (albedo * env_radiance(P.env, ei)) * env_vis;
+    return o;
+}
+
+// The order-sensitive part of a sample: candidate reservoir (:500-512) and radiance sum.  A miss
+// adds (env, +0): x + (+0) == x for every x that can occur here (sums of non-negative terms).
+F3D_HD void accumulate_sample(Reservoir &cand, V3 &radiance, V3 a, V3 b, float target_pdf) {
     if (target_pdf > 0.0f) {
         cand.directional = true;
         cand.w_sum = cand.w_sum + target_pdf;
         cand.m = cand.m + 1u;
         cand.target_pdf = target_pdf;
     }
+    radiance = (radiance + a) + b;
 }
 
 // Everything after the sample loop (:549-574) plus the temporal pass; returns Welford m2.
@@ -339,7 +405,8 @@ F3D_HD float frame_tail(const FrameParams &P, uint32_t gx, uint32_t gy, Reservoi
     return m2;
 }
 
-// The sample loop of main_terrain (:476-548): primary, sun-shadow and IBL-occlusion rays per sample.
+// The sample loop of main_terrain (:476-548): primary, sun-shadow and IBL-occlusion rays per sample,
+// one sample after the other on one lane.
 // (A per-lane ray state machine with ballot-gated shading transitions was measured at 0.5-0.7x of
 // this nested form on MI355X and removed -- profiles/README.md.)
 template <class Pending>
@@ -349,40 +416,10 @@ F3D_HD float frame_pixel(const FrameParams &P, uint32_t gx, uint32_t gy, Pending
     V3 radiance = V3{0.0f, 0.0f, 0.0f};
     Reservoir cand = empty_reservoir();
     for (uint32_t s = 0u; s < P.spp; s++) {
-        const float jx = tent_offset(rng_next(rng)) * 0.5f;
-        const float jy = tent_offset(rng_next(rng)) * 0.5f;
-        const V3 rd = camera_dir(P.cam, gx, gy, jx, jy);
-        const SurfaceHit hit = closest_hit(P, P.cam.origin, 1e-3f, rd, 1e30f, pend);
-        if (hit.kind == 0u) {
-            radiance = radiance + env_radiance(P.env, rd);
-            continue;
-        }
-        const V3 n = hit.n;
-        const bool on_terrain = hit.kind == 1u;
-        const V3 so = along(hit.p, 1e-3f, n);
-        {
-            const V3 albedo = on_terrain ? P.light.albedo : V3{0.7f, 0.7f, 0.8f};
-            candidate_update(P, cand, n, albedo);
-            // sun through the merged reservoir, :517-532.  (radiance + sun) + ibl is evaluated in
-            // that order, so the sun term can be added as soon as its shadow ray is back.
-            const V3 sun_dir = h.prev_valid ? P.light.wi_reuse : P.light.wi;
-            const float nd = f_max(dot(n, sun_dir), 0.0f);
-            V3 sun = V3{0.0f, 0.0f, 0.0f};
-            if (nd > 0.0f) {
-                float vis = 1.0f;
-                if (P.light.shadows_enabled != 0u && occluded(P, so, 1e-3f, sun_dir, 1e30f, true, pend)) vis = 0.0f;
-                sun = (((albedo * P.light.color) * nd) * vis) * h.reuse_w;
-            }
-            radiance = radiance + sun;
-        }
-        // one cosine-weighted IBL sample, :537-545
-        const float u1 = rng_next(rng);
-        const float u2 = rng_next(rng);
-        const V3 ei = cosine_dir(n, u1, u2);
-        const float env_vis = occluded(P, so, 1e-3f, ei, 1e30f, false, pend) ? 0.0f : 1.0f;
-        const V3 albedo = on_terrain ? P.light.albedo : V3{0.7f, 0.7f, 0.8f};
-        const V3 ibl = (albedo * env_radiance(P.env, ei)) * env_vis;
-        radiance = radiance + ibl;
+        const PrimaryHit ph = sample_primary(P, gx, gy, rng, pend);
+        rng = ph.rng;
+        const SampleOut o = sample_shade(P, h, ph, rng, pend);
+        accumulate_sample(cand, radiance, o.a, o.b, o.target_pdf);
     }
     return frame_tail(P, gx, gy, cand, radiance);
 }

@@ -11,9 +11,16 @@ spatial ReSTIR pass sees its +-3 pixel neighbourhood (reference pt_restir_spatia
   per window  all-reduce(MAX) of the 16-byte statistics record (variance gate);
   at the end  gather of the RGBA8 / AOV strips to rank 0.
 
-DEM tables are replicated (<= 80 MB).  The driver is written against a tiny backend
-interface (make_session / buffers) so the world_size-2 gloo test can run it on the CPU with
-the kernel emulator under tests/emul.
+DEM tables are replicated (<= 125 MB).  The driver is written against a tiny backend
+interface (make_session / buffers / probe) so the world_size-2 gloo test can run it on the
+CPU with the kernel emulator under tests/emul.
+
+Strips are LOAD-BALANCED, not equal: a sky row costs a fraction of a terrain row and the sky
+sits at the top of the frame, so equal strips would leave the top ranks idle (strong scaling
+is bounded by the slowest strip).  Before the render every rank times a few probe frames of
+its strip, the times are all-gathered, a per-row cost density is updated multiplicatively and
+the rows are re-partitioned (`balance_iters` rounds; the best measured partition wins).  Any
+partition gives the same image -- state is keyed by full-image coordinates.
 """
 from __future__ import annotations
 
@@ -49,6 +56,38 @@ def strip_rows(height: int, world: int, rank: int):
     return begin, end
 
 
+def partition_rows(density, world: int, min_rows: int = 3):
+    """Boundaries b[0..world] of contiguous strips with (nearly) equal summed row density,
+    every strip at least `min_rows` rows (the spatial pass needs a full 3-row halo donor)."""
+    density = np.asarray(density, np.float64)
+    height = len(density)
+    if height < world * min_rows:
+        raise ValueError(f"strips need at least {min_rows} rows each ({height} rows / {world} ranks)")
+    if not np.all(np.isfinite(density)) or density.min() < 0.0 or density.sum() <= 0.0:
+        density = np.ones(height)
+    cum = np.concatenate([[0.0], np.cumsum(density)])
+    bounds = [0]
+    for k in range(1, world):
+        target = cum[-1] * k / world
+        b = int(np.searchsorted(cum, target, side="left"))
+        if b > 0 and abs(cum[b - 1] - target) <= abs(cum[min(b, height)] - target):
+            b -= 1
+        bounds.append(min(max(b, bounds[-1] + min_rows), height - (world - k) * min_rows))
+    bounds.append(height)
+    return bounds
+
+
+def rebalance(density, bounds, times):
+    """Multiplicative update of the per-row cost density from measured strip times: rows of strip i
+    are scaled so that they sum to times[i] (keeps the within-strip shape learnt so far)."""
+    density = np.array(density, np.float64)
+    for i, t in enumerate(times):
+        rows = slice(bounds[i], bounds[i + 1])
+        total = density[rows].sum()
+        density[rows] = density[rows] * (t / total) if total > 0.0 else t / max(1, bounds[i + 1] - bounds[i])
+    return density
+
+
 class HipBackend:
     """Product backend: strips rendered by libf3dhip.so, buffers are torch CUDA tensors."""
 
@@ -76,19 +115,48 @@ class HipBackend:
     def sync(self):
         self.torch.cuda.synchronize(self.device)
 
+    def probe(self, dem, width, height, cam, row_begin, row_end, kw, frames=2):
+        """Average frame-kernel milliseconds of the strip [row_begin, row_end) over `frames` probe
+        frames (after one untimed frame) in a throw-away session; halos stay empty."""
+        nbytes = (row_end - row_begin + 2 * HALO_ROWS) * width * RES_BYTES
+        res = [self.empty_bytes(nbytes), self.empty_bytes(nbytes)]
+        stats = self.empty_i32(4)
+        session = self.make_session(dem, width, height, cam, row_begin, row_end, res, stats, kw)
+        try:
+            session.enqueue_frames(0, 1)
+            session.kernel_timing(True)
+            session.enqueue_frames(1, frames)
+            self.sync()
+            ms, _ = session.kernel_timing(False)
+        finally:
+            session.close()
+        return ms
+
 
 class StripRenderer:
-    def __init__(self, dem, width, height, cam, *, rank=0, world=1, device=0, backend=None, **kw):
+    def __init__(self, dem, width, height, cam, *, rank=0, world=1, device=0, backend=None, row_bounds=None,
+                 balance_iters=3, **kw):
         import torch
 
         self.torch = torch
         self.rank, self.world = rank, world
         self.width, self.height = int(width), int(height)
         self.backend = backend or HipBackend(device)
-        self.row_begin, self.row_end = strip_rows(self.height, world, rank)
+        self.balance_log = []
+        if row_bounds is not None:
+            self.bounds = [int(b) for b in row_bounds]
+            if (len(self.bounds) != world + 1 or self.bounds[0] != 0 or self.bounds[-1] != self.height
+                    or any(b1 - b0 < (HALO_ROWS if world > 1 else 1) for b0, b1 in zip(self.bounds, self.bounds[1:]))):
+                raise ValueError(f"row_bounds must be {world + 1} increasing rows from 0 to {self.height}, "
+                                 f"strips of at least {HALO_ROWS} rows")
+        else:
+            self.bounds = [strip_rows(self.height, world, r)[0] for r in range(world)] + [self.height]
+            if world > 1 and self.height < world * HALO_ROWS:
+                raise ValueError(f"strips need at least {HALO_ROWS} rows each ({self.height} rows / {world} ranks)")
+            if world > 1 and balance_iters > 0 and hasattr(self.backend, "probe"):
+                self.bounds = self._balance(dem, cam, kw, balance_iters)
+        self.row_begin, self.row_end = self.bounds[rank], self.bounds[rank + 1]
         self.rows = self.row_end - self.row_begin
-        if self.rows < HALO_ROWS and world > 1:
-            raise ValueError(f"strips need at least {HALO_ROWS} rows each ({self.height} rows / {world} ranks)")
         nbytes = (self.rows + 2 * HALO_ROWS) * self.width * RES_BYTES
         self.res = [self.backend.empty_bytes(nbytes), self.backend.empty_bytes(nbytes)]
         self.stats = self.backend.empty_i32(4)
@@ -97,6 +165,38 @@ class StripRenderer:
         self.variance_threshold = float(kw.get("variance_threshold", 1e-3))
         self.session = self.backend.make_session(dem, self.width, self.height, cam, self.row_begin, self.row_end,
                                                  self.res, self.stats, kw)
+
+    # -- load balancing ----------------------------------------------------------------
+    def _gather_floats(self, value: float):
+        import torch.distributed as dist
+
+        mine = self.torch.tensor([float(value)], dtype=self.torch.float64, device=self.backend.empty_i32(1).device)
+        parts = [self.torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(parts, mine)
+        return [float(p.item()) for p in parts]
+
+    def _balance(self, dem, cam, kw, iters):
+        """Measure-and-repartition loop (module docstring).  Every rank sees the same gathered
+        times, so every rank derives the same boundaries; the best MEASURED partition is kept."""
+        bounds = list(self.bounds)
+        density = np.ones(self.height)
+        best = None
+        for it in range(iters + 1):
+            ms = self.backend.probe(dem, self.width, self.height, cam, bounds[self.rank], bounds[self.rank + 1], kw)
+            times = self._gather_floats(ms)
+            if not all(np.isfinite(t) and t > 0.0 for t in times):
+                break  # backend without timing: keep what we have
+            self.balance_log.append({"bounds": list(bounds), "ms": times})
+            if best is None or max(times) < best[0]:
+                best = (max(times), list(bounds))
+            if it == iters:
+                break
+            density = rebalance(density, bounds, times)
+            new_bounds = partition_rows(density, self.world, HALO_ROWS)
+            if new_bounds == bounds:
+                break
+            bounds = new_bounds
+        return best[1] if best else list(self.bounds)
 
     # -- communication ------------------------------------------------------------------
     def _rows(self, which, first):
@@ -195,7 +295,7 @@ class StripRenderer:
 
         torch = self.torch
         dev = self.res[0].device
-        max_rows = -(-self.height // self.world) + 1
+        max_rows = max(b1 - b0 for b0, b1 in zip(self.bounds, self.bounds[1:]))
         result = {}
         for key, chans, dtype in (("rgba", 4, torch.uint8), ("albedo", 3, torch.float32),
                                   ("normal", 3, torch.float32), ("depth", 1, torch.float32)):
@@ -207,8 +307,7 @@ class StripRenderer:
             if self.rank == 0:
                 rows = []
                 for r in range(self.world):
-                    b, e = strip_rows(self.height, self.world, r)
-                    rows.append(parts[r][: e - b].cpu().numpy())
+                    rows.append(parts[r][: self.bounds[r + 1] - self.bounds[r]].cpu().numpy())
                 full = np.concatenate(rows, axis=0)
                 result[key] = full[..., 0] if key == "depth" else full
         return result if self.rank == 0 else None

@@ -101,6 +101,73 @@ HostTables build_tables_host(const float *heights, uint32_t w, uint32_t h, float
 }
 }  // namespace
 
+// CPU mirror of the frame kernel's sample-lane form (f3d_kernels.hip frame_lanes<S>): the S
+// "lanes" of a pixel are array slots stepped in lockstep -- hit flags predicted from the G-buffer,
+// primaries re-traced until every sample started from the right stream state, contributions
+// replayed in sample order.  Same helpers (sample_primary / sample_shade / accumulate_sample) as
+// the device code, so the CPU parity tests pin the speculation scheme against the oracle.
+static uint32_t g_sample_lanes = 1u;
+static uint64_t g_retraces = 0;  // primaries traced a second time (statistics for the tests)
+
+template <class Pending>
+static float frame_pixel_lanes(const FrameParams &P, uint32_t gx, uint32_t gy, uint32_t S, Pending &pend) {
+    const FrameHead h = frame_head(P, gx, gy);
+    uint32_t stream = h.rng;
+    V3 radiance = V3{0.0f, 0.0f, 0.0f};
+    Reservoir cand = empty_reservoir();
+    const uint32_t group = (1u << S) - 1u;
+    uint64_t retraces = 0;
+    for (uint32_t s0 = 0u; s0 < P.spp; s0 += S) {
+        const uint32_t n_act = P.spp - s0 < S ? P.spp - s0 : S;
+        uint32_t pred = h.centre_hit ? group : 0u;
+        uint32_t traced[8];
+        PrimaryHit ph[8];
+        for (uint32_t j = 0; j < 8u; j++) {
+            traced[j] = 0xFFFFFFFFu;
+            ph[j].hit.kind = 0u;
+            ph[j].rng = 0u;
+        }
+        for (;;) {
+            uint32_t draws[8];
+            bool need[8], any = false;
+            for (uint32_t j = 0; j < S; j++) {
+                draws[j] = 2u * j + 2u * (uint32_t)__builtin_popcount(pred & ((1u << j) - 1u));
+                need[j] = j < n_act && draws[j] != traced[j];
+                any = any || need[j];
+            }
+            if (!any) break;
+            for (uint32_t j = 0; j < S; j++) {
+                if (!need[j]) continue;
+                if (traced[j] != 0xFFFFFFFFu) retraces++;
+                uint32_t st = stream;
+                rng_skip(st, draws[j]);
+                ph[j] = sample_primary(P, gx, gy, st, pend);
+                traced[j] = draws[j];
+            }
+            pred = 0u;
+            for (uint32_t j = 0; j < n_act; j++)
+                if (ph[j].hit.kind != 0u) pred |= 1u << j;
+        }
+        SampleOut o[8];
+        for (uint32_t j = 0; j < n_act; j++) {
+            uint32_t rng = ph[j].rng;
+            o[j] = sample_shade(P, h, ph[j], rng, pend);
+        }
+        for (uint32_t k = 0; k < n_act; k++) accumulate_sample(cand, radiance, o[k].a, o[k].b, o[k].target_pdf);
+        rng_skip(stream, 2u * n_act + 2u * (uint32_t)__builtin_popcount(pred));
+    }
+    if (retraces) {
+#pragma omp atomic
+        g_retraces += retraces;
+    }
+    return frame_tail(P, gx, gy, cand, radiance);
+}
+
+template <class Pending>
+static float frame_pixel_any(const FrameParams &P, uint32_t gx, uint32_t gy, Pending &pend) {
+    return g_sample_lanes > 1u ? frame_pixel_lanes(P, gx, gy, g_sample_lanes, pend) : frame_pixel(P, gx, gy, pend);
+}
+
 extern "C" {
 
 int emul_trace_batch(const float *heights, uint32_t w, uint32_t h, float origin_x, float origin_z, float spacing_x,
@@ -247,7 +314,7 @@ int emul_render(const f3d_terrain_ref_desc *d, uint32_t row_begin, uint32_t row_
                 ArrayPending pend;
                 for (uint32_t x = 0; x < W; x++) {
                     if (logging) pend.log = &pixel_logs[(size_t)(y - row_begin) * W + x];
-                    const float v = frame_pixel(P, x, (uint32_t)y, pend);
+                    const float v = frame_pixel_any(P, x, (uint32_t)y, pend);
                     if (!f_finite(v)) nonfinite = true;
                     else vmax_m2 = f_max(vmax_m2, f_max(v, 0.0f));
                 }
@@ -370,7 +437,7 @@ void emul_session_frame(void *h, uint32_t frame, int32_t collect, uint32_t *stat
     for (uint32_t y = P.row_begin; y < P.row_end; y++) {
         ArrayPending pend;
         for (uint32_t x = 0; x < s->width; x++) {
-            const float v = frame_pixel(P, x, y, pend);
+            const float v = frame_pixel_any(P, x, y, pend);
             if (!f_finite(v)) bad = true;
             else vmax = f_max(vmax, f_max(v, 0.0f));
         }
@@ -395,5 +462,13 @@ int emul_session_resolve(void *h, uint32_t frames, uint8_t *rgba, float *albedo,
 }
 
 void emul_session_destroy(void *h) { delete (EmulSession *)h; }
+
+// sample lanes of the frame emulation (1 = frame_pixel; 2, 4, 8 = the frame_lanes mirror)
+void emul_set_sample_lanes(uint32_t lanes) { g_sample_lanes = (lanes == 2u || lanes == 4u || lanes == 8u) ? lanes : 1u; }
+uint64_t emul_take_retraces() {
+    const uint64_t r = g_retraces;
+    g_retraces = 0;
+    return r;
+}
 
 }  // extern "C"

@@ -47,9 +47,26 @@ def _worker(rank, world, port, out_path, mode):
         kw = scenes.fixed_frames(kw, 6, spp=2)
     else:  # converge through two Welford windows
         kw = {**kw, "variance_threshold": 5e-3, "max_frames": 256, "spp": 1}
-    r = StripRenderer(dem, 72, 50, scenes.CAM, rank=rank, world=world, backend=emul.EmulBackend(), **kw)
+    backend, extra = emul.EmulBackend(), {}
+    if mode == "balanced":
+        # synthetic probe: rows of the top half ("sky") cost 1, the others 5 -> unequal strips
+        class CostBackend(emul.EmulBackend):
+            def probe(self, dem, width, height, cam, row_begin, row_end, kw, frames=2):
+                return float(sum(1.0 if y < height // 2 else 5.0 for y in range(row_begin, row_end)))
+
+        backend = CostBackend()
+        kw = scenes.fixed_frames(kw, 6, spp=2)
+    if mode == "bounds":
+        extra["row_bounds"] = [0, 7, 50] if world == 2 else [0, 3, 41, 50]
+        kw = scenes.fixed_frames(kw, 6, spp=2)
+    r = StripRenderer(dem, 72, 50, scenes.CAM, rank=rank, world=world, backend=backend, **extra, **kw)
+    if mode == "balanced":
+        sizes = [b1 - b0 for b0, b1 in zip(r.bounds, r.bounds[1:])]
+        costs = [sum(1.0 if y < 25 else 5.0 for y in range(b0, b1)) for b0, b1 in zip(r.bounds, r.bounds[1:])]
+        assert sizes[0] > sizes[-1] and max(costs) / (sum(costs) / world) < 1.1, (r.bounds, costs)
+        assert len(r.balance_log) >= 2
     image = r.render() if mode == "converge" else None
-    if mode == "fixed":
+    if mode in ("fixed", "balanced", "bounds"):
         r.run_frames(0, 6, collect_last=True)
         var = r.window_variance(6)
         image = r.gather_image(6)
@@ -90,6 +107,42 @@ def test_strips_over_gloo_reproduce_the_single_strip_image(world):
     for key in ("rgba", "albedo", "normal", "depth"):
         assert np.array_equal(single[key], multi[key], equal_nan=True), key
     assert single["variance"] == multi["variance"]
+
+
+@pytest.mark.parametrize("world,mode", [(2, "balanced"), (3, "balanced"), (2, "bounds"), (3, "bounds")])
+def test_unequal_strips_reproduce_the_single_strip_image(world, mode):
+    """Load-balanced (measured, here with a synthetic cost probe) and hand-picked boundaries:
+    every rank derives the same partition and the stitched image is still bit-identical."""
+    single = _run(1, "fixed")
+    multi = _run(world, mode)
+    for key in ("rgba", "albedo", "normal", "depth"):
+        assert np.array_equal(single[key], multi[key], equal_nan=True), key
+    assert single["variance"] == multi["variance"]
+
+
+def test_partition_rows_balances_density_and_respects_the_halo_minimum():
+    from forge3d_amd.distributed import partition_rows, rebalance
+
+    h = 1080
+    density = np.where(np.arange(h) < 400, 0.2, 1.0)
+    for world in (2, 4, 8):
+        b = partition_rows(density, world)
+        assert b[0] == 0 and b[-1] == h and all(b1 - b0 >= 3 for b0, b1 in zip(b, b[1:]))
+        cost = [density[b0:b1].sum() for b0, b1 in zip(b, b[1:])]
+        assert max(cost) / (sum(cost) / world) < 1.02
+    # degenerate densities fall back to equal strips; tiny images keep >= 3 rows per strip
+    assert partition_rows(np.zeros(12), 4) == [0, 3, 6, 9, 12]
+    assert partition_rows([1e9, 0, 0, 0, 0, 0, 0, 0, 0, 1e9], 3) == [0, 3, 7, 10]
+    with pytest.raises(ValueError):
+        partition_rows(np.ones(8), 3)
+    # the multiplicative update converges on a step-shaped cost within a few rounds
+    true = np.where(np.arange(h) < 333, 0.15, 1.0)
+    est, b = np.ones(h), partition_rows(np.ones(h), 8)
+    for _ in range(4):
+        est = rebalance(est, b, [true[b0:b1].sum() for b0, b1 in zip(b, b[1:])])
+        b = partition_rows(est, 8)
+    cost = [true[b0:b1].sum() for b0, b1 in zip(b, b[1:])]
+    assert max(cost) / (sum(cost) / 8) < 1.05
 
 
 def test_distributed_convergence_gate_matches_single_process():

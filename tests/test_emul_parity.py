@@ -26,7 +26,6 @@ def _same(a, b):
     assert a["frames"] == b["frames"] and np.float32(a["variance"]) == np.float32(b["variance"])
 
 
-@pytest.mark.parametrize("state_machine", ["0", "1"])
 @pytest.mark.parametrize("size,spp,frames,extra", [
     ((64, 64), 1, 3, {}),
     ((96, 64), 3, 5, {}),
@@ -34,8 +33,7 @@ def _same(a, b):
     ((128, 96), 2, 34, {}),                       # crosses a Welford window + the M-clamp
     ((72, 56), 2, 4, {"earth_model": "flat", "refraction_model": "none", "sun_color": (0.2, 0.3, 1.5)}),
 ])
-def test_kernel_code_matches_oracle(monkeypatch, state_machine, size, spp, frames, extra):
-    monkeypatch.setenv("F3D_EMUL_STATE_MACHINE", state_machine)
+def test_kernel_code_matches_oracle(size, spp, frames, extra):
     dem = scenes.golden_dem()
     kw = scenes.fixed_frames(scenes.scene_kwargs(dem), frames, spp=spp, **extra)
     want = oracle.render(dem, size[0], size[1], scenes.CAM, dump_state=True, **kw)
@@ -44,6 +42,31 @@ def test_kernel_code_matches_oracle(monkeypatch, state_machine, size, spp, frame
     assert np.array_equal(got["accum"][:, :3], want["accum"][:, :3])          # accumulated radiance
     assert np.array_equal(got["accum"][:, 3], want["welford"][:, 0])          # Welford mean
     assert np.array_equal(got["m2"], want["welford"][:, 1])                   # Welford m2
+
+
+@pytest.mark.parametrize("lanes,size,spp,frames,extra", [
+    (2, (96, 64), 3, 5, {}),                      # odd spp: the last round has an idle lane
+    (4, (96, 64), 6, 4, {}),
+    (8, (96, 80), 8, 3, {}),
+    (8, (64, 48), 19, 2, {}),                     # three rounds, the last one ragged
+    (4, (80, 80), 4, 4, {"mesh_vertices": QUAD_V, "mesh_indices": QUAD_I}),
+    (8, (128, 96), 8, 34, {}),                    # Welford window + M-clamp
+    (8, (64, 64), 1, 3, {}),                      # fewer samples than lanes
+])
+def test_sample_lane_frames_match_oracle(lanes, size, spp, frames, extra):
+    """The frame kernel's sample-lane form (S samples of a pixel traced at once, hit flags
+    predicted from the G-buffer, contributions replayed in order) reproduces the sequential
+    sample loop bit for bit -- including the silhouette pixels where the prediction is wrong."""
+    dem = scenes.golden_dem()
+    kw = scenes.fixed_frames(scenes.scene_kwargs(dem), frames, spp=spp, **extra)
+    want = oracle.render(dem, size[0], size[1], scenes.CAM, dump_state=True, **kw)
+    got = emul.render(dem, size[0], size[1], scenes.CAM, sample_lanes=lanes, **kw)
+    _same(got, want)
+    assert np.array_equal(got["accum"][:, :3], want["accum"][:, :3])
+    assert np.array_equal(got["accum"][:, 3], want["welford"][:, 0])
+    assert np.array_equal(got["m2"], want["welford"][:, 1])
+    if spp > 1:
+        assert got["retraces"] > 0  # the scene has silhouettes: mispredictions were exercised
 
 
 def test_env_map_and_ragged_dem():

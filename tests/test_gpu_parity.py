@@ -82,6 +82,31 @@ def test_every_kernel_variant_is_bit_identical(f3d, oracle, variant):
             assert np.array_equal(got[key], want[key], equal_nan=True), (variant, key)
 
 
+@pytest.mark.parametrize("variant,spp", [(1000000, 8), (2000000, 8), (4000000, 8), (8000000, 8), (8001000, 8),
+                                         (4160000, 6), (8000000, 19), (2000000, 3), (8000000, 1), (0, 8)])
+def test_sample_lane_kernels_are_bit_identical(f3d, oracle, variant, spp):
+    """Sample lanes (x1000000: 1, 2, 4 or 8 samples of a pixel traced at once on neighbouring lanes,
+    hit flags predicted from the G-buffer, contributions replayed in sample order; 0 = automatic,
+    which picks 8 for an image this small) against the oracle's sequential sample loop: ragged
+    tiles, ragged last round, silhouettes (mispredicted hit flags), with and without a mesh."""
+    from forge3d_amd.session import TerrainSession
+
+    dem = scenes.golden_dem()
+    quad_v = np.array([[-18.0, 22.0, -6.0], [18.0, 22.0, -6.0], [18.0, 40.0, -6.0], [-18.0, 40.0, -6.0]], np.float32)
+    quad_i = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+    for extra in ({}, {"mesh_vertices": quad_v, "mesh_indices": quad_i}):
+        kw = scenes.fixed_frames(scenes.scene_kwargs(dem), 4, spp=spp, **extra)
+        want = oracle.render(dem, 110, 77, scenes.CAM, **kw)
+        with TerrainSession(dem, 110, 77, scenes.CAM, kernel_variant=variant, **kw) as s:
+            s.enqueue_frames(0, 4, True)
+            m2, bad = s.window_stats()
+            got = s.resolve(4)
+        assert not bad
+        assert np.float32(max(0.0, m2) / np.float32(3.0)) == np.float32(want["variance"])
+        for key in ("rgba", "albedo", "normal", "depth"):
+            assert np.array_equal(got[key], want[key], equal_nan=True), (variant, key)
+
+
 def test_ragged_nonsquare_dem_and_sun_colour(f3d, oracle):
     dem = scenes.golden_dem(2)[:37, :100].copy()  # 100 x 37 texels -> 128 x 64 padded pyramid
     kw = scenes.fixed_frames(scenes.scene_kwargs(dem), 6, spp=2, sun_color=(0.2, 0.3, 1.5), seed=12345,

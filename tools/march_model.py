@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""SIMT schedule model of the march kernel from the CPU emulator's per-ray step logs.
+
+Renders a strip of the headline frame (1920 wide, full DEM) through tests/emul with
+F3D_EMUL_RAYLOG and replays the per-ray march-step counts through schedules of a 64-lane
+wave (8x8 pixel tile).  Cost unit = one march iteration of the wave; a schedule's lane
+utilisation = total lane-steps / (64 * wave iterations).
+
+  nested        shipped kernel: per sample, primary / shadow / IBL phases in lockstep
+  sec-fused     per sample: primary, then each lane runs shadow+IBL back to back
+  sec-batched   all primaries of the frame first (lockstep), then each lane runs all its
+                secondary rays back to back
+  continuous    each lane runs all of its rays back to back
+  ideal         perfect packing
+"""
+import os
+import struct
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+
+def load_log(path):
+    data = open(path, "rb").read()
+    W, rows, spp, _ = struct.unpack_from("<4I", data, 0)
+    off = 16
+    rec = np.dtype([("kind", "<u4"), ("steps", "<u4"), ("mask", "<u8")])
+    pixels = []
+    for _ in range(W * rows):
+        (n,) = struct.unpack_from("<I", data, off)
+        off += 4
+        pixels.append(np.frombuffer(data, rec, n, off))
+        off += 16 * n
+    return W, rows, spp, pixels
+
+
+def main():
+    from emul import emul
+    from forge3d_amd import datasets
+
+    rows = tuple(int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "480:608").split(":"))
+    w, h, spp = 1920, 1080, 8
+    dem, cam, kw = datasets.rainier_proxy_scene(2048)
+    log = tempfile.mktemp(suffix=".raylog")
+    os.environ["F3D_EMUL_RAYLOG"] = log
+    emul.render(dem, w, h, cam, rows=rows, **dict(kw, spp=spp, max_frames=2, min_frames=2, variance_threshold=1e30))
+    W, R, spp, pixels = load_log(log)
+    os.unlink(log)
+
+    names = ["nested", "sec-fused", "sec-batched", "continuous"]
+    cost = dict.fromkeys(names, 0.0)
+    lane_steps = 0.0
+    by_kind = {2: [0.0, 0.0], 7: [0.0, 0.0], 3: [0.0, 0.0]}
+    leafs = 0
+    hist = []
+    for ty in range(0, R, 8):
+        for tx in range(0, W, 8):
+            lanes = [pixels[y * W + x] for y in range(ty, min(ty + 8, R)) for x in range(tx, min(tx + 8, W))]
+            # per lane: samples[s] = (primary, shadow, ibl) step counts
+            P = np.zeros((len(lanes), spp, 3))
+            for li, rays in enumerate(lanes):
+                s = -1
+                for kind, steps, mask in rays:
+                    if kind == 2:
+                        s += 1
+                        P[li, s, 0] = steps
+                    elif kind == 7:
+                        P[li, s, 1] = steps
+                    else:
+                        P[li, s, 2] = steps
+                    leafs += bin(int(mask)).count("1")
+            lane_steps += P.sum()
+            mx = P.max(axis=0)  # (spp, 3)
+            cost["nested"] += mx.sum()
+            cost["sec-fused"] += mx[:, 0].sum() + (P[:, :, 1] + P[:, :, 2]).max(axis=0).sum()
+            cost["sec-batched"] += mx[:, 0].sum() + (P[:, :, 1] + P[:, :, 2]).sum(axis=1).max()
+            cost["continuous"] += P.sum(axis=(1, 2)).max()
+            for j, k in enumerate((2, 7, 3)):
+                by_kind[k][0] += P[:, :, j].sum()
+                by_kind[k][1] += 64 * mx[:, j].sum()
+            hist.append(P.reshape(-1))
+    n_rays = sum(len(p) for p in pixels)
+    print(f"rows {rows}: {n_rays} rays, {lane_steps / n_rays:.1f} steps/ray, {leafs / n_rays:.2f} queued leaves/ray")
+    for k, name in ((2, "primary"), (7, "shadow"), (3, "ibl")):
+        u, c = by_kind[k]
+        print(f"  {name:8s}: lane-steps {u:.3g} ({u / lane_steps:.1%} of all), lockstep utilisation {u / c:.3f}")
+    for name in names:
+        print(f"  {name:12s}: utilisation {lane_steps / (64 * cost[name]):.3f}  wave iterations {cost[name]:.0f}")
+    print(f"  ideal       : wave iterations {lane_steps / 64:.0f}")
+    allp = np.concatenate(hist)
+    allp = allp[allp > 0]
+    print("  steps/ray percentiles 10/50/90/99/max:", [float(np.percentile(allp, q)) for q in (10, 50, 90, 99, 100)])
+
+
+
+
+def simulate_batched(P, batch, quorum, switch_cost):
+    """Phase-B simulator: P (lanes, spp, 3) step counts; per batch of `batch` samples the lanes run
+    their secondary rays back to back; finished lanes wait until `quorum` lanes wait (or nobody
+    marches), then all of them switch (cost `switch_cost` iterations)."""
+    lanes, spp, _ = P.shape
+    total = 0.0
+    for b0 in range(0, spp, batch):
+        total += P[:, b0:b0 + batch, 0].max(axis=0).sum()  # primaries in lockstep
+        queues = []
+        for li in range(lanes):
+            q = [x for s in range(b0, min(b0 + batch, spp)) for x in (P[li, s, 1], P[li, s, 2]) if x > 0]
+            queues.append(q[::-1])
+        remaining = np.zeros(lanes)
+        pending = np.array([len(q) for q in queues])
+        while True:
+            waiting = (remaining <= 0) & (pending > 0)
+            marching = remaining > 0
+            if not marching.any() and not waiting.any():
+                break
+            if waiting.sum() >= quorum or not marching.any():
+                total += switch_cost
+                for li in np.nonzero(waiting)[0]:
+                    remaining[li] = queues[li].pop()
+                    pending[li] -= 1
+                marching = remaining > 0
+            # advance to the next event in one go
+            if waiting.sum() >= quorum:
+                continue
+            live = remaining[marching]
+            # steps until the number of waiting lanes can change
+            step = live.min()
+            total += step
+            remaining[marching] -= step
+    return total
+
+
+def batched_table(rows="480:608"):
+    from emul import emul
+    from forge3d_amd import datasets
+
+    rows = tuple(int(x) for x in rows.split(":"))
+    w, h, spp = 1920, 1080, 8
+    dem, cam, kw = datasets.rainier_proxy_scene(2048)
+    log = tempfile.mktemp(suffix=".raylog")
+    os.environ["F3D_EMUL_RAYLOG"] = log
+    emul.render(dem, w, h, cam, rows=rows, **dict(kw, spp=spp, max_frames=2, min_frames=2, variance_threshold=1e30))
+    W, R, spp, pixels = load_log(log)
+    os.unlink(log)
+    waves = []
+    for ty in range(0, R, 8):
+        for tx in range(0, W, 8 * 4):  # every 4th tile: the simulator is slow
+            lanes = [pixels[y * W + x] for y in range(ty, min(ty + 8, R)) for x in range(tx, min(tx + 8, W))]
+            P = np.zeros((len(lanes), spp, 3))
+            for li, rays in enumerate(lanes):
+                s = -1
+                for kind, steps, mask in rays:
+                    if kind == 2:
+                        s += 1
+                    P[li, s, {2: 0, 7: 1}.get(int(kind), 2)] = steps
+            waves.append(P)
+    lane_steps = sum(P.sum() for P in waves)
+    nested = sum(P.max(axis=0).sum() for P in waves)
+    print(f"{len(waves)} waves; nested iterations {nested:.0f} (utilisation {lane_steps / 64 / nested:.3f})")
+    for batch in (1, 2, 4, 8):
+        for quorum in (1, 8, 16, 32):
+            for sc in (1.5, 3.0):
+                c = sum(simulate_batched(P, batch, quorum, sc) for P in waves)
+                print(f"  batch {batch} quorum {quorum:2d} switch {sc}: iterations {c:.0f}  = {nested / c:.2f}x fewer")
+
+
+def ibl_batched_bound(rows="480:608"):
+    """Upper bound (free switches) for deferring only the IBL rays of B consecutive samples."""
+    from emul import emul
+    from forge3d_amd import datasets
+
+    rows = tuple(int(x) for x in rows.split(":"))
+    dem, cam, kw = datasets.rainier_proxy_scene(2048)
+    log = tempfile.mktemp(suffix=".raylog")
+    os.environ["F3D_EMUL_RAYLOG"] = log
+    emul.render(dem, 1920, 1080, cam, rows=rows, **dict(kw, spp=8, max_frames=2, min_frames=2, variance_threshold=1e30))
+    W, R, spp, pixels = load_log(log)
+    os.unlink(log)
+    nested = 0.0
+    alt = {2: 0.0, 4: 0.0, 8: 0.0}
+    alt_si = {2: 0.0, 4: 0.0, 8: 0.0}
+    for ty in range(0, R, 8):
+        for tx in range(0, W, 8):
+            lanes = [pixels[y * W + x] for y in range(ty, min(ty + 8, R)) for x in range(tx, min(tx + 8, W))]
+            P = np.zeros((len(lanes), spp, 3))
+            for li, rays in enumerate(lanes):
+                s = -1
+                for kind, steps, mask in rays:
+                    if kind == 2:
+                        s += 1
+                    P[li, s, {2: 0, 7: 1}.get(int(kind), 2)] = steps
+            mx = P.max(axis=0)
+            nested += mx.sum()
+            for B in alt:
+                ib = P[:, :, 2].reshape(len(lanes), spp // B, B).sum(axis=2).max(axis=0).sum()
+                alt[B] += mx[:, 0].sum() + mx[:, 1].sum() + ib
+                sb = P[:, :, 1].reshape(len(lanes), spp // B, B).sum(axis=2).max(axis=0).sum()
+                alt_si[B] += mx[:, 0].sum() + sb + ib
+    for B in alt:
+        print(f"  IBL rays of {B} samples back to back: {nested / alt[B]:.3f}x fewer iterations;"
+              f" + shadow rays likewise (separately): {nested / alt_si[B]:.3f}x")
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "batched":
+        batched_table(sys.argv[1])
+    elif len(sys.argv) > 2 and sys.argv[2] == "ibl":
+        ibl_batched_bound(sys.argv[1])
+    else:
+        main()
