@@ -32,7 +32,9 @@ sys.path.insert(0, str(ROOT))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-STATE_BYTES_PER_PIXEL_FRAME = 88  # res r16+w16, accum r16+w16, m2 r4+w4, g-buffer r16
+# reservoir r16+w16, accumulation r16+w16, Welford m2 r4+w4, G-buffer r16 = 88 B per
+# pixel-frame; the sample-lane form of the frame kernel adds the frame-head record (w8 + r8)
+STATE_BYTES_PER_PIXEL_FRAME = {False: 88, True: 104}
 
 
 def parse_args():
@@ -46,14 +48,14 @@ def parse_args():
     ap.add_argument("--dem", type=int, default=2048)
     ap.add_argument("--variant", type=int, default=int(os.environ.get("F3D_KERNEL_VARIANT", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the cpu_baseline sample")
     return ap.parse_args()
 
 
 def cpu_baseline(dem, cam, kw, args):
     """Time the CPU oracle (test infrastructure, used here ONLY as the reported baseline) on a
-    bounded sample of the same workload: same DEM/camera/sun/spp at reduced resolution and 2
-    frames, sized for ~args.cpu_seconds of CPU work; also returns the per-sample traversal
+    bounded sample of the same workload: same DEM/camera/sun/spp, resolution and frame count
+    sized for ~args.cpu_seconds of CPU work; also returns the per-sample traversal
     counts that define the algorithmic bytes."""
     from oracle import oracle
 
@@ -66,9 +68,13 @@ def cpu_baseline(dem, cam, kw, args):
     budget = args.cpu_seconds * rate  # samples the host can trace in the target time
     scale = min(args.width / w, max(1.0, (budget / probe["n_samples"]) ** 0.5))
     w2, h2 = min(args.width, int(w * scale) // 8 * 8), min(args.height, int(h * scale) // 8 * 8)
-    frames = int(max(2, min(32, budget // (w2 * h2 * args.spp))))
-    k.update(max_frames=frames, min_frames=frames)
-    out = oracle.render(dem, w2, h2, cam, **k)
+    out = oracle.render(dem, w2, h2, cam, **k)  # 2 frames at the sample's resolution: the real rate
+    frames = int(min(32, args.cpu_seconds * out["n_samples"] / max(out["loop_seconds"], 1e-9) // (w2 * h2 * args.spp)))
+    if frames >= 3:
+        k.update(max_frames=frames, min_frames=frames)
+        out = oracle.render(dem, w2, h2, cam, **k)
+    else:
+        frames = 2
     n = out["n_samples"]
     return {
         "value": n / out["loop_seconds"] / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
@@ -144,7 +150,8 @@ def main():
                                           "sample": f"failed: {exc}"}
         if counts is not None:
             # algorithmic bytes per sample: S/k + 8 n_node + 16 n_leaf + 16 n_hit
-            b_alg = (STATE_BYTES_PER_PIXEL_FRAME / args.spp + 8.0 * counts["n_node"] + 16.0 * counts["n_leaf"]
+            lanes = r.session.sample_lanes()
+            b_alg = (STATE_BYTES_PER_PIXEL_FRAME[lanes > 1] / args.spp + 8.0 * counts["n_node"] + 16.0 * counts["n_leaf"]
                      + 16.0 * counts["n_hit"])
             per_launch = b_alg * samples_per_step / world
             achieved = per_launch / (kernel_ms * 1e-3) / 1e9
@@ -154,14 +161,15 @@ def main():
             traffic = None
             try:
                 pmc = json.loads((ROOT / "profiles" / "r01_pmc_traffic.json").read_text())
-                if world == 1 and (args.width, args.height, args.spp, args.dem) == (1920, 1080, 8, 2048):
+                if (world == 1 and (args.width, args.height, args.spp, args.dem) == (1920, 1080, 8, 2048)
+                        and pmc.get("sample_lanes", 1) == lanes):
                     traffic = pmc["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
             result["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_frame",
-                "kernel_ms": kernel_ms, "launches": launches, "bytes_per_sample": b_alg,
+                "kernel_ms": kernel_ms, "launches": launches, "bytes_per_sample": b_alg, "sample_lanes": lanes,
                 "per_sample_counts": counts,
             }
         if image is not None:

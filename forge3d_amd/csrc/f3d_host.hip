@@ -187,13 +187,13 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
     // + 1000000 * sample lanes per pixel (f3d_kernels.hip frame_lanes): 1, 2, 4, 8; 0 = automatic.
     // A wave of the 1-lane kernel lasts spp x 3 traversals whatever the image size, so small images
     // and thin multi-GPU strips are latency-bound and even a 1080p frame ends in a ~1 ms tail of
-    // half-empty SIMDs; trading pixels per wave for sample lanes keeps ~16 waves per wave slot
-    // (measured at 1080p / 8 spp: 3881, 4866, 5024, 4898 Msamples/s for 1, 2, 4, 8 lanes).
+    // half-empty SIMDs; trading pixels per wave for sample lanes keeps ~32 waves per wave slot
+    // (measured at 1080p / 8 spp: 3881, 4860, 5074, 5120 Msamples/s for 1, 2, 4, 8 lanes).
     {
         uint32_t lanes = (uint32_t)((s.variant / 1000000) % 10);
         if (lanes == 0u && s.variant % 1000 != 0) lanes = 1u;  // register-budget A/B kernels exist for 1 lane only
         if (lanes == 0u) {
-            constexpr uint64_t kTargetWaves = 98304;  // 16 x (256 CUs x 4 SIMDs x 6 waves)
+            constexpr uint64_t kTargetWaves = 196608;  // 32 x (256 CUs x 4 SIMDs x 6 waves)
             lanes = 1u;
             while (lanes < 8u && lanes * 2u <= P.spp && ((uint64_t)s.rows * s.width * lanes + 63u) / 64u < kTargetWaves)
                 lanes *= 2u;
@@ -211,7 +211,8 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
         // set BEFORE the large allocations are made (the reference allocates, then checks).
         const uint64_t planned = s.mem.device_bytes + 2 * (uint64_t)res_n * sizeof(PackedReservoir) +
                                  (uint64_t)px * (sizeof(float4) + sizeof(float) + sizeof(float4) + sizeof(float) + 4 +
-                                                 3 * sizeof(float) + 3 * sizeof(float)) + 16;
+                                                 3 * sizeof(float) + 3 * sizeof(float) +
+                                                 (P.sample_lanes > 1u ? sizeof(uint2) : 0)) + 16;
         if (planned > s.budget)
             fail(F3D_STATUS_RENDER,
                  "terrain PT exceeds the memory budget before rendering: tracked total %llu (host-visible %llu) > "
@@ -228,6 +229,7 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
         }
         hip_check(hipMemsetAsync(s.res[i], 0, res_n * sizeof(PackedReservoir), s.stream), "reservoir clear");
     }
+    if (P.sample_lanes > 1u) P.head = (uint2 *)s.mem.alloc(px * sizeof(uint2), "frame head records");
     P.accum_mean = (float4 *)s.mem.alloc(px * sizeof(float4), "accumulation");
     P.welford_m2 = (float *)s.mem.alloc(px * sizeof(float), "welford");
     s.gbuffer_n = (float4 *)s.mem.alloc(px * sizeof(float4), "g-buffer");
@@ -267,6 +269,7 @@ void enqueue_frame(f3d_session &s, uint32_t frame, bool collect) {
     P.res_in = s.res[(frame & 1u) ^ 1u];
     P.collect_stats = collect ? 1u : 0u;
     if (collect) hip_check(hipMemsetAsync(s.stats, 0, 2 * sizeof(uint32_t), s.stream), "stats clear");
+    if (P.sample_lanes > 1u) hip_check(launch_head(P, s.stream), "frame head kernel");
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (s.timing) {
         hip_check(hipEventCreate(&e0), "event");
@@ -443,6 +446,8 @@ int f3d_session_kernel_timing(f3d_session *s, int32_t enable, double *avg_ms, ui
     if (avg_ms) *avg_ms = s->events.empty() ? 0.0 : total / (double)s->events.size();
     return F3D_STATUS_OK;
 }
+
+uint32_t f3d_session_sample_lanes(f3d_session *s) { return s ? s->params.sample_lanes : 0u; }
 
 int f3d_terrain_ref_render(const f3d_terrain_ref_desc *desc, f3d_terrain_ref_out *out, char *err, size_t errlen) {
     if (err && errlen) err[0] = 0;

@@ -18,10 +18,13 @@ constexpr int kNumXcd = 8;
 // can look its (per-lane) level up with one ds_read_b64 instead of a vector load from the kernarg
 // segment, and -- only for the sorted descent kept for the test hook / A-B builds -- the
 // pending-sibling words as a [level][lane] column (bank = lane, conflict-free).
-constexpr int kLdsWords = kMaxLevels * kWave + 4 * kMaxLevels;
+// Rows kParkRow.. of the column hold the sample-lane frame's accumulators between rounds.
+constexpr int kParkRow = 3 * kLeafFifo, kParkWords = 7;
+constexpr int kLdsRows = kParkRow + kParkWords > kMaxLevels ? kParkRow + kParkWords : kMaxLevels;
+constexpr int kLdsWords = kLdsRows * kWave + 4 * kMaxLevels;
 struct LdsPending {
     uint32_t *col;          // lds + lane
-    const uint32_t *table;  // lds + kMaxLevels * kWave: {band_offset, band_shift, node_offset, tiles_x} per level
+    const uint32_t *table;  // lds + kLdsRows * kWave: {band_offset, band_shift, node_offset, tiles_x} per level
     uint32_t leaf_quorum;
     __device__ __forceinline__ void put(uint32_t level, uint32_t word) { col[level * kWave] = word; }
     __device__ __forceinline__ uint32_t get(uint32_t level) const { return col[level * kWave]; }
@@ -65,14 +68,14 @@ struct LdsPending {
 };
 __device__ __forceinline__ LdsPending make_pending(uint32_t *lds, const TerrainDev &T) {
     if (threadIdx.x < kMaxLevels) {
-        uint32_t *e = lds + kMaxLevels * kWave + 4 * threadIdx.x;
+        uint32_t *e = lds + kLdsRows * kWave + 4 * threadIdx.x;
         e[0] = T.band_offset[threadIdx.x];
         e[1] = T.band_shift[threadIdx.x];
         e[2] = T.node_offset[threadIdx.x];
         e[3] = T.tiles_x[threadIdx.x];
     }
     __syncthreads();
-    return LdsPending{lds + threadIdx.x, lds + kMaxLevels * kWave, T.leaf_quorum ? T.leaf_quorum : kDefaultLeafQuorum};
+    return LdsPending{lds + threadIdx.x, lds + kLdsRows * kWave, T.leaf_quorum ? T.leaf_quorum : kDefaultLeafQuorum};
 }
 
 // Pixel tile of a wave with S sample lanes per pixel: 64 / S pixels, TW x TH.
@@ -154,16 +157,21 @@ __device__ __forceinline__ void publish_window_stats(const FrameParams &P, bool 
 //       right, so this settles in at most S rounds and in one for almost every pixel.
 //   (b) radiance sum and candidate reservoir: every lane of the group replays all S contributions in
 //       sample order (7 ds_bpermute per sample), so each holds the exact running values.
-// Results are bit-identical to frame_pixel; frame head and tail run redundantly on the S lanes
-// (only sample lane 0 writes), which costs S x their ~4 % share -- the price of S x shorter waves.
+// Results are bit-identical to frame_pixel.  The frame head (spatial reuse of the previous frame,
+// ~1 200 instructions a pixel) would run redundantly on all S lanes, so it runs in its own
+// pixel-parallel launch (k_head) and leaves an 8-byte record per pixel; the short tail runs on
+// sample lane 0.
 template <uint32_t S>
 __device__ __forceinline__ float frame_lanes(const FrameParams &P, uint32_t gx, uint32_t gy, LdsPending &pend) {
     const uint32_t lane = threadIdx.x, j = lane & (S - 1u), base = lane & ~(S - 1u);
     constexpr uint32_t kGroup = (1u << S) - 1u;
-    const FrameHead h = frame_head(P, gx, gy);  // identical on the S lanes of the pixel
-    uint32_t stream = h.rng;                    // state at the start of the current round
-    V3 radiance = V3{0.0f, 0.0f, 0.0f};
-    Reservoir cand = empty_reservoir();
+    const FrameHead h = unpack_head(P, gx, gy, P.head[(size_t)(gy - P.row_begin) * P.cam.width + gx]);  // k_head
+    uint32_t stream = h.rng;  // state at the start of the current round
+    // The accumulators live in the lane's LDS column between rounds (7 words), not in registers:
+    // nothing reads them while the rays of a round are traced.
+    uint32_t *park = pend.col + kParkRow * kWave;
+#pragma unroll
+    for (int w = 0; w < kParkWords; w++) park[w * kWave] = 0u;  // radiance = 0, empty candidate reservoir
     for (uint32_t s0 = 0u; s0 < P.spp; s0 += S) {  // wave-uniform
         const uint32_t n_act = P.spp - s0 < S ? P.spp - s0 : S;
         const bool act = j < n_act;
@@ -192,6 +200,13 @@ __device__ __forceinline__ float frame_lanes(const FrameParams &P, uint32_t gx, 
             uint32_t rng = ph.rng;
             o = sample_shade(P, h, ph, rng, pend);
         }
+        V3 radiance = V3{f_from_bits(park[0]), f_from_bits(park[kWave]), f_from_bits(park[2 * kWave])};
+        Reservoir cand;
+        cand.w_sum = f_from_bits(park[3 * kWave]);
+        cand.m = park[4 * kWave];
+        cand.target_pdf = f_from_bits(park[5 * kWave]);
+        cand.directional = park[6 * kWave] != 0u;
+        cand.weight = 0.0f;
 #pragma unroll
         for (uint32_t k = 0u; k < S; k++) {
             const int src = (int)(base + k);
@@ -200,9 +215,29 @@ __device__ __forceinline__ float frame_lanes(const FrameParams &P, uint32_t gx, 
             const float tp = __shfl(o.target_pdf, src, kWave);
             if (k < n_act) accumulate_sample(cand, radiance, a, b, tp);
         }
+        park[0] = f_bits(radiance.x);
+        park[kWave] = f_bits(radiance.y);
+        park[2 * kWave] = f_bits(radiance.z);
+        park[3 * kWave] = f_bits(cand.w_sum);
+        park[4 * kWave] = cand.m;
+        park[5 * kWave] = f_bits(cand.target_pdf);
+        park[6 * kWave] = cand.directional ? 1u : 0u;
         rng_skip(stream, 2u * n_act + 2u * (uint32_t)__popc(pred));
     }
-    return j == 0u ? frame_tail(P, gx, gy, cand, radiance) : 0.0f;
+    if (j != 0u) return 0.0f;
+    Reservoir cand;
+    cand.w_sum = f_from_bits(park[3 * kWave]);
+    cand.m = park[4 * kWave];
+    cand.target_pdf = f_from_bits(park[5 * kWave]);
+    cand.directional = park[6 * kWave] != 0u;
+    cand.weight = 0.0f;
+    return frame_tail(P, gx, gy, cand, V3{f_from_bits(park[0]), f_from_bits(park[kWave]), f_from_bits(park[2 * kWave])});
+}
+
+// Frame head of the sample-lane form: one lane per pixel (8x8 tiles).
+__global__ __launch_bounds__(kWave) void k_head(const FrameParams P) {
+    uint32_t gx, gy;
+    if (tile_pixel(P, gx, gy)) P.head[(size_t)(gy - P.row_begin) * P.cam.width + gx] = pack_head(frame_head(P, gx, gy));
 }
 
 // VARIANT is reserved for A/B builds (0 = the shipped kernel).
@@ -292,14 +327,24 @@ static inline uint32_t frame_grid(const FrameParams &p, uint32_t lanes = 1u) {
     return ((tiles_x * tiles_y + kNumXcd - 1u) / kNumXcd) * kNumXcd;
 }
 
+hipError_t launch_head(const FrameParams &p, hipStream_t stream) {
+    hipLaunchKernelGGL(k_head, dim3(frame_grid(p)), dim3(kWave), 0, stream, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_frame(const FrameParams &p, int variant, hipStream_t stream) {
     const uint32_t lanes = p.sample_lanes ? p.sample_lanes : 1u;
     const dim3 grid(frame_grid(p, lanes)), block(kWave);
-    if (lanes != 1u) {  // sample-lane kernels: one register budget (6 waves/SIMD)
-        switch (lanes) {
-            case 2: hipLaunchKernelGGL((k_frame<0, 6, 2>), grid, block, 0, stream, p); break;
-            case 4: hipLaunchKernelGGL((k_frame<0, 6, 4>), grid, block, 0, stream, p); break;
-            case 8: hipLaunchKernelGGL((k_frame<0, 6, 8>), grid, block, 0, stream, p); break;
+    if (lanes != 1u) {  // sample-lane kernels (register-budget A/B variants for 4 and 8 lanes only)
+        switch (lanes * 1000 + (uint32_t)(variant % 1000)) {
+            case 2000: hipLaunchKernelGGL((k_frame<0, 6, 2>), grid, block, 0, stream, p); break;
+            case 4000: hipLaunchKernelGGL((k_frame<0, 6, 4>), grid, block, 0, stream, p); break;
+            case 4104: hipLaunchKernelGGL((k_frame<0, 4, 4>), grid, block, 0, stream, p); break;
+            case 4105: hipLaunchKernelGGL((k_frame<0, 5, 4>), grid, block, 0, stream, p); break;
+            case 4108: hipLaunchKernelGGL((k_frame<0, 8, 4>), grid, block, 0, stream, p); break;
+            case 8000: hipLaunchKernelGGL((k_frame<0, 6, 8>), grid, block, 0, stream, p); break;
+            case 8104: hipLaunchKernelGGL((k_frame<0, 4, 8>), grid, block, 0, stream, p); break;
+            case 8105: hipLaunchKernelGGL((k_frame<0, 5, 8>), grid, block, 0, stream, p); break;
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();

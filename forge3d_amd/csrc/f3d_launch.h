@@ -26,6 +26,7 @@ struct ResolveParams {
     float *albedo, *normal;
 };
 
+hipError_t launch_head(const FrameParams &p, hipStream_t stream);  // sample-lane form: before launch_frame
 hipError_t launch_frame(const FrameParams &p, int variant, hipStream_t stream);
 hipError_t launch_gbuffer(const FrameParams &p, float4 *gbuffer_n, float *depth, hipStream_t stream);
 hipError_t launch_resolve(const ResolveParams &p, hipStream_t stream);

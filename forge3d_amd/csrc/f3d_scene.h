@@ -134,6 +134,7 @@ struct FrameParams {
     uint32_t collect_stats;         // this frame closes a convergence window
     uint32_t tile_map;              // workgroup -> tile mapping (f3d_kernels.hip tile_pixel)
     uint32_t sample_lanes;          // lanes per pixel in the frame kernel: 1 (frame_pixel), 2, 4, 8 (frame_lanes)
+    uint2 *head;                    // sample-lane form only: per-pixel record of k_head {reuse_w bits, flags}
 };
 
 }  // namespace f3d

@@ -298,6 +298,21 @@ F3D_HD FrameHead frame_head(const FrameParams &P, uint32_t gx, uint32_t gy) {
     return h;
 }
 
+// FrameHead as an 8-byte record (the sample-lane frame runs frame_head in its own pixel-parallel
+// kernel, f3d_kernels.hip k_head, instead of once per sample lane); the stream seed is recomputed.
+constexpr uint32_t kHeadPrevValid = 1u, kHeadCentreHit = 2u;
+F3D_HD uint2 pack_head(const FrameHead &h) {
+    return uint2{f_bits(h.reuse_w), (h.prev_valid ? kHeadPrevValid : 0u) | (h.centre_hit ? kHeadCentreHit : 0u)};
+}
+F3D_HD FrameHead unpack_head(const FrameParams &P, uint32_t gx, uint32_t gy, uint2 rec) {
+    FrameHead h;
+    h.centre_hit = (rec.y & kHeadCentreHit) != 0u;
+    h.prev_valid = (rec.y & kHeadPrevValid) != 0u;
+    h.reuse_w = f_from_bits(rec.x);
+    h.rng = P.cam.seed_hi ^ (gx * 1664525u) ^ (gy * 1013904223u) ^ (P.frame_index * 92837111u) ^ P.cam.seed_lo;
+    return h;
+}
+
 // ---- one camera sample, cut where the samples of a pixel depend on one another -----------
 // Samples of a pixel-frame are chained only through (a) the RNG stream -- a sample draws 2 numbers
 // for its jitter and 2 more for the IBL direction IF its primary ray hit (:477-478, :537-538), so

@@ -124,6 +124,10 @@ class TerrainSession:
         return {"gpu_resource_bytes": int(g.value), "minmax_pyramid_bytes": int(p.value),
                 "peak_host_visible_bytes": int(h.value), "rows": int(rows.value), "width": int(width.value)}
 
+    def sample_lanes(self) -> int:
+        """Sample lanes per pixel of the frame kernel (1, 2, 4 or 8; chosen from the strip size and spp)."""
+        return int(self._lib.f3d_session_sample_lanes(self._handle))
+
     def kernel_timing(self, enable: bool):
         """enable=True starts recording a hipEvent pair around every frame launch;
         enable=False stops and returns (average ms per launch, launches)."""

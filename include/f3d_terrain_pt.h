@@ -109,7 +109,9 @@ typedef struct f3d_session_opts {
     uint32_t row_begin;  /* first owned image row */
     uint32_t row_end;    /* one past the last owned row; 0 = height */
     uint64_t memory_budget_bytes; /* 0 = 512 MiB (reference MEMORY_BUDGET_LIMIT) */
-    int32_t kernel_variant;       /* 0 = default; others are A/B variants for profiling */
+    int32_t kernel_variant;       /* 0 = default.  Tuning digits: v % 1000 register-budget A/B kernel,
+                                   * (v / 1000) % 10 tile-to-XCD map, (v / 10000) % 100 leaf-FIFO drain quorum,
+                                   * (v / 1000000) % 10 sample lanes per pixel (1, 2, 4, 8; 0 = automatic) */
     /* Optional caller-owned DEVICE buffers (NULL -> the library allocates).  The
      * strip driver allocates these as torch tensors so RCCL can move them.
      *   reservoirs[2]: ping-pong packed reservoirs, each (rows + 6) * width * 16 B,
@@ -155,6 +157,8 @@ int f3d_session_info(f3d_session *session, uint64_t *gpu_resource_bytes, uint64_
  * measured with hipEvents recorded on the session stream around every launch when
  * timing is enabled (bench.py's roofline leg).  enable: 1 start, 0 stop. */
 int f3d_session_kernel_timing(f3d_session *session, int32_t enable, double *avg_ms, uint32_t *launches);
+/* Sample lanes per pixel the frame kernel of this session runs with (1, 2, 4 or 8); 0 on a NULL session. */
+uint32_t f3d_session_sample_lanes(f3d_session *session);
 
 /* ---- test hooks (KATs restated from the reference's Rust unit tests) ----------- */
 /* build_minmax_mips on the GPU (reference terrain_heightfield.rs:132-202); output in

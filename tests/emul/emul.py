@@ -155,6 +155,9 @@ class _EmulStripSession:
     def kernel_timing(self, enable):
         return 0.0, 0
 
+    def sample_lanes(self):
+        return 1
+
     def close(self):
         if self._h:
             lib().emul_session_destroy(C.c_void_p(self._h))
