@@ -1,0 +1,219 @@
+// forge3d_amd/csrc/f3d_bvh.h -- mesh acceleration structure (host build, HIP-free).
+//
+// Reference: the driver builds a SAH BVH on the CPU for the optional mesh (`accel::build_bvh`,
+// src/accel/sah_cpu.rs:23-96, called from render_terrain.rs:597-627) and uploads it, but its
+// kernel never reads it: `intersect_mesh` sweeps every triangle (hybrid_traversal.wgsl:137-172).
+// The RESULT of that sweep is "the triangle with the smallest Moller-Trumbore t, the lowest index
+// among equal t" (closest hit) or "is there any triangle hit" (occlusion rays).  Here the BVH is
+// actually used: same per-triangle arithmetic, same answer, O(log T) instead of O(T) per ray.
+//
+// Layout for the GPU: a THREADED binary BVH in depth-first preorder -- a ray that enters node i
+// continues at i + 1 (its first child, or the node after a leaf's triangles are tested), a ray
+// that misses it continues at skip[i] (the node after i's subtree).  No stack, no per-lane LDS, one
+// 32-byte record (two dwordx4 loads) per visited node; triangles are copied into leaf order as three
+// float4 (xyz + the ORIGINAL triangle index in v0.w) so a leaf is a contiguous 48-byte-stride run.
+// Visiting order is fixed (not front-to-back); closest-hit rays prune with the best t so far.
+//
+// Node boxes are padded (kPadRel of the scene diagonal): Moller-Trumbore accepts points a few ulps
+// outside the exact triangle, and the slab test rounds too; the padding dominates both, so a triangle
+// the sweep would accept is never culled (tests compare with the brute-force oracle bit for bit).
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "f3d_scene.h"
+
+namespace f3d {
+
+constexpr uint32_t kBvhLeafMax = 4u;    // triangles per leaf (the reference's builder: leaf <= 4)
+constexpr uint32_t kBvhBins = 16u;      // SAH bins per axis
+constexpr float kBvhPadRel = 1e-5f;     // box padding as a fraction of the scene diagonal
+
+struct MeshBvh {
+    std::vector<BvhNode> nodes;
+    std::vector<float> tris;  // 12 floats per triangle: v0.xyz, index bits, v1.xyz, 0, v2.xyz, 0
+    size_t bytes() const { return nodes.size() * sizeof(BvhNode) + tris.size() * sizeof(float); }
+};
+
+namespace bvh_detail {
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() {
+        for (int a = 0; a < 3; a++) {
+            lo[a] = INFINITY;
+            hi[a] = -INFINITY;
+        }
+    }
+    void grow(const float *p) {
+        for (int a = 0; a < 3; a++) {
+            lo[a] = std::min(lo[a], p[a]);
+            hi[a] = std::max(hi[a], p[a]);
+        }
+    }
+    void grow(const Box &b) {
+        for (int a = 0; a < 3; a++) {
+            lo[a] = std::min(lo[a], b.lo[a]);
+            hi[a] = std::max(hi[a], b.hi[a]);
+        }
+    }
+    float half_area() const {
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct Prim {
+    Box box;
+    float centroid[3];
+    uint32_t tri;
+};
+
+struct Builder {
+    const float *verts;
+    const uint32_t *idx;
+    std::vector<Prim> prims;
+    MeshBvh out;
+    float pad;
+
+    // Binned SAH split of prims[first, first + count), count > kBvhLeafMax (cost model of
+    // sah_cpu.rs:235-306: SA-weighted primitive counts); returns the size of the left part.
+    uint32_t split(uint32_t first, uint32_t count) {
+        Box cb;
+        cb.reset();
+        for (uint32_t i = first; i < first + count; i++) cb.grow(prims[i].centroid);
+        float best_cost = INFINITY;
+        int best_axis = -1;
+        uint32_t best_bin = 0;
+        for (int a = 0; a < 3; a++) {
+            const float extent = cb.hi[a] - cb.lo[a];
+            if (!(extent > 0.0f)) continue;
+            Box bin_box[kBvhBins];
+            uint32_t bin_n[kBvhBins] = {};
+            for (auto &b : bin_box) b.reset();
+            const float scale = (float)kBvhBins / extent;
+            for (uint32_t i = first; i < first + count; i++) {
+                uint32_t b = (uint32_t)((prims[i].centroid[a] - cb.lo[a]) * scale);
+                b = b < kBvhBins ? b : kBvhBins - 1u;
+                bin_n[b]++;
+                bin_box[b].grow(prims[i].box);
+            }
+            float right_area[kBvhBins];
+            uint32_t right_n[kBvhBins];
+            Box acc;
+            acc.reset();
+            uint32_t n = 0;
+            for (int b = (int)kBvhBins - 1; b > 0; b--) {
+                acc.grow(bin_box[b]);
+                n += bin_n[b];
+                right_area[b] = acc.half_area();
+                right_n[b] = n;
+            }
+            acc.reset();
+            n = 0;
+            for (uint32_t b = 0; b + 1 < kBvhBins; b++) {
+                acc.grow(bin_box[b]);
+                n += bin_n[b];
+                if (n == 0 || right_n[b + 1] == 0) continue;
+                const float cost = acc.half_area() * (float)n + right_area[b + 1] * (float)right_n[b + 1];
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_axis = a;
+                    best_bin = b;
+                }
+            }
+        }
+        if (best_axis < 0) return count / 2u;  // coincident centroids: split by order
+        const float extent = cb.hi[best_axis] - cb.lo[best_axis];
+        const float scale = (float)kBvhBins / extent;
+        auto mid = std::partition(prims.begin() + first, prims.begin() + first + count, [&](const Prim &p) {
+            uint32_t b = (uint32_t)((p.centroid[best_axis] - cb.lo[best_axis]) * scale);
+            b = b < kBvhBins ? b : kBvhBins - 1u;
+            return b <= best_bin;
+        });
+        const uint32_t left = (uint32_t)(mid - (prims.begin() + first));
+        if (left == 0u || left == count) return count / 2u;
+        return left;
+    }
+
+    void emit(uint32_t first, uint32_t count, uint32_t depth = 0u) {
+        Box bounds;
+        bounds.reset();
+        for (uint32_t i = first; i < first + count; i++) bounds.grow(prims[i].box);
+        const uint32_t me = (uint32_t)out.nodes.size();
+        out.nodes.push_back(BvhNode{});
+        // leaves of <= kBvhLeafMax triangles; a runaway one-sided SAH recursion falls back to halving
+        const uint32_t left = count <= kBvhLeafMax ? 0u : (depth < 48u ? split(first, count) : count / 2u);
+        uint32_t leaf = 0u;
+        if (left == 0u) {
+            // a leaf: copy its triangles (ascending original index, like the sweep's order) into leaf order
+            std::sort(prims.begin() + first, prims.begin() + first + count,
+                      [](const Prim &a, const Prim &b) { return a.tri < b.tri; });
+            const uint32_t tri_first = (uint32_t)(out.tris.size() / 12u);
+            for (uint32_t i = first; i < first + count; i++) {
+                const uint32_t t = prims[i].tri;
+                for (int v = 0; v < 3; v++) {
+                    const float *p = verts + 3u * (size_t)idx[3u * (size_t)t + v];
+                    out.tris.push_back(p[0]);
+                    out.tris.push_back(p[1]);
+                    out.tris.push_back(p[2]);
+                    float w = 0.0f;
+                    if (v == 0) std::memcpy(&w, &t, sizeof(float));
+                    out.tris.push_back(w);
+                }
+            }
+            leaf = (tri_first << 3) | count;
+        } else {
+            emit(first, left, depth + 1u);
+            emit(first + left, count - left, depth + 1u);
+        }
+        BvhNode &n = out.nodes[me];
+        for (int a = 0; a < 3; a++) {
+            n.bmin[a] = bounds.lo[a] - pad;
+            n.bmax[a] = bounds.hi[a] + pad;
+        }
+        n.skip = (uint32_t)out.nodes.size();
+        n.leaf = leaf;
+    }
+};
+
+}  // namespace bvh_detail
+
+// verts: xyz per vertex; idx: 3 per triangle, every index < vertex_count (validate_scene).
+inline MeshBvh build_mesh_bvh(const float *verts, uint32_t vertex_count, const uint32_t *idx, uint32_t index_count) {
+    using namespace bvh_detail;
+    Builder b;
+    b.verts = verts;
+    b.idx = idx;
+    const uint32_t ntri = index_count / 3u;
+    b.prims.reserve(ntri);
+    Box scene;
+    scene.reset();
+    for (uint32_t t = 0; t < ntri; t++) {
+        Prim p;
+        p.box.reset();
+        p.tri = t;
+        bool ok = true;
+        for (int v = 0; v < 3; v++) ok = ok && idx[3u * (size_t)t + v] < vertex_count;
+        if (!ok) continue;  // the sweep skips such triangles (hybrid_traversal.wgsl:150-153)
+        for (int v = 0; v < 3; v++) p.box.grow(verts + 3u * (size_t)idx[3u * (size_t)t + v]);
+        for (int a = 0; a < 3; a++) p.centroid[a] = 0.5f * (p.box.lo[a] + p.box.hi[a]);
+        scene.grow(p.box);
+        b.prims.push_back(p);
+    }
+    if (b.prims.empty()) return b.out;
+    const float dx = scene.hi[0] - scene.lo[0], dy = scene.hi[1] - scene.lo[1], dz = scene.hi[2] - scene.lo[2];
+    float mag = 0.0f;
+    for (int a = 0; a < 3; a++) mag = std::max(mag, std::max(std::fabs(scene.lo[a]), std::fabs(scene.hi[a])));
+    b.pad = kBvhPadRel * std::sqrt(dx * dx + dy * dy + dz * dz) + 4e-6f * mag + 1e-30f;
+    b.out.nodes.reserve(2u * b.prims.size());
+    b.out.tris.reserve(12u * b.prims.size());
+    b.emit(0u, (uint32_t)b.prims.size());
+    return b.out;
+}
+
+}  // namespace f3d

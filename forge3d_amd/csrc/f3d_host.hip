@@ -175,6 +175,20 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
         P.mesh.vertex_count = d.mesh_vertex_count;
         P.mesh.index_count = d.mesh_index_count;
         P.mesh.traversal_mode = 0u;
+        // acceleration structure (reference: accel::build_bvh on the CPU, render_terrain.rs:597-627 -- which its
+        // kernel then never reads; here the rays actually walk it, f3d_bvh.h)
+        const MeshBvh bvh = build_mesh_bvh(d.mesh_vertices, d.mesh_vertex_count, d.mesh_indices, d.mesh_index_count);
+        if (!bvh.nodes.empty()) {
+            BvhNode *dn = (BvhNode *)s.mem.alloc(bvh.nodes.size() * sizeof(BvhNode), "mesh BVH nodes");
+            float4 *dt = (float4 *)s.mem.alloc(bvh.tris.size() * sizeof(float), "mesh BVH triangles");
+            hip_check(hipMemcpy(dn, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice),
+                      "BVH upload");
+            hip_check(hipMemcpy(dt, bvh.tris.data(), bvh.tris.size() * sizeof(float), hipMemcpyHostToDevice),
+                      "BVH upload");
+            P.mesh.bvh_nodes = dn;
+            P.mesh.bvh_tris = dt;
+            P.mesh.bvh_node_count = (uint32_t)bvh.nodes.size();
+        }
     }
     P.row_begin = s.row_begin;
     P.row_end = s.row_end;
@@ -187,16 +201,17 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
     // + 1000000 * sample lanes per pixel (f3d_kernels.hip frame_lanes): 1, 2, 4, 8; 0 = automatic.
     // A wave of the 1-lane kernel lasts spp x 3 traversals whatever the image size, so small images
     // and thin multi-GPU strips are latency-bound and even a 1080p frame ends in a ~1 ms tail of
-    // half-empty SIMDs; trading pixels per wave for sample lanes keeps ~32 waves per wave slot
-    // (measured at 1080p / 8 spp: 3881, 4860, 5074, 5120 Msamples/s for 1, 2, 4, 8 lanes).
+    // half-empty SIMDs; sample lanes trade pixels per wave for shorter waves.
     {
         uint32_t lanes = (uint32_t)((s.variant / 1000000) % 10);
         if (lanes == 0u && s.variant % 1000 != 0) lanes = 1u;  // register-budget A/B kernels exist for 1 lane only
         if (lanes == 0u) {
-            constexpr uint64_t kTargetWaves = 196608;  // 32 x (256 CUs x 4 SIMDs x 6 waves)
-            lanes = 1u;
-            while (lanes < 8u && lanes * 2u <= P.spp && ((uint64_t)s.rows * s.width * lanes + 63u) / 64u < kTargetWaves)
-                lanes *= 2u;
+            // measured (Msamples/s for 1 / 2 / 4 / 8 lanes): 1080p 3881 / 4860 / 5255 / 5261; 3840x2160
+            // 5612 / 5738 / 5820 / 5458; 4096^2 with a 600k-triangle mesh 2271 / - / 2474 / 2440; an eighth of
+            // a 1080p frame only scales with 8.  So: 4 lanes when spp allows, 8 for small strips.
+            constexpr uint64_t kSmallStripWaves = 98304;  // 16 x (256 CUs x 4 SIMDs x 6 waves)
+            lanes = P.spp >= 4u ? 4u : (P.spp >= 2u ? 2u : 1u);
+            if (lanes == 4u && P.spp >= 8u && ((uint64_t)s.rows * s.width * 4u + 63u) / 64u < kSmallStripWaves) lanes = 8u;
         }
         if (lanes != 1u && lanes != 2u && lanes != 4u && lanes != 8u)
             fail(F3D_STATUS_VALUE, "kernel_variant: sample lanes must be 1, 2, 4 or 8 (got %u)", lanes);

@@ -24,6 +24,9 @@
 struct alignas(16) float4 {
     float x, y, z, w;
 };
+struct alignas(8) uint2 {
+    unsigned int x, y;
+};
 #endif
 
 namespace f3d {

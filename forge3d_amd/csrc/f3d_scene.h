@@ -70,11 +70,24 @@ struct TerrainDev {
     uint32_t leaf_quorum;   // lanes of a wave that must hold a fat leaf before the leaf body runs
 };
 
+// Threaded BVH node (f3d_bvh.h): preorder layout, enter -> node + 1, miss / subtree done -> skip.
+struct BvhNode {
+    float bmin[3];
+    uint32_t skip;
+    float bmax[3];
+    uint32_t leaf;  // 0 = inner node; else (first triangle << 3) | triangle count (1..4)
+};
+static_assert(sizeof(BvhNode) == 32, "BvhNode is two dwordx4 loads");
+
 struct MeshDev {  // HybridUniforms mesh part, hybrid_traversal.wgsl:9-17
     const float4 *vertices;  // xyz + pad (reference MeshVertex)
     const uint32_t *indices;
     uint32_t vertex_count, index_count;
     uint32_t traversal_mode;  // 0 hybrid (mesh + terrain), 3 terrain only
+    // acceleration structure over the triangles (null -> the reference's sweep over all of them)
+    const BvhNode *bvh_nodes;
+    const float4 *bvh_tris;  // 3 float4 per triangle in leaf order; v0.w = original triangle index (bits)
+    uint32_t bvh_node_count;
 };
 
 struct EnvDev {  // equirect environment, hybrid_terrain_traversal.wgsl:392-405

@@ -15,6 +15,7 @@
 
 #include "../../include/f3d_terrain_pt.h"
 #include "f3d_build.h"
+#include "f3d_bvh.h"
 #include "f3d_scene.h"
 
 namespace f3d {
@@ -329,6 +330,9 @@ inline bool fill_uniforms(const f3d_terrain_ref_desc &d, FrameParams &P) {
     P.mesh.indices = nullptr;
     P.mesh.vertex_count = 0;
     P.mesh.index_count = 0;
+    P.mesh.bvh_nodes = nullptr;
+    P.mesh.bvh_tris = nullptr;
+    P.mesh.bvh_node_count = 0;
 
     const float kDegF = 0.017453292519943295f;
     const V3 origin{d.cam_origin[0], d.cam_origin[1], d.cam_origin[2]};

@@ -48,7 +48,7 @@ F3D_HD bool ray_triangle(V3 o, float tmin, V3 d, float tmax, V3 v0, V3 v1, V3 v2
 
 // intersect_mesh, hybrid_traversal.wgsl:137-172: the reference sweeps every triangle
 // (its BVH buffer is bound but never read); triangle data is wave-uniform here.
-F3D_HD bool mesh_closest(const MeshDev &M, V3 o, float tmin, V3 d, float tmax, float &t_best, V3 &n_best) {
+F3D_HD bool mesh_sweep(const MeshDev &M, V3 o, float tmin, V3 d, float tmax, float &t_best, V3 &n_best) {
     bool any = false;
     t_best = tmax;
     if (M.index_count < 3u) return false;
@@ -66,6 +66,67 @@ F3D_HD bool mesh_closest(const MeshDev &M, V3 o, float tmin, V3 d, float tmax, f
         }
     }
     return any;
+}
+
+// The same answer through the threaded BVH of f3d_bvh.h: every triangle whose (padded) leaf box the
+// ray touches is put through the sweep's own ray_triangle; the sweep keeps the first triangle in
+// index order among those with the smallest t (`t < t_best` is strict), hence the tie rule below.
+// ANY: stop at the first accepted triangle (occlusion rays only need existence).
+template <bool ANY>
+F3D_HD bool mesh_bvh(const MeshDev &M, V3 o, float tmin, V3 d, float tmax, float &t_best, V3 &n_best) {
+    const float ix = (d.x < 0.0f ? -1.0f : 1.0f) / f_max(f_abs(d.x), 1e-12f);
+    const float iy = (d.y < 0.0f ? -1.0f : 1.0f) / f_max(f_abs(d.y), 1e-12f);
+    const float iz = (d.z < 0.0f ? -1.0f : 1.0f) / f_max(f_abs(d.z), 1e-12f);
+    const float4 *nodes = reinterpret_cast<const float4 *>(M.bvh_nodes);
+    bool any = false;
+    uint32_t best_tri = 0xFFFFFFFFu;
+    t_best = tmax;
+    uint32_t node = 0u;
+    while (node < M.bvh_node_count) {
+        const float4 lo = nodes[2u * node], hi = nodes[2u * node + 1u];
+        const float ax = (lo.x - o.x) * ix, bx = (hi.x - o.x) * ix;
+        const float ay = (lo.y - o.y) * iy, by = (hi.y - o.y) * iy;
+        const float az = (lo.z - o.z) * iz, bz = (hi.z - o.z) * iz;
+        const float enter = f_max(f_max(f_min(ax, bx), f_min(ay, by)), f_max(f_min(az, bz), tmin));
+        const float exit = f_min(f_min(f_max(ax, bx), f_max(ay, by)), f_min(f_max(az, bz), t_best));
+        if (!(enter <= exit * 1.00001f)) {  // conservative: boxes are padded, ties are kept
+            node = f_bits(lo.w);
+            continue;
+        }
+        const uint32_t leaf = f_bits(hi.w);
+        if (leaf == 0u) {
+            node = node + 1u;
+            continue;
+        }
+        const uint32_t first = leaf >> 3, count = leaf & 7u;
+        for (uint32_t k = 0u; k < count; k++) {
+            const float4 a = M.bvh_tris[3u * (first + k)], b = M.bvh_tris[3u * (first + k) + 1u],
+                         c = M.bvh_tris[3u * (first + k) + 2u];
+            float t;
+            V3 n;
+            if (ray_triangle(o, tmin, d, tmax, V3{a.x, a.y, a.z}, V3{b.x, b.y, b.z}, V3{c.x, c.y, c.z}, t, n)) {
+                if (ANY) {
+                    t_best = t;
+                    n_best = n;
+                    return true;
+                }
+                const uint32_t tri = f_bits(a.w);
+                if (t < t_best || (t == t_best && tri < best_tri)) {
+                    t_best = t;
+                    n_best = n;
+                    best_tri = tri;
+                    any = true;
+                }
+            }
+        }
+        node = f_bits(lo.w);
+    }
+    return any;
+}
+
+F3D_HD bool mesh_closest(const MeshDev &M, V3 o, float tmin, V3 d, float tmax, float &t_best, V3 &n_best) {
+    if (M.bvh_nodes) return mesh_bvh<false>(M, o, tmin, d, tmax, t_best, n_best);
+    return mesh_sweep(M, o, tmin, d, tmax, t_best, n_best);
 }
 
 // intersect_hybrid, hybrid_traversal.wgsl:175-201 (closest hit, curvature off)
@@ -112,7 +173,12 @@ F3D_HD bool occluded(const FrameParams &P, V3 o, float tmin, V3 d, float tmax, b
     if (P.mesh.traversal_mode == 0u) {
         float t;
         V3 n;
-        if (mesh_closest(P.mesh, o, tmin, d, tmax, t, n)) {
+        if (P.mesh.bvh_nodes) {
+            // Any triangle hit already decides the answer: the reference takes the closest mesh hit, returns
+            // (t < 1e30) = true when it is nearer than its early-exit distance, and otherwise keeps hit = true
+            // whatever the terrain does (:204-259), so existence is all that is read from the mesh here.
+            if (mesh_bvh<true>(P.mesh, o, tmin, d, tmax, t, n)) return true;
+        } else if (mesh_sweep(P.mesh, o, tmin, d, tmax, t, n)) {
             if (t < 0.01f) return t < 1e30f;
             if (t < best_t) {
                 best_t = t;

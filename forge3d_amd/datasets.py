@@ -91,3 +91,30 @@ def mini_dem_scene(dem_256: np.ndarray):
               sun_elevation_deg=35.0, sun_intensity=2.5, env_intensity=0.35, max_frames=512, min_frames=32,
               variance_threshold=1e-3, seed=7)
     return dem, cam, kw
+
+
+def proxy_buildings(dem: np.ndarray, spacing: float, n_boxes: int = 50_000, seed: int = 7):
+    """BASELINE.md input "S4": procedurally extruded boxes (12 triangles each) standing on the DEM,
+    a stand-in for the Lyon CityGML LOD2 buildings of BASELINE.json config 4.  Terrain is centred on
+    the world origin, y up, DEM row = +z.  Returns (vertices (8n, 3) f32, indices (12n, 3) u32)."""
+    rng = np.random.default_rng(seed)
+    h, w = dem.shape
+    ox, oz = -0.5 * (w - 1) * spacing, -0.5 * (h - 1) * spacing
+    ci = rng.integers(w // 8, w - w // 8, n_boxes)
+    cj = rng.integers(h // 8, h - h // 8, n_boxes)
+    half_w = rng.uniform(4.0, 18.0, n_boxes)
+    half_d = rng.uniform(4.0, 18.0, n_boxes)
+    height = rng.uniform(6.0, 60.0, n_boxes)
+    ground = dem[cj, ci].astype(np.float64)
+    cx, cz = ox + ci * spacing, oz + cj * spacing
+    corners = np.array([(-1, -1), (1, -1), (1, 1), (-1, 1)], np.float64)
+    verts = np.empty((n_boxes, 8, 3), np.float64)
+    for k, (sx, sz) in enumerate(corners):
+        for lvl, y in enumerate((ground - 3.0, ground + height)):
+            verts[:, 4 * lvl + k, 0] = cx + sx * half_w
+            verts[:, 4 * lvl + k, 1] = y
+            verts[:, 4 * lvl + k, 2] = cz + sz * half_d
+    quads = ((0, 1, 2, 3), (7, 6, 5, 4), (0, 4, 5, 1), (1, 5, 6, 2), (2, 6, 7, 3), (3, 7, 4, 0))
+    local = np.array([t for a, b, c, d in quads for t in ((a, b, c), (a, c, d))], np.uint32)
+    idx = (local[None, :, :] + (8 * np.arange(n_boxes, dtype=np.uint32))[:, None, None]).reshape(-1, 3)
+    return verts.reshape(-1, 3).astype(np.float32), idx.astype(np.uint32)

@@ -106,6 +106,7 @@ HostTables build_tables_host(const float *heights, uint32_t w, uint32_t h, float
 // primaries re-traced until every sample started from the right stream state, contributions
 // replayed in sample order.  Same helpers (sample_primary / sample_shade / accumulate_sample) as
 // the device code, so the CPU parity tests pin the speculation scheme against the oracle.
+static bool g_use_bvh = true;  // false: the reference's sweep over all triangles (A/B of the BVH itself)
 static uint32_t g_sample_lanes = 1u;
 static uint64_t g_retraces = 0;  // primaries traced a second time (statistics for the tests)
 
@@ -263,6 +264,7 @@ int emul_render(const f3d_terrain_ref_desc *d, uint32_t row_begin, uint32_t row_
         HostTables t = build_tables_host(d->heights, d->dem_width, d->dem_height, d->exaggeration);
         t.attach(P.terrain);
         std::vector<float> env4, mesh4;
+        MeshBvh bvh;
         if (d->env_map) {
             env4 = pad_rgb_to_rgba(d->env_map, (size_t)d->env_width * d->env_height, 1.0f);
             P.env.texels = (const float4 *)env4.data();
@@ -276,6 +278,12 @@ int emul_render(const f3d_terrain_ref_desc *d, uint32_t row_begin, uint32_t row_
             P.mesh.vertex_count = d->mesh_vertex_count;
             P.mesh.index_count = d->mesh_index_count;
             P.mesh.traversal_mode = 0u;
+            if (g_use_bvh) {
+                bvh = build_mesh_bvh(d->mesh_vertices, d->mesh_vertex_count, d->mesh_indices, d->mesh_index_count);
+                P.mesh.bvh_nodes = bvh.nodes.data();
+                P.mesh.bvh_tris = (const float4 *)bvh.tris.data();
+                P.mesh.bvh_node_count = (uint32_t)bvh.nodes.size();
+            }
         }
         if (row_end == 0) row_end = d->height;
         P.row_begin = row_begin;
@@ -373,6 +381,7 @@ struct EmulSession {
     HostTables tables;
     std::vector<float> env4, mesh4;
     std::vector<uint32_t> mesh_idx;
+    MeshBvh bvh;
     std::vector<float4> accum, gbuf;
     std::vector<float> m2, depth;
     PackedReservoir *res[2] = {nullptr, nullptr};
@@ -397,6 +406,12 @@ void *emul_session_create(const f3d_terrain_ref_desc *d, uint32_t row_begin, uin
             s->P.mesh.vertex_count = d->mesh_vertex_count;
             s->P.mesh.index_count = d->mesh_index_count;
             s->P.mesh.traversal_mode = 0u;
+            if (g_use_bvh) {
+                s->bvh = build_mesh_bvh(d->mesh_vertices, d->mesh_vertex_count, d->mesh_indices, d->mesh_index_count);
+                s->P.mesh.bvh_nodes = s->bvh.nodes.data();
+                s->P.mesh.bvh_tris = (const float4 *)s->bvh.tris.data();
+                s->P.mesh.bvh_node_count = (uint32_t)s->bvh.nodes.size();
+            }
         }
         if (row_end == 0) row_end = d->height;
         s->P.row_begin = row_begin;
@@ -463,6 +478,7 @@ int emul_session_resolve(void *h, uint32_t frames, uint8_t *rgba, float *albedo,
 
 void emul_session_destroy(void *h) { delete (EmulSession *)h; }
 
+void emul_set_use_bvh(int32_t on) { g_use_bvh = on != 0; }
 // sample lanes of the frame emulation (1 = frame_pixel; 2, 4, 8 = the frame_lanes mirror)
 void emul_set_sample_lanes(uint32_t lanes) { g_sample_lanes = (lanes == 2u || lanes == 4u || lanes == 8u) ? lanes : 1u; }
 uint64_t emul_take_retraces() {

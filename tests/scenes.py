@@ -104,3 +104,34 @@ def proof_rays(n_random: int = 10_000, mask: bool = True):
             for x in range(255):
                 rays.append(ray(f(x) + f(0.5), f(z) + f(0.5), az, el))
     return heights, np.asarray(rays, dtype=np.float32)
+
+
+def box_city(n_boxes: int = 120, seed: int = 7, span: float = SPAN, base: float = 0.0, top: float = 26.0):
+    """Procedural 'buildings' over the golden scene's footprint: axis-aligned boxes (12 triangles
+    each, shared vertices, coplanar pairs -> equal-t ties along the quad diagonals) plus a few
+    free-standing slivers and one degenerate triangle.  Returns (vertices (N,3) f32, indices (M,3) u32)."""
+    rng = np.random.default_rng(seed)
+    verts, tris = [], []
+    for _ in range(n_boxes):
+        cx, cz = rng.uniform(-0.45 * span, 0.45 * span, 2)
+        w, d = rng.uniform(1.0, 5.0, 2)
+        h0 = base + rng.uniform(0.0, 6.0)
+        h1 = h0 + rng.uniform(2.0, top)
+        o = len(verts)
+        for y in (h0, h1):
+            for dx, dz in ((-w, -d), (w, -d), (w, d), (-w, d)):
+                verts.append((cx + dx, y, cz + dz))
+        quads = ((0, 1, 2, 3), (7, 6, 5, 4), (0, 4, 5, 1), (1, 5, 6, 2), (2, 6, 7, 3), (3, 7, 4, 0))
+        for a, b, c, d4 in quads:
+            tris.append((o + a, o + b, o + c))
+            tris.append((o + a, o + c, o + d4))
+    for _ in range(24):  # thin slivers at random orientations
+        p = rng.uniform(-0.4 * span, 0.4 * span, 3)
+        p[1] = rng.uniform(8.0, 30.0)
+        o = len(verts)
+        verts += [tuple(p), tuple(p + rng.normal(0, 6.0, 3)), tuple(p + rng.normal(0, 0.05, 3))]
+        tris.append((o, o + 1, o + 2))
+    o = len(verts)
+    verts += [(1.0, 20.0, 1.0), (2.0, 20.0, 2.0), (3.0, 20.0, 3.0)]  # collinear: rejected by |a| < 1e-7
+    tris.append((o, o + 1, o + 2))
+    return np.asarray(verts, np.float32), np.asarray(tris, np.uint32)

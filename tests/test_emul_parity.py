@@ -69,6 +69,21 @@ def test_sample_lane_frames_match_oracle(lanes, size, spp, frames, extra):
         assert got["retraces"] > 0  # the scene has silhouettes: mispredictions were exercised
 
 
+@pytest.mark.parametrize("seed,lanes", [(7, 1), (11, 4), (23, 8)])
+def test_mesh_bvh_reproduces_the_reference_sweep(seed, lanes):
+    """The threaded BVH (f3d_bvh.h) against the oracle's sweep over every triangle
+    (hybrid_traversal.wgsl:137-172) on ~1 500 triangles: boxes whose quads are coplanar triangle
+    pairs (equal-t ties on the diagonals -> lowest index wins), slivers, a degenerate triangle."""
+    dem = scenes.golden_dem()
+    v, i = scenes.box_city(seed=seed)
+    kw = scenes.fixed_frames(scenes.scene_kwargs(dem), 3, spp=max(2, lanes), mesh_vertices=v, mesh_indices=i)
+    want = oracle.render(dem, 144, 112, scenes.CAM, dump_state=True, **kw)
+    got = emul.render(dem, 144, 112, scenes.CAM, sample_lanes=lanes, **kw)
+    _same(got, want)
+    assert np.array_equal(got["accum"][:, :3], want["accum"][:, :3])
+    assert int((want["albedo"][..., 2] > 0.7).sum()) > 2000  # the mesh is really in view
+
+
 def test_env_map_and_ragged_dem():
     dem = scenes.golden_dem(2)[:37, :100].copy()
     env = np.random.default_rng(5).uniform(0.1, 2.0, size=(16, 32, 3)).astype(np.float32)

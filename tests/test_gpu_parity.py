@@ -107,6 +107,17 @@ def test_sample_lane_kernels_are_bit_identical(f3d, oracle, variant, spp):
             assert np.array_equal(got[key], want[key], equal_nan=True), (variant, key)
 
 
+@pytest.mark.parametrize("seed,spp", [(7, 1), (11, 4), (23, 8)])
+def test_mesh_bvh_reproduces_the_reference_sweep(f3d, oracle, seed, spp):
+    """~1 500 triangles through the threaded BVH on the device vs the oracle's sweep over every
+    triangle: coplanar pairs (equal-t ties), slivers, a degenerate triangle; closest and any hit."""
+    dem = scenes.golden_dem()
+    v, i = scenes.box_city(seed=seed)
+    kw = scenes.fixed_frames(scenes.scene_kwargs(dem), 3, spp=spp, mesh_vertices=v, mesh_indices=i)
+    _same(f3d.hybrid_render_terrain_reference(dem, 144, 112, scenes.CAM, **kw),
+          oracle.render(dem, 144, 112, scenes.CAM, **kw))
+
+
 def test_ragged_nonsquare_dem_and_sun_colour(f3d, oracle):
     dem = scenes.golden_dem(2)[:37, :100].copy()  # 100 x 37 texels -> 128 x 64 padded pyramid
     kw = scenes.fixed_frames(scenes.scene_kwargs(dem), 6, spp=2, sun_color=(0.2, 0.3, 1.5), seed=12345,

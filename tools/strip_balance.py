@@ -22,7 +22,8 @@ dem, cam, kw = datasets.rainier_proxy_scene(2048)
 kw = dict(kw, spp=SPP, max_frames=64, min_frames=64, variance_threshold=1e30, memory_budget_bytes=8 << 30)
 backend = HipBackend(0)
 full = min(backend.probe(dem, W, H, cam, 0, H, kw, frames=4) for _ in range(2))
-print(json.dumps({"full_frame_ms": full}))
+full_1lane = min(backend.probe(dem, W, H, cam, 0, H, dict(kw, kernel_variant=1000000), frames=4) for _ in range(2))
+print(json.dumps({"full_frame_ms": full, "full_frame_ms_1_lane_kernel": full_1lane}))
 for world in (2, 4, 8):
     bounds = [strip_rows(H, world, r)[0] for r in range(world)] + [H]
     density = np.ones(H)
