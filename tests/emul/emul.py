@@ -8,6 +8,7 @@ the comparison on the real device through libf3dhip.so.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import subprocess
 from pathlib import Path
 
@@ -23,8 +24,9 @@ _CSRC = _HERE.parent.parent / "forge3d_amd" / "csrc"
 def build(force=False):
     srcs = [_HERE / "f3d_emul.cpp"] + sorted(_CSRC.glob("*.h"))
     if force or not _LIB.exists() or _LIB.stat().st_mtime < max(s.stat().st_mtime for s in srcs):
+        extra = os.environ.get("F3D_EMUL_CXXFLAGS", "").split()  # experiment switches (-DF3D_...)
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-march=x86-64-v3",
-                        "-ffp-contract=off", str(_HERE / "f3d_emul.cpp"), "-o", str(_LIB)],
+                        "-ffp-contract=off", *extra, str(_HERE / "f3d_emul.cpp"), "-o", str(_LIB)],
                        check=True, capture_output=True)
     return _LIB
 

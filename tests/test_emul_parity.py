@@ -118,6 +118,24 @@ def test_traversal_matches_oracle_on_the_reference_proof_rays():
         assert np.array_equal(got["normal"], want["normal"])
 
 
+@pytest.mark.parametrize("curved", [True, False])
+def test_stackless_march_matches_oracle_on_the_proof_rays(curved):
+    """The frame kernel's traversal (f3d_march.h) in its four start/answer modes: any hit (2) and
+    closest hit (3), from the root or from the origin's cell (+4)."""
+    heights, rays = scenes.proof_rays(n_random=6000, mask=True)
+    inv2r = float(np.float32(1.0 / 14_650_000.0))
+    base = dict(spacing=(500.0, 500.0), inv_two_r_prime=inv2r, curvature_enabled=True, apply_curvature=curved)
+    want_any = oracle.terrain_trace_batch(heights, rays, any_hit=True, **base)
+    want_closest = oracle.terrain_trace_batch(heights, rays, any_hit=False, **base)
+    for mode in (2, 6):
+        got = emul.terrain_trace_batch(heights, rays, any_hit=mode, **base)
+        assert np.array_equal(got["hit"], want_any["hit"]), mode
+    for mode in (3, 7):
+        got = emul.terrain_trace_batch(heights, rays, any_hit=mode, **base)
+        assert np.array_equal(got["hit"], want_closest["hit"]), mode
+        assert np.array_equal(got["t"], want_closest["t"]) and np.array_equal(got["normal"], want_closest["normal"])
+
+
 @pytest.mark.parametrize("shape", [(256, 256), (37, 100), (2, 2), (3, 9), (130, 65), (9, 3)])
 def test_table_builder_matches_build_minmax_mips(shape):
     dem = np.random.default_rng(shape[0] * 1000 + shape[1]).normal(1000.0, 300.0, size=shape).astype(np.float32)

@@ -186,6 +186,34 @@ def test_terrain_trace_batch_matches_oracle_and_kat_gates(f3d, oracle):
     assert np.array_equal(hit, want2["hit"]) and np.array_equal(t, want2["t"]) and np.array_equal(nrm, want2["normal"])
 
 
+@pytest.mark.parametrize("curved", [True, False])
+def test_stackless_march_modes_on_the_proof_rays(f3d, oracle, curved):
+    """f3d_terrain_trace_batch modes 2 / 3 (+4): the frame kernel's stackless march, any and closest
+    hit, from the root or the origin's cell."""
+    import ctypes as C
+
+    from forge3d_amd import _native
+
+    heights, rays = scenes.proof_rays()
+    inv2r = float(np.float32(1.0 / 14_650_000.0))
+    base = dict(spacing=(500.0, 500.0), inv_two_r_prime=inv2r, curvature_enabled=True, apply_curvature=curved)
+    want_any = oracle.terrain_trace_batch(heights, rays, any_hit=True, **base)
+    want_closest = oracle.terrain_trace_batch(heights, rays, any_hit=False, **base)
+    n = rays.shape[0]
+    err = C.create_string_buffer(256)
+    for mode in (2, 6, 3, 7):
+        hit, t, nrm = np.zeros(n, np.uint32), np.zeros(n, np.float32), np.zeros((n, 3), np.float32)
+        rc = _native.lib().f3d_terrain_trace_batch(heights.ctypes.data, 256, 256, 0.0, 0.0, 500.0, 500.0, 1.0, inv2r, 1,
+                                                   rays.ctypes.data, n, mode, 1 if curved else 0, hit.ctypes.data,
+                                                   t.ctypes.data, nrm.ctypes.data, err, len(err))
+        assert rc == 0, err.value
+        if mode & 1:
+            assert np.array_equal(hit, want_closest["hit"]) and np.array_equal(t, want_closest["t"]), mode
+            assert np.array_equal(nrm, want_closest["normal"]), mode
+        else:
+            assert np.array_equal(hit, want_any["hit"]), mode
+
+
 @pytest.mark.parametrize("shape", [(256, 256), (37, 100), (2, 2), (3, 9), (130, 65)])
 def test_gpu_built_minmax_pyramid_matches_oracle(f3d, oracle, shape):
     import ctypes as C

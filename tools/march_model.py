@@ -207,10 +207,101 @@ def ibl_batched_bound(rows="480:608"):
               f" + shadow rays likewise (separately): {nested / alt_si[B]:.3f}x")
 
 
+def lanes_model(rows="480:608", S=8):
+    """Lockstep utilisation of the sample-lane kernel: a wave = (64 / S) pixels x S samples, one
+    phase per ray type."""
+    from emul import emul
+    from forge3d_amd import datasets
+
+    rows = tuple(int(x) for x in rows.split(":"))
+    dem, cam, kw = datasets.rainier_proxy_scene(2048)
+    log = tempfile.mktemp(suffix=".raylog")
+    os.environ["F3D_EMUL_RAYLOG"] = log
+    emul.render(dem, 1920, 1080, cam, rows=rows, **dict(kw, spp=8, max_frames=2, min_frames=2, variance_threshold=1e30))
+    W, R, spp, pixels = load_log(log)
+    os.unlink(log)
+    tw, th = {1: (8, 8), 2: (8, 4), 4: (4, 4), 8: (4, 2)}[S]
+    tot = np.zeros(3)
+    cost = np.zeros(3)
+    for ty in range(0, R, th):
+        for tx in range(0, W, tw):
+            lanes = [pixels[y * W + x] for y in range(ty, min(ty + th, R)) for x in range(tx, min(tx + tw, W))]
+            P = np.zeros((len(lanes), spp, 3))
+            for li, rays in enumerate(lanes):
+                s = -1
+                for kind, steps, mask in rays:
+                    if kind == 2:
+                        s += 1
+                    P[li, s, {2: 0, 7: 1}.get(int(kind), 2)] = steps
+            for r0 in range(0, spp, S):
+                blk = P[:, r0:r0 + S, :].reshape(-1, 3)
+                tot += blk.sum(axis=0)
+                cost += 64 * blk.max(axis=0)
+    names = ("primary", "shadow", "ibl")
+    print(f"S={S}: overall utilisation {tot.sum() / cost.sum():.3f}; wave iterations {cost.sum() / 64:.0f}")
+    for k in range(3):
+        print(f"  {names[k]:8s}: {tot[k] / cost[k]:.3f} ({cost[k] / cost.sum():.1%} of the iterations)")
+
+
+def split_model(rows="480:608", S=8):
+    """What if the last few marching any-hit rays of a phase were split into segments handed to
+    the idle lanes (one rebalance per phase, when <= thr lanes still march)?"""
+    from emul import emul
+    from forge3d_amd import datasets
+
+    rows = tuple(int(x) for x in rows.split(":"))
+    dem, cam, kw = datasets.rainier_proxy_scene(2048)
+    log = tempfile.mktemp(suffix=".raylog")
+    os.environ["F3D_EMUL_RAYLOG"] = log
+    emul.render(dem, 1920, 1080, cam, rows=rows, **dict(kw, spp=8, max_frames=2, min_frames=2, variance_threshold=1e30))
+    W, R, spp, pixels = load_log(log)
+    os.unlink(log)
+    tw, th = {1: (8, 8), 2: (8, 4), 4: (4, 4), 8: (4, 2)}[S]
+    base = np.zeros(3)
+    alt = {(thr, ov): np.zeros(3) for thr in (4, 8, 16, 32) for ov in (3, 8)}
+    for ty in range(0, R, th):
+        for tx in range(0, W, tw):
+            lanes = [pixels[y * W + x] for y in range(ty, min(ty + th, R)) for x in range(tx, min(tx + tw, W))]
+            P = np.zeros((len(lanes), spp, 3))
+            for li, rays in enumerate(lanes):
+                s = -1
+                for kind, steps, mask in rays:
+                    if kind == 2:
+                        s += 1
+                    P[li, s, {2: 0, 7: 1}.get(int(kind), 2)] = steps
+            for r0 in range(0, spp, S):
+                blk = P[:, r0:r0 + S, :].reshape(-1, 3)
+                base += blk.max(axis=0)
+                for (thr, ov), acc in alt.items():
+                    for k in range(3):
+                        st = np.sort(blk[:, k])[::-1]  # descending
+                        if k == 0 or st[0] == 0:
+                            acc[k] += st[0]
+                            continue
+                        n = len(st)
+                        t_reb = st[thr] if thr < n else 0.0  # when only thr rays are left marching
+                        live = st[:thr] - t_reb
+                        live = live[live > 0]
+                        if len(live) == 0:
+                            acc[k] += st[0]
+                            continue
+                        m = max(1, 64 // len(live))
+                        after = (live / m + ov).max() if m > 1 else live.max()
+                        acc[k] += min(st[0], t_reb + 2 + after)
+    print(f"S={S}: baseline iterations primary/shadow/ibl = {base.astype(int)}  total {base.sum():.0f}")
+    for (thr, ov), acc in alt.items():
+        print(f"  rebalance at <= {thr:2d} marching, segment overhead {ov} steps: shadow {base[1] / acc[1]:.2f}x ibl {base[2] / acc[2]:.2f}x"
+              f" total {base.sum() / acc.sum():.3f}x fewer iterations")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[2] == "batched":
         batched_table(sys.argv[1])
     elif len(sys.argv) > 2 and sys.argv[2] == "ibl":
         ibl_batched_bound(sys.argv[1])
+    elif len(sys.argv) > 2 and sys.argv[2].startswith("lanes"):
+        lanes_model(sys.argv[1], int(sys.argv[2][5:] or 8))
+    elif len(sys.argv) > 2 and sys.argv[2] == "split":
+        split_model(sys.argv[1])
     else:
         main()
