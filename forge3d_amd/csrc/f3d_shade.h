@@ -192,7 +192,9 @@ F3D_HD bool occluded(const FrameParams &P, V3 o, float tmin, V3 d, float tmax, b
 #else
     // occlusion rays start on the surface: the march starts in the origin's cell.  Only sun
     // rays carry the curvature policy (apply_curvature is a compile-time constant per call site).
-    TraceHit th = apply_curvature ? march_ray(P.terrain, r, true, true, pend)
+    // (with the curvature policy switched off for the whole render, c2 = 0 and fma(t*t, 0, y) == y: the
+    // curved instantiation then computes the flat answers exactly, so there is no third copy of the march)
+    TraceHit th = apply_curvature ? march_terrain<true>(P.terrain, r, true, true, pend)
                                   : march_terrain<false>(P.terrain, r, true, true, pend);
 #endif
     if (th.hit && th.t < best_t) {
@@ -431,14 +433,20 @@ F3D_HD SampleOut sample_shade(const FrameParams &P, const FrameHead &h, const Pr
     o.a = V3{0.0f, 0.0f, 0.0f};
     if (nd > 0.0f) {
         float vis = 1.0f;
+#if !defined(F3D_TIMING_NO_SHADOW)  // timing experiment only (wrong image): tools/gpu_build_ab.sh
         if (P.light.shadows_enabled != 0u && occluded(P, so, 1e-3f, sun_dir, 1e30f, true, pend)) vis = 0.0f;
+#endif
         o.a = (((albedo * P.light.color) * nd) * vis) * h.reuse_w;
     }
     // one cosine-weighted IBL sample, :537-545
     const float u1 = rng_next(rng);
     const float u2 = rng_next(rng);
     const V3 ei = cosine_dir(n, u1, u2);
+#if defined(F3D_TIMING_NO_IBL)  // timing experiment only (wrong image): tools/gpu_build_ab.sh, profiles/README.md
+    const float env_vis = 1.0f;
+#else
     const float env_vis = occluded(P, so, 1e-3f, ei, 1e30f, false, pend) ? 0.0f : 1.0f;
+#endif
     o.b = (albedo * env_radiance(P.env, ei)) * env_vis;
     return o;
 }

@@ -294,6 +294,68 @@ def split_model(rows="480:608", S=8):
               f" total {base.sum() / acc.sum():.3f}x fewer iterations")
 
 
+def persistent_model(rows="480:608"):
+    """Kernel-B model: all IBL (or shadow) rays of the strip in generation order, traced by 64-lane
+    waves of PERSISTENT lanes that refill from a queue when >= Q lanes are idle (refill costs R
+    iterations for the wave)."""
+    from emul import emul
+    from forge3d_amd import datasets
+
+    rows = tuple(int(x) for x in rows.split(":"))
+    dem, cam, kw = datasets.rainier_proxy_scene(2048)
+    log = tempfile.mktemp(suffix=".raylog")
+    os.environ["F3D_EMUL_RAYLOG"] = log
+    emul.render(dem, 1920, 1080, cam, rows=rows, **dict(kw, spp=8, max_frames=2, min_frames=2, variance_threshold=1e30))
+    W, R, spp, pixels = load_log(log)
+    os.unlink(log)
+    for kind, name in ((3, "ibl"), (7, "shadow")):
+        steps = []
+        for ty in range(0, R, 2):  # 4x2-pixel tiles, sample-major inside the pixel: the order kernel A would emit
+            for tx in range(0, W, 4):
+                for y in range(ty, min(ty + 2, R)):
+                    for x in range(tx, min(tx + 4, W)):
+                        steps.extend(int(s) for k, s, _ in pixels[y * W + x] if k == kind)
+        steps = np.asarray(steps[:400000], np.float64)
+        lockstep = sum(steps[i:i + 64].max() for i in range(0, len(steps), 64))
+        print(f"{name}: {len(steps)} rays, mean {steps.mean():.1f} steps; lockstep waves {lockstep:.0f} iterations"
+              f" (utilisation {steps.sum() / 64 / lockstep:.3f})")
+        for Q in (8, 16, 32):
+            for Rc in (2.0, 4.0):
+                # one long-lived wave per 4096 rays (many waves in flight on the chip)
+                total = 0.0
+                for c0 in range(0, len(steps), 4096):
+                    chunk = steps[c0:c0 + 4096]
+                    nxt = 64
+                    rem = chunk[:64].copy()
+                    if len(rem) < 64:
+                        total += rem.max() if len(rem) else 0.0
+                        continue
+                    while True:
+                        idle = rem <= 0
+                        n_idle = int(idle.sum())
+                        if nxt < len(chunk) and (n_idle >= Q or n_idle == 64):
+                            take = min(n_idle, len(chunk) - nxt)
+                            idx = np.nonzero(idle)[0][:take]
+                            rem[idx] = chunk[nxt:nxt + take]
+                            nxt += take
+                            total += Rc
+                            continue
+                        live = rem[rem > 0]
+                        if len(live) == 0:
+                            break
+                        if nxt >= len(chunk):
+                            total += live.max()
+                            break
+                        # run until enough lanes are idle to refill
+                        order = np.sort(live)
+                        need = max(0, Q - n_idle)
+                        step = order[min(need, len(order)) - 1] if need > 0 else order[0]
+                        total += step
+                        rem -= step
+                print(f"   persistent, refill at {Q:2d} idle, refill cost {Rc}: {total:.0f} iterations = {lockstep / total:.2f}x fewer"
+                      f" (utilisation {steps.sum() / 64 / total:.3f})")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[2] == "batched":
         batched_table(sys.argv[1])
@@ -303,5 +365,7 @@ if __name__ == "__main__":
         lanes_model(sys.argv[1], int(sys.argv[2][5:] or 8))
     elif len(sys.argv) > 2 and sys.argv[2] == "split":
         split_model(sys.argv[1])
+    elif len(sys.argv) > 2 and sys.argv[2] == "persistent":
+        persistent_model(sys.argv[1])
     else:
         main()
