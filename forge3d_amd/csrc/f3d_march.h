@@ -63,6 +63,141 @@ F3D_HD bool march_band_rejects(const RayCtx &r, float t0, float t1, float mn, fl
 // is sitting in the FIFO.
 constexpr uint32_t kLeafFifo = 4;  // entries per lane
 
+// Per-lane position of a march.
+struct MarchState {
+    float t_cur;
+    uint32_t level, nx, nz;
+    bool marching, unverified_start;
+};
+
+// Root slab interval of a ray (:288-297 for the root node): [lo, hi], empty when lo > hi.
+F3D_HD void march_root_interval(const TerrainDev &T, const RayCtx &r, float &lo, float &hi) {
+    const float ax = (plane_at(T.origin_x, 0u, T.spacing_x) - r.o.x) * r.inv_x;
+    const float bx = (plane_at(T.origin_x, T.cell_w, T.spacing_x) - r.o.x) * r.inv_x;
+    const float az = (plane_at(T.origin_z, 0u, T.spacing_z) - r.o.z) * r.inv_z;
+    const float bz = (plane_at(T.origin_z, T.cell_h, T.spacing_z) - r.o.z) * r.inv_z;
+    lo = f_max(f_max(f_min(ax, bx), f_min(az, bz)), r.tmin);
+    hi = f_min(f_min(f_max(ax, bx), f_max(az, bz)), r.tmax);
+}
+
+// Put a lane at the start of its ray: at the root, or (secondary rays) in the cell the ray starts in,
+// located from the position and validated by that cell's own slab interval on the first step.
+F3D_HD MarchState march_begin(const TerrainDev &T, const RayCtx &r, bool start_in_cell) {
+    MarchState m;
+    float hi;
+    march_root_interval(T, r, m.t_cur, hi);
+    m.marching = !(m.t_cur > hi);
+    m.level = T.mip_count - 1u;
+    m.nx = 0u;
+    m.nz = 0u;
+    m.unverified_start = false;
+    if (start_in_cell) {
+        const float fx = f_floor((f_fma(m.t_cur, r.d.x, r.o.x) - T.origin_x) * T.inv_spacing_x);
+        const float fz = f_floor((f_fma(m.t_cur, r.d.z, r.o.z) - T.origin_z) * T.inv_spacing_z);
+        m.nx = sat_u32(fx);
+        m.nz = sat_u32(fz);
+        m.nx = m.nx < T.cell_w - 1u ? m.nx : T.cell_w - 1u;
+        m.nz = m.nz < T.cell_h - 1u ? m.nz : T.cell_h - 1u;
+        m.level = 0u;
+        m.unverified_start = true;
+    }
+    return m;
+}
+
+// One march step of a lane: test the current node and move DOWN, or ACROSS (+ UP).
+template <bool CURVED, class Ctx>
+F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint32_t &queued, Ctx &ctx) {
+    ctx.note(0);
+    const uint32_t top = T.mip_count - 1u;
+    const uint32_t level = m.level, nx = m.nx, nz = m.nz;
+    const bool x_forward = !(r.d.x < 0.0f), z_forward = !(r.d.z < 0.0f);
+    // node extent in cells, clamped at ragged edges (:282-286), and its four plane parameters
+    const uint32_t cx0 = nx << level, cz0 = nz << level;
+    uint32_t cx1 = (nx + 1u) << level, cz1 = (nz + 1u) << level;
+    cx1 = cx1 < T.cell_w ? cx1 : T.cell_w;
+    cz1 = cz1 < T.cell_h ? cz1 : T.cell_h;
+    const float tx0 = (plane_at(T.origin_x, cx0, T.spacing_x) - r.o.x) * r.inv_x;
+    const float tx1 = (plane_at(T.origin_x, cx1, T.spacing_x) - r.o.x) * r.inv_x;
+    const float tz0 = (plane_at(T.origin_z, cz0, T.spacing_z) - r.o.z) * r.inv_z;
+    const float tz1 = (plane_at(T.origin_z, cz1, T.spacing_z) - r.o.z) * r.inv_z;
+    const float x_out = f_max(tx0, tx1), z_out = f_max(tz0, tz1);
+    const float enter = f_max(f_min(tx0, tx1), f_min(tz0, tz1)), exit = f_min(x_out, z_out);
+    if (m.unverified_start && !(enter <= m.t_cur && m.t_cur <= exit)) {
+        // the position was rounded across a cell boundary: walk down from the root instead
+        m.level = top;
+        m.nx = 0u;
+        m.nz = 0u;
+    } else {
+        const float lo = f_max(enter, r.tmin), hi = f_min(exit, r.tmax);
+        // the node's (min,max) band: one 8-byte record of the row-major table of its level
+        uint32_t band_offset, band_shift;
+        ctx.band_entry(T, level, band_offset, band_shift);
+        const NodeRec band = T.bands[band_offset + (nz << band_shift) + nx];
+        const bool pass = !(lo > hi) && !march_band_rejects<CURVED>(r, lo, hi, band.mn, band.mx);  // :297-304
+        if (pass && level > 0u) {
+            // DOWN into the child the ray is in at t_cur: it has passed the child boundary plane
+            // iff that plane's parameter is <= t_cur
+            const uint32_t cl = level - 1u;
+            const uint32_t xm = (2u * nx + 1u) << cl, zm = (2u * nz + 1u) << cl;
+            const float txm = (plane_at(T.origin_x, xm, T.spacing_x) - r.o.x) * r.inv_x;
+            const float tzm = (plane_at(T.origin_z, zm, T.spacing_z) - r.o.z) * r.inv_z;
+            uint32_t ix = (x_forward != (txm <= m.t_cur)) ? 0u : 1u;
+            uint32_t iz = (z_forward != (tzm <= m.t_cur)) ? 0u : 1u;
+            if (!(xm < T.cell_w)) ix = 0u;  // the far half lies outside the cell grid
+            if (!(zm < T.cell_h)) iz = 0u;
+            m.nx = 2u * nx + ix;
+            m.nz = 2u * nz + iz;
+            m.level = cl;
+        } else {
+            if (pass) {  // a leaf to solve: queue it and march on as if it had missed
+                ctx.note(1);
+                ctx.fifo_put(queued, nx | (nz << 16), lo, hi);
+                queued++;
+            }
+            // ---- across the exit boundary of this node (straight-line: no nested divergence) ----
+            const bool cross_x = x_out <= z_out, cross_z = z_out <= x_out;
+            // a backward step from column 0 wraps to 0xFFFFFFFF, whose shifted value is >= cell_w too
+            // (cell_w <= 2^13, level <= 15), so one unsigned comparison covers both directions
+            const uint32_t qx = nx + ((cross_x && x_forward) ? 1u : 0u) - ((cross_x && !x_forward) ? 1u : 0u);
+            const uint32_t qz = nz + ((cross_z && z_forward) ? 1u : 0u) - ((cross_z && !z_forward) ? 1u : 0u);
+            const bool left = !(exit < r.tmax) || (qx << level) >= T.cell_w || (qz << level) >= T.cell_h;
+            // leaving the parent as well: continue one level up (jumping h > 1 levels when the crossing
+            // leaves h ancestors was modelled on the emulator's step logs: fewer IBL steps, but more
+            // shadow steps and 7-17 % more wave iterations -- tools/march_model.py)
+            const bool up = level < top && (((qx ^ nx) | (qz ^ nz)) > 1u);
+            m.nx = up ? qx >> 1 : qx;
+            m.nz = up ? qz >> 1 : qz;
+            m.level = up ? level + 1u : level;
+            m.t_cur = f_max(m.t_cur, exit);
+            m.marching = !left;  // out of the footprint, or past tmax
+        }
+    }
+    m.unverified_start = false;
+}
+
+// Drain the lane's leaf FIFO: solve the queued leaves in ray order until one hits.
+template <class Ctx>
+F3D_HD void march_drain(const TerrainDev &T, const RayCtx &r, bool any_hit, MarchState &m, uint32_t &queued,
+                        TraceHit &res, Ctx &ctx) {
+    for (uint32_t k = 0u; ctx.any(k < queued && !res.hit); k++) {
+        if (k < queued && !res.hit) {
+            uint32_t cell;
+            float lo, hi;
+            ctx.fifo_get(k, cell, lo, hi);
+            const uint32_t cx = cell & 0xFFFFu, cz = cell >> 16;
+            const LeafRec leaf = T.leaves[tiled_index(cx, cz, T.tiles_x[0])];
+            float t;
+            if (leaf_solve(T, r, leaf, cx, cz, lo, hi, any_hit, t) && t < res.t) {
+                res.hit = true;  // first hit in ray order is final (see the header)
+                res.t = t;
+                res.n = leaf_normal(T, leaf, along(r.o, t, r.d), cx, cz);
+                m.marching = false;
+            }
+        }
+    }
+    queued = 0u;
+}
+
 // CURVED: the sun-ray curvature policy is active for this ray (compile-time so that the other
 // two thirds of the rays do not carry the parabola arithmetic).  start_in_cell: begin in the cell
 // the ray is in (secondary rays) instead of at the root (camera rays entering from outside).
@@ -75,122 +210,13 @@ F3D_HD TraceHit march_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit
     res.t = r.tmax;
     res.n = V3{0.0f, 0.0f, 0.0f};
     ctx.note(2 | (any_hit ? 1 : 0) | (CURVED ? 4 : 0));  // statistics hook: a new ray starts
-    const uint32_t top = T.mip_count - 1u;
-    bool marching = true;
-    // root slab interval (:288-297 for the root node)
-    float t_cur = 0.0f;
-    {
-        const float ax = (plane_at(T.origin_x, 0u, T.spacing_x) - r.o.x) * r.inv_x;
-        const float bx = (plane_at(T.origin_x, T.cell_w, T.spacing_x) - r.o.x) * r.inv_x;
-        const float az = (plane_at(T.origin_z, 0u, T.spacing_z) - r.o.z) * r.inv_z;
-        const float bz = (plane_at(T.origin_z, T.cell_h, T.spacing_z) - r.o.z) * r.inv_z;
-        const float lo = f_max(f_max(f_min(ax, bx), f_min(az, bz)), r.tmin);
-        const float hi = f_min(f_min(f_max(ax, bx), f_max(az, bz)), r.tmax);
-        if (lo > hi) marching = false;
-        t_cur = lo;
-    }
-    const bool x_forward = !(r.d.x < 0.0f), z_forward = !(r.d.z < 0.0f);
-    uint32_t level = top, nx = 0u, nz = 0u;
-    bool unverified_start = false;
-    if (start_in_cell) {
-        const float fx = f_floor((f_fma(t_cur, r.d.x, r.o.x) - T.origin_x) * T.inv_spacing_x);
-        const float fz = f_floor((f_fma(t_cur, r.d.z, r.o.z) - T.origin_z) * T.inv_spacing_z);
-        nx = sat_u32(fx);
-        nz = sat_u32(fz);
-        nx = nx < T.cell_w - 1u ? nx : T.cell_w - 1u;
-        nz = nz < T.cell_h - 1u ? nz : T.cell_h - 1u;
-        level = 0u;
-        unverified_start = true;
-    }
+    MarchState m = march_begin(T, r, start_in_cell);
     uint32_t queued = 0u;
     for (;;) {
-        if (marching) {
-            ctx.note(0);
-            // node extent in cells, clamped at ragged edges (:282-286), and its four plane parameters
-            const uint32_t cx0 = nx << level, cz0 = nz << level;
-            uint32_t cx1 = (nx + 1u) << level, cz1 = (nz + 1u) << level;
-            cx1 = cx1 < T.cell_w ? cx1 : T.cell_w;
-            cz1 = cz1 < T.cell_h ? cz1 : T.cell_h;
-            const float tx0 = (plane_at(T.origin_x, cx0, T.spacing_x) - r.o.x) * r.inv_x;
-            const float tx1 = (plane_at(T.origin_x, cx1, T.spacing_x) - r.o.x) * r.inv_x;
-            const float tz0 = (plane_at(T.origin_z, cz0, T.spacing_z) - r.o.z) * r.inv_z;
-            const float tz1 = (plane_at(T.origin_z, cz1, T.spacing_z) - r.o.z) * r.inv_z;
-            const float x_out = f_max(tx0, tx1), z_out = f_max(tz0, tz1);
-            const float enter = f_max(f_min(tx0, tx1), f_min(tz0, tz1)), exit = f_min(x_out, z_out);
-            if (unverified_start && !(enter <= t_cur && t_cur <= exit)) {
-                // the position was rounded across a cell boundary: walk down from the root instead
-                level = top;
-                nx = 0u;
-                nz = 0u;
-            } else {
-                const float lo = f_max(enter, r.tmin), hi = f_min(exit, r.tmax);
-                // the node's (min,max) band: one 8-byte record of the row-major table of its level
-                uint32_t band_offset, band_shift;
-                ctx.band_entry(T, level, band_offset, band_shift);
-                const NodeRec band = T.bands[band_offset + (nz << band_shift) + nx];
-                const bool pass = !(lo > hi) && !march_band_rejects<CURVED>(r, lo, hi, band.mn, band.mx);  // :297-304
-                if (pass && level > 0u) {
-                    // DOWN into the child the ray is in at t_cur: it has passed the child boundary plane
-                    // iff that plane's parameter is <= t_cur
-                    const uint32_t cl = level - 1u;
-                    const uint32_t xm = (2u * nx + 1u) << cl, zm = (2u * nz + 1u) << cl;
-                    const float txm = (plane_at(T.origin_x, xm, T.spacing_x) - r.o.x) * r.inv_x;
-                    const float tzm = (plane_at(T.origin_z, zm, T.spacing_z) - r.o.z) * r.inv_z;
-                    uint32_t ix = (x_forward != (txm <= t_cur)) ? 0u : 1u;
-                    uint32_t iz = (z_forward != (tzm <= t_cur)) ? 0u : 1u;
-                    if (!(xm < T.cell_w)) ix = 0u;  // the far half lies outside the cell grid
-                    if (!(zm < T.cell_h)) iz = 0u;
-                    nx = 2u * nx + ix;
-                    nz = 2u * nz + iz;
-                    level = cl;
-                } else {
-                    if (pass) {  // a leaf to solve: queue it and march on as if it had missed
-                        ctx.note(1);
-                        ctx.fifo_put(queued, nx | (nz << 16), lo, hi);
-                        queued++;
-                    }
-                    // ---- across the exit boundary of this node (straight-line: no nested divergence) ----
-                    const bool cross_x = x_out <= z_out, cross_z = z_out <= x_out;
-                    const uint32_t px = nx, pz = nz;
-                    // a backward step from column 0 wraps to 0xFFFFFFFF, whose shifted value is >= cell_w too
-                    // (cell_w <= 2^13, level <= 15), so one unsigned comparison covers both directions
-                    nx = nx + ((cross_x && x_forward) ? 1u : 0u) - ((cross_x && !x_forward) ? 1u : 0u);
-                    nz = nz + ((cross_z && z_forward) ? 1u : 0u) - ((cross_z && !z_forward) ? 1u : 0u);
-                    const bool left = !(exit < r.tmax) || (nx << level) >= T.cell_w || (nz << level) >= T.cell_h;
-                    // leaving the parent as well: continue one level up (jumping h > 1 levels when the crossing
-                    // leaves h ancestors was modelled on the emulator's step logs: fewer IBL steps, but more
-                    // shadow steps and 7-17 % more wave iterations -- tools/march_model.py)
-                    const bool up = level < top && (((nx ^ px) | (nz ^ pz)) > 1u);
-                    nx = up ? nx >> 1 : nx;
-                    nz = up ? nz >> 1 : nz;
-                    level = up ? level + 1u : level;
-                    t_cur = f_max(t_cur, exit);
-                    marching = !left;  // out of the footprint, or past tmax
-                }
-            }
-            unverified_start = false;
-        }
-        // ---- drain the leaf FIFOs when the wave says so ----
-        if (ctx.flush_now(queued, marching)) {
-            for (uint32_t k = 0u; ctx.any(k < queued && !res.hit); k++) {
-                if (k < queued && !res.hit) {
-                    uint32_t cell;
-                    float lo, hi;
-                    ctx.fifo_get(k, cell, lo, hi);
-                    const uint32_t cx = cell & 0xFFFFu, cz = cell >> 16;
-                    const LeafRec leaf = T.leaves[tiled_index(cx, cz, T.tiles_x[0])];
-                    float t;
-                    if (leaf_solve(T, r, leaf, cx, cz, lo, hi, any_hit, t) && t < res.t) {
-                        res.hit = true;  // first hit in ray order is final (see the header)
-                        res.t = t;
-                        res.n = leaf_normal(T, leaf, along(r.o, t, r.d), cx, cz);
-                        marching = false;
-                    }
-                }
-            }
-            queued = 0u;
-        }
-        if (!ctx.any(marching || queued != 0u)) break;
+        if (m.marching) march_step<CURVED>(T, r, m, queued, ctx);
+        // drain the leaf FIFOs when the wave says so
+        if (ctx.flush_now(queued, m.marching)) march_drain(T, r, any_hit, m, queued, res, ctx);
+        if (!ctx.any(m.marching || queued != 0u)) break;
     }
     return res;
 }
