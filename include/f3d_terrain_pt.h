@@ -160,6 +160,15 @@ int f3d_session_kernel_timing(f3d_session *session, int32_t enable, double *avg_
 /* Sample lanes per pixel the frame kernel of this session runs with (1, 2, 4 or 8); 0 on a NULL session. */
 uint32_t f3d_session_sample_lanes(f3d_session *session);
 
+/* ---- post filter ---------------------------------------------- */
+/* Edge-aware a-trous denoiser: replaces forge3d.denoise.atrous_denoise
+ * (reference python/forge3d/denoise.py:18-127).  color / albedo / normal: H x W x 3 f32,
+ * depth: H x W f32; albedo, normal, depth may be NULL.  `out` (H x W x 3 f32) is caller-owned.
+ * iterations < 1 runs one pass, like the reference. */
+int f3d_atrous_denoise(const float *color, const float *albedo, const float *normal, const float *depth,
+                       uint32_t width, uint32_t height, int32_t iterations, float sigma_color, float sigma_albedo,
+                       float sigma_normal, float sigma_depth, float *out, char *err, size_t errlen);
+
 /* ---- test hooks (KATs restated from the reference's Rust unit tests) ----------- */
 /* build_minmax_mips on the GPU (reference terrain_heightfield.rs:132-202); output in
  * the reference's layout: levels back to back, finest first, each (ph, pw, 2) f32;
