@@ -69,6 +69,9 @@ def cpu_baseline(dem, cam, kw, args):
     scale = min(args.width / w, max(1.0, (budget / probe["n_samples"]) ** 0.5))
     w2, h2 = min(args.width, int(w * scale) // 8 * 8), min(args.height, int(h * scale) // 8 * 8)
     out = oracle.render(dem, w2, h2, cam, **k)  # 2 frames at the sample's resolution: the real rate
+    # the per-sample traversal counts of the roofline always come from these two frames (a fixed definition,
+    # independent of how fast the host is)
+    counts = {key: out[key] / out["n_samples"] for key in ("n_node", "n_leaf", "n_hit")}
     frames = int(min(32, args.cpu_seconds * out["n_samples"] / max(out["loop_seconds"], 1e-9) // (w2 * h2 * args.spp)))
     if frames >= 3:
         k.update(max_frames=frames, min_frames=frames)
@@ -80,7 +83,7 @@ def cpu_baseline(dem, cam, kw, args):
         "value": n / out["loop_seconds"] / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
         "sample": f"CPU oracle (C, OpenMP), same DEM/camera/sun, {w2}x{h2}, {args.spp} spp x {frames} frames "
                   f"= {n / 1e6:.2f} Msamples in {out['loop_seconds']:.1f} s",
-    }, {"n_node": out["n_node"] / n, "n_leaf": out["n_leaf"] / n, "n_hit": out["n_hit"] / n}
+    }, counts
 
 
 def main():

@@ -483,3 +483,14 @@ def test_full_size_properties(f3d):
     assert np.abs(np.linalg.norm(a["normal"][hits], axis=-1) - 1.0).max() < 1e-2
     assert (a["albedo"][~hits] == 0).all()
     assert a["any_valid_reservoir"]
+    # the 1-lane kernel and the 8-sample-lane kernel (speculative RNG states, ordered replay) produce the
+    # same two million pixels as the default, bit for bit
+    for variant in (1000000, 8000000):
+        with TerrainSession(dem, W, H, cam, memory_budget_bytes=4 << 30, kernel_variant=variant, **k) as s:
+            assert s.sample_lanes() == variant // 1000000
+            s.enqueue_frames(0, 4, True)
+            m2v, _ = s.window_stats()
+            v = s.resolve(4)
+        assert m2v == m2
+        for key in ("rgba", "albedo", "normal", "depth"):
+            assert np.array_equal(a[key], v[key], equal_nan=True), (variant, key)
