@@ -98,6 +98,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    if os.environ.get("F3D_DIST_BACKEND") == "gloo":  # rehearsal: all ranks share the one GPU of a test box
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     from forge3d_amd import datasets
     from forge3d_amd.distributed import StripRenderer, init_process_group

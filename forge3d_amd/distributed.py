@@ -45,7 +45,8 @@ def init_process_group(world: int, rank: int, backend: str | None = None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # F3D_DIST_BACKEND=gloo: rehearsal of a multi-rank job on ONE GPU (RCCL refuses two ranks per device)
+        backend = os.environ.get("F3D_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
 
@@ -166,11 +167,23 @@ class StripRenderer:
         self.session = self.backend.make_session(dem, self.width, self.height, cam, self.row_begin, self.row_end,
                                                  self.res, self.stats, kw)
 
+    # -- communication device ---------------------------------------------------------
+    def _comm_device(self):
+        """Device the collectives run on: the buffers' own device with RCCL; the host when the process
+        group cannot move device memory (gloo with GPU buffers -- the 2-process single-GPU test), in
+        which case halos, statistics and strips are staged through host copies."""
+        import torch.distributed as dist
+
+        dev = self.backend.empty_i32(1).device
+        if dev.type != "cpu" and self.world > 1 and dist.get_backend() == "gloo":
+            return self.torch.device("cpu")
+        return dev
+
     # -- load balancing ----------------------------------------------------------------
     def _gather_floats(self, value: float):
         import torch.distributed as dist
 
-        mine = self.torch.tensor([float(value)], dtype=self.torch.float64, device=self.backend.empty_i32(1).device)
+        mine = self.torch.tensor([float(value)], dtype=self.torch.float64, device=self._comm_device())
         parts = [self.torch.empty_like(mine) for _ in range(self.world)]
         dist.all_gather(parts, mine)
         return [float(p.item()) for p in parts]
@@ -210,15 +223,30 @@ class StripRenderer:
             return
         import torch.distributed as dist
 
-        ops = []
+        staged = self._comm_device() != self.res[0].device
+        ops, landed = [], []
+
+        def send(first, peer):
+            rows = self._rows(which, first)
+            ops.append(dist.P2POp(dist.isend, rows.cpu() if staged else rows, peer))
+
+        def recv(first, peer):
+            rows = self._rows(which, first)
+            box = self.torch.empty(rows.shape, dtype=rows.dtype) if staged else rows
+            landed.append((rows, box))
+            ops.append(dist.P2POp(dist.irecv, box, peer))
+
         if self.rank > 0:
-            ops.append(dist.P2POp(dist.isend, self._rows(which, HALO_ROWS), self.rank - 1))
-            ops.append(dist.P2POp(dist.irecv, self._rows(which, 0), self.rank - 1))
+            send(HALO_ROWS, self.rank - 1)
+            recv(0, self.rank - 1)
         if self.rank < self.world - 1:
-            ops.append(dist.P2POp(dist.isend, self._rows(which, self.rows), self.rank + 1))
-            ops.append(dist.P2POp(dist.irecv, self._rows(which, self.rows + HALO_ROWS), self.rank + 1))
+            send(self.rows, self.rank + 1)
+            recv(self.rows + HALO_ROWS, self.rank + 1)
         for work in dist.batch_isend_irecv(ops):
             work.wait()
+        if staged:
+            for rows, box in landed:
+                rows.copy_(box)
 
     def barrier(self):
         if self.world > 1:
@@ -231,7 +259,7 @@ class StripRenderer:
             return float(value)
         import torch.distributed as dist
 
-        t = self.torch.tensor([float(value)], dtype=self.torch.float64, device=self.res[0].device)
+        t = self.torch.tensor([float(value)], dtype=self.torch.float64, device=self._comm_device())
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -256,8 +284,9 @@ class StripRenderer:
             import torch.distributed as dist
 
             self.backend.sync()
-            dist.all_reduce(self.stats, op=dist.ReduceOp.MAX)
-            host = self.stats.cpu().numpy().astype(np.uint32)
+            stats = self.stats.to(self._comm_device())
+            dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+            host = stats.cpu().numpy().astype(np.uint32)
             m2 = float(host[:1].view(np.float32)[0])
             bad = bool(host[1])
         if bad:
@@ -294,7 +323,7 @@ class StripRenderer:
         import torch.distributed as dist
 
         torch = self.torch
-        dev = self.res[0].device
+        dev = self._comm_device()
         max_rows = max(b1 - b0 for b0, b1 in zip(self.bounds, self.bounds[1:]))
         result = {}
         for key, chans, dtype in (("rgba", 4, torch.uint8), ("albedo", 3, torch.float32),
