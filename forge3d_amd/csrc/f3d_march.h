@@ -61,7 +61,10 @@ F3D_HD bool march_band_rejects(const RayCtx &r, float t0, float t1, float mn, fl
 // not depend on when it is evaluated; any-hit rays need the OR, closest-hit rays the FIRST queued
 // leaf (ray order = FIFO order) that hits.  The price is a few extra march steps for rays whose hit
 // is sitting in the FIFO.
-constexpr uint32_t kLeafFifo = 4;  // entries per lane
+#ifndef F3D_LEAF_FIFO
+#define F3D_LEAF_FIFO 4
+#endif
+constexpr uint32_t kLeafFifo = F3D_LEAF_FIFO;  // entries per lane (A/B: 2, 3, 6, 8 -- profiles/README.md)
 
 // Per-lane position of a march.
 struct MarchState {
