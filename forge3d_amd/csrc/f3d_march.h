@@ -137,6 +137,7 @@ F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint
         ctx.band_entry(T, level, band_offset, band_shift);
         const NodeRec band = T.bands[band_offset + (nz << band_shift) + nx];
         const bool pass = !(lo > hi) && !march_band_rejects<CURVED>(r, lo, hi, band.mn, band.mx);  // :297-304
+        if (pass) ctx.note(-1);  // statistics hook (host emulator only): the last step whose band test passed
         if (pass && level > 0u) {
             // DOWN into the child the ray is in at t_cur: it has passed the child boundary plane
             // iff that plane's parameter is <= t_cur

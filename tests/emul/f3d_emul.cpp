@@ -30,6 +30,8 @@ struct ArrayPending {
         if (!log) return;
         if (kind >= 2) {
             log->push_back(RayLog{(uint32_t)kind, 0u, 0ull});
+        } else if (kind < 0) {  // band test passed at this step: remember it in bits 8.. of `kind`
+            if (!log->empty()) log->back().kind = (log->back().kind & 0xFFu) | (log->back().steps << 8);
         } else if (!log->empty()) {
             RayLog &r = log->back();
             if (kind == 1 && r.steps < 64u) r.leaf_mask |= 1ull << r.steps;

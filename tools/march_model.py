@@ -67,6 +67,7 @@ def main():
             for li, rays in enumerate(lanes):
                 s = -1
                 for kind, steps, mask in rays:
+                    kind = int(kind) & 0xFF
                     if kind == 2:
                         s += 1
                         P[li, s, 0] = steps
@@ -156,6 +157,7 @@ def batched_table(rows="480:608"):
             for li, rays in enumerate(lanes):
                 s = -1
                 for kind, steps, mask in rays:
+                    kind = int(kind) & 0xFF
                     if kind == 2:
                         s += 1
                     P[li, s, {2: 0, 7: 1}.get(int(kind), 2)] = steps
@@ -192,6 +194,7 @@ def ibl_batched_bound(rows="480:608"):
             for li, rays in enumerate(lanes):
                 s = -1
                 for kind, steps, mask in rays:
+                    kind = int(kind) & 0xFF
                     if kind == 2:
                         s += 1
                     P[li, s, {2: 0, 7: 1}.get(int(kind), 2)] = steps
@@ -230,6 +233,7 @@ def lanes_model(rows="480:608", S=8):
             for li, rays in enumerate(lanes):
                 s = -1
                 for kind, steps, mask in rays:
+                    kind = int(kind) & 0xFF
                     if kind == 2:
                         s += 1
                     P[li, s, {2: 0, 7: 1}.get(int(kind), 2)] = steps
@@ -266,6 +270,7 @@ def split_model(rows="480:608", S=8):
             for li, rays in enumerate(lanes):
                 s = -1
                 for kind, steps, mask in rays:
+                    kind = int(kind) & 0xFF
                     if kind == 2:
                         s += 1
                     P[li, s, {2: 0, 7: 1}.get(int(kind), 2)] = steps
@@ -356,6 +361,52 @@ def persistent_model(rows="480:608"):
                       f" (utilisation {steps.sum() / 64 / total:.3f})")
 
 
+def walkout_model(rows="480:608"):
+    """How much of an occlusion ray's march is pure walk-out (steps after the LAST node whose band
+    test passed)?  An oracle 'certificate' that ended a ray right there bounds what horizon tables
+    could buy; reported per phase as lockstep wave iterations with S = 4 sample lanes."""
+    from emul import emul
+    from forge3d_amd import datasets
+
+    rows = tuple(int(x) for x in rows.split(":"))
+    dem, cam, kw = datasets.rainier_proxy_scene(2048)
+    log = tempfile.mktemp(suffix=".raylog")
+    os.environ["F3D_EMUL_RAYLOG"] = log
+    emul.render(dem, 1920, 1080, cam, rows=rows, **dict(kw, spp=8, max_frames=2, min_frames=2, variance_threshold=1e30))
+    W, R, spp, pixels = load_log(log)
+    os.unlink(log)
+    S, tw, th = 4, 4, 4
+    base = np.zeros(3)
+    cut = np.zeros(3)
+    lane_steps = np.zeros(3)
+    lane_cut = np.zeros(3)
+    for ty in range(0, R, th):
+        for tx in range(0, W, tw):
+            lanes = [pixels[y * W + x] for y in range(ty, min(ty + th, R)) for x in range(tx, min(tx + tw, W))]
+            P = np.zeros((len(lanes), spp, 3))
+            Q = np.zeros((len(lanes), spp, 3))
+            for li, rays in enumerate(lanes):
+                s = -1
+                for kind, steps, mask in rays:
+                    k = int(kind) & 0xFF
+                    last_pass = int(kind) >> 8
+                    if k == 2:
+                        s += 1
+                    j = {2: 0, 7: 1}.get(k, 2)
+                    P[li, s, j] = steps
+                    Q[li, s, j] = min(int(steps), last_pass + 2)  # + the step that notices the clearance
+            for r0 in range(0, spp, S):
+                b, q = P[:, r0:r0 + S, :].reshape(-1, 3), Q[:, r0:r0 + S, :].reshape(-1, 3)
+                base += b.max(axis=0)
+                cut += np.stack([b[:, 0], q[:, 1], q[:, 2]], 1).max(axis=0)  # primaries untouched
+                lane_steps += b.sum(axis=0)
+                lane_cut += q.sum(axis=0)
+    for j, name in enumerate(("primary", "shadow", "ibl")):
+        print(f"  {name:8s}: lane-steps {lane_steps[j]:.3g} -> {lane_cut[j]:.3g} ({lane_cut[j] / max(lane_steps[j], 1):.2f}); "
+              f"lockstep wave iterations {base[j]:.0f} -> {cut[j] if j else base[j]:.0f}")
+    print(f"  total wave iterations {base.sum():.0f} -> {cut.sum():.0f} = {base.sum() / cut.sum():.3f}x fewer with a perfect certificate")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[2] == "batched":
         batched_table(sys.argv[1])
@@ -367,5 +418,7 @@ if __name__ == "__main__":
         split_model(sys.argv[1])
     elif len(sys.argv) > 2 and sys.argv[2] == "persistent":
         persistent_model(sys.argv[1])
+    elif len(sys.argv) > 2 and sys.argv[2] == "walkout":
+        walkout_model(sys.argv[1])
     else:
         main()
