@@ -29,6 +29,8 @@ struct LdsPending {
     __device__ __forceinline__ void put(uint32_t level, uint32_t word) { col[level * kWave] = word; }
     __device__ __forceinline__ uint32_t get(uint32_t level) const { return col[level * kWave]; }
     __device__ __forceinline__ void note(int) const {}  // step-statistics hook (host emulator only)
+    __device__ __forceinline__ void feature(float) const {}
+    __device__ __forceinline__ void hint(float) const {}
     // (leaf-gate A/B build only) may the lanes that hold a fat leaf solve it now?
     __device__ __forceinline__ bool leaf_gate(bool at_leaf) const {
         const unsigned long long leaf = __ballot(at_leaf), inner = __ballot(!at_leaf);
@@ -67,15 +69,16 @@ struct LdsPending {
     }
 };
 __device__ __forceinline__ LdsPending make_pending(uint32_t *lds, const TerrainDev &T) {
-    if (threadIdx.x < kMaxLevels) {
-        uint32_t *e = lds + kLdsRows * kWave + 4 * threadIdx.x;
-        e[0] = T.band_offset[threadIdx.x];
-        e[1] = T.band_shift[threadIdx.x];
-        e[2] = T.node_offset[threadIdx.x];
-        e[3] = T.tiles_x[threadIdx.x];
+    const uint32_t lane = threadIdx.x & (kWave - 1u);  // `lds` is this WAVE's block (workgroups may hold several)
+    if (lane < kMaxLevels) {
+        uint32_t *e = lds + kLdsRows * kWave + 4 * lane;
+        e[0] = T.band_offset[lane];
+        e[1] = T.band_shift[lane];
+        e[2] = T.node_offset[lane];
+        e[3] = T.tiles_x[lane];
     }
     __syncthreads();
-    return LdsPending{lds + threadIdx.x, lds + kLdsRows * kWave, T.leaf_quorum ? T.leaf_quorum : kDefaultLeafQuorum};
+    return LdsPending{lds + lane, lds + kLdsRows * kWave, T.leaf_quorum ? T.leaf_quorum : kDefaultLeafQuorum};
 }
 
 // Pixel tile of a wave with S sample lanes per pixel: 64 / S pixels, TW x TH.
@@ -135,7 +138,7 @@ __device__ __forceinline__ void publish_window_stats(const FrameParams &P, bool 
     uint32_t bits = (active && !bad) ? f_bits(f_max(m2, 0.0f)) : 0u;
     bits = wave_max_u32(bits);
     const unsigned long long any_bad = __ballot(bad);
-    if (threadIdx.x == 0) {
+    if ((threadIdx.x & (kWave - 1u)) == 0u) {
         // most waves lose the race for the maximum: look before paying for the atomic
         if (bits > __hip_atomic_load(&P.stats[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
             atomicMax(&P.stats[0], bits);
@@ -161,11 +164,17 @@ __device__ __forceinline__ void publish_window_stats(const FrameParams &P, bool 
 // ~1 200 instructions a pixel) would run redundantly on all S lanes, so it runs in its own
 // pixel-parallel launch (k_head) and leaves an 8-byte record per pixel; the short tail runs on
 // sample lane 0.
+// (`valid` masks the lanes outside the image: every lane of the wave runs the function to its end.)
 template <uint32_t S>
-__device__ __forceinline__ float frame_lanes(const FrameParams &P, uint32_t gx, uint32_t gy, LdsPending &pend) {
-    const uint32_t lane = threadIdx.x, j = lane & (S - 1u), base = lane & ~(S - 1u);
+__device__ __forceinline__ float frame_lanes(const FrameParams &P, uint32_t gx, uint32_t gy, bool valid, LdsPending &pend) {
+    const uint32_t lane = threadIdx.x & (kWave - 1u), j = lane & (S - 1u), base = lane & ~(S - 1u);
     constexpr uint32_t kGroup = (1u << S) - 1u;
-    const FrameHead h = unpack_head(P, gx, gy, P.head[(size_t)(gy - P.row_begin) * P.cam.width + gx]);  // k_head
+    FrameHead h;
+    h.centre_hit = false;
+    h.prev_valid = false;
+    h.reuse_w = 1.0f;
+    h.rng = 0u;
+    if (valid) h = unpack_head(P, gx, gy, P.head[(size_t)(gy - P.row_begin) * P.cam.width + gx]);  // k_head
     uint32_t stream = h.rng;  // state at the start of the current round
     // The accumulators live in the lane's LDS column between rounds (7 words), not in registers:
     // nothing reads them while the rays of a round are traced.
@@ -174,7 +183,7 @@ __device__ __forceinline__ float frame_lanes(const FrameParams &P, uint32_t gx, 
     for (int w = 0; w < kParkWords; w++) park[w * kWave] = 0u;  // radiance = 0, empty candidate reservoir
     for (uint32_t s0 = 0u; s0 < P.spp; s0 += S) {  // wave-uniform
         const uint32_t n_act = P.spp - s0 < S ? P.spp - s0 : S;
-        const bool act = j < n_act;
+        const bool act = valid && j < n_act;
         uint32_t pred = h.centre_hit ? kGroup : 0u;  // predicted hit flags of this round's samples
         uint32_t traced = 0xFFFFFFFFu;               // draws in front of my sample when I last traced it
         PrimaryHit ph;
@@ -196,10 +205,19 @@ __device__ __forceinline__ float frame_lanes(const FrameParams &P, uint32_t gx, 
         o.a = V3{0.0f, 0.0f, 0.0f};
         o.b = V3{0.0f, 0.0f, 0.0f};
         o.target_pdf = 0.0f;
+        IblRay q;
+        q.valid = false;
+        q.o = q.d = q.b0 = V3{0.0f, 0.0f, 0.0f};
+        q.key = 2.0f;
         if (act) {
             uint32_t rng = ph.rng;
-            o = sample_shade(P, h, ph, rng, pend);
+            q = sample_shade_sun(P, h, ph, rng, o, pend);
         }
+        // (Sorting the IBL rays of a 4-wave workgroup by cos(normal, ray) -- a good predictor of the march
+        // length, 1.6x fewer IBL wave iterations in the step-log model -- was built and measured: bit-identical,
+        // but 0.81x: the waves that finish early wait at the workgroup barrier and the occupancy the kernel
+        // lives on is gone.  profiles/README.md)
+        if (q.valid) o.b = q.b0 * (ibl_occluded(P, q.o, q.d, pend) ? 0.0f : 1.0f);
         V3 radiance = V3{f_from_bits(park[0]), f_from_bits(park[kWave]), f_from_bits(park[2 * kWave])};
         Reservoir cand;
         cand.w_sum = f_from_bits(park[3 * kWave]);
@@ -224,7 +242,7 @@ __device__ __forceinline__ float frame_lanes(const FrameParams &P, uint32_t gx, 
         park[6 * kWave] = cand.directional ? 1u : 0u;
         rng_skip(stream, 2u * n_act + 2u * (uint32_t)__popc(pred));
     }
-    if (j != 0u) return 0.0f;
+    if (!valid || j != 0u) return 0.0f;
     Reservoir cand;
     cand.w_sum = f_from_bits(park[3 * kWave]);
     cand.m = park[4 * kWave];
@@ -254,7 +272,7 @@ __global__ __launch_bounds__(kWave, MIN_WAVES) void k_frame(const FrameParams P)
         if (active) m2 = frame_pixel(P, gx, gy, pend);
         if (P.collect_stats != 0u) publish_window_stats(P, active, m2);
     } else {
-        if (active) m2 = frame_lanes<S>(P, gx, gy, pend);
+        m2 = frame_lanes<S>(P, gx, gy, active, pend);
         if (P.collect_stats != 0u) publish_window_stats(P, active && (threadIdx.x & (S - 1u)) == 0u, m2);
     }
 }
@@ -335,7 +353,7 @@ hipError_t launch_head(const FrameParams &p, hipStream_t stream) {
 hipError_t launch_frame(const FrameParams &p, int variant, hipStream_t stream) {
     const uint32_t lanes = p.sample_lanes ? p.sample_lanes : 1u;
     const dim3 grid(frame_grid(p, lanes)), block(kWave);
-    if (lanes != 1u) {  // sample-lane kernels (register-budget A/B variants for 4 and 8 lanes only)
+    if (lanes != 1u) {  // one wave per workgroup (register-budget A/B variants for 4 and 8 lanes only)
         switch (lanes * 1000 + (uint32_t)(variant % 1000)) {
             case 2000: hipLaunchKernelGGL((k_frame<0, 6, 2>), grid, block, 0, stream, p); break;
             case 4000: hipLaunchKernelGGL((k_frame<0, 6, 4>), grid, block, 0, stream, p); break;

@@ -214,6 +214,7 @@ F3D_HD TraceHit march_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit
     res.t = r.tmax;
     res.n = V3{0.0f, 0.0f, 0.0f};
     ctx.note(2 | (any_hit ? 1 : 0) | (CURVED ? 4 : 0));  // statistics hook: a new ray starts
+    ctx.feature(r.d.y);
     MarchState m = march_begin(T, r, start_in_cell);
     uint32_t queued = 0u;
     for (;;) {

@@ -411,16 +411,28 @@ struct SampleOut {
     float target_pdf;  // candidate weight of the hit (:500-512); 0 = no candidate
 };
 
-// Shading of one sample whose primary hit is known (:486-548); draws u1, u2 from `rng` on a hit.
+// The IBL-occlusion ray of a sample and what its verdict scales: ibl = b0 * (occluded ? 0 : 1).
+struct IblRay {
+    bool valid;  // false: the primary ray missed, there is no IBL ray
+    V3 o, d;     // origin (hit point lifted off the surface), cosine-weighted direction
+    V3 b0;       // albedo * env(d)
+    float key;   // cos(normal, d): small = grazing = a long march (scheduling hint only)
+};
+
+// First half of the shading of a sample whose primary hit is known (:486-536): candidate, sun term
+// (with its shadow ray), and the IBL ray to trace; draws u1, u2 from `rng` on a hit.
 template <class Pending>
-F3D_HD SampleOut sample_shade(const FrameParams &P, const FrameHead &h, const PrimaryHit &ph, uint32_t &rng,
-                              Pending &pend) {
-    SampleOut o;
+F3D_HD IblRay sample_shade_sun(const FrameParams &P, const FrameHead &h, const PrimaryHit &ph, uint32_t &rng,
+                               SampleOut &o, Pending &pend) {
+    IblRay q;
+    q.valid = false;
+    q.o = q.d = q.b0 = V3{0.0f, 0.0f, 0.0f};
+    q.key = 2.0f;
     o.b = V3{0.0f, 0.0f, 0.0f};
     o.target_pdf = 0.0f;
     if (ph.hit.kind == 0u) {
         o.a = env_radiance(P.env, ph.rd);
-        return o;
+        return q;
     }
     const V3 n = ph.hit.n;
     const V3 albedo = ph.hit.kind == 1u ? P.light.albedo : V3{0.7f, 0.7f, 0.8f};
@@ -433,6 +445,9 @@ F3D_HD SampleOut sample_shade(const FrameParams &P, const FrameHead &h, const Pr
     o.a = V3{0.0f, 0.0f, 0.0f};
     if (nd > 0.0f) {
         float vis = 1.0f;
+#if defined(F3D_MODEL_HINT_SUN)  // scheduling-model builds of the emulator only
+        pend.hint(F3D_MODEL_HINT_SUN);
+#endif
 #if !defined(F3D_TIMING_NO_SHADOW)  // timing experiment only (wrong image): tools/gpu_build_ab.sh
         if (P.light.shadows_enabled != 0u && occluded(P, so, 1e-3f, sun_dir, 1e30f, true, pend)) vis = 0.0f;
 #endif
@@ -442,12 +457,34 @@ F3D_HD SampleOut sample_shade(const FrameParams &P, const FrameHead &h, const Pr
     const float u1 = rng_next(rng);
     const float u2 = rng_next(rng);
     const V3 ei = cosine_dir(n, u1, u2);
-#if defined(F3D_TIMING_NO_IBL)  // timing experiment only (wrong image): tools/gpu_build_ab.sh, profiles/README.md
-    const float env_vis = 1.0f;
-#else
-    const float env_vis = occluded(P, so, 1e-3f, ei, 1e30f, false, pend) ? 0.0f : 1.0f;
+#if defined(F3D_MODEL_HINT)  // scheduling-model builds of the emulator only (tools/march_model.py predictor)
+    pend.hint(F3D_MODEL_HINT);
 #endif
-    o.b = (albedo * env_radiance(P.env, ei)) * env_vis;
+    q.valid = true;
+    q.o = so;
+    q.d = ei;
+    q.b0 = albedo * env_radiance(P.env, ei);
+    q.key = dot(n, ei);
+    return q;
+}
+
+// The verdict of an IBL ray (intersect_ibl_occlusion_ray, hybrid_traversal.wgsl:250-259).
+template <class Pending>
+F3D_HD bool ibl_occluded(const FrameParams &P, V3 o, V3 d, Pending &pend) {
+#if defined(F3D_TIMING_NO_IBL)  // timing experiment only (wrong image): tools/gpu_build_ab.sh, profiles/README.md
+    return false;
+#else
+    return occluded(P, o, 1e-3f, d, 1e30f, false, pend);
+#endif
+}
+
+// Shading of one sample on one lane: both halves back to back.
+template <class Pending>
+F3D_HD SampleOut sample_shade(const FrameParams &P, const FrameHead &h, const PrimaryHit &ph, uint32_t &rng,
+                              Pending &pend) {
+    SampleOut o;
+    const IblRay q = sample_shade_sun(P, h, ph, rng, o, pend);
+    if (q.valid) o.b = q.b0 * (ibl_occluded(P, q.o, q.d, pend) ? 0.0f : 1.0f);
     return o;
 }
 

@@ -34,9 +34,21 @@ struct ArrayPending {
             if (!log->empty()) log->back().kind = (log->back().kind & 0xFFu) | (log->back().steps << 8);
         } else if (!log->empty()) {
             RayLog &r = log->back();
-            if (kind == 1 && r.steps < 64u) r.leaf_mask |= 1ull << r.steps;
+            if (kind == 1 && r.steps < 32u) r.leaf_mask |= 1ull << r.steps;
             r.steps++;
         }
+    }
+    // statistics: a per-ray feature (e.g. the direction's elevation) for scheduling models, kept in leaf_mask's
+    // upper half (tools/march_model.py)
+    float hinted = NAN;  // a feature supplied by the shading code for the NEXT ray (overrides the march's own)
+    void hint(float f) { hinted = f; }
+    void feature(float f) {
+        if (!log || log->empty()) return;
+        if (hinted == hinted) f = hinted;
+        hinted = NAN;
+        uint32_t bits;
+        memcpy(&bits, &f, 4);
+        log->back().leaf_mask = (log->back().leaf_mask & 0xFFFFFFFFull) | ((uint64_t)bits << 32);
     }
     bool leaf_gate(bool) const { return true; }  // one lane at a time: the gate is always open
     // deferred leaf FIFO of the march: a single lane drains only when its FIFO is full or its march

@@ -407,6 +407,102 @@ def walkout_model(rows="480:608"):
     print(f"  total wave iterations {base.sum():.0f} -> {cut.sum():.0f} = {base.sum() / cut.sum():.3f}x fewer with a perfect certificate")
 
 
+def sorted_groups_model(rows="480:608"):
+    """Upper bound for re-dealing the IBL (and sun) rays of a WORKGROUP of G waves by predicted length
+    before tracing them: a perfect predictor = sort by the actual step count, then cut into waves."""
+    from emul import emul
+    from forge3d_amd import datasets
+
+    rows = tuple(int(x) for x in rows.split(":"))
+    dem, cam, kw = datasets.rainier_proxy_scene(2048)
+    log = tempfile.mktemp(suffix=".raylog")
+    os.environ["F3D_EMUL_RAYLOG"] = log
+    emul.render(dem, 1920, 1080, cam, rows=rows, **dict(kw, spp=8, max_frames=2, min_frames=2, variance_threshold=1e30))
+    W, R, spp, pixels = load_log(log)
+    os.unlink(log)
+    S, tw, th = 4, 4, 4
+    for G in (1, 2, 4, 8, 16):
+        tot = np.zeros(3)
+        srt = np.zeros(3)
+        for ty in range(0, R, th):
+            for tx0 in range(0, W, tw * G):
+                per_round = [[[] for _ in range(3)] for _ in range(spp // S)]
+                for g in range(G):
+                    tx = tx0 + g * tw
+                    lanes = [pixels[y * W + x] for y in range(ty, min(ty + th, R)) for x in range(tx, min(tx + tw, W))]
+                    P = np.zeros((len(lanes), spp, 3))
+                    for li, rays in enumerate(lanes):
+                        s = -1
+                        for kind, steps, mask in rays:
+                            kind = int(kind) & 0xFF
+                            if kind == 2:
+                                s += 1
+                            P[li, s, {2: 0, 7: 1}.get(kind, 2)] = steps
+                    for r in range(spp // S):
+                        blk = P[:, r * S:(r + 1) * S, :].reshape(-1, 3)
+                        tot += blk.max(axis=0)
+                        for j in range(3):
+                            per_round[r][j].append(blk[:, j])
+                for r in range(spp // S):
+                    for j in range(3):
+                        allr = np.sort(np.concatenate(per_round[r][j]))[::-1]
+                        srt[j] += sum(allr[i] for i in range(0, len(allr), 64))
+        print(f"  workgroup of {G:2d} waves: shadow {tot[1] / srt[1]:.2f}x ibl {tot[2] / srt[2]:.2f}x fewer iterations; "
+              f"total {tot.sum() / (tot[0] + srt[1] + srt[2]):.3f}x (perfect length predictor)")
+
+
+def predictor_model(rows="480:608", want_kind=3):
+    """Like sorted_groups_model, but the rays of a workgroup are sorted by a feature known BEFORE tracing
+    (the direction's elevation d.y, logged by the emulator) instead of by their true length."""
+    from emul import emul
+    from forge3d_amd import datasets
+
+    rows = tuple(int(x) for x in rows.split(":"))
+    dem, cam, kw = datasets.rainier_proxy_scene(2048)
+    log = tempfile.mktemp(suffix=".raylog")
+    os.environ["F3D_EMUL_RAYLOG"] = log
+    emul.render(dem, 1920, 1080, cam, rows=rows, **dict(kw, spp=8, max_frames=2, min_frames=2, variance_threshold=1e30))
+    W, R, spp, pixels = load_log(log)
+    os.unlink(log)
+    S, tw, th = 4, 4, 4
+    feats, lens = [], []
+    for G in (4, 8, 16):
+        tot = srt = per = 0.0
+        for ty in range(0, R, th):
+            for tx0 in range(0, W, tw * G):
+                for r in range(spp // S):
+                    steps, feat = [], []
+                    for g in range(G):
+                        tx = tx0 + g * tw
+                        wave_steps = []
+                        for y in range(ty, min(ty + th, R)):
+                            for x in range(tx, min(tx + tw, W)):
+                                s = -1
+                                for kind, st, mask in pixels[y * W + x]:
+                                    k = int(kind) & 0xFF
+                                    if k == 2:
+                                        s += 1
+                                    elif k == want_kind and r * S <= s < (r + 1) * S:
+                                        wave_steps.append(float(st))
+                                        feat.append(float(np.uint32(int(mask) >> 32).view(np.float32)))
+                        if wave_steps:
+                            tot += max(wave_steps)
+                            steps.extend(wave_steps)
+                    if not steps:
+                        continue
+                    steps, feat = np.asarray(steps), np.asarray(feat)
+                    if G == 4:
+                        feats.append(feat)
+                        lens.append(steps)
+                    by_len = np.sort(steps)[::-1]
+                    by_feat = steps[np.argsort(feat)]  # ascending elevation: grazing rays first
+                    per += sum(by_len[i] for i in range(0, len(by_len), 64))
+                    srt += sum(by_feat[i:i + 64].max() for i in range(0, len(by_feat), 64))
+        print(f"  kind-{want_kind} rays, workgroup of {G:2d} waves: sorted by the feature {tot / srt:.2f}x fewer iterations (perfect predictor {tot / per:.2f}x)")
+    f, l = np.concatenate(feats), np.concatenate(lens)
+    print("  rank correlation of steps with d.y:", float(np.corrcoef(np.argsort(np.argsort(f)), np.argsort(np.argsort(l)))[0, 1]))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[2] == "batched":
         batched_table(sys.argv[1])
@@ -420,5 +516,9 @@ if __name__ == "__main__":
         persistent_model(sys.argv[1])
     elif len(sys.argv) > 2 and sys.argv[2] == "walkout":
         walkout_model(sys.argv[1])
+    elif len(sys.argv) > 2 and sys.argv[2] == "sorted":
+        sorted_groups_model(sys.argv[1])
+    elif len(sys.argv) > 2 and sys.argv[2] == "predictor":
+        predictor_model(sys.argv[1], int(sys.argv[3]) if len(sys.argv) > 3 else 3)
     else:
         main()
