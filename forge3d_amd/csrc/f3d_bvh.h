@@ -20,9 +20,11 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "f3d_scene.h"
@@ -32,6 +34,8 @@ namespace f3d {
 constexpr uint32_t kBvhLeafMax = 4u;    // triangles per leaf (the reference's builder: leaf <= 4)
 constexpr uint32_t kBvhBins = 16u;      // SAH bins per axis
 constexpr float kBvhPadRel = 1e-5f;     // box padding as a fraction of the scene diagonal
+constexpr uint32_t kBvhParallelMin = 20000u;  // triangles from which the build uses worker threads
+constexpr uint32_t kBvhTopDepth = 6u;         // levels split on the calling thread (<= 64 subtree tasks)
 
 struct MeshBvh {
     std::vector<BvhNode> nodes;
@@ -140,7 +144,8 @@ struct Builder {
         return left;
     }
 
-    void emit(uint32_t first, uint32_t count, uint32_t depth = 0u) {
+    // Build the subtree over prims[first, first + count) into `out` (indices local to that arena).
+    void emit(MeshBvh &out, uint32_t first, uint32_t count, uint32_t depth) {
         Box bounds;
         bounds.reset();
         for (uint32_t i = first; i < first + count; i++) bounds.grow(prims[i].box);
@@ -168,8 +173,8 @@ struct Builder {
             }
             leaf = (tri_first << 3) | count;
         } else {
-            emit(first, left, depth + 1u);
-            emit(first + left, count - left, depth + 1u);
+            emit(out, first, left, depth + 1u);
+            emit(out, first + left, count - left, depth + 1u);
         }
         BvhNode &n = out.nodes[me];
         for (int a = 0; a < 3; a++) {
@@ -184,7 +189,8 @@ struct Builder {
 }  // namespace bvh_detail
 
 // verts: xyz per vertex; idx: 3 per triangle, every index < vertex_count (validate_scene).
-inline MeshBvh build_mesh_bvh(const float *verts, uint32_t vertex_count, const uint32_t *idx, uint32_t index_count) {
+inline MeshBvh build_mesh_bvh(const float *verts, uint32_t vertex_count, const uint32_t *idx, uint32_t index_count,
+                              uint32_t parallel_min = kBvhParallelMin) {
     using namespace bvh_detail;
     Builder b;
     b.verts = verts;
@@ -210,9 +216,117 @@ inline MeshBvh build_mesh_bvh(const float *verts, uint32_t vertex_count, const u
     float mag = 0.0f;
     for (int a = 0; a < 3; a++) mag = std::max(mag, std::max(std::fabs(scene.lo[a]), std::fabs(scene.hi[a])));
     b.pad = kBvhPadRel * std::sqrt(dx * dx + dy * dy + dz * dz) + 4e-6f * mag + 1e-30f;
-    b.out.nodes.reserve(2u * b.prims.size());
-    b.out.tris.reserve(12u * b.prims.size());
-    b.emit(0u, (uint32_t)b.prims.size());
+    // Large meshes: the top kBvhTopDepth levels are split on this thread (the splits partition disjoint
+    // ranges of `prims`), the subtrees below are built by a few worker threads into their own arenas
+    // and spliced into preorder afterwards (`skip` links and triangle offsets shifted).  The result does
+    // not depend on the number of threads.
+    const uint32_t total = (uint32_t)b.prims.size();
+#ifdef F3D_BVH_TIMING
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_mark = now();
+    auto lap = [&](const char *what) { double t = now(); fprintf(stderr, "  bvh %-10s %.3f s\n", what, t - t_mark); t_mark = t; };
+    lap("prims");
+#else
+    auto lap = [](const char *) {};
+#endif
+    if (total < parallel_min) {
+        b.out.nodes.reserve(2u * (size_t)total);
+        b.out.tris.reserve(12u * (size_t)total);
+        b.emit(b.out, 0u, total, 0u);
+        return b.out;
+    }
+    struct Top {
+        uint32_t first, count, left;  // left == 0: a subtree task (index in `task`)
+        uint32_t task;
+    };
+    std::vector<Top> tops;       // preorder of the top part
+    std::vector<MeshBvh> arenas;  // one per subtree task
+    {
+        struct Item {
+            uint32_t first, count, depth;
+        };
+        std::vector<Item> stack{{0u, total, 0u}};
+        while (!stack.empty()) {  // depth-first, left child first == preorder
+            const Item it = stack.back();
+            stack.pop_back();
+            if (it.depth >= kBvhTopDepth || it.count <= 4u * kBvhLeafMax) {
+                tops.push_back(Top{it.first, it.count, 0u, (uint32_t)arenas.size()});
+                arenas.emplace_back();
+                continue;
+            }
+            const uint32_t left = b.split(it.first, it.count);
+            tops.push_back(Top{it.first, it.count, left, 0u});
+            stack.push_back(Item{it.first + left, it.count - left, it.depth + 1u});
+            stack.push_back(Item{it.first, left, it.depth + 1u});
+        }
+    }
+    lap("top");
+    {
+        std::vector<uint32_t> jobs;
+        for (uint32_t i = 0; i < (uint32_t)tops.size(); i++)
+            if (tops[i].left == 0u) jobs.push_back(i);
+        std::atomic<uint32_t> next{0u};
+        auto work = [&]() {
+            for (;;) {
+                const uint32_t j = next.fetch_add(1u);
+                if (j >= (uint32_t)jobs.size()) break;
+                const Top &t = tops[jobs[j]];
+                MeshBvh &arena = arenas[t.task];
+                arena.nodes.reserve(2u * (size_t)t.count);
+                arena.tris.reserve(12u * (size_t)t.count);
+                b.emit(arena, t.first, t.count, kBvhTopDepth);
+            }
+        };
+        const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+        const uint32_t nthreads = std::min<uint32_t>(std::min<uint32_t>(hw, 32u), (uint32_t)jobs.size());
+        std::vector<std::thread> pool;
+        for (uint32_t i = 1; i < nthreads; i++) pool.emplace_back(work);
+        work();
+        for (auto &th : pool) th.join();
+    }
+    lap("subtrees");
+    // splice: walk the top part in preorder again
+    b.out.nodes.reserve(2u * (size_t)total);
+    b.out.tris.reserve(12u * (size_t)total);
+    struct Frame {
+        uint32_t top, node, pending;  // index in tops, node index in out, children still to finish
+    };
+    std::vector<Frame> open;
+    auto close_finished = [&]() {
+        while (!open.empty() && open.back().pending == 0u) {
+            BvhNode &n = b.out.nodes[open.back().node];
+            n.skip = (uint32_t)b.out.nodes.size();
+            // box of an inner top node = union of its children's (already padded) boxes
+            const BvhNode &l = b.out.nodes[open.back().node + 1u];
+            const BvhNode &r = b.out.nodes[l.skip];
+            for (int a = 0; a < 3; a++) {
+                n.bmin[a] = std::min(l.bmin[a], r.bmin[a]);
+                n.bmax[a] = std::max(l.bmax[a], r.bmax[a]);
+            }
+            n.leaf = 0u;
+            open.pop_back();
+            if (!open.empty()) open.back().pending--;
+        }
+    };
+    for (uint32_t i = 0; i < (uint32_t)tops.size(); i++) {
+        const Top &t = tops[i];
+        if (t.left != 0u) {
+            open.push_back(Frame{i, (uint32_t)b.out.nodes.size(), 2u});
+            b.out.nodes.push_back(BvhNode{});
+            continue;
+        }
+        const MeshBvh &arena = arenas[t.task];
+        const uint32_t node0 = (uint32_t)b.out.nodes.size(), tri0 = (uint32_t)(b.out.tris.size() / 12u);
+        for (BvhNode n : arena.nodes) {
+            n.skip += node0;
+            if (n.leaf != 0u) n.leaf = (((n.leaf >> 3) + tri0) << 3) | (n.leaf & 7u);
+            b.out.nodes.push_back(n);
+        }
+        b.out.tris.insert(b.out.tris.end(), arena.tris.begin(), arena.tris.end());
+        if (!open.empty()) open.back().pending--;
+        close_finished();
+    }
+    lap("splice");
     return b.out;
 }
 

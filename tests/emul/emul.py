@@ -106,6 +106,19 @@ def terrain_trace_batch(heights, rays, *, origin=(0.0, 0.0), spacing=(1.0, 1.0),
     return {"hit": hit, "t": t, "normal": nrm}
 
 
+def bvh_fingerprint(vertices, indices, threaded: bool):
+    """(FNV-1a of the node + triangle arrays, node count) of the mesh BVH, built on one thread or with
+    the worker threads of the large-mesh path (forced on for any size)."""
+    v = np.ascontiguousarray(vertices, np.float32)
+    i = np.ascontiguousarray(indices, np.uint32)
+    fn = lib().emul_bvh_fingerprint
+    fn.restype = C.c_uint64
+    fn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p]
+    n = C.c_uint32(0)
+    h = fn(v.ctypes.data, v.shape[0], i.ctypes.data, i.size, 1 if threaded else 0, C.addressof(n))
+    return int(h), int(n.value)
+
+
 def build_minmax_mips(heights):
     dem = np.ascontiguousarray(heights, np.float32)
     h, w = dem.shape

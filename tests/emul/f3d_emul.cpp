@@ -493,6 +493,20 @@ int emul_session_resolve(void *h, uint32_t frames, uint8_t *rgba, float *albedo,
 void emul_session_destroy(void *h) { delete (EmulSession *)h; }
 
 void emul_set_use_bvh(int32_t on) { g_use_bvh = on != 0; }
+// FNV-1a over the node and triangle arrays of the mesh BVH built with / without worker threads
+uint64_t emul_bvh_fingerprint(const float *verts, uint32_t nverts, const uint32_t *idx, uint32_t nidx, int32_t parallel,
+                              uint32_t *node_count) {
+    const MeshBvh bvh = build_mesh_bvh(verts, nverts, idx, nidx, parallel ? 1u : 0xFFFFFFFFu);
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t n) {
+        const unsigned char *b = (const unsigned char *)p;
+        for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 1099511628211ull;
+    };
+    mix(bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode));
+    mix(bvh.tris.data(), bvh.tris.size() * sizeof(float));
+    if (node_count) *node_count = (uint32_t)bvh.nodes.size();
+    return h;
+}
 // sample lanes of the frame emulation (1 = frame_pixel; 2, 4, 8 = the frame_lanes mirror)
 void emul_set_sample_lanes(uint32_t lanes) { g_sample_lanes = (lanes == 2u || lanes == 4u || lanes == 8u) ? lanes : 1u; }
 uint64_t emul_take_retraces() {

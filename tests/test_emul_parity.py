@@ -84,6 +84,17 @@ def test_mesh_bvh_reproduces_the_reference_sweep(seed, lanes):
     assert int((want["albedo"][..., 2] > 0.7).sum()) > 2000  # the mesh is really in view
 
 
+def test_threaded_bvh_build_equals_the_single_thread_build():
+    """Large meshes are built by worker threads (top levels split on the caller, subtrees in their own
+    arenas, spliced into preorder): the arrays must be the single-thread build's, byte for byte."""
+    from forge3d_amd import datasets
+
+    dem = scenes.golden_dem()
+    for boxes in (3, 40, 2500):
+        v, i = datasets.proxy_buildings(dem, 1.0, n_boxes=boxes, seed=boxes)
+        assert emul.bvh_fingerprint(v, i, True) == emul.bvh_fingerprint(v, i, False)
+
+
 def test_env_map_and_ragged_dem():
     dem = scenes.golden_dem(2)[:37, :100].copy()
     env = np.random.default_rng(5).uniform(0.1, 2.0, size=(16, 32, 3)).astype(np.float32)

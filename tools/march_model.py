@@ -503,6 +503,59 @@ def predictor_model(rows="480:608", want_kind=3):
     print("  rank correlation of steps with d.y:", float(np.corrcoef(np.argsort(np.argsort(f)), np.argsort(np.argsort(l)))[0, 1]))
 
 
+def pairing_model(rows="480:608"):
+    """Static pairing inside a wave: the G most grazing IBL rays (lowest cos(normal, ray), known before
+    tracing) are cut in two, the far half goes to the lane with the G-th steepest ray, which traces it
+    after its own.  Assumes the cut halves the steps (+ `ov` steps per segment).  Needs an emulator built
+    with -DF3D_MODEL_HINT="dot(n,ei)"."""
+    from emul import emul
+    from forge3d_amd import datasets
+
+    rows = tuple(int(x) for x in rows.split(":"))
+    dem, cam, kw = datasets.rainier_proxy_scene(2048)
+    log = tempfile.mktemp(suffix=".raylog")
+    os.environ["F3D_EMUL_RAYLOG"] = log
+    emul.render(dem, 1920, 1080, cam, rows=rows, **dict(kw, spp=8, max_frames=2, min_frames=2, variance_threshold=1e30))
+    W, R, spp, pixels = load_log(log)
+    os.unlink(log)
+    S, tw, th = 4, 4, 4
+    base = 0.0
+    alt = {(G, ov, parts): 0.0 for G in (4, 8, 16, 24) for ov in (3, 6) for parts in (2, 3)}
+    for ty in range(0, R, th):
+        for tx in range(0, W, tw):
+            for r in range(spp // S):
+                steps, key = [], []
+                for y in range(ty, min(ty + th, R)):
+                    for x in range(tx, min(tx + tw, W)):
+                        s = -1
+                        for kind, st, mask in pixels[y * W + x]:
+                            k = int(kind) & 0xFF
+                            if k == 2:
+                                s += 1
+                            elif k == 3 and r * S <= s < (r + 1) * S:
+                                steps.append(float(st))
+                                key.append(float(np.uint32(int(mask) >> 32).view(np.float32)))
+                if not steps:
+                    continue
+                steps, key = np.asarray(steps), np.asarray(key)
+                base += steps.max()
+                order = np.argsort(key)  # grazing first
+                n = len(steps)
+                for (G, ov, parts), _ in alt.items():
+                    g = min(G, n // (parts if parts > 1 else 2))
+                    t = steps.copy()
+                    for i in range(g):
+                        donor = order[i]
+                        piece = steps[donor] / parts + ov
+                        t[donor] = piece
+                        for p in range(1, parts):
+                            helper = order[n - 1 - (i * (parts - 1) + (p - 1))]
+                            t[helper] = t[helper] + piece
+                    alt[(G, ov, parts)] += t.max()
+    for (G, ov, parts), v in alt.items():
+        print(f"  {G:2d} donors cut in {parts}, overhead {ov}: IBL wave iterations {base / v:.2f}x fewer")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[2] == "batched":
         batched_table(sys.argv[1])
@@ -520,5 +573,7 @@ if __name__ == "__main__":
         sorted_groups_model(sys.argv[1])
     elif len(sys.argv) > 2 and sys.argv[2] == "predictor":
         predictor_model(sys.argv[1], int(sys.argv[3]) if len(sys.argv) > 3 else 3)
+    elif len(sys.argv) > 2 and sys.argv[2] == "pairing":
+        pairing_model(sys.argv[1])
     else:
         main()
