@@ -457,6 +457,34 @@ def test_strips_reproduce_the_full_image(f3d):
         s.close()
 
 
+def test_maximum_dem_size_matches_the_oracle(f3d, oracle):
+    """The largest heightfield the reference accepts (8193 texels per side = 8192 cells, the 13-bit node
+    packing of hybrid_terrain_traversal.wgsl:143-146): 14 levels, 67 M cells, ~2 GB of tables -- index
+    arithmetic, table build and traversal against the oracle on a small image."""
+    n = 8193
+    t = np.arange(n, dtype=np.float32)
+    dem = (900.0 + 600.0 * np.sin(t * 0.0031)[None, :] * np.cos(t * 0.0017)[:, None]
+           + 40.0 * np.sin(t * 0.09)[:, None] * np.sin(t * 0.11)[None, :]).astype(np.float32)
+    span = (n - 1) * 5.0
+    cam = {"origin": (0.35 * span, 2600.0, 0.42 * span), "look_at": (0.0, 700.0, 0.0), "up": (0.0, 1.0, 0.0),
+           "fov_y": 50.0, "exposure": 1.0}
+    kw = dict(spacing=(5.0, 5.0), exaggeration=1.0, sun_azimuth_deg=200.0, sun_elevation_deg=18.0, spp=2, max_frames=2,
+              min_frames=2, variance_threshold=1e30)
+    want = oracle.render(dem, 48, 40, cam, **kw)
+    from forge3d_amd.session import TerrainSession
+
+    with TerrainSession(dem, 48, 40, cam, memory_budget_bytes=8 << 30, **kw) as s:
+        s.enqueue_frames(0, 2, True)
+        m2, bad = s.window_stats()
+        got = s.resolve(2)
+        assert s.info()["minmax_pyramid_bytes"] > 1_500_000_000
+    assert not bad and np.isfinite(want["depth"]).mean() > 0.3
+    for key in ("rgba", "albedo", "normal", "depth"):
+        assert np.array_equal(got[key], want[key], equal_nan=True), key
+    with pytest.raises(RuntimeError, match="8193"):
+        f3d.hybrid_render_terrain_reference(np.zeros((4, 8194), np.float32), 8, 8, cam, **kw)
+
+
 def test_full_size_properties(f3d):
     """BASELINE.json config 2 size (1920x1080, 8 spp) on the proxy DEM: determinism,
     frame-additivity of the accumulation, finite outputs, AOV/hit-mask consistency."""
