@@ -277,14 +277,18 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
     hip_check(launch_gbuffer(P, s.gbuffer_n, s.depth, s.stream), "g-buffer pass");
 }
 
-void enqueue_frame(f3d_session &s, uint32_t frame, bool collect) {
+// part: 0 the whole strip; 1 frame head + the strip's edge tile rows; 2 the interior (after part 1)
+void enqueue_frame(f3d_session &s, uint32_t frame, bool collect, uint32_t part = 0u) {
     FrameParams &P = s.params;
     P.frame_index = frame;
     P.res_out = s.res[frame & 1u];
     P.res_in = s.res[(frame & 1u) ^ 1u];
     P.collect_stats = collect ? 1u : 0u;
-    if (collect) hip_check(hipMemsetAsync(s.stats, 0, 2 * sizeof(uint32_t), s.stream), "stats clear");
-    if (P.sample_lanes > 1u) hip_check(launch_head(P, s.stream), "frame head kernel");
+    P.part = part;
+    if (part != 2u) {
+        if (collect) hip_check(hipMemsetAsync(s.stats, 0, 2 * sizeof(uint32_t), s.stream), "stats clear");
+        if (P.sample_lanes > 1u) hip_check(launch_head(P, s.stream), "frame head kernel");
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (s.timing) {
         hip_check(hipEventCreate(&e0), "event");
@@ -296,6 +300,7 @@ void enqueue_frame(f3d_session &s, uint32_t frame, bool collect) {
         hip_check(hipEventRecord(e1, s.stream), "event record");
         s.events.emplace_back(e0, e1);
     }
+    P.part = 0u;
 }
 
 bool closes_window(uint32_t frame, uint32_t max_frames) {
@@ -349,6 +354,17 @@ int f3d_session_enqueue_frames(f3d_session *s, uint32_t first_frame, uint32_t co
     try {
         for (uint32_t i = 0; i < count; i++)
             enqueue_frame(*s, first_frame + i, collect_stats_on_last != 0 && i + 1 == count);
+    } catch (const Failure &f) {
+        return report(f, err, errlen);
+    }
+    return F3D_STATUS_OK;
+}
+
+int f3d_session_enqueue_frame_part(f3d_session *s, uint32_t frame, uint32_t part, int32_t collect_stats, char *err,
+                                   size_t errlen) {
+    try {
+        if (!s || (part != 1u && part != 2u)) fail(F3D_STATUS_VALUE, "frame part must be 1 (edge rows) or 2 (interior)");
+        enqueue_frame(*s, frame, collect_stats != 0, part);
     } catch (const Failure &f) {
         return report(f, err, errlen);
     }

@@ -216,11 +216,13 @@ class StripRenderer:
         w = self.width * RES_BYTES
         return self.res[which][first * w:(first + HALO_ROWS) * w]
 
-    def exchange_halos(self, which: int):
-        """Send my edge rows of reservoir buffer `which` to the strip neighbours and
-        receive theirs into my halo rows (point-to-point over the direct xGMI link)."""
+    def start_halo_exchange(self, which: int):
+        """Post the sends of my edge rows of reservoir buffer `which` and the receives into my halo rows
+        (point-to-point over the direct xGMI link); returns what finish_halo_exchange needs.  With RCCL
+        the transfers run on its own stream, ordered after the work already enqueued on the session's
+        stream -- i.e. after the EDGE rows of the frame -- and overlap what is enqueued next."""
         if self.world == 1:
-            return
+            return None
         import torch.distributed as dist
 
         staged = self._comm_device() != self.res[0].device
@@ -242,11 +244,21 @@ class StripRenderer:
         if self.rank < self.world - 1:
             send(self.rows, self.rank + 1)
             recv(self.rows + HALO_ROWS, self.rank + 1)
-        for work in dist.batch_isend_irecv(ops):
+        return dist.batch_isend_irecv(ops), landed, staged
+
+    def finish_halo_exchange(self, pending):
+        """Make the session's stream wait for the halos (before the next frame's head reads them)."""
+        if pending is None:
+            return
+        works, landed, staged = pending
+        for work in works:
             work.wait()
         if staged:
             for rows, box in landed:
                 rows.copy_(box)
+
+    def exchange_halos(self, which: int):
+        self.finish_halo_exchange(self.start_halo_exchange(which))
 
     def barrier(self):
         if self.world > 1:
@@ -265,13 +277,18 @@ class StripRenderer:
 
     # -- rendering ----------------------------------------------------------------------
     def run_frames(self, first: int, count: int, collect_last: bool = False):
-        """Enqueue `count` accumulation frames; strips exchange halos after every frame."""
+        """Enqueue `count` accumulation frames.  Strips render each frame in two launches -- the edge
+        rows (the neighbours' halos) first, then the interior -- and exchange the halos in between, so
+        that the transfer overlaps the interior; the next frame waits for the halos only."""
         if self.world == 1:
             self.session.enqueue_frames(first, count, collect_last)
             return
         for f in range(first, first + count):
-            self.session.enqueue_frames(f, 1, collect_last and f + 1 == first + count)
-            self.exchange_halos(f & 1)
+            collect = collect_last and f + 1 == first + count
+            self.session.enqueue_frame_part(f, 1, collect)
+            pending = self.start_halo_exchange(f & 1)
+            self.session.enqueue_frame_part(f, 2, collect)
+            self.finish_halo_exchange(pending)
 
     def window_variance(self, frames: int):
         """Variance gate of render_terrain.rs:1206-1231 across all strips."""

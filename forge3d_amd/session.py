@@ -84,6 +84,11 @@ class TerrainSession:
         self._check(self._lib.f3d_session_enqueue_frames(self._handle, int(first_frame), int(count),
                                                          1 if collect_stats else 0, self._err, len(self._err)))
 
+    def enqueue_frame_part(self, frame: int, part: int, collect_stats: bool = False):
+        """One frame in two launches: part 1 = head + the strip's edge rows (the halo donors), part 2 = interior."""
+        self._check(self._lib.f3d_session_enqueue_frame_part(self._handle, int(frame), int(part),
+                                                             1 if collect_stats else 0, self._err, len(self._err)))
+
     def window_stats(self):
         """(max Welford m2 over the owned pixels, saw non-finite) -- synchronises the stream."""
         m2, bad = C.c_float(0.0), C.c_int32(0)

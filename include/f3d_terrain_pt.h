@@ -132,6 +132,12 @@ void f3d_session_destroy(f3d_session *session);
  * convergence statistic read by f3d_session_window_stats. */
 int f3d_session_enqueue_frames(f3d_session *session, uint32_t first_frame, uint32_t count,
                                int32_t collect_stats_on_last, char *err, size_t errlen);
+/* One frame in two launches, for strips of a multi-GPU job: part 1 = frame head + the strip's EDGE tile
+ * rows (they contain the first and last 3 pixel rows, the halo a neighbouring strip needs), part 2 = the
+ * interior.  The caller starts the halo exchange between the two, so that it overlaps the interior.
+ * Same result as f3d_session_enqueue_frames(frame, 1). */
+int f3d_session_enqueue_frame_part(f3d_session *session, uint32_t frame, uint32_t part, int32_t collect_stats,
+                                   char *err, size_t errlen);
 /* Variance gate input for the window that ends after `frames` frames
  * (render_terrain.rs:1206-1231): synchronises the stream, returns max m2 over the
  * owned pixels (NOT yet divided by n-1) and whether a non-finite m2 was seen. */

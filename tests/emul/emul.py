@@ -149,6 +149,10 @@ class _EmulStripSession:
             L.emul_session_frame(C.c_void_p(self._h), C.c_uint32(first + i), C.c_int32(1 if last else 0),
                                  C.c_void_p(self._stats.data_ptr()))
 
+    def enqueue_frame_part(self, frame, part, collect=False):
+        lib().emul_session_frame_part(C.c_void_p(self._h), C.c_uint32(frame), C.c_uint32(part),
+                                      C.c_int32(1 if collect else 0), C.c_void_p(self._stats.data_ptr()))
+
     def window_stats(self):
         host = self._stats.numpy().astype(np.uint32)
         return float(host[:1].view(np.float32)[0]), bool(host[1])

@@ -454,16 +454,22 @@ void *emul_session_create(const f3d_terrain_ref_desc *d, uint32_t row_begin, uin
     return s;
 }
 
-// one frame; stats[0] = max m2 bits, stats[1] = nonfinite (same record as the device writes)
-void emul_session_frame(void *h, uint32_t frame, int32_t collect, uint32_t *stats) {
+// one frame (part 0), or its edge rows (part 1: the first and last kHaloRows pixel rows, what a neighbouring
+// strip needs as halo) / the interior (part 2, after part 1); stats[0] = max m2 bits, stats[1] = nonfinite
+// (same record as the device writes; part 2 merges into what part 1 left)
+void emul_session_frame_part(void *h, uint32_t frame, uint32_t part, int32_t collect, uint32_t *stats) {
     EmulSession *s = (EmulSession *)h;
     FrameParams &P = s->P;
     P.frame_index = frame;
     P.res_out = s->res[frame & 1u];
     P.res_in = s->res[(frame & 1u) ^ 1u];
+    const uint32_t rows = P.row_end - P.row_begin;
     float vmax = 0.0f;
     bool bad = false;
     for (uint32_t y = P.row_begin; y < P.row_end; y++) {
+        const uint32_t r = y - P.row_begin;
+        const bool edge = rows <= 2u * kHaloRows || r < kHaloRows || r + kHaloRows >= rows;
+        if ((part == 1u && !edge) || (part == 2u && edge)) continue;
         ArrayPending pend;
         for (uint32_t x = 0; x < s->width; x++) {
             const float v = frame_pixel_any(P, x, y, pend);
@@ -472,9 +478,18 @@ void emul_session_frame(void *h, uint32_t frame, int32_t collect, uint32_t *stat
         }
     }
     if (collect && stats) {
-        stats[0] = f_bits(vmax);
-        stats[1] = bad ? 1u : 0u;
+        if (part == 2u) {
+            stats[0] = f_bits(f_max(f_from_bits(stats[0]), vmax));
+            stats[1] |= bad ? 1u : 0u;
+        } else {
+            stats[0] = f_bits(vmax);
+            stats[1] = bad ? 1u : 0u;
+        }
     }
+}
+
+void emul_session_frame(void *h, uint32_t frame, int32_t collect, uint32_t *stats) {
+    emul_session_frame_part(h, frame, 0u, collect, stats);
 }
 
 int emul_session_resolve(void *h, uint32_t frames, uint8_t *rgba, float *albedo, float *normal, float *depth,

@@ -457,6 +457,32 @@ def test_strips_reproduce_the_full_image(f3d):
         s.close()
 
 
+@pytest.mark.parametrize("variant,rows", [(0, (0, 0)), (1000000, (0, 0)), (8000000, (16, 61)), (4000000, (7, 12)),
+                                          (2000000, (30, 33))])
+def test_frame_in_two_parts_equals_the_whole_frame(f3d, variant, rows):
+    """f3d_session_enqueue_frame_part: edge rows first (the halo donors of a multi-GPU strip), then the
+    interior -- same reservoirs, accumulation, statistics and image as one launch, for every tile shape,
+    for strips whose height is not a multiple of the tile height and for strips without an interior."""
+    from forge3d_amd.session import TerrainSession
+
+    dem = scenes.golden_dem()
+    kw = scenes.fixed_frames(scenes.scene_kwargs(dem), 4, spp=8)
+    opts = dict(kernel_variant=variant, row_begin=rows[0], row_end=rows[1])
+    with TerrainSession(dem, 150, 97, scenes.CAM, **opts, **kw) as s:
+        s.enqueue_frames(0, 4, True)
+        m2, bad = s.window_stats()
+        want = s.resolve(4)
+    with TerrainSession(dem, 150, 97, scenes.CAM, **opts, **kw) as s:
+        for f in range(4):
+            s.enqueue_frame_part(f, 1, f == 3)
+            s.enqueue_frame_part(f, 2, f == 3)
+        m2b, badb = s.window_stats()
+        got = s.resolve(4)
+    assert (m2, bad) == (m2b, badb)
+    for key in ("rgba", "albedo", "normal", "depth"):
+        assert np.array_equal(got[key], want[key], equal_nan=True), key
+
+
 def test_maximum_dem_size_matches_the_oracle(f3d, oracle):
     """The largest heightfield the reference accepts (8193 texels per side = 8192 cells, the 13-bit node
     packing of hybrid_terrain_traversal.wgsl:143-146): 14 levels, 67 M cells, ~2 GB of tables -- index
