@@ -116,7 +116,7 @@ def box_city(n_boxes: int = 120, seed: int = 7, span: float = SPAN, base: float 
         cx, cz = rng.uniform(-0.45 * span, 0.45 * span, 2)
         w, d = rng.uniform(1.0, 5.0, 2)
         h0 = base + rng.uniform(0.0, 6.0)
-        h1 = h0 + rng.uniform(2.0, top)
+        h1 = h0 + rng.uniform(min(2.0, 0.5 * top), max(top, 1e-3))
         o = len(verts)
         for y in (h0, h1):
             for dx, dz in ((-w, -d), (w, -d), (w, d), (-w, d)):
@@ -135,3 +135,47 @@ def box_city(n_boxes: int = 120, seed: int = 7, span: float = SPAN, base: float 
     verts += [(1.0, 20.0, 1.0), (2.0, 20.0, 2.0), (3.0, 20.0, 3.0)]  # collinear: rejected by |a| < 1e-7
     tris.append((o, o + 1, o + 2))
     return np.asarray(verts, np.float32), np.asarray(tris, np.uint32)
+
+
+def random_scene(seed: int):
+    """A seeded random small scene for fuzzing parity: ragged DEM with terraces (exactly flat areas
+    and exact height ties), random camera / sun / earth model / spp / optional mesh and env map."""
+    rng = np.random.default_rng(seed)
+    h, w = int(rng.integers(9, 90)), int(rng.integers(9, 90))
+    yy, xx = np.mgrid[0:h, 0:w]
+    dem = np.zeros((h, w))
+    for octave in range(4):
+        f = 2.0 ** octave / 24.0
+        dem += rng.uniform(0.3, 1.0) / 2 ** octave * np.sin(xx * f * rng.uniform(0.5, 2) + rng.uniform(0, 6)) \
+            * np.cos(yy * f * rng.uniform(0.5, 2) + rng.uniform(0, 6))
+    dem = dem - dem.min()
+    if rng.random() < 0.5:
+        dem = np.round(dem * 6) / 6  # terraces: flat cells, equal corner heights, exact min == max bands
+    dem = dem.astype(np.float32)
+    spacing = float(rng.choice([0.5, 1.0, 7.5, 30.0]))
+    relief = float(rng.uniform(0.05, 0.6)) * spacing * max(h, w)
+    span = spacing * max(h, w)
+    ang = rng.uniform(0, 2 * np.pi)
+    dist = rng.uniform(0.2, 1.4) * span
+    cam = {"origin": (float(np.cos(ang) * dist), float(relief * rng.uniform(0.3, 2.5)), float(np.sin(ang) * dist)),
+           "look_at": (float(rng.uniform(-0.2, 0.2) * span), float(relief * rng.uniform(0.0, 0.6)),
+                       float(rng.uniform(-0.2, 0.2) * span)),
+           "up": (0.0, 1.0, 0.0), "fov_y": float(rng.uniform(25, 80)), "exposure": float(rng.uniform(0.5, 2.0))}
+    spp = int(rng.choice([1, 2, 3, 4, 5, 8, 11, 16]))
+    kw = dict(spacing=(spacing, spacing * float(rng.choice([1.0, 1.0, 1.3]))), exaggeration=relief / max(float(dem.max()), 1e-6),
+              albedo=tuple(float(x) for x in rng.uniform(0.2, 0.9, 3)), sun_azimuth_deg=float(rng.uniform(0, 360)),
+              sun_elevation_deg=float(rng.uniform(2, 85)), sun_intensity=float(rng.uniform(0.5, 4)),
+              env_intensity=float(rng.uniform(0.1, 0.8)), seed=int(rng.integers(0, 2 ** 31)), spp=spp,
+              earth_model=str(rng.choice(["ellipsoid", "sphere", "flat"])),
+              refraction_model=str(rng.choice(["bennett", "none"])))
+    if kw["earth_model"] == "flat":
+        kw["refraction_model"] = "none"  # the only combination the reference accepts
+    frames = int(rng.choice([2, 3, 5]))
+    kw = fixed_frames(kw, frames)
+    if rng.random() < 0.3:
+        kw["env_map"] = rng.uniform(0.05, 2.0, size=(int(rng.integers(2, 9)), int(rng.integers(2, 17)), 3)).astype(np.float32)
+    if rng.random() < 0.35:
+        v, i = box_city(n_boxes=int(rng.integers(1, 25)), seed=seed, span=0.8 * span, base=0.0, top=relief)
+        kw["mesh_vertices"], kw["mesh_indices"] = v, i
+    size = (int(rng.integers(17, 120)), int(rng.integers(17, 100)))
+    return dem, size, cam, kw

@@ -95,6 +95,21 @@ def test_threaded_bvh_build_equals_the_single_thread_build():
         assert emul.bvh_fingerprint(v, i, True) == emul.bvh_fingerprint(v, i, False)
 
 
+@pytest.mark.parametrize("seed", list(range(100, 112)) + [1179])
+def test_random_scenes_match_the_oracle(seed):
+    """Fuzz (the GPU suite runs more seeds): random ragged / terraced DEMs, cameras, suns, models, meshes."""
+    dem, size, cam, kw = scenes.random_scene(seed)
+    lanes = [1, 2, 4, 8][seed % 4]
+    try:
+        want = oracle.render(dem, size[0], size[1], cam, **kw)
+    except RuntimeError as exc:  # seed 1179: the render itself is an error ("no valid reservoirs ...")
+        with pytest.raises(RuntimeError, match="no valid reservoirs"):
+            emul.render(dem, size[0], size[1], cam, sample_lanes=lanes, **kw)
+        assert "no valid reservoirs" in str(exc)
+        return
+    _same(emul.render(dem, size[0], size[1], cam, sample_lanes=lanes, **kw), want)
+
+
 def test_env_map_and_ragged_dem():
     dem = scenes.golden_dem(2)[:37, :100].copy()
     env = np.random.default_rng(5).uniform(0.1, 2.0, size=(16, 32, 3)).astype(np.float32)

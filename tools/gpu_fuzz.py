@@ -1,0 +1,40 @@
+#!/usr/bin/env python
+"""Wide parity fuzz on the GPU: N seeded random scenes (tests/scenes.random_scene) through libf3dhip vs
+the oracle, bit for bit (or the same render error).  python tools/gpu_fuzz.py [first_seed] [count]"""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+import forge3d_amd as f3d  # noqa: E402
+import scenes  # noqa: E402
+from oracle import oracle  # noqa: E402  (checker only: this is a test tool)
+
+first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 2000), (int(sys.argv[2]) if len(sys.argv) > 2 else 400)
+bad, errors, t0 = [], 0, time.time()
+for seed in range(first, first + count):
+    dem, size, cam, kw = scenes.random_scene(seed)
+    try:
+        want = oracle.render(dem, size[0], size[1], cam, **kw)
+    except RuntimeError as exc:
+        errors += 1
+        try:
+            f3d.hybrid_render_terrain_reference(dem, size[0], size[1], cam, **kw)
+            bad.append((seed, "oracle raised, GPU did not"))
+        except RuntimeError:
+            pass
+        continue
+    try:
+        got = f3d.hybrid_render_terrain_reference(dem, size[0], size[1], cam, **kw)
+    except RuntimeError as exc:
+        bad.append((seed, f"GPU raised: {str(exc)[:80]}"))
+        continue
+    if not all(np.array_equal(got[k], want[k], equal_nan=True) for k in ("rgba", "albedo", "normal", "depth")) \
+            or got["frames"] != want["frames"] or np.float32(got["variance"]) != np.float32(want["variance"]):
+        bad.append((seed, "image differs"))
+print(f"{count} scenes from seed {first}: {len(bad)} mismatches {bad[:10]}, {errors} render errors on both sides, "
+      f"{time.time() - t0:.1f} s")
