@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """Wide parity fuzz on the GPU: N seeded random scenes (tests/scenes.random_scene) through libf3dhip vs
-the oracle, bit for bit (or the same render error).  python tools/gpu_fuzz.py [first_seed] [count]"""
+the oracle, bit for bit (or the same render error).  python tools/gpu_fuzz.py [first_seed] [count]
+(run with OMP_NUM_THREADS=8: the oracle's OpenMP team of a 128-thread host is slower than 8 threads on
+images this small)."""
 import sys
 import time
 from pathlib import Path
@@ -16,8 +18,11 @@ from oracle import oracle  # noqa: E402  (checker only: this is a test tool)
 
 first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 2000), (int(sys.argv[2]) if len(sys.argv) > 2 else 400)
 bad, errors, t0 = [], 0, time.time()
+log = open(ROOT / "gpurun_out" / "fuzz_progress.log", "a") if (ROOT / "gpurun_out").exists() else None
 for seed in range(first, first + count):
     dem, size, cam, kw = scenes.random_scene(seed)
+    if log:
+        print(seed, round(time.time() - t0, 2), file=log, flush=True)
     try:
         want = oracle.render(dem, size[0], size[1], cam, **kw)
     except RuntimeError as exc:
