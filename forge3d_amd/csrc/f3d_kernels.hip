@@ -85,7 +85,11 @@ __device__ __forceinline__ LdsPending make_pending(uint32_t *lds, const TerrainD
 template <uint32_t S>
 struct TileShape {
     static constexpr uint32_t kLogS = S == 1u ? 0u : (S == 2u ? 1u : (S == 4u ? 2u : 3u));
+#if defined(F3D_TILE_LOGW_S4)  // A/B of the tile shape (profiles/README.md)
+    static constexpr uint32_t kLogW = S <= 2u ? 3u : (S == 4u ? F3D_TILE_LOGW_S4 : 2u);
+#else
     static constexpr uint32_t kLogW = S <= 2u ? 3u : 2u;      // 8, 8, 4, 4 pixels wide
+#endif
     static constexpr uint32_t kLogH = 6u - kLogS - kLogW;     // 8, 4, 4, 2 pixels high
 };
 
@@ -361,7 +365,11 @@ __global__ void k_level_build(const LevelBuildParams B) {
 // ---- launchers ---------------------------------------------------------------------
 static inline uint32_t frame_grid(const FrameParams &p, uint32_t lanes = 1u) {
     const uint32_t log_s = lanes == 1u ? 0u : (lanes == 2u ? 1u : (lanes == 4u ? 2u : 3u));
+#if defined(F3D_TILE_LOGW_S4)
+    const uint32_t log_w = lanes <= 2u ? 3u : (lanes == 4u ? F3D_TILE_LOGW_S4 : 2u), log_h = 6u - log_s - log_w;
+#else
     const uint32_t log_w = lanes <= 2u ? 3u : 2u, log_h = 6u - log_s - log_w;  // TileShape<S>
+#endif
     const uint32_t rows = p.row_end - p.row_begin;
     const uint32_t tiles_x = (p.cam.width + (1u << log_w) - 1u) >> log_w, all_rows = (rows + (1u << log_h) - 1u) >> log_h;
     uint32_t tiles_y = all_rows, top = 0u, bottom_first = all_rows;
