@@ -52,26 +52,32 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline(dem, cam, kw, args):
+def cpu_baseline(dem, cam, kw, args, world=1):
     """Time the CPU oracle (test infrastructure, used here ONLY as the reported baseline) on a
     bounded sample of the same workload: same DEM/camera/sun/spp, resolution and frame count
     sized for ~args.cpu_seconds of CPU work; also returns the per-sample traversal
-    counts that define the algorithmic bytes."""
+    counts that define the algorithmic bytes.  With world > 1 (the baseline is
+    an N = 1 figure) only the two-frame counting run is made, for the roofline of the strip kernel."""
     from oracle import oracle
 
     oracle.build()
+    # torch.distributed.run exports OMP_NUM_THREADS=1 to its workers: give the oracle its share of the host
+    if world > 1 or os.environ.get("OMP_NUM_THREADS") == "1":
+        oracle.set_num_threads(max(1, (os.cpu_count() or 1) // max(1, world)))
     cores = oracle.num_threads()
     k = dict(kw, spp=args.spp, max_frames=2, min_frames=2, variance_threshold=1e30)
     w, h = 240, 135
     probe = oracle.render(dem, w, h, cam, **k)
     rate = probe["n_samples"] / max(probe["loop_seconds"], 1e-9)
-    budget = args.cpu_seconds * rate  # samples the host can trace in the target time
+    budget = (2.0 if world > 1 else args.cpu_seconds) * rate  # samples the host can trace in the target time
     scale = min(args.width / w, max(1.0, (budget / probe["n_samples"]) ** 0.5))
     w2, h2 = min(args.width, int(w * scale) // 8 * 8), min(args.height, int(h * scale) // 8 * 8)
     out = oracle.render(dem, w2, h2, cam, **k)  # 2 frames at the sample's resolution: the real rate
     # the per-sample traversal counts of the roofline always come from these two frames (a fixed definition,
     # independent of how fast the host is)
     counts = {key: out[key] / out["n_samples"] for key in ("n_node", "n_leaf", "n_hit")}
+    if world > 1:
+        return None, counts
     frames = int(min(32, args.cpu_seconds * out["n_samples"] / max(out["loop_seconds"], 1e-9) // (w2 * h2 * args.spp)))
     if frames >= 3:
         k.update(max_frames=frames, min_frames=frames)
@@ -149,7 +155,9 @@ def main():
         counts = None
         if not args.no_cpu_baseline:
             try:
-                result["cpu_baseline"], counts = cpu_baseline(dem, cam, kw, args)
+                baseline, counts = cpu_baseline(dem, cam, kw, args, world)
+                if baseline is not None:  # reported at N = 1 only
+                    result["cpu_baseline"] = baseline
             except Exception as exc:  # the baseline is a report, never a reason to lose the GPU number
                 result["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": 0, "kind": "port",
                                           "sample": f"failed: {exc}"}
@@ -159,7 +167,9 @@ def main():
             b_alg = (STATE_BYTES_PER_PIXEL_FRAME[lanes > 1] / args.spp + 8.0 * counts["n_node"] + 16.0 * counts["n_leaf"]
                      + 16.0 * counts["n_hit"])
             per_launch = b_alg * samples_per_step / world
-            achieved = per_launch / (kernel_ms * 1e-3) / 1e9
+            # strips launch the frame kernel twice per frame (edge rows, interior): price the frame, not the launch
+            frame_kernel_ms = kernel_ms * launches / max(1, args.steps)
+            achieved = per_launch / (frame_kernel_ms * 1e-3) / 1e9
             # HBM bytes per launch from the rocprofv3 PMC passes of the SAME command (committed
             # under profiles/; bench.py cannot run the profiler itself): only quoted when the
             # run matches the profiled configuration.
@@ -174,7 +184,7 @@ def main():
             result["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_frame",
-                "kernel_ms": kernel_ms, "launches": launches, "bytes_per_sample": b_alg, "sample_lanes": lanes,
+                "kernel_ms": frame_kernel_ms, "launches": launches, "bytes_per_sample": b_alg, "sample_lanes": lanes,
                 "per_sample_counts": counts,
             }
         if image is not None:

@@ -1441,3 +1441,12 @@ int f3do_num_threads(void) {
     return 1;
 #endif
 }
+
+/* torch.distributed.run exports OMP_NUM_THREADS=1 to its workers; the benchmark's CPU leg sets its own team. */
+void f3do_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}

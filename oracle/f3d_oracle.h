@@ -129,6 +129,7 @@ float f3do_f16_round(float v);
 void f3do_sincos_2pi(float u, float *s, float *c);
 
 int f3do_num_threads(void);
+void f3do_set_num_threads(int n);
 
 #ifdef __cplusplus
 }

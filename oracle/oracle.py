@@ -328,3 +328,7 @@ def effective_radius_m(earth_model, refraction_model, azimuth_deg, *, latitude_d
 
 def num_threads() -> int:
     return int(lib().f3do_num_threads())
+
+
+def set_num_threads(n: int) -> None:
+    lib().f3do_set_num_threads(C.c_int(int(n)))
