@@ -385,6 +385,17 @@ def test_native_trust_boundary_validation(f3d):
         _native.hybrid_render_terrain_reference(dem, 4096, 4096, dict(scenes.CAM), **base)
 
 
+def test_sun_color_live_control_changes_output(f3d, reference):
+    """reference test_sun_color_live_control_changes_output (:697-709): the same scene under a blue sun."""
+    dem, out_default = reference
+    out_blue = f3d.hybrid_render_terrain_reference(dem, scenes.SIZE, scenes.SIZE, scenes.CAM,
+                                                   **{**scenes.scene_kwargs(dem), "sun_color": (0.2, 0.3, 1.5)})
+    diff = float(np.abs(out_default["rgba"][..., :3].astype(np.float64) - out_blue["rgba"][..., :3].astype(np.float64)).mean())
+    assert diff > 1.0
+    lit = np.isfinite(out_default["depth"])
+    assert out_blue["rgba"][lit][:, 2].mean() > out_blue["rgba"][lit][:, 0].mean()  # and it is blue where the sun reaches
+
+
 def test_zero_sun_color_render_succeeds_and_removes_direct_sun(f3d):
     dem = scenes.golden_dem()
     kw = scenes.fixed_frames(scenes.scene_kwargs(dem), 32)
