@@ -398,6 +398,7 @@ hipError_t launch_frame(const FrameParams &p, int variant, hipStream_t stream) {
             case 4000: hipLaunchKernelGGL((k_frame<0, 6, 4>), grid, block, 0, stream, p); break;
             case 4104: hipLaunchKernelGGL((k_frame<0, 4, 4>), grid, block, 0, stream, p); break;
             case 4105: hipLaunchKernelGGL((k_frame<0, 5, 4>), grid, block, 0, stream, p); break;
+            case 4107: hipLaunchKernelGGL((k_frame<0, 7, 4>), grid, block, 0, stream, p); break;
             case 4108: hipLaunchKernelGGL((k_frame<0, 8, 4>), grid, block, 0, stream, p); break;
             case 8000: hipLaunchKernelGGL((k_frame<0, 6, 8>), grid, block, 0, stream, p); break;
             case 8104: hipLaunchKernelGGL((k_frame<0, 4, 8>), grid, block, 0, stream, p); break;
