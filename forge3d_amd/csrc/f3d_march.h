@@ -108,8 +108,11 @@ F3D_HD MarchState march_begin(const TerrainDev &T, const RayCtx &r, bool start_i
 }
 
 // One march step of a lane: test the current node and move DOWN, or ACROSS (+ UP).
-template <bool CURVED, class Ctx>
-F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint32_t &queued, Ctx &ctx) {
+// SLICED: the lane walks a slice of a ray (march_shared below): nodes entered at or beyond t_stop
+// belong to the next slice.
+template <bool CURVED, bool SLICED, class Ctx>
+F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint32_t &queued, Ctx &ctx,
+                       float t_stop = 3.0e38f) {
     ctx.note(0);
     const uint32_t top = T.mip_count - 1u;
     const uint32_t level = m.level, nx = m.nx, nz = m.nz;
@@ -164,7 +167,8 @@ F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint
             // (cell_w <= 2^13, level <= 15), so one unsigned comparison covers both directions
             const uint32_t qx = nx + ((cross_x && x_forward) ? 1u : 0u) - ((cross_x && !x_forward) ? 1u : 0u);
             const uint32_t qz = nz + ((cross_z && z_forward) ? 1u : 0u) - ((cross_z && !z_forward) ? 1u : 0u);
-            const bool left = !(exit < r.tmax) || (qx << level) >= T.cell_w || (qz << level) >= T.cell_h;
+            const bool left = !(exit < r.tmax) || (SLICED && !(exit < t_stop)) || (qx << level) >= T.cell_w ||
+                              (qz << level) >= T.cell_h;
             // leaving the parent as well: continue one level up (jumping h > 1 levels when the crossing
             // leaves h ancestors was modelled on the emulator's step logs: fewer IBL steps, but more
             // shadow steps and 7-17 % more wave iterations -- tools/march_model.py)
@@ -202,11 +206,96 @@ F3D_HD void march_drain(const TerrainDev &T, const RayCtx &r, bool any_hit, Marc
     queued = 0u;
 }
 
+// ---- the last few rays of a wave, shared by all its lanes -----------------------------------------
+// The step counts of the IBL-occlusion rays are heavy-tailed: in the step logs of the headline frame
+// 31 % of the IBL wave iterations run with ONE lane still marching, 46 % with at most two, 60 % with
+// at most four (tools/march_model.py tail) -- a quarter of the whole frame.  An any-hit answer is the
+// OR over the leaves along the ray, and every node / leaf verdict uses the node's own slab interval
+// clipped by the RAY's (tmin, tmax) only, so a ray can be cut into SLICES walked by different lanes:
+// a slice walks the nodes whose entry parameter is below `stop`, starting at the node of a given level
+// that contains the ray at its `begin` (located from the position and validated by that node's own
+// interval, like the in-cell start of secondary rays; the node that contains a cut is visited by both
+// neighbours, none is skipped).  So when at most kShareBelow (16) lanes of the wave still march, the wave
+// drains its leaf FIFOs and deals every surviving ray over its lanes as slices with geometric boundaries
+// (the steps grow with the distance walked), tagged with the owner's lane; slices that hit mark the
+// owner on a verdict board in LDS; when again only a few slices are left they are dealt again (up to
+// kShareRounds times).  Same measure-zero caveat as the in-cell start: ancestors of a slice's start node
+// are not consulted.  Offered to the rays WITHOUT the curvature policy only, i.e. the IBL rays: their
+// directions differ per lane anyway, whereas the sun rays of a wave share one direction whose constants
+// live in scalar registers as long as the ray is loop-invariant (and their tail is short: 17 % of the
+// shadow iterations run with <= 4 lanes).
+#ifndef F3D_SHARE_BELOW
+#define F3D_SHARE_BELOW 16
+#endif
+#ifndef F3D_SHARE_ROUNDS
+#define F3D_SHARE_ROUNDS 10
+#endif
+#ifndef F3D_SHARE_AVAIL
+#define F3D_SHARE_AVAIL 4
+#endif
+constexpr uint32_t kShareBelow = F3D_SHARE_BELOW, kShareRounds = F3D_SHARE_ROUNDS;
+constexpr uint32_t kShareAvail = F3D_SHARE_AVAIL;  // ... and at least this many lanes of the call per marching ray
+
+// Level-`level` node containing the ray at parameter t (clamped into the grid; the caller validates it).
+F3D_HD void march_locate(const TerrainDev &T, const RayCtx &r, float t, uint32_t level, uint32_t &nx, uint32_t &nz) {
+    const float fx = f_floor((f_fma(t, r.d.x, r.o.x) - T.origin_x) * T.inv_spacing_x);
+    const float fz = f_floor((f_fma(t, r.d.z, r.o.z) - T.origin_z) * T.inv_spacing_z);
+    nx = sat_u32(fx);
+    nz = sat_u32(fz);
+    nx = nx < T.cell_w - 1u ? nx : T.cell_w - 1u;
+    nz = nz < T.cell_h - 1u ? nz : T.cell_h - 1u;
+    nx >>= level;
+    nz >>= level;
+}
+
+// A lane's share of the dealt rays: the ray, where the slice stops, and whose ray it is.
+struct MarchSlice {
+    RayCtx r;
+    float t_stop, t_end;  // t_end: where the ray leaves the footprint
+    uint32_t owner;       // lane that wants the verdict
+};
+
+// Phase 2 of an any-hit march (see above).  `m` holds the lane's position on its own ray, own_hit its
+// verdict so far; returns the final verdict of the lane's OWN ray.
+template <bool CURVED, class Ctx>
+F3D_HD bool march_shared(const TerrainDev &T, const RayCtx &own_ray, MarchState m, bool own_hit, Ctx &ctx) {
+    MarchSlice s;
+    s.r = own_ray;
+    s.t_stop = 3.0e38f;
+    s.owner = ctx.lane();
+    {
+        float lo;
+        march_root_interval(T, own_ray, lo, s.t_end);
+    }
+    ctx.verdict_post(own_hit);
+    uint32_t queued = 0u;
+    TraceHit res;
+    res.n = V3{0.0f, 0.0f, 0.0f};
+    for (uint32_t round = 0u;; round++) {
+        ctx.template deal<CURVED>(T, s, m);  // m.marching now says whether this lane got a slice
+        res.hit = false;
+        res.t = s.r.tmax;
+        bool again = false;
+        for (;;) {
+            if (m.marching) march_step<CURVED, true>(T, s.r, m, queued, ctx, s.t_stop);
+            again = round + 1u < kShareRounds && ctx.share_now(m.marching);
+            if (again || ctx.flush_now(queued, m.marching)) {
+                march_drain(T, s.r, true, m, queued, res, ctx);
+                if (res.hit) ctx.verdict_set(s.owner);
+                if (ctx.verdict_get(s.owner)) m.marching = false;  // another slice of this ray has hit
+            }
+            if (again || !ctx.any(m.marching || queued != 0u)) break;
+        }
+        if (!again) break;
+    }
+    return ctx.verdict_get(ctx.lane());
+}
+
 // CURVED: the sun-ray curvature policy is active for this ray (compile-time so that the other
 // two thirds of the rays do not carry the parabola arithmetic).  start_in_cell: begin in the cell
 // the ray is in (secondary rays) instead of at the root (camera rays entering from outside).
-// Ctx provides: note(), band_entry(), the FIFO storage fifo_put/fifo_get, and the wave votes
-// flush_now(queued, marching) / any(pred).
+// Ctx provides: note(), band_entry(), the FIFO storage fifo_put/fifo_get, the wave votes
+// flush_now(queued, marching) / any(pred), and share_now / deal / verdict_* (ray sharing).
 template <bool CURVED, class Ctx>
 F3D_HD TraceHit march_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit, bool start_in_cell, Ctx &ctx) {
     TraceHit res;
@@ -217,11 +306,22 @@ F3D_HD TraceHit march_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit
     ctx.feature(r.d.y);
     MarchState m = march_begin(T, r, start_in_cell);
     uint32_t queued = 0u;
+    bool deal = false;
     for (;;) {
-        if (m.marching) march_step<CURVED>(T, r, m, queued, ctx);
-        // drain the leaf FIFOs when the wave says so
-        if (ctx.flush_now(queued, m.marching)) march_drain(T, r, any_hit, m, queued, res, ctx);
-        if (!ctx.any(m.marching || queued != 0u)) break;
+        if (m.marching) march_step<CURVED, false>(T, r, m, queued, ctx);
+#if !defined(F3D_NO_SHARE)
+#if defined(F3D_SHARE_CURVED)
+        if (any_hit) deal = ctx.share_now(m.marching);
+#else
+        if (!CURVED && any_hit) deal = ctx.share_now(m.marching);  // the last few IBL rays: share them (needs empty FIFOs)
+#endif
+#endif
+        if (deal || ctx.flush_now(queued, m.marching)) march_drain(T, r, any_hit, m, queued, res, ctx);
+        if (deal || !ctx.any(m.marching || queued != 0u)) break;
+    }
+    if (deal) {
+        res.hit = march_shared<CURVED>(T, r, m, res.hit, ctx);
+        res.t = r.tmin;  // any-hit callers read only `hit` (and t < tmax)
     }
     return res;
 }

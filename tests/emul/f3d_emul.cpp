@@ -51,6 +51,14 @@ struct ArrayPending {
         log->back().leaf_mask = (log->back().leaf_mask & 0xFFFFFFFFull) | ((uint64_t)bits << 32);
     }
     bool leaf_gate(bool) const { return true; }  // one lane at a time: the gate is always open
+    // ray sharing needs other lanes: never offered here
+    uint32_t lane() const { return 0u; }
+    bool share_now(bool) const { return false; }
+    template <bool CURVED>
+    void deal(const TerrainDev &, MarchSlice &, MarchState &) const {}
+    void verdict_post(bool) const {}
+    void verdict_set(uint32_t) const {}
+    bool verdict_get(uint32_t) const { return false; }
     // deferred leaf FIFO of the march: a single lane drains only when its FIFO is full or its march
     // has ended, i.e. as LATE as possible -- the opposite extreme of the device's wave vote, so the
     // order-independence the deferral relies on is exercised by every CPU parity test

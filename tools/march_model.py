@@ -556,6 +556,44 @@ def pairing_model(rows="480:608"):
         print(f"  {G:2d} donors cut in {parts}, overhead {ov}: IBL wave iterations {base / v:.2f}x fewer")
 
 
+def tail_occupancy(rows="480:608"):
+    """Share of a phase's wave iterations that run with at most k lanes still marching (S = 4 tiles)."""
+    from emul import emul
+    from forge3d_amd import datasets
+
+    rows = tuple(int(x) for x in rows.split(":"))
+    dem, cam, kw = datasets.rainier_proxy_scene(2048)
+    log = tempfile.mktemp(suffix=".raylog")
+    os.environ["F3D_EMUL_RAYLOG"] = log
+    emul.render(dem, 1920, 1080, cam, rows=rows, **dict(kw, spp=8, max_frames=2, min_frames=2, variance_threshold=1e30))
+    W, R, spp, pixels = load_log(log)
+    os.unlink(log)
+    S, tw, th = 4, 4, 4
+    ks = (1, 2, 4, 8, 16, 32)
+    tot = np.zeros(3)
+    low = np.zeros((3, len(ks)))
+    for ty in range(0, R, th):
+        for tx in range(0, W, tw):
+            lanes = [pixels[y * W + x] for y in range(ty, min(ty + th, R)) for x in range(tx, min(tx + tw, W))]
+            P = np.zeros((len(lanes), spp, 3))
+            for li, rays in enumerate(lanes):
+                s = -1
+                for kind, steps, mask in rays:
+                    k = int(kind) & 0xFF
+                    if k == 2:
+                        s += 1
+                    P[li, s, {2: 0, 7: 1}.get(k, 2)] = steps
+            for r0 in range(0, spp, S):
+                blk = P[:, r0:r0 + S, :].reshape(-1, 3)
+                for j in range(3):
+                    st = np.sort(blk[:, j])[::-1]
+                    tot[j] += st[0]
+                    for i, k in enumerate(ks):
+                        low[j, i] += st[0] - (st[k] if k < len(st) else 0.0)  # iterations after only k lanes are left
+    for j, name in enumerate(("primary", "shadow", "ibl")):
+        print(f"  {name:8s}: " + ", ".join(f"<= {k} lanes: {low[j, i] / tot[j]:.0%}" for i, k in enumerate(ks)))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[2] == "batched":
         batched_table(sys.argv[1])
@@ -575,5 +613,7 @@ if __name__ == "__main__":
         predictor_model(sys.argv[1], int(sys.argv[3]) if len(sys.argv) > 3 else 3)
     elif len(sys.argv) > 2 and sys.argv[2] == "pairing":
         pairing_model(sys.argv[1])
+    elif len(sys.argv) > 2 and sys.argv[2] == "tail":
+        tail_occupancy(sys.argv[1])
     else:
         main()
