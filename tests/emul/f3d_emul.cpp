@@ -215,7 +215,47 @@ int emul_trace_batch(const float *heights, uint32_t w, uint32_t h, float origin_
             ArrayPending pend;
             RayCtx rc = make_ray(T, V3{r[0], r[1], r[2]}, r[3], V3{r[4], r[5], r[6]}, r[7], apply_curvature != 0);
             TraceHit hit;
-            if ((any_hit & 3) >= 2) {  // stackless march: 2 any hit, 3 closest; +4 start in the origin cell
+            const uint32_t slices = ((uint32_t)any_hit >> 4) & 15u, slice_level = ((uint32_t)any_hit >> 8) & 15u;
+            if ((any_hit & 3) == 2 && slices > 1u) {
+                // the any-hit ray as `slices` geometric parameter slices of its root interval, each started at a
+                // node of level `slice_level` located from the position -- what the frame kernel's ray sharing
+                // does across lanes (march_shared / deal), here one after the other: the OR is the answer
+                float lo, hi;
+                march_root_interval(T, rc, lo, hi);
+                hit.hit = false;
+                hit.t = rc.tmin;
+                hit.n = V3{0.0f, 0.0f, 0.0f};
+                const bool curved = rc.c2 != 0.0f || rc.has_vertex;
+                const float base = f_max(lo, 1e-3f * f_max(hi, 1e-30f));
+                const float lg = log2f(f_max(hi, base) / base) / (float)slices;
+                for (uint32_t k = 0; k < slices && !(lo > hi); k++) {
+                    const float begin = k == 0u ? lo : base * exp2f(lg * (float)k);
+                    const float stop = k + 1u == slices ? 3.0e38f : base * exp2f(lg * (float)(k + 1u));
+                    MarchState m = march_begin(T, rc, (any_hit & 4) != 0);
+                    if (k > 0u) {
+                        const uint32_t top = T.mip_count - 1u;
+                        m.level = slice_level < top ? slice_level : top;
+                        m.t_cur = begin;
+                        march_locate(T, rc, begin, m.level, m.nx, m.nz);
+                        m.unverified_start = true;
+                        m.marching = begin <= hi;
+                    }
+                    uint32_t queued = 0u;
+                    TraceHit res;
+                    res.hit = false;
+                    res.t = rc.tmax;
+                    res.n = V3{0.0f, 0.0f, 0.0f};
+                    for (;;) {
+                        if (m.marching) {
+                            if (curved) march_step<true, true>(T, rc, m, queued, pend, stop);
+                            else march_step<false, true>(T, rc, m, queued, pend, stop);
+                        }
+                        if (pend.flush_now(queued, m.marching)) march_drain(T, rc, true, m, queued, res, pend);
+                        if (!pend.any(m.marching || queued != 0u)) break;
+                    }
+                    if (res.hit) hit.hit = true;
+                }
+            } else if ((any_hit & 3) >= 2) {  // stackless march: 2 any hit, 3 closest; +4 start in the origin cell
                 hit = march_ray(T, rc, (any_hit & 3) == 2, (any_hit & 4) != 0, pend);
             } else {
                 hit = trace_terrain(T, rc, any_hit != 0, pend);

@@ -162,6 +162,21 @@ def test_stackless_march_matches_oracle_on_the_proof_rays(curved):
         assert np.array_equal(got["t"], want_closest["t"]) and np.array_equal(got["normal"], want_closest["normal"])
 
 
+@pytest.mark.parametrize("slices,level", [(2, 0), (5, 3), (8, 6), (15, 8), (3, 15)])
+def test_any_hit_ray_cut_into_slices_gives_the_same_answer(slices, level):
+    """Ray sharing (f3d_march.h march_shared): an any-hit ray walked as geometric parameter slices, each
+    started at a node of `level` located from the position, ORs to the oracle's answer on all proof rays
+    (the device deals such slices over the lanes of a wave; here they run one after the other)."""
+    heights, rays = scenes.proof_rays(n_random=6000, mask=True)
+    inv2r = float(np.float32(1.0 / 14_650_000.0))
+    for curved in (True, False):
+        base = dict(spacing=(500.0, 500.0), inv_two_r_prime=inv2r, curvature_enabled=True, apply_curvature=curved)
+        want = oracle.terrain_trace_batch(heights, rays, any_hit=True, **base)
+        for start in (0, 4):
+            got = emul.terrain_trace_batch(heights, rays, any_hit=2 | start | (slices << 4) | (level << 8), **base)
+            assert np.array_equal(got["hit"], want["hit"]), (curved, start)
+
+
 @pytest.mark.parametrize("shape", [(256, 256), (37, 100), (2, 2), (3, 9), (130, 65), (9, 3)])
 def test_table_builder_matches_build_minmax_mips(shape):
     dem = np.random.default_rng(shape[0] * 1000 + shape[1]).normal(1000.0, 300.0, size=shape).astype(np.float32)
