@@ -20,6 +20,8 @@ from forge3d_amd.distributed import HALO_ROWS, HipBackend, partition_rows, rebal
 W, H, SPP = 1920, 1080, 8
 dem, cam, kw = datasets.rainier_proxy_scene(2048)
 kw = dict(kw, spp=SPP, max_frames=64, min_frames=64, variance_threshold=1e30, memory_budget_bytes=8 << 30)
+if len(sys.argv) > 1:  # force a kernel variant for the strips (e.g. 4000000 = 4 sample lanes)
+    kw["kernel_variant"] = int(sys.argv[1])
 backend = HipBackend(0)
 full = min(backend.probe(dem, W, H, cam, 0, H, kw, frames=4) for _ in range(2))
 full_1lane = min(backend.probe(dem, W, H, cam, 0, H, dict(kw, kernel_variant=1000000), frames=4) for _ in range(2))
