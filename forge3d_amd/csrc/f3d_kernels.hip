@@ -136,7 +136,10 @@ struct LdsPending {
             m.unverified_start = false;
         } else {
             // nodes the march works on grow with the distance walked: about one level per doubling of t
-            const uint32_t top = T.mip_count - 1u, lvl = level + (uint32_t)(lg * (float)k);
+#ifndef F3D_SHARE_LEVEL_GAIN
+#define F3D_SHARE_LEVEL_GAIN 1.0f
+#endif
+            const uint32_t top = T.mip_count - 1u, lvl = level + (uint32_t)(F3D_SHARE_LEVEL_GAIN * lg * (float)k);
             m.level = lvl < top ? lvl : top;
             march_locate(T, r, begin, m.level, m.nx, m.nz);
             m.unverified_start = true;
