@@ -316,6 +316,8 @@ F3D_HD TraceHit march_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit
         if (!CURVED && any_hit) deal = ctx.share_now(m.marching);  // the last few IBL rays: share them (needs empty FIFOs)
 #endif
 #endif
+        // (Balancing the queued leaf solves of a wave over its lanes -- ceil(sum / lanes) rounds instead of
+        // max(queued), the owner's ray fetched by ds_bpermute -- was built and measured: bit-identical, 0.96x.)
         if (deal || ctx.flush_now(queued, m.marching)) march_drain(T, r, any_hit, m, queued, res, ctx);
         if (deal || !ctx.any(m.marching || queued != 0u)) break;
     }

@@ -594,6 +594,57 @@ def tail_occupancy(rows="480:608"):
         print(f"  {name:8s}: " + ", ".join(f"<= {k} lanes: {low[j, i] / tot[j]:.0%}" for i, k in enumerate(ks)))
 
 
+def drain_model(rows="480:608"):
+    """How well are the deferred leaf solves packed?  Replays the leaf positions of the first 32 steps of
+    every ray (leaf_mask) through the wave's FIFO rule (drain when a FIFO holds 4 or nobody marches) and
+    reports drain iterations (each = one leaf solve per lane with something queued) against the ideal."""
+    from emul import emul
+    from forge3d_amd import datasets
+
+    rows = tuple(int(x) for x in rows.split(":"))
+    dem, cam, kw = datasets.rainier_proxy_scene(2048)
+    log = tempfile.mktemp(suffix=".raylog")
+    os.environ["F3D_EMUL_RAYLOG"] = log
+    emul.render(dem, 1920, 1080, cam, rows=rows, **dict(kw, spp=8, max_frames=2, min_frames=2, variance_threshold=1e30))
+    W, R, spp, pixels = load_log(log)
+    os.unlink(log)
+    S, tw, th = 4, 4, 4
+    march_it = np.zeros(3)
+    drain_it = np.zeros(3)
+    solves = np.zeros(3)
+    for ty in range(0, R, th):
+        for tx in range(0, W, tw * 3):  # every third tile: python loop
+            lanes = [pixels[y * W + x] for y in range(ty, min(ty + th, R)) for x in range(tx, min(tx + tw, W))]
+            per = [[[] for _ in range(3)] for _ in range(spp // S)]
+            for rays in lanes:
+                s = -1
+                for kind, steps, mask in rays:
+                    k = int(kind) & 0xFF
+                    if k == 2:
+                        s += 1
+                    per[s // S][{2: 0, 7: 1}.get(k, 2)].append((int(steps), int(mask) & 0xFFFFFFFF))
+            for r in range(spp // S):
+                for j in range(3):
+                    rays = per[r][j]
+                    if not rays:
+                        continue
+                    n = max(st for st, _ in rays)
+                    march_it[j] += n
+                    q = [0] * len(rays)
+                    for it in range(n):
+                        for i, (st, mask) in enumerate(rays):
+                            if it < st and it < 32 and (mask >> it) & 1:
+                                q[i] += 1
+                        marching = any(it + 1 < st for st, _ in rays)
+                        if max(q) >= 4 or (not marching and max(q) > 0):
+                            drain_it[j] += max(q)
+                            solves[j] += sum(q)
+                            q = [0] * len(rays)
+    for j, name in enumerate(("primary", "shadow", "ibl")):
+        print(f"  {name:8s}: march iterations {march_it[j]:.0f}, drain iterations {drain_it[j]:.0f} "
+              f"(x ~3 march steps each), lane utilisation of the drains {solves[j] / max(1.0, 64 * drain_it[j]):.2f}")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[2] == "batched":
         batched_table(sys.argv[1])
@@ -615,5 +666,7 @@ if __name__ == "__main__":
         pairing_model(sys.argv[1])
     elif len(sys.argv) > 2 and sys.argv[2] == "tail":
         tail_occupancy(sys.argv[1])
+    elif len(sys.argv) > 2 and sys.argv[2] == "drain":
+        drain_model(sys.argv[1])
     else:
         main()
