@@ -58,9 +58,9 @@ struct LdsPending {
     __device__ __forceinline__ bool any(bool pred) const { return __ballot(pred) != 0ull; }
     // ---- ray sharing (f3d_march.h march_shared) ----
     __device__ __forceinline__ uint32_t lane() const { return threadIdx.x & (kWave - 1u); }
-    __device__ __forceinline__ bool share_now(bool marching) const {
+    __device__ __forceinline__ bool share_now(bool marching, uint32_t below = kShareBelow) const {
         const uint32_t n = (uint32_t)__popcll(__ballot(marching));
-        return n != 0u && n <= kShareBelow && (uint32_t)__popcll(__ballot(true)) >= kShareAvail * n;
+        return n != 0u && n <= below && (uint32_t)__popcll(__ballot(true)) >= kShareAvail * n;
     }
     // the verdict board lives in row kBoardRow of the WAVE's columns: board[l] = col[l - lane]
     // (volatile: lanes talk to each other through it without a barrier -- one wave, LDS operations in order)

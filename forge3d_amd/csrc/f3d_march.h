@@ -310,8 +310,8 @@ F3D_HD TraceHit march_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit
     for (;;) {
         if (m.marching) march_step<CURVED, false>(T, r, m, queued, ctx);
 #if !defined(F3D_NO_SHARE)
-#if defined(F3D_SHARE_CURVED)
-        if (any_hit) deal = ctx.share_now(m.marching);
+#if defined(F3D_SHARE_CURVED)  // A/B: sun rays too, with their own threshold (profiles/README.md)
+        if (any_hit) deal = CURVED ? ctx.share_now(m.marching, F3D_SHARE_CURVED) : ctx.share_now(m.marching);
 #else
         if (!CURVED && any_hit) deal = ctx.share_now(m.marching);  // the last few IBL rays: share them (needs empty FIFOs)
 #endif

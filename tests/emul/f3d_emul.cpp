@@ -53,7 +53,7 @@ struct ArrayPending {
     bool leaf_gate(bool) const { return true; }  // one lane at a time: the gate is always open
     // ray sharing needs other lanes: never offered here
     uint32_t lane() const { return 0u; }
-    bool share_now(bool) const { return false; }
+    bool share_now(bool, uint32_t = 0u) const { return false; }
     template <bool CURVED>
     void deal(const TerrainDev &, MarchSlice &, MarchState &) const {}
     void verdict_post(bool) const {}
