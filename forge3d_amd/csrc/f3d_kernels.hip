@@ -66,8 +66,8 @@ struct LdsPending {
     // (volatile: lanes talk to each other through it without a barrier -- one wave, LDS operations in order)
     __device__ __forceinline__ volatile uint32_t *board() const { return col - lane() + kBoardRow * kWave; }
     __device__ __forceinline__ void verdict_post(bool hit) const { board()[lane()] = hit ? 1u : 0u; }
-    __device__ __forceinline__ void verdict_set(uint32_t owner) const { board()[owner] = 1u; }
-    __device__ __forceinline__ bool verdict_get(uint32_t owner) const { return board()[owner] != 0u; }
+    __device__ __forceinline__ void verdict_set(uint32_t owner) const { board()[owner & (kWave - 1u)] = 1u; }
+    __device__ __forceinline__ bool verdict_get(uint32_t owner) const { return board()[owner & (kWave - 1u)] != 0u; }
     // Deal the marching slices over the lanes of this call: lane i of the call works on ray (i / per),
     // slice (i % per) of its remaining range; `per` = the largest power of two that fits.
     template <bool CURVED>
@@ -127,7 +127,7 @@ struct LdsPending {
         s.r = r;
         s.t_end = t_end;
         s.t_stop = stop;
-        s.owner = owner;
+        s.owner = owner;  // (garbage in lanes without a slice -- they read lane 0's registers above: the board masks it)
         m.t_cur = begin;
         if (k == 0u) {  // the first slice continues exactly where the source lane was
             m.level = level;
