@@ -11,6 +11,7 @@
 // GPU.  There is no CPU fallback: every entry point that computes needs a HIP device.
 #include <hip/hip_runtime.h>
 
+#include <exception>
 #include <new>
 
 #include "f3d_launch.h"
@@ -22,6 +23,42 @@ namespace {
 
 void hip_check(hipError_t e, const char *what) {
     if (e != hipSuccess) fail(F3D_STATUS_DEVICE, "HIP failure in %s: %s", what, hipGetErrorString(e));
+}
+
+// Binds a device for the duration of a C-ABI call and gives the caller's current device back afterwards:
+// entry points may be called from any thread and with any device current.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int device) {
+        if (device < 0 || hipGetDevice(&prev) != hipSuccess) return;
+        if (prev != device) switched = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
+// Runs `body` behind the C ABI: no C++ exception crosses the extern "C" boundary.
+template <class Body>
+int c_abi(char *err, size_t errlen, Body &&body) {
+    if (err && errlen) err[0] = 0;
+    try {
+        body();
+    } catch (const Failure &f) {
+        return report(f, err, errlen);
+    } catch (const std::exception &e) {  // std::bad_alloc from the host-side builders, ...
+        if (err && errlen) snprintf(err, errlen, "host failure: %s", e.what());
+        return F3D_STATUS_DEVICE;
+    } catch (...) {
+        if (err && errlen) snprintf(err, errlen, "unknown host failure");
+        return F3D_STATUS_DEVICE;
+    }
+    return F3D_STATUS_OK;
+}
+f3d_session &checked(f3d_session *s) {
+    if (!s) fail(F3D_STATUS_VALUE, "null session handle");
+    return *s;
 }
 
 }  // namespace
@@ -39,6 +76,15 @@ struct Ledger {
         owned.push_back(p);
         device_bytes += bytes;
         return p;
+    }
+    void free(void *p, size_t bytes) {  // give a buffer back before the session ends (build-time scratch)
+        for (auto it = owned.begin(); it != owned.end(); ++it)
+            if (*it == p) {
+                owned.erase(it);
+                (void)hipFree(p);
+                device_bytes -= bytes;
+                return;
+            }
     }
     void note_host_visible(uint64_t bytes) {
         if (bytes > host_visible_peak) host_visible_peak = bytes;
@@ -59,8 +105,11 @@ struct TerrainTables {
     NodeRec *bands = nullptr;  // row-major (min,max) of every level (the march's table)
 };
 
+// keep_nodes: the tiled node table (levels >= 1) is the input of the band tables and of the sorted descent
+// kept for the test hook (f3d_terrain_trace_batch modes 0 / 1, f3d_build_minmax_mips); the frame kernel's
+// march reads the band tables only, so sessions give the node table back once the bands are built.
 TerrainTables build_tables(Ledger &mem, const float *d_heights, uint32_t w, uint32_t h, float exaggeration,
-                           hipStream_t stream) {
+                           hipStream_t stream, bool keep_nodes) {
     TerrainTables t;
     t.layout = table_layout(w, h);
     const TableLayout &L = t.layout;
@@ -74,6 +123,14 @@ TerrainTables build_tables(Ledger &mem, const float *d_heights, uint32_t w, uint
         hip_check(launch_level_build(level_build_params(L, l, t.leaves, t.nodes), stream), "node table build");
     for (uint32_t l = 0; l < L.levels; l++)
         hip_check(launch_band_build(band_build_params(L, l, t.leaves, t.nodes, t.bands), stream), "band table build");
+#if !defined(F3D_TRAVERSAL_DESCENT)  // (A/B builds of the frame kernel on the sorted descent need the node table)
+    if (!keep_nodes) {
+        hip_check(hipStreamSynchronize(stream), "table build");
+        mem.free(t.nodes, (L.node_count ? L.node_count : 1) * sizeof(NodeRec));
+        t.nodes = nullptr;
+        t.bytes = L.leaf_count * sizeof(LeafRec) + L.band_count * sizeof(NodeRec);
+    }
+#endif
     apply_layout(L, t.dev);
     t.dev.leaves = t.leaves;
     t.dev.nodes = t.nodes;
@@ -146,7 +203,10 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
     const size_t dem_n = (size_t)d.dem_width * d.dem_height;
     float *d_heights = (float *)s.mem.alloc(dem_n * sizeof(float), "DEM upload");
     hip_check(hipMemcpy(d_heights, d.heights, dem_n * sizeof(float), hipMemcpyHostToDevice), "DEM upload");
-    s.tables = build_tables(s.mem, d_heights, d.dem_width, d.dem_height, d.exaggeration, s.stream);
+    s.tables = build_tables(s.mem, d_heights, d.dem_width, d.dem_height, d.exaggeration, s.stream, false);
+    // the corner records hold every height (x exaggeration): the raw upload is build-time scratch
+    hip_check(hipStreamSynchronize(s.stream), "table build");
+    s.mem.free(d_heights, dem_n * sizeof(float));
     apply_layout(s.tables.layout, P.terrain);
     P.terrain.leaves = s.tables.leaves;
     P.terrain.nodes = s.tables.nodes;
@@ -198,6 +258,9 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
     P.tile_map = (s.variant / 1000) % 10 ? (uint32_t)((s.variant / 1000) % 10) : 2u;
     // + 10000 * leaf quorum (f3d_trace.h "leaf gating"); 0 = default
     P.terrain.leaf_quorum = (s.variant / 10000) % 100 ? (uint32_t)((s.variant / 10000) % 100) : kDefaultLeafQuorum;
+    // + 10000000 * ray-sharing threshold (f3d_march.h: deal the IBL rays when at most this many lanes of a wave
+    // still march; 0 = default 16, 64 = share from the first step -- test coverage of the dealing code)
+    P.terrain.share_below = (uint32_t)((s.variant / 10000000) % 100);
     // + 1000000 * sample lanes per pixel (f3d_kernels.hip frame_lanes): 1, 2, 4, 8; 0 = automatic.
     // A wave of the 1-lane kernel lasts spp x 3 traversals whatever the image size, so small images
     // and thin multi-GPU strips are latency-bound and even a 1080p frame ends in a ~1 ms tail of
@@ -285,16 +348,15 @@ void enqueue_frame(f3d_session &s, uint32_t frame, bool collect, uint32_t part =
     P.res_in = s.res[(frame & 1u) ^ 1u];
     P.collect_stats = collect ? 1u : 0u;
     P.part = part;
-    if (part != 2u) {
-        if (collect) hip_check(hipMemsetAsync(s.stats, 0, 2 * sizeof(uint32_t), s.stream), "stats clear");
-        if (P.sample_lanes > 1u) hip_check(launch_head(P, s.stream), "frame head kernel");
-    }
+    if (part != 2u && collect) hip_check(hipMemsetAsync(s.stats, 0, 2 * sizeof(uint32_t), s.stream), "stats clear");
+    // the timed bracket covers the frame-head launch too: its record bytes are part of the roofline's state bytes
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (s.timing) {
         hip_check(hipEventCreate(&e0), "event");
         hip_check(hipEventCreate(&e1), "event");
         hip_check(hipEventRecord(e0, s.stream), "event record");
     }
+    if (part != 2u && P.sample_lanes > 1u) hip_check(launch_head(P, s.stream), "frame head kernel");
     hip_check(launch_frame(P, s.variant, s.stream), "frame kernel");
     if (s.timing) {
         hip_check(hipEventRecord(e1, s.stream), "event record");
@@ -333,11 +395,14 @@ int f3d_session_create(const f3d_terrain_ref_desc *desc, const f3d_session_opts 
     if (!desc || !session) return F3D_STATUS_VALUE;
     f3d_session *s = new (std::nothrow) f3d_session();
     if (!s) return F3D_STATUS_DEVICE;
-    try {
-        session_init(*s, *desc, opts);
-    } catch (const Failure &f) {
+    int caller_device = -1;
+    (void)hipGetDevice(&caller_device);
+    const int rc = c_abi(err, errlen, [&] { session_init(*s, *desc, opts); });
+    if (caller_device >= 0 && caller_device != s->device) (void)hipSetDevice(caller_device);  // session_init bound its own
+    if (rc != F3D_STATUS_OK) {
+        DeviceGuard g(s->device);
         delete s;
-        return report(f, err, errlen);
+        return rc;
     }
     *session = s;
     return F3D_STATUS_OK;
@@ -345,47 +410,42 @@ int f3d_session_create(const f3d_terrain_ref_desc *desc, const f3d_session_opts 
 
 void f3d_session_destroy(f3d_session *session) {
     if (!session) return;
+    DeviceGuard g(session->device);
     (void)hipStreamSynchronize(session->stream);
     delete session;
 }
 
 int f3d_session_enqueue_frames(f3d_session *s, uint32_t first_frame, uint32_t count, int32_t collect_stats_on_last,
                                char *err, size_t errlen) {
-    try {
+    return c_abi(err, errlen, [&] {
+        DeviceGuard g(checked(s).device);
         for (uint32_t i = 0; i < count; i++)
             enqueue_frame(*s, first_frame + i, collect_stats_on_last != 0 && i + 1 == count);
-    } catch (const Failure &f) {
-        return report(f, err, errlen);
-    }
-    return F3D_STATUS_OK;
+    });
 }
 
 int f3d_session_enqueue_frame_part(f3d_session *s, uint32_t frame, uint32_t part, int32_t collect_stats, char *err,
                                    size_t errlen) {
-    try {
-        if (!s || (part != 1u && part != 2u)) fail(F3D_STATUS_VALUE, "frame part must be 1 (edge rows) or 2 (interior)");
+    return c_abi(err, errlen, [&] {
+        DeviceGuard g(checked(s).device);
+        if (part != 1u && part != 2u) fail(F3D_STATUS_VALUE, "frame part must be 1 (edge rows) or 2 (interior)");
         enqueue_frame(*s, frame, collect_stats != 0, part);
-    } catch (const Failure &f) {
-        return report(f, err, errlen);
-    }
-    return F3D_STATUS_OK;
+    });
 }
 
 int f3d_session_window_stats(f3d_session *s, float *max_m2, int32_t *nonfinite, char *err, size_t errlen) {
-    try {
+    return c_abi(err, errlen, [&] {
+        DeviceGuard g(checked(s).device);
         hip_check(hipMemcpyAsync(s->host_stats, s->stats, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream),
                   "stats readback");
         hip_check(hipStreamSynchronize(s->stream), "stream sync");
         if (max_m2) *max_m2 = f_from_bits(s->host_stats[0]);
         if (nonfinite) *nonfinite = s->host_stats[1] != 0u;
-    } catch (const Failure &f) {
-        return report(f, err, errlen);
-    }
-    return F3D_STATUS_OK;
+    });
 }
 
 int f3d_session_halo(f3d_session *s, int32_t which, int32_t side, void **ptr, uint64_t *bytes) {
-    if (!s || which < 0 || which > 1 || side < 0 || side > 3) return F3D_STATUS_VALUE;
+    if (!s || !ptr || !bytes || which < 0 || which > 1 || side < 0 || side > 3) return F3D_STATUS_VALUE;
     const size_t row = (size_t)s->width;
     size_t first;
     switch (side) {
@@ -401,22 +461,21 @@ int f3d_session_halo(f3d_session *s, int32_t which, int32_t side, void **ptr, ui
 
 int f3d_session_resolve_device(f3d_session *s, uint32_t frames, void *d_rgba, void *d_albedo, void *d_normal,
                                void *d_depth, char *err, size_t errlen) {
-    try {
+    return c_abi(err, errlen, [&] {
+        DeviceGuard g(checked(s).device);
         if (frames == 0) fail(F3D_STATUS_VALUE, "resolve needs at least one accumulated frame");
         resolve(*s, frames, d_rgba ? (uint8_t *)d_rgba : s->d_rgba, d_albedo ? (float *)d_albedo : s->d_albedo,
                 d_normal ? (float *)d_normal : s->d_normal);
         if (d_depth)
             hip_check(hipMemcpyAsync(d_depth, s->depth, (size_t)s->rows * s->width * sizeof(float),
                                      hipMemcpyDeviceToDevice, s->stream), "depth copy");
-    } catch (const Failure &f) {
-        return report(f, err, errlen);
-    }
-    return F3D_STATUS_OK;
+    });
 }
 
 int f3d_session_resolve(f3d_session *s, uint32_t frames, uint8_t *rgba, float *albedo, float *normal, float *depth,
                         int32_t *any_valid_reservoir, char *err, size_t errlen) {
-    try {
+    return c_abi(err, errlen, [&] {
+        DeviceGuard g(checked(s).device);
         if (frames == 0) fail(F3D_STATUS_VALUE, "resolve needs at least one accumulated frame");
         resolve(*s, frames, s->d_rgba, s->d_albedo, s->d_normal);
         const size_t px = (size_t)s->rows * s->width;
@@ -437,10 +496,7 @@ int f3d_session_resolve(f3d_session *s, uint32_t frames, uint8_t *rgba, float *a
         if (s->host_stats[3] != 0u)
             fail(F3D_STATUS_RENDER, "terrain PT reservoir bookkeeping produced non-finite values");
         if (any_valid_reservoir) *any_valid_reservoir = s->host_stats[2] != 0u;
-    } catch (const Failure &f) {
-        return report(f, err, errlen);
-    }
-    return F3D_STATUS_OK;
+    });
 }
 
 int f3d_session_info(f3d_session *s, uint64_t *gpu_resource_bytes, uint64_t *minmax_pyramid_bytes,
@@ -456,6 +512,7 @@ int f3d_session_info(f3d_session *s, uint64_t *gpu_resource_bytes, uint64_t *min
 
 int f3d_session_kernel_timing(f3d_session *s, int32_t enable, double *avg_ms, uint32_t *launches) {
     if (!s) return F3D_STATUS_VALUE;
+    DeviceGuard g(s->device);
     if (enable) {
         for (auto &e : s->events) {
             (void)hipEventDestroy(e.first);
@@ -549,6 +606,11 @@ int f3d_terrain_ref_render(const f3d_terrain_ref_desc *desc, f3d_terrain_ref_out
                  (unsigned long long)out->peak_host_visible_bytes, (unsigned long long)s->budget);
     } catch (const Failure &f) {
         rc = report(f, err, errlen);
+    } catch (const std::exception &e) {
+        if (err && errlen) snprintf(err, errlen, "host failure: %s", e.what());
+        rc = F3D_STATUS_DEVICE;
+    } catch (...) {
+        rc = F3D_STATUS_DEVICE;
     }
     f3d_session_destroy(s);
     return rc;
@@ -570,7 +632,7 @@ int f3d_build_minmax_mips(const float *heights, uint32_t width, uint32_t height,
             fail(F3D_STATUS_DEVICE, "no HIP device available: libf3dhip has no CPU fallback");
         float *d_h = (float *)mem.alloc(n * sizeof(float), "DEM upload");
         hip_check(hipMemcpy(d_h, heights, n * sizeof(float), hipMemcpyHostToDevice), "DEM upload");
-        TerrainTables t = build_tables(mem, d_h, width, height, 1.0f, nullptr);
+        TerrainTables t = build_tables(mem, d_h, width, height, 1.0f, nullptr, true);
         hip_check(hipDeviceSynchronize(), "table build");
         const TableLayout &L = t.layout;
         const uint32_t levels = L.levels;
@@ -637,7 +699,7 @@ int f3d_terrain_trace_batch(const float *heights, uint32_t width, uint32_t heigh
         const size_t dem_n = (size_t)width * height;
         float *d_h = (float *)mem.alloc(dem_n * sizeof(float), "DEM upload");
         hip_check(hipMemcpy(d_h, heights, dem_n * sizeof(float), hipMemcpyHostToDevice), "DEM upload");
-        TerrainTables t = build_tables(mem, d_h, width, height, exaggeration, nullptr);
+        TerrainTables t = build_tables(mem, d_h, width, height, exaggeration, nullptr, true);
         RayBatchParams B{};
         B.terrain = t.dev;
         B.terrain.origin_x = origin_x;
@@ -654,8 +716,10 @@ int f3d_terrain_trace_batch(const float *heights, uint32_t width, uint32_t heigh
         B.n = n;
         // 0 closest / 1 any-hit through the sorted descent; 2 any / 3 closest through the march,
         // +4: the march starts in the origin cell (secondary rays) instead of at the root
+        // bits 8..15: ray-sharing threshold override (0 = default)
         B.any_hit = (uint32_t)any_hit & 3u;
         B.start_in_cell = ((uint32_t)any_hit >> 2) & 1u;
+        B.terrain.share_below = ((uint32_t)any_hit >> 8) & 255u;
         B.apply_curvature = apply_curvature != 0;
         B.out_hit = (uint32_t *)mem.alloc((size_t)n * 4, "hits");
         B.out_t = (float *)mem.alloc((size_t)n * 4, "t");

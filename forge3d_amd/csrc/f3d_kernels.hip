@@ -19,14 +19,14 @@ constexpr int kNumXcd = 8;
 // segment, and -- only for the sorted descent kept for the test hook / A-B builds -- the
 // pending-sibling words as a [level][lane] column (bank = lane, conflict-free).
 // Rows kParkRow.. of the column hold the sample-lane frame's accumulators between rounds.
-constexpr int kParkRow = 3 * kLeafFifo, kParkWords = 7;
+constexpr int kParkRow = 3 * kLeafFifoRows, kParkWords = 7;
 constexpr int kBoardRow = kParkRow + kParkWords;  // verdict board of the ray sharing (f3d_march.h): one word per lane
 constexpr int kLdsRows = kBoardRow + 1 > kMaxLevels ? kBoardRow + 1 : kMaxLevels;
 constexpr int kLdsWords = kLdsRows * kWave + 4 * kMaxLevels;
 struct LdsPending {
     uint32_t *col;          // lds + lane
     const uint32_t *table;  // lds + kLdsRows * kWave: {band_offset, band_shift, node_offset, tiles_x} per level
-    uint32_t leaf_quorum;
+    uint32_t leaf_quorum, share_below;
     __device__ __forceinline__ void put(uint32_t level, uint32_t word) { col[level * kWave] = word; }
     __device__ __forceinline__ uint32_t get(uint32_t level) const { return col[level * kWave]; }
     __device__ __forceinline__ void note(int) const {}  // step-statistics hook (host emulator only)
@@ -43,6 +43,7 @@ struct LdsPending {
         col[(3u * k + 1u) * kWave] = f_bits(lo);
         col[(3u * k + 2u) * kWave] = f_bits(hi);
     }
+    __device__ __forceinline__ void fifo_retag(uint32_t k, uint32_t cell) { col[(3u * k) * kWave] = cell; }
     __device__ __forceinline__ void fifo_get(uint32_t k, uint32_t &cell, float &lo, float &hi) const {
         cell = col[(3u * k) * kWave];
         lo = f_from_bits(col[(3u * k + 1u) * kWave]);
@@ -58,7 +59,8 @@ struct LdsPending {
     __device__ __forceinline__ bool any(bool pred) const { return __ballot(pred) != 0ull; }
     // ---- ray sharing (f3d_march.h march_shared) ----
     __device__ __forceinline__ uint32_t lane() const { return threadIdx.x & (kWave - 1u); }
-    __device__ __forceinline__ bool share_now(bool marching, uint32_t below = kShareBelow) const {
+    __device__ __forceinline__ bool share_now(bool marching) const { return share_now(marching, share_below); }
+    __device__ __forceinline__ bool share_now(bool marching, uint32_t below) const {
         const uint32_t n = (uint32_t)__popcll(__ballot(marching));
         return n != 0u && n <= below && (uint32_t)__popcll(__ballot(true)) >= kShareAvail * n;
     }
@@ -85,7 +87,7 @@ struct LdsPending {
         const uint32_t sh = 31u - (uint32_t)__clz((int)(avail / n)), per = 1u << sh;
         const uint32_t q = rank >> sh, k = rank & (per - 1u);
         const bool take = q < n;
-        int src = 0;
+        int src = (int)lane();  // lanes without a slice read their OWN registers below (always an active lane)
         {
             unsigned long long rest = mask;
             for (uint32_t i = 0u; i < n; i++) {  // wave-uniform, n <= kShareBelow
@@ -127,7 +129,7 @@ struct LdsPending {
         s.r = r;
         s.t_end = t_end;
         s.t_stop = stop;
-        s.owner = owner;  // (garbage in lanes without a slice -- they read lane 0's registers above: the board masks it)
+        s.owner = take ? owner : lane();  // lanes without a slice own nothing but themselves
         m.t_cur = begin;
         if (k == 0u) {  // the first slice continues exactly where the source lane was
             m.level = level;
@@ -169,7 +171,8 @@ __device__ __forceinline__ LdsPending make_pending(uint32_t *lds, const TerrainD
         e[3] = T.tiles_x[lane];
     }
     __syncthreads();
-    return LdsPending{lds + lane, lds + kLdsRows * kWave, T.leaf_quorum ? T.leaf_quorum : kDefaultLeafQuorum};
+    return LdsPending{lds + lane, lds + kLdsRows * kWave, T.leaf_quorum ? T.leaf_quorum : kDefaultLeafQuorum,
+                      T.share_below ? (T.share_below < 64u ? T.share_below : 64u) : kShareBelow};
 }
 
 // Pixel tile of a wave with S sample lanes per pixel: 64 / S pixels, TW x TH.

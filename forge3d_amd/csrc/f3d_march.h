@@ -24,10 +24,18 @@
 // Secondary rays start in the cell their origin is in (validated by that cell's own slab interval)
 // instead of walking ~11 levels down from the root.
 //
-// Deviations from the reference's enumeration, both measure-zero and documented in DESIGN.md:
-// a ray leaving a node EXACTLY through a corner (equal f32 plane parameters) skips the two cells it
-// touches in that single point; the start cell is located from the ray position.  tests/ compare
-// hit, t and normal with the oracle on 75 000 proof rays and whole renders bit for bit.
+// Corners.  A ray that passes EXACTLY through a lattice corner (equal f32 plane parameters: diagonal
+// rays over square DEMs, the unjittered centre ray of a camera on the diagonal, a 45-degree sun) touches
+// the two cells beside the corner in that single point; the reference visits them with the zero-length
+// interval [T, T] (:288-297 keeps lo == hi).  Such a visit can only answer an ANY-hit ray (the closest-hit
+// solve finds no root on a zero-length interval: a = b = 0), and it does: `c <= 0 -> hit` (:197-201) fires
+// for rays that run below the surface there.  The march detects every exact corner passage -- leaving a
+// node through its own corner (x_out == z_out), or entering a node on the mid-plane of the node it
+// descends (t_mid == t_cur with the entry plane's parameter equal too) -- and queues a TIE entry; the
+// drain judges the two side cells by their own band test and the zero-length solve (march_drain).
+// The start cell is located from the ray position and validated by its own slab interval.  tests/
+// compare hit, t and normal with the oracle on 75 000 proof rays, on adversarial lattice-aligned ray
+// sets (tests/test_adversarial_march.py) and whole renders bit for bit.
 #pragma once
 
 #include "f3d_trace.h"
@@ -65,6 +73,15 @@ F3D_HD bool march_band_rejects(const RayCtx &r, float t0, float t1, float mn, fl
 #define F3D_LEAF_FIFO 4
 #endif
 constexpr uint32_t kLeafFifo = F3D_LEAF_FIFO;  // entries per lane (A/B: 2, 3, 6, 8 -- profiles/README.md)
+// A step queues at most two entries (a leaf AND the corner it leaves through) and the wave drains as soon
+// as one lane holds kLeafFifo: storage for one more.
+constexpr uint32_t kLeafFifoRows = kLeafFifo + 1u;
+// TIE entry (see "Corners" above): corner lattice point (X, Z) <= 8192 in 14 bits each, the ray's x / z
+// direction, which side cell is next, and the flag; its `lo` word holds the corner's ray parameter T.
+constexpr uint32_t kTieFlag = 0x80000000u, kTieSecond = 0x40000000u, kTieZFwd = 0x20000000u, kTieXFwd = 0x10000000u;
+F3D_HD uint32_t tie_entry(uint32_t X, uint32_t Z, bool x_forward, bool z_forward) {
+    return kTieFlag | (z_forward ? kTieZFwd : 0u) | (x_forward ? kTieXFwd : 0u) | (Z << 14) | X;
+}
 
 // Per-lane position of a march.
 struct MarchState {
@@ -94,7 +111,9 @@ F3D_HD MarchState march_begin(const TerrainDev &T, const RayCtx &r, bool start_i
     m.nx = 0u;
     m.nz = 0u;
     m.unverified_start = false;
-    if (start_in_cell) {
+    // (a ray that ENTERS the footprint, t_cur > tmin, may do so exactly through a lattice corner on the
+    // boundary: only the walk down from the root sees the cell it touches there -- "Corners" above)
+    if (start_in_cell && !(m.t_cur > r.tmin)) {
         const float fx = f_floor((f_fma(m.t_cur, r.d.x, r.o.x) - T.origin_x) * T.inv_spacing_x);
         const float fz = f_floor((f_fma(m.t_cur, r.d.z, r.o.z) - T.origin_z) * T.inv_spacing_z);
         m.nx = sat_u32(fx);
@@ -110,8 +129,9 @@ F3D_HD MarchState march_begin(const TerrainDev &T, const RayCtx &r, bool start_i
 // One march step of a lane: test the current node and move DOWN, or ACROSS (+ UP).
 // SLICED: the lane walks a slice of a ray (march_shared below): nodes entered at or beyond t_stop
 // belong to the next slice.
+// any_hit: the ray is an occlusion ray (corner ties matter, see the header); a constant at every call site.
 template <bool CURVED, bool SLICED, class Ctx>
-F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint32_t &queued, Ctx &ctx,
+F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint32_t &queued, Ctx &ctx, bool any_hit,
                        float t_stop = 3.0e38f) {
     ctx.note(0);
     const uint32_t top = T.mip_count - 1u;
@@ -152,6 +172,22 @@ F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint
             uint32_t iz = (z_forward != (tzm <= m.t_cur)) ? 0u : 1u;
             if (!(xm < T.cell_w)) ix = 0u;  // the far half lies outside the cell grid
             if (!(zm < T.cell_h)) iz = 0u;
+#if !defined(F3D_NO_CORNER_TIES)  // A/B + test-of-the-tests switch: the round-1 behaviour
+            if (any_hit && (txm == m.t_cur || tzm == m.t_cur)) {
+                // the ray is ON a child boundary at its current parameter: if it is also on the plane it
+                // entered this node through, it passes exactly through the lattice corner where both meet
+                // (the half it does not enter is touched in that one point: "Corners" in the header)
+                const uint32_t xin = x_forward ? cx0 : cx1, zin = z_forward ? cz0 : cz1;
+                const float txin = x_forward ? tx0 : tx1, tzin = z_forward ? tz0 : tz1;
+                if (txm == m.t_cur && tzin == m.t_cur && xm < T.cell_w) {
+                    ctx.fifo_put(queued, tie_entry(xm, zin, x_forward, z_forward), m.t_cur, m.t_cur);
+                    queued++;
+                } else if (tzm == m.t_cur && txin == m.t_cur && zm < T.cell_h) {
+                    ctx.fifo_put(queued, tie_entry(xin, zm, x_forward, z_forward), m.t_cur, m.t_cur);
+                    queued++;
+                }
+            }
+#endif
             m.nx = 2u * nx + ix;
             m.nz = 2u * nz + iz;
             m.level = cl;
@@ -163,6 +199,13 @@ F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint
             }
             // ---- across the exit boundary of this node (straight-line: no nested divergence) ----
             const bool cross_x = x_out <= z_out, cross_z = z_out <= x_out;
+#if !defined(F3D_NO_CORNER_TIES)
+            if (any_hit && cross_x && cross_z && exit < r.tmax) {  // out through the node's own corner
+                ctx.fifo_put(queued, tie_entry(x_forward ? cx1 : cx0, z_forward ? cz1 : cz0, x_forward, z_forward), exit,
+                             exit);
+                queued++;
+            }
+#endif
             // a backward step from column 0 wraps to 0xFFFFFFFF, whose shifted value is >= cell_w too
             // (cell_w <= 2^13, level <= 15), so one unsigned comparison covers both directions
             const uint32_t qx = nx + ((cross_x && x_forward) ? 1u : 0u) - ((cross_x && !x_forward) ? 1u : 0u);
@@ -183,23 +226,50 @@ F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint
     m.unverified_start = false;
 }
 
-// Drain the lane's leaf FIFO: solve the queued leaves in ray order until one hits.
+// Drain the lane's leaf FIFO: solve the queued leaves in ray order until one hits.  A TIE entry (any-hit
+// rays only) stands for the two cells beside a lattice corner the ray passes exactly through: each is
+// judged as the reference judges it -- cell range, the zero-length interval [T, T] clipped by the ray's
+// (tmin, tmax), the cell's own (min,max) band (= min / max of its corner record; its ancestors' tests
+// are implied, their intervals contain T and their bands contain the cell's), then the leaf solve.
 template <class Ctx>
 F3D_HD void march_drain(const TerrainDev &T, const RayCtx &r, bool any_hit, MarchState &m, uint32_t &queued,
                         TraceHit &res, Ctx &ctx) {
-    for (uint32_t k = 0u; ctx.any(k < queued && !res.hit); k++) {
+    uint32_t k = 0u;  // per lane: a tie entry is visited twice
+    while (ctx.any(k < queued && !res.hit)) {
         if (k < queued && !res.hit) {
             uint32_t cell;
             float lo, hi;
             ctx.fifo_get(k, cell, lo, hi);
-            const uint32_t cx = cell & 0xFFFFu, cz = cell >> 16;
-            const LeafRec leaf = T.leaves[tiled_index(cx, cz, T.tiles_x[0])];
-            float t;
-            if (leaf_solve(T, r, leaf, cx, cz, lo, hi, any_hit, t) && t < res.t) {
-                res.hit = true;  // first hit in ray order is final (see the header)
-                res.t = t;
-                res.n = leaf_normal(T, leaf, along(r.o, t, r.d), cx, cz);
-                m.marching = false;
+            uint32_t cx = cell & 0xFFFFu, cz = cell >> 16;
+            bool solve = true;
+            const bool tie = any_hit && (cell & kTieFlag) != 0u;
+            if (tie) {
+                const uint32_t X = cell & 0x3FFFu, Z = (cell >> 14) & 0x3FFFu;
+                const bool xf = (cell & kTieXFwd) != 0u, zf = (cell & kTieZFwd) != 0u, second = (cell & kTieSecond) != 0u;
+                // first visit: the cell across the x plane in the row the ray comes from; second: the cell across
+                // the z plane in the column it comes from (an index of -1 wraps and fails the range test)
+                const uint32_t near_x = xf ? X - 1u : X, far_x = xf ? X : X - 1u;
+                const uint32_t near_z = zf ? Z - 1u : Z, far_z = zf ? Z : Z - 1u;
+                cx = second ? near_x : far_x;
+                cz = second ? far_z : near_z;
+                hi = f_min(lo, r.tmax);
+                lo = f_max(lo, r.tmin);
+                solve = cx < T.cell_w && cz < T.cell_h && !(lo > hi);
+                if (!second) ctx.fifo_retag(k, cell | kTieSecond);
+                else k++;
+            } else {
+                k++;
+            }
+            if (solve) {
+                const LeafRec leaf = T.leaves[tiled_index(cx, cz, T.tiles_x[0])];
+                float t;
+                if (!(tie && band_rejects(r, lo, hi, min4(leaf), max4(leaf))) &&
+                    leaf_solve(T, r, leaf, cx, cz, lo, hi, any_hit, t) && t < res.t) {
+                    res.hit = true;  // first hit in ray order is final (see the header)
+                    res.t = t;
+                    res.n = leaf_normal(T, leaf, along(r.o, t, r.d), cx, cz);
+                    m.marching = false;
+                }
             }
         }
     }
@@ -277,7 +347,7 @@ F3D_HD bool march_shared(const TerrainDev &T, const RayCtx &own_ray, MarchState 
         res.t = s.r.tmax;
         bool again = false;
         for (;;) {
-            if (m.marching) march_step<CURVED, true>(T, s.r, m, queued, ctx, s.t_stop);
+            if (m.marching) march_step<CURVED, true>(T, s.r, m, queued, ctx, true, s.t_stop);
             again = round + 1u < kShareRounds && ctx.share_now(m.marching);
             if (again || ctx.flush_now(queued, m.marching)) {
                 march_drain(T, s.r, true, m, queued, res, ctx);
@@ -308,7 +378,7 @@ F3D_HD TraceHit march_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit
     uint32_t queued = 0u;
     bool deal = false;
     for (;;) {
-        if (m.marching) march_step<CURVED, false>(T, r, m, queued, ctx);
+        if (m.marching) march_step<CURVED, false>(T, r, m, queued, ctx, any_hit);
 #if !defined(F3D_NO_SHARE)
 #if defined(F3D_SHARE_CURVED)  // A/B: sun rays too, with their own threshold (profiles/README.md)
         if (any_hit) deal = CURVED ? ctx.share_now(m.marching, F3D_SHARE_CURVED) : ctx.share_now(m.marching);

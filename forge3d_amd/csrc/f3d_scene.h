@@ -68,6 +68,7 @@ struct TerrainDev {
     float inv_two_r_prime;  // EarthCurvatureUniforms, terrain_heightfield.rs:42-84
     uint32_t curvature_enabled;
     uint32_t leaf_quorum;   // lanes of a wave that must hold a fat leaf before the leaf body runs
+    uint32_t share_below;   // ray sharing (f3d_march.h): deal when at most this many lanes still march; 0 = default
 };
 
 // Threaded BVH node (f3d_bvh.h): preorder layout, enter -> node + 1, miss / subtree done -> skip.

@@ -192,8 +192,9 @@ struct TableLayout {
     uint32_t node_offset[kMaxLevels]{};
     uint64_t leaf_count = 0, node_count = 0;
     uint32_t cell_w = 0, cell_h = 0;
-    // row-major band tables of the march (all levels, pitch = level_w = 2^band_shift)
-    uint32_t band_offset[kMaxLevels]{}, band_shift[kMaxLevels]{};
+    // row-major band tables of the march (all levels, pitch = level_w = 2^band_shift; only the rows that
+    // hold cells are stored: the march never visits a node whose first cell lies outside the grid)
+    uint32_t band_offset[kMaxLevels]{}, band_shift[kMaxLevels]{}, band_rows[kMaxLevels]{};
     uint64_t band_count = 0;
 };
 
@@ -208,8 +209,10 @@ inline TableLayout table_layout(uint32_t w, uint32_t h) {
         const uint32_t l = t.levels;
         t.level_w[l] = lw;
         t.level_h[l] = lh;
-        t.dim_x[l] = pad8(lw);
-        t.dim_y[l] = pad8(lh);
+        // the leaf table covers the cell grid only (the reference's level 0 is padded to the power of two with
+        // (+inf,-inf) records nobody reads: terrain_heightfield.rs:154-155); node levels keep the pow2 padding
+        t.dim_x[l] = l == 0 ? pad8(t.cell_w) : pad8(lw);
+        t.dim_y[l] = l == 0 ? pad8(t.cell_h) : pad8(lh);
         t.tiles_x[l] = t.dim_x[l] / 8u;
         if (l >= 1) {
             t.node_offset[l] = (uint32_t)t.node_count;
@@ -224,9 +227,12 @@ inline TableLayout table_layout(uint32_t w, uint32_t h) {
     for (uint32_t l = 0; l < t.levels; l++) {
         uint32_t shift = 0;
         while ((1u << shift) < t.level_w[l]) shift++;
+        uint32_t rows = (t.cell_h + (1u << l) - 1u) >> l;
+        rows = rows < 1u ? 1u : (rows < t.level_h[l] ? rows : t.level_h[l]);
         t.band_offset[l] = (uint32_t)t.band_count;
         t.band_shift[l] = shift;
-        t.band_count += (uint64_t)t.level_w[l] * t.level_h[l];
+        t.band_rows[l] = rows;
+        t.band_count += (uint64_t)t.level_w[l] * rows;
     }
     return t;
 }
@@ -251,7 +257,7 @@ inline BandBuildParams band_build_params(const TableLayout &t, uint32_t l, const
     b.dst = bands + t.band_offset[l];
     b.level = l;
     b.width = t.level_w[l];
-    b.height = t.level_h[l];
+    b.height = t.band_rows[l];
     b.shift = t.band_shift[l];
     b.src_tiles_x = t.tiles_x[l];
     b.cell_w = t.cell_w;

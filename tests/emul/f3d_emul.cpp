@@ -62,8 +62,9 @@ struct ArrayPending {
     // deferred leaf FIFO of the march: a single lane drains only when its FIFO is full or its march
     // has ended, i.e. as LATE as possible -- the opposite extreme of the device's wave vote, so the
     // order-independence the deferral relies on is exercised by every CPU parity test
-    uint32_t q_cell[kLeafFifo];
-    float q_lo[kLeafFifo], q_hi[kLeafFifo];
+    uint32_t q_cell[kLeafFifoRows];
+    float q_lo[kLeafFifoRows], q_hi[kLeafFifoRows];
+    void fifo_retag(uint32_t k, uint32_t cell) { q_cell[k] = cell; }
     void fifo_put(uint32_t k, uint32_t cell, float lo, float hi) {
         q_cell[k] = cell;
         q_lo[k] = lo;
@@ -247,8 +248,8 @@ int emul_trace_batch(const float *heights, uint32_t w, uint32_t h, float origin_
                     res.n = V3{0.0f, 0.0f, 0.0f};
                     for (;;) {
                         if (m.marching) {
-                            if (curved) march_step<true, true>(T, rc, m, queued, pend, stop);
-                            else march_step<false, true>(T, rc, m, queued, pend, stop);
+                            if (curved) march_step<true, true>(T, rc, m, queued, pend, true, stop);
+                            else march_step<false, true>(T, rc, m, queued, pend, true, stop);
                         }
                         if (pend.flush_now(queued, m.marching)) march_drain(T, rc, true, m, queued, res, pend);
                         if (!pend.any(m.marching || queued != 0u)) break;

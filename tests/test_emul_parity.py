@@ -185,3 +185,28 @@ def test_table_builder_matches_build_minmax_mips(shape):
     assert len(got) == len(want)
     for a, b in zip(got, want):
         assert a.shape == b.shape and np.array_equal(a, b)
+
+
+def test_600k_triangle_bvh_reproduces_the_sweep():
+    """BASELINE.json configs[3] stand-in: 600 000 triangles, built by the multi-arena worker-thread path
+    (>= 64 subtrees spliced), walked by the kernel code against the oracle's sweep over every triangle; a
+    24x24 close-up keeps the sweep at a few seconds (the GPU suite runs 64x64 through the device)."""
+    from forge3d_amd import datasets
+
+    dem = datasets.rainier_proxy(512)
+    spacing = 40.0
+    v, i = datasets.proxy_buildings(dem, spacing)
+    centres = v.reshape(-1, 8, 3).mean(1)
+    cell = np.floor(centres[:, [0, 2]] / 250.0).astype(np.int64)
+    uniq, counts = np.unique(cell, axis=0, return_counts=True)
+    spot = (uniq[counts.argmax()] + 0.5) * 250.0
+    near = centres[np.hypot(centres[:, 0] - spot[0], centres[:, 2] - spot[1]) < 200.0]
+    target = (float(spot[0]), float(near[:, 1].mean()), float(spot[1]))
+    cam = {"origin": (target[0] + 190.0, target[1] + 130.0, target[2] + 150.0), "look_at": target,
+           "up": (0.0, 1.0, 0.0), "fov_y": 55.0, "exposure": 1.0}
+    kw = dict(spacing=(spacing, spacing), exaggeration=1.0, albedo=(0.6, 0.6, 0.6), sun_azimuth_deg=302.0,
+              sun_elevation_deg=24.0, spp=1, max_frames=2, min_frames=2, variance_threshold=1e30,
+              mesh_vertices=v, mesh_indices=i)
+    want = oracle.render(dem, 24, 24, cam, **kw)
+    assert float((want["albedo"][..., 2] > 0.75).mean()) > 0.2  # buildings fill a good part of the view
+    _same(emul.render(dem, 24, 24, cam, **kw), want)

@@ -574,3 +574,82 @@ def test_full_size_properties(f3d):
         assert m2v == m2
         for key in ("rgba", "albedo", "normal", "depth"):
             assert np.array_equal(a[key], v[key], equal_nan=True), (variant, key)
+
+
+# ---------------------------------------------------------------------------------------
+# BASELINE.json configs at full size, bit-exact against the oracle
+# ---------------------------------------------------------------------------------------
+def _session_render(dem, w, h, cam, frames, variant=0, **kw):
+    from forge3d_amd.session import TerrainSession
+
+    with TerrainSession(dem, w, h, cam, kernel_variant=variant, memory_budget_bytes=8 << 30, **kw) as s:
+        s.enqueue_frames(0, frames, True)
+        m2, bad = s.window_stats()
+        out = s.resolve(frames)
+        out["sample_lanes"] = s.sample_lanes()
+    assert not bad
+    out["variance"] = float(np.float32(max(0.0, m2)) / np.float32(frames - 1))
+    return out
+
+
+def test_config2_exactly_as_benched_matches_the_oracle(f3d, oracle):
+    """BASELINE.json configs[1] exactly as bench.py times it -- the 2048^2 rainier-proxy DEM, 1920x1080,
+    8 spp per frame -- two frames against the CPU oracle (a few seconds on the GPU box's host cores),
+    every pixel of every output, for the default (4 sample lanes) kernel, the 1-lane and the 8-lane kernel."""
+    from forge3d_amd import datasets
+
+    dem, cam, kw = datasets.rainier_proxy_scene(2048)
+    k = dict(kw, spp=8, max_frames=2, min_frames=2, variance_threshold=1e30)
+    want = oracle.render(dem, 1920, 1080, cam, **k)
+    assert 0.3 < np.isfinite(want["depth"]).mean() < 0.5  # the benched camera: ~40 % terrain, the rest sky
+    for variant, lanes in ((0, 4), (1000000, 1), (8000000, 8)):
+        got = _session_render(dem, 1920, 1080, cam, 2, variant, **k)
+        assert got["sample_lanes"] == lanes
+        assert np.float32(got["variance"]) == np.float32(want["variance"]), variant
+        for key in ("rgba", "albedo", "normal", "depth"):
+            assert np.array_equal(got[key], want[key], equal_nan=True), (variant, key)
+
+
+@pytest.mark.parametrize("spp,frames", [(16, 2), (1, 16)])
+def test_config1_rainier_512_matches_the_oracle(f3d, oracle, spp, frames):
+    """BASELINE.json configs[0] (512x512 at 16 spp) on the reference's locked mini-DEM scene
+    (tests/test_hybrid_terrain_pt.py:30-76; BASELINE.md input S1): 16 spp x 2 frames and 1 spp x 16 frames,
+    through the one-shot C ABI, bit for bit."""
+    dem = scenes.golden_dem()
+    kw = scenes.fixed_frames(scenes.scene_kwargs(dem), frames, spp=spp)
+    _same(f3d.hybrid_render_terrain_reference(dem, 512, 512, scenes.CAM, **kw),
+          oracle.render(dem, 512, 512, scenes.CAM, **kw))
+
+
+def test_config4_standin_600k_triangles_matches_the_oracle_sweep(f3d, oracle):
+    """BASELINE.json configs[3] stand-in (BASELINE.md input S4): 50 000 extruded boxes = 600 000 triangles
+    on the proxy DEM.  The device walks the threaded BVH built by the multi-arena worker-thread path; the
+    oracle sweeps every triangle for every ray like the reference (hybrid_traversal.wgsl:137-172) --
+    ~3e10 ray/triangle tests, seconds on the GPU box's host.  A close-up camera so that buildings fill
+    a good part of the 64x64 image."""
+    from forge3d_amd import datasets
+
+    dem = datasets.rainier_proxy(512)
+    spacing = 40.0
+    v, i = datasets.proxy_buildings(dem, spacing)
+    assert i.shape[0] == 600_000
+    # look at the densest spot of the box field from 260 m away
+    centres = v.reshape(-1, 8, 3).mean(1)
+    cell = np.floor(centres[:, [0, 2]] / 250.0).astype(np.int64)
+    uniq, counts = np.unique(cell, axis=0, return_counts=True)
+    spot = (uniq[counts.argmax()] + 0.5) * 250.0
+    near = centres[np.hypot(centres[:, 0] - spot[0], centres[:, 2] - spot[1]) < 200.0]
+    target = (float(spot[0]), float(near[:, 1].mean()), float(spot[1]))
+    cam = {"origin": (target[0] + 190.0, target[1] + 130.0, target[2] + 150.0), "look_at": target,
+           "up": (0.0, 1.0, 0.0), "fov_y": 55.0, "exposure": 1.0}
+    kw = dict(spacing=(spacing, spacing), exaggeration=1.0, albedo=(0.6, 0.6, 0.6), sun_azimuth_deg=302.0,
+              sun_elevation_deg=24.0, spp=2, max_frames=2, min_frames=2, variance_threshold=1e30,
+              mesh_vertices=v, mesh_indices=i)
+    want = oracle.render(dem, 64, 64, cam, **kw)
+    mesh_px = float((want["albedo"][..., 2] > 0.75).mean())
+    assert mesh_px > 0.05, mesh_px  # buildings are really in view (mesh albedo .7,.7,.8)
+    for variant in (0, 8000000):
+        got = _session_render(dem, 64, 64, cam, 2, variant, **kw)
+        assert np.float32(got["variance"]) == np.float32(want["variance"]), variant
+        for key in ("rgba", "albedo", "normal", "depth"):
+            assert np.array_equal(got[key], want[key], equal_nan=True), (variant, key)
