@@ -160,6 +160,18 @@ struct f3d_session {
     int variant = 0;
     bool require_valid_reservoirs = false;
     uint64_t budget = 0;
+    // band pipelining (f3d_session_opts.bands): horizontal bands of the strip, their streams and events
+    struct Band {
+        uint32_t begin = 0, end = 0;   // image rows
+        hipStream_t stream = nullptr;  // == the session stream when the strip is one band
+        bool edge = true;              // contains rows a neighbouring strip needs as halo (frame part 1)
+        hipEvent_t done[2] = {nullptr, nullptr};  // frame f of this band has finished: done[f & 1]
+        int64_t last = -1;             // last frame enqueued
+        bool unjoined = false;         // the session stream has not been ordered after `last` yet
+    };
+    std::vector<Band> bands;
+    std::vector<hipStream_t> band_streams;
+    hipEvent_t fork = nullptr;  // position of the session stream when a batch of band launches began
     // per-launch timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -168,12 +180,19 @@ struct f3d_session {
             (void)hipEventDestroy(e.first);
             (void)hipEventDestroy(e.second);
         }
+        for (auto &b : bands)
+            for (hipEvent_t e : b.done)
+                if (e) (void)hipEventDestroy(e);
+        if (fork) (void)hipEventDestroy(fork);
+        for (hipStream_t st : band_streams) (void)hipStreamDestroy(st);
         if (host_stats) (void)hipHostFree(host_stats);
         mem.release();
     }
 };
 
 namespace {
+
+void plan_bands(f3d_session &s, uint32_t want, uint32_t want_streams);
 
 void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_session_opts *opts) {
     validate_desc(d);
@@ -252,6 +271,8 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
     }
     P.row_begin = s.row_begin;
     P.row_end = s.row_end;
+    P.band_begin = s.row_begin;
+    P.band_end = s.row_end;
     // variant = kernel variant + 1000 * tile map; map 0 = default (tile rows dealt round-robin
     // to the XCDs: 1.77x faster than contiguous bands on the headline scene, whose sky bands
     // left whole XCDs idle -- profiles/README.md)
@@ -332,6 +353,8 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
              (unsigned long long)s.mem.device_bytes, (unsigned long long)s.mem.host_visible_peak,
              (unsigned long long)s.budget);
 
+    plan_bands(s, opts ? opts->bands : 0u, opts ? opts->band_streams : 0u);
+
     // one-shot G-buffer + AOV pass, render_terrain.rs:1091-1121
     P.frame_index = 0;
     P.res_in = s.res[1];
@@ -340,29 +363,127 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
     hip_check(launch_gbuffer(P, s.gbuffer_n, s.depth, s.stream), "g-buffer pass");
 }
 
-// part: 0 the whole strip; 1 frame head + the strip's edge tile rows; 2 the interior (after part 1)
-void enqueue_frame(f3d_session &s, uint32_t frame, bool collect, uint32_t part = 0u) {
+// One band of one frame: frame head (sample-lane form) + frame kernel over the band's rows, on the band's
+// stream, after the frame before of this band and of its two neighbours (the head's spatial reuse reads the
+// previous frame's reservoirs of +-3 rows; everything else a band touches is its own).
+void enqueue_band(f3d_session &s, f3d_session::Band &b, size_t index, uint32_t frame, bool collect) {
     FrameParams &P = s.params;
     P.frame_index = frame;
     P.res_out = s.res[frame & 1u];
     P.res_in = s.res[(frame & 1u) ^ 1u];
     P.collect_stats = collect ? 1u : 0u;
-    P.part = part;
-    if (part != 2u && collect) hip_check(hipMemsetAsync(s.stats, 0, 2 * sizeof(uint32_t), s.stream), "stats clear");
+    P.band_begin = b.begin;
+    P.band_end = b.end;
+    const bool piped = b.stream != s.stream;
+    if (piped) {
+        hip_check(hipStreamWaitEvent(b.stream, s.fork, 0), "band fork");
+        for (int d = -1; d <= 1; d += 2) {
+            const size_t n = index + (size_t)d;  // index - 1 wraps for band 0
+            if (n >= s.bands.size() || frame == 0u) continue;
+            f3d_session::Band &nb = s.bands[n];
+            if (nb.last != (int64_t)frame - 1)
+                fail(F3D_STATUS_VALUE, "frames must be enqueued in order (band %zu is at frame %lld, frame %u wanted)", n,
+                     (long long)nb.last, frame);
+            if (nb.stream != b.stream) hip_check(hipStreamWaitEvent(b.stream, nb.done[(frame - 1u) & 1u], 0), "band wait");
+        }
+    }
     // the timed bracket covers the frame-head launch too: its record bytes are part of the roofline's state bytes
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (s.timing) {
         hip_check(hipEventCreate(&e0), "event");
         hip_check(hipEventCreate(&e1), "event");
-        hip_check(hipEventRecord(e0, s.stream), "event record");
+        hip_check(hipEventRecord(e0, b.stream), "event record");
     }
-    if (part != 2u && P.sample_lanes > 1u) hip_check(launch_head(P, s.stream), "frame head kernel");
-    hip_check(launch_frame(P, s.variant, s.stream), "frame kernel");
+    if (P.sample_lanes > 1u) hip_check(launch_head(P, b.stream), "frame head kernel");
+    hip_check(launch_frame(P, s.variant, b.stream), "frame kernel");
     if (s.timing) {
-        hip_check(hipEventRecord(e1, s.stream), "event record");
+        hip_check(hipEventRecord(e1, b.stream), "event record");
         s.events.emplace_back(e0, e1);
     }
-    P.part = 0u;
+    if (piped) {
+        hip_check(hipEventRecord(b.done[frame & 1u], b.stream), "band done");
+        b.unjoined = true;
+    }
+    b.last = frame;
+    P.band_begin = s.row_begin;
+    P.band_end = s.row_end;
+}
+
+// Start of a batch of band launches: they are ordered after what the session stream holds now.
+void fork_bands(f3d_session &s, bool clear_stats) {
+    if (clear_stats) hip_check(hipMemsetAsync(s.stats, 0, 2 * sizeof(uint32_t), s.stream), "stats clear");
+    if (s.fork) hip_check(hipEventRecord(s.fork, s.stream), "band fork");
+}
+
+// Order the session stream after every band launch made so far (before anything reads the results).
+void join_bands(f3d_session &s, bool edges_only = false) {
+    for (auto &b : s.bands)
+        if (b.unjoined && (b.edge || !edges_only)) {
+            hip_check(hipStreamWaitEvent(s.stream, b.done[b.last & 1], 0), "band join");
+            b.unjoined = false;
+        }
+}
+
+// part: 0 every band; 1 the edge bands (halo donors of a multi-GPU strip), then the session stream is
+// ordered after them; 2 the interior bands
+void enqueue_frame(f3d_session &s, uint32_t frame, bool collect, uint32_t part = 0u, bool fork = true) {
+    if (fork && part != 2u) fork_bands(s, collect);
+    for (size_t i = 0; i < s.bands.size(); i++) {
+        f3d_session::Band &b = s.bands[i];
+        if ((part == 1u && !b.edge) || (part == 2u && b.edge)) continue;
+        enqueue_band(s, b, i, frame, collect);
+    }
+    if (part == 1u) join_bands(s, true);
+}
+
+// Cut the strip into bands (multiples of 8 rows from its first row: every tile shape of the frame kernels and
+// the 8x8 tiles of the head kernel start on such a row).  With three or more bands the first and the last are
+// EDGE bands -- 8 rows at the top, the last 3..10 rows -- so that a multi-GPU strip can ship its halo rows
+// while the interior bands still render.
+void plan_bands(f3d_session &s, uint32_t want, uint32_t want_streams) {
+    const uint32_t rows = s.rows;
+    const bool strip = s.rows != s.height;
+    if (want == 0u) {
+        // automatic: a strip that cannot fill the chip for long is latency-bound (one wave's chain of ~200
+        // dependent steps), so overlap consecutive frames; a whole frame keeps one launch per frame
+        const uint64_t waves = ((uint64_t)rows * s.width * s.params.sample_lanes + 63u) / 64u;
+        want = (strip && waves < 131072u) ? 4u : 1u;
+    }
+    if (want > 64u) want = 64u;
+    std::vector<std::pair<uint32_t, uint32_t>> cuts;  // (first row, end row) relative to the strip
+    const uint32_t bottom = rows > kHaloRows ? ((rows - kHaloRows) / 8u) * 8u : 0u;
+    if (want >= 3u && bottom >= 16u) {
+        const uint32_t units = (bottom - 8u) / 8u, inner = std::min(want - 2u, units);
+        cuts.emplace_back(0u, 8u);
+        for (uint32_t k = 0; k < inner; k++)
+            cuts.emplace_back(8u + (units * k / inner) * 8u, 8u + (units * (k + 1u) / inner) * 8u);
+        cuts.emplace_back(bottom, rows);
+    } else if (want == 2u && rows >= 16u) {
+        const uint32_t mid = (rows / 16u) * 8u;
+        cuts.emplace_back(0u, mid);
+        cuts.emplace_back(mid, rows);
+    } else {
+        cuts.emplace_back(0u, rows);
+    }
+    const size_t n = cuts.size();
+    uint32_t n_streams = n == 1 ? 0u : (want_streams ? want_streams : 4u);
+    if (n_streams > n) n_streams = (uint32_t)n;
+    for (uint32_t i = 0; i < n_streams; i++) {
+        hipStream_t st = nullptr;
+        hip_check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "band stream");
+        s.band_streams.push_back(st);
+    }
+    if (n > 1) hip_check(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming), "band event");
+    s.bands.resize(n);
+    for (size_t i = 0; i < n; i++) {
+        f3d_session::Band &b = s.bands[i];
+        b.begin = s.row_begin + cuts[i].first;
+        b.end = s.row_begin + cuts[i].second;
+        b.edge = n < 3 || i == 0 || i + 1 == n;
+        b.stream = n == 1 ? s.stream : s.band_streams[i % n_streams];
+        if (n > 1)
+            for (auto &e : b.done) hip_check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "band event");
+    }
 }
 
 bool closes_window(uint32_t frame, uint32_t max_frames) {
@@ -371,6 +492,7 @@ bool closes_window(uint32_t frame, uint32_t max_frames) {
 }
 
 void resolve(f3d_session &s, uint32_t frames, uint8_t *d_rgba, float *d_albedo, float *d_normal) {
+    join_bands(s);
     ResolveParams R{};
     R.frame = s.params;
     R.frame.res_in = s.res[(frames - 1u) & 1u];
@@ -411,6 +533,7 @@ int f3d_session_create(const f3d_terrain_ref_desc *desc, const f3d_session_opts 
 void f3d_session_destroy(f3d_session *session) {
     if (!session) return;
     DeviceGuard g(session->device);
+    for (hipStream_t st : session->band_streams) (void)hipStreamSynchronize(st);
     (void)hipStreamSynchronize(session->stream);
     delete session;
 }
@@ -419,8 +542,9 @@ int f3d_session_enqueue_frames(f3d_session *s, uint32_t first_frame, uint32_t co
                                char *err, size_t errlen) {
     return c_abi(err, errlen, [&] {
         DeviceGuard g(checked(s).device);
+        if (count) fork_bands(*s, collect_stats_on_last != 0);
         for (uint32_t i = 0; i < count; i++)
-            enqueue_frame(*s, first_frame + i, collect_stats_on_last != 0 && i + 1 == count);
+            enqueue_frame(*s, first_frame + i, collect_stats_on_last != 0 && i + 1 == count, 0u, false);
     });
 }
 
@@ -436,6 +560,7 @@ int f3d_session_enqueue_frame_part(f3d_session *s, uint32_t frame, uint32_t part
 int f3d_session_window_stats(f3d_session *s, float *max_m2, int32_t *nonfinite, char *err, size_t errlen) {
     return c_abi(err, errlen, [&] {
         DeviceGuard g(checked(s).device);
+        join_bands(*s);
         hip_check(hipMemcpyAsync(s->host_stats, s->stats, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream),
                   "stats readback");
         hip_check(hipStreamSynchronize(s->stream), "stream sync");
@@ -523,6 +648,8 @@ int f3d_session_kernel_timing(f3d_session *s, int32_t enable, double *avg_ms, ui
         return F3D_STATUS_OK;
     }
     s->timing = false;
+    for (hipStream_t st : s->band_streams)
+        if (hipStreamSynchronize(st) != hipSuccess) return F3D_STATUS_DEVICE;
     if (hipStreamSynchronize(s->stream) != hipSuccess) return F3D_STATUS_DEVICE;
     double total = 0.0;
     for (auto &e : s->events) {

@@ -187,32 +187,13 @@ struct TileShape {
     static constexpr uint32_t kLogH = 6u - kLogS - kLogW;     // 8, 4, 4, 2 pixels high
 };
 
-// Edge tile rows of a strip of `rows` pixel rows with tiles 2^log_h rows high: the first `top` tile rows
-// and the tile rows from `bottom_first` on together cover (at least) the first and last kHaloRows pixel
-// rows; when the strip is too thin for an interior everything is edge.
-__host__ __device__ inline void edge_tile_rows(uint32_t rows, uint32_t log_h, uint32_t &top, uint32_t &bottom_first,
-                                               uint32_t all_rows) {
-    const uint32_t th = 1u << log_h;
-    top = (kHaloRows + th - 1u) >> log_h;
-    bottom_first = rows > kHaloRows ? (rows - kHaloRows) >> log_h : 0u;
-    if (top >= bottom_first) {  // no interior
-        top = all_rows;
-        bottom_first = all_rows;
-    }
-}
-
+// Pixel of this lane: the launch covers the image rows [band_begin, band_end) of the strip, tiled from band_begin.
 template <uint32_t S = 1u>
 __device__ __forceinline__ bool tile_pixel(const FrameParams &P, uint32_t &gx, uint32_t &gy) {
     using Shape = TileShape<S>;
     constexpr uint32_t TW = 1u << Shape::kLogW, TH = 1u << Shape::kLogH;
-    const uint32_t rows = P.row_end - P.row_begin;
-    const uint32_t tiles_x = (P.cam.width + TW - 1u) >> Shape::kLogW, all_rows = (rows + TH - 1u) >> Shape::kLogH;
-    // part 1 / 2 (multi-GPU strips: the edge rows are rendered first so that their halo exchange overlaps the
-    // interior): a launch covers a subset of the tile rows, renumbered 0 .. tiles_y - 1
-    uint32_t tiles_y = all_rows, top = 0u, bottom_first = all_rows;
-    if (P.part != 0u) edge_tile_rows(rows, Shape::kLogH, top, bottom_first, all_rows);
-    if (P.part == 1u) tiles_y = top + (all_rows - bottom_first);
-    if (P.part == 2u) tiles_y = bottom_first - top;
+    const uint32_t rows = P.band_end - P.band_begin;
+    const uint32_t tiles_x = (P.cam.width + TW - 1u) >> Shape::kLogW, tiles_y = (rows + TH - 1u) >> Shape::kLogH;
     const uint32_t ntiles = tiles_x * tiles_y;
     // Workgroup b is observed to run on XCD b % 8.  tile_map picks how tiles are dealt to XCDs:
     //   1  tile id = workgroup id (consecutive tiles on different XCDs)
@@ -235,12 +216,9 @@ __device__ __forceinline__ bool tile_pixel(const FrameParams &P, uint32_t &gx, u
     }
     if (tile >= ntiles) return false;
     const uint32_t pixel = threadIdx.x >> Shape::kLogS;  // the S sample lanes of a pixel are neighbours
-    uint32_t ty = tile / tiles_x;
-    if (P.part == 1u) ty = ty < top ? ty : bottom_first + (ty - top);
-    if (P.part == 2u) ty = top + ty;
     gx = (tile % tiles_x) * TW + (pixel & (TW - 1u));
-    gy = P.row_begin + ty * TH + (pixel >> Shape::kLogW);
-    return gx < P.cam.width && gy < P.row_end;
+    gy = P.band_begin + (tile / tiles_x) * TH + (pixel >> Shape::kLogW);
+    return gx < P.cam.width && gy < P.band_end;
 }
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
@@ -464,27 +442,22 @@ static inline uint32_t frame_grid(const FrameParams &p, uint32_t lanes = 1u) {
 #else
     const uint32_t log_w = lanes <= 2u ? 3u : 2u, log_h = 6u - log_s - log_w;  // TileShape<S>
 #endif
-    const uint32_t rows = p.row_end - p.row_begin;
-    const uint32_t tiles_x = (p.cam.width + (1u << log_w) - 1u) >> log_w, all_rows = (rows + (1u << log_h) - 1u) >> log_h;
-    uint32_t tiles_y = all_rows, top = 0u, bottom_first = all_rows;
-    if (p.part != 0u) edge_tile_rows(rows, log_h, top, bottom_first, all_rows);
-    if (p.part == 1u) tiles_y = top + (all_rows - bottom_first);
-    if (p.part == 2u) tiles_y = bottom_first - top;
+    const uint32_t rows = p.band_end - p.band_begin;
+    const uint32_t tiles_x = (p.cam.width + (1u << log_w) - 1u) >> log_w, tiles_y = (rows + (1u << log_h) - 1u) >> log_h;
     if (tiles_y == 0u) return 0u;
     if (p.tile_map == 2u) return ((tiles_y + kNumXcd - 1u) / kNumXcd) * tiles_x * kNumXcd;
     return ((tiles_x * tiles_y + kNumXcd - 1u) / kNumXcd) * kNumXcd;
 }
 
-hipError_t launch_head(const FrameParams &p, hipStream_t stream) {  // always all rows of the strip
-    FrameParams all = p;
-    all.part = 0u;
-    hipLaunchKernelGGL(k_head, dim3(frame_grid(all)), dim3(kWave), 0, stream, all);
+hipError_t launch_head(const FrameParams &p, hipStream_t stream) {  // the band's pixels, one lane each (8x8 tiles)
+    if (frame_grid(p) == 0u) return hipSuccess;
+    hipLaunchKernelGGL(k_head, dim3(frame_grid(p)), dim3(kWave), 0, stream, p);
     return hipGetLastError();
 }
 
 hipError_t launch_frame(const FrameParams &p, int variant, hipStream_t stream) {
     const uint32_t lanes = p.sample_lanes ? p.sample_lanes : 1u;
-    if (frame_grid(p, lanes) == 0u) return hipSuccess;  // a strip without interior rows (part 2)
+    if (frame_grid(p, lanes) == 0u) return hipSuccess;  // an empty band
     const dim3 grid(frame_grid(p, lanes)), block(kWave);
     if (lanes != 1u) {  // one wave per workgroup (register-budget A/B variants for 4 and 8 lanes only)
         switch (lanes * 1000 + (uint32_t)(variant % 1000)) {

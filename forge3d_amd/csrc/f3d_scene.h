@@ -149,8 +149,8 @@ struct FrameParams {
     uint32_t tile_map;              // workgroup -> tile mapping (f3d_kernels.hip tile_pixel)
     uint32_t sample_lanes;          // lanes per pixel in the frame kernel: 1 (frame_pixel), 2, 4, 8 (frame_lanes)
     uint2 *head;                    // sample-lane form only: per-pixel record of k_head {reuse_w bits, flags}
-    uint32_t part;                  // which tile rows this launch covers: 0 all, 1 the strip's EDGE rows (the >= 3
-                                    // pixel rows a neighbouring strip needs as halo), 2 the interior
+    uint32_t band_begin, band_end;  // image rows THIS launch covers (a band of the strip; the host pipelines bands
+                                    // of consecutive frames over several streams, f3d_host.hip)
 };
 
 }  // namespace f3d

@@ -119,6 +119,13 @@ typedef struct f3d_session_opts {
      *   stats:         4 x u32 {max m2 bits, nonfinite flag, any_valid flag, bad_reservoir flag}. */
     void *ext_reservoirs[2];
     void *ext_stats;
+    /* Band pipelining: the strip is cut into `bands` horizontal bands (0 = automatic: 1 for strips that fill
+     * the chip, several for thin multi-GPU strips) whose launches go round-robin to `band_streams` internal
+     * HIP streams (0 = automatic); band b of frame f + 1 waits only for bands b - 1, b, b + 1 of frame f (the
+     * spatial reuse reads +-3 rows), so consecutive frames overlap and a thin strip is no longer bound by the
+     * latency of one wave's ray chain.  Results do not depend on either number. */
+    uint32_t bands;
+    uint32_t band_streams;
 } f3d_session_opts;
 
 int f3d_session_create(const f3d_terrain_ref_desc *desc, const f3d_session_opts *opts,
@@ -132,10 +139,10 @@ void f3d_session_destroy(f3d_session *session);
  * convergence statistic read by f3d_session_window_stats. */
 int f3d_session_enqueue_frames(f3d_session *session, uint32_t first_frame, uint32_t count,
                                int32_t collect_stats_on_last, char *err, size_t errlen);
-/* One frame in two launches, for strips of a multi-GPU job: part 1 = frame head + the strip's EDGE tile
- * rows (they contain the first and last 3 pixel rows, the halo a neighbouring strip needs), part 2 = the
- * interior.  The caller starts the halo exchange between the two, so that it overlaps the interior.
- * Same result as f3d_session_enqueue_frames(frame, 1). */
+/* One frame in two steps, for strips of a multi-GPU job: part 1 = the strip's EDGE bands (they contain the
+ * first and last 3 pixel rows, the halo a neighbouring strip needs; on return the session stream is ordered
+ * after them), part 2 = the interior bands.  The caller starts the halo exchange between the two, so that it
+ * overlaps the interior.  Same result as f3d_session_enqueue_frames(frame, 1). */
 int f3d_session_enqueue_frame_part(f3d_session *session, uint32_t frame, uint32_t part, int32_t collect_stats,
                                    char *err, size_t errlen);
 /* Variance gate input for the window that ends after `frames` frames

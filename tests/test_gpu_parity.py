@@ -653,3 +653,41 @@ def test_config4_standin_600k_triangles_matches_the_oracle_sweep(f3d, oracle):
         assert np.float32(got["variance"]) == np.float32(want["variance"]), variant
         for key in ("rgba", "albedo", "normal", "depth"):
             assert np.array_equal(got[key], want[key], equal_nan=True), (variant, key)
+
+
+@pytest.mark.parametrize("bands,streams,variant,rows", [(2, 2, 0, (0, 0)), (3, 2, 0, (0, 0)), (5, 4, 8000000, (0, 0)),
+                                                         (8, 3, 1000000, (0, 0)), (4, 4, 0, (16, 75)),
+                                                         (6, 1, 4000000, (5, 97)), (64, 4, 2000000, (0, 0)),
+                                                         (3, 3, 0, (40, 60))])
+def test_band_pipelining_is_bit_identical(f3d, bands, streams, variant, rows):
+    """f3d_session_opts.bands / band_streams: the strip cut into horizontal bands whose launches go to several
+    streams, band b of frame f + 1 waiting only for bands b-1, b, b+1 of frame f -- same reservoirs,
+    accumulation, statistics and image as one launch per frame, whole frames enqueued at once, one by one and
+    as edge / interior parts, for every tile shape, ragged strips and strips too thin for an interior."""
+    from forge3d_amd.session import TerrainSession
+
+    dem = scenes.golden_dem()
+    frames = 7
+    kw = scenes.fixed_frames(scenes.scene_kwargs(dem), frames, spp=8)
+    opts = dict(kernel_variant=variant, row_begin=rows[0], row_end=rows[1])
+    with TerrainSession(dem, 150, 97, scenes.CAM, bands=1, **opts, **kw) as s:
+        s.enqueue_frames(0, frames, True)
+        m2, bad = s.window_stats()
+        want = s.resolve(frames)
+    for how in ("batch", "single", "parts"):
+        with TerrainSession(dem, 150, 97, scenes.CAM, bands=bands, band_streams=streams, **opts, **kw) as s:
+            if how == "batch":
+                s.enqueue_frames(0, 3)
+                s.enqueue_frames(3, frames - 3, True)
+            elif how == "single":
+                for f in range(frames):
+                    s.enqueue_frames(f, 1, f + 1 == frames)
+            else:
+                for f in range(frames):
+                    s.enqueue_frame_part(f, 1, f + 1 == frames)
+                    s.enqueue_frame_part(f, 2, f + 1 == frames)
+            m2b, badb = s.window_stats()
+            got = s.resolve(frames)
+        assert (m2, bad) == (m2b, badb), how
+        for key in ("rgba", "albedo", "normal", "depth"):
+            assert np.array_equal(got[key], want[key], equal_nan=True), (how, key)

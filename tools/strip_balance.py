@@ -1,11 +1,15 @@
 #!/usr/bin/env python
 """Single-GPU rehearsal of the multi-GPU strip balancing (forge3d_amd/distributed.py).
 
-For N = 2, 4, 8 strips of the headline frame: time every strip of the equal partition and of
-each re-balanced partition on THIS GPU (one after the other), exactly as the ranks of a real
-job would, and report the compute-only bound on strong scaling T(full frame) / max_i T(strip i).
-Communication (92 KB halo per neighbour and frame) is not included.
+For N strips of the headline frame: time every strip of the equal partition and of each re-balanced
+partition on THIS GPU (one after the other), exactly as the ranks of a real job would, and report the
+compute-only bound on strong scaling T(full frame) / max_i T(strip i).  Communication (92 KB halo per
+neighbour and frame) is not included.
+
+    python tools/strip_balance.py [--worlds 2,4,8] [--bands B] [--streams S] [--variant V] [--frames K]
+    python tools/strip_balance.py --sweep      # bands x streams grid on the 8-strip partition
 """
+import argparse
 import json
 import sys
 from pathlib import Path
@@ -17,23 +21,47 @@ sys.path.insert(0, str(ROOT))
 from forge3d_amd import datasets  # noqa: E402
 from forge3d_amd.distributed import HALO_ROWS, HipBackend, partition_rows, rebalance, strip_rows  # noqa: E402
 
+ap = argparse.ArgumentParser()
+ap.add_argument("--worlds", default="2,4,8")
+ap.add_argument("--bands", type=int, default=0)
+ap.add_argument("--streams", type=int, default=0)
+ap.add_argument("--variant", type=int, default=0)
+ap.add_argument("--frames", type=int, default=16)
+ap.add_argument("--sweep", action="store_true")
+args = ap.parse_args()
+
 W, H, SPP = 1920, 1080, 8
 dem, cam, kw = datasets.rainier_proxy_scene(2048)
-kw = dict(kw, spp=SPP, max_frames=64, min_frames=64, variance_threshold=1e30, memory_budget_bytes=8 << 30)
-if len(sys.argv) > 1:  # force a kernel variant for the strips (e.g. 4000000 = 4 sample lanes)
-    kw["kernel_variant"] = int(sys.argv[1])
+kw = dict(kw, spp=SPP, max_frames=64, min_frames=64, variance_threshold=1e30, memory_budget_bytes=8 << 30,
+          kernel_variant=args.variant)
 backend = HipBackend(0)
-full = min(backend.probe(dem, W, H, cam, 0, H, kw, frames=4) for _ in range(2))
-full_1lane = min(backend.probe(dem, W, H, cam, 0, H, dict(kw, kernel_variant=1000000), frames=4) for _ in range(2))
-print(json.dumps({"full_frame_ms": full, "full_frame_ms_1_lane_kernel": full_1lane}))
-for world in (2, 4, 8):
+
+
+def probe(b0, b1, **extra):
+    return min(backend.probe(dem, W, H, cam, b0, b1, dict(kw, **extra), frames=args.frames) for _ in range(2))
+
+
+full = probe(0, H)
+print(json.dumps({"full_frame_ms": full}), flush=True)
+if args.sweep:
+    # the balanced 8-strip partition of profiles/r01_strip_balance.log
+    bounds = [0, 394, 483, 552, 624, 703, 801, 917, 1080]
+    for bands, streams in ((1, 0), (3, 2), (4, 2), (4, 4), (6, 3), (6, 4), (8, 4), (8, 8), (12, 4)):
+        times = [probe(bounds[r], bounds[r + 1], bands=bands, band_streams=streams) for r in range(8)]
+        print(json.dumps({"world": 8, "bands": bands, "streams": streams, "ms": [round(t, 3) for t in times],
+                          "compute_bound_speedup": full / max(times)}), flush=True)
+    for bands, streams in ((2, 2), (4, 4), (8, 4)):  # does the whole frame gain from overlapping its own tail?
+        print(json.dumps({"world": 1, "bands": bands, "streams": streams,
+                          "ms": probe(0, H, bands=bands, band_streams=streams)}), flush=True)
+    sys.exit(0)
+for world in [int(x) for x in args.worlds.split(",")]:
     bounds = [strip_rows(H, world, r)[0] for r in range(world)] + [H]
     density = np.ones(H)
     for it in range(4):
-        times = [backend.probe(dem, W, H, cam, bounds[r], bounds[r + 1], kw, frames=4) for r in range(world)]
+        times = [probe(bounds[r], bounds[r + 1], bands=args.bands, band_streams=args.streams) for r in range(world)]
         print(json.dumps({"world": world, "round": it, "bounds": bounds, "ms": [round(t, 3) for t in times],
                           "imbalance": max(times) / (sum(times) / world),
-                          "compute_bound_speedup": full / max(times)}))
+                          "compute_bound_speedup": full / max(times)}), flush=True)
         density = rebalance(density, bounds, times)
         new_bounds = partition_rows(density, world, HALO_ROWS)
         if new_bounds == bounds:
