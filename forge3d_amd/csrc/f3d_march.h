@@ -176,9 +176,15 @@ F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint
             if (any_hit && (txm == m.t_cur || tzm == m.t_cur)) {
                 // the ray is ON a child boundary at its current parameter: if it is also on the plane it
                 // entered this node through, it passes exactly through the lattice corner where both meet
-                // (the half it does not enter is touched in that one point: "Corners" in the header)
-                const uint32_t xin = x_forward ? cx0 : cx1, zin = z_forward ? cz0 : cz1;
-                const float txin = x_forward ? tx0 : tx1, tzin = z_forward ? tz0 : tz1;
+                // (the half it does not enter is touched in that one point: "Corners" in the header).
+                // Rare: the entry planes are recomputed here instead of being kept alive across the band fetch.
+                uint32_t lv = level;
+                F3D_OPAQUE(lv);
+                const uint32_t ex1 = (nx + 1u) << lv, ez1 = (nz + 1u) << lv;
+                const uint32_t xin = x_forward ? nx << lv : (ex1 < T.cell_w ? ex1 : T.cell_w);
+                const uint32_t zin = z_forward ? nz << lv : (ez1 < T.cell_h ? ez1 : T.cell_h);
+                const float txin = (plane_at(T.origin_x, xin, T.spacing_x) - r.o.x) * r.inv_x;
+                const float tzin = (plane_at(T.origin_z, zin, T.spacing_z) - r.o.z) * r.inv_z;
                 if (txm == m.t_cur && tzin == m.t_cur && xm < T.cell_w) {
                     ctx.fifo_put(queued, tie_entry(xm, zin, x_forward, z_forward), m.t_cur, m.t_cur);
                     queued++;
@@ -200,9 +206,13 @@ F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint
             // ---- across the exit boundary of this node (straight-line: no nested divergence) ----
             const bool cross_x = x_out <= z_out, cross_z = z_out <= x_out;
 #if !defined(F3D_NO_CORNER_TIES)
-            if (any_hit && cross_x && cross_z && exit < r.tmax) {  // out through the node's own corner
-                ctx.fifo_put(queued, tie_entry(x_forward ? cx1 : cx0, z_forward ? cz1 : cz0, x_forward, z_forward), exit,
-                             exit);
+            if (any_hit && cross_x && cross_z && exit < r.tmax) {  // out through the node's own corner (rare)
+                uint32_t lv = level;
+                F3D_OPAQUE(lv);
+                const uint32_t ex1 = (nx + 1u) << lv, ez1 = (nz + 1u) << lv;
+                const uint32_t X = x_forward ? (ex1 < T.cell_w ? ex1 : T.cell_w) : nx << lv;
+                const uint32_t Z = z_forward ? (ez1 < T.cell_h ? ez1 : T.cell_h) : nz << lv;
+                ctx.fifo_put(queued, tie_entry(X, Z, x_forward, z_forward), exit, exit);
                 queued++;
             }
 #endif

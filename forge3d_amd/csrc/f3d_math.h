@@ -15,11 +15,19 @@
 #include <hip/hip_runtime.h>
 #define F3D_HD __host__ __device__ __forceinline__
 #define F3D_LAMBDA __attribute__((always_inline))
+// "Forget" where a register value came from: code on a rarely taken branch recomputes what it needs from this
+// value instead of keeping the hot path's temporaries alive across a memory wait (f3d_march.h, corner ties).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define F3D_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define F3D_OPAQUE(x) (void)(x)
+#endif
 #else
 #include <cmath>
 #include <cstring>
 #define F3D_HD inline
 #define F3D_LAMBDA __attribute__((always_inline))
+#define F3D_OPAQUE(x) (void)(x)
 // Host-only builds (tests/emul) have no HIP vector types.
 struct alignas(16) float4 {
     float x, y, z, w;
