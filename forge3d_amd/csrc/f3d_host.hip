@@ -375,13 +375,18 @@ void enqueue_band(f3d_session &s, f3d_session::Band &b, size_t index, uint32_t f
     P.band_begin = b.begin;
     P.band_end = b.end;
     const bool piped = b.stream != s.stream;
+    if (b.last != (int64_t)frame - 1 && !(b.last < 0 && frame == 0u) && piped)
+        fail(F3D_STATUS_VALUE, "frames must be enqueued in order (band %zu is at frame %lld, frame %u wanted)", index,
+             (long long)b.last, frame);
     if (piped) {
         hip_check(hipStreamWaitEvent(b.stream, s.fork, 0), "band fork");
         for (int d = -1; d <= 1; d += 2) {
             const size_t n = index + (size_t)d;  // index - 1 wraps for band 0
             if (n >= s.bands.size() || frame == 0u) continue;
             f3d_session::Band &nb = s.bands[n];
-            if (nb.last != (int64_t)frame - 1)
+            // the neighbour has frame - 1 enqueued, or (enqueued before this band) frame itself already: its
+            // done[(frame - 1) & 1] still holds frame - 1 -- the events alternate and nobody is two frames ahead
+            if (nb.last != (int64_t)frame - 1 && nb.last != (int64_t)frame)
                 fail(F3D_STATUS_VALUE, "frames must be enqueued in order (band %zu is at frame %lld, frame %u wanted)", n,
                      (long long)nb.last, frame);
             if (nb.stream != b.stream) hip_check(hipStreamWaitEvent(b.stream, nb.done[(frame - 1u) & 1u], 0), "band wait");
