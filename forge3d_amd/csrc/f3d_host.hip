@@ -669,6 +669,18 @@ int f3d_session_kernel_timing(f3d_session *s, int32_t enable, double *avg_ms, ui
 
 uint32_t f3d_session_sample_lanes(f3d_session *s) { return s ? s->params.sample_lanes : 0u; }
 
+int f3d_session_debug_wave_times(f3d_session *s, void *device_buffer) {
+#if defined(F3D_WAVE_TIMES)
+    if (!s) return F3D_STATUS_VALUE;
+    s->params.wave_times = (unsigned long long *)device_buffer;
+    return F3D_STATUS_OK;
+#else
+    (void)s;
+    (void)device_buffer;
+    return F3D_STATUS_VALUE;  // diagnostics are compiled out of the shipped library
+#endif
+}
+
 int f3d_terrain_ref_render(const f3d_terrain_ref_desc *desc, f3d_terrain_ref_out *out, char *err, size_t errlen) {
     if (err && errlen) err[0] = 0;
     if (!desc || !out) return F3D_STATUS_VALUE;

@@ -363,6 +363,9 @@ __global__ __launch_bounds__(kWave) void k_head(const FrameParams P) {
 template <int VARIANT, int MIN_WAVES = 1, uint32_t S = 1u>
 __global__ __launch_bounds__(kWave, MIN_WAVES) void k_frame(const FrameParams P) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[kLdsWords];
+#if defined(F3D_WAVE_TIMES)  // diagnostics: when did this wave run? (tools/wave_times.py)
+    const unsigned long long t_start = wall_clock64();
+#endif
     LdsPending pend = make_pending(lds, P.terrain);
     uint32_t gx = 0u, gy = 0u;
     const bool active = tile_pixel<S>(P, gx, gy);
@@ -374,6 +377,12 @@ __global__ __launch_bounds__(kWave, MIN_WAVES) void k_frame(const FrameParams P)
         m2 = frame_lanes<S>(P, gx, gy, active, pend);
         if (P.collect_stats != 0u) publish_window_stats(P, active && (threadIdx.x & (S - 1u)) == 0u, m2);
     }
+#if defined(F3D_WAVE_TIMES)
+    if (P.wave_times && threadIdx.x == 0u) {
+        P.wave_times[2u * blockIdx.x] = t_start;
+        P.wave_times[2u * blockIdx.x + 1u] = wall_clock64();
+    }
+#endif
 }
 
 __global__ __launch_bounds__(kWave) void k_gbuffer(const FrameParams P, float4 *gbuffer_n, float *depth) {

@@ -149,6 +149,7 @@ struct FrameParams {
     uint32_t tile_map;              // workgroup -> tile mapping (f3d_kernels.hip tile_pixel)
     uint32_t sample_lanes;          // lanes per pixel in the frame kernel: 1 (frame_pixel), 2, 4, 8 (frame_lanes)
     uint2 *head;                    // sample-lane form only: per-pixel record of k_head {reuse_w bits, flags}
+    unsigned long long *wave_times;  // diagnostics (builds with -DF3D_WAVE_TIMES): {start, end} clock per workgroup
     uint32_t band_begin, band_end;  // image rows THIS launch covers (a band of the strip; the host pipelines bands
                                     // of consecutive frames over several streams, f3d_host.hip)
 };

@@ -173,6 +173,10 @@ int f3d_session_kernel_timing(f3d_session *session, int32_t enable, double *avg_
 /* Sample lanes per pixel the frame kernel of this session runs with (1, 2, 4 or 8); 0 on a NULL session. */
 uint32_t f3d_session_sample_lanes(f3d_session *session);
 
+/* Diagnostics (only in builds with -DF3D_WAVE_TIMES; F3D_STATUS_VALUE otherwise): every frame-kernel workgroup
+ * writes its {start, end} wall clock (100 MHz ticks) to device_buffer[2 * workgroup]; NULL switches it off. */
+int f3d_session_debug_wave_times(f3d_session *session, void *device_buffer);
+
 /* ---- post filter ---------------------------------------------- */
 /* Edge-aware a-trous denoiser: replaces forge3d.denoise.atrous_denoise
  * (reference python/forge3d/denoise.py:18-127).  color / albedo / normal: H x W x 3 f32,
