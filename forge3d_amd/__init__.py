@@ -6,6 +6,8 @@ the PROMETHEUS terrain path tracer behind ``forge3d.hybrid_render_terrain_refere
     clean = f3d.denoise.atrous_denoise(out["rgba"][..., :3] / 255.0, albedo=out["albedo"], normal=out["normal"])
     f3d.numpy_to_png("frame.png", out["rgba"])
 
+    plume = f3d.smoke.domain_from_density(density_zyx); rgba = plume.render_rgba(1920, 1080, eye, target)  # smoke ray-marcher
+
     viewer = f3d.offline.OfflineTerrainViewer(1920, 1080)       # ViewerHandle-shaped facade (parity unpinned)
     viewer.load_terrain("dem.npy", spacing=10.0); viewer.set_orbit_camera(28, 49, 25_000); viewer.snapshot("a.png")
 
@@ -13,9 +15,9 @@ Everything else forge3d offers (raster viewer, cartography, GIS, ...) is out of 
 (SURVEY.md section 8).  There is no CPU fallback: the HIP library must be built
 (``__graft_entry__.build()``) and a gfx950 device must be present.
 """
-from . import denoise, io, offline  # noqa: F401
+from . import denoise, io, offline, smoke  # noqa: F401
 from .io import numpy_to_png, png_to_numpy
 from .path_tracing import hybrid_render_terrain_reference
 
-__all__ = ["hybrid_render_terrain_reference", "denoise", "io", "offline", "numpy_to_png", "png_to_numpy"]
+__all__ = ["hybrid_render_terrain_reference", "denoise", "io", "offline", "smoke", "numpy_to_png", "png_to_numpy"]
 __version__ = "0.1.0"

@@ -172,6 +172,9 @@ struct f3d_session {
     std::vector<Band> bands;
     std::vector<hipStream_t> band_streams;
     hipEvent_t fork = nullptr;  // position of the session stream when a batch of band launches began
+    // longest-first dispatch (f3d_kernels.hip k_tile_order): one-band sessions with the default tile map
+    uint32_t *tile_cost = nullptr, *tile_order = nullptr;
+    int64_t cost_frame = -1, order_frame = -1;  // newest frame whose wave durations are in tile_cost / went into tile_order
     // per-launch timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -354,6 +357,16 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
              (unsigned long long)s.budget);
 
     plan_bands(s, opts ? opts->bands : 0u, opts ? opts->band_streams : 0u);
+    // tile-map digit 4 = the default map WITHOUT longest-first dispatch (A/B)
+    const bool lpt = s.bands.size() == 1 && ((s.variant / 1000) % 10 == 0);
+    if ((s.variant / 1000) % 10 == 4) P.tile_map = 2u;
+    if (lpt) {
+        uint32_t grid = 0;
+        const uint32_t tiles = frame_tile_count(P, &grid);
+        s.tile_cost = (uint32_t *)s.mem.alloc((size_t)tiles * sizeof(uint32_t), "tile costs");
+        s.tile_order = (uint32_t *)s.mem.alloc((size_t)(grid ? grid : 1u) * sizeof(uint32_t), "tile order");
+        hip_check(hipMemsetAsync(s.tile_cost, 0, (size_t)tiles * sizeof(uint32_t), s.stream), "tile cost clear");
+    }
 
     // one-shot G-buffer + AOV pass, render_terrain.rs:1091-1121
     P.frame_index = 0;
@@ -400,7 +413,22 @@ void enqueue_band(f3d_session &s, f3d_session::Band &b, size_t index, uint32_t f
         hip_check(hipEventRecord(e0, b.stream), "event record");
     }
     if (P.sample_lanes > 1u) hip_check(launch_head(P, b.stream), "frame head kernel");
+    // longest-first dispatch: the order is rebuilt from the newest wave durations every kOrderEvery frames
+    // (a tile costs about the same from frame to frame); the first frame of a session runs in image order
+    constexpr int64_t kOrderEvery = 4;
+    P.tile_cost = s.tile_cost;
+    P.tile_order = nullptr;
+    if (s.tile_cost && s.cost_frame >= 0) {
+        if (s.order_frame < 0 || s.cost_frame - s.order_frame >= kOrderEvery) {
+            hip_check(launch_tile_order(P, s.tile_cost, s.tile_order, b.stream), "tile order kernel");
+            s.order_frame = s.cost_frame;
+        }
+        P.tile_order = s.tile_order;
+    }
     hip_check(launch_frame(P, s.variant, b.stream), "frame kernel");
+    if (s.tile_cost) s.cost_frame = (int64_t)frame;
+    P.tile_order = nullptr;
+    P.tile_cost = nullptr;
     if (s.timing) {
         hip_check(hipEventRecord(e1, b.stream), "event record");
         s.events.emplace_back(e0, e1);
@@ -447,13 +475,10 @@ void enqueue_frame(f3d_session &s, uint32_t frame, bool collect, uint32_t part =
 // while the interior bands still render.
 void plan_bands(f3d_session &s, uint32_t want, uint32_t want_streams) {
     const uint32_t rows = s.rows;
-    const bool strip = s.rows != s.height;
-    if (want == 0u) {
-        // automatic: a strip that cannot fill the chip for long is latency-bound (one wave's chain of ~200
-        // dependent steps), so overlap consecutive frames; a whole frame keeps one launch per frame
-        const uint64_t waves = ((uint64_t)rows * s.width * s.params.sample_lanes + 63u) / 64u;
-        want = (strip && waves < 131072u) ? 4u : 1u;
-    }
+    // automatic = one band: cutting the strip into bands on several streams reproduces the image bit for bit
+    // (tests) but measured SLOWER on MI355X (profiles/README.md "band pipelining": kernels of different
+    // streams did not overlap), whereas longest-first dispatch of one launch removes most of the tail
+    if (want == 0u) want = 1u;
     if (want > 64u) want = 64u;
     std::vector<std::pair<uint32_t, uint32_t>> cuts;  // (first row, end row) relative to the strip
     const uint32_t bottom = rows > kHaloRows ? ((rows - kHaloRows) / 8u) * 8u : 0u;

@@ -188,37 +188,98 @@ struct TileShape {
 };
 
 // Pixel of this lane: the launch covers the image rows [band_begin, band_end) of the strip, tiled from band_begin.
+// `tile` returns the tile id of the wave (0xFFFFFFFF: the workgroup is padding).
 template <uint32_t S = 1u>
-__device__ __forceinline__ bool tile_pixel(const FrameParams &P, uint32_t &gx, uint32_t &gy) {
+__device__ __forceinline__ bool tile_pixel(const FrameParams &P, uint32_t &gx, uint32_t &gy, uint32_t &tile,
+                                           const uint32_t *order = nullptr) {
     using Shape = TileShape<S>;
     constexpr uint32_t TW = 1u << Shape::kLogW, TH = 1u << Shape::kLogH;
     const uint32_t rows = P.band_end - P.band_begin;
     const uint32_t tiles_x = (P.cam.width + TW - 1u) >> Shape::kLogW, tiles_y = (rows + TH - 1u) >> Shape::kLogH;
     const uint32_t ntiles = tiles_x * tiles_y;
+    tile = 0xFFFFFFFFu;
     // Workgroup b is observed to run on XCD b % 8.  tile_map picks how tiles are dealt to XCDs:
     //   1  tile id = workgroup id (consecutive tiles on different XCDs)
     //   2  tile ROWS dealt round-robin to XCDs (row r -> XCD r % 8) -- the default: the load
     //      balance of 1 with each XCD's L2 still seeing whole rows of coherent rays
     //   3  contiguous image bands per XCD (best L2 locality, but a sky band idles its XCD:
     //      measured 1.77x slower on the headline scene)
-    uint32_t tile;
-    if (P.tile_map == 1u) {
-        tile = blockIdx.x;
+    // `order` (map 2 only): the same row -> XCD dealing, but each XCD starts its most expensive tiles first.
+    uint32_t t;
+    if (order) {
+        t = order[blockIdx.x];
+    } else if (P.tile_map == 1u) {
+        t = blockIdx.x;
     } else if (P.tile_map == 2u) {
         const uint32_t xcd = blockIdx.x % kNumXcd, i = blockIdx.x / kNumXcd;
         const uint32_t rows_per_xcd = (tiles_y + kNumXcd - 1u) / kNumXcd;
         const uint32_t ty = (i / tiles_x) * kNumXcd + xcd;
         if (i >= rows_per_xcd * tiles_x || ty >= tiles_y) return false;
-        tile = ty * tiles_x + (i % tiles_x);
+        t = ty * tiles_x + (i % tiles_x);
     } else {  // 3 (and anything else): contiguous bands
         const uint32_t per_xcd = (ntiles + kNumXcd - 1u) / kNumXcd;
-        tile = (blockIdx.x % kNumXcd) * per_xcd + blockIdx.x / kNumXcd;
+        t = (blockIdx.x % kNumXcd) * per_xcd + blockIdx.x / kNumXcd;
     }
-    if (tile >= ntiles) return false;
+    if (t >= ntiles) return false;
+    tile = t;
     const uint32_t pixel = threadIdx.x >> Shape::kLogS;  // the S sample lanes of a pixel are neighbours
-    gx = (tile % tiles_x) * TW + (pixel & (TW - 1u));
-    gy = P.band_begin + (tile / tiles_x) * TH + (pixel >> Shape::kLogW);
+    gx = (t % tiles_x) * TW + (pixel & (TW - 1u));
+    gy = P.band_begin + (t / tiles_x) * TH + (pixel >> Shape::kLogW);
     return gx < P.cam.width && gy < P.band_end;
+}
+__device__ __forceinline__ bool tile_pixel(const FrameParams &P, uint32_t &gx, uint32_t &gy) {
+    uint32_t tile;
+    return tile_pixel<1u>(P, gx, gy, tile);
+}
+
+// ---- longest-first dispatch ------------------------------------------------------------------------
+// Wave durations of the frame kernel are heavy-tailed (headline frame: median 20 us, 99th percentile 560 us,
+// maximum 1.4 ms -- tools/wave_times.py): dispatched in image order, the long waves that happen to start late
+// keep the kernel alive while the chip is empty (2.96 ms against 2.69 ms of perfectly packed wave time; a thin
+// multi-GPU strip: 0.63 against 0.31 ms).  A tile costs about the same in consecutive frames, so every wave
+// leaves its duration in tile_cost and k_tile_order sorts the tiles of each XCD (rows stay dealt round-robin to
+// the XCDs) by descending cost class for the next frames: list scheduling, longest first.  One workgroup per
+// XCD: LDS histogram over 64 logarithmic classes, prefix, scatter; the order inside a class is whatever the
+// atomics give -- dispatch order never changes a result.
+struct TileOrderParams {
+    const uint32_t *cost;  // per tile, 100 MHz ticks
+    uint32_t *order;       // per frame-kernel workgroup: tile id, 0xFFFFFFFF = padding
+    uint32_t tiles_x, tiles_y;
+};
+__device__ __forceinline__ uint32_t cost_class(uint32_t ticks) {  // 0 = most expensive ... 63 = cheapest
+    const uint32_t v = ticks | 1u, lg = 31u - (uint32_t)__clz((int)v);
+    const uint32_t frac = lg >= 2u ? (v >> (lg - 2u)) & 3u : 0u;
+    const uint32_t q = lg * 4u + frac;  // log2 with two fractional bits; 8 us ... 2.6 ms -> 38 ... 71
+    const uint32_t c = q > 71u ? 71u : q;
+    return c < 9u ? 63u : (71u - c > 63u ? 63u : 71u - c);
+}
+__global__ __launch_bounds__(1024) void k_tile_order(const TileOrderParams B) {
+    __shared__ uint32_t hist[65];
+    const uint32_t xcd = blockIdx.x, rows_per_xcd = (B.tiles_y + kNumXcd - 1u) / kNumXcd, slots = rows_per_xcd * B.tiles_x;
+    if (threadIdx.x < 65u) hist[threadIdx.x] = 0u;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < slots; i += blockDim.x) {
+        const uint32_t ty = (i / B.tiles_x) * kNumXcd + xcd;
+        const uint32_t cls = ty < B.tiles_y ? cost_class(B.cost[ty * B.tiles_x + i % B.tiles_x]) : 64u;
+        atomicAdd(&hist[cls], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        uint32_t run = 0u;
+        for (uint32_t c = 0u; c < 65u; c++) {
+            const uint32_t n = hist[c];
+            hist[c] = run;
+            run += n;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < slots; i += blockDim.x) {
+        const uint32_t ty = (i / B.tiles_x) * kNumXcd + xcd;
+        const bool real = ty < B.tiles_y;
+        const uint32_t tile = real ? ty * B.tiles_x + i % B.tiles_x : 0xFFFFFFFFu;
+        const uint32_t cls = real ? cost_class(B.cost[tile]) : 64u;
+        B.order[atomicAdd(&hist[cls], 1u) * kNumXcd + xcd] = tile;
+    }
 }
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
@@ -363,12 +424,10 @@ __global__ __launch_bounds__(kWave) void k_head(const FrameParams P) {
 template <int VARIANT, int MIN_WAVES = 1, uint32_t S = 1u>
 __global__ __launch_bounds__(kWave, MIN_WAVES) void k_frame(const FrameParams P) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[kLdsWords];
-#if defined(F3D_WAVE_TIMES)  // diagnostics: when did this wave run? (tools/wave_times.py)
-    const unsigned long long t_start = wall_clock64();
-#endif
+    const unsigned long long t_start = wall_clock64();  // 100 MHz: the wave's cost for the next tile ordering
     LdsPending pend = make_pending(lds, P.terrain);
-    uint32_t gx = 0u, gy = 0u;
-    const bool active = tile_pixel<S>(P, gx, gy);
+    uint32_t gx = 0u, gy = 0u, tile;
+    const bool active = tile_pixel<S>(P, gx, gy, tile, P.tile_order);
     float m2 = 0.0f;
     if constexpr (S == 1u) {
         if (active) m2 = frame_pixel(P, gx, gy, pend);
@@ -377,12 +436,16 @@ __global__ __launch_bounds__(kWave, MIN_WAVES) void k_frame(const FrameParams P)
         m2 = frame_lanes<S>(P, gx, gy, active, pend);
         if (P.collect_stats != 0u) publish_window_stats(P, active && (threadIdx.x & (S - 1u)) == 0u, m2);
     }
-#if defined(F3D_WAVE_TIMES)
-    if (P.wave_times && threadIdx.x == 0u) {
-        P.wave_times[2u * blockIdx.x] = t_start;
-        P.wave_times[2u * blockIdx.x + 1u] = wall_clock64();
-    }
+    if (threadIdx.x == 0u) {
+        const unsigned long long t_end = wall_clock64();
+        if (P.tile_cost && tile != 0xFFFFFFFFu) P.tile_cost[tile] = (uint32_t)(t_end - t_start);
+#if defined(F3D_WAVE_TIMES)  // diagnostics: when did this wave run? (tools/wave_times.py)
+        if (P.wave_times) {
+            P.wave_times[2u * blockIdx.x] = t_start;
+            P.wave_times[2u * blockIdx.x + 1u] = t_end;
+        }
 #endif
+    }
 }
 
 __global__ __launch_bounds__(kWave) void k_gbuffer(const FrameParams P, float4 *gbuffer_n, float *depth) {
@@ -492,6 +555,23 @@ hipError_t launch_frame(const FrameParams &p, int variant, hipStream_t stream) {
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+hipError_t launch_tile_order(const FrameParams &p, const uint32_t *cost, uint32_t *order, hipStream_t stream) {
+    const uint32_t lanes = p.sample_lanes ? p.sample_lanes : 1u;
+    const uint32_t log_s = lanes == 1u ? 0u : (lanes == 2u ? 1u : (lanes == 4u ? 2u : 3u));
+    const uint32_t log_w = lanes <= 2u ? 3u : 2u, log_h = 6u - log_s - log_w;  // TileShape<S>
+    const uint32_t rows = p.band_end - p.band_begin;
+    TileOrderParams B{cost, order, (p.cam.width + (1u << log_w) - 1u) >> log_w, (rows + (1u << log_h) - 1u) >> log_h};
+    hipLaunchKernelGGL(k_tile_order, dim3(kNumXcd), dim3(1024), 0, stream, B);
+    return hipGetLastError();
+}
+uint32_t frame_tile_count(const FrameParams &p, uint32_t *grid) {
+    const uint32_t lanes = p.sample_lanes ? p.sample_lanes : 1u;
+    const uint32_t log_s = lanes == 1u ? 0u : (lanes == 2u ? 1u : (lanes == 4u ? 2u : 3u));
+    const uint32_t log_w = lanes <= 2u ? 3u : 2u, log_h = 6u - log_s - log_w;
+    const uint32_t rows = p.band_end - p.band_begin;
+    if (grid) *grid = frame_grid(p, lanes);
+    return ((p.cam.width + (1u << log_w) - 1u) >> log_w) * ((rows + (1u << log_h) - 1u) >> log_h);
 }
 hipError_t launch_gbuffer(const FrameParams &p, float4 *gbuffer_n, float *depth, hipStream_t stream) {
     hipLaunchKernelGGL(k_gbuffer, dim3(frame_grid(p)), dim3(kWave), 0, stream, p, gbuffer_n, depth);

@@ -28,6 +28,9 @@ struct ResolveParams {
 
 hipError_t launch_head(const FrameParams &p, hipStream_t stream);  // sample-lane form: before launch_frame
 hipError_t launch_frame(const FrameParams &p, int variant, hipStream_t stream);
+// longest-first dispatch of the frame kernel: tile count (and grid) of the current band, and the ordering kernel
+uint32_t frame_tile_count(const FrameParams &p, uint32_t *grid);
+hipError_t launch_tile_order(const FrameParams &p, const uint32_t *cost, uint32_t *order, hipStream_t stream);
 hipError_t launch_gbuffer(const FrameParams &p, float4 *gbuffer_n, float *depth, hipStream_t stream);
 hipError_t launch_resolve(const ResolveParams &p, hipStream_t stream);
 hipError_t launch_ray_batch(const RayBatchParams &p, hipStream_t stream);

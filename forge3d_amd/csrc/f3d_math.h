@@ -183,6 +183,26 @@ F3D_HD float acos_det(float x) {  // x in [-1, 1]
     return kHalfPi - asin_half(x);
 }
 
+// e^x with every operation spelled (cephes expf scheme: n = rint(x log2 e), two-constant reduction, degree-5
+// polynomial, scaling through the exponent bits): < 2 ulp, and the same bits on host and device.
+F3D_HD float exp_det(float x) {
+    if (x > 88.0f) return __builtin_inff();
+    if (x < -103.0f) return 0.0f;
+    const float n = f_rint(x * 1.44269504088896341f);
+    float r = f_fma(n, -0.693359375f, x);
+    r = f_fma(n, 2.12194440e-4f, r);
+    const float z = r * r;
+    float p = f_fma(1.9875691500e-4f, r, 1.3981999507e-3f);
+    p = f_fma(p, r, 8.3334519073e-3f);
+    p = f_fma(p, r, 4.1665795894e-2f);
+    p = f_fma(p, r, 1.6666665459e-1f);
+    p = f_fma(p, r, 5.0000001201e-1f);
+    const float y = f_fma(p, z, r) + 1.0f;
+    const int e = (int)n;
+    if (e < -126) return (y * f_from_bits((uint32_t)(e + 64 + 127) << 23)) * 5.42101086242752217e-20f;  // 2^-64
+    return y * f_from_bits((uint32_t)(e + 127) << 23);
+}
+
 // ---- IEEE binary16 storage rounding (RGBA16F targets of the reference) ----
 F3D_HD uint16_t half_bits(float f) {
     uint32_t x = f_bits(f);

@@ -149,6 +149,10 @@ struct FrameParams {
     uint32_t tile_map;              // workgroup -> tile mapping (f3d_kernels.hip tile_pixel)
     uint32_t sample_lanes;          // lanes per pixel in the frame kernel: 1 (frame_pixel), 2, 4, 8 (frame_lanes)
     uint2 *head;                    // sample-lane form only: per-pixel record of k_head {reuse_w bits, flags}
+    // longest-first dispatch (f3d_kernels.hip k_tile_order): frame-kernel workgroup b renders tile tile_order[b]
+    // (null: the tile_map formula); every wave leaves its duration in tile_cost[tile] for the next ordering
+    const uint32_t *tile_order;
+    uint32_t *tile_cost;
     unsigned long long *wave_times;  // diagnostics (builds with -DF3D_WAVE_TIMES): {start, end} clock per workgroup
     uint32_t band_begin, band_end;  // image rows THIS launch covers (a band of the strip; the host pipelines bands
                                     // of consecutive frames over several streams, f3d_host.hip)

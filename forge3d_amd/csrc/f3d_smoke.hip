@@ -1,0 +1,379 @@
+// forge3d_amd/csrc/f3d_smoke.hip -- smoke volume ray-marcher on gfx950 (BASELINE.json config 5).
+//
+// Reference: SmokeVolume::raymarch_rgba / raymarch_projection_rgba / march_ray_rgba / sun_transmittance,
+// src/smoke/render.rs:7-330 with sampling.rs and types.rs -- single-threaded CPU Rust, six separate f32 fields,
+// every field sampled at every step.  Here: one lane per pixel, 8x8 pixel tiles per wave (neighbouring rays walk
+// neighbouring voxels), and the six fields re-packed into two records per voxel so that a trilinear tap is
+// 8 x dwordx4 (+ 8 x dwordx2 only where there is smoke):
+//     A = (density, soot, age, temperature)   everything the extinction and the self-shadow march need
+//     B = (humidity, emission)                colour / glow only, read when density > 1e-5 like the reference's use
+// Results are bit-identical to oracle/smoke_oracle.c (same operation order, no contraction, exp_det).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <exception>
+
+#include "f3d_setup.h"
+
+using namespace f3d;
+
+namespace {
+
+struct SmokeSettingsDev {
+    float density_scale, extinction, scattering, absorption, phase_g;
+    uint32_t max_steps, self_shadow, shadow_steps;
+    float jitter_strength, exposure, soot_absorption, fire_glow;
+    V3 thin, dense;
+};
+
+struct SmokeParams {
+    const float4 *rec_a;  // density, soot, age, temperature
+    const float2 *rec_b;  // humidity, emission
+    uint32_t nx, ny, nz;
+    V3 origin, voxel, bmin, bmax;
+    uint32_t frame_index, width, height, mode;  // mode 0 perspective, 1 projection
+    V3 eye, forward, right, camera_up, sun, view;
+    float tan_half_fov, aspect, diagonal, step, shadow_step;
+    SmokeSettingsDev st;
+    uint8_t *out;
+};
+
+struct PackParams {
+    const float *density, *temperature, *soot, *humidity, *emission, *age;
+    float4 *rec_a;
+    float2 *rec_b;
+    uint64_t n;
+};
+
+__global__ void k_smoke_pack(const PackParams P) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n) return;
+    P.rec_a[i] = float4{P.density[i], P.soot[i], P.age[i], P.temperature[i]};
+    P.rec_b[i] = float2{P.humidity[i], P.emission[i]};
+}
+
+__device__ __forceinline__ float lerp_ref(float a, float b, float t) { return a + (b - a) * t; }  // sampling.rs:88-90
+__device__ __forceinline__ V3 vadd(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 vscale(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float vdot(V3 a, V3 b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }  // glam order
+
+// trilinear tap set of grid_coord_from_world + sample_scalar (types.rs:375-381, sampling.rs:1-34)
+struct Tap {
+    uint32_t i000, dx, dy, dz;  // linear index of the low corner, strides to the high ones (0 at the border)
+    float fx, fy, fz;
+};
+__device__ __forceinline__ Tap make_tap(const SmokeParams &P, V3 pos) {
+    const float gx = (pos.x - P.origin.x) / P.voxel.x - 0.5f, gy = (pos.y - P.origin.y) / P.voxel.y - 0.5f,
+                gz = (pos.z - P.origin.z) / P.voxel.z - 0.5f;
+    const float x = f_clamp(gx, 0.0f, (float)(P.nx - 1u)), y = f_clamp(gy, 0.0f, (float)(P.ny - 1u)),
+                z = f_clamp(gz, 0.0f, (float)(P.nz - 1u));
+    const uint32_t x0 = (uint32_t)f_floor(x), y0 = (uint32_t)f_floor(y), z0 = (uint32_t)f_floor(z);
+    Tap t;
+    t.i000 = (z0 * P.ny + y0) * P.nx + x0;
+    t.dx = x0 + 1u < P.nx ? 1u : 0u;
+    t.dy = y0 + 1u < P.ny ? P.nx : 0u;
+    t.dz = z0 + 1u < P.nz ? P.nx * P.ny : 0u;
+    t.fx = x - (float)x0;
+    t.fy = y - (float)y0;
+    t.fz = z - (float)z0;
+    return t;
+}
+__device__ __forceinline__ float tri(const Tap &t, float c000, float c100, float c010, float c110, float c001, float c101,
+                                     float c011, float c111) {
+    const float c00 = lerp_ref(c000, c100, t.fx), c10 = lerp_ref(c010, c110, t.fx);
+    const float c01 = lerp_ref(c001, c101, t.fx), c11 = lerp_ref(c011, c111, t.fx);
+    return lerp_ref(lerp_ref(c00, c10, t.fy), lerp_ref(c01, c11, t.fy), t.fz);
+}
+#define F3D_TRI(buf, member)                                                                                    \
+    tri(t, buf[t.i000].member, buf[t.i000 + t.dx].member, buf[t.i000 + t.dy].member, buf[t.i000 + t.dx + t.dy].member, \
+        buf[t.i000 + t.dz].member, buf[t.i000 + t.dx + t.dz].member, buf[t.i000 + t.dy + t.dz].member,               \
+        buf[t.i000 + t.dx + t.dy + t.dz].member)
+
+__device__ __forceinline__ float smoothstep_ref(float e0, float e1, float x) {  // render_smoothstep, render.rs:405-408
+    const float t = f_clamp((x - e0) / f_max(e1 - e0, 1.0e-6f), 0.0f, 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+
+// ray_box_intersection, render.rs:363-392 (f32::min / max ignore a NaN operand, like fminf / fmaxf)
+__device__ __forceinline__ bool ray_box(V3 o, V3 d, V3 mn, V3 mx, float &near_t, float &far_t) {
+    const float inf = __builtin_inff();
+    const float ix = f_abs(d.x) > 1.0e-12f ? 1.0f / d.x : inf, iy = f_abs(d.y) > 1.0e-12f ? 1.0f / d.y : inf,
+                iz = f_abs(d.z) > 1.0e-12f ? 1.0f / d.z : inf;
+    const float ax = (mn.x - o.x) * ix, bx = (mx.x - o.x) * ix, ay = (mn.y - o.y) * iy, by = (mx.y - o.y) * iy,
+                az = (mn.z - o.z) * iz, bz = (mx.z - o.z) * iz;
+    near_t = f_max(f_max(f_min(ax, bx), f_min(ay, by)), f_min(az, bz));
+    far_t = f_min(f_min(f_max(ax, bx), f_max(ay, by)), f_max(az, bz));
+    return far_t >= f_max(near_t, 0.0f);
+}
+
+// sun_transmittance, render.rs:290-330
+__device__ float sun_transmittance(const SmokeParams &P, V3 start) {
+    float t0, t1;
+    if (!ray_box(vadd(start, vscale(P.sun, P.shadow_step)), P.sun, P.bmin, P.bmax, t0, t1)) return 1.0f;
+    t0 = f_max(t0, 0.0f);
+    float od = 0.0f;
+    for (uint32_t i = 0u; i < P.st.shadow_steps; i++) {
+        const float tt = t0 + ((float)i + 0.5f) * P.shadow_step;
+        if (tt > t1) break;
+        const Tap t = make_tap(P, vadd(start, vscale(P.sun, P.shadow_step + tt)));
+        const float density = F3D_TRI(P.rec_a, x), soot = F3D_TRI(P.rec_a, y), age = f_max(F3D_TRI(P.rec_a, z), 0.0f);
+        const float age_t = smoothstep_ref(1.6f, 17.0f, age);
+        const float gate = 0.50f + 0.50f * smoothstep_ref(0.045f, 0.34f, density);
+        od += density * P.st.density_scale * (1.0f - 0.58f * age_t) * gate * P.st.extinction *
+              (1.0f + soot * P.st.soot_absorption) * P.shadow_step;
+        if (od > 8.0f) break;
+    }
+    return f_clamp(exp_det(-od), 0.0f, 1.0f);
+}
+
+__device__ __forceinline__ V3 mix3(V3 a, V3 b, float t) {
+    return V3{lerp_ref(a.x, b.x, t), lerp_ref(a.y, b.y, t), lerp_ref(a.z, b.z, t)};
+}
+__device__ __forceinline__ uint8_t to_u8(float v) { return (uint8_t)(f_clamp(v, 0.0f, 1.0f) * 255.0f + 0.5f); }
+
+// march_ray_rgba, render.rs:192-288
+__device__ uchar4 march_ray(const SmokeParams &P, V3 origin, V3 dir, float t0, float t1, uint32_t seed) {
+    uint32_t v = seed;  // hash01, sampling.rs:96-103
+    v ^= v >> 16;
+    v *= 0x7FEB352Du;
+    v ^= v >> 15;
+    v *= 0x846CA68Bu;
+    v ^= v >> 16;
+    const float jitter = ((float)v / 4294967296.0f - 0.5f) * P.st.jitter_strength * P.step;
+    float t = f_max(t0 + jitter, 0.0f), transmittance = 1.0f;
+    V3 rgb = V3{0.0f, 0.0f, 0.0f};
+    const float cos_theta = f_clamp(vdot(dir, P.sun), -1.0f, 1.0f);
+    const float g2 = P.st.phase_g * P.st.phase_g;  // henyey_greenstein, render.rs:394-398 (powf(d, 1.5) = d sqrt(d))
+    const float denom = f_max(1.0f + g2 - 2.0f * P.st.phase_g * cos_theta, 1.0e-4f);
+    const float phase = (1.0f - g2) / (4.0f * kPi * (denom * f_sqrt(denom)));
+    for (uint32_t steps = 0u; t < t1 && steps < P.st.max_steps && transmittance > 0.01f; steps++, t += P.step) {
+        const V3 p = vadd(origin, vscale(dir, t));
+        const Tap tp = make_tap(P, p);
+        const Tap &t_ = tp;
+#define t t_
+        const float s_density = F3D_TRI(P.rec_a, x), s_soot = F3D_TRI(P.rec_a, y), s_age = f_max(F3D_TRI(P.rec_a, z), 0.0f);
+#undef t
+        const float age_t = smoothstep_ref(1.6f, 17.0f, s_age);
+        const float gate = 0.50f + 0.50f * smoothstep_ref(0.045f, 0.34f, s_density);
+        const float density = f_max(s_density * P.st.density_scale * (1.0f - 0.58f * age_t) * gate, 0.0f);
+        if (!(density > 1.0e-5f)) continue;
+#define t t_
+        const float s_temperature = F3D_TRI(P.rec_a, w), s_humidity = F3D_TRI(P.rec_b, x), s_emission = F3D_TRI(P.rec_b, y);
+#undef t
+        const float sigma_t = density * P.st.extinction * (1.0f + s_soot * P.st.soot_absorption * 0.85f);
+        const float seg_tr = f_clamp(exp_det(-sigma_t * P.step), 0.0f, 1.0f);
+        const float seg_w = sigma_t > 1.0e-6f ? (1.0f - seg_tr) / sigma_t : P.step;
+        const float light = P.st.self_shadow ? sun_transmittance(P, p) : 1.0f;
+        // smoke_color, render.rs:343-361
+        const float body = f_clamp(s_density * 1.45f + s_soot * 1.35f, 0.0f, 1.0f);
+        V3 col = mix3(P.st.thin, P.st.dense, body);
+        col = mix3(col, V3{0.36f, 0.39f, 0.43f}, f_clamp(s_age / 9.0f, 0.0f, 1.0f) * 0.42f);
+        const float milk = f_clamp(s_humidity, 0.0f, 1.0f) * (0.18f + 0.42f * body);
+        col = mix3(col, V3{0.93f, 0.92f, 0.84f}, f_clamp(milk, 0.0f, 0.38f));
+        const float freshness = f_clamp(1.0f - s_age / 17.0f, 0.0f, 1.0f);
+        col = mix3(col, V3{0.95f, 0.62f, 0.28f}, f_clamp(s_temperature * 0.12f * freshness, 0.0f, 1.0f) * 0.07f);
+
+        const float albedo = f_clamp(P.st.scattering / (P.st.scattering + P.st.absorption + s_soot * 0.55f + 1.0e-5f), 0.02f, 0.98f);
+        const float sigma_s = sigma_t * albedo;
+        const V3 sun_rad = vscale(V3{1.0f, 0.96f, 0.84f}, 11.5f);
+        const V3 sky = vscale(vscale(V3{0.52f, 0.60f, 0.72f}, 0.36f + 0.26f * f_clamp(1.0f - light, 0.0f, 1.0f)),
+                              f_clamp(1.0f - s_soot * 0.32f, 0.50f, 1.0f));
+        const V3 bounce = vscale(vscale(V3{0.58f, 0.54f, 0.48f}, 0.070f), f_clamp(1.0f - p.y / f_max(P.bmax.y, 1.0f), 0.0f, 1.0f));
+        const float powder = f_clamp(1.0f - exp_det(-sigma_t * P.step * 2.2f), 0.0f, 1.0f);
+        const float pw = powder * 0.055f * f_sqrt(light);
+        const V3 cs = vscale(col, sigma_s);
+        const V3 multiple = cs * vadd(vadd(sky, bounce), V3{pw, pw, pw});
+        const V3 direct = vscale(vscale(cs * sun_rad, phase), light);
+        const float fresh_heat = s_temperature * freshness * freshness;
+        const V3 emission = vscale(V3{1.0f, 0.30f, 0.055f}, f_clamp((fresh_heat * 0.10f + s_emission * 1.18f) * P.st.fire_glow, 0.0f, 5.0f));
+        const V3 source = vadd(vadd(direct, multiple), emission);
+        rgb = vadd(rgb, vscale(vscale(source, seg_w), transmittance));
+        transmittance *= seg_tr;
+    }
+    const float alpha = f_clamp(1.0f - transmittance, 0.0f, 1.0f);
+    const V3 straight = alpha > 1.0e-5f ? V3{rgb.x / alpha, rgb.y / alpha, rgb.z / alpha} : rgb;
+    const V3 e = vscale(straight, P.st.exposure);
+    return uchar4{to_u8(e.x / (1.0f + e.x)), to_u8(e.y / (1.0f + e.y)), to_u8(e.z / (1.0f + e.z)), to_u8(alpha)};
+}
+
+__global__ __launch_bounds__(64) void k_smoke(const SmokeParams P) {
+    const uint32_t tiles_x = (P.width + 7u) / 8u;
+    const uint32_t x = (blockIdx.x % tiles_x) * 8u + (threadIdx.x & 7u), y = (blockIdx.x / tiles_x) * 8u + (threadIdx.x >> 3);
+    if (x >= P.width || y >= P.height) return;
+    V3 origin, dir;
+    uint32_t seed = x * 73856093u + y * 19349663u + P.frame_index;
+    if (P.mode == 0u) {  // raymarch_rgba, render.rs:69-75
+        const float px = (((float)x + 0.5f) / (float)P.width * 2.0f - 1.0f) * P.aspect * P.tan_half_fov;
+        const float py = (1.0f - ((float)y + 0.5f) / (float)P.height * 2.0f) * P.tan_half_fov;
+        const V3 d = vadd(vadd(P.forward, vscale(P.right, px)), vscale(P.camera_up, py));
+        dir = vscale(d, 1.0f / f_sqrt(vdot(d, d)));
+        origin = P.eye;
+    } else {  // raymarch_projection_rgba, render.rs:140-160
+        const float fz = ((float)y + 0.5f) / (float)P.height, fx = ((float)x + 0.5f) / (float)P.width;
+        const V3 plane = V3{lerp_ref(P.bmin.x, P.bmax.x, fx), (P.bmin.y + P.bmax.y) * 0.5f, lerp_ref(P.bmin.z, P.bmax.z, fz)};
+        dir = P.view;
+        origin = V3{plane.x - dir.x * P.diagonal, plane.y - dir.y * P.diagonal, plane.z - dir.z * P.diagonal};
+        seed += 0x9e3779b9u;
+    }
+    uchar4 px4 = uchar4{0, 0, 0, 0};
+    float t0, t1;
+    if (ray_box(origin, dir, P.bmin, P.bmax, t0, t1)) px4 = march_ray(P, origin, dir, f_max(t0, 0.0f), t1, seed);
+    reinterpret_cast<uchar4 *>(P.out)[(size_t)y * P.width + x] = px4;
+}
+
+void hip_ok(hipError_t e, const char *what) {
+    if (e != hipSuccess) fail(F3D_STATUS_DEVICE, "HIP failure in %s: %s", what, hipGetErrorString(e));
+}
+
+V3 normalize_or_zero(V3 a) {  // glam Vec3::normalize_or_zero
+    const float rcp = 1.0f / std::sqrt((a.x * a.x) + (a.y * a.y) + (a.z * a.z));
+    if (std::isfinite(rcp) && rcp > 0.0f) return V3{a.x * rcp, a.y * rcp, a.z * rcp};
+    return V3{0.0f, 0.0f, 0.0f};
+}
+float len2(V3 a) { return (a.x * a.x) + (a.y * a.y) + (a.z * a.z); }
+V3 cross_glam(V3 a, V3 b) { return V3{a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+
+void validate_settings(const f3d_smoke_settings &s) {  // SmokeRenderSettings::validate, types.rs:271-316
+    const char *names[11] = {"density_scale", "extinction", "scattering", "absorption", "phase_g", "step_size",
+                             "shadow_step_size", "jitter_strength", "exposure", "soot_absorption", "fire_glow"};
+    const float vals[11] = {s.density_scale, s.extinction, s.scattering, s.absorption, s.phase_g, s.step_size,
+                            s.shadow_step_size, s.jitter_strength, s.exposure, s.soot_absorption, s.fire_glow};
+    for (int i = 0; i < 11; i++)
+        if (!std::isfinite(vals[i])) fail(F3D_STATUS_RENDER, "%s must be finite", names[i]);
+    if (s.density_scale < 0.0f || s.extinction < 0.0f || s.scattering < 0.0f)
+        fail(F3D_STATUS_RENDER, "density_scale, extinction, and scattering must be >= 0");
+    if (s.absorption < 0.0f || s.soot_absorption < 0.0f || s.fire_glow < 0.0f)
+        fail(F3D_STATUS_RENDER, "absorption, soot_absorption, and fire_glow must be >= 0");
+    if (!(s.phase_g >= -0.99f && s.phase_g <= 0.99f)) fail(F3D_STATUS_RENDER, "phase_g must be in [-0.99, 0.99]");
+    if (s.step_size < 0.0f || s.shadow_step_size < 0.0f) fail(F3D_STATUS_RENDER, "step sizes must be >= 0");
+    if (s.max_steps == 0u || s.shadow_steps == 0u) fail(F3D_STATUS_RENDER, "max_steps and shadow_steps must be >= 1");
+    if (!(s.jitter_strength >= 0.0f && s.jitter_strength <= 1.0f)) fail(F3D_STATUS_RENDER, "jitter_strength must be in [0, 1]");
+    for (int c = 0; c < 2; c++)
+        for (int a = 0; a < 3; a++) {
+            const float v = c ? s.dense_color[a] : s.thin_color[a];
+            if (!std::isfinite(v) || v < 0.0f)
+                fail(F3D_STATUS_RENDER, "%s[%d] must be finite and >= 0", c ? "dense_color" : "thin_color", a);
+        }
+}
+
+void validate_volume(const f3d_smoke_volume &v) {  // SmokeDomainConfig::validate, types.rs:29-62
+    for (int a = 0; a < 3; a++)
+        if (v.dims[a] < 2u) fail(F3D_STATUS_VALUE, "dims[%d] must be >= 2", a);
+    const uint64_t n = (uint64_t)v.dims[0] * v.dims[1] * v.dims[2];
+    if (n > 256ull * 256ull * 256ull)
+        fail(F3D_STATUS_VALUE, "smoke domain has %llu voxels, exceeding CPU reference limit %llu", (unsigned long long)n,
+             256ull * 256ull * 256ull);
+    for (int a = 0; a < 3; a++)
+        if (!std::isfinite(v.voxel_size[a]) || v.voxel_size[a] <= 0.0f) fail(F3D_STATUS_VALUE, "voxel_size[%d] must be finite and > 0", a);
+    for (int a = 0; a < 3; a++)
+        if (!std::isfinite(v.origin[a])) fail(F3D_STATUS_VALUE, "origin[%d] must be finite", a);
+    if (!v.density || !v.temperature || !v.soot || !v.humidity || !v.emission || !v.age)
+        fail(F3D_STATUS_VALUE, "all six smoke fields are required");
+}
+
+}  // namespace
+
+extern "C" int f3d_smoke_render(const f3d_smoke_volume *vol, const f3d_smoke_view *view, const f3d_smoke_settings *settings,
+                                uint8_t *rgba, double *kernel_seconds, char *err, size_t errlen) {
+    if (err && errlen) err[0] = 0;
+    std::vector<void *> owned;
+    int rc = F3D_STATUS_OK;
+    try {
+        if (!vol || !view || !settings || !rgba) fail(F3D_STATUS_VALUE, "null argument");
+        validate_settings(*settings);
+        validate_volume(*vol);
+        if (view->width == 0u || view->height == 0u) fail(F3D_STATUS_RENDER, "width and height must be >= 1");
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+            fail(F3D_STATUS_DEVICE, "no HIP device available: libf3dhip has no CPU fallback");
+        SmokeParams P{};
+        P.nx = vol->dims[0];
+        P.ny = vol->dims[1];
+        P.nz = vol->dims[2];
+        P.origin = V3{vol->origin[0], vol->origin[1], vol->origin[2]};
+        P.voxel = V3{vol->voxel_size[0], vol->voxel_size[1], vol->voxel_size[2]};
+        P.bmin = P.origin;
+        P.bmax = V3{vol->origin[0] + (float)vol->dims[0] * vol->voxel_size[0], vol->origin[1] + (float)vol->dims[1] * vol->voxel_size[1],
+                    vol->origin[2] + (float)vol->dims[2] * vol->voxel_size[2]};
+        P.frame_index = vol->frame_index;
+        P.width = view->width;
+        P.height = view->height;
+        P.mode = view->projection ? 1u : 0u;
+        P.sun = normalize_or_zero(V3{view->sun_direction[0], view->sun_direction[1], view->sun_direction[2]});
+        if (P.mode == 0u) {
+            if (!std::isfinite(view->fovy_deg) || view->fovy_deg <= 0.0f || view->fovy_deg >= 179.0f)
+                fail(F3D_STATUS_RENDER, "fovy_deg must be finite and in (0, 179)");
+            P.eye = V3{view->camera_pos[0], view->camera_pos[1], view->camera_pos[2]};
+            const V3 target = V3{view->target[0], view->target[1], view->target[2]};
+            P.forward = normalize_or_zero(V3{target.x - P.eye.x, target.y - P.eye.y, target.z - P.eye.z});
+            if (len2(P.forward) < 1.0e-12f) fail(F3D_STATUS_RENDER, "camera_pos and target must not be equal");
+            const V3 up = normalize_or_zero(V3{view->up[0], view->up[1], view->up[2]});
+            if (len2(up) < 1.0e-12f) fail(F3D_STATUS_RENDER, "up vector must not be zero");
+            P.right = normalize_or_zero(cross_glam(P.forward, up));
+            P.camera_up = normalize_or_zero(cross_glam(P.right, P.forward));
+            if (len2(P.sun) < 1.0e-12f) fail(F3D_STATUS_RENDER, "sun_direction must not be zero");
+            P.tan_half_fov = std::tan((view->fovy_deg * (3.14159265358979323846f / 180.0f)) * 0.5f);
+            P.aspect = (float)view->width / (float)view->height;
+        } else {
+            P.view = normalize_or_zero(V3{view->view_direction[0], view->view_direction[1], view->view_direction[2]});
+            if (len2(P.view) < 1.0e-12f) fail(F3D_STATUS_RENDER, "view_direction must not be zero");
+            if (len2(P.sun) < 1.0e-12f) fail(F3D_STATUS_RENDER, "sun_direction must not be zero");
+        }
+        const float min_step = std::fmax(std::fmin(std::fmin(std::fmin(INFINITY, vol->voxel_size[0]), vol->voxel_size[1]), vol->voxel_size[2]), 1.0e-4f);
+        P.step = settings->step_size > 0.0f ? settings->step_size : min_step * 0.75f;
+        P.shadow_step = settings->shadow_step_size > 0.0f ? settings->shadow_step_size : P.step * 2.0f;
+        const V3 ext = V3{P.bmax.x - P.bmin.x, P.bmax.y - P.bmin.y, P.bmax.z - P.bmin.z};
+        P.diagonal = std::fmax(std::sqrt(len2(ext)), P.step * 2.0f);
+        P.st = SmokeSettingsDev{settings->density_scale, settings->extinction, settings->scattering, settings->absorption,
+                                settings->phase_g, settings->max_steps, settings->self_shadow ? 1u : 0u, settings->shadow_steps,
+                                settings->jitter_strength, settings->exposure, settings->soot_absorption, settings->fire_glow,
+                                V3{settings->thin_color[0], settings->thin_color[1], settings->thin_color[2]},
+                                V3{settings->dense_color[0], settings->dense_color[1], settings->dense_color[2]}};
+
+        auto alloc = [&](size_t bytes, const char *what) {
+            void *p = nullptr;
+            hip_ok(hipMalloc(&p, bytes), what);
+            owned.push_back(p);
+            return p;
+        };
+        const uint64_t n = (uint64_t)P.nx * P.ny * P.nz;
+        const float *host[6] = {vol->density, vol->temperature, vol->soot, vol->humidity, vol->emission, vol->age};
+        float *dev[6];
+        for (int i = 0; i < 6; i++) {
+            dev[i] = (float *)alloc(n * sizeof(float), "smoke field");
+            hip_ok(hipMemcpy(dev[i], host[i], n * sizeof(float), hipMemcpyHostToDevice), "smoke field upload");
+        }
+        float4 *rec_a = (float4 *)alloc(n * sizeof(float4), "smoke records");
+        float2 *rec_b = (float2 *)alloc(n * sizeof(float2), "smoke records");
+        const PackParams pack{dev[0], dev[1], dev[2], dev[3], dev[4], dev[5], rec_a, rec_b, n};
+        hipLaunchKernelGGL(k_smoke_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, pack);
+        hip_ok(hipGetLastError(), "smoke pack kernel");
+        P.rec_a = rec_a;
+        P.rec_b = rec_b;
+        const size_t px = (size_t)P.width * P.height;
+        P.out = (uint8_t *)alloc(px * 4, "smoke rgba");
+        hipEvent_t e0, e1;
+        hip_ok(hipEventCreate(&e0), "event");
+        hip_ok(hipEventCreate(&e1), "event");
+        hip_ok(hipEventRecord(e0, nullptr), "event");
+        const uint32_t tiles = ((P.width + 7u) / 8u) * ((P.height + 7u) / 8u);
+        hipLaunchKernelGGL(k_smoke, dim3(tiles), dim3(64), 0, nullptr, P);
+        hip_ok(hipGetLastError(), "smoke kernel");
+        hip_ok(hipEventRecord(e1, nullptr), "event");
+        hip_ok(hipMemcpy(rgba, P.out, px * 4, hipMemcpyDeviceToHost), "smoke readback");
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (kernel_seconds) *kernel_seconds = ms * 1e-3;
+    } catch (const Failure &f) {
+        rc = report(f, err, errlen);
+    } catch (const std::exception &e) {
+        if (err && errlen) snprintf(err, errlen, "host failure: %s", e.what());
+        rc = F3D_STATUS_DEVICE;
+    } catch (...) {
+        rc = F3D_STATUS_DEVICE;
+    }
+    for (void *p : owned) (void)hipFree(p);
+    return rc;
+}

@@ -1,0 +1,350 @@
+"""Smoke volumes rendered on the GPU: the ``forge3d.smoke`` surface of the reference for its ray-marcher.
+
+Reference: ``SmokeDomain`` / ``SmokeRenderSettings`` / ``SmokeEmitter`` of the compiled extension
+(src/smoke/py.rs:11-625, re-exported by python/forge3d/smoke.py:62-66) with
+``render_rgba`` = ``SmokeVolume::raymarch_rgba`` and ``render_projection_rgba`` =
+``SmokeVolume::raymarch_projection_rgba`` (src/smoke/render.rs:7-178).  Same constructor signatures, array
+layouts ((z, y, x) NumPy arrays, x fastest), validation messages and exception types; the ray-march itself runs
+in libf3dhip.so (csrc/f3d_smoke.hip), one lane per pixel.  The transport solver (``SmokeDomain.step``,
+src/smoke/sim.rs) is NOT part of the offline render path this package replaces: it raises.
+
+``render_sequence`` spreads the frames of an animation over the ranks of a torch.distributed job (frames are
+independent: BASELINE.json configs[4] "smoke sequence ... x 120 frames, 8 x MI355X" = frame replicas).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, fields
+from typing import Iterable, Sequence
+
+import numpy as np
+
+from . import _native
+
+MAX_VOXELS = 256 * 256 * 256  # MAX_CPU_VOXELS, src/smoke/types.rs:4
+
+
+class _Volume(C.Structure):
+    _fields_ = [("density", C.c_void_p), ("temperature", C.c_void_p), ("soot", C.c_void_p), ("humidity", C.c_void_p),
+                ("emission", C.c_void_p), ("age", C.c_void_p), ("dims", C.c_uint32 * 3), ("voxel_size", C.c_float * 3),
+                ("origin", C.c_float * 3), ("frame_index", C.c_uint32)]
+
+
+class _View(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("projection", C.c_int32), ("camera_pos", C.c_float * 3),
+                ("target", C.c_float * 3), ("up", C.c_float * 3), ("fovy_deg", C.c_float),
+                ("view_direction", C.c_float * 3), ("sun_direction", C.c_float * 3)]
+
+
+class _Settings(C.Structure):
+    _fields_ = [("density_scale", C.c_float), ("extinction", C.c_float), ("scattering", C.c_float),
+                ("absorption", C.c_float), ("phase_g", C.c_float), ("step_size", C.c_float), ("max_steps", C.c_uint32),
+                ("self_shadow", C.c_int32), ("shadow_steps", C.c_uint32), ("shadow_step_size", C.c_float),
+                ("jitter_strength", C.c_float), ("exposure", C.c_float), ("thin_color", C.c_float * 3),
+                ("dense_color", C.c_float * 3), ("soot_absorption", C.c_float), ("fire_glow", C.c_float)]
+
+
+def _f3(v, name="value"):
+    t = tuple(float(x) for x in v)
+    if len(t) != 3:
+        raise ValueError(f"{name} must have three components")
+    return t
+
+
+@dataclass
+class SmokeRenderSettings:
+    """src/smoke/py.rs:276-333 (defaults src/smoke/types.rs:247-268); invalid values raise ValueError."""
+    density_scale: float = 1.0
+    extinction: float = 2.6
+    scattering: float = 0.85
+    absorption: float = 0.45
+    phase_g: float = 0.24
+    step_size: float = 0.0
+    max_steps: int = 256
+    self_shadow: bool = True
+    shadow_steps: int = 20
+    shadow_step_size: float = 0.0
+    jitter_strength: float = 0.5
+    exposure: float = 1.0
+    thin_color: tuple = (0.50, 0.54, 0.58)
+    dense_color: tuple = (0.93, 0.91, 0.82)
+    soot_absorption: float = 0.22
+    fire_glow: float = 0.35
+
+    def __post_init__(self):
+        self.thin_color, self.dense_color = _f3(self.thin_color, "thin_color"), _f3(self.dense_color, "dense_color")
+        problem = self.problem()
+        if problem:
+            raise ValueError(problem)
+
+    def problem(self) -> "str | None":
+        """SmokeRenderSettings::validate (types.rs:271-316): the first violated rule, or None."""
+        scalars = ("density_scale", "extinction", "scattering", "absorption", "phase_g", "step_size", "shadow_step_size",
+                   "jitter_strength", "exposure", "soot_absorption", "fire_glow")
+        for name in scalars:
+            if not math.isfinite(float(getattr(self, name))):
+                return f"{name} must be finite"
+        if min(self.density_scale, self.extinction, self.scattering) < 0.0:
+            return "density_scale, extinction, and scattering must be >= 0"
+        if min(self.absorption, self.soot_absorption, self.fire_glow) < 0.0:
+            return "absorption, soot_absorption, and fire_glow must be >= 0"
+        if not -0.99 <= self.phase_g <= 0.99:
+            return "phase_g must be in [-0.99, 0.99]"
+        if self.step_size < 0.0 or self.shadow_step_size < 0.0:
+            return "step sizes must be >= 0"
+        if int(self.max_steps) == 0 or int(self.shadow_steps) == 0:
+            return "max_steps and shadow_steps must be >= 1"
+        if not 0.0 <= self.jitter_strength <= 1.0:
+            return "jitter_strength must be in [0, 1]"
+        for name in ("thin_color", "dense_color"):
+            for axis, value in enumerate(getattr(self, name)):
+                if not math.isfinite(value) or value < 0.0:
+                    return f"{name}[{axis}] must be finite and >= 0"
+        return None
+
+    def _native(self) -> _Settings:
+        s = _Settings()
+        for f in fields(self):
+            v = getattr(self, f.name)
+            if f.name in ("thin_color", "dense_color"):
+                setattr(s, f.name, (C.c_float * 3)(*v))
+            elif f.name in ("max_steps", "shadow_steps"):
+                setattr(s, f.name, int(v))
+            elif f.name == "self_shadow":
+                s.self_shadow = 1 if v else 0
+            else:
+                setattr(s, f.name, float(v))
+        return s
+
+    def __repr__(self):
+        return f"SmokeRenderSettings(extinction={self.extinction}, phase_g={self.phase_g}, max_steps={self.max_steps})"
+
+
+@dataclass
+class SmokeEmitter:
+    """src/smoke/py.rs:20-61 (defaults types.rs:85-101)."""
+    center: tuple = (0.0, 0.0, 0.0)
+    radius: float = 1.0
+    density_rate: float = 1.0
+    temperature_rate: float = 1.0
+    fuel_rate: float = 0.0
+    soot_rate: float = 0.2
+    humidity_rate: float = 0.0
+    emission_rate: float = 1.0
+    velocity: tuple = (0.0, 1.0, 0.0)
+    start_time: float = 0.0
+    end_time: float = 3.4028234663852886e38
+
+    def __post_init__(self):
+        self.center, self.velocity = _f3(self.center, "center"), _f3(self.velocity, "velocity")
+        if not (math.isfinite(self.radius) and self.radius > 0.0):
+            raise ValueError("radius must be finite and > 0")
+        if self.end_time < self.start_time:
+            raise ValueError("end_time must be >= start_time")
+
+
+class SmokeDomain:
+    """Dense smoke state + GPU ray-marcher (reference SmokeDomain, src/smoke/py.rs:342-641).
+
+    Fields are float32 arrays of shape (nz, ny, nx) -- ``dims`` is (nx, ny, nz) like the reference's."""
+
+    FIELDS = ("density", "temperature", "soot", "humidity", "emission_rate", "particle_age")
+
+    def __init__(self, dims, voxel_size=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), brick_size=(16, 16, 16),
+                 sparse_threshold=1.0e-5):
+        self._dims = tuple(int(d) for d in dims)
+        self._voxel, self._origin = _f3(voxel_size, "voxel_size"), _f3(origin, "origin")
+        for axis, d in enumerate(self._dims):
+            if d < 2:
+                raise ValueError(f"dims[{axis}] must be >= 2")
+        n = self._dims[0] * self._dims[1] * self._dims[2]
+        if n > MAX_VOXELS:
+            raise ValueError(f"smoke domain has {n} voxels, exceeding CPU reference limit {MAX_VOXELS}")
+        for axis, v in enumerate(self._voxel):
+            if not (math.isfinite(v) and v > 0.0):
+                raise ValueError(f"voxel_size[{axis}] must be finite and > 0")
+        for axis, v in enumerate(self._origin):
+            if not math.isfinite(v):
+                raise ValueError(f"origin[{axis}] must be finite")
+        if any(int(b) == 0 for b in brick_size):
+            raise ValueError(f"brick_size[{[int(b) for b in brick_size].index(0)}] must be >= 1")
+        if not (math.isfinite(sparse_threshold) and sparse_threshold >= 0.0):
+            raise ValueError("sparse_threshold must be finite and >= 0")
+        self.sparse_threshold = float(sparse_threshold)
+        shape = (self._dims[2], self._dims[1], self._dims[0])
+        self.density = np.zeros(shape, np.float32)
+        self.temperature = np.zeros(shape, np.float32)
+        self.soot = np.zeros(shape, np.float32)
+        self.humidity = np.zeros(shape, np.float32)
+        self.emission_rate = np.zeros(shape, np.float32)
+        self.particle_age = np.full(shape, -1.0, np.float32)
+        self.velocity = np.zeros(shape + (3,), np.float32)
+        self.time_seconds = 0.0
+        self.frame_index = 0
+        self.last_kernel_seconds = 0.0
+
+    # -- construction / state ---------------------------------------------------------------------------
+    @staticmethod
+    def from_density(density, voxel_size=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0)) -> "SmokeDomain":
+        arr = np.asarray(density)
+        if arr.ndim != 3:
+            raise ValueError("density must be a 3-D float32 array (z, y, x)")
+        dom = SmokeDomain((arr.shape[2], arr.shape[1], arr.shape[0]), voxel_size, origin)
+        dom.set_density(arr)
+        return dom
+
+    dims = property(lambda self: self._dims)
+    voxel_size = property(lambda self: self._voxel)
+    origin = property(lambda self: self._origin)
+
+    def _checked(self, value, name):
+        arr = np.ascontiguousarray(value, dtype=np.float32)
+        if arr.shape != self.density.shape:
+            raise ValueError(f"{name} shape must be (z={self._dims[2]}, y={self._dims[1]}, x={self._dims[0]})")
+        if not np.isfinite(arr).all():
+            raise ValueError(f"{name} contains non-finite values")
+        return arr
+
+    def set_density(self, density) -> None:
+        """SmokeVolume::set_density (types.rs:489-511): also restarts the age of every occupied voxel."""
+        self.density = self._checked(density, "density")
+        self.particle_age = np.where(self.density > self.sparse_threshold, 0.0, -1.0).astype(np.float32)
+
+    def set_velocity(self, velocity) -> None:
+        arr = np.ascontiguousarray(velocity, dtype=np.float32)
+        if arr.shape != self.density.shape + (3,):
+            raise ValueError(f"velocity shape must be (z={self._dims[2]}, y={self._dims[1]}, x={self._dims[0]}, 3)")
+        if not np.isfinite(arr).all():
+            raise ValueError("velocity contains non-finite values")
+        self.velocity = arr
+
+    def set_temperature(self, v) -> None:
+        self.temperature = self._checked(v, "temperature")
+
+    def set_soot(self, v) -> None:
+        self.soot = self._checked(v, "soot")
+
+    def set_humidity(self, v) -> None:
+        self.humidity = self._checked(v, "humidity")
+
+    def set_emission(self, v) -> None:
+        self.emission_rate = self._checked(v, "emission")
+
+    def set_particle_age(self, v) -> None:
+        self.particle_age = self._checked(v, "particle_age")
+
+    def add_emitter(self, emitter: SmokeEmitter, dt: float) -> None:
+        """SmokeVolume::add_emitter (src/smoke/sim.rs:7-45): deposit a smooth ball of smoke, f32 arithmetic."""
+        if not (math.isfinite(dt) and dt > 0.0):
+            raise ValueError("dt must be finite and > 0")
+        f = np.float32
+        nx, ny, nz = self._dims
+        z, y, x = np.meshgrid(np.arange(nz, dtype=np.float32), np.arange(ny, dtype=np.float32),
+                              np.arange(nx, dtype=np.float32), indexing="ij")
+        px = f(self._origin[0]) + (x + f(0.5)) * f(self._voxel[0])
+        py = f(self._origin[1]) + (y + f(0.5)) * f(self._voxel[1])
+        pz = f(self._origin[2]) + (z + f(0.5)) * f(self._voxel[2])
+        dx, dy, dz = px - f(emitter.center[0]), py - f(emitter.center[1]), pz - f(emitter.center[2])
+        d = np.sqrt(dx * dx + dy * dy + dz * dz, dtype=np.float32)
+        radius = f(max(emitter.radius, 1.0e-6))
+        inside = ~(d > radius)
+        t = np.clip(d / np.maximum(radius, f(1.0e-6)), f(0.0), f(1.0)).astype(np.float32)
+        falloff = (f(1.0) - t * t * (f(3.0) - f(2.0) * t)).astype(np.float32)
+        amount = (f(dt) * falloff).astype(np.float32)
+        for name, rate in (("density", emitter.density_rate), ("temperature", emitter.temperature_rate),
+                           ("soot", emitter.soot_rate), ("humidity", emitter.humidity_rate)):
+            field = getattr(self, name)
+            field[inside] = np.maximum(field[inside] + f(rate) * amount[inside], f(0.0))
+        self.emission_rate[inside] += f(emitter.emission_rate) * falloff[inside]
+        self.particle_age[inside] = 0.0
+        for c in range(3):
+            self.velocity[..., c][inside] += f(emitter.velocity[c]) * amount[inside]
+
+    def step(self, settings=None, emitters=None) -> None:
+        raise NotImplementedError(
+            "SmokeDomain.step (the transport solver, reference src/smoke/sim.rs) is outside the offline render path "
+            "forge3d_amd replaces; advance the state with the reference package or load precomputed fields")
+
+    def to_density_numpy(self) -> np.ndarray:
+        return self.density.copy()
+
+    def to_velocity_numpy(self) -> np.ndarray:
+        return self.velocity.copy()
+
+    def to_particle_age_numpy(self) -> np.ndarray:
+        return self.particle_age.copy()
+
+    # -- rendering ----------------------------------------------------------------------------------------
+    def _render(self, view: _View, settings) -> np.ndarray:
+        settings = settings or SmokeRenderSettings()
+        problem = settings.problem()
+        if problem:
+            raise RuntimeError(problem)  # the reference validates again inside the ray-marcher (render.rs:19)
+        keep = [np.ascontiguousarray(getattr(self, name), dtype=np.float32) for name in self.FIELDS]
+        vol = _Volume()
+        vol.density, vol.temperature, vol.soot, vol.humidity, vol.emission, vol.age = (a.ctypes.data for a in keep)
+        vol.dims = (C.c_uint32 * 3)(*self._dims)
+        vol.voxel_size = (C.c_float * 3)(*self._voxel)
+        vol.origin = (C.c_float * 3)(*self._origin)
+        vol.frame_index = int(self.frame_index) & 0xFFFFFFFF
+        out = np.zeros((int(view.height), int(view.width), 4), np.uint8)
+        err = C.create_string_buffer(512)
+        seconds = C.c_double(0.0)
+        native = settings._native()
+        rc = _native.lib().f3d_smoke_render(C.byref(vol), C.byref(view), C.byref(native), out.ctypes.data,
+                                            C.byref(seconds), err, len(err))
+        if rc != 0:
+            message = err.value.decode("utf-8", "replace")
+            raise (ValueError if rc == _native.STATUS_VALUE else RuntimeError)(message)
+        self.last_kernel_seconds = float(seconds.value)
+        return out
+
+    def render_rgba(self, width, height, camera_pos, target, up=(0.0, 1.0, 0.0), fovy_deg=45.0,
+                    sun_direction=(0.4, 0.8, -0.2), settings=None, certificate=None, cache=None) -> np.ndarray:
+        """Perspective ray-march, (height, width, 4) uint8: straight colour + alpha = 1 - transmittance
+        (reference SmokeDomain.render_rgba, src/smoke/py.rs:531-584).  certificate / cache: accepted, ignored."""
+        if int(width) < 1 or int(height) < 1:
+            raise RuntimeError("width and height must be >= 1")
+        view = _View(int(width), int(height), 0)
+        view.camera_pos, view.target, view.up = ((C.c_float * 3)(*_f3(v)) for v in (camera_pos, target, up))
+        view.fovy_deg = float(fovy_deg)
+        view.sun_direction = (C.c_float * 3)(*_f3(sun_direction))
+        return self._render(view, settings)
+
+    def render_projection_rgba(self, width, height, view_direction=(0.0, -1.0, 0.0), sun_direction=(0.4, 0.8, -0.2),
+                               settings=None, certificate=None, cache=None) -> np.ndarray:
+        """Map-aligned parallel projection (reference render_projection_rgba, src/smoke/py.rs:586-625)."""
+        if int(width) < 1 or int(height) < 1:
+            raise RuntimeError("width and height must be >= 1")
+        view = _View(int(width), int(height), 1)
+        view.view_direction = (C.c_float * 3)(*_f3(view_direction))
+        view.sun_direction = (C.c_float * 3)(*_f3(sun_direction))
+        return self._render(view, settings)
+
+    def __repr__(self):
+        return f"SmokeDomain(dims={list(self._dims)}, time_seconds={self.time_seconds:.3f}, frame_index={self.frame_index})"
+
+
+def domain_from_density(density, voxel_size=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0)) -> SmokeDomain:
+    """reference python/forge3d/smoke.py:571-578"""
+    return SmokeDomain.from_density(density, voxel_size, origin)
+
+
+def render_sequence(frames: "Sequence[SmokeDomain]", width, height, camera_pos, target, *, rank=0, world=1, **kwargs):
+    """Frames of an animation are independent: rank r renders frames r, r + world, ...; with an initialised
+    torch.distributed process group the images are gathered on rank 0 (list in frame order; None elsewhere)."""
+    mine = {i: frames[i].render_rgba(width, height, camera_pos, target, **kwargs) for i in range(rank, len(frames), world)}
+    if world == 1:
+        return [mine[i] for i in range(len(frames))]
+    import torch
+    import torch.distributed as dist
+
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object({i: torch.from_numpy(a) for i, a in mine.items()}, gathered, dst=0)
+    if rank != 0:
+        return None
+    merged = {}
+    for part in gathered:
+        merged.update({i: t.numpy() for i, t in part.items()})
+    return [merged[i] for i in range(len(frames))]

@@ -186,6 +186,41 @@ int f3d_atrous_denoise(const float *color, const float *albedo, const float *nor
                        uint32_t width, uint32_t height, int32_t iterations, float sigma_color, float sigma_albedo,
                        float sigma_normal, float sigma_depth, float *out, char *err, size_t errlen);
 
+/* ---- smoke volume ray-marcher (BASELINE.json configs[4]) --------------------------
+ * Replaces SmokeVolume::raymarch_rgba / raymarch_projection_rgba (reference src/smoke/render.rs:7-178, bound to
+ * Python as SmokeDomain.render_rgba / render_projection_rgba, src/smoke/py.rs:531-625).  Fields are the reference's
+ * (x fastest, then y, then z: index = (z * ny + y) * nx + x, types.rs:359-361). */
+typedef struct f3d_smoke_volume {
+    const float *density, *temperature, *soot, *humidity, *emission, *age; /* emission = emission_rate, age = particle_age */
+    uint32_t dims[3];    /* nx, ny, nz (each >= 2; nx*ny*nz <= 256^3 like the reference) */
+    float voxel_size[3];
+    float origin[3];
+    uint32_t frame_index; /* jitter seed term (SmokeVolume::frame_index as u32) */
+} f3d_smoke_volume;
+
+typedef struct f3d_smoke_view {
+    uint32_t width, height;
+    int32_t projection;       /* 0: perspective camera (raymarch_rgba); 1: map-aligned parallel projection */
+    float camera_pos[3], target[3], up[3], fovy_deg; /* perspective */
+    float view_direction[3];  /* projection */
+    float sun_direction[3];
+} f3d_smoke_view;
+
+typedef struct f3d_smoke_settings { /* SmokeRenderSettings, reference src/smoke/types.rs:227-269 */
+    float density_scale, extinction, scattering, absorption, phase_g, step_size;
+    uint32_t max_steps;
+    int32_t self_shadow;
+    uint32_t shadow_steps;
+    float shadow_step_size, jitter_strength, exposure;
+    float thin_color[3], dense_color[3];
+    float soot_absorption, fire_glow;
+} f3d_smoke_settings;
+
+/* rgba: caller-owned height x width x 4 bytes (straight colour, alpha = 1 - transmittance).  kernel_seconds
+ * (optional) receives the ray-march kernel's device time.  Errors carry the reference's message texts. */
+int f3d_smoke_render(const f3d_smoke_volume *volume, const f3d_smoke_view *view, const f3d_smoke_settings *settings,
+                     uint8_t *rgba, double *kernel_seconds, char *err, size_t errlen);
+
 /* ---- test hooks (KATs restated from the reference's Rust unit tests) ----------- */
 /* build_minmax_mips on the GPU (reference terrain_heightfield.rs:132-202); output in
  * the reference's layout: levels back to back, finest first, each (ph, pw, 2) f32;

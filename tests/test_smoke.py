@@ -1,0 +1,200 @@
+"""Smoke ray-marcher: the oracle against the reference's own unit tests restated as
+known-answer properties (src/smoke/render.rs:420-592, tests/test_smoke.py:54-76 of the reference) -- the only
+pins this path has: the reference ships no golden image for it and cannot be built here -- and, `-m gpu`, the HIP
+kernel against the oracle bit for bit (integer RGBA8 outputs)."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from oracle import smoke_oracle
+
+
+def ball(dims, centre, radius, value):
+    nz, ny, nx = dims
+    z, y, x = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    d = np.sqrt((x + 0.5 - centre[0]) ** 2 + (y + 0.5 - centre[1]) ** 2 + (z + 0.5 - centre[2]) ** 2)
+    t = np.clip(d / radius, 0.0, 1.0)
+    return (value * (1.0 - t * t * (3.0 - 2.0 * t)) * (d <= radius)).astype(np.float32)
+
+
+def plume(seed=5, dims=(40, 28, 48)):
+    """A filamentary test plume with every field populated (soot core, humid fringe, hot emitting base)."""
+    rng = np.random.default_rng(seed)
+    nz, ny, nx = dims
+    density = np.zeros(dims, np.float32)
+    for _ in range(14):
+        c = (rng.uniform(8, nx - 8), rng.uniform(4, ny - 6), rng.uniform(8, nz - 8))
+        density += ball(dims, c, rng.uniform(3, 9), rng.uniform(0.2, 1.6))
+    y = np.arange(ny, dtype=np.float32)[None, :, None]
+    fields = {
+        "density": density,
+        "soot": (0.35 * density * (y < ny * 0.5)).astype(np.float32),
+        "humidity": (0.8 * (density > 0.05) * (y / ny)).astype(np.float32),
+        "temperature": (1.5 * density * (y < 6)).astype(np.float32),
+        "emission_rate": (2.0 * density * (y < 4)).astype(np.float32),
+        "particle_age": np.where(density > 1e-5, 20.0 * y / ny, -1.0).astype(np.float32),
+    }
+    return fields
+
+
+CAMERA = dict(camera_pos=(24.0, 30.0, -46.0), target=(24.0, 12.0, 20.0), up=(0.0, 1.0, 0.0), fovy_deg=42.0)
+
+
+# ---- the reference's unit tests as KATs on the oracle --------------------------------------------------
+def test_raymarch_returns_nonblank_smoke_layer():
+    """render.rs:426-466 (the emitter's smooth ball written directly: SmokeVolume::add_emitter, sim.rs:7-45)."""
+    fields = {"density": ball((16, 16, 16), (8, 8, 8), 4.0, 4.0), "temperature": ball((16, 16, 16), (8, 8, 8), 4.0, 1.0)}
+    fields["particle_age"] = np.where(fields["density"] > 0, 0.0, -1.0).astype(np.float32)
+    rgba = smoke_oracle.render_rgba(fields, 32, 32, (8.0, 8.0, -18.0), (8.0, 8.0, 8.0), sun_direction=(0.4, 0.8, -0.2))
+    assert rgba.shape == (32, 32, 4) and int(rgba[..., 3].max()) > 0
+    assert int(rgba[0, 0, 3]) == 0  # rays that miss the box stay transparent
+
+
+def test_projected_raymarch_returns_map_aligned_smoke_layer():
+    """render.rs:468-496"""
+    fields = {"density": ball((14, 12, 18), (8, 4, 7), 3.5, 5.0)}
+    rgba = smoke_oracle.render_projection_rgba(fields, 36, 28, (0.0, -1.0, 0.0), (0.4, 0.8, -0.2))
+    assert rgba.shape == (28, 36, 4) and int(rgba[..., 3].max()) > 0
+    ys, xs = np.nonzero(rgba[..., 3] > 128)  # the blob sits where the map says: x ~ 8/18, z ~ 7/14 of the image
+    assert abs(xs.mean() / 36 - 8 / 18) < 0.08 and abs(ys.mean() / 28 - 7 / 14) < 0.08
+
+
+def test_sun_transmittance_tracks_volume_self_shadowing():
+    """render.rs:498-541: lit > 0.95, occluded < 0.35"""
+    density = np.zeros((12, 12, 24), np.float32)
+    soot = np.zeros_like(density)
+    density[3:9, 3:9, 8:14] = 1.2
+    soot[3:9, 3:9, 8:14] = 0.18
+    fields = {"density": density, "soot": soot}
+    st = dict(density_scale=1.4, extinction=1.8, shadow_steps=48, shadow_step_size=0.5)
+    lit = smoke_oracle.sun_transmittance(fields, (15.0, 6.0, 6.0), (1.0, 0.0, 0.0), 0.5, 48, **st)
+    occluded = smoke_oracle.sun_transmittance(fields, (15.0, 6.0, 6.0), (-1.0, 0.0, 0.0), 0.5, 48, **st)
+    assert lit > 0.95 and occluded < 0.35
+
+
+def test_raymarch_emission_adds_warm_source_radiance():
+    """render.rs:543-591"""
+    density = np.zeros((16, 16, 16), np.float32)
+    density[5:11, 5:11, 5:11] = 0.55
+    hot = {"density": density, "temperature": np.where(density > 0, 0.85, 0).astype(np.float32),
+           "emission_rate": np.where(density > 0, 1.4, 0).astype(np.float32)}
+    st = dict(density_scale=1.2, extinction=1.25, fire_glow=1.25, exposure=1.15)
+    args = (32, 32, (8.0, 8.0, -18.0), (8.0, 8.0, 8.0))
+    with_e = smoke_oracle.render_rgba(hot, *args, sun_direction=(0.3, 0.8, -0.2), **st).astype(np.int16)
+    without = smoke_oracle.render_rgba({"density": density}, *args, sun_direction=(0.3, 0.8, -0.2), **st).astype(np.int16)
+    assert (with_e[..., 0] - with_e[..., 2]).max() > (without[..., 0] - without[..., 2]).max() + 12
+    assert with_e[..., 0].max() > without[..., 0].max()
+
+
+def test_oracle_rejects_what_the_reference_rejects():
+    fields = {"density": ball((8, 8, 8), (4, 4, 4), 3.0, 1.0)}
+    for kw, needle in ((dict(phase_g=1.5), "phase_g must be in"), (dict(max_steps=0), "max_steps and shadow_steps"),
+                       (dict(jitter_strength=2.0), "jitter_strength"), (dict(extinction=-1.0), "must be >= 0")):
+        with pytest.raises(RuntimeError, match=needle):
+            smoke_oracle.render_rgba(fields, 8, 8, (4.0, 4.0, -10.0), (4.0, 4.0, 4.0), **kw)
+    with pytest.raises(RuntimeError, match="must not be equal"):
+        smoke_oracle.render_rgba(fields, 8, 8, (4.0, 4.0, 4.0), (4.0, 4.0, 4.0))
+    with pytest.raises(RuntimeError, match="fovy_deg"):
+        smoke_oracle.render_rgba(fields, 8, 8, (4.0, 4.0, -10.0), (4.0, 4.0, 4.0), fovy_deg=180.0)
+
+
+def test_python_surface_without_a_gpu():
+    """constructor signatures / validation of forge3d_amd.smoke (reference src/smoke/py.rs) -- no device needed"""
+    from forge3d_amd import smoke
+
+    dom = smoke.domain_from_density(ball((12, 10, 14), (7, 5, 6), 3.0, 1.0), voxel_size=(2.0, 3.0, 4.0))
+    assert dom.dims == (14, 10, 12) and dom.to_density_numpy().shape == (12, 10, 14)
+    assert dom.to_velocity_numpy().shape == (12, 10, 14, 3) and float(dom.to_particle_age_numpy().max()) == 0.0
+    with pytest.raises(ValueError, match=r"dims\[1\] must be >= 2"):
+        smoke.SmokeDomain((4, 1, 4))
+    with pytest.raises(ValueError, match="density shape must be"):
+        dom.set_density(np.zeros((3, 3, 3), np.float32))
+    with pytest.raises(ValueError, match="phase_g"):
+        smoke.SmokeRenderSettings(phase_g=1.0)
+    with pytest.raises(NotImplementedError):
+        dom.step()
+    e = smoke.SmokeDomain((16, 16, 16))
+    e.add_emitter(smoke.SmokeEmitter(center=(8.0, 8.0, 8.0), radius=4.0, density_rate=4.0), 1.0)
+    assert np.allclose(e.density, ball((16, 16, 16), (8, 8, 8), 4.0, 4.0), atol=1e-5)
+
+
+# ---- the HIP kernel against the oracle ---------------------------------------------------------------------
+def _domain(fields, voxel_size=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), frame_index=0):
+    from forge3d_amd import smoke
+
+    d = fields["density"]
+    dom = smoke.SmokeDomain((d.shape[2], d.shape[1], d.shape[0]), voxel_size, origin)
+    dom.set_density(d)
+    for name, setter in (("temperature", dom.set_temperature), ("soot", dom.set_soot), ("humidity", dom.set_humidity),
+                         ("emission_rate", dom.set_emission), ("particle_age", dom.set_particle_age)):
+        if name in fields:
+            setter(fields[name])
+        elif name == "particle_age":
+            dom.set_particle_age(np.full(d.shape, -1.0, np.float32))
+    dom.frame_index = frame_index
+    return dom
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,settings,geom", [
+    ((96, 64), {}, {}),
+    ((160, 90), dict(self_shadow=False, exposure=1.4, phase_g=-0.5), dict(voxel_size=(2.0, 1.5, 2.5), origin=(-10.0, 3.0, 7.0))),
+    ((61, 47), dict(step_size=0.4, shadow_step_size=1.1, shadow_steps=33, max_steps=900, jitter_strength=1.0), dict(frame_index=77)),
+    ((128, 128), dict(density_scale=2.5, extinction=4.0, soot_absorption=0.9, fire_glow=1.5, thin_color=(0.2, 0.3, 0.4)), {}),
+])
+def test_hip_smoke_matches_the_oracle_bit_for_bit(size, settings, geom):
+    from forge3d_amd import smoke
+
+    fields = plume()
+    vs, og = geom.get("voxel_size", (1.0, 1.0, 1.0)), geom.get("origin", (0.0, 0.0, 0.0))
+    cam = {k: (tuple(np.array(v) * np.array(vs) + np.array(og)) if k in ("camera_pos", "target") else v)
+           for k, v in CAMERA.items()}
+    dom = _domain(fields, vs, og, geom.get("frame_index", 0))
+    st = smoke.SmokeRenderSettings(**settings)
+    got = dom.render_rgba(size[0], size[1], settings=st, sun_direction=(0.4, 0.8, -0.2), **cam)
+    want = smoke_oracle.render_rgba(fields, size[0], size[1], sun_direction=(0.4, 0.8, -0.2), voxel_size=vs, origin=og,
+                                    frame_index=geom.get("frame_index", 0), **cam, **settings)
+    assert int(want[..., 3].max()) > 100 and (want[..., 3] == 0).mean() > 0.05
+    assert np.array_equal(got, want), f"{(got != want).any(-1).sum()} pixels differ"
+    got_p = dom.render_projection_rgba(size[0], size[1], (0.2, -1.0, 0.1), (0.4, 0.8, -0.2), settings=st)
+    want_p = smoke_oracle.render_projection_rgba(fields, size[0], size[1], (0.2, -1.0, 0.1), (0.4, 0.8, -0.2), voxel_size=vs,
+                                                 origin=og, frame_index=geom.get("frame_index", 0), **settings)
+    assert np.array_equal(got_p, want_p)
+
+
+@pytest.mark.gpu
+def test_config5_smoke_frame_at_1080p_matches_the_oracle():
+    """BASELINE.json configs[4] frame size: 1920x1080 over a 96 x 64 x 128 plume, whole image against the oracle;
+    and the frame replicas of a short sequence (frame_index drives the jitter) through render_sequence."""
+    from forge3d_amd import smoke
+
+    fields = plume(seed=9, dims=(96, 64, 128))
+    cam = dict(camera_pos=(64.0, 70.0, -120.0), target=(64.0, 28.0, 48.0), up=(0.0, 1.0, 0.0), fovy_deg=40.0)
+    dom = _domain(fields)
+    got = dom.render_rgba(1920, 1080, **cam)
+    want = smoke_oracle.render_rgba(fields, 1920, 1080, **cam)
+    assert np.array_equal(got, want)
+    assert dom.last_kernel_seconds > 0.0
+    frames = [_domain(fields, frame_index=i) for i in range(3)]
+    seq = smoke.render_sequence(frames, 240, 135, cam["camera_pos"], cam["target"], fovy_deg=40.0)
+    for i, img in enumerate(seq):
+        assert np.array_equal(img, smoke_oracle.render_rgba(fields, 240, 135, frame_index=i, **cam))
+    assert not np.array_equal(seq[0], seq[1])  # the jitter really changes with the frame
+
+
+@pytest.mark.gpu
+def test_hip_smoke_errors_are_the_reference_errors():
+    from forge3d_amd import smoke
+
+    dom = _domain({"density": ball((8, 8, 8), (4, 4, 4), 3.0, 1.0)})
+    with pytest.raises(RuntimeError, match="camera_pos and target must not be equal"):
+        dom.render_rgba(8, 8, (4.0, 4.0, 4.0), (4.0, 4.0, 4.0))
+    with pytest.raises(RuntimeError, match="up vector must not be zero"):
+        dom.render_rgba(8, 8, (4.0, 4.0, -9.0), (4.0, 4.0, 4.0), up=(0.0, 0.0, 0.0))
+    with pytest.raises(RuntimeError, match="fovy_deg must be finite"):
+        dom.render_rgba(8, 8, (4.0, 4.0, -9.0), (4.0, 4.0, 4.0), fovy_deg=179.5)
+    with pytest.raises(RuntimeError, match="view_direction must not be zero"):
+        dom.render_projection_rgba(8, 8, (0.0, 0.0, 0.0))
+    with pytest.raises(RuntimeError, match="width and height"):
+        dom.render_rgba(0, 8, (4.0, 4.0, -9.0), (4.0, 4.0, 4.0))
