@@ -28,6 +28,7 @@ ap.add_argument("--streams", type=int, default=0)
 ap.add_argument("--variant", type=int, default=0)
 ap.add_argument("--frames", type=int, default=16)
 ap.add_argument("--sweep", action="store_true")
+ap.add_argument("--rounds", type=int, default=4)
 args = ap.parse_args()
 
 W, H, SPP = 1920, 1080, 8
@@ -57,7 +58,7 @@ if args.sweep:
 for world in [int(x) for x in args.worlds.split(",")]:
     bounds = [strip_rows(H, world, r)[0] for r in range(world)] + [H]
     density = np.ones(H)
-    for it in range(4):
+    for it in range(args.rounds):
         times = [probe(bounds[r], bounds[r + 1], bands=args.bands, band_streams=args.streams) for r in range(world)]
         print(json.dumps({"world": world, "round": it, "bounds": bounds, "ms": [round(t, 3) for t in times],
                           "imbalance": max(times) / (sum(times) / world),
