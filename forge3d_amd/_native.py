@@ -44,6 +44,21 @@ class Desc(C.Structure):
         ("width", C.c_uint32), ("height", C.c_uint32),
         ("seed", C.c_uint32), ("spp", C.c_uint32), ("max_frames", C.c_uint32), ("min_frames", C.c_uint32),
         ("variance_threshold", C.c_float),
+        ("atmosphere", C.c_void_p),
+    ]
+
+
+class AetherLuts(C.Structure):
+    """f3d_aether_luts"""
+    _fields_ = [
+        ("transmittance", C.c_void_p), ("accumulated_scattering", C.c_void_p), ("aerial", C.c_void_p),
+        ("transmittance_mu", C.c_uint32), ("transmittance_height", C.c_uint32),
+        ("scattering_mu_view", C.c_uint32), ("scattering_mu_sun", C.c_uint32), ("scattering_height", C.c_uint32),
+        ("scattering_nu", C.c_uint32),
+        ("aerial_distance", C.c_uint32), ("aerial_mu_view", C.c_uint32), ("aerial_height", C.c_uint32),
+        ("turbidity", C.c_float), ("ozone_du", C.c_float), ("mie_g", C.c_float), ("bottom_radius_m", C.c_float),
+        ("top_radius_m", C.c_float), ("rayleigh_scale_height_m", C.c_float), ("mie_scale_height_m", C.c_float),
+        ("max_aerial_distance_m", C.c_float), ("ground_albedo", C.c_float), ("scattering_orders", C.c_uint32),
     ]
 
 
@@ -175,43 +190,40 @@ def _extract_sun_color(obj):
     return out
 
 
-_ATMOSPHERE_KEYS = ("enabled", "lut_handle", "turbidity", "ozone_du", "mie_g", "ground_albedo", "scattering_orders")
-
-
-def _check_atmosphere(atmosphere):
-    """extract_atmosphere_lut_handle, terrain_reference.rs:45-219: key validation is
-    reproduced; the AETHER aerial-perspective post itself is SURVEY.md 8(f) row 1 (next)."""
+def _resolve_atmosphere(atmosphere):
+    """extract_atmosphere_lut_handle, terrain_reference.rs:45-219 -> forge3d_amd.atmosphere.resolve_setting"""
     if atmosphere is None:
         return None
-    from collections.abc import Mapping
+    from .atmosphere import resolve_setting
 
-    if isinstance(atmosphere, Mapping):
-        for key in atmosphere.keys():
-            if not isinstance(key, str):
-                raise TypeError("atmosphere mapping keys must be strings")
-            if key not in _ATMOSPHERE_KEYS:
-                raise ValueError(
-                    f"unknown atmosphere setting {key!r}; expected one of {', '.join(_ATMOSPHERE_KEYS)}"
-                )
-        if atmosphere.get("enabled") is False:
-            return None
-    elif not any(hasattr(atmosphere, k) for k in _ATMOSPHERE_KEYS):
-        raise TypeError(
-            "atmosphere must be an AtmosphereLutHandle, a mapping, or an object with recognized AETHER settings"
-        )
-    elif getattr(atmosphere, "enabled", None) is False:
-        return None
-    raise RuntimeError(
-        "forge3d_amd: the AETHER atmosphere post (atmosphere=...) is not built yet on the MI355X path; "
-        "refusing to return an image without it"
-    )
+    return resolve_setting(atmosphere)
+
+
+def attach_atmosphere(desc, handle, keep):
+    """Point desc.atmosphere at an f3d_aether_luts built from an AtmosphereLutHandle (keep-alives appended)."""
+    if handle is None:
+        return
+    luts = AetherLuts()
+    tables = [np.ascontiguousarray(t, dtype=np.uint16) for t in (handle.transmittance, handle.accumulated_scattering,
+                                                                  handle.aerial_perspective)]
+    luts.transmittance, luts.accumulated_scattering, luts.aerial = (t.ctypes.data for t in tables)
+    dims, cfg = handle.config.dimensions, handle.config
+    for name in ("transmittance_mu", "transmittance_height", "scattering_mu_view", "scattering_mu_sun", "scattering_height",
+                 "scattering_nu", "aerial_distance", "aerial_mu_view", "aerial_height"):
+        setattr(luts, name, int(getattr(dims, name)))
+    for name in ("turbidity", "ozone_du", "mie_g", "bottom_radius_m", "top_radius_m", "rayleigh_scale_height_m",
+                 "mie_scale_height_m", "max_aerial_distance_m", "ground_albedo"):
+        setattr(luts, name, float(getattr(cfg, name)))
+    luts.scattering_orders = int(cfg.scattering_orders)
+    keep += tables + [luts]
+    desc.atmosphere = C.addressof(luts)
 
 
 def make_desc(heightmap, width, height, cam, spacing, exaggeration, albedo, sun_azimuth_deg, sun_elevation_deg,
               sun_intensity, env_map, env_intensity, mesh_vertices, mesh_indices, spp, max_frames, min_frames,
               variance_threshold, seed, sun_color, observer_latitude_deg, observer_longitude_deg, earth_model,
-              sphere_radius_m, refraction_model, refraction_k, pressure_mbar, temperature_c):
-    """Build the C descriptor; returns (desc, keepalive list)."""
+              sphere_radius_m, refraction_model, refraction_k, pressure_mbar, temperature_c, atmosphere=None):
+    """Build the C descriptor; returns (desc, keepalive list).  atmosphere: an AtmosphereLutHandle or None."""
     dem = np.ascontiguousarray(heightmap, dtype=np.float32)
     if dem.ndim != 2:
         raise TypeError("heightmap must be a 2-D float32 array")
@@ -271,6 +283,7 @@ def make_desc(heightmap, width, height, cam, spacing, exaggeration, albedo, sun_
     d.seed, d.spp = int(seed), int(spp)
     d.max_frames, d.min_frames = int(max_frames), int(min_frames)
     d.variance_threshold = float(variance_threshold)
+    attach_atmosphere(d, atmosphere, keep)
     return d, keep
 
 
@@ -286,12 +299,12 @@ def hybrid_render_terrain_reference(heightmap, width, height, cam, spacing=(1.0,
     hand-written HIP kernels on gfx950 through ``f3d_terrain_ref_render``."""
     _ = cache, certificate  # accepted and ignored (SURVEY.md 8b "side channels")
     sun = [1.0, 0.97, 0.92] if sun_color is None else _extract_sun_color(sun_color)
-    _check_atmosphere(atmosphere)
+    aether = _resolve_atmosphere(atmosphere)
     d, keep = make_desc(heightmap, width, height, cam, spacing, exaggeration, albedo, sun_azimuth_deg,
                         sun_elevation_deg, sun_intensity, env_map, env_intensity, mesh_vertices, mesh_indices, spp,
                         max_frames, min_frames, variance_threshold, seed, sun, observer_latitude_deg,
                         observer_longitude_deg, earth_model, sphere_radius_m, refraction_model, refraction_k,
-                        pressure_mbar, temperature_c)
+                        pressure_mbar, temperature_c, aether)
     L = lib()
     h, w = int(height), int(width)
     rgba = np.zeros((h, w, 4), np.uint8)

@@ -1,0 +1,262 @@
+"""AETHER atmosphere transport for the terrain path tracer: configuration, LUT payloads and their provenance.
+
+Reference surface: ``AtmosphereConfig`` / ``LutDimensions`` (src/core/atmosphere/bake.rs:30-243), the shipped
+five-anchor turbidity bank and its interpolation (src/core/atmosphere/precomputed.rs:5-140,
+``load_precomputed_atmosphere_luts`` bake.rs:674-769) and the typed hand-off ``AtmosphereLutHandle``
+(src/core/atmosphere/runtime.rs:38-89) that ``hybrid_render_terrain_reference(atmosphere=...)`` consumes
+(src/py_functions/path_tracing/terrain_reference.rs:45-219).
+
+Where the tables come from.  The reference compiles its bank (5 x 598 032 bytes, ``turbidity-{1,2,4,8,10}.bin``)
+into the extension module.  This package does not ship that data: ``load_shipped`` reads the bank from a directory
+-- ``bank_dir=``, ``$FORGE3D_AETHER_LUT_DIR``, or ``$FORGE3D_REPO_ROOT/src/core/atmosphere/precomputed`` (a forge3d
+checkout) -- verifies every anchor it touches against the reference's locked SHA-256 (precomputed.rs:36-43) and
+applies the reference's bracket interpolation.  Nothing is substituted: a missing bank is an error.
+"""
+from __future__ import annotations
+
+import hashlib
+import math
+import os
+from dataclasses import dataclass, field, replace
+from pathlib import Path
+
+import numpy as np
+
+TURBIDITY_BANK = (1.0, 2.0, 4.0, 8.0, 10.0)
+ANCHOR_SHA256 = {  # precomputed.rs:36-43
+    1.0: "9ead28087343283942d0bf834aecfb7b3a7b0ea513b830731c2cf9bc77a15f0b",
+    2.0: "c6a77bd25241d6123078cace17d9a2181b520c44ac0e871274d755e092e565bc",
+    4.0: "350a1d13863ac0f4a38a3be585e663a8e8c701c14cb5484760cb0d5ccbe772cd",
+    8.0: "56594423699db4a644650e21f231824f19cb52c0abd718c88b7e4f21f00759cf",
+    10.0: "633b77f0a6d8c31a4640e666ba45c7068fa31b7f623b1f711e5117583c1f51f5",
+}
+WAVELENGTHS_NM = (380.0, 420.0, 460.0, 500.0, 540.0, 580.0, 620.0, 660.0, 700.0, 740.0, 780.0)
+
+
+@dataclass(frozen=True)
+class LutDimensions:
+    """bake.rs:30-58 (default = the shipped bank's, precomputed.rs:6-11)"""
+    transmittance_mu: int = 32
+    transmittance_height: int = 8
+    scattering_mu_view: int = 17
+    scattering_mu_sun: int = 17
+    scattering_height: int = 8
+    scattering_nu: int = 16
+    aerial_distance: int = 8
+    aerial_mu_view: int = 8
+    aerial_height: int = 8
+
+    def texel_counts(self):
+        s = self.scattering_mu_view * self.scattering_mu_sun * self.scattering_height * self.scattering_nu
+        return (self.transmittance_mu * self.transmittance_height, s, s,
+                self.aerial_distance * self.aerial_mu_view * self.aerial_height)
+
+
+@dataclass(frozen=True)
+class AtmosphereConfig:
+    """bake.rs:131-162"""
+    turbidity: float = 2.0
+    ozone_du: float = 300.0
+    mie_g: float = 0.8
+    bottom_radius_m: float = 6_360_000.0
+    top_radius_m: float = 6_460_000.0
+    rayleigh_scale_height_m: float = 8_000.0
+    mie_scale_height_m: float = 1_200.0
+    max_aerial_distance_m: float = 160_000.0
+    ground_albedo: float = 0.3
+    scattering_orders: int = 4
+    dimensions: LutDimensions = field(default_factory=LutDimensions)
+
+    def problem(self) -> "str | None":
+        """AtmosphereConfig::validate, bake.rs:164-229: the first violated rule."""
+        scalars = (self.turbidity, self.ozone_du, self.mie_g, self.bottom_radius_m, self.top_radius_m,
+                   self.rayleigh_scale_height_m, self.mie_scale_height_m, self.max_aerial_distance_m, self.ground_albedo)
+        if not all(math.isfinite(v) for v in scalars):
+            return "all scalar parameters must be finite"
+        if not 1.0 <= self.turbidity <= 10.0:
+            return "turbidity must be in [1, 10]"
+        if not 0.0 <= self.ozone_du <= 600.0:
+            return "ozone must be in [0, 600] DU"
+        if not 0.0 <= self.mie_g <= 0.99:
+            return "mie_g must be in [0, 0.99]"
+        if self.bottom_radius_m <= 0.0 or self.top_radius_m <= self.bottom_radius_m:
+            return "top radius must exceed a positive bottom radius"
+        if min(self.rayleigh_scale_height_m, self.mie_scale_height_m, self.max_aerial_distance_m) <= 0.0:
+            return "scale heights and aerial distance must be positive"
+        if not 0.0 <= self.ground_albedo <= 1.0:
+            return "ground albedo must be in [0, 1]"
+        if not 2 <= int(self.scattering_orders) <= 8:
+            return "scattering_orders must be in [2, 8]"
+        return None
+
+
+def _f32(v) -> np.float32:
+    return np.float32(v)
+
+
+def _same_bits(a, b) -> bool:
+    return _f32(a).tobytes() == _f32(b).tobytes()
+
+
+def find_bank(bank_dir=None) -> Path:
+    """Directory holding the reference's turbidity-*.bin anchors."""
+    candidates = []
+    if bank_dir:
+        candidates.append(Path(bank_dir))
+    if os.environ.get("FORGE3D_AETHER_LUT_DIR"):
+        candidates.append(Path(os.environ["FORGE3D_AETHER_LUT_DIR"]))
+    if os.environ.get("FORGE3D_REPO_ROOT"):
+        candidates.append(Path(os.environ["FORGE3D_REPO_ROOT"]) / "src" / "core" / "atmosphere" / "precomputed")
+    for c in candidates:
+        if c.is_dir() and any(c.glob("turbidity-*.bin")):
+            return c
+    raise FileNotFoundError(
+        "no AETHER LUT bank found (looked in bank_dir, $FORGE3D_AETHER_LUT_DIR, $FORGE3D_REPO_ROOT/src/core/atmosphere/"
+        "precomputed): forge3d_amd does not ship the reference's baked tables")
+
+
+def _read_anchor(bank: Path, turbidity: float, dims: LutDimensions):
+    name = bank / f"turbidity-{int(turbidity)}.bin"
+    counts = dims.texel_counts()
+    expected = sum(counts) * 8 + 4 * 4  # four RGBA16F tables + four f32 order deltas (precomputed.rs:13-25)
+    raw = name.read_bytes()
+    if len(raw) != expected:
+        raise ValueError(f"{name}: {len(raw)} bytes, the shipped anchor layout has {expected}")
+    digest = hashlib.sha256(raw).hexdigest()
+    if digest != ANCHOR_SHA256[turbidity]:
+        raise ValueError(f"{name}: SHA-256 {digest} is not the reference's locked anchor {ANCHOR_SHA256[turbidity]}")
+    tables, off = [], 0
+    for n in counts:
+        tables.append(np.frombuffer(raw, dtype="<u2", count=n * 4, offset=off).copy())
+        off += n * 8
+    deltas = np.frombuffer(raw, dtype="<f4", count=4, offset=off).copy()
+    return tables, deltas
+
+
+@dataclass
+class AtmosphereLutHandle:
+    """Immutable LUT payload + the physical configuration it was baked for (runtime.rs:38-89).
+    Tables are RGBA16F bit patterns (uint16), x fastest."""
+    config: AtmosphereConfig
+    transmittance: np.ndarray
+    single_scattering: np.ndarray
+    accumulated_scattering: np.ndarray
+    aerial_perspective: np.ndarray
+    order_deltas: np.ndarray
+    precomputed: bool = True
+    precomputed_turbidity_bracket: "tuple | None" = None
+
+    @classmethod
+    def load_shipped(cls, config: "AtmosphereConfig | None" = None, bank_dir=None) -> "AtmosphereLutHandle":
+        """load_precomputed_atmosphere_luts, bake.rs:690-769: only the turbidity may differ from the shipped
+        physical inputs; between anchors every f16 texel is interpolated in f32 and rounded back to f16."""
+        config = config or AtmosphereConfig()
+        problem = config.problem()
+        if problem:
+            raise ValueError(problem)
+        defaults = AtmosphereConfig()
+        if config.dimensions != LutDimensions():
+            raise RuntimeError(f"precomputed atmosphere bank does not support dimensions={config.dimensions}; shipped dimensions are "
+                               f"{LutDimensions()}")
+        for name in ("ozone_du", "mie_g", "bottom_radius_m", "top_radius_m", "rayleigh_scale_height_m",
+                     "mie_scale_height_m", "max_aerial_distance_m", "ground_albedo"):
+            if not _same_bits(getattr(config, name), getattr(defaults, name)):
+                raise RuntimeError(f"precomputed atmosphere bank does not support {name}={getattr(config, name)}; shipped value is "
+                                   f"{getattr(defaults, name)}")
+        if int(config.scattering_orders) != 4:
+            raise RuntimeError(f"precomputed atmosphere bank does not support scattering_orders={config.scattering_orders}; shipped value is 4")
+        t = _f32(config.turbidity)
+        lower = upper = 4
+        factor = _f32(0.0)
+        for i in range(4):  # precomputed_bracket, bake.rs:674-688
+            a, b = _f32(TURBIDITY_BANK[i]), _f32(TURBIDITY_BANK[i + 1])
+            if t <= b:
+                lower, upper, factor = i, i + 1, (t - a) / (b - a)
+                break
+        bank = find_bank(bank_dir)
+        if lower == upper or factor <= 0.0:
+            pick = lower
+        elif factor >= 1.0:
+            pick = upper
+        else:
+            pick = None
+        if pick is not None:
+            tables, deltas = _read_anchor(bank, TURBIDITY_BANK[pick], config.dimensions)
+        else:
+            (ta, da), (tb, db) = (_read_anchor(bank, TURBIDITY_BANK[k], config.dimensions) for k in (lower, upper))
+            tables = []
+            for a, b in zip(ta, tb):
+                fa, fb = a.view(np.float16).astype(np.float32), b.view(np.float16).astype(np.float32)
+                tables.append((fa + (fb - fa) * factor).astype(np.float16).view(np.uint16))
+            deltas = (da + (db - da) * factor).astype(np.float32)
+        return cls(config, tables[0], tables[1], tables[2], tables[3], deltas, True,
+                   (TURBIDITY_BANK[lower], TURBIDITY_BANK[upper]))
+
+    def deterministic_sha256_hex(self) -> str:
+        """A stable key of payload + configuration (the reference hashes its own serialisation; this key is this
+        package's, used for cache lookups only)."""
+        h = hashlib.sha256()
+        for arr in (self.transmittance, self.single_scattering, self.accumulated_scattering, self.aerial_perspective):
+            h.update(np.ascontiguousarray(arr, "<u2").tobytes())
+        h.update(np.ascontiguousarray(self.order_deltas, "<f4").tobytes())
+        h.update(repr(self.config).encode())
+        return h.hexdigest()
+
+    def byte_size(self) -> int:
+        return 2 * (self.transmittance.size + self.single_scattering.size + self.accumulated_scattering.size
+                    + self.aerial_perspective.size)
+
+
+_SETTING_KEYS = ("enabled", "lut_handle", "turbidity", "ozone_du", "mie_g", "ground_albedo", "scattering_orders")
+
+
+def resolve_setting(atmosphere, bank_dir=None) -> "AtmosphereLutHandle | None":
+    """``atmosphere=`` of hybrid_render_terrain_reference -> handle or None
+    (extract_atmosphere_lut_handle, terrain_reference.rs:45-219: same acceptance rules, messages and exception types)."""
+    from collections.abc import Mapping
+
+    if atmosphere is None:
+        return None
+    if isinstance(atmosphere, AtmosphereLutHandle):
+        return atmosphere
+    is_mapping = isinstance(atmosphere, Mapping)
+    if is_mapping:
+        for key in atmosphere.keys():
+            if not isinstance(key, str):
+                raise TypeError("atmosphere mapping keys must be strings")
+            if key not in _SETTING_KEYS:
+                raise ValueError(f'unknown atmosphere setting "{key}"; expected one of {", ".join(_SETTING_KEYS)}')
+        item = atmosphere.get
+    else:
+        def item(name):
+            return getattr(atmosphere, name, None)
+        if all(not hasattr(atmosphere, k) for k in _SETTING_KEYS):
+            raise TypeError("atmosphere must be an AtmosphereLutHandle, a mapping, or an object with recognized AETHER settings")
+    if item("enabled") is False:
+        return None
+    handle = item("lut_handle")
+    if handle is not None:
+        if not isinstance(handle, AtmosphereLutHandle):
+            raise TypeError("atmosphere.lut_handle must be an AtmosphereLutHandle returned by atmosphere_bake_luts()")
+        for name in ("turbidity", "ozone_du", "mie_g", "ground_albedo"):
+            supplied = item(name)
+            if supplied is not None and not _same_bits(supplied, getattr(handle.config, name)):
+                raise ValueError(f"atmosphere.{name}={float(_f32(supplied))} does not match the exact LUT handle value "
+                                 f"{float(_f32(getattr(handle.config, name)))}; refusing to substitute or relabel transport")
+        orders = item("scattering_orders")
+        if orders is not None and int(orders) != int(handle.config.scattering_orders):
+            raise ValueError(f"atmosphere.scattering_orders={int(orders)} does not match the exact LUT handle value "
+                             f"{handle.config.scattering_orders}; refusing to substitute or relabel transport")
+        return handle
+    overrides = {k: (int(item(k)) if k == "scattering_orders" else float(item(k)))
+                 for k in ("turbidity", "ozone_du", "mie_g", "ground_albedo", "scattering_orders") if item(k) is not None}
+    config = replace(AtmosphereConfig(), **overrides)
+    problem = config.problem()
+    if problem:
+        raise ValueError(f"invalid AETHER settings: invalid atmosphere configuration: {problem}")
+    try:
+        return AtmosphereLutHandle.load_shipped(config, bank_dir)
+    except (RuntimeError, FileNotFoundError, ValueError) as error:
+        raise RuntimeError(
+            f"PROMETHEUS AETHER could not resolve the shipped LUT bank: {error}. Custom physical inputs require "
+            "lut_handle=atmosphere_bake_luts(...) from an atmosphere-bake build; no nearby or default LUT was substituted.")

@@ -158,6 +158,7 @@ struct f3d_session {
     uint8_t *d_rgba = nullptr;
     float *d_albedo = nullptr, *d_normal = nullptr;
     int variant = 0;
+    AetherDev aether{};  // enabled = 0 without desc.atmosphere
     bool require_valid_reservoirs = false;
     uint64_t budget = 0;
     // band pipelining (f3d_session_opts.bands): horizontal bands of the strip, their streams and events
@@ -196,6 +197,81 @@ struct f3d_session {
 namespace {
 
 void plan_bands(f3d_session &s, uint32_t want, uint32_t want_streams);
+
+// AETHER LUT payload -> device tables (reference AetherPostPass::new, aether_post.rs:42-100: config.validate,
+// validate_luts, three RGBA16F texture uploads).  The tables are decoded to float4 once here.
+void upload_aether(f3d_session &s, const f3d_aether_luts &L, const f3d_terrain_ref_desc &d) {
+    auto bad = [](const char *why) { fail(F3D_STATUS_RENDER, "invalid AETHER PT settings: %s", why); };
+    const float scalars[9] = {L.turbidity, L.ozone_du, L.mie_g, L.bottom_radius_m, L.top_radius_m, L.rayleigh_scale_height_m,
+                              L.mie_scale_height_m, L.max_aerial_distance_m, L.ground_albedo};
+    for (float v : scalars)
+        if (!std::isfinite(v)) bad("all scalar parameters must be finite");  // AtmosphereConfig::validate, bake.rs:164-229
+    if (!(L.turbidity >= 1.0f && L.turbidity <= 10.0f)) bad("turbidity must be in [1, 10]");
+    if (!(L.ozone_du >= 0.0f && L.ozone_du <= 600.0f)) bad("ozone must be in [0, 600] DU");
+    if (!(L.mie_g >= 0.0f && L.mie_g <= 0.99f)) bad("mie_g must be in [0, 0.99]");
+    if (L.bottom_radius_m <= 0.0f || L.top_radius_m <= L.bottom_radius_m) bad("top radius must exceed a positive bottom radius");
+    if (L.rayleigh_scale_height_m <= 0.0f || L.mie_scale_height_m <= 0.0f || L.max_aerial_distance_m <= 0.0f)
+        bad("scale heights and aerial distance must be positive");
+    if (!(L.ground_albedo >= 0.0f && L.ground_albedo <= 1.0f)) bad("ground albedo must be in [0, 1]");
+    if (L.scattering_orders < 2u || L.scattering_orders > 8u) bad("scattering_orders must be in [2, 8]");
+    const uint32_t dims[9] = {L.transmittance_mu, L.transmittance_height, L.scattering_mu_view, L.scattering_mu_sun,
+                              L.scattering_height, L.scattering_nu, L.aerial_distance, L.aerial_mu_view, L.aerial_height};
+    for (uint32_t v : dims)
+        if (v < 2u || v > 4096u) fail(F3D_STATUS_RENDER, "PROMETHEUS AETHER LUT dimensions do not match metadata");
+    if (!L.transmittance || !L.accumulated_scattering || !L.aerial)
+        fail(F3D_STATUS_RENDER, "PROMETHEUS AETHER requires rgba16float accumulated-scattering LUTs");
+    struct Table {
+        const uint16_t *src;
+        size_t texels;
+        float max_value;
+        bool alpha_only;
+        const char *label;
+    };
+    const Table tables[3] = {
+        {L.transmittance, (size_t)L.transmittance_mu * L.transmittance_height, 1.0f, false, "transmittance"},
+        {L.accumulated_scattering, (size_t)L.scattering_mu_view * L.scattering_mu_sun * L.scattering_height * L.scattering_nu,
+         65504.0f, false, "accumulated-scattering"},
+        {L.aerial, (size_t)L.aerial_distance * L.aerial_mu_view * L.aerial_height, 1.0f, true, "aerial-perspective"}};
+    const float4 *dev[3];
+    for (int t = 0; t < 3; t++) {
+        std::vector<float> f(tables[t].texels * 4);
+        for (size_t i = 0; i < f.size(); i++) {
+            const float v = half_value(tables[t].src[i]);
+            // validate_lut_payload / the aerial semantics check, runtime.rs:124-150, :229-240
+            if (!std::isfinite(v) || v < 0.0f || v > tables[t].max_value)
+                fail(F3D_STATUS_RENDER, "runtime %s payload component %zu must be finite and in [0, %g], got %g", tables[t].label, i,
+                     (double)tables[t].max_value, (double)v);
+            if (tables[t].alpha_only && (i & 3u) != 3u && v != 0.0f)
+                fail(F3D_STATUS_RENDER,
+                     "runtime aerial-perspective payload must store zero RGB and unit-bounded transmittance alpha");
+            f[i] = v;
+        }
+        float4 *p = (float4 *)s.mem.alloc(f.size() * sizeof(float), "AETHER LUT");
+        hip_check(hipMemcpy(p, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice), "AETHER LUT upload");
+        dev[t] = p;
+    }
+    AetherDev &A = s.aether;
+    A.transmittance = dev[0];
+    A.scattering = dev[1];
+    A.aerial = dev[2];
+    A.t_mu = L.transmittance_mu;
+    A.t_h = L.transmittance_height;
+    A.s_view = L.scattering_mu_view;
+    A.s_sun = L.scattering_mu_sun;
+    A.s_h = L.scattering_height;
+    A.s_nu = L.scattering_nu;
+    A.a_dist = L.aerial_distance;
+    A.a_mu = L.aerial_mu_view;
+    A.a_h = L.aerial_height;
+    A.bottom_radius = L.bottom_radius_m;
+    A.top_radius = L.top_radius_m;
+    A.max_aerial_distance = L.max_aerial_distance_m;
+    A.ozone_du = L.ozone_du;
+    A.turbidity = L.turbidity;
+    A.sun_intensity = aether_clamp_scale(f_clamp(d.sun_intensity, 0.0f, 65504.0f));
+    A.exposure = aether_clamp_scale(f_clamp(d.exposure, 0.0f, 65504.0f));
+    A.enabled = 1u;
+}
 
 void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_session_opts *opts) {
     validate_desc(d);
@@ -272,6 +348,7 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
             P.mesh.bvh_node_count = (uint32_t)bvh.nodes.size();
         }
     }
+    if (d.atmosphere) upload_aether(s, *d.atmosphere, d);
     P.row_begin = s.row_begin;
     P.row_end = s.row_end;
     P.band_begin = s.row_begin;
@@ -530,6 +607,8 @@ void resolve(f3d_session &s, uint32_t frames, uint8_t *d_rgba, float *d_albedo, 
     R.rgba = d_rgba;
     R.albedo = d_albedo;
     R.normal = d_normal;
+    R.aether = s.aether;
+    R.depth = s.depth;
     hip_check(hipMemsetAsync(s.stats + 2, 0, 2 * sizeof(uint32_t), s.stream), "stats clear");
     hip_check(launch_resolve(R, s.stream), "resolve kernel");
 }

@@ -459,7 +459,7 @@ __global__ __launch_bounds__(kWave) void k_resolve(const ResolveParams R) {
     uint32_t gx, gy;
     const bool active = tile_pixel(R.frame, gx, gy);
     uint32_t flags = 0u;
-    if (active) flags = resolve_pixel(R.frame, R.frames, gx, gy, R.rgba, R.albedo, R.normal);
+    if (active) flags = resolve_pixel(R.frame, R.frames, gx, gy, R.rgba, R.albedo, R.normal, &R.aether, R.depth);
     const unsigned long long valid = __ballot((flags & 1u) != 0u), bad = __ballot((flags & 2u) != 0u);
     if (threadIdx.x == 0) {
         if (valid) atomicOr(&R.frame.stats[2], 1u);

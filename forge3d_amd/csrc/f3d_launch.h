@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include "f3d_aether.h"
 #include "f3d_build.h"
 #include "f3d_scene.h"
 
@@ -24,6 +25,8 @@ struct ResolveParams {
     uint32_t frames;
     uint8_t *rgba;
     float *albedo, *normal;
+    AetherDev aether;    // enabled = 0: the plain Reinhard resolve
+    const float *depth;  // frame-0 depth AOV (the aerial-perspective post's segment length)
 };
 
 hipError_t launch_head(const FrameParams &p, hipStream_t stream);  // sample-lane form: before launch_frame

@@ -302,7 +302,7 @@ inline LevelBuildParams level_build_params(const TableLayout &t, uint32_t l, con
 // curvature, camera, lighting (render_terrain.rs:571-576, :635-742).  Returns whether a
 // sun-lit scene must end with valid reservoirs (render_terrain.rs:465-471).
 inline bool fill_uniforms(const f3d_terrain_ref_desc &d, FrameParams &P) {
-    const float kScaleMax = 1.0e6f;  // AETHER_RADIOMETRIC_SCALE_MAX
+    const float kScaleMax = 65504.0f;  // AETHER_RADIOMETRIC_SCALE_MAX (reference src/core/atmosphere/mod.rs:11)
     const float exposure = f_clamp(d.exposure, 0.0f, kScaleMax);
     const float sun_intensity = f_clamp(d.sun_intensity, 0.0f, kScaleMax);
     const float sun_color[3] = {f_clamp(d.sun_color[0], 0.0f, kScaleMax), f_clamp(d.sun_color[1], 0.0f, kScaleMax),

@@ -13,6 +13,7 @@
 // its G-buffer centre ray (:619-644) are the same ray.
 #pragma once
 
+#include "f3d_aether.h"
 #include "f3d_march.h"
 #include "f3d_trace.h"
 
@@ -569,8 +570,10 @@ F3D_HD void gbuffer_pixel(const FrameParams &P, uint32_t gx, uint32_t gy, float4
 // ---- final resolve: last spatial pass + validity (render_terrain.rs:1313-1337),
 // Reinhard -> RGBA16F -> u8 (hybrid_kernel.wgsl:109-112, render_terrain.rs:1358-1366),
 // AOVs through RGBA16F (render_terrain.rs:438-447, :1367-1393). flags: bit0 valid, bit1 bad.
+// aether != null && aether->enabled: the AETHER aerial-perspective post (f3d_aether.h) replaces the plain Reinhard.
 F3D_HD uint32_t resolve_pixel(const FrameParams &P, uint32_t frames, uint32_t gx, uint32_t gy, uint8_t *rgba,
-                              float *albedo, float *normal) {
+                              float *albedo, float *normal, const AetherDev *aether = nullptr,
+                              const float *depth = nullptr) {
     const size_t lp = (size_t)(gy - P.row_begin) * P.cam.width + gx;
     const float4 g = P.gbuffer_n[lp];
     const Reservoir r = spatial_reuse(P, P.res_in, gx, gy, frames - 1u, V3{g.x, g.y, g.z});
@@ -580,8 +583,27 @@ F3D_HD uint32_t resolve_pixel(const FrameParams &P, uint32_t frames, uint32_t gx
 
     const float4 am = P.accum_mean[lp];
     const float count = (float)frames;
-    const V3 e = V3{am.x / count, am.y / count, am.z / count} * P.cam.exposure;
-    const float ldr[3] = {e.x / (1.0f + e.x), e.y / (1.0f + e.y), e.z / (1.0f + e.z)};
+    const V3 mean = V3{am.x / count, am.y / count, am.z / count};
+    float ldr[3];
+    if (aether && aether->enabled != 0u) {
+        // the unjittered pixel ray as prometheus_aerial.wgsl:113-121 forms it
+        const float ndc_x = (((float)gx + 0.5f) / (float)P.cam.width) * 2.0f - 1.0f;
+        const float ndc_y = (1.0f - ((float)gy + 0.5f) / (float)P.cam.height) * 2.0f - 1.0f;
+        const float aspect = (float)P.cam.width / (float)P.cam.height;
+        const float sx = ndc_x * P.cam.half_h * aspect, sy = ndc_y * P.cam.half_h;
+        const V3 ray = normalize(V3{P.cam.right.x * sx + P.cam.up.x * sy + P.cam.forward.x,
+                                    P.cam.right.y * sx + P.cam.up.y * sy + P.cam.forward.y,
+                                    P.cam.right.z * sx + P.cam.up.z * sy + P.cam.forward.z});
+        const V3 c = aether_resolve(*aether, mean, depth[lp], g.w != 0.0f, ray, P.light.wi, P.cam.origin.y);
+        ldr[0] = c.x;
+        ldr[1] = c.y;
+        ldr[2] = c.z;
+    } else {
+        const V3 e = mean * P.cam.exposure;
+        ldr[0] = e.x / (1.0f + e.x);
+        ldr[1] = e.y / (1.0f + e.y);
+        ldr[2] = e.z / (1.0f + e.z);
+    }
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         const float v = round_to_half(ldr[c]);

@@ -26,7 +26,7 @@ class TerrainSession:
                  env_intensity=0.35, mesh_vertices=None, mesh_indices=None, spp=1, max_frames=512, min_frames=32,
                  variance_threshold=1e-3, seed=7, observer_latitude_deg=0.0, observer_longitude_deg=0.0,
                  earth_model="ellipsoid", sphere_radius_m=6_371_008.8, refraction_model="bennett",
-                 refraction_k=0.13, pressure_mbar=1013.25, temperature_c=15.0):
+                 refraction_k=0.13, pressure_mbar=1013.25, temperature_c=15.0, atmosphere=None):
         self._lib = _native.lib()
         self._handle = C.c_void_p(None)
         desc, keep = _native.make_desc(heightmap, width, height, dict(camera or {}), spacing, exaggeration, albedo,
@@ -34,7 +34,7 @@ class TerrainSession:
                                        mesh_vertices, mesh_indices, spp, max_frames, min_frames,
                                        variance_threshold, seed, sun_color, observer_latitude_deg,
                                        observer_longitude_deg, earth_model, sphere_radius_m, refraction_model,
-                                       refraction_k, pressure_mbar, temperature_c)
+                                       refraction_k, pressure_mbar, temperature_c, atmosphere)
         opts = _native.SessionOpts()
         opts.device = int(device)
         opts.stream = C.c_void_p(int(stream) or None)

@@ -39,6 +39,21 @@ extern "C" {
 #define F3D_REFRACTION_SAEMUNDSSON 2
 #define F3D_REFRACTION_EFFECTIVE_RADIUS 3
 
+/* AETHER LUT payload handed to the aerial-perspective post: the reference's AtmosphereLutHandle
+ * (src/core/atmosphere/runtime.rs:38-89; payload layout src/core/atmosphere/precomputed.rs:5-25) as plain host
+ * pointers.  Tables are RGBA16F bit patterns, x fastest: transmittance [height][mu], accumulated scattering
+ * [height * nu_count + nu][mu_sun][mu_view], aerial [height][mu_view][distance] (rgb = 0, a = mean transmittance). */
+typedef struct f3d_aether_luts {
+    const uint16_t *transmittance, *accumulated_scattering, *aerial;
+    uint32_t transmittance_mu, transmittance_height;
+    uint32_t scattering_mu_view, scattering_mu_sun, scattering_height, scattering_nu;
+    uint32_t aerial_distance, aerial_mu_view, aerial_height;
+    /* AtmosphereConfig, src/core/atmosphere/bake.rs:131-162 */
+    float turbidity, ozone_du, mie_g, bottom_radius_m, top_radius_m, rayleigh_scale_height_m, mie_scale_height_m,
+        max_aerial_distance_m, ground_albedo;
+    uint32_t scattering_orders;
+} f3d_aether_luts;
+
 /* Mirrors TerrainReferenceDesc (reference
  * src/path_tracing/hybrid_compute/render_terrain.rs:239-282) plus the earth /
  * refraction parameters the PyO3 seam parses (src/py_functions/path_tracing/
@@ -68,6 +83,9 @@ typedef struct f3d_terrain_ref_desc {
     uint32_t width, height;
     uint32_t seed, spp, max_frames, min_frames;
     float variance_threshold;
+    /* TerrainReferenceDesc::atmosphere (render_terrain.rs:265): NULL = no aerial perspective; else the converged
+     * accumulation goes through the AETHER post (aether_post.rs, prometheus_aerial.wgsl) before the resolve. */
+    const f3d_aether_luts *atmosphere;
 } f3d_terrain_ref_desc;
 
 /* Mirrors TerrainReferenceOutput (render_terrain.rs:285-299).  The four image

@@ -1130,6 +1130,171 @@ static void fmt_rust_exp(char *buf, size_t n, double v, int prec) {
     snprintf(buf, n, "%se%d", tmp, ex);
 }
 
+
+/* ------------------------------------------------------------------------- */
+/* AETHER aerial-perspective post (prometheus_aerial.wgsl + evaluation_core.wgsl) */
+/* ------------------------------------------------------------------------- */
+/* e^x with every operation spelled (the reference's det_exp is exp2(x*log2e) on the GPU driver; this fixed
+ * polynomial is shared -- restated, not included -- with the HIP kernel so that both produce the same bits) */
+static float ae_exp(float x) {
+    if (x > 88.0f) return INFINITY;
+    if (x < -103.0f) return 0.0f;
+    float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693359375f, x);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float z = r * r;
+    float p = fmaf(1.9875691500e-4f, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    float y = fmaf(p, z, r) + 1.0f;
+    int e = (int)n;
+    union { uint32_t u; float f; } sc;
+    if (e < -126) {
+        sc.u = (uint32_t)(e + 64 + 127) << 23;
+        return (y * sc.f) * 5.42101086242752217e-20f;
+    }
+    sc.u = (uint32_t)(e + 127) << 23;
+    return y * sc.f;
+}
+static float ae_clamp_scale(float v) { return fminf(fmaxf(v, 0.0f), 65504.0f); } /* evaluation_core.wgsl:29-33 */
+static v3 ae_clamp_hdr(v3 c) { /* :35-37 */
+    return v3_make(fminf(fmaxf(c.x, 0.0f), 65504.0f), fminf(fmaxf(c.y, 0.0f), 65504.0f), fminf(fmaxf(c.z, 0.0f), 65504.0f));
+}
+static float ae_mu_to_unit(float mu) { /* :82-90 */
+    float b = clampf(mu, -1.0f, 1.0f), m = sqrtf(fabsf(b));
+    return 0.5f * ((b >= 0.0f ? m : -m) + 1.0f);
+}
+static float ae_nu_to_unit(float nu) { return 1.0f - sqrtf(fmaxf(0.5f * (1.0f - clampf(nu, -1.0f, 1.0f)), 0.0f)); } /* :92-94 */
+static int ae_round_index(float unit, uint32_t n) { return (int)rintf(unit * (float)((n > 1u ? n : 1u) - 1u)); }
+
+/* aether_eval_sample_accumulated_scattering, :119-177 (table = rgba f32, x = view fastest, then sun, then h*nu+n) */
+static v3 ae_scattering(const f3do_aether *A, float height_unit, float mu_sun, float mu_view, float nu) {
+    const uint32_t sv = A->dims[2], ss = A->dims[3], sh = A->dims[4], sn = A->dims[5];
+    int hc = (int)sh > 2 ? (int)sh : 2, nc = (int)sn > 2 ? (int)sn : 2;
+    float c[4] = {ae_mu_to_unit(mu_view) * (float)(sv - 1u), ae_mu_to_unit(mu_sun) * (float)(ss - 1u),
+                  sqrtf(clampf(height_unit, 0.0f, 1.0f)) * (float)(hc - 1), ae_nu_to_unit(nu) * (float)(nc - 1)};
+    int lim[4] = {(int)sv - 1, (int)ss - 1, hc - 1, nc - 1}, lo[4], hi[4];
+    float fr[4];
+    for (int k = 0; k < 4; k++) {
+        float fl = floorf(c[k]);
+        lo[k] = (int)fl;
+        hi[k] = lo[k] + 1 < lim[k] ? lo[k] + 1 : lim[k];
+        fr[k] = c[k] - fl;
+    }
+    int depth = (int)(sh * sn);
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+    for (int hs = 0; hs < 2; hs++)
+        for (int ns = 0; ns < 2; ns++)
+            for (int s2 = 0; s2 < 2; s2++)
+                for (int vs = 0; vs < 2; vs++) {
+                    int vi = vs ? hi[0] : lo[0], si = s2 ? hi[1] : lo[1], hh = hs ? hi[2] : lo[2], ni = ns ? hi[3] : lo[3];
+                    float w = (vs ? fr[0] : 1.0f - fr[0]) * (s2 ? fr[1] : 1.0f - fr[1]) * (hs ? fr[2] : 1.0f - fr[2]) *
+                              (ns ? fr[3] : 1.0f - fr[3]);
+                    int x = vi, y = si, z = hh * nc + ni;
+                    x = x < 0 ? 0 : (x > (int)sv - 1 ? (int)sv - 1 : x);
+                    y = y < 0 ? 0 : (y > (int)ss - 1 ? (int)ss - 1 : y);
+                    z = z < 0 ? 0 : (z > depth - 1 ? depth - 1 : z);
+                    const float *t = A->scattering + 4 * (((size_t)z * ss + (size_t)y) * sv + (size_t)x);
+                    ax = ax + w * t[0];
+                    ay = ay + w * t[1];
+                    az = az + w * t[2];
+                }
+    return v3_make(fmaxf(ax, 0.0f), fmaxf(ay, 0.0f), fmaxf(az, 0.0f));
+}
+static float ae_radius(float cam_h, float mu, float dist, float bottom) { /* :179-192 */
+    float r = fmaxf(bottom, 1.0f) + clampf(cam_h, 0.0f, 100000.0f), d = clampf(dist, 0.0f, 20000000.0f);
+    return sqrtf(fmaxf(r * r + d * d + 2.0f * r * d * clampf(mu, -1.0f, 1.0f), 0.0f));
+}
+static float ae_altitude(float cam_h, float mu, float dist, float bottom) { /* :194-203 */
+    return clampf(ae_radius(cam_h, mu, dist, bottom) - fmaxf(bottom, 1.0f), 0.0f, 100000.0f);
+}
+static const float AE_WL[11] = {380.0f, 420.0f, 460.0f, 500.0f, 540.0f, 580.0f, 620.0f, 660.0f, 700.0f, 740.0f, 780.0f};
+static const float AE_CIE[11][3] = {{0.001368f, 0.000039f, 0.006450f}, {0.134380f, 0.004000f, 0.645600f}, {0.290800f, 0.060000f, 1.669200f},
+                                    {0.004900f, 0.323000f, 0.272000f}, {0.290400f, 0.954000f, 0.020300f}, {0.916300f, 0.870000f, 0.001650f},
+                                    {0.854450f, 0.381000f, 0.000190f}, {0.164900f, 0.061000f, 0.000000f}, {0.011359f, 0.004102f, 0.000000f},
+                                    {0.000690f, 0.000249f, 0.000000f}, {0.000042f, 0.000015f, 0.000000f}};
+/* aether_eval_segment_transmittance, :238-344 */
+static v3 ae_segment_transmittance(float dist, float cam_h, float mu, float bottom, float density_scale, float turbidity, float ozone_du) {
+    float d = clampf(dist, 0.0f, 20000000.0f), ch = clampf(cam_h, 0.0f, 100000.0f), hs[16];
+    for (int i = 0; i < 16; i++) hs[i] = ae_altitude(ch, mu, d * ((float)(2 * i + 1) * 0.03125f), bottom);
+    float ray = ae_exp(-hs[0] / 8000.0f), mie = ae_exp(-hs[0] / 1200.0f), ozo = fmaxf(1.0f - fabsf((hs[0] - 25000.0f) / 15000.0f), 0.0f);
+    for (int i = 1; i < 16; i++) ray = ray + ae_exp(-hs[i] / 8000.0f);
+    for (int i = 1; i < 16; i++) mie = mie + ae_exp(-hs[i] / 1200.0f);
+    for (int i = 1; i < 16; i++) ozo = ozo + fmaxf(1.0f - fabsf((hs[i] - 25000.0f) / 15000.0f), 0.0f);
+    float per = d * density_scale * 0.0625f;
+    float ray_col = per * ray, mie_col = per * mie, ozo_col = per * ozo * ozone_du / 300.0f;
+    float X = 0.0f, Y = 0.0f, Z = 0.0f;
+    for (int w = 0; w < 11; w++) { /* aether_eval_spectral_xyz, :50-80 */
+        float ratio = 550.0f / AE_WL[w], r2 = ratio * ratio;
+        float ray_beta = 1.2989e-5f * r2 * r2, mie_beta = 1.0e-5f * turbidity * ratio;
+        float od = (AE_WL[w] - 600.0f) / 85.0f;
+        float ozo_beta = 1.2e-6f * ae_exp(-0.5f * od * od);
+        float t = ae_exp(-fmaxf(ray_beta * ray_col + mie_beta * mie_col + ozo_beta * ozo_col, 0.0f));
+        float ew = (w == 0 || w == 10) ? 0.5f : 1.0f;
+        float cx = AE_CIE[w][0] * t * ew, cy = AE_CIE[w][1] * t * ew, cz = AE_CIE[w][2] * t * ew;
+        X = w == 0 ? cx : X + cx;
+        Y = w == 0 ? cy : Y + cy;
+        Z = w == 0 ? cz : Z + cz;
+    }
+    v3 xyz = v3_make(X, Y, Z); /* aether_eval_xyz_to_rgb, :42-48 */
+    v3 rgb = v3_make(dot3(v3_make(3.2404542f, -1.5371385f, -0.4985314f), xyz) / 3.2613921f,
+                     dot3(v3_make(-0.9692660f, 1.8760108f, 0.0415560f), xyz) / 2.5069624f,
+                     dot3(v3_make(0.0556434f, -0.2040259f, 1.0572252f), xyz) / 2.3679786f);
+    return v3_make(clampf(rgb.x, 0.0f, 1.0f), clampf(rgb.y, 0.0f, 1.0f), clampf(rgb.z, 0.0f, 1.0f));
+}
+/* prometheus_aerial.wgsl main, :99-231: returns the Reinhard-mapped colour stored to the RGBA16F output */
+static v3 ae_post_pixel(const f3do_aether *A, const uniforms_t *un, uint32_t gx, uint32_t gy, const float *acc, float depth,
+                        int visible, float sun_intensity_in) {
+    float den = fmaxf(acc[3], 1.0f);
+    v3 surface = ae_clamp_hdr(v3_make(acc[0] / den, acc[1] / den, acc[2] / den));
+    float ndc_x = (((float)gx + 0.5f) / (float)un->width) * 2.0f - 1.0f;
+    float ndc_y = (1.0f - ((float)gy + 0.5f) / (float)un->height) * 2.0f - 1.0f;
+    float aspect = (float)un->width / (float)un->height;
+    float sx = ndc_x * un->half_h * aspect, sy = ndc_y * un->half_h;
+    v3 ray = normalize3(v3_make(un->cam_right.x * sx + un->cam_up.x * sy + un->cam_forward.x,
+                                un->cam_right.y * sx + un->cam_up.y * sy + un->cam_forward.y,
+                                un->cam_right.z * sx + un->cam_up.z * sy + un->cam_forward.z));
+    v3 sun = normalize3(un->light_dir);
+    float sun_i = ae_clamp_scale(sun_intensity_in), exposure = ae_clamp_scale(un->cam_exposure);
+    float atm_h = fmaxf(A->top_radius_m - A->bottom_radius_m, 1.0f);
+    float cam_h = fmaxf(un->cam_origin.y, 0.0f), cam_unit = clampf(cam_h / atm_h, 0.0f, 1.0f);
+    float nu = dot3(ray, sun);
+    v3 hdr;
+    if (!visible) {
+        v3 s = ae_scattering(A, cam_unit, sun.y, ray.y, nu);
+        hdr = ae_clamp_hdr(v3_make(s.x * sun_i, s.y * sun_i, s.z * sun_i));
+    } else {
+        float end_h = ae_altitude(cam_h, ray.y, depth, A->bottom_radius_m);
+        float r = fmaxf(A->bottom_radius_m, 1.0f) + clampf(cam_h, 0.0f, 100000.0f), bd = clampf(depth, 0.0f, 20000000.0f);
+        float end_r = fmaxf(ae_radius(cam_h, ray.y, bd, A->bottom_radius_m), 1.0f);
+        float end_view_mu = clampf((r * clampf(ray.y, -1.0f, 1.0f) + bd) / end_r, -1.0f, 1.0f);
+        float end_sun_mu = clampf((r * clampf(sun.y, -1.0f, 1.0f) + bd * clampf(nu, -1.0f, 1.0f)) / end_r, -1.0f, 1.0f);
+        v3 seg = ae_segment_transmittance(depth, cam_h, ray.y, A->bottom_radius_m, 1.0f, A->turbidity, A->ozone_du);
+        int bx = ae_round_index(0.5f * (clampf(ray.y, -1.0f, 1.0f) + 1.0f), A->dims[0]), by = ae_round_index(clampf(cam_unit, 0.0f, 1.0f), A->dims[1]);
+        const float *bt = A->transmittance + 4 * ((size_t)by * A->dims[0] + (size_t)bx);
+        v3 boundary = v3_make(clampf(bt[0], 0.0f, 1.0f), clampf(bt[1], 0.0f, 1.0f), clampf(bt[2], 0.0f, 1.0f));
+        v3 cs = ae_scattering(A, cam_unit, sun.y, ray.y, nu);
+        cs = v3_make(cs.x * sun_i, cs.y * sun_i, cs.z * sun_i);
+        float end_unit = clampf(end_h / atm_h, 0.0f, 1.0f);
+        v3 es = ae_scattering(A, end_unit, end_sun_mu, end_view_mu, nu);
+        es = v3_make(es.x * sun_i, es.y * sun_i, es.z * sun_i);
+        float dist_unit = depth / fmaxf(A->max_aerial_distance_m, 1.0f);
+        int ax = ae_round_index(clampf(dist_unit, 0.0f, 1.0f), A->dims[6]), ay = ae_round_index(0.5f * (clampf(ray.y, -1.0f, 1.0f) + 1.0f), A->dims[7]),
+            az = ae_round_index(clampf(cam_unit, 0.0f, 1.0f), A->dims[8]);
+        float aerial_t = clampf(A->aerial[4 * (((size_t)az * A->dims[7] + (size_t)ay) * A->dims[6] + (size_t)ax) + 3], 0.0f, 1.0f);
+        float mean_t = dot3(seg, v3_make(0.2126f, 0.7152f, 0.0722f));
+        float k = aerial_t / fmaxf(mean_t, 1.0e-6f);
+        v3 tr = v3_make(fmaxf(clampf(seg.x * k, 0.0f, 1.0f), boundary.x), fmaxf(clampf(seg.y * k, 0.0f, 1.0f), boundary.y),
+                        fmaxf(clampf(seg.z * k, 0.0f, 1.0f), boundary.z));
+        v3 ins = v3_make(fmaxf(cs.x - tr.x * es.x, 0.0f), fmaxf(cs.y - tr.y * es.y, 0.0f), fmaxf(cs.z - tr.z * es.z, 0.0f));
+        hdr = ae_clamp_hdr(v3_make(surface.x * tr.x + ins.x, surface.y * tr.y + ins.y, surface.z * tr.z + ins.z));
+    }
+    v3 e = v3_make(hdr.x * exposure, hdr.y * exposure, hdr.z * exposure);
+    return v3_make(e.x / (1.0f + e.x), e.y / (1.0f + e.y), e.z / (1.0f + e.z));
+}
+
 int f3do_render(const f3do_desc *d, f3do_out *out, char *err, size_t errlen) {
     int rc = 0;
     mips_t mips;
@@ -1183,8 +1348,8 @@ int f3do_render(const f3do_desc *d, f3do_out *out, char *err, size_t errlen) {
             if (d->mesh_indices[i] >= d->mesh_vertex_count)
                 FAIL(2, "mesh indices reference out-of-bounds vertices");
     }
-    /* clamps, render_terrain.rs:571-576 (AETHER_RADIOMETRIC_SCALE_MAX = 1e6) */
-    const float SCALE_MAX = 1.0e6f;
+    /* clamps, render_terrain.rs:571-576 (AETHER_RADIOMETRIC_SCALE_MAX = 65504, src/core/atmosphere/mod.rs:11) */
+    const float SCALE_MAX = 65504.0f;
     const float exposure = clampf(d->exposure, 0.0f, SCALE_MAX);
     const float sun_intensity = clampf(d->sun_intensity, 0.0f, SCALE_MAX);
     const float sun_color[3] = {clampf(d->sun_color[0], 0.0f, SCALE_MAX), clampf(d->sun_color[1], 0.0f, SCALE_MAX),
@@ -1368,6 +1533,19 @@ int f3do_render(const f3do_desc *d, f3do_out *out, char *err, size_t errlen) {
             FAIL(2,
                  "terrain PT ReSTIR reuse chain produced no valid reservoirs for a sun-lit scene \xe2\x80\x94 "
                  "temporal/spatial reuse is broken");
+    }
+
+    /* AETHER aerial-perspective post over the converged accumulation (render_terrain.rs:1249-1310) */
+    if (d->atmosphere) {
+        uniforms_t pu = un;
+        for (size_t i = 0; i < P; i++) {
+            int visible = !isnan(st.aov_depth[i]);
+            v3 ldr = ae_post_pixel(d->atmosphere, &pu, (uint32_t)(i % d->width), (uint32_t)(i / d->width), &st.accum[4 * i],
+                                   st.aov_depth[i], visible, sun_intensity);
+            st.out_tex[4 * i + 0] = f32_to_f16_bits(ldr.x);
+            st.out_tex[4 * i + 1] = f32_to_f16_bits(ldr.y);
+            st.out_tex[4 * i + 2] = f32_to_f16_bits(ldr.z);
+        }
     }
 
     /* readbacks + quantisation, render_terrain.rs:1340-1393 */

@@ -39,6 +39,16 @@ typedef struct {
     float target_pdf;
 } f3do_reservoir;
 
+/* AETHER LUT payload (reference AtmosphereLuts, src/core/atmosphere/bake.rs:410-423) decoded to f32 RGBA:
+ * dims = {transmittance mu, height, scattering view, sun, height, nu, aerial distance, mu, height}. */
+typedef struct {
+    const float *transmittance, *scattering, *aerial;
+    uint32_t dims[9];
+    float turbidity, ozone_du, mie_g, bottom_radius_m, top_radius_m, rayleigh_scale_height_m, mie_scale_height_m,
+        max_aerial_distance_m, ground_albedo;
+    uint32_t scattering_orders;
+} f3do_aether;
+
 /* Scene description == reference TerrainReferenceDesc
  * (src/path_tracing/hybrid_compute/render_terrain.rs:239-282). */
 typedef struct {
@@ -67,6 +77,7 @@ typedef struct {
     uint32_t width, height;
     uint32_t seed, spp, max_frames, min_frames;
     float variance_threshold;
+    const f3do_aether *atmosphere; /* NULL = no aerial-perspective post */
 } f3do_desc;
 
 typedef struct {

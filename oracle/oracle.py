@@ -95,7 +95,33 @@ class Desc(C.Structure):
         ("max_frames", C.c_uint32),
         ("min_frames", C.c_uint32),
         ("variance_threshold", C.c_float),
+        ("atmosphere", C.c_void_p),
     ]
+
+
+class Aether(C.Structure):
+    """f3do_aether: the three tables the post reads, decoded to f32 RGBA"""
+    _fields_ = [("transmittance", C.c_void_p), ("scattering", C.c_void_p), ("aerial", C.c_void_p),
+                ("dims", C.c_uint32 * 9), ("turbidity", C.c_float), ("ozone_du", C.c_float), ("mie_g", C.c_float),
+                ("bottom_radius_m", C.c_float), ("top_radius_m", C.c_float), ("rayleigh_scale_height_m", C.c_float),
+                ("mie_scale_height_m", C.c_float), ("max_aerial_distance_m", C.c_float), ("ground_albedo", C.c_float),
+                ("scattering_orders", C.c_uint32)]
+
+
+def aether_struct(handle):
+    """(Aether, keep-alives) from an AtmosphereLutHandle-like object (uint16 RGBA16F tables + config)."""
+    a = Aether()
+    keep = [np.ascontiguousarray(np.asarray(t, np.uint16).view(np.float16).astype(np.float32))
+            for t in (handle.transmittance, handle.accumulated_scattering, handle.aerial_perspective)]
+    a.transmittance, a.scattering, a.aerial = (k.ctypes.data for k in keep)
+    d, c = handle.config.dimensions, handle.config
+    a.dims = (C.c_uint32 * 9)(d.transmittance_mu, d.transmittance_height, d.scattering_mu_view, d.scattering_mu_sun,
+                              d.scattering_height, d.scattering_nu, d.aerial_distance, d.aerial_mu_view, d.aerial_height)
+    for name in ("turbidity", "ozone_du", "mie_g", "bottom_radius_m", "top_radius_m", "rayleigh_scale_height_m",
+                 "mie_scale_height_m", "max_aerial_distance_m", "ground_albedo"):
+        setattr(a, name, float(getattr(c, name)))
+    a.scattering_orders = int(c.scattering_orders)
+    return a, keep
 
 
 class Out(C.Structure):
@@ -184,8 +210,9 @@ def render(heightmap, width, height, camera=None, *, spacing=(1.0, 1.0), exagger
            variance_threshold=1e-3, seed=7, observer_latitude_deg=0.0,
            observer_longitude_deg=0.0, earth_model="ellipsoid", sphere_radius_m=6_371_008.8,
            refraction_model="bennett", refraction_k=0.13, pressure_mbar=1013.25,
-           temperature_c=15.0, dump_state=False):
-    """Run the CPU oracle; returns the reference's result dict (+ counters)."""
+           temperature_c=15.0, dump_state=False, atmosphere=None):
+    """Run the CPU oracle; returns the reference's result dict (+ counters).  atmosphere: an
+    AtmosphereLutHandle-like object (the AETHER aerial-perspective post) or None."""
     L = lib()
     dem = np.ascontiguousarray(heightmap, dtype=np.float32)
     cam = dict(camera or {})
@@ -231,6 +258,10 @@ def render(heightmap, width, height, camera=None, *, spacing=(1.0, 1.0), exagger
     d.seed, d.spp = int(seed) & 0xFFFFFFFF, int(spp)
     d.max_frames, d.min_frames = int(max_frames), int(min_frames)
     d.variance_threshold = float(variance_threshold)
+    if atmosphere is not None:
+        aether, aether_keep = aether_struct(atmosphere)
+        keep += aether_keep + [aether]
+        d.atmosphere = C.addressof(aether)
 
     P = int(width) * int(height)
     rgba = np.zeros((height, width, 4), np.uint8)
