@@ -32,9 +32,11 @@ sys.path.insert(0, str(ROOT))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# reservoir r16+w16, accumulation r16+w16, Welford m2 r4+w4, G-buffer r16 = 88 B per
-# pixel-frame; the sample-lane form of the frame kernel adds the frame-head record (w8 + r8)
-STATE_BYTES_PER_PIXEL_FRAME = {False: 88, True: 104}
+# state bytes the FRAME KERNEL moves per pixel-frame.  1-lane kernel (head fused): reservoir r16+w16,
+# accumulation r16+w16, Welford m2 r4+w4, G-buffer r16 = 88 B.  Sample-lane kernel: the head (reservoir and
+# G-buffer reads, 32 B) runs in k_head, which is timed and priced separately; k_frame reads its 8-byte record and
+# the parked reservoir: r8 + r16 + w16 + r16 + w16 + r4 + w4 = 80 B.
+STATE_BYTES_PER_PIXEL_FRAME = {False: 88, True: 80}
 
 
 def parse_args():
@@ -49,7 +51,31 @@ def parse_args():
     ap.add_argument("--variant", type=int, default=int(os.environ.get("F3D_KERNEL_VARIANT", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--extra-windows", type=int, default=4, help="further timed windows of --steps frames (spread report)")
+    ap.add_argument("--no-terrain-filling", action="store_true", help="skip the second, terrain-filling camera")
     return ap.parse_args()
+
+
+def kernel_source_hash() -> str:
+    """SHA-256 over the kernel sources: ties a PMC traffic figure under profiles/ to the code it was measured on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for path in sorted((ROOT / "forge3d_amd" / "csrc").glob("*")):
+        if path.suffix in (".h", ".hip"):
+            h.update(path.name.encode())
+            h.update(path.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def terrain_filling_camera(dem, kw):
+    """Second workload for the same DEM: a camera inside the footprint looking across the massif, so that nearly
+    every pixel is terrain (the headline camera of BASELINE.json configs[1] sees ~60 % sky)."""
+    spacing = kw["spacing"][0]
+    span = (dem.shape[1] - 1) * spacing
+    top = float(dem.max())
+    return {"origin": (-0.30 * span, 0.62 * top, -0.34 * span), "look_at": (0.02 * span, 0.30 * top, 0.03 * span),
+            "up": (0.0, 1.0, 0.0), "fov_y": 38.0, "exposure": 1.0}
 
 
 def cpu_baseline(dem, cam, kw, args, world=1):
@@ -112,10 +138,11 @@ def main():
 
     init_process_group(world, rank)
     dem, cam, kw = datasets.rainier_proxy_scene(args.dem)
-    total_frames = args.warmup + args.steps
-    kw = dict(kw, spp=args.spp, max_frames=max(total_frames, 2), min_frames=max(total_frames, 2),
-              variance_threshold=1e30)
+    kw = dict(kw, spp=args.spp, variance_threshold=1e30)
 
+    windows = 1 + max(0, args.extra_windows)
+    total_frames = args.warmup + args.steps * windows
+    kw = dict(kw, max_frames=max(total_frames, 2), min_frames=max(total_frames, 2))
     r = StripRenderer(dem, args.width, args.height, cam, rank=rank, world=world, device=local_rank,
                       kernel_variant=args.variant, memory_budget_bytes=8 << 30, **kw)
     # warmup (untimed) ---------------------------------------------------------------
@@ -131,8 +158,19 @@ def main():
     kernel_ms, launches = r.session.kernel_timing(False)
     elapsed = r.max_over_ranks(elapsed)
     kernel_ms = r.max_over_ranks(kernel_ms)
+    # further windows of the same K frames (the accumulation simply continues): the spread of the measurement
+    window_ms = [elapsed / args.steps * 1e3]
+    for wi in range(1, windows):
+        r.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        r.run_frames(args.warmup + wi * args.steps, args.steps)
+        torch.cuda.synchronize()
+        r.barrier()
+        window_ms.append(r.max_over_ranks(time.perf_counter() - t1) / args.steps * 1e3)
     # final composition (untimed, but exercised): gather strips to rank 0
     image = r.gather_image(total_frames)
+    halo_bytes = 0 if world == 1 else 3 * args.width * 16 * ((1 if rank > 0 else 0) + (1 if rank < world - 1 else 0))
 
     if rank == 0:
         samples_per_step = args.width * args.height * args.spp
@@ -140,6 +178,9 @@ def main():
         result = {
             "metric": "Msamples/s (W*H*spp/s) at 1080p, 256 spp", "value": value, "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            # the timed region above is window 0; the others repeat it on the continuing accumulation
+            "windows_ms_per_step": [round(x, 4) for x in window_ms],
+            "median_window_ms_per_step": float(np.median(window_ms)),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (rainier-proxy 2048^2 DEM, seed 20260926; real Rainier DEM is git-LFS)",
             "config": {
@@ -148,8 +189,9 @@ def main():
                             f"= {args.spp * args.steps} spp, sun az302/el24, orbit phi28/theta49 fov42",
                 "parallelism": "1 GPU" if world == 1 else f"{world} row strips, RCCL halo exchange + gather",
                 "kernel_variant": args.variant,
-                **({"strip_row_bounds": r.bounds, "strip_probe_ms": r.balance_log[-1]["ms"] if r.balance_log else None}
-                   if world > 1 else {}),
+                **({"strip_row_bounds": r.bounds, "strip_probe_ms": r.balance_log[-1]["ms"] if r.balance_log else None,
+                    "rccl_ranks": world, "halo_bytes_per_frame_rank0": halo_bytes,
+                    "dist_backend": os.environ.get("F3D_DIST_BACKEND") or "nccl"} if world > 1 else {}),
             },
         }
         counts = None
@@ -173,24 +215,55 @@ def main():
             # HBM bytes per launch from the rocprofv3 PMC passes of the SAME command (committed
             # under profiles/; bench.py cannot run the profiler itself): only quoted when the
             # run matches the profiled configuration.
-            traffic = None
+            traffic, traffic_note = None, "no PMC profile of these kernel sources under profiles/"
             try:
-                pmc = json.loads((ROOT / "profiles" / "r01_pmc_traffic.json").read_text())
-                if (world == 1 and (args.width, args.height, args.spp, args.dem) == (1920, 1080, 8, 2048)
+                pmc = json.loads((ROOT / "profiles" / "r02_pmc_traffic.json").read_text())
+                if pmc.get("kernel_source_hash") != kernel_source_hash():
+                    traffic_note = "profiles/r02_pmc_traffic.json was measured on other kernel sources: not quoted"
+                elif (world == 1 and (args.width, args.height, args.spp, args.dem) == (1920, 1080, 8, 2048)
                         and pmc.get("sample_lanes", 1) == lanes):
                     traffic = pmc["hbm_bytes_per_launch"]
+                    traffic_note = "rocprofv3 PMC passes of this command on these kernel sources (profiles/r02_pmc_traffic.json)"
             except Exception:
-                traffic = None
+                pass
             result["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_frame",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note, "kernel": "k_frame",
                 "kernel_ms": frame_kernel_ms, "launches": launches, "bytes_per_sample": b_alg, "sample_lanes": lanes,
                 "per_sample_counts": counts,
             }
         if image is not None:
             result["config"]["image_mean_rgb"] = [float(x) for x in image["rgba"][..., :3].mean((0, 1))]
-        print(json.dumps(result))
+            # what the samples were: the headline camera looks past the mountain (mostly sky)
+            hit = float(np.isfinite(image["depth"]).mean())
+            result["hit_fraction"] = hit  # centre rays that hit terrain
+            result["shaded_msamples_per_s"] = value * hit  # samples that were shaded (sun + sky ray each)
+            result["grays_per_s"] = value * 1e6 * (1.0 + 2.0 * hit) / 1e9  # primary + 2 occlusion rays per shaded sample
+        result["kernel_source_hash"] = kernel_source_hash()
     r.close()
+    if rank == 0 and world == 1 and not args.no_terrain_filling:
+        # the same DEM from inside the footprint: (nearly) every sample is shaded -- a harder number than the headline
+        cam2 = terrain_filling_camera(dem, kw)
+        frames2 = 4 + 16
+        r2 = StripRenderer(dem, args.width, args.height, cam2, rank=0, world=1, device=local_rank, kernel_variant=args.variant,
+                           memory_budget_bytes=8 << 30, **dict(kw, max_frames=frames2, min_frames=frames2))
+        r2.run_frames(0, 4)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        r2.run_frames(4, 16)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t2
+        img2 = r2.gather_image(frames2)
+        r2.close()
+        rate2 = args.width * args.height * args.spp * 16 / dt2 / 1e6
+        hit2 = float(np.isfinite(img2["depth"]).mean())
+        result["config_terrain_filling"] = {
+            "value": rate2, "unit": "Msamples/s", "ms_per_step": dt2 / 16 * 1e3, "steps": 16, "hit_fraction": hit2,
+            "shaded_msamples_per_s": rate2 * hit2, "grays_per_s": rate2 * 1e6 * (1.0 + 2.0 * hit2) / 1e9,
+            "camera": {k: [float(x) for x in v] if isinstance(v, tuple) else v for k, v in cam2.items()},
+        }
+    if rank == 0:
+        print(json.dumps(result))
 
 
 if __name__ == "__main__":

@@ -1,25 +1,41 @@
 #!/bin/bash
 # rocprofv3 passes for the frame kernel (run on the GPU box via gpurun).  $1 = variant, $2 = tag
-V=${1:-0}; TAG=${2:-r1}
+# One --kernel-trace --stats pass + four separate --pmc passes (never combined with other trace domains);
+# writes text summaries + pmc_traffic.json (with the kernel-source hash bench.py checks) under gpurun_out/prof_$TAG.
+V=${1:-0}; TAG=${2:-r02}
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --variant $V"
+BENCH="python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --extra-windows 0 --no-terrain-filling --variant $V"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $BENCH > $OUT/trace.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU -d $OUT/pmc1 -o bench -- $BENCH > $OUT/pmc1.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -d $OUT/pmc2 -o bench -- $BENCH > $OUT/pmc2.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE TCC_HIT_sum -d $OUT/pmc3 -o bench -- $BENCH > $OUT/pmc3.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum -d $OUT/pmc4 -o bench -- $BENCH > $OUT/pmc4.log 2>&1
-find $OUT -name "*.csv" | head -40
+cd $R
+python tools/rocpd_summary.py $OUT > $OUT/summary.txt 2>&1
 python - <<PY
-import csv, glob, collections
-for d in ("trace","pmc1","pmc2","pmc3","pmc4"):
-    for f in glob.glob("$OUT/%s/**/*kernel_stats.csv" % d, recursive=True):
-        print("==", f)
-        print(open(f).read()[:1500])
-    for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % d, recursive=True):
-        acc = collections.defaultdict(lambda: [0.0, 0])
-        for row in csv.DictReader(open(f)):
-            if "k_frame" in row.get("Kernel_Name", ""):
-                a = acc[row["Counter_Name"]]; a[0] += float(row["Counter_Value"]); a[1] += 1
-        print("==", d, {k: (v[0] / max(v[1], 1), v[1]) for k, v in acc.items()})
+import glob, json, sqlite3, sys
+sys.path.insert(0, "$R")
+import bench
+def avg(db, counter, like):
+    cur = sqlite3.connect(db).cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
+    name_col = "kernel_name" if "kernel_name" in cols else "name"
+    row = cur.execute(f"select avg(value), count(*) from counters_collection where counter_name=? and {name_col} like ?", (counter, like)).fetchone()
+    return row
+out = {"kernel_source_hash": bench.kernel_source_hash(), "variant": int("$V"), "workload": "rainier-proxy 2048^2, 1920x1080, 8 spp/frame, 1 GPU",
+       "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE TCC_HIT_sum / --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum, separate passes, bench.py --steps 8 --warmup 2"}
+try:
+    f = avg(glob.glob("$OUT/pmc3/*.db")[0], "FETCH_SIZE", "%k_frame%")
+    w = avg(glob.glob("$OUT/pmc4/*.db")[0], "WRITE_SIZE", "%k_frame%")
+    h = avg(glob.glob("$OUT/pmc3/*.db")[0], "TCC_HIT_sum", "%k_frame%")
+    m = avg(glob.glob("$OUT/pmc4/*.db")[0], "TCC_MISS_sum", "%k_frame%")
+    out.update(FETCH_SIZE_KB_per_dispatch=f[0], WRITE_SIZE_KB_per_dispatch=w[0], dispatches=f[1], gfx950_fetch_correction=2.0,
+               hbm_bytes_per_launch=int((2.0 * f[0] + w[0]) * 1024), l2_hit_rate=h[0] / (h[0] + m[0]), sample_lanes=4,
+               note="MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE count KB; gfx950 FETCH_SIZE under-reports wide reads, doubled (upper bound)")
+except Exception as exc:
+    out["error"] = str(exc)
+json.dump(out, open("$OUT/pmc_traffic.json", "w"), indent=1)
+print(json.dumps(out))
 PY
+head -30 $OUT/summary.txt
