@@ -51,7 +51,14 @@ F3D_HD float march_height(const RayCtx &r, float t) {
 
 template <bool CURVED>
 F3D_HD bool march_band_rejects(const RayCtx &r, float t0, float t1, float mn, float mx) {
+#if defined(F3D_NO_PACKED_F32)
     const float y0 = march_height<CURVED>(r, t0), y1 = march_height<CURVED>(r, t1);
+#else
+    const F2 tt = f2(t0, t1);
+    F2 yy = fma2(tt, f2(r.d.y, r.d.y), f2(r.o.y, r.o.y));                // march_height at both ends at once
+    if (CURVED) yy = fma2(tt * tt, f2(r.c2, r.c2), yy);
+    const float y0 = yy.x, y1 = yy.y;
+#endif
     float lo = f_min(y0, y1);
     if (CURVED) {
         if (r.has_vertex && r.vertex >= t0 && r.vertex <= t1) lo = f_min(lo, march_height<true>(r, r.vertex));
@@ -142,10 +149,19 @@ F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint
     uint32_t cx1 = (nx + 1u) << level, cz1 = (nz + 1u) << level;
     cx1 = cx1 < T.cell_w ? cx1 : T.cell_w;
     cz1 = cz1 < T.cell_h ? cz1 : T.cell_h;
+#if defined(F3D_NO_PACKED_F32)  // A/B: the scalar form
     const float tx0 = (plane_at(T.origin_x, cx0, T.spacing_x) - r.o.x) * r.inv_x;
     const float tx1 = (plane_at(T.origin_x, cx1, T.spacing_x) - r.o.x) * r.inv_x;
     const float tz0 = (plane_at(T.origin_z, cz0, T.spacing_z) - r.o.z) * r.inv_z;
     const float tz1 = (plane_at(T.origin_z, cz1, T.spacing_z) - r.o.z) * r.inv_z;
+#else
+    // (plane_at(origin, cell, spacing) - o) * inv for the x and the z plane of a corner at once (packed f32)
+    const F2 grid_o = f2(T.origin_x, T.origin_z), grid_s = f2(T.spacing_x, T.spacing_z);
+    const F2 ray_o = f2(r.o.x, r.o.z), ray_inv = f2(r.inv_x, r.inv_z);
+    const F2 t_lo = (fma2(f2((float)cx0, (float)cz0), grid_s, grid_o) - ray_o) * ray_inv;
+    const F2 t_hi = (fma2(f2((float)cx1, (float)cz1), grid_s, grid_o) - ray_o) * ray_inv;
+    const float tx0 = t_lo.x, tz0 = t_lo.y, tx1 = t_hi.x, tz1 = t_hi.y;
+#endif
     const float x_out = f_max(tx0, tx1), z_out = f_max(tz0, tz1);
     const float enter = f_max(f_min(tx0, tx1), f_min(tz0, tz1)), exit = f_min(x_out, z_out);
     if (m.unverified_start && !(enter <= m.t_cur && m.t_cur <= exit)) {
@@ -166,8 +182,13 @@ F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint
             // iff that plane's parameter is <= t_cur
             const uint32_t cl = level - 1u;
             const uint32_t xm = (2u * nx + 1u) << cl, zm = (2u * nz + 1u) << cl;
+#if defined(F3D_NO_PACKED_F32)
             const float txm = (plane_at(T.origin_x, xm, T.spacing_x) - r.o.x) * r.inv_x;
             const float tzm = (plane_at(T.origin_z, zm, T.spacing_z) - r.o.z) * r.inv_z;
+#else
+            const F2 t_mid = (fma2(f2((float)xm, (float)zm), grid_s, grid_o) - ray_o) * ray_inv;
+            const float txm = t_mid.x, tzm = t_mid.y;
+#endif
             uint32_t ix = (x_forward != (txm <= m.t_cur)) ? 0u : 1u;
             uint32_t iz = (z_forward != (tzm <= m.t_cur)) ? 0u : 1u;
             if (!(xm < T.cell_w)) ix = 0u;  // the far half lies outside the cell grid

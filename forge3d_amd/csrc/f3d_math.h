@@ -43,6 +43,23 @@ struct V3 {
     float x, y, z;
 };
 
+// Two independent f32 values in one register pair: gfx950 issues v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 at
+// the rate of their scalar forms, so the x- and z-plane arithmetic of the march pairs up (same IEEE operations,
+// same results).  GCC (the host emulator) gets a plain struct.
+#if defined(__clang__)
+typedef float F2 __attribute__((ext_vector_type(2)));
+F3D_HD F2 f2(float a, float b) { return F2{a, b}; }
+F3D_HD F2 fma2(F2 a, F2 b, F2 c) { return __builtin_elementwise_fma(a, b, c); }
+#else
+struct F2 {
+    float x, y;
+};
+F3D_HD F2 f2(float a, float b) { return F2{a, b}; }
+F3D_HD F2 operator-(F2 a, F2 b) { return F2{a.x - b.x, a.y - b.y}; }
+F3D_HD F2 operator*(F2 a, F2 b) { return F2{a.x * b.x, a.y * b.y}; }
+F3D_HD F2 fma2(F2 a, F2 b, F2 c) { return F2{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)}; }
+#endif
+
 F3D_HD float f_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 F3D_HD float f_min(float a, float b) { return __builtin_fminf(a, b); }
 F3D_HD float f_max(float a, float b) { return __builtin_fmaxf(a, b); }

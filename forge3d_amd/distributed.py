@@ -50,6 +50,16 @@ def init_process_group(world: int, rank: int, backend: str | None = None):
     dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
 
+def _rust_exp(value: float, precision: int) -> str:
+    """Rust's {:.Ne} (no exponent padding), as the reference formats the variance in its error message."""
+    if value != value:
+        return "NaN"
+    if value in (float("inf"), float("-inf")):
+        return "inf" if value > 0 else "-inf"
+    mantissa, exponent = f"{value:.{precision}e}".split("e")
+    return f"{mantissa}e{int(exponent)}"
+
+
 def strip_rows(height: int, world: int, rank: int):
     """Contiguous, balanced row strips."""
     begin = (height * rank) // world
@@ -140,7 +150,7 @@ class HipBackend:
 
 class StripRenderer:
     def __init__(self, dem, width, height, cam, *, rank=0, world=1, device=0, backend=None, row_bounds=None,
-                 balance_iters=3, **kw):
+                 balance_iters=5, **kw):
         import torch
 
         self.torch = torch
@@ -165,6 +175,10 @@ class StripRenderer:
         nbytes = (self.rows + 2 * HALO_ROWS) * self.width * RES_BYTES
         self.res = [self.backend.empty_bytes(nbytes), self.backend.empty_bytes(nbytes)]
         self.stats = self.backend.empty_i32(4)
+        # render_terrain.rs:465-471: a sun-lit scene must end with valid reservoirs
+        sun_rgb = kw.get("sun_color", (1.0, 0.97, 0.92))
+        self.require_valid_reservoirs = (float(kw.get("sun_elevation_deg", 45.0)) > 0.0 and float(kw.get("sun_intensity", 2.5)) > 0.0
+                                         and any(float(c) > 0.0 for c in sun_rgb))
         self.max_frames = int(kw.get("max_frames", 512))
         self.min_frames = int(kw.get("min_frames", 32))
         self.variance_threshold = float(kw.get("variance_threshold", 1e-3))
@@ -314,51 +328,105 @@ class StripRenderer:
             raise RuntimeError("[Render] Render error: terrain PT produced non-finite variance (NaN in accumulation)")
         return max(0.0, float(np.float32(m2) / np.float32(n_window - 1)))
 
+    def _agree(self, error: "Exception | None"):
+        """All ranks learn whether ANY rank failed before the next collective, so that nobody is left waiting in
+        it: rank-local failures (a probe, a resolve, a non-finite statistic) are re-raised everywhere."""
+        if self.world == 1:
+            if error is not None:
+                raise error
+            return
+        import torch.distributed as dist
+
+        flag = self.torch.tensor([1 if error is not None else 0], dtype=self.torch.int32, device=self._comm_device())
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if error is not None:
+            raise error
+        if int(flag.item()) != 0:
+            raise RuntimeError("[Render] Render error: another rank of the strip job failed; this rank stops with it")
+
     def render(self):
         """The reference accumulation loop (render_terrain.rs:1123-1244) over all strips."""
         frames, variance, converged = 0, float("inf"), False
         while frames < self.max_frames:
             stop = min((frames // WELFORD_WINDOW + 1) * WELFORD_WINDOW, self.max_frames)
-            self.run_frames(frames, stop - frames, collect_last=True)
+            error = None
+            try:
+                self.run_frames(frames, stop - frames, collect_last=True)
+            except Exception as exc:  # noqa: BLE001 -- re-raised on every rank by _agree
+                error = exc
+            self._agree(error)
             frames = stop
-            v = self.window_variance(frames)
+            v, error = None, None
+            try:
+                v = self.window_variance(frames)
+            except Exception as exc:  # noqa: BLE001
+                error = exc
+            self._agree(error)
             if v is not None:
                 variance = v
                 if frames >= self.min_frames and variance < self.variance_threshold:
                     converged = True
                     break
         if not converged:
+            # same text as the single-GPU path (csrc/f3d_host.hip) and the reference (render_terrain.rs:1232-1243)
             raise RuntimeError(
-                f"[Render] Render error: terrain PT did not converge: per-pixel luminance variance {variance:.3e} "
-                f"over the last {WELFORD_WINDOW}-frame window after {frames} frames")
+                f"[Render] Render error: terrain PT did not converge: per-pixel luminance variance {_rust_exp(variance, 3)} "
+                f"over the last {WELFORD_WINDOW}-frame window after {frames} frames (threshold "
+                f"{_rust_exp(self.variance_threshold, 1)}); raise max_frames or simplify the scene \u2014 refusing to return a "
+                "fake reference")
         image = self.gather_image(frames)
         if image is not None:
             image.update(frames=frames, variance=variance, converged=True)
         return image
 
     def gather_image(self, frames: int):
-        """Resolve the owned rows and gather RGBA8 + AOV strips on rank 0 (None elsewhere)."""
-        out = self.session.resolve(frames)
+        """Resolve the owned rows and gather RGBA8 + AOV strips on rank 0 (None elsewhere).  With RCCL the strips
+        are resolved straight into device tensors (f3d_session_resolve_device) and gathered device to device; the
+        sun-lit-scene check of the reference (some reservoir must be valid, render_terrain.rs:1313-1337) is made
+        over ALL strips."""
         if self.world == 1:
-            return out
+            return self.session.resolve(frames)
         import torch.distributed as dist
 
         torch = self.torch
         dev = self._comm_device()
+        on_device = dev == self.res[0].device and dev.type != "cpu" and hasattr(self.session, "resolve_device")
         max_rows = max(b1 - b0 for b0, b1 in zip(self.bounds, self.bounds[1:]))
+        specs = (("rgba", 4, torch.uint8), ("albedo", 3, torch.float32), ("normal", 3, torch.float32),
+                 ("depth", 1, torch.float32))
+        mine, error, valid = {}, None, 0
+        try:
+            if on_device:
+                for key, chans, dtype in specs:
+                    mine[key] = torch.zeros((max_rows, self.width, chans), dtype=dtype, device=dev)
+                self.session.resolve_device(frames, *(mine[k].data_ptr() for k in ("rgba", "albedo", "normal", "depth")))
+                self.backend.sync()
+                valid = int(self.stats.cpu()[2].item() != 0)
+                if int(self.stats.cpu()[3].item()) != 0:
+                    raise RuntimeError("[Render] Render error: terrain PT reservoir bookkeeping produced non-finite values")
+            else:
+                out = self.session.resolve(frames)
+                valid = int(bool(out.get("any_valid_reservoir", True)))
+                for key, chans, dtype in specs:
+                    t = torch.zeros((max_rows, self.width, chans), dtype=dtype, device=dev)
+                    t[: self.rows] = torch.from_numpy(np.ascontiguousarray(out[key]).reshape(self.rows, self.width, chans)).to(dev)
+                    mine[key] = t
+        except Exception as exc:  # noqa: BLE001 -- re-raised on every rank by _agree
+            error = exc
+        self._agree(error)
+        flag = torch.tensor([valid], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if getattr(self, "require_valid_reservoirs", False) and int(flag.item()) == 0:
+            raise RuntimeError(
+                "[Render] Render error: terrain PT ReSTIR reuse chain produced no valid reservoirs for a sun-lit scene "
+                "\u2014 temporal/spatial reuse is broken")
         result = {}
-        for key, chans, dtype in (("rgba", 4, torch.uint8), ("albedo", 3, torch.float32),
-                                  ("normal", 3, torch.float32), ("depth", 1, torch.float32)):
-            mine = torch.zeros((max_rows, self.width, chans), dtype=dtype, device=dev)
-            src = torch.from_numpy(np.ascontiguousarray(out[key]).reshape(self.rows, self.width, chans))
-            mine[: self.rows] = src.to(dev)
-            parts = [torch.empty_like(mine) for _ in range(self.world)] if self.rank == 0 else None
-            dist.gather(mine, parts, dst=0)
+        for key, chans, dtype in specs:
+            parts = [torch.empty_like(mine[key]) for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(mine[key], parts, dst=0)
             if self.rank == 0:
-                rows = []
-                for r in range(self.world):
-                    rows.append(parts[r][: self.bounds[r + 1] - self.bounds[r]].cpu().numpy())
-                full = np.concatenate(rows, axis=0)
+                full = np.concatenate([parts[r][: self.bounds[r + 1] - self.bounds[r]].cpu().numpy()
+                                       for r in range(self.world)], axis=0)
                 result[key] = full[..., 0] if key == "depth" else full
         return result if self.rank == 0 else None
 

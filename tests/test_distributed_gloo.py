@@ -59,7 +59,35 @@ def _worker(rank, world, port, out_path, mode):
     if mode == "bounds":
         extra["row_bounds"] = [0, 7, 50] if world == 2 else [0, 3, 41, 50]
         kw = scenes.fixed_frames(kw, 6, spp=2)
+    if mode == "noconv":  # the variance gate cannot be met: every rank must raise the reference's message
+        kw = {**scenes.scene_kwargs(dem), "variance_threshold": 1e-12, "max_frames": 8, "min_frames": 2, "spp": 1}
+    if mode == "rankfail":  # one rank's session breaks in the middle of the render: nobody may be left in a collective
+        kw = scenes.fixed_frames(kw, 40, spp=1)
     r = StripRenderer(dem, 72, 50, scenes.CAM, rank=rank, world=world, backend=backend, **extra, **kw)
+    if mode in ("noconv", "rankfail"):
+        if mode == "rankfail" and rank == world - 1:
+            real = r.session.enqueue_frame_part
+
+            def broken(frame, part, collect=False):
+                if frame >= 33:
+                    raise RuntimeError("[Device] Device error: injected failure on the last rank")
+                return real(frame, part, collect)
+
+            r.session.enqueue_frame_part = broken
+        message = ""
+        try:
+            r.render()
+        except RuntimeError as exc:
+            message = str(exc)
+        r.close()
+        with open(f"{out_path}.{rank}", "w") as f:
+            f.write(message)
+        if rank == 0:
+            with open(out_path, "wb") as f:
+                pickle.dump({"messages": world}, f)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if mode == "balanced":
         sizes = [b1 - b0 for b0, b1 in zip(r.bounds, r.bounds[1:])]
         costs = [sum(1.0 if y < 25 else 5.0 for y in range(b0, b1)) for b0, b1 in zip(r.bounds, r.bounds[1:])]
@@ -157,6 +185,32 @@ def test_distributed_convergence_gate_matches_single_process():
     assert np.float32(multi["variance"]) == np.float32(want["variance"])
     for key in ("rgba", "albedo", "normal", "depth"):
         assert np.array_equal(multi[key], want[key], equal_nan=True), key
+
+
+def _messages(world, mode):
+    import glob
+
+    _run(world, mode)
+    out = []
+    for path in sorted(glob.glob(os.path.join(tempfile.gettempdir(), "*.pkl.[0-9]"))):
+        out.append(open(path).read())
+        os.unlink(path)
+    return out
+
+
+def test_every_rank_raises_the_reference_non_convergence_message():
+    msgs = _messages(2, "noconv")
+    assert len(msgs) == 2
+    for m in msgs:
+        assert "did not converge: per-pixel luminance variance" in m and "over the last 32-frame window after 8 frames" in m
+        assert "(threshold 1.0e-12); raise max_frames or simplify the scene" in m and "refusing to return a fake reference" in m
+
+
+def test_a_failing_rank_stops_every_rank_instead_of_hanging_them():
+    msgs = _messages(2, "rankfail")
+    assert len(msgs) == 2
+    assert any("injected failure on the last rank" in m for m in msgs)
+    assert any("another rank of the strip job failed" in m for m in msgs)
 
 
 def test_strip_rows_partition_the_image():
