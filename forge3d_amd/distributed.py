@@ -301,12 +301,23 @@ class StripRenderer:
         if self.world == 1:
             self.session.enqueue_frames(first, count, collect_last)
             return
+        # A rank whose session fails keeps posting its halo transfers for the rest of the batch (with whatever its
+        # buffers hold): its neighbours are inside matching send / recv pairs and would wait forever otherwise.
+        # The failure is raised at the end of the batch; render() then makes every rank stop (_agree).
+        error = None
         for f in range(first, first + count):
             collect = collect_last and f + 1 == first + count
-            self.session.enqueue_frame_part(f, 1, collect)
-            pending = self.start_halo_exchange(f & 1)
-            self.session.enqueue_frame_part(f, 2, collect)
+            for part in (1, 2):
+                if error is None:
+                    try:
+                        self.session.enqueue_frame_part(f, part, collect)
+                    except Exception as exc:  # noqa: BLE001
+                        error = exc
+                if part == 1:
+                    pending = self.start_halo_exchange(f & 1)
             self.finish_halo_exchange(pending)
+        if error is not None:
+            raise error
 
     def window_variance(self, frames: int):
         """Variance gate of render_terrain.rs:1206-1231 across all strips."""
