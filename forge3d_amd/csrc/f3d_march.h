@@ -51,7 +51,7 @@ F3D_HD float march_height(const RayCtx &r, float t) {
 
 template <bool CURVED>
 F3D_HD bool march_band_rejects(const RayCtx &r, float t0, float t1, float mn, float mx) {
-#if defined(F3D_NO_PACKED_F32)
+#if !defined(F3D_PACKED_F32)
     const float y0 = march_height<CURVED>(r, t0), y1 = march_height<CURVED>(r, t1);
 #else
     const F2 tt = f2(t0, t1);
@@ -149,7 +149,7 @@ F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint
     uint32_t cx1 = (nx + 1u) << level, cz1 = (nz + 1u) << level;
     cx1 = cx1 < T.cell_w ? cx1 : T.cell_w;
     cz1 = cz1 < T.cell_h ? cz1 : T.cell_h;
-#if defined(F3D_NO_PACKED_F32)  // A/B: the scalar form
+#if !defined(F3D_PACKED_F32)  // the shipped scalar form; packed f32 pairs measured 0.92x (5335 vs 5780 Msamples/s)
     const float tx0 = (plane_at(T.origin_x, cx0, T.spacing_x) - r.o.x) * r.inv_x;
     const float tx1 = (plane_at(T.origin_x, cx1, T.spacing_x) - r.o.x) * r.inv_x;
     const float tz0 = (plane_at(T.origin_z, cz0, T.spacing_z) - r.o.z) * r.inv_z;
@@ -182,7 +182,7 @@ F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint
             // iff that plane's parameter is <= t_cur
             const uint32_t cl = level - 1u;
             const uint32_t xm = (2u * nx + 1u) << cl, zm = (2u * nz + 1u) << cl;
-#if defined(F3D_NO_PACKED_F32)
+#if !defined(F3D_PACKED_F32)
             const float txm = (plane_at(T.origin_x, xm, T.spacing_x) - r.o.x) * r.inv_x;
             const float tzm = (plane_at(T.origin_z, zm, T.spacing_z) - r.o.z) * r.inv_z;
 #else

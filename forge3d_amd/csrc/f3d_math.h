@@ -43,9 +43,10 @@ struct V3 {
     float x, y, z;
 };
 
-// Two independent f32 values in one register pair: gfx950 issues v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 at
-// the rate of their scalar forms, so the x- and z-plane arithmetic of the march pairs up (same IEEE operations,
-// same results).  GCC (the host emulator) gets a plain struct.
+// Two independent f32 values in one register pair (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).  A/B only
+// (-DF3D_PACKED_F32): pairing the x- and z-plane arithmetic of the march gives the same results but measured
+// 0.92x on MI355X -- the pairs need aligned registers and extra moves at the 80-VGPR budget (profiles/README.md).
+// GCC (the host emulator) gets a plain struct.
 #if defined(__clang__)
 typedef float F2 __attribute__((ext_vector_type(2)));
 F3D_HD F2 f2(float a, float b) { return F2{a, b}; }
