@@ -12,6 +12,8 @@
 #include <hip/hip_runtime.h>
 
 #include <exception>
+#include <memory>
+#include <mutex>
 #include <new>
 
 #include "f3d_launch.h"
@@ -141,6 +143,98 @@ TerrainTables build_tables(Ledger &mem, const float *d_heights, uint32_t w, uint
 }  // namespace
 
 // ---------------------------------------------------------------------------------------
+// scene cache: acceleration tables of recently rendered DEMs stay on the device
+// ---------------------------------------------------------------------------------------
+// A caller rendering a camera path calls the one-shot entry point once per frame with the same DEM; rebuilding
+// 123 MB of tables (and uploading 17 MB) every time is wasted work.  Tables are immutable once built, so sessions
+// SHARE them: the cache maps (device, DEM bytes, dims, exaggeration) to a reference-counted table set and keeps
+// the most recent kSceneCacheEntries of them after their last session has gone.  A per-process cache behind a
+// mutex -- the only global state of the library besides the HIP context.
+namespace {
+
+struct CachedTables {
+    int device = 0;
+    uint64_t key = 0, dem_bytes = 0;
+    uint32_t w = 0, h = 0;
+    float exaggeration = 0.0f;
+    Ledger mem;  // owns leaf + band tables
+    TerrainTables tables;
+    uint64_t stamp = 0;
+    ~CachedTables() {
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        (void)hipSetDevice(device);
+        mem.release();
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+std::mutex g_scene_mutex;
+std::vector<std::shared_ptr<CachedTables>> g_scene_cache;
+uint64_t g_scene_stamp = 0;
+size_t g_scene_limit = 2;  // f3d_scene_cache_limit
+
+uint64_t hash_bytes(const void *data, size_t n, uint64_t seed) {  // 8 bytes at a time, multiply-xorshift
+    const uint8_t *p = (const uint8_t *)data;
+    uint64_t h = seed ^ (n * 0x9E3779B97F4A7C15ull);
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t v;
+        memcpy(&v, p + i, 8);
+        h = (h ^ v) * 0xFF51AFD7ED558CCDull;
+        h ^= h >> 32;
+    }
+    for (; i < n; i++) h = (h ^ p[i]) * 0x100000001B3ull;
+    return h ^ (h >> 29);
+}
+
+// Tables for this DEM on this device: from the cache, or built now (and cached when the limit allows).
+std::shared_ptr<CachedTables> acquire_tables(int device, const float *heights, uint32_t w, uint32_t h, float exaggeration,
+                                             hipStream_t stream, bool *was_cached) {
+    const uint64_t bytes = (uint64_t)w * h * sizeof(float);
+    uint64_t key = hash_bytes(heights, bytes, 0x6a09e667f3bcc908ull);
+    key = hash_bytes(&exaggeration, sizeof(float), key ^ ((uint64_t)w << 32 | h));
+    {
+        std::lock_guard<std::mutex> lock(g_scene_mutex);
+        for (auto &e : g_scene_cache)
+            if (e->device == device && e->key == key && e->w == w && e->h == h && e->exaggeration == exaggeration &&
+                e->dem_bytes == bytes) {
+                e->stamp = ++g_scene_stamp;
+                *was_cached = true;
+                return e;
+            }
+    }
+    *was_cached = false;
+    auto e = std::make_shared<CachedTables>();
+    e->device = device;
+    e->key = key;
+    e->dem_bytes = bytes;
+    e->w = w;
+    e->h = h;
+    e->exaggeration = exaggeration;
+    float *d_heights = (float *)e->mem.alloc(bytes, "DEM upload");
+    hip_check(hipMemcpy(d_heights, heights, bytes, hipMemcpyHostToDevice), "DEM upload");
+    e->tables = build_tables(e->mem, d_heights, w, h, exaggeration, stream, false);
+    // the corner records hold every height (x exaggeration): the raw upload is build-time scratch
+    hip_check(hipStreamSynchronize(stream), "table build");
+    e->mem.free(d_heights, bytes);
+    std::lock_guard<std::mutex> lock(g_scene_mutex);
+    e->stamp = ++g_scene_stamp;
+    if (g_scene_limit > 0) {
+        g_scene_cache.push_back(e);
+        while (g_scene_cache.size() > g_scene_limit) {  // drop the least recently used (sessions holding it keep it alive)
+            size_t oldest = 0;
+            for (size_t i = 1; i < g_scene_cache.size(); i++)
+                if (g_scene_cache[i]->stamp < g_scene_cache[oldest]->stamp) oldest = i;
+            g_scene_cache.erase(g_scene_cache.begin() + (long)oldest);
+        }
+    }
+    return e;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
 // session
 // ---------------------------------------------------------------------------------------
 struct f3d_session {
@@ -148,6 +242,7 @@ struct f3d_session {
     hipStream_t stream = nullptr;
     int device = 0;
     FrameParams params{};
+    std::shared_ptr<CachedTables> scene;  // shared, immutable acceleration tables (scene cache)
     TerrainTables tables;
     uint32_t width = 0, height = 0, row_begin = 0, row_end = 0, rows = 0;
     PackedReservoir *res[2] = {nullptr, nullptr};
@@ -297,14 +392,11 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
     FrameParams &P = s.params;
     s.require_valid_reservoirs = fill_uniforms(d, P);  // curvature, camera, lighting
 
-    // DEM upload + GPU table build (reference: CPU build + per-level write_texture)
-    const size_t dem_n = (size_t)d.dem_width * d.dem_height;
-    float *d_heights = (float *)s.mem.alloc(dem_n * sizeof(float), "DEM upload");
-    hip_check(hipMemcpy(d_heights, d.heights, dem_n * sizeof(float), hipMemcpyHostToDevice), "DEM upload");
-    s.tables = build_tables(s.mem, d_heights, d.dem_width, d.dem_height, d.exaggeration, s.stream, false);
-    // the corner records hold every height (x exaggeration): the raw upload is build-time scratch
-    hip_check(hipStreamSynchronize(s.stream), "table build");
-    s.mem.free(d_heights, dem_n * sizeof(float));
+    // DEM upload + GPU table build (reference: CPU build + per-level write_texture), or the cached tables of this DEM
+    bool was_cached = false;
+    s.scene = acquire_tables(s.device, d.heights, d.dem_width, d.dem_height, d.exaggeration, s.stream, &was_cached);
+    s.tables = s.scene->tables;
+    s.mem.device_bytes += s.scene->mem.device_bytes;  // shared, but part of this render's working set
     apply_layout(s.tables.layout, P.terrain);
     P.terrain.leaves = s.tables.leaves;
     P.terrain.nodes = s.tables.nodes;
@@ -996,6 +1088,22 @@ int f3d_effective_radius_m(int32_t earth_model, double latitude_deg, double sphe
         return report(f, err, errlen);
     }
     return F3D_STATUS_OK;
+}
+
+void f3d_scene_cache_limit(uint32_t entries) {
+    std::lock_guard<std::mutex> lock(g_scene_mutex);
+    g_scene_limit = entries;
+    while (g_scene_cache.size() > g_scene_limit) {
+        size_t oldest = 0;
+        for (size_t i = 1; i < g_scene_cache.size(); i++)
+            if (g_scene_cache[i]->stamp < g_scene_cache[oldest]->stamp) oldest = i;
+        g_scene_cache.erase(g_scene_cache.begin() + (long)oldest);
+    }
+}
+
+uint32_t f3d_scene_cache_entries(void) {
+    std::lock_guard<std::mutex> lock(g_scene_mutex);
+    return (uint32_t)g_scene_cache.size();
 }
 
 int f3d_device_count(void) {

@@ -70,83 +70,15 @@ struct LdsPending {
     __device__ __forceinline__ void verdict_post(bool hit) const { board()[lane()] = hit ? 1u : 0u; }
     __device__ __forceinline__ void verdict_set(uint32_t owner) const { board()[owner & (kWave - 1u)] = 1u; }
     __device__ __forceinline__ bool verdict_get(uint32_t owner) const { return board()[owner & (kWave - 1u)] != 0u; }
-    // Deal the marching slices over the lanes of this call: lane i of the call works on ray (i / per),
-    // slice (i % per) of its remaining range; `per` = the largest power of two that fits.
+    // wave primitives of march_deal (f3d_march.h)
+    __device__ __forceinline__ unsigned long long ballot(bool pred) const { return __ballot(pred); }
+    __device__ __forceinline__ float shfl(float v, int src) const { return __shfl(v, src, kWave); }
+    __device__ __forceinline__ uint32_t shfl(uint32_t v, int src) const { return (uint32_t)__shfl((int)v, src, kWave); }
+    __device__ __forceinline__ float fast_log2(float x) const { return __builtin_amdgcn_logf(x); }
+    __device__ __forceinline__ float fast_exp2(float x) const { return __builtin_amdgcn_exp2f(x); }
     template <bool CURVED>
     __device__ __forceinline__ void deal(const TerrainDev &T, MarchSlice &s, MarchState &m) const {
-        const unsigned long long active = __ballot(true), mask = __ballot(m.marching);
-        const unsigned long long below = (1ull << lane()) - 1ull;
-        const uint32_t n = (uint32_t)__popcll(mask);
-        if (n == 0u) {
-            m.marching = false;
-            return;
-        }
-        const uint32_t avail = (uint32_t)__popcll(active);
-        const uint32_t rank = (uint32_t)__popcll(active & below);
-        // (dealing avail / n slices per ray instead of the power of two below measured slower: 5843 vs 6058)
-        const uint32_t sh = 31u - (uint32_t)__clz((int)(avail / n)), per = 1u << sh;
-        const uint32_t q = rank >> sh, k = rank & (per - 1u);
-        const bool take = q < n;
-        int src = (int)lane();  // lanes without a slice read their OWN registers below (always an active lane)
-        {
-            unsigned long long rest = mask;
-            for (uint32_t i = 0u; i < n; i++) {  // wave-uniform, n <= kShareBelow
-                const int b = __ffsll((long long)rest) - 1;
-                rest &= rest - 1ull;
-                if (q == i) src = b;
-            }
-        }
-        RayCtx r;
-        r.o = V3{__shfl(s.r.o.x, src, kWave), __shfl(s.r.o.y, src, kWave), __shfl(s.r.o.z, src, kWave)};
-        r.d = V3{__shfl(s.r.d.x, src, kWave), __shfl(s.r.d.y, src, kWave), __shfl(s.r.d.z, src, kWave)};
-        r.tmin = __shfl(s.r.tmin, src, kWave);
-        r.tmax = __shfl(s.r.tmax, src, kWave);
-        r.inv_x = __shfl(s.r.inv_x, src, kWave);
-        r.inv_z = __shfl(s.r.inv_z, src, kWave);
-        if (CURVED) {
-            r.c2 = __shfl(s.r.c2, src, kWave);
-            r.vertex = __shfl(s.r.vertex, src, kWave);
-            r.has_vertex = __shfl((int)s.r.has_vertex, src, kWave) != 0;
-        } else {
-            r.c2 = 0.0f;
-            r.vertex = 0.0f;
-            r.has_vertex = false;
-        }
-        const float t0 = __shfl(m.t_cur, src, kWave), t_end = __shfl(s.t_end, src, kWave);
-        const float t1 = f_min(__shfl(s.t_stop, src, kWave), t_end);  // the slice being cut again ends here
-        const uint32_t owner = (uint32_t)__shfl((int)s.owner, src, kWave);
-        const uint32_t level = (uint32_t)__shfl((int)m.level, src, kWave);
-        const uint32_t nx = (uint32_t)__shfl((int)m.nx, src, kWave), nz = (uint32_t)__shfl((int)m.nz, src, kWave);
-        const float stop_src = __shfl(s.t_stop, src, kWave);
-        // `per` slices of [t0, t1] with GEOMETRIC boundaries t0 (t1/t0)^(k/per): the march's steps grow with
-        // the ray's clearance, i.e. roughly with the distance from its origin, so equal-t slices would leave
-        // almost all the work in the first one.  Any boundaries are valid; slice k begins exactly where slice
-        // k - 1 stops (same expression, same inputs); the last slice inherits the stop of the slice it cuts.
-        const float base = f_max(t0, 1e-3f * f_max(t1, 1e-30f));  // t0 can be ~0 for a ray that has barely started
-        const float lg = __builtin_amdgcn_logf(f_max(t1, base) / base) / (float)per;
-        const float begin = k == 0u ? t0 : base * __builtin_amdgcn_exp2f(lg * (float)k);
-        const float stop = k + 1u == per ? stop_src : base * __builtin_amdgcn_exp2f(lg * (float)(k + 1u));
-        s.r = r;
-        s.t_end = t_end;
-        s.t_stop = stop;
-        s.owner = take ? owner : lane();  // lanes without a slice own nothing but themselves
-        m.t_cur = begin;
-        if (k == 0u) {  // the first slice continues exactly where the source lane was
-            m.level = level;
-            m.nx = nx;
-            m.nz = nz;
-            m.unverified_start = false;
-        } else {
-            // nodes the march works on grow with the distance walked: about one level per doubling of t
-#ifndef F3D_SHARE_LEVEL_GAIN
-#define F3D_SHARE_LEVEL_GAIN 1.0f
-#endif
-            const uint32_t top = T.mip_count - 1u, lvl = level + (uint32_t)(F3D_SHARE_LEVEL_GAIN * lg * (float)k);
-            m.level = lvl < top ? lvl : top;
-            march_locate(T, r, begin, m.level, m.nx, m.nz);
-            m.unverified_start = true;
-        }
-        m.marching = take && begin <= t1;
+        march_deal<CURVED>(T, s, m, *this);
     }
     __device__ __forceinline__ void band_entry(const TerrainDev &, uint32_t level, uint32_t &offset,
                                                uint32_t &shift) const {

@@ -356,6 +356,86 @@ struct MarchSlice {
     uint32_t owner;       // lane that wants the verdict
 };
 
+// Deal the marching slices of a wave over the lanes of the call: lane i of the call works on ray (i / per), slice
+// (i % per) of its remaining range; `per` = the largest power of two that fits.  Written against the wave
+// primitives of Ctx (ballot / shfl / lane / fast_log2 / fast_exp2) so that the device (f3d_kernels.hip LdsPending)
+// and the 64-lane host emulator (tests/emul) run the SAME dealing code.
+#ifndef F3D_SHARE_LEVEL_GAIN
+#define F3D_SHARE_LEVEL_GAIN 1.0f
+#endif
+F3D_HD uint32_t bits_set(unsigned long long v) { return (uint32_t)__builtin_popcountll(v); }
+template <bool CURVED, class Ctx>
+F3D_HD void march_deal(const TerrainDev &T, MarchSlice &s, MarchState &m, const Ctx &ctx) {
+    const unsigned long long active = ctx.ballot(true), mask = ctx.ballot(m.marching);
+    const unsigned long long below = (1ull << ctx.lane()) - 1ull;
+    const uint32_t n = bits_set(mask);
+    if (n == 0u) {
+        m.marching = false;
+        return;
+    }
+    const uint32_t avail = bits_set(active), rank = bits_set(active & below);
+    // (dealing avail / n slices per ray instead of the power of two below measured slower: 5843 vs 6058)
+    const uint32_t sh = 31u - (uint32_t)__builtin_clz(avail / n), per = 1u << sh;
+    const uint32_t q = rank >> sh, k = rank & (per - 1u);
+    const bool take = q < n;
+    int src = (int)ctx.lane();  // lanes without a slice read their OWN registers below (always an active lane)
+    {
+        unsigned long long rest = mask;
+        for (uint32_t i = 0u; i < n; i++) {  // wave-uniform, n <= the sharing threshold
+            const int b = __builtin_ffsll((long long)rest) - 1;
+            rest &= rest - 1ull;
+            if (q == i) src = b;
+        }
+    }
+    RayCtx r;
+    r.o = V3{ctx.shfl(s.r.o.x, src), ctx.shfl(s.r.o.y, src), ctx.shfl(s.r.o.z, src)};
+    r.d = V3{ctx.shfl(s.r.d.x, src), ctx.shfl(s.r.d.y, src), ctx.shfl(s.r.d.z, src)};
+    r.tmin = ctx.shfl(s.r.tmin, src);
+    r.tmax = ctx.shfl(s.r.tmax, src);
+    r.inv_x = ctx.shfl(s.r.inv_x, src);
+    r.inv_z = ctx.shfl(s.r.inv_z, src);
+    if (CURVED) {
+        r.c2 = ctx.shfl(s.r.c2, src);
+        r.vertex = ctx.shfl(s.r.vertex, src);
+        r.has_vertex = ctx.shfl((uint32_t)s.r.has_vertex, src) != 0u;
+    } else {
+        r.c2 = 0.0f;
+        r.vertex = 0.0f;
+        r.has_vertex = false;
+    }
+    const float t0 = ctx.shfl(m.t_cur, src), t_end = ctx.shfl(s.t_end, src);
+    const float stop_src = ctx.shfl(s.t_stop, src);
+    const float t1 = f_min(stop_src, t_end);  // the slice being cut again ends here
+    const uint32_t owner = ctx.shfl(s.owner, src);
+    const uint32_t level = ctx.shfl(m.level, src), nx = ctx.shfl(m.nx, src), nz = ctx.shfl(m.nz, src);
+    // `per` slices of [t0, t1] with GEOMETRIC boundaries t0 (t1/t0)^(k/per): the march's steps grow with
+    // the ray's clearance, i.e. roughly with the distance from its origin, so equal-t slices would leave
+    // almost all the work in the first one.  Any boundaries are valid; slice k begins exactly where slice
+    // k - 1 stops (same expression, same inputs); the last slice inherits the stop of the slice it cuts.
+    const float base = f_max(t0, 1e-3f * f_max(t1, 1e-30f));  // t0 can be ~0 for a ray that has barely started
+    const float lg = ctx.fast_log2(f_max(t1, base) / base) / (float)per;
+    const float begin = k == 0u ? t0 : base * ctx.fast_exp2(lg * (float)k);
+    const float stop = k + 1u == per ? stop_src : base * ctx.fast_exp2(lg * (float)(k + 1u));
+    s.r = r;
+    s.t_end = t_end;
+    s.t_stop = stop;
+    s.owner = take ? owner : ctx.lane();  // lanes without a slice own nothing but themselves
+    m.t_cur = begin;
+    if (k == 0u) {  // the first slice continues exactly where the source lane was
+        m.level = level;
+        m.nx = nx;
+        m.nz = nz;
+        m.unverified_start = false;
+    } else {
+        // nodes the march works on grow with the distance walked: about one level per doubling of t
+        const uint32_t top = T.mip_count - 1u, lvl = level + (uint32_t)(F3D_SHARE_LEVEL_GAIN * lg * (float)k);
+        m.level = lvl < top ? lvl : top;
+        march_locate(T, r, begin, m.level, m.nx, m.nz);
+        m.unverified_start = true;
+    }
+    m.marching = take && begin <= t1;
+}
+
 // Phase 2 of an any-hit march (see above).  `m` holds the lane's position on its own ray, own_hit its
 // verdict so far; returns the final verdict of the lane's OWN ray.
 template <bool CURVED, class Ctx>

@@ -91,12 +91,170 @@ def png_to_numpy(path) -> np.ndarray:
     return out.reshape(h, w) if bpp == 1 else out.reshape(h, w, bpp)
 
 
-def load_heightmap(path) -> np.ndarray:
-    """A 2-D float32 heightmap from a ``.npy`` file (GeoTIFF readers are outside this repository)."""
+# ---- float / integer GeoTIFF DEMs (TIFF 6.0 baseline + the GeoTIFF scale tag) ------------------------------------
+_TIFF_TYPES = {1: ("B", 1), 2: ("c", 1), 3: ("H", 2), 4: ("I", 4), 5: ("II", 8), 6: ("b", 1), 8: ("h", 2), 9: ("i", 4),
+               11: ("f", 4), 12: ("d", 8), 16: ("Q", 8), 17: ("q", 8)}
+
+
+def _lzw_decode(data: bytes) -> bytes:
+    """TIFF LZW (MSB-first codes, 9..12 bits, ClearCode 256, EOI 257, early change)."""
+    out = bytearray()
+    table = [bytes([i]) for i in range(256)] + [b"", b""]
+    bits, nbits, width, prev, pos = 0, 0, 9, None, 0
+    n = len(data)
+    while True:
+        while nbits < width and pos < n:
+            bits = (bits << 8) | data[pos]
+            pos += 1
+            nbits += 8
+        if nbits < width:
+            break
+        code = (bits >> (nbits - width)) & ((1 << width) - 1)
+        nbits -= width
+        if code == 257:
+            break
+        if code == 256:
+            table = table[:258]
+            width, prev = 9, None
+            continue
+        if prev is None:
+            entry = table[code]
+        elif code < len(table):
+            entry = table[code]
+            table.append(prev + entry[:1])
+        else:
+            entry = prev + prev[:1]
+            table.append(entry)
+        out += entry
+        prev = entry
+        if len(table) + 1 >= (1 << width) and width < 12:  # early change: widen one code early
+            width += 1
+    return bytes(out)
+
+
+def _packbits_decode(data: bytes) -> bytes:
+    out, i = bytearray(), 0
+    while i < len(data):
+        n = data[i]
+        i += 1
+        if n < 128:
+            out += data[i:i + n + 1]
+            i += n + 1
+        elif n > 128:
+            out += data[i:i + 1] * (257 - n)
+            i += 1
+    return bytes(out)
+
+
+def read_geotiff(path):
+    """(heights float32 (H, W), info) from a single-band TIFF / GeoTIFF DEM: little or big endian, classic TIFF,
+    strips or tiles, uncompressed / LZW / Deflate / PackBits, predictors 1, 2 (integers) and 3 (floating point),
+    8/16/32-bit integer or 32/64-bit float samples.  info: {"pixel_scale": (sx, sy) or None, "tiepoint": ...,
+    "nodata": float or None}.  (The reference reads DEMs through rasterio, python/forge3d/io.py.)"""
+    raw = Path(path).read_bytes()
+    if raw[:2] == b"II":
+        e = "<"
+    elif raw[:2] == b"MM":
+        e = ">"
+    else:
+        raise ValueError("not a TIFF file")
+    if struct.unpack(e + "H", raw[2:4])[0] != 42:
+        raise ValueError("only classic TIFF (version 42) is supported, not BigTIFF")
+    (ifd,) = struct.unpack(e + "I", raw[4:8])
+    (count,) = struct.unpack(e + "H", raw[ifd:ifd + 2])
+    tags = {}
+    for k in range(count):
+        tag, typ, n, _ = struct.unpack(e + "HHI4s", raw[ifd + 2 + 12 * k:ifd + 14 + 12 * k])
+        fmt, size = _TIFF_TYPES.get(typ, ("B", 1))
+        field = raw[ifd + 10 + 12 * k:ifd + 14 + 12 * k]
+        if size * n > 4:
+            (off,) = struct.unpack(e + "I", field)
+            field = raw[off:off + size * n]
+        if typ == 2:
+            tags[tag] = field[:n].split(b"\0")[0].decode("latin-1")
+        elif typ == 5:
+            v = struct.unpack(e + "II" * n, field[:8 * n])
+            tags[tag] = tuple(v[2 * i] / max(v[2 * i + 1], 1) for i in range(n))
+        else:
+            tags[tag] = struct.unpack(e + fmt * n, field[:size * n])
+    one = lambda t, d=None: tags[t][0] if t in tags else d  # noqa: E731
+    w, h = one(256), one(257)
+    bits, fmt_code, spp = one(258, 1), one(339, 1), one(277, 1)
+    compression, predictor = one(259, 1), one(317, 1)
+    if spp != 1:
+        raise ValueError(f"DEM TIFFs have one band, this file has {spp}")
+    dtype = {(8, 1): "u1", (16, 1): "u2", (32, 1): "u4", (8, 2): "i1", (16, 2): "i2", (32, 2): "i4", (32, 3): "f4",
+             (64, 3): "f8"}.get((bits, fmt_code))
+    if dtype is None:
+        raise ValueError(f"unsupported TIFF sample layout: {bits} bits, SampleFormat {fmt_code}")
+    bps = bits // 8
+
+    def decode(chunk: bytes, rows: int, cols: int) -> np.ndarray:
+        if compression in (8, 32946):
+            chunk = zlib.decompress(chunk)
+        elif compression == 5:
+            chunk = _lzw_decode(chunk)
+        elif compression == 32773:
+            chunk = _packbits_decode(chunk)
+        elif compression != 1:
+            raise ValueError(f"unsupported TIFF compression {compression}")
+        chunk = chunk[:rows * cols * bps]
+        if predictor == 3:  # floating-point predictor: bytes differenced, then planes of significance per row
+            b = np.frombuffer(chunk, np.uint8).reshape(rows, cols * bps).astype(np.uint8)
+            b = np.cumsum(b, axis=1, dtype=np.uint8)
+            b = b.reshape(rows, bps, cols)  # most significant byte plane first
+            b = b.transpose(0, 2, 1)
+            if e == "<":
+                b = b[:, :, ::-1]
+            return np.ascontiguousarray(b).view(e + dtype).reshape(rows, cols)
+        a = np.frombuffer(chunk, e + dtype).reshape(rows, cols)
+        if predictor == 2:
+            a = np.cumsum(a, axis=1, dtype=a.dtype.newbyteorder("="))
+        return a
+
+    out = np.zeros((h, w), np.float64 if dtype == "f8" else np.float32)
+    if 322 in tags:  # tiles
+        tw, th = one(322), one(323)
+        offsets, counts = tags[324], tags[325]
+        across = (w + tw - 1) // tw
+        for i, (off, n) in enumerate(zip(offsets, counts)):
+            ty, tx = divmod(i, across)
+            tile = decode(raw[off:off + n], th, tw)
+            y0, x0 = ty * th, tx * tw
+            out[y0:y0 + th, x0:x0 + tw] = tile[: h - y0, : w - x0]
+    else:
+        rps = min(one(278, h), h)
+        for i, (off, n) in enumerate(zip(tags[273], tags[279])):
+            y0 = i * rps
+            rows = min(rps, h - y0)
+            out[y0:y0 + rows] = decode(raw[off:off + n], rows, w)
+    nodata = None
+    if 42113 in tags:
+        try:
+            nodata = float(tags[42113])
+        except ValueError:
+            nodata = None
+    info = {"pixel_scale": tuple(tags[33550][:2]) if 33550 in tags else None,
+            "tiepoint": tuple(tags[33922][:6]) if 33922 in tags else None, "nodata": nodata}
+    return np.ascontiguousarray(out, np.float32), info
+
+
+def load_heightmap(path, fill_nodata: bool = True) -> np.ndarray:
+    """A 2-D float32 heightmap from a ``.npy`` file or a single-band (Geo)TIFF; GDAL nodata cells are replaced by
+    the smallest valid height when fill_nodata (the path tracer rejects non-finite samples)."""
     p = Path(path)
-    if p.suffix.lower() != ".npy":
-        raise ValueError(f"unsupported heightmap format {p.suffix!r}: convert the DEM to a 2-D float32 .npy")
-    dem = np.load(p)
+    suffix = p.suffix.lower()
+    if suffix == ".npy":
+        dem = np.load(p)
+    elif suffix in (".tif", ".tiff"):
+        dem, info = read_geotiff(p)
+        bad = ~np.isfinite(dem)
+        if info["nodata"] is not None:
+            bad |= dem == np.float32(info["nodata"])
+        if fill_nodata and bad.any():
+            dem = np.where(bad, dem[~bad].min() if (~bad).any() else 0.0, dem)
+    else:
+        raise ValueError(f"unsupported heightmap format {p.suffix!r}: use a 2-D float32 .npy or a GeoTIFF")
     if dem.ndim != 2:
         raise ValueError("heightmap must be a 2-D array")
     return np.ascontiguousarray(dem, np.float32)

@@ -78,7 +78,7 @@ class OfflineTerrainViewer:
         self.last_result = hybrid_render_terrain_reference(
             self._dem, int(width or self.width), int(height or self.height), dict(self._camera, fov_y=self._fov),
             spacing=self._spacing, exaggeration=self._z_scale, sun_azimuth_deg=self._sun[0],
-            sun_elevation_deg=self._sun[1], **self._render)
+            sun_elevation_deg=self._sun[1], **{k: v for k, v in self._render.items() if v is not None})
         return self.last_result
 
     def snapshot(self, path: Union[str, Path], width: Optional[int] = None, height: Optional[int] = None) -> None:

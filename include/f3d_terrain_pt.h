@@ -260,6 +260,12 @@ int f3d_effective_radius_m(int32_t earth_model, double latitude_deg, double sphe
                            double refraction_k, double azimuth_deg, double *radius_out, char *err,
                            size_t errlen);
 
+/* Scene cache: the acceleration tables of the most recently rendered DEMs (default 2 per process) stay on the
+ * device and are shared by every session / one-shot call that renders the same heights, dims and exaggeration --
+ * a camera path does not rebuild them per frame.  0 entries switches the cache off and frees it. */
+void f3d_scene_cache_limit(uint32_t entries);
+uint32_t f3d_scene_cache_entries(void);
+
 int f3d_device_count(void);
 const char *f3d_device_name(int32_t device); /* gcnArchName, "" when unavailable */
 const char *f3d_version(void);

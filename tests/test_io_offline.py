@@ -30,7 +30,151 @@ def test_png_round_trip_and_foreign_file(tmp_path):
     np.save(tmp_path / "d.npy", np.ones((5, 7), np.float64))
     assert io.load_heightmap(tmp_path / "d.npy").dtype == np.float32
     with pytest.raises(ValueError, match="unsupported heightmap"):
-        io.load_heightmap(tmp_path / "d.tif")
+        io.load_heightmap(tmp_path / "d.asc")
+
+
+def _write_tiff(path, array, *, big_endian=False, tile=None, compression=1, predictor=1, scale=None, nodata=None):
+    """A tiny independent TIFF writer for the reader's tests: strips or tiles, none / Deflate, predictors 1-3."""
+    import struct
+    import zlib
+
+    e = ">" if big_endian else "<"
+    a = np.ascontiguousarray(array)
+    h, w = a.shape
+    code = {"f": 3, "i": 2, "u": 1}[a.dtype.kind]
+    bps = a.dtype.itemsize
+
+    def pack(block):
+        block = np.ascontiguousarray(block).astype(a.dtype.newbyteorder(e))
+        if predictor == 2:
+            d = block.astype(block.dtype.newbyteorder("=")).copy()
+            d[:, 1:] = d[:, 1:] - d[:, :-1]
+            block = d.astype(a.dtype.newbyteorder(e))
+        raw = block.tobytes()
+        if predictor == 3:
+            rows, cols = block.shape
+            b = np.frombuffer(raw, np.uint8).reshape(rows, cols, bps)
+            if e == "<":
+                b = b[:, :, ::-1]
+            b = b.transpose(0, 2, 1).reshape(rows, cols * bps).astype(np.int16)
+            b[:, 1:] = b[:, 1:] - b[:, :-1]
+            raw = (b & 255).astype(np.uint8).tobytes()
+        return zlib.compress(raw) if compression == 8 else raw
+
+    chunks = []
+    if tile:
+        th, tw = tile
+        for y0 in range(0, h, th):
+            for x0 in range(0, w, tw):
+                blk = np.zeros((th, tw), a.dtype)
+                part = a[y0:y0 + th, x0:x0 + tw]
+                blk[:part.shape[0], :part.shape[1]] = part
+                chunks.append(pack(blk))
+    else:
+        rps = 8
+        for y0 in range(0, h, rps):
+            chunks.append(pack(a[y0:y0 + rps]))
+    entries, extra = [], b""
+    data_start = 8
+    offsets, pos = [], data_start
+    for c in chunks:
+        offsets.append(pos)
+        pos += len(c) + (len(c) & 1)
+    body = b"".join(c + (b"\0" if len(c) & 1 else b"") for c in chunks)
+    n_tags = 10 + (2 if tile else 1) + (1 if scale else 0) + (1 if nodata is not None else 0)
+    ifd_pos = pos
+    extra_pos = ifd_pos + 2 + 12 * n_tags + 4
+
+    def tag(t, typ, values):
+        nonlocal extra, extra_pos
+        fmt = {3: "H", 4: "I", 12: "d", 2: "s"}[typ]
+        if typ == 2:
+            payload = values.encode() + b"\0"
+            n = len(payload)
+        else:
+            payload = struct.pack(e + fmt * len(values), *values)
+            n = len(values)
+        if len(payload) <= 4:
+            field = payload.ljust(4, b"\0")
+        else:
+            field = struct.pack(e + "I", extra_pos)
+            extra += payload + (b"\0" if len(payload) & 1 else b"")
+            extra_pos += len(payload) + (len(payload) & 1)
+        entries.append((t, struct.pack(e + "HHI", t, typ, n) + field))
+
+    tag(256, 4, [w]); tag(257, 4, [h]); tag(258, 3, [bps * 8]); tag(259, 3, [compression]); tag(262, 3, [1])
+    tag(277, 3, [1]); tag(317, 3, [predictor]); tag(339, 3, [code])
+    if tile:
+        tag(322, 4, [tile[1]]); tag(323, 4, [tile[0]]); tag(324, 4, offsets); tag(325, 4, [len(c) for c in chunks])
+    else:
+        tag(273, 4, offsets); tag(278, 4, [8]); tag(279, 4, [len(c) for c in chunks])
+    if scale:
+        tag(33550, 12, [scale[0], scale[1], 0.0])
+    if nodata is not None:
+        tag(42113, 2, str(nodata))
+    entries.sort()
+    ifd = struct.pack(e + "H", len(entries)) + b"".join(x[1] for x in entries) + struct.pack(e + "I", 0)
+    header = (b"MM" if big_endian else b"II") + struct.pack(e + "HI", 42, ifd_pos)
+    Path(path).write_bytes(header + body + ifd + extra)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(big_endian=True), dict(tile=(16, 16)), dict(compression=8, predictor=3),
+                                dict(compression=8, predictor=3, big_endian=True, tile=(16, 32)),
+                                dict(scale=(30.0, 30.0), nodata=-9999.0)])
+def test_geotiff_reader_decodes_float_dems(tmp_path, kw):
+    from forge3d_amd import io
+
+    rng = np.random.default_rng(2)
+    dem = rng.normal(1500.0, 400.0, (45, 70)).astype(np.float32)
+    if "nodata" in kw:
+        dem[3:6, 10:14] = -9999.0
+    _write_tiff(tmp_path / "d.tif", dem, **kw)
+    got, info = io.read_geotiff(tmp_path / "d.tif")
+    assert np.array_equal(got, dem)
+    if "scale" in kw:
+        assert info["pixel_scale"] == (30.0, 30.0) and info["nodata"] == -9999.0
+        filled = io.load_heightmap(tmp_path / "d.tif")
+        assert np.isfinite(filled).all() and filled.min() == dem[dem > -9999.0].min()
+
+
+def test_geotiff_reader_decodes_integer_dems_and_foreign_files(tmp_path):
+    from forge3d_amd import io
+
+    rng = np.random.default_rng(4)
+    dem = rng.integers(-200, 4000, (33, 41)).astype(np.int16)
+    _write_tiff(tmp_path / "i.tif", dem, compression=8, predictor=2)
+    assert np.array_equal(io.read_geotiff(tmp_path / "i.tif")[0], dem.astype(np.float32))
+    PIL = pytest.importorskip("PIL.Image")
+    f = rng.normal(900.0, 200.0, (37, 53)).astype(np.float32)
+    for comp in (None, "tiff_lzw", "tiff_adobe_deflate", "packbits"):  # files of another encoder (libtiff)
+        PIL.fromarray(f).save(tmp_path / "p.tif", compression=comp)
+        assert np.array_equal(io.read_geotiff(tmp_path / "p.tif")[0], f), comp
+    with pytest.raises(ValueError, match="not a TIFF"):
+        (tmp_path / "x.tif").write_bytes(b"nope")
+        io.read_geotiff(tmp_path / "x.tif")
+
+
+def test_viewer_handle_and_renderer_names():
+    import forge3d_amd as f3d
+
+    h = f3d.open_viewer_async(320, 200, fov_deg=50.0)
+    assert isinstance(h, f3d.ViewerHandle) and h.is_running and h.get_stats()["backend"] == "hip-gfx950"
+    h.load_terrain(np.zeros((8, 8), np.float32), spacing=10.0)
+    h.set_orbit_camera(0.0, 90.0, 100.0, target=(0.0, 0.0, 0.0))
+    h.set_sun(302.0, 24.0)
+    h.set_z_scale(2.0)
+    with pytest.raises(f3d.viewer.ViewerError, match="raster viewer"):
+        h.add_label("x", (0, 0, 0))
+    with pytest.raises(f3d.viewer.ViewerError):
+        f3d.open_viewer_async(obj_path="a.obj")
+    with h:
+        pass
+    assert not h.is_running
+    r = f3d.Renderer(64, 48, exposure=1.5)
+    assert r.get_config()["lighting"]["exposure"] == 1.5 and r.render_triangle_rgba().shape == (48, 64, 4)
+    assert tuple(r.render_triangle_rgba()[24, 32]) == (128, 64, 32, 255) and tuple(r.render_triangle_rgba()[0, 0]) == (16, 16, 24, 255)
+    with pytest.raises(TypeError, match="Unexpected arguments: bogus"):
+        f3d.Renderer(8, 8, bogus=1)
 
 
 def test_orbit_mapping_of_the_facade():
@@ -68,3 +212,36 @@ def test_snapshot_writes_the_path_traced_frame(tmp_path):
                                                sun_elevation_deg=kw["sun_elevation_deg"], spp=2, max_frames=4,
                                                min_frames=4, variance_threshold=1e30)
     assert np.array_equal(io.png_to_numpy(tmp_path / "snap.png"), want["rgba"])
+
+
+@pytest.mark.gpu
+def test_viewer_handle_animation_reuses_the_cached_scene(tmp_path):
+    """ViewerHandle over a GeoTIFF DEM: a three-frame orbit; the DEM's tables are built once (scene cache) and every
+    frame equals the direct call."""
+    import forge3d_amd as f3d
+    import scenes
+    from forge3d_amd import _native, io
+
+    dem = (scenes.golden_dem() * 20.0).astype(np.float32)
+    spacing = scenes.SPAN / (dem.shape[1] - 1)
+    _write_tiff(tmp_path / "dem.tif", dem, compression=8, predictor=3, scale=(spacing, spacing))
+    L = _native.lib()
+    L.f3d_scene_cache_limit(0)
+    L.f3d_scene_cache_limit(2)
+    h = f3d.open_viewer_async(96, 64, terrain_path=tmp_path / "dem.tif", fov_deg=45.0)
+    h._render.update(spp=2, max_frames=3, min_frames=3, variance_threshold=1e30)
+    h.set_sun(225.0, 35.0)
+    keys = [dict(phi_deg=p, theta_deg=60.0, radius=110.0, target=(0.0, 5.0, 0.0)) for p in (20.0, 50.0, 80.0)]
+    h.render_animation(keys, tmp_path / "frames", width=96, height=64)
+    assert L.f3d_scene_cache_entries() == 1
+    from forge3d_amd.datasets import orbit_camera
+
+    for i, k in enumerate(keys):
+        cam = orbit_camera(k["target"], k["radius"], k["phi_deg"], k["theta_deg"], 45.0)
+        want = f3d.hybrid_render_terrain_reference(dem, 96, 64, cam, spacing=(spacing, spacing), sun_azimuth_deg=225.0,
+                                                   sun_elevation_deg=35.0, spp=2, max_frames=3, min_frames=3,
+                                                   variance_threshold=1e30)
+        assert np.array_equal(io.png_to_numpy(tmp_path / "frames" / f"frame_{i:04d}.png"), want["rgba"]), i
+    L.f3d_scene_cache_limit(0)
+    assert L.f3d_scene_cache_entries() == 0
+    L.f3d_scene_cache_limit(2)
