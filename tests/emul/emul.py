@@ -106,6 +106,28 @@ def terrain_trace_batch(heights, rays, *, origin=(0.0, 0.0), spacing=(1.0, 1.0),
     return {"hit": hit, "t": t, "normal": nrm}
 
 
+def terrain_trace_batch_wave(heights, rays, *, origin=(0.0, 0.0), spacing=(1.0, 1.0), exaggeration=1.0, inv_two_r_prime=0.0,
+                             curvature_enabled=False, any_hit=2, apply_curvature=True, share_below=0):
+    """The stackless march over the batch in 64-lane WAVES with the ray sharing live (lanes are fibers, votes and
+    shuffles are exchanged in lockstep): any_hit = 2 any / 3 closest, +4 start in the origin's cell; share_below =
+    sharing threshold (0 = default 16, 64 = every any-hit ray without curvature policy is dealt at once)."""
+    dem = np.ascontiguousarray(heights, np.float32)
+    r = np.ascontiguousarray(rays, np.float32)
+    n = r.shape[0]
+    hit, t, nrm = np.zeros(n, np.uint32), np.zeros(n, np.float32), np.zeros((n, 3), np.float32)
+    stats = np.zeros(2, np.uint64)
+    rc = lib().emul_trace_batch_wave(C.c_void_p(dem.ctypes.data), C.c_uint32(dem.shape[1]), C.c_uint32(dem.shape[0]),
+                                     C.c_float(origin[0]), C.c_float(origin[1]), C.c_float(spacing[0]), C.c_float(spacing[1]),
+                                     C.c_float(exaggeration), C.c_float(inv_two_r_prime), C.c_uint32(1 if curvature_enabled else 0),
+                                     C.c_void_p(r.ctypes.data), C.c_uint32(n), C.c_int32(int(any_hit)),
+                                     C.c_int32(1 if apply_curvature else 0), C.c_uint32(int(share_below)),
+                                     C.c_void_p(hit.ctypes.data), C.c_void_p(t.ctypes.data), C.c_void_p(nrm.ctypes.data),
+                                     C.c_void_p(stats.ctypes.data))
+    if rc != 0:
+        raise RuntimeError(f"emul status {rc}")
+    return {"hit": hit, "t": t, "normal": nrm, "exchanges": int(stats[0]), "deals": int(stats[1])}
+
+
 def bvh_fingerprint(vertices, indices, threaded: bool):
     """(FNV-1a of the node + triangle arrays, node count) of the mesh BVH, built on one thread or with
     the worker threads of the large-mesh path (forced on for any size)."""

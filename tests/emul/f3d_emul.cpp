@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <ucontext.h>
 #include <vector>
 
 #include "../../forge3d_amd/csrc/f3d_setup.h"
@@ -87,6 +89,141 @@ struct ArrayPending {
         offset = T.node_offset[l];
         tiles_x = T.tiles_x[l];
     }
+};
+
+// ---- a 64-lane wave on the host -----------------------------------------------------------------------
+// The march's ray sharing (f3d_march.h march_shared / march_deal) is wave-cooperative code: ballots, cross-lane
+// shuffles, a verdict board shared by the lanes.  To run it in the GPU-less container every lane of a wave is a
+// FIBER (ucontext): a lane runs until it reaches a wave primitive, parks there, and when every lane that is still
+// alive has parked at the same kind of primitive the exchange happens and they all continue -- the lockstep the
+// device gives for free.  Lanes that return leave the wave, like lanes whose EXEC bit has gone.  Divergent regions
+// that contain primitives must be entered through Wave::run with the participating lanes (the kernels' own
+// structure: everybody calls march_ray together).
+struct Wave {
+    static constexpr int kLanes = 64;
+    static constexpr size_t kStack = 256 * 1024;
+    enum Op { kNone, kBallot, kShfl };
+    ucontext_t sched{}, ctx[kLanes]{};
+    std::vector<char> stacks;
+    bool alive[kLanes]{}, parked[kLanes]{};
+    Op op[kLanes]{};
+    uint32_t val[kLanes]{};
+    int src[kLanes]{};
+    uint64_t ballot_result = 0;
+    uint32_t shfl_result[kLanes]{};
+    uint32_t board[kLanes]{};  // verdict board of the ray sharing
+    int current = -1;
+    std::function<void(int)> body;
+    uint64_t exchanges = 0, deals = 0;
+
+    Wave() : stacks(kLanes * kStack) {}
+    static void trampoline(unsigned lo, unsigned hi) {
+        Wave *w = (Wave *)(((uintptr_t)hi << 32) | (uintptr_t)lo);
+        const int lane = w->current;
+        w->body(lane);
+        w->alive[lane] = false;
+        swapcontext(&w->ctx[lane], &w->sched);
+    }
+    void park(int lane) {
+        parked[lane] = true;
+        swapcontext(&ctx[lane], &sched);
+    }
+    uint64_t ballot(int lane, bool pred) {
+        op[lane] = kBallot;
+        val[lane] = pred ? 1u : 0u;
+        park(lane);
+        return ballot_result;
+    }
+    uint32_t shfl(int lane, uint32_t v, int from) {
+        op[lane] = kShfl;
+        val[lane] = v;
+        src[lane] = from;
+        park(lane);
+        return shfl_result[lane];
+    }
+    // run body(lane) for the lanes of `mask` as one wave
+    void run(uint64_t mask, std::function<void(int)> fn) {
+        body = std::move(fn);
+        for (int l = 0; l < kLanes; l++) {
+            alive[l] = (mask >> l) & 1ull;
+            parked[l] = false;
+            if (!alive[l]) continue;
+            getcontext(&ctx[l]);
+            ctx[l].uc_stack.ss_sp = stacks.data() + (size_t)l * kStack;
+            ctx[l].uc_stack.ss_size = kStack;
+            ctx[l].uc_link = &sched;
+            const uintptr_t self = (uintptr_t)this;
+            makecontext(&ctx[l], (void (*)())trampoline, 2, (unsigned)(self & 0xFFFFFFFFu), (unsigned)(self >> 32));
+        }
+        for (;;) {
+            bool any = false;
+            for (int l = 0; l < kLanes; l++) {
+                if (!alive[l] || parked[l]) continue;
+                current = l;
+                swapcontext(&sched, &ctx[l]);  // until it parks at a primitive or returns
+            }
+            Op kind = kNone;
+            for (int l = 0; l < kLanes; l++) {
+                if (!alive[l]) continue;
+                any = true;
+                if (kind == kNone) kind = op[l];
+                if (op[l] != kind) {
+                    fprintf(stderr, "wave emulator: lanes parked at different primitives\n");
+                    abort();
+                }
+            }
+            if (!any) return;
+            exchanges++;
+            if (kind == kBallot) {
+                ballot_result = 0;
+                for (int l = 0; l < kLanes; l++)
+                    if (alive[l] && val[l]) ballot_result |= 1ull << l;
+            } else {
+                for (int l = 0; l < kLanes; l++) {
+                    if (!alive[l]) continue;
+                    const int from = src[l] & (kLanes - 1);
+                    if (!alive[from]) {  // the device would read garbage: the product code must never do this
+                        fprintf(stderr, "wave emulator: lane %d shuffles from dead lane %d\n", l, from);
+                        abort();
+                    }
+                    shfl_result[l] = val[from];
+                }
+            }
+            for (int l = 0; l < kLanes; l++) parked[l] = false;
+        }
+    }
+};
+
+// Per-lane traversal context of a wave lane: FIFO in lane-private storage, votes through the wave.
+struct WavePending : ArrayPending {
+    Wave *wave = nullptr;
+    int me = 0;
+    uint32_t share_below = kShareBelow;
+    uint32_t lane() const { return (uint32_t)me; }
+    unsigned long long ballot(bool pred) const { return wave->ballot(me, pred); }
+    float shfl(float v, int from) const { return f_from_bits(wave->shfl(me, f_bits(v), from)); }
+    uint32_t shfl(uint32_t v, int from) const { return wave->shfl(me, v, from); }
+    float fast_log2(float x) const { return log2f(x); }
+    float fast_exp2(float x) const { return exp2f(x); }
+    bool any(bool pred) const { return ballot(pred) != 0ull; }
+    bool flush_now(uint32_t queued, bool marching) const {  // LdsPending::flush_now with the default quorum (64)
+        const unsigned long long have = ballot(queued != 0u);
+        if (have == 0ull) return false;
+        return bits_set(have) >= 64u || ballot(queued >= kLeafFifo) != 0ull || ballot(marching) == 0ull;
+    }
+    bool share_now(bool marching) const { return share_now(marching, share_below); }
+    bool share_now(bool marching, uint32_t below) const {
+        const uint32_t n = bits_set(ballot(marching));
+        return n != 0u && n <= below && bits_set(ballot(true)) >= kShareAvail * n;
+    }
+    template <bool CURVED>
+    void deal(const TerrainDev &T, MarchSlice &s, MarchState &m) const {
+        wave->deals++;
+        march_deal<CURVED>(T, s, m, *this);
+    }
+    void verdict_post(bool hit) const { wave->board[me] = hit ? 1u : 0u; }
+    void verdict_set(uint32_t owner) const { wave->board[owner & 63u] = 1u; }
+    bool verdict_get(uint32_t owner) const { return wave->board[owner & 63u] != 0u; }
 };
 
 struct HostTables {
@@ -268,6 +405,62 @@ int emul_trace_batch(const float *heights, uint32_t w, uint32_t h, float origin_
                 out_normal[3 * i + 1] = hit.hit ? hit.n.y : 0.0f;
                 out_normal[3 * i + 2] = hit.hit ? hit.n.z : 0.0f;
             }
+        }
+    } catch (const Failure &f) {
+        return f.status;
+    }
+    return 0;
+}
+
+// terrain any-hit / closest march over a ray batch in WAVES of 64 lanes with the ray sharing live
+// (f3d_kernels.hip k_ray_batch on the host): mode 2 any / 3 closest, +4 start in the origin's cell;
+// share_below = the sharing threshold (0 = default).  stats_out[0] = wave exchanges, [1] = rays that were dealt.
+int emul_trace_batch_wave(const float *heights, uint32_t w, uint32_t h, float origin_x, float origin_z, float spacing_x,
+                          float spacing_z, float exaggeration, float inv_two_r_prime, uint32_t curvature_enabled,
+                          const float *rays, uint32_t n, int32_t mode, int32_t apply_curvature, uint32_t share_below,
+                          uint32_t *out_hit, float *out_t, float *out_normal, uint64_t *stats_out) {
+    try {
+        HostTables t = build_tables_host(heights, w, h, exaggeration);
+        TerrainDev T{};
+        t.attach(T);
+        T.origin_x = origin_x;
+        T.origin_z = origin_z;
+        T.spacing_x = spacing_x;
+        T.spacing_z = spacing_z;
+        T.inv_spacing_x = 1.0f / spacing_x;
+        T.inv_spacing_z = 1.0f / spacing_z;
+        T.inv_two_r_prime = inv_two_r_prime;
+        T.curvature_enabled = curvature_enabled;
+        const long waves = ((long)n + 63) / 64;
+        uint64_t exchanges = 0, deals = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : exchanges, deals)
+        for (long wv = 0; wv < waves; wv++) {
+            Wave wave;
+            const uint32_t first = (uint32_t)wv * 64u, count = n - first < 64u ? n - first : 64u;
+            const uint64_t mask = count == 64u ? ~0ull : ((1ull << count) - 1ull);
+            wave.run(mask, [&](int lane) {
+                const uint32_t i = first + (uint32_t)lane;
+                const float *r = rays + 8 * (size_t)i;
+                WavePending pend;
+                pend.wave = &wave;
+                pend.me = lane;
+                pend.share_below = share_below ? (share_below < 64u ? share_below : 64u) : kShareBelow;
+                RayCtx rc = make_ray(T, V3{r[0], r[1], r[2]}, r[3], V3{r[4], r[5], r[6]}, r[7], apply_curvature != 0);
+                const TraceHit hit = march_ray(T, rc, (mode & 3) == 2, (mode & 4) != 0, pend);
+                out_hit[i] = hit.hit ? 1u : 0u;
+                if (out_t) out_t[i] = hit.t;
+                if (out_normal) {
+                    out_normal[3 * i] = hit.hit ? hit.n.x : 0.0f;
+                    out_normal[3 * i + 1] = hit.hit ? hit.n.y : 0.0f;
+                    out_normal[3 * i + 2] = hit.hit ? hit.n.z : 0.0f;
+                }
+            });
+            exchanges += wave.exchanges;
+            deals += wave.deals;
+        }
+        if (stats_out) {
+            stats_out[0] = exchanges;
+            stats_out[1] = deals;  // lane-calls of march_deal
         }
     } catch (const Failure &f) {
         return f.status;

@@ -65,3 +65,39 @@ def test_lattice_aligned_renders_match_the_oracle(case):
             assert np.array_equal(got[key], want[key]), (key, lanes)
         assert np.array_equal(got["depth"], want["depth"], equal_nan=True)
         assert np.float32(got["variance"]) == np.float32(want["variance"])
+
+
+# ---- the ray sharing on a 64-lane wave (tests/emul Wave: lanes are fibers, ballots / shuffles in lockstep) --------
+@pytest.mark.parametrize("share", [0, 64, 3])
+def test_ray_sharing_on_the_host_wave_matches_the_oracle(share):
+    """march_shared / march_deal / the verdict board executed by 64 cooperating lanes on the CPU: the proof rays
+    shuffled so that every wave mixes short and very long marches, the last wave partial; sharing threshold at
+    its default, at 64 lanes (every ray dealt from its first step) and at 3."""
+    heights, rays = scenes.proof_rays(n_random=5000, mask=True)
+    rays = rays[np.random.default_rng(11).permutation(rays.shape[0])][: 64 * 300 + 37].copy()
+    base = dict(spacing=(500.0, 500.0), inv_two_r_prime=0.0, curvature_enabled=False, apply_curvature=False)
+    want_any = oracle.terrain_trace_batch(heights, rays, any_hit=True, **base)
+    want_closest = oracle.terrain_trace_batch(heights, rays, any_hit=False, **base)
+    for mode in (2, 6):
+        got = emul.terrain_trace_batch_wave(heights, rays, any_hit=mode, share_below=share, **base)
+        assert np.array_equal(got["hit"], want_any["hit"]), (mode, share)
+        assert got["deals"] > 0  # the dealing code really ran
+    got = emul.terrain_trace_batch_wave(heights, rays, any_hit=3, share_below=share, **base)
+    assert np.array_equal(got["hit"], want_closest["hit"]) and np.array_equal(got["t"], want_closest["t"])
+    assert np.array_equal(got["normal"], want_closest["normal"]) and got["deals"] == 0  # closest-hit rays are never dealt
+
+
+@pytest.mark.parametrize("name", ["diagplane", "ragged", "terrace", "rand_sym_int"])
+def test_lattice_aligned_rays_on_the_host_wave(name):
+    """The adversarial sets through the wave: corner ties inside dealt slices, slices that begin on lattice planes."""
+    dem = DEMS[name]
+    for spacing, share in ((1.0, 64), (10.0, 0), (0.5, 5)):
+        rays = scenes.adversarial_rays(dem, spacing)
+        h, w = dem.shape
+        base = dict(origin=(-0.5 * (w - 1) * spacing, -0.5 * (h - 1) * spacing), spacing=(spacing, spacing),
+                    inv_two_r_prime=0.0, curvature_enabled=False, apply_curvature=False)
+        want = oracle.terrain_trace_batch(dem, rays, any_hit=True, **base)
+        for mode in (2, 6):
+            got = emul.terrain_trace_batch_wave(dem, rays, any_hit=mode, share_below=share, **base)
+            bad = np.nonzero(got["hit"] != want["hit"])[0]
+            assert bad.size == 0, (name, spacing, share, mode, bad.size, rays[bad[:2]].tolist())
