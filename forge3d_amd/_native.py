@@ -80,7 +80,7 @@ class SessionOpts(C.Structure):
         ("row_begin", C.c_uint32), ("row_end", C.c_uint32),
         ("memory_budget_bytes", C.c_uint64), ("kernel_variant", C.c_int32),
         ("ext_reservoirs", C.c_void_p * 2), ("ext_stats", C.c_void_p),
-        ("bands", C.c_uint32), ("band_streams", C.c_uint32),
+        ("bands", C.c_uint32), ("band_streams", C.c_uint32), ("mesh_builder", C.c_uint32),
     ]
 
 

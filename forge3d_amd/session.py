@@ -20,7 +20,7 @@ WELFORD_WINDOW = 32
 class TerrainSession:
     def __init__(self, heightmap, width, height, camera=None, *, row_begin=0, row_end=0, device=-1, stream=0,
                  memory_budget_bytes=0, kernel_variant=0, ext_reservoirs=(None, None), ext_stats=None, bands=0,
-                 band_streams=0,
+                 band_streams=0, mesh_builder=0,
                  spacing=(1.0, 1.0), exaggeration=1.0, albedo=(0.6, 0.6, 0.6), sun_azimuth_deg=315.0,
                  sun_elevation_deg=45.0, sun_intensity=2.5, sun_color=(1.0, 0.97, 0.92), env_map=None,
                  env_intensity=0.35, mesh_vertices=None, mesh_indices=None, spp=1, max_frames=512, min_frames=32,
@@ -45,6 +45,7 @@ class TerrainSession:
         opts.ext_reservoirs[1] = C.c_void_p(ext_reservoirs[1] or None)
         opts.ext_stats = C.c_void_p(ext_stats or None)
         opts.bands, opts.band_streams = int(bands), int(band_streams)
+        opts.mesh_builder = int(mesh_builder)
         err = C.create_string_buffer(1024)
         rc = self._lib.f3d_session_create(C.byref(desc), C.byref(opts), C.byref(self._handle), err, len(err))
         del keep

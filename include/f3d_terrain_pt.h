@@ -144,6 +144,11 @@ typedef struct f3d_session_opts {
      * latency of one wave's ray chain.  Results do not depend on either number. */
     uint32_t bands;
     uint32_t band_streams;
+    /* Acceleration structure of the optional triangle mesh: 0 = automatic (host SAH unless F3D_MESH_BVH=lbvh is
+     * set in the environment), 1 = binned-SAH build on the host (reference accel::build_bvh, src/accel/sah_cpu.rs),
+     * 2 = linear BVH built on the GPU (reference src/accel/lbvh_gpu: Morton codes, radix sort, Karras topology,
+     * bottom-up refit).  Images do not depend on the choice. */
+    uint32_t mesh_builder;
 } f3d_session_opts;
 
 int f3d_session_create(const f3d_terrain_ref_desc *desc, const f3d_session_opts *opts,
