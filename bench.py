@@ -57,14 +57,27 @@ def parse_args():
 
 
 def kernel_source_hash() -> str:
-    """SHA-256 over the kernel sources: ties a PMC traffic figure under profiles/ to the code it was measured on."""
+    """SHA-256 over the frame kernel's sources (f3d_kernels.hip, the host driver and every header they include,
+    transitively) plus the build flags: ties a PMC traffic figure under profiles/ to the code it was measured on.
+    Sources of the other rows (smoke, denoiser, LBVH ...) do not enter."""
     import hashlib
+    import re
 
+    csrc = ROOT / "forge3d_amd" / "csrc"
+    todo, seen = ["f3d_kernels.hip", "f3d_host.hip"], set()
+    while todo:
+        name = todo.pop()
+        if name in seen or not (csrc / name).exists():
+            continue
+        seen.add(name)
+        todo += re.findall(r'#include\s+"([^"]+)"', (csrc / name).read_text())
     h = hashlib.sha256()
-    for path in sorted((ROOT / "forge3d_amd" / "csrc").glob("*")):
-        if path.suffix in (".h", ".hip"):
-            h.update(path.name.encode())
-            h.update(path.read_bytes())
+    for name in sorted(seen):
+        h.update(name.encode())
+        h.update((csrc / name).read_bytes())
+    import __graft_entry__ as entry
+
+    h.update(" ".join(entry.HIPCC_FLAGS).encode())
     return h.hexdigest()[:16]
 
 
