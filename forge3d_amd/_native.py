@@ -84,7 +84,7 @@ class SessionOpts(C.Structure):
     ]
 
 
-# every symbol include/f3d_terrain_pt.h declares: (name, restype, argtypes)
+# every symbol include/f3d_terrain_pt.h and include/f3d_wavefront.h declare: (name, restype, argtypes)
 _P = C.POINTER
 ABI = [
     ("f3d_terrain_ref_render", C.c_int, [_P(Desc), _P(Out), C.c_char_p, C.c_size_t]),
@@ -94,6 +94,8 @@ ABI = [
     ("f3d_session_window_stats", C.c_int, [C.c_void_p, _P(C.c_float), _P(C.c_int32), C.c_char_p, C.c_size_t]),
     ("f3d_scene_cache_limit", None, [C.c_uint32]),
     ("f3d_scene_cache_entries", C.c_uint32, []),
+    ("f3d_wavefront_render", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32,
+                                       C.c_void_p, C.c_char_p, C.c_size_t]),
     ("f3d_smoke_render", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_double), C.c_char_p, C.c_size_t]),
     ("f3d_session_debug_wave_times", C.c_int, [C.c_void_p, C.c_void_p]),
     ("f3d_session_halo", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _P(C.c_void_p), _P(C.c_uint64)]),

@@ -1,0 +1,196 @@
+// forge3d_amd/csrc/f3d_wavefront.hip -- multi-bounce PBR path tracer on gfx950: kernels + host driver + C ABI
+// (include/f3d_wavefront.h).  The per-pixel path logic lives in f3d_wf_path.h (host + device, so
+// the test emulator runs the same code); this file owns the launch shape and the scene upload.
+//
+// Reference driver: render_pt_reference (src/path_tracing/adjudication.rs:76-364) submits, for each of the spp frames,
+// raygen + up to 16 x {intersect, shade, shadow, scatter} dispatches of ceil(4 W H / 256) workgroups each and maps the
+// queue header back to the host between bounces.  Here: ONE launch per batch of frames, one wave per 8x8-pixel tile,
+// the per-pixel running sum in registers; a 512 x 512 x 4096-frame gate render is a single kernel.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <exception>
+#include <vector>
+
+#include "../../include/f3d_wavefront.h"
+#include "f3d_wf_host.h"
+
+using namespace f3d;
+
+namespace {
+
+struct WfParams {
+    wf::SceneDev S;
+    float4 *accum;
+    uint32_t first, count;
+    unsigned long long *vertices;
+};
+
+// One wave = one 8x8 pixel tile; tiles are dealt to workgroups in row-major order, i.e. round robin over the 8 XCDs,
+// so cheap (sky) and expensive (geometry) image regions spread over all of them.
+__global__ __launch_bounds__(64) void k_wavefront(const WfParams P) {
+    const uint32_t tiles_x = (P.S.width + 7u) / 8u;
+    const uint32_t x = (blockIdx.x % tiles_x) * 8u + (threadIdx.x & 7u), y = (blockIdx.x / tiles_x) * 8u + (threadIdx.x >> 3);
+    uint32_t vertices = 0u;
+    if (x < P.S.width && y < P.S.height) {
+        const uint32_t pixel = y * P.S.width + x;
+        float4 a = P.accum[pixel];
+        V3 acc{a.x, a.y, a.z};
+        vertices = wf::trace_pixel(P.S, pixel, P.first, P.count, acc);
+        P.accum[pixel] = float4{acc.x, acc.y, acc.z, a.w};
+    }
+    unsigned long long total = vertices;
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
+    if (threadIdx.x == 0u && P.vertices) atomicAdd(P.vertices, total);
+}
+
+struct ResolveParamsWf {
+    const float4 *accum;
+    float4 *hdr;
+    uchar4 *rgba;
+    uint32_t pixels, frames;
+    float exposure;
+};
+
+// mean over frames, alpha 1 (adjudication.rs:296-306); Reinhard + piecewise sRGB + u8 (core/tonemap.rs:11-30)
+__global__ void k_wf_resolve(const ResolveParamsWf R) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R.pixels) return;
+    const float inv = 1.0f / (float)R.frames;
+    const float4 a = R.accum[i];
+    const float m[3] = {a.x * inv, a.y * inv, a.z * inv};
+    if (R.hdr) R.hdr[i] = float4{m[0], m[1], m[2], 1.0f};
+    if (R.rgba) {
+        uint8_t c[3];
+        for (int k = 0; k < 3; k++) {
+            const float x = f_max(m[k], 0.0f) * R.exposure;
+            const float t = x / (1.0f + x);
+            const float s = t <= 0.0031308f ? 12.92f * t : 1.055f * wf::pow_det(t, 1.0f / 2.4f) - 0.055f;
+            c[k] = (uint8_t)(f_clamp(s, 0.0f, 1.0f) * 255.0f + 0.5f);
+        }
+        R.rgba[i] = uchar4{c[0], c[1], c[2], 255};
+    }
+}
+
+void ok(hipError_t e, const char *what) {
+    if (e != hipSuccess) fail(F3D_STATUS_DEVICE, "HIP failure in %s: %s", what, hipGetErrorString(e));
+}
+
+struct DeviceScope {  // the caller's current device is restored on every exit path
+    int before = -1;
+    bool switched = false;
+    explicit DeviceScope(int want) {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+            fail(F3D_STATUS_DEVICE, "no HIP device available: libf3dhip has no CPU fallback");
+        if (want >= 0) {
+            if (want >= n) fail(F3D_STATUS_VALUE, "device %d out of range (%d devices)", want, n);
+            ok(hipGetDevice(&before), "hipGetDevice");
+            if (before != want) {
+                ok(hipSetDevice(want), "hipSetDevice");
+                switched = true;
+            }
+        }
+    }
+    ~DeviceScope() {
+        if (switched) (void)hipSetDevice(before);
+    }
+};
+
+}  // namespace
+
+extern "C" int f3d_wavefront_render(const f3d_wf_scene *scene, uint32_t width, uint32_t height, uint32_t first_frame,
+                                    uint32_t frame_count, uint32_t frames_per_launch, int32_t device, f3d_wf_out *out, char *err,
+                                    size_t errlen) {
+    if (err && errlen) err[0] = 0;
+    std::vector<void *> owned;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = F3D_STATUS_OK;
+    try {
+        if (!scene || !out) fail(F3D_STATUS_VALUE, "null argument");
+        wf::validate_scene(*scene, width, height, frame_count);
+        if ((uint64_t)first_frame + frame_count > 0xFFFFFFFFull) fail(F3D_STATUS_VALUE, "frame range overflows u32");
+        DeviceScope scope(device);
+        auto alloc = [&](size_t bytes, const char *what) {
+            void *p = nullptr;
+            ok(hipMalloc(&p, bytes ? bytes : 16), what);
+            owned.push_back(p);
+            return p;
+        };
+        auto upload = [&](const void *src, size_t bytes, const char *what) {
+            void *p = alloc(bytes, what);
+            if (bytes) ok(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice), what);
+            return p;
+        };
+        wf::PreparedScene prep = wf::prepare_scene(*scene, width, height);
+        WfParams P{};
+        P.S = prep.S;
+        wf::SceneDev &S = P.S;
+        S.spheres = (const wf::SphereDev *)upload(prep.spheres.data(), prep.spheres.size() * sizeof(wf::SphereDev), "spheres");
+        S.mats = (const wf::MaterialDev *)upload(prep.mats.data(), prep.mats.size() * sizeof(wf::MaterialDev), "materials");
+        std::vector<wf::BlasDev> blas(prep.bvh.size());
+        for (size_t m = 0; m < prep.bvh.size(); m++) {  // one threaded BVH per BLAS
+            const MeshBvh &bvh = prep.bvh[m];
+            blas[m].nodes = (const BvhNode *)upload(bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode), "bvh nodes");
+            blas[m].tris = (const float4 *)upload(bvh.tris.data(), bvh.tris.size() * sizeof(float), "bvh triangles");
+            blas[m].node_count = (uint32_t)bvh.nodes.size();
+            blas[m].pad = 0u;
+        }
+        S.blas = (const wf::BlasDev *)upload(blas.data(), blas.size() * sizeof(wf::BlasDev), "blas table");
+        S.inst = (const wf::InstanceDev *)upload(prep.inst.data(), prep.inst.size() * sizeof(wf::InstanceDev), "instances");
+        S.dir = (const wf::DirLightDev *)upload(prep.dir.data(), prep.dir.size() * sizeof(wf::DirLightDev), "directional lights");
+        S.area = (const wf::AreaLightDev *)upload(prep.area.data(), prep.area.size() * sizeof(wf::AreaLightDev), "area lights");
+
+        const size_t pixels = (size_t)width * height;
+        P.accum = (float4 *)alloc(pixels * sizeof(float4), "accumulation");
+        if (out->accum)
+            ok(hipMemcpy(P.accum, out->accum, pixels * sizeof(float4), hipMemcpyHostToDevice), "accumulation upload");
+        else
+            ok(hipMemset(P.accum, 0, pixels * sizeof(float4)), "accumulation clear");
+        P.vertices = (unsigned long long *)alloc(sizeof(unsigned long long), "counter");
+        ok(hipMemset(P.vertices, 0, sizeof(unsigned long long)), "counter clear");
+
+        const uint32_t tiles = ((width + 7u) / 8u) * ((height + 7u) / 8u);
+        const uint32_t chunk = frames_per_launch ? frames_per_launch : 4096u;
+        ok(hipEventCreate(&e0), "event");
+        ok(hipEventCreate(&e1), "event");
+        ok(hipEventRecord(e0, nullptr), "event");
+        for (uint32_t done = 0u; done < frame_count; done += chunk) {
+            P.first = first_frame + done;
+            P.count = frame_count - done < chunk ? frame_count - done : chunk;
+            hipLaunchKernelGGL(k_wavefront, dim3(tiles), dim3(64), 0, nullptr, P);
+            ok(hipGetLastError(), "path tracing kernel");
+        }
+        ok(hipEventRecord(e1, nullptr), "event");
+        const uint32_t total_frames = first_frame + frame_count;
+        float4 *d_hdr = out->hdr ? (float4 *)alloc(pixels * sizeof(float4), "hdr") : nullptr;
+        uchar4 *d_rgba = out->rgba ? (uchar4 *)alloc(pixels * 4, "rgba") : nullptr;
+        if (d_hdr || d_rgba) {
+            const ResolveParamsWf R{P.accum, d_hdr, d_rgba, (uint32_t)pixels, total_frames, scene->cam_exposure};
+            hipLaunchKernelGGL(k_wf_resolve, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, nullptr, R);
+            ok(hipGetLastError(), "resolve kernel");
+        }
+        ok(hipDeviceSynchronize(), "path tracing");
+        if (d_hdr) ok(hipMemcpy(out->hdr, d_hdr, pixels * sizeof(float4), hipMemcpyDeviceToHost), "hdr readback");
+        if (d_rgba) ok(hipMemcpy(out->rgba, d_rgba, pixels * 4, hipMemcpyDeviceToHost), "rgba readback");
+        if (out->accum) ok(hipMemcpy(out->accum, P.accum, pixels * sizeof(float4), hipMemcpyDeviceToHost), "accumulation readback");
+        unsigned long long vertices = 0;
+        ok(hipMemcpy(&vertices, P.vertices, sizeof(vertices), hipMemcpyDeviceToHost), "counter readback");
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        out->loop_seconds = ms * 1e-3;
+        out->paths = (uint64_t)pixels * frame_count;
+        out->path_vertices = vertices;
+    } catch (const Failure &f) {
+        rc = report(f, err, errlen);
+    } catch (const std::exception &e) {
+        if (err && errlen) snprintf(err, errlen, "host failure: %s", e.what());
+        rc = F3D_STATUS_DEVICE;
+    } catch (...) {
+        rc = F3D_STATUS_DEVICE;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    for (void *p : owned) (void)hipFree(p);
+    return rc;
+}

@@ -1,0 +1,692 @@
+// forge3d_amd/csrc/f3d_wf_path.h -- one pixel's paths of the multi-bounce PBR tracer, host + device.
+//
+// Reference: the wavefront tracer behind render_pt_reference (src/path_tracing/adjudication.rs:76-364):
+// pt_raygen.wgsl:162-226 -> up to 16 x { pt_intersect.wgsl:431-558, pt_shade.wgsl:460-862, pt_shadow.wgsl:248-294,
+// pt_scatter.wgsl:76-133 } with a host read-back of the queue header between bounces (wavefront/render.rs:87-208).
+//
+// MI355X form.  A pixel's rays never meet another pixel's, so the five queues, their atomics and the per-bounce host
+// round trip are a schedule, not part of the result.  Here a lane owns a pixel for a whole batch of frames and runs a
+// FLAT loop whose body is one path vertex: (new camera ray if the previous path ended) -> closest hit -> on a miss
+// add the background and end the path, otherwise next-event estimation with its shadow rays traced on the spot,
+// continuation sample, roulette.  A lane whose path ends starts its next frame's path in the very next iteration, so
+// lanes of a wave never wait for the longest path of a frame; the running sum of the pixel stays in registers for
+// the whole batch, and nothing but the final sums ever reaches HBM.  Contributions are added in the order the
+// reference's stages add them, so the result is the sequential sum oracle/wavefront_oracle.c computes, bit for bit.
+// Instanced meshes are walked through the threaded BVH of f3d_bvh.h (one 32-byte record per visited node, no stack)
+// with the reference's two triangle tests: watertight for closest hits (pt_intersect.wgsl:113-178), Moller-Trumbore
+// for shadow rays (pt_shadow.wgsl:205-236); equal-t hits resolve to the lowest triangle index (the oracle's sweep).
+//
+// Not here (off / empty in render_pt_reference): ReSTIR guiding, fog medium, hair segments.
+// Numerics: f3d_math.h contract (no contraction; dot = fma chain; fixed-polynomial sincos/atan/exp/log).
+#pragma once
+
+#include "f3d_math.h"
+#include "f3d_scene.h"
+
+namespace f3d {
+namespace wf {
+
+struct SphereDev {
+    V3 c;
+    float r;
+};
+struct MaterialDev {  // Sphere's material half (pt_shade.wgsl:235-245) + object_importance[mat]
+    V3 albedo;
+    float metallic;
+    V3 emissive;
+    float roughness;
+    float ior, ax, ay, importance;
+};
+struct BlasDev {
+    const BvhNode *nodes;
+    const float4 *tris;  // 3 float4 per triangle in leaf order, v0.w = original triangle index
+    uint32_t node_count, pad;
+};
+struct InstanceDev {
+    float w2o[16];  // world_to_object, column-major
+    uint32_t blas, material, pad0, pad1;
+};
+struct DirLightDev {
+    V3 wi;  // normalize(-direction)
+    float importance;
+    V3 Li;  // color * intensity
+    float pad;
+};
+struct AreaLightDev {
+    V3 position;
+    float rad;  // max(radius, 1e-6)
+    V3 nL;
+    float importance;
+    V3 tL;
+    float p_area;
+    V3 bL;
+    float pad;
+    V3 Li;
+    float pad2;
+};
+struct SceneDev {
+    const SphereDev *spheres;
+    const MaterialDev *mats;
+    const BlasDev *blas;
+    const InstanceDev *inst;
+    const DirLightDev *dir;
+    const AreaLightDev *area;
+    uint32_t sphere_count, blas_count, inst_count, dir_count, area_count;
+    float dir_sum_imp, area_sum_imp;
+    V3 env_ground, env_sky, miss_ground, miss_sky;
+    V3 cam_origin, cam_right, cam_up, cam_neg_forward;
+    float half_w, half_h;
+    uint32_t width, height, seed_hi, seed_lo;
+};
+
+constexpr float kTwoPiInv = 0.15915494309189533577f;
+
+F3D_HD float f_saturate(float x) { return f_clamp(x, 0.0f, 1.0f); }
+F3D_HD V3 scale3(V3 a, float s) { return a * s; }
+F3D_HD float comp3(V3 a, uint32_t k) { return k == 0u ? a.x : (k == 1u ? a.y : a.z); }
+F3D_HD V3 mix3(V3 a, V3 b, float t) { return V3{mix(a.x, b.x, t), mix(a.y, b.y, t), mix(a.z, b.z, t)}; }
+F3D_HD V3 reflect3(V3 i, V3 n) { return i - n * (2.0f * dot(n, i)); }
+F3D_HD float pow5(float x) {
+    const float x2 = x * x;
+    return (x2 * x2) * x;
+}
+F3D_HD float pow16(float x) {
+    float a = x * x;
+    a = a * a;
+    a = a * a;
+    return a * a;
+}
+// natural log of a positive normal float (cephes logf scheme), every operation spelled
+F3D_HD float log_det(float x) {
+    const uint32_t b = f_bits(x);
+    int e = (int)(b >> 23) - 126;
+    float m = f_from_bits((b & 0x007FFFFFu) | 0x3F000000u);
+    if (m < 0.707106781186547524f) {
+        e -= 1;
+        m = (m + m) - 1.0f;
+    } else {
+        m = m - 1.0f;
+    }
+    const float z = m * m;
+    float p = f_fma(7.0376836292e-2f, m, -1.1514610310e-1f);
+    p = f_fma(p, m, 1.1676998740e-1f);
+    p = f_fma(p, m, -1.2420140846e-1f);
+    p = f_fma(p, m, 1.4249322787e-1f);
+    p = f_fma(p, m, -1.6668057665e-1f);
+    p = f_fma(p, m, 2.0000714765e-1f);
+    p = f_fma(p, m, -2.4999993993e-1f);
+    p = f_fma(p, m, 3.3333331174e-1f);
+    float y = (p * m) * z;
+    const float fe = (float)e;
+    y = f_fma(-2.12194440e-4f, fe, y);
+    y = f_fma(-0.5f, z, y);
+    const float r = m + y;
+    return f_fma(0.693359375f, fe, r);
+}
+F3D_HD float pow_det(float x, float y) {  // x >= 0, y > 0
+    if (!(x > 0.0f)) return 0.0f;
+    if (x < 1.17549435e-38f) return 0.0f;
+    return exp_det(y * log_det(x));
+}
+F3D_HD void sincos_rad(float a, float &s, float &c) {
+    float u = a * kTwoPiInv;
+    u = u - f_floor(u);
+    sincos_turn(u, s, c);
+}
+F3D_HD uint32_t splitmix32(uint32_t x) {  // adjudication.rs:222-228
+    x += 0x9E3779B9u;
+    uint32_t z = x;
+    z = (z ^ (z >> 16)) * 0x21F0AAADu;
+    z = (z ^ (z >> 15)) * 0x735A2D97u;
+    return z ^ (z >> 15);
+}
+
+// ---- camera ray, pt_raygen.wgsl:88-226 (spp 1 per frame, Van der Corput / Halton-3 + Cranley-Patterson + tent) ----
+F3D_HD float tent(float u) { return u < 0.5f ? f_sqrt(2.0f * u) - 1.0f : 1.0f - f_sqrt(2.0f * (1.0f - u)); }
+F3D_HD float halton3(uint32_t i) {
+    float f = 1.0f, r = 0.0f;
+    while (i != 0u) {
+        f = f / 3.0f;
+        r = r + (float)(i % 3u) * f;
+        i = i / 3u;
+    }
+    return r;
+}
+F3D_HD float rotate01(float u, float r) {
+    const float x = u + r;
+    return x - f_floor(x);
+}
+
+struct PathState {
+    V3 o, d, thr;
+    float tmin;
+    uint32_t depth, rng_hi;
+};
+
+F3D_HD void camera_ray(const SceneDev &S, uint32_t pixel, uint32_t frame, uint32_t seed_hi, uint32_t seed_lo, PathState &P) {
+    const uint32_t px = pixel % S.width, py = pixel / S.width;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float u1 = (float)__brev(frame) * 2.3283064365386963e-10f;  // radical_inverse_vdc: a bit reversal
+#else
+    uint32_t n = frame;
+    n = (n << 16) | (n >> 16);
+    n = ((n & 0x55555555u) << 1) | ((n & 0xAAAAAAAAu) >> 1);
+    n = ((n & 0x33333333u) << 2) | ((n & 0xCCCCCCCCu) >> 2);
+    n = ((n & 0x0F0F0F0Fu) << 4) | ((n & 0xF0F0F0F0u) >> 4);
+    n = ((n & 0x00FF00FFu) << 8) | ((n & 0xFF00FF00u) >> 8);
+    const float u1 = (float)n * 2.3283064365386963e-10f;
+#endif
+    const float u2 = halton3(frame);
+    uint32_t rot = seed_lo ^ (px * 9781u) ^ (py * 6271u) ^ (seed_hi * 13007u);
+    const float r1 = rng_next(rot), r2 = rng_next(rot);
+    const float jx = tent(rotate01(u1, r1)) * 0.5f, jy = tent(rotate01(u2, r2)) * 0.5f;
+    const float ndc_x = ((((float)px + 0.5f) + jx) / (float)S.width) * 2.0f - 1.0f;
+    const float ndc_y = (1.0f - (((float)py + 0.5f) + jy) / (float)S.height) * 2.0f - 1.0f;
+    const V3 c = normalize(V3{ndc_x * S.half_w, ndc_y * S.half_h, -1.0f});
+    const V3 R = S.cam_right, U = S.cam_up, F = S.cam_neg_forward;
+    P.d = normalize(V3{(c.x * R.x + c.y * U.x) + c.z * F.x, (c.x * R.y + c.y * U.y) + c.z * F.y, (c.x * R.z + c.y * U.z) + c.z * F.z});
+    P.o = S.cam_origin;
+    P.tmin = 1e-4f;
+    P.thr = V3{1.0f, 1.0f, 1.0f};
+    P.depth = 0u;
+    P.rng_hi = seed_hi ^ (pixel * 9781u) ^ (frame * 6271u);
+}
+
+// ---- geometry -----------------------------------------------------------------------------------------------------
+F3D_HD V3 xf_point(const float *m, V3 p) {
+    return V3{((m[0] * p.x + m[4] * p.y) + m[8] * p.z) + m[12] * 1.0f, ((m[1] * p.x + m[5] * p.y) + m[9] * p.z) + m[13] * 1.0f,
+              ((m[2] * p.x + m[6] * p.y) + m[10] * p.z) + m[14] * 1.0f};
+}
+F3D_HD V3 xf_vector(const float *m, V3 v) {
+    return V3{((m[0] * v.x + m[4] * v.y) + m[8] * v.z) + m[12] * 0.0f, ((m[1] * v.x + m[5] * v.y) + m[9] * v.z) + m[13] * 0.0f,
+              ((m[2] * v.x + m[6] * v.y) + m[10] * v.z) + m[14] * 0.0f};
+}
+F3D_HD V3 xf_normal(const float *m, V3 n) {  // transpose(world_to_object) * (n, 0), normalised
+    return normalize(V3{((m[0] * n.x + m[1] * n.y) + m[2] * n.z) + m[3] * 0.0f, ((m[4] * n.x + m[5] * n.y) + m[6] * n.z) + m[7] * 0.0f,
+                        ((m[8] * n.x + m[9] * n.y) + m[10] * n.z) + m[11] * 0.0f});
+}
+
+// watertight test, pt_intersect.wgsl:113-178 (t only; the normal is taken from the winning triangle afterwards)
+F3D_HD bool tri_watertight(V3 o, V3 d, float tmin, float tmax, V3 v0, V3 v1, V3 v2, float &t_out) {
+    const V3 A = v0 - o, B = v1 - o, C = v2 - o;
+    const float adx = f_abs(d.x), ady = f_abs(d.y), adz = f_abs(d.z);
+    uint32_t kz = 2u, kx = 0u, ky = 1u;
+    if (adx > ady && adx > adz) {
+        kz = 0u, kx = 1u, ky = 2u;
+    } else if (ady > adz) {
+        kz = 1u, kx = 2u, ky = 0u;
+    }
+    const float Sz = 1.0f / comp3(d, kz), Sx = comp3(d, kx) * Sz, Sy = comp3(d, ky) * Sz;
+    const float ax = comp3(A, kx) - Sx * comp3(A, kz), ay = comp3(A, ky) - Sy * comp3(A, kz);
+    const float bx = comp3(B, kx) - Sx * comp3(B, kz), by = comp3(B, ky) - Sy * comp3(B, kz);
+    const float cx = comp3(C, kx) - Sx * comp3(C, kz), cy = comp3(C, ky) - Sy * comp3(C, kz);
+    const float az = comp3(A, kz) * Sz, bz = comp3(B, kz) * Sz, cz = comp3(C, kz) * Sz;
+    const float U = (bx * cy) - (by * cx), V = (cx * ay) - (cy * ax), W = (ax * by) - (ay * bx);
+    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
+    const float det = (U + V) + W;
+    if (det == 0.0f) return false;
+    const float T = (U * az + V * bz) + W * cz;
+    const float t = T / det;
+    if (t > tmin && t < tmax) {
+        t_out = t;
+        return true;
+    }
+    return false;
+}
+// Moller-Trumbore any-hit, pt_shadow.wgsl:205-236
+F3D_HD bool tri_shadow(V3 ro, V3 rd, float tmin, float tmax, V3 v0, V3 v1, V3 v2) {
+    const V3 e1 = v1 - v0, e2 = v2 - v0;
+    const V3 h = cross(rd, e2);
+    const float a = dot(e1, h);
+    if (f_abs(a) < 1e-7f) return false;
+    const float f = 1.0f / a;
+    const V3 s = ro - v0;
+    const float u = f * dot(s, h);
+    if (u < 0.0f || u > 1.0f) return false;
+    const V3 q = cross(s, e1);
+    const float v = f * dot(rd, q);
+    if (v < 0.0f || u + v > 1.0f) return false;
+    const float t = f * dot(e2, q);
+    return t > tmin && t < tmax;
+}
+
+// Threaded-BVH walk of one BLAS.  ANY: Moller-Trumbore, stop at the first hit.  Otherwise: watertight test, the
+// smallest t wins and the lowest original index among equal t (what a sweep in index order with `t < best` returns).
+template <bool ANY>
+F3D_HD bool walk_blas(const BlasDev &M, V3 o, V3 d, float tmin, float tmax, float &t_best, V3 &n_best) {
+    const float ix = (d.x < 0.0f ? -1.0f : 1.0f) / f_max(f_abs(d.x), 1e-12f);
+    const float iy = (d.y < 0.0f ? -1.0f : 1.0f) / f_max(f_abs(d.y), 1e-12f);
+    const float iz = (d.z < 0.0f ? -1.0f : 1.0f) / f_max(f_abs(d.z), 1e-12f);
+    const float4 *nodes = reinterpret_cast<const float4 *>(M.nodes);
+    bool any = false;
+    uint32_t best_tri = 0xFFFFFFFFu, best_slot = 0u;
+    t_best = tmax;
+    uint32_t node = 0u;
+    while (node < M.node_count) {
+        const float4 lo = nodes[2u * node], hi = nodes[2u * node + 1u];
+        const float ax = (lo.x - o.x) * ix, bx = (hi.x - o.x) * ix;
+        const float ay = (lo.y - o.y) * iy, by = (hi.y - o.y) * iy;
+        const float az = (lo.z - o.z) * iz, bz = (hi.z - o.z) * iz;
+        const float enter = f_max(f_max(f_min(ax, bx), f_min(ay, by)), f_max(f_min(az, bz), tmin));
+        const float exit = f_min(f_min(f_max(ax, bx), f_max(ay, by)), f_min(f_max(az, bz), t_best));
+        if (!(enter <= exit * 1.00001f + 1e-6f)) {  // conservative: boxes are padded, ties are kept
+            node = f_bits(lo.w);
+            continue;
+        }
+        const uint32_t leaf = f_bits(hi.w);
+        if (leaf == 0u) {
+            node = node + 1u;
+            continue;
+        }
+        const uint32_t first = leaf >> 3, count = leaf & 7u;
+        for (uint32_t k = 0u; k < count; k++) {
+            const float4 a = M.tris[3u * (first + k)], b = M.tris[3u * (first + k) + 1u], c = M.tris[3u * (first + k) + 2u];
+            const V3 v0{a.x, a.y, a.z}, v1{b.x, b.y, b.z}, v2{c.x, c.y, c.z};
+            if (ANY) {
+                if (tri_shadow(o, d, tmin, tmax, v0, v1, v2)) return true;
+            } else {
+                float t;
+                if (tri_watertight(o, d, tmin, tmax, v0, v1, v2, t)) {
+                    const uint32_t tri = f_bits(a.w);
+                    if (t < t_best || (t == t_best && tri < best_tri)) {
+                        t_best = t;
+                        best_tri = tri;
+                        best_slot = first + k;
+                        any = true;
+                    }
+                }
+            }
+        }
+        node = f_bits(lo.w);
+    }
+    if (!ANY && any) {
+        const float4 a = M.tris[3u * best_slot], b = M.tris[3u * best_slot + 1u], c = M.tris[3u * best_slot + 2u];
+        const V3 v0{a.x, a.y, a.z};
+        n_best = normalize(cross(V3{b.x, b.y, b.z} - v0, V3{c.x, c.y, c.z} - v0));
+    }
+    return any;
+}
+
+struct SurfaceHitWf {
+    V3 p, n;
+    float t;
+    uint32_t mat;
+};
+
+// pt_intersect.wgsl main, :431-558
+F3D_HD bool closest(const SceneDev &S, V3 o, V3 d, float tmin, SurfaceHitWf &H) {
+    const float tmax = 1e30f;
+    float t_best = 1e30f;
+    V3 n = V3{0.0f, 1.0f, 0.0f};
+    uint32_t mat = 0u;
+    for (uint32_t i = 0u; i < S.sphere_count; i++) {
+        const SphereDev s = S.spheres[i];
+        const V3 oc = o - s.c;
+        const float b = dot(oc, d);
+        const float cterm = dot(oc, oc) - s.r * s.r;
+        const float disc = b * b - cterm;
+        float t = 1e30f;
+        if (disc > 0.0f) {
+            const float q = f_sqrt(disc);
+            const float t0 = -b - q, t1 = -b + q;
+            t = t0 > 1e-3f ? t0 : (t1 > 1e-3f ? t1 : 1e30f);
+        }
+        if (t >= tmin && t < f_min(t_best, tmax)) {
+            t_best = t;
+            const V3 hp = o + d * t;
+            n = normalize(hp - s.c);
+            mat = i;
+        }
+    }
+    if (S.inst_count == 0u) {
+        float t;
+        V3 nn;
+        if (S.blas_count > 0u && walk_blas<false>(S.blas[0], o, d, tmin, tmax, t, nn) && t < t_best) {
+            t_best = t;
+            n = nn;
+            mat = 0u;
+        }
+    } else {
+        for (uint32_t ii = 0u; ii < S.inst_count; ii++) {
+            const InstanceDev &I = S.inst[ii];
+            const V3 oo = xf_point(I.w2o, o);
+            const V3 dd = normalize(xf_vector(I.w2o, d));
+            float t;
+            V3 nn;
+            if (walk_blas<false>(S.blas[I.blas], oo, dd, tmin, tmax, t, nn) && t < t_best) {
+                t_best = t;
+                n = xf_normal(I.w2o, nn);
+                mat = I.material;
+            }
+        }
+    }
+    if (!(t_best < 1e20f)) return false;
+    H.p = o + d * t_best;
+    H.t = t_best;
+    H.n = n;
+    H.mat = mat;
+    return true;
+}
+
+// pt_shadow.wgsl main, :248-294
+F3D_HD bool shadowed(const SceneDev &S, V3 ro, V3 rd, float tmin, float tmax) {
+    for (uint32_t i = 0u; i < S.sphere_count; i++) {
+        const SphereDev s = S.spheres[i];
+        const V3 oc = ro - s.c;
+        const float b = dot(oc, rd);
+        const float cterm = dot(oc, oc) - s.r * s.r;
+        const float disc = b * b - cterm;
+        if (disc <= 0.0f) continue;
+        const float q = f_sqrt(disc);
+        const float t0 = -b - q, t1 = -b + q;
+        if ((t0 > tmin && t0 < tmax) || (t1 > tmin && t1 < tmax)) return true;
+    }
+    float t;
+    V3 nn;
+    if (S.inst_count == 0u) return S.blas_count > 0u && walk_blas<true>(S.blas[0], ro, rd, tmin, tmax, t, nn);
+    for (uint32_t ii = 0u; ii < S.inst_count; ii++) {
+        const InstanceDev &I = S.inst[ii];
+        if (walk_blas<true>(S.blas[I.blas], xf_point(I.w2o, ro), normalize(xf_vector(I.w2o, rd)), tmin, tmax, t, nn)) return true;
+    }
+    return false;
+}
+
+// ---- BSDF and samplers, pt_shade.wgsl:43-455 ------------------------------------------------------------------------
+struct Frame3 {
+    V3 t, b, n;
+};
+F3D_HD Frame3 tangent_frame(V3 n) {  // make_tangent_basis, :351-360
+    const float sign = n.z < 0.0f ? -1.0f : 1.0f;
+    const float a = -1.0f / (sign + n.z);
+    const float b = (n.x * n.y) * a;
+    return Frame3{V3{1.0f + ((sign * n.x) * n.x) * a, sign * b, -sign * n.x}, V3{b, sign + (n.y * n.y) * a, -n.y}, n};
+}
+F3D_HD V3 to_world(const Frame3 &m, V3 v) {
+    return V3{(m.t.x * v.x + m.b.x * v.y) + m.n.x * v.z, (m.t.y * v.x + m.b.y * v.y) + m.n.y * v.z,
+              (m.t.z * v.x + m.b.z * v.y) + m.n.z * v.z};
+}
+F3D_HD V3 cosine_hemisphere(float u1, float u2) {
+    const float r = f_sqrt(u1);
+    float s, c;
+    sincos_turn(u2, s, c);
+    return V3{r * c, r * s, f_sqrt(f_max(0.0f, 1.0f - u1))};
+}
+F3D_HD V3 schlick(float cos_theta, V3 F0) {
+    const float w = pow5(1.0f - f_saturate(cos_theta));
+    return V3{F0.x + (1.0f - F0.x) * w, F0.y + (1.0f - F0.y) * w, F0.z + (1.0f - F0.z) * w};
+}
+F3D_HD float ggx_d(float n_dot_h, float alpha) {
+    const float a2 = alpha * alpha, ndh2 = n_dot_h * n_dot_h;
+    const float q = ndh2 * (a2 - 1.0f) + 1.0f;
+    return a2 / f_max(kPi * (q * q), 1e-6f);
+}
+F3D_HD float smith_g1(float n_dot_v, float alpha) {
+    const float a1 = alpha + 1.0f;
+    const float k = (a1 * a1) / 8.0f;
+    return n_dot_v / (n_dot_v * (1.0f - k) + k);
+}
+F3D_HD float ggx_d_aniso(V3 h, V3 t, V3 b, V3 n, float ax, float ay) {
+    const float hx = dot(h, t), hy = dot(h, b), hz = f_max(dot(h, n), 0.0f);
+    const float x2 = (hx * hx) / (ax * ax + 1e-8f), y2 = (hy * hy) / (ay * ay + 1e-8f);
+    const float denom = (x2 + y2) + hz * hz;
+    return 1.0f / f_max((((kPi * ax) * ay) * denom) * denom, 1e-6f);
+}
+F3D_HD float smith_g1_aniso(V3 v, V3 t, V3 b, V3 n, float ax, float ay) {
+    const float vx = dot(v, t), vy = dot(v, b), vz = f_max(dot(v, n), 0.0f);
+    const float alpha_v = f_sqrt((vx * vx) * (ax * ax) + (vy * vy) * (ay * ay)) / f_max(vz, 1e-6f);
+    return 2.0f / (1.0f + f_sqrt(1.0f + alpha_v * alpha_v));
+}
+
+struct MatCtx {  // a hit's material, unpacked once
+    V3 albedo, F0;
+    float metallic, roughness, ax, ay, imp;
+    bool aniso;
+};
+struct Bsdf {
+    V3 f;
+    float pdf;
+};
+// bsdf_eval_pdf, :43-100 (the anisotropic branch reads the frame as ROWS of the basis matrix, like the reference)
+F3D_HD Bsdf bsdf_eval(const MatCtx &M, V3 wo, V3 wi, V3 n) {
+    const float n_dot_l = f_max(dot(n, wi), 0.0f), n_dot_v = f_max(dot(n, wo), 0.0f);
+    if (n_dot_l <= 0.0f || n_dot_v <= 0.0f) return Bsdf{V3{0.0f, 0.0f, 0.0f}, 0.0f};
+    const float kd = f_saturate(1.0f - M.metallic);
+    const V3 fd = V3{M.albedo.x / kPi, M.albedo.y / kPi, M.albedo.z / kPi} * kd;
+    const float pdf_d = n_dot_l / kPi;
+    const float m = f_max(0.02f, M.roughness * M.roughness);
+    const V3 h = normalize(wi + wo);
+    const float n_dot_h = f_max(dot(n, h), 0.0f), v_dot_h = f_max(dot(wo, h), 0.0f);
+    float D, G;
+    if (!M.aniso) {
+        D = ggx_d(n_dot_h, m);
+        G = smith_g1(n_dot_l, m) * smith_g1(n_dot_v, m);
+    } else {
+        const Frame3 bs = tangent_frame(n);
+        const V3 t{bs.t.x, bs.b.x, bs.n.x}, bb{bs.t.y, bs.b.y, bs.n.y}, nn{bs.t.z, bs.b.z, bs.n.z};
+        D = ggx_d_aniso(h, t, bb, nn, M.ax, M.ay);
+        G = smith_g1_aniso(wi, t, bb, nn, M.ax, M.ay) * smith_g1_aniso(wo, t, bb, nn, M.ax, M.ay);
+    }
+    const V3 F = schlick(v_dot_h, M.F0);
+    const float spec = (D * G) / f_max((4.0f * n_dot_l) * n_dot_v, 1e-6f);
+    const float pdf_s = (D * n_dot_h) / f_max(4.0f * v_dot_h, 1e-6f);
+    const float ks = 1.0f - kd;
+    return Bsdf{fd + F * spec, f_max(kd * pdf_d + ks * pdf_s, 1e-8f)};
+}
+F3D_HD float up_lobe_pdf(V3 w) {  // power_cosine_pdf_about_up, m = 16, :165-169
+    const float c = f_max(dot(V3{0.0f, 1.0f, 0.0f}, normalize(w)), 0.0f);
+    return ((16.0f + 1.0f) * pow16(c)) / (2.0f * kPi);
+}
+
+// importance-weighted pick (:622-633, :667-678); `imp(i)` = max(importance_i, 0)
+template <class Imp>
+F3D_HD uint32_t pick(uint32_t count, float sum_imp, uint32_t &rng, Imp imp) {
+    uint32_t idx = 0u;
+    if (sum_imp > 0.0f) {
+        const float rsel = rng_next(rng) * sum_imp;
+        float acc = 0.0f;
+        for (uint32_t i = 0u; i < count; i++) {
+            acc = acc + imp(i);
+            if (rsel <= acc) {
+                idx = i;
+                break;
+            }
+        }
+    } else {
+        idx = sat_u32(f_floor(rng_next(rng) * (float)count));
+    }
+    return idx < count - 1u ? idx : count - 1u;
+}
+
+// One surface vertex: emission, NEE (environment / directional / area) with its shadow rays, continuation sample,
+// roulette (pt_shade.wgsl main :460-862 + pt_shadow.wgsl main).  Returns true when the path continues in P.
+F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, uint32_t seed_lo, const SurfaceHitWf &H, PathState &P,
+                           V3 &acc) {
+    (void)seed_lo;
+    const MaterialDev md = S.mats[H.mat];
+    MatCtx M;
+    M.albedo = md.albedo;
+    M.metallic = md.metallic;
+    M.roughness = md.roughness;
+    M.ax = f_max(0.002f, md.ax);
+    M.ay = f_max(0.002f, md.ay);
+    M.aniso = !(f_abs(M.ax - M.ay) < 1e-4f);
+    M.imp = md.importance;
+    const float sm = f_saturate(md.metallic);
+    M.F0 = V3{mix(0.04f, md.albedo.x, sm), mix(0.04f, md.albedo.y, sm), mix(0.04f, md.albedo.z, sm)};
+    if (md.emissive.x > 0.0f || md.emissive.y > 0.0f || md.emissive.z > 0.0f) acc = acc + P.thr * md.emissive;
+
+    uint32_t rng = P.rng_hi ^ (pixel * 26699u) ^ (frame * 30977u);
+    const V3 n = normalize(H.n), wo = normalize(normalize(neg(P.d)));
+    const float n_dot_v = f_max(dot(n, wo), 0.0f);
+    const Frame3 basis = tangent_frame(n);
+    const V3 so = H.p + n * 1e-3f;
+
+    {  // environment, mixture of a power-cosine lobe about +Y and the cosine hemisphere, balance heuristic
+        const float u1 = rng_next(rng), u2 = rng_next(rng), u3 = rng_next(rng);
+        V3 wi;
+        if (u1 < 0.5f) {
+            float s, c;
+            sincos_turn(u3, s, c);
+            const float ct = pow_det(1.0f - u2, 1.0f / (16.0f + 1.0f));
+            const float st = f_sqrt(f_max(0.0f, 1.0f - ct * ct));
+            wi = V3{st * c, ct, st * s};
+        } else {
+            wi = to_world(basis, cosine_hemisphere(u2, u3));
+        }
+        const float pdf_up = up_lobe_pdf(wi);
+        const float cos_surf = f_max(dot(n, wi), 0.0f);
+        const float pdf_light = 0.5f * pdf_up + (1.0f - 0.5f) * (cos_surf / kPi);
+        if (cos_surf > 0.0f) {
+            const V3 L_env = mix3(S.env_ground, S.env_sky, 0.5f * (wi.y + 1.0f));
+            const Bsdf br = bsdf_eval(M, wo, wi, n);
+            const float w_mis = pdf_light / f_max(pdf_light + br.pdf, 1e-8f);
+            const float k = (((cos_surf / f_max(pdf_light, 1e-8f)) * w_mis) * M.imp) * 1.0f;
+            const V3 contrib = ((P.thr * br.f) * L_env) * k;
+            if (!shadowed(S, so, wi, 1e-3f, 1e30f)) acc = acc + contrib;
+        }
+    }
+    if (S.dir_count > 0u) {  // delta lights: weight 1
+        const uint32_t idx = pick(S.dir_count, S.dir_sum_imp, rng, [&](uint32_t i) { return S.dir[i].importance; });
+        const DirLightDev L = S.dir[idx];
+        const float cos_surf = f_max(dot(n, L.wi), 0.0f);
+        if (cos_surf > 0.0f) {
+            const Bsdf br = bsdf_eval(M, wo, L.wi, n);
+            const float p_sel = S.dir_sum_imp > 0.0f ? L.importance / f_max(S.dir_sum_imp, 1e-8f) : 1.0f / (float)S.dir_count;
+            const float k = ((cos_surf / f_max(p_sel, 1e-8f)) * M.imp) * 1.0f;
+            const V3 contrib = ((P.thr * br.f) * L.Li) * k;
+            if (!shadowed(S, so, L.wi, 1e-3f, 1e30f)) acc = acc + contrib;
+        }
+    }
+    if (S.area_count > 0u) {  // discs, sampled uniformly by area, balance heuristic
+        const uint32_t idx = pick(S.area_count, S.area_sum_imp, rng, [&](uint32_t i) { return S.area[i].importance; });
+        const AreaLightDev L = S.area[idx];
+        const float u1 = rng_next(rng), u2 = rng_next(rng);
+        const float r = f_sqrt(u1) * L.rad;
+        float s, c;
+        sincos_turn(u2, s, c);
+        const V3 X = (L.position + L.tL * (r * c)) + L.bL * (r * s);
+        const V3 dir = X - H.p;
+        const float dist = f_sqrt(dot(dir, dir));
+        if (dist > 1e-6f) {
+            const V3 wi{dir.x / dist, dir.y / dist, dir.z / dist};
+            const float cos_surf = f_max(dot(n, wi), 0.0f), cos_on_light = f_max(dot(L.nL, neg(wi)), 0.0f);
+            if (cos_surf > 0.0f && cos_on_light > 0.0f) {
+                const float pdf = (L.p_area * (dist * dist)) / f_max(cos_on_light, 1e-6f);
+                if (pdf > 0.0f) {
+                    const Bsdf br = bsdf_eval(M, wo, wi, n);
+                    const float p_sel = S.area_sum_imp > 0.0f ? L.importance / f_max(S.area_sum_imp, 1e-8f) : 1.0f / (float)S.area_count;
+                    const float pdf_light = p_sel * pdf;
+                    const float w_mis = pdf_light / f_max(pdf_light + br.pdf, 1e-8f);
+                    const float k = (((cos_surf / f_max(pdf_light, 1e-8f)) * w_mis) * M.imp) * 1.0f;
+                    const V3 contrib = ((P.thr * br.f) * L.Li) * k;
+                    if (!shadowed(S, so, wi, 1e-3f, dist - 1e-3f)) acc = acc + contrib;
+                }
+            }
+        }
+    }
+
+    V3 wi, thr;
+    if (md.metallic > 0.5f) {  // GGX half-vector sampling
+        const float u1 = rng_next(rng), u2 = rng_next(rng);
+        const float a = f_max(0.02f, md.roughness * md.roughness);
+        const V3 t{basis.t.x, basis.b.x, basis.n.x}, bb{basis.t.y, basis.b.y, basis.n.y}, nn{basis.t.z, basis.b.z, basis.n.z};
+        V3 hw;
+        if (!M.aniso) {
+            const float a2 = a * a;
+            const float ct = f_sqrt((1.0f - u1) / (1.0f + (a2 - 1.0f) * u1));
+            const float st = f_sqrt(f_max(0.0f, 1.0f - ct * ct));
+            float s, c;
+            sincos_turn(u2, s, c);
+            hw = normalize(to_world(basis, V3{st * c, st * s, ct}));
+        } else {
+            float s2, c2;
+            sincos_turn(u2, s2, c2);
+            float phi = atan_det((M.ay / f_max(M.ax, 1e-6f)) * (s2 / c2));
+            if (u2 > 0.5f) phi = phi + kPi;
+            float sp, cp;
+            sincos_rad(phi, sp, cp);
+            const float denom = (cp * cp) / f_max(M.ax * M.ax, 1e-8f) + (sp * sp) / f_max(M.ay * M.ay, 1e-8f);
+            const float ratio = u1 / f_max(1.0f - u1, 1e-6f);
+            const float ct = 1.0f / f_sqrt(1.0f + ratio * denom);
+            const float st = f_sqrt(f_max(0.0f, 1.0f - ct * ct));
+            hw = normalize((t * (st * cp) + bb * (st * sp)) + nn * ct);
+        }
+        wi = normalize(reflect3(neg(wo), hw));
+        const float n_dot_l = f_max(dot(n, wi), 0.0f), n_dot_h = f_max(dot(n, hw), 0.0f), v_dot_h = f_max(dot(wo, hw), 0.0f);
+        if (!(n_dot_l > 0.0f && n_dot_v > 0.0f)) return false;
+        const float D = M.aniso ? ggx_d_aniso(hw, t, bb, nn, M.ax, M.ay) : ggx_d(n_dot_h, a);
+        const float G = M.aniso ? smith_g1_aniso(wi, t, bb, nn, M.ax, M.ay) * smith_g1_aniso(wo, t, bb, nn, M.ax, M.ay)
+                                : smith_g1(n_dot_l, a) * smith_g1(n_dot_v, a);
+        const V3 spec = schlick(v_dot_h, M.F0) * ((D * G) / f_max((4.0f * n_dot_l) * n_dot_v, 1e-6f));
+        const float pdf = (D * n_dot_h) / f_max(4.0f * v_dot_h, 1e-6f);
+        thr = (P.thr * spec) * (n_dot_l / f_max(pdf, 1e-6f));
+    } else if (md.ior > 1.01f) {  // smooth dielectric, Schlick-weighted reflect / refract
+        const float cosi = f_saturate(dot(n, wo));
+        const float r0 = (md.ior - 1.0f) / (md.ior + 1.0f);
+        const float F0s = r0 * r0;
+        const float F = F0s + (1.0f - F0s) * pow5(1.0f - cosi);
+        if (rng_next(rng) < F) {
+            wi = normalize(reflect3(neg(wo), n));
+        } else {
+            const bool entering = dot(n, wo) > 0.0f;
+            const float eta = entering ? 1.0f / md.ior : md.ior / 1.0f;
+            const V3 N = entering ? n : neg(n), I = neg(wo);
+            const float ni = dot(N, I);
+            const float kk = 1.0f - (eta * eta) * (1.0f - ni * ni);
+            wi = kk < 0.0f ? normalize(reflect3(neg(wo), n)) : normalize(I * eta - N * (eta * ni + f_sqrt(kk)));
+        }
+        thr = P.thr * V3{f_max(md.albedo.x, 0.0f), f_max(md.albedo.y, 0.0f), f_max(md.albedo.z, 0.0f)};
+    } else {  // Lambert
+        const float u1 = rng_next(rng), u2 = rng_next(rng);
+        wi = normalize(to_world(basis, cosine_hemisphere(u1, u2)));
+        const float cos_theta = f_max(0.0f, dot(n, wi));
+        const float pdf = cos_theta / kPi + 1e-8f;
+        thr = (P.thr * V3{md.albedo.x / kPi, md.albedo.y / kPi, md.albedo.z / kPi}) * (cos_theta / pdf);
+    }
+    float rr = 1.0f;
+    if (P.depth >= 4u) {
+        const float q = f_clamp(1.0f - f_max(thr.x, f_max(thr.y, thr.z)), 0.0f, 0.95f);
+        if (rng_next(rng) < q) return false;
+        rr = 1.0f / (1.0f - q);
+    }
+    if (!((P.depth + 1u) < 16u)) return false;
+    P.o = H.p + normalize(H.n) * 1e-3f;
+    P.tmin = 1e-3f;
+    P.d = wi;
+    P.thr = thr * rr;
+    P.depth = P.depth + 1u;
+    P.rng_hi = rng;
+    return true;
+}
+
+// A pixel's frames [first, first + count): returns the number of path vertices (closest-hit queries) it traced.
+F3D_HD uint32_t trace_pixel(const SceneDev &S, uint32_t pixel, uint32_t first, uint32_t count, V3 &acc) {
+    uint32_t frame = first, vertices = 0u, seed_lo = 0u;
+    const uint32_t end = first + count;
+    bool fresh = true;
+    PathState P;
+    P.o = P.d = P.thr = V3{0.0f, 0.0f, 0.0f};
+    P.tmin = 0.0f;
+    P.depth = P.rng_hi = 0u;
+    while (frame < end) {
+        if (fresh) {
+            const uint32_t seed_hi = splitmix32(S.seed_hi ^ frame);
+            seed_lo = splitmix32(S.seed_lo ^ (frame * 0x00009E3Du));
+            camera_ray(S, pixel, frame, seed_hi, seed_lo, P);
+            fresh = false;
+        }
+        vertices++;
+        SurfaceHitWf H;
+        if (!closest(S, P.o, P.d, P.tmin, H)) {  // pt_scatter.wgsl:113-131
+            acc = acc + P.thr * mix3(S.miss_ground, S.miss_sky, 0.5f * (P.d.y + 1.0f));
+            fresh = true;
+        } else if (!surface_vertex(S, pixel, frame, seed_lo, H, P, acc)) {
+            fresh = true;
+        }
+        if (fresh) frame++;
+    }
+    return vertices;
+}
+
+}  // namespace wf
+}  // namespace f3d

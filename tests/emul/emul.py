@@ -243,3 +243,24 @@ class EmulBackend:
 
     def sync(self):
         pass
+
+
+def wavefront_render(scene, width, height, frames, first_frame=0, accum=None):
+    """The multi-bounce PBR tracer's device path code (csrc/f3d_wf_path.h) compiled for the host:
+    adds `frames` frames to `accum` and returns dict(accum, path_vertices)."""
+    from forge3d_amd import wavefront as wfm
+
+    if not isinstance(scene, dict):
+        scene = scene.as_dict()
+    s, keep = wfm._marshal(scene)
+    acc = np.zeros((height, width, 4), np.float32) if accum is None else np.ascontiguousarray(accum, np.float32).copy()
+    vertices = C.c_uint64(0)
+    err = C.create_string_buffer(512)
+    L = lib()
+    L.emul_wavefront_render.restype = C.c_int
+    rc = L.emul_wavefront_render(C.byref(s), C.c_uint32(width), C.c_uint32(height), C.c_uint32(first_frame), C.c_uint32(frames),
+                                 acc.ctypes.data_as(C.c_void_p), C.byref(vertices), err, C.c_size_t(len(err)))
+    del keep
+    if rc != 0:
+        _native.raise_status(rc, err.value.decode(errors="replace"))
+    return {"accum": acc, "path_vertices": int(vertices.value)}

@@ -15,6 +15,7 @@
 
 #include "../../forge3d_amd/csrc/f3d_setup.h"
 #include "../../forge3d_amd/csrc/f3d_shade.h"
+#include "../../forge3d_amd/csrc/f3d_wf_host.h"
 
 using namespace f3d;
 
@@ -770,6 +771,41 @@ uint64_t emul_take_retraces() {
     const uint64_t r = g_retraces;
     g_retraces = 0;
     return r;
+}
+
+// The multi-bounce PBR tracer's per-pixel path code (f3d_wf_path.h) on the host: same validation and scene
+// preparation as f3d_wavefront_render, the prepared arrays read in place, one OpenMP iteration per pixel.
+int emul_wavefront_render(const f3d_wf_scene *scene, uint32_t width, uint32_t height, uint32_t first_frame, uint32_t frame_count,
+                          float *accum, uint64_t *vertices_out, char *err, size_t errlen) {
+    try {
+        wf::validate_scene(*scene, width, height, frame_count);
+        wf::PreparedScene prep = wf::prepare_scene(*scene, width, height);
+        std::vector<wf::BlasDev> blas(prep.bvh.size());
+        for (size_t m = 0; m < prep.bvh.size(); m++)
+            blas[m] = wf::BlasDev{prep.bvh[m].nodes.data(), reinterpret_cast<const float4 *>(prep.bvh[m].tris.data()),
+                                  (uint32_t)prep.bvh[m].nodes.size(), 0u};
+        wf::SceneDev S = prep.S;
+        S.spheres = prep.spheres.data();
+        S.mats = prep.mats.data();
+        S.blas = blas.data();
+        S.inst = prep.inst.data();
+        S.dir = prep.dir.data();
+        S.area = prep.area.data();
+        const int64_t pixels = (int64_t)width * height;
+        uint64_t vertices = 0;
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : vertices)
+        for (int64_t p = 0; p < pixels; p++) {
+            V3 acc{accum[4 * p], accum[4 * p + 1], accum[4 * p + 2]};
+            vertices += wf::trace_pixel(S, (uint32_t)p, first_frame, frame_count, acc);
+            accum[4 * p] = acc.x;
+            accum[4 * p + 1] = acc.y;
+            accum[4 * p + 2] = acc.z;
+        }
+        if (vertices_out) *vertices_out = vertices;
+        return 0;
+    } catch (const Failure &f) {
+        return report(f, err, errlen);
+    }
 }
 
 }  // extern "C"

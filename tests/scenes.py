@@ -270,3 +270,94 @@ def adversarial_scenes():
                 out.append((f"{name}-{cname}-az{az:.0f}", dem, (33, 31),
                             {**cam, "up": (0.0, 1.0, 0.0), "fov_y": 50.0, "exposure": 1.0}, kw))
     return out
+
+
+# ---- scenes for the multi-bounce PBR tracer --------------------------------------------------
+def _rotation_scale(rng, scale_range=(0.6, 1.6)):
+    """Column-major object_to_world / world_to_object pair (float32): rotation about a random axis, non-uniform
+    scale, translation; the inverse is computed in float64 and rounded, like a host that inverts once."""
+    axis = rng.normal(size=3)
+    axis /= np.linalg.norm(axis)
+    ang = rng.uniform(0, 2 * np.pi)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+    S = np.diag(rng.uniform(*scale_range, size=3))
+    M = np.eye(4)
+    M[:3, :3] = R @ S
+    M[:3, 3] = rng.uniform(-1.5, 1.5, size=3) + np.array([0.0, 0.8, 0.0])
+    return (M.T.astype(np.float32).reshape(-1).tolist(), np.linalg.inv(M).T.astype(np.float32).reshape(-1).tolist())
+
+
+def _blob_mesh(rng, n_lat=5, n_lon=7, radius=0.6):
+    """A lumpy closed mesh (latitude/longitude grid), plus one degenerate and one duplicated triangle."""
+    verts = []
+    for i in range(n_lat + 1):
+        th = np.pi * i / n_lat
+        for j in range(n_lon):
+            ph = 2 * np.pi * j / n_lon
+            r = radius * (1.0 + 0.25 * rng.uniform(-1, 1))
+            verts.append([r * np.sin(th) * np.cos(ph), r * np.cos(th), r * np.sin(th) * np.sin(ph)])
+    tris = []
+    for i in range(n_lat):
+        for j in range(n_lon):
+            a, b = i * n_lon + j, i * n_lon + (j + 1) % n_lon
+            c, d = a + n_lon, b + n_lon
+            tris += [[a, c, b], [b, c, d]]
+    tris.append([0, 0, 1])           # zero area
+    tris.append(list(tris[3]))       # coplanar duplicate: equal-t tie
+    return np.asarray(verts, np.float32), np.asarray(tris, np.uint32)
+
+
+def wavefront_random_scene(seed: int):
+    """Spheres with every material class (Lambert, isotropic / anisotropic GGX metal, dielectric, emitter), a ground
+    quad, transformed instances of a lumpy mesh, several directional and disc lights with unequal importances, a
+    graded environment.  Returns (WavefrontScene, width, height, frames)."""
+    from forge3d_amd.wavefront import AreaLight, DirectionalLight, Instance, Sphere, WavefrontScene
+
+    rng = np.random.default_rng(1000 + seed)
+    kinds = ["lambert", "metal", "aniso", "glass", "emitter", "lambert"]
+    spheres = []
+    for k in range(int(rng.integers(3, 7))):
+        kind = kinds[(seed + k) % len(kinds)]
+        s = Sphere(center=tuple(rng.uniform(-2.0, 2.0, 3) * np.array([1.0, 0.3, 1.0]) + np.array([0.0, 0.8, 0.0])),
+                   radius=float(rng.uniform(0.3, 0.9)), albedo=tuple(rng.uniform(0.15, 0.9, 3)),
+                   roughness=float(rng.uniform(0.05, 0.95)))
+        if kind == "metal":
+            s.metallic = 1.0
+        elif kind == "aniso":
+            s.metallic, s.ax, s.ay = 0.9, float(rng.uniform(0.05, 0.4)), float(rng.uniform(0.4, 0.9))
+        elif kind == "glass":
+            s.ior = float(rng.uniform(1.2, 1.9))
+        elif kind == "emitter":
+            s.emissive = tuple(rng.uniform(0.5, 3.0, 3))
+        spheres.append(s)
+    spheres.append(Sphere(center=(0.0, -1000.0, 0.0), radius=0.0, albedo=(0.5, 0.45, 0.4), roughness=0.8))   # ground material
+    e = 12.0
+    ground = (np.array([[-e, 0.0, -e], [-e, 0.0, e], [e, 0.0, e], [e, 0.0, -e]], np.float32), np.array([[0, 1, 2], [0, 2, 3]], np.uint32))
+    meshes, instances = [ground], []
+    with_instances = seed % 4 != 3          # every 4th scene uses the non-instanced path (BLAS 0, material 0)
+    if with_instances:
+        meshes.append(_blob_mesh(rng))
+        instances.append(Instance(blas_index=0, material_id=len(spheres) - 1))
+        for _ in range(int(rng.integers(1, 4))):
+            o2w, w2o = _rotation_scale(rng)
+            instances.append(Instance(blas_index=1, material_id=int(rng.integers(0, len(spheres) + 2)), object_to_world=o2w,
+                                      world_to_object=w2o))
+    dirs = [DirectionalLight(tuple(rng.normal(size=3) * np.array([1.0, 0.2, 1.0]) + np.array([0.0, -1.0, 0.0])),
+                             float(rng.uniform(0.5, 3.0)), tuple(rng.uniform(0.6, 1.0, 3)), float(rng.choice([0.0, 0.5, 1.0, 2.0])))
+            for _ in range(int(rng.integers(0, 4)))]
+    areas = [AreaLight(position=tuple(rng.uniform(-2.0, 2.0, 3) * np.array([1.0, 0.0, 1.0]) + np.array([0.0, rng.uniform(2.5, 4.0), 0.0])),
+                       normal=tuple(rng.normal(size=3) * 0.3 + np.array([0.0, -1.0, 0.0])), radius=float(rng.uniform(0.2, 1.0)),
+                       intensity=float(rng.uniform(2.0, 12.0)), color=tuple(rng.uniform(0.5, 1.0, 3)),
+                       importance=float(rng.choice([0.0, 1.0, 3.0])))
+             for _ in range(int(rng.integers(0, 3)))]
+    scene = WavefrontScene(
+        spheres=spheres, meshes=meshes, instances=instances, dir_lights=dirs, area_lights=areas,
+        object_importance=[float(x) for x in rng.uniform(0.5, 1.5, int(rng.integers(0, len(spheres) + 1)))],
+        env_ground=tuple(rng.uniform(0.05, 0.4, 3)), env_sky=tuple(rng.uniform(0.3, 0.9, 3)),
+        miss_ground=tuple(rng.uniform(0.05, 0.3, 3)), miss_sky=tuple(rng.uniform(0.3, 0.8, 3)),
+        cam_origin=tuple(rng.uniform(-1.0, 1.0, 3) + np.array([0.0, 2.0, 6.0])), cam_look_at=(0.0, 0.7, 0.0),
+        fov_y_deg=float(rng.uniform(30.0, 60.0)), exposure=float(rng.uniform(0.6, 1.4)),
+        seed_hi=int(rng.integers(0, 2**32)), seed_lo=int(rng.integers(0, 2**32)))
+    width, height = [(64, 48), (57, 33), (40, 72), (96, 64)][seed % 4]
+    return scene, width, height, int(rng.integers(3, 9))

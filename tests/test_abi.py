@@ -1,4 +1,4 @@
-"""The C-ABI shared library: loads, exports every symbol include/f3d_terrain_pt.h declares,
+"""The C-ABI shared library: loads, exports every symbol include/*.h declares,
 agrees with the ctypes mirror on struct layout, and fails LOUDLY (status 4, no CPU fallback)
 when asked to compute without a HIP device.  No compute calls are made when a GPU is absent.
 """
@@ -30,7 +30,8 @@ def native():
 
 
 def _declared_functions():
-    text = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
+    text = "\n".join(h.read_text() for h in sorted((ROOT / "include").glob("*.h")))
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(f3d_[a-z0-9_]+)\s*\(", text)))
 
 
