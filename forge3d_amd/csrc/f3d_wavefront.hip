@@ -4,11 +4,14 @@
 //
 // Reference driver: render_pt_reference (src/path_tracing/adjudication.rs:76-364) submits, for each of the spp frames,
 // raygen + up to 16 x {intersect, shade, shadow, scatter} dispatches of ceil(4 W H / 256) workgroups each and maps the
-// queue header back to the host between bounces.  Here: ONE launch per batch of frames, one wave per 8x8-pixel tile,
-// the per-pixel running sum in registers; a 512 x 512 x 4096-frame gate render is a single kernel.
+// queue header back to the host between bounces.  Here a round of (up to thousands of) frames is two launches: a
+// producer that traces every (pixel, frame) path with all the parallelism W x H x frames offers and leaves one
+// 16-byte total per pixel-frame in HBM, and a streaming fold that adds them per pixel in frame order.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <exception>
 #include <vector>
 
@@ -21,27 +24,71 @@ namespace {
 
 struct WfParams {
     wf::SceneDev S;
-    float4 *accum;
-    uint32_t first, count;
+    float4 *totals;  // [frame - first][pixel]: a frame's contributions, summed in stage order (w unused)
+    uint32_t first, count, frames_per_lane;
     unsigned long long *vertices;
 };
 
-// One wave = one 8x8 pixel tile; tiles are dealt to workgroups in row-major order, i.e. round robin over the 8 XCDs,
-// so cheap (sky) and expensive (geometry) image regions spread over all of them.
-__global__ __launch_bounds__(64) void k_wavefront(const WfParams P) {
-    const uint32_t tiles_x = (P.S.width + 7u) / 8u;
-    const uint32_t x = (blockIdx.x % tiles_x) * 8u + (threadIdx.x & 7u), y = (blockIdx.x / tiles_x) * 8u + (threadIdx.x >> 3);
+// Producer.  One wave = one 8x8 pixel tile x one group of `frames_per_lane` consecutive frames; a lane follows its
+// pixel's paths of those frames in the flat loop of f3d_wf_path.h and writes one 16-byte total per frame.  Frame totals
+// do not depend on the pixel's running sum, so there are W x H x frames / frames_per_lane independent lanes -- at the
+// adjudication gate's 512 x 512 one lane per pixel would be 4 096 waves for 1 024 SIMDs, the sky ones done at once.
+// Workgroup index = group * tiles + tile: consecutive workgroups are neighbouring tiles, dealt round robin over the XCDs.
+#ifndef F3D_WF_WAVES
+#define F3D_WF_WAVES 4
+#endif
+__global__ __launch_bounds__(64, F3D_WF_WAVES) void k_wf_paths(const WfParams P) {
+    const uint32_t tiles_x = (P.S.width + 7u) / 8u, tiles = tiles_x * ((P.S.height + 7u) / 8u);
+    const uint32_t tile = blockIdx.x % tiles, group = blockIdx.x / tiles;
+    const uint32_t x = (tile % tiles_x) * 8u + (threadIdx.x & 7u), y = (tile / tiles_x) * 8u + (threadIdx.x >> 3);
+    const uint32_t begin = group * P.frames_per_lane;
     uint32_t vertices = 0u;
-    if (x < P.S.width && y < P.S.height) {
-        const uint32_t pixel = y * P.S.width + x;
-        float4 a = P.accum[pixel];
-        V3 acc{a.x, a.y, a.z};
-        vertices = wf::trace_pixel(P.S, pixel, P.first, P.count, acc);
-        P.accum[pixel] = float4{acc.x, acc.y, acc.z, a.w};
+    if (x < P.S.width && y < P.S.height && begin < P.count) {
+        const uint32_t pixel = y * P.S.width + x, pixels = P.S.width * P.S.height;
+        const uint32_t n = P.count - begin < P.frames_per_lane ? P.count - begin : P.frames_per_lane;
+        float4 *out = P.totals + (size_t)begin * pixels + pixel;
+        const uint32_t first = P.first + begin;
+        vertices = wf::trace_frames(P.S, pixel, first, n, wf::HipWave{}, [&](uint32_t frame, V3 total) {
+            out[(size_t)(frame - first) * pixels] = float4{total.x, total.y, total.z, 0.0f};
+        });
     }
     unsigned long long total = vertices;
     for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
     if (threadIdx.x == 0u && P.vertices) atomicAdd(P.vertices, total);
+}
+
+struct FoldParams {
+    const float4 *totals;
+    float4 *accum;
+    uint32_t pixels, count;
+};
+
+// Consumer: the frame totals of a pixel are added to its running sum in frame order (the one order-sensitive step).
+// Lanes = pixels, loads are coalesced and independent of the adds; reads count x 16 B per pixel at HBM speed.
+__global__ __launch_bounds__(256) void k_wf_fold(const FoldParams F) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= F.pixels) return;
+    float4 a = F.accum[p];
+    const float4 *t = F.totals + p;
+    uint32_t f = 0u;
+    for (; f + 8u <= F.count; f += 8u) {
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = t[(size_t)(f + k) * F.pixels];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            a.x = a.x + v[k].x;
+            a.y = a.y + v[k].y;
+            a.z = a.z + v[k].z;
+        }
+    }
+    for (; f < F.count; f++) {
+        const float4 v = t[(size_t)f * F.pixels];
+        a.x = a.x + v.x;
+        a.y = a.y + v.y;
+        a.z = a.z + v.z;
+    }
+    F.accum[p] = a;
 }
 
 struct ResolveParamsWf {
@@ -142,38 +189,53 @@ extern "C" int f3d_wavefront_render(const f3d_wf_scene *scene, uint32_t width, u
         S.area = (const wf::AreaLightDev *)upload(prep.area.data(), prep.area.size() * sizeof(wf::AreaLightDev), "area lights");
 
         const size_t pixels = (size_t)width * height;
-        P.accum = (float4 *)alloc(pixels * sizeof(float4), "accumulation");
+        float4 *d_accum = (float4 *)alloc(pixels * sizeof(float4), "accumulation");
         if (out->accum)
-            ok(hipMemcpy(P.accum, out->accum, pixels * sizeof(float4), hipMemcpyHostToDevice), "accumulation upload");
+            ok(hipMemcpy(d_accum, out->accum, pixels * sizeof(float4), hipMemcpyHostToDevice), "accumulation upload");
         else
-            ok(hipMemset(P.accum, 0, pixels * sizeof(float4)), "accumulation clear");
+            ok(hipMemset(d_accum, 0, pixels * sizeof(float4)), "accumulation clear");
         P.vertices = (unsigned long long *)alloc(sizeof(unsigned long long), "counter");
         ok(hipMemset(P.vertices, 0, sizeof(unsigned long long)), "counter clear");
 
+        // Rounds: a round traces `round_frames` frames of every pixel into the totals buffer (16 B per pixel-frame, 4 GB
+        // by default -- a sliver of the 288 GB) and folds them; lanes take `frames_per_lane` frames each: few enough
+        // that a round has tens of thousands of waves, many enough that the lanes of a wave end their batches together.
         const uint32_t tiles = ((width + 7u) / 8u) * ((height + 7u) / 8u);
-        const uint32_t chunk = frames_per_launch ? frames_per_launch : 4096u;
+        const uint64_t budget = 4ull << 30;
+        uint32_t round_frames = frames_per_launch ? frames_per_launch : (uint32_t)std::min<uint64_t>(frame_count, std::max<uint64_t>(1, budget / (pixels * sizeof(float4))));
+        round_frames = std::min(round_frames, frame_count);
+        uint32_t fpl = 32u;  // measured at the gate (512 x 512 x 4096): 8 / 16 / 32 / 64 / 128 / 256 -> 150 / 147 / 145 / 148 / 157 / 176 ms
+        while (fpl > 8u && (uint64_t)tiles * ((round_frames + fpl - 1u) / fpl) < 32768ull) fpl >>= 1;
+        if (const char *e = getenv("F3D_WF_FRAMES_PER_LANE")) fpl = (uint32_t)std::max(1, atoi(e));
+        fpl = std::min(fpl, round_frames);
+        P.frames_per_lane = fpl;
+        P.totals = (float4 *)alloc((size_t)round_frames * pixels * sizeof(float4), "frame totals");
         ok(hipEventCreate(&e0), "event");
         ok(hipEventCreate(&e1), "event");
         ok(hipEventRecord(e0, nullptr), "event");
-        for (uint32_t done = 0u; done < frame_count; done += chunk) {
+        for (uint32_t done = 0u; done < frame_count; done += round_frames) {
             P.first = first_frame + done;
-            P.count = frame_count - done < chunk ? frame_count - done : chunk;
-            hipLaunchKernelGGL(k_wavefront, dim3(tiles), dim3(64), 0, nullptr, P);
+            P.count = std::min(round_frames, frame_count - done);
+            const uint32_t groups = (P.count + fpl - 1u) / fpl;
+            hipLaunchKernelGGL(k_wf_paths, dim3(tiles * groups), dim3(64), 0, nullptr, P);
             ok(hipGetLastError(), "path tracing kernel");
+            const FoldParams F{P.totals, d_accum, (uint32_t)pixels, P.count};
+            hipLaunchKernelGGL(k_wf_fold, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, nullptr, F);
+            ok(hipGetLastError(), "fold kernel");
         }
         ok(hipEventRecord(e1, nullptr), "event");
         const uint32_t total_frames = first_frame + frame_count;
         float4 *d_hdr = out->hdr ? (float4 *)alloc(pixels * sizeof(float4), "hdr") : nullptr;
         uchar4 *d_rgba = out->rgba ? (uchar4 *)alloc(pixels * 4, "rgba") : nullptr;
         if (d_hdr || d_rgba) {
-            const ResolveParamsWf R{P.accum, d_hdr, d_rgba, (uint32_t)pixels, total_frames, scene->cam_exposure};
+            const ResolveParamsWf R{d_accum, d_hdr, d_rgba, (uint32_t)pixels, total_frames, scene->cam_exposure};
             hipLaunchKernelGGL(k_wf_resolve, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, nullptr, R);
             ok(hipGetLastError(), "resolve kernel");
         }
         ok(hipDeviceSynchronize(), "path tracing");
         if (d_hdr) ok(hipMemcpy(out->hdr, d_hdr, pixels * sizeof(float4), hipMemcpyDeviceToHost), "hdr readback");
         if (d_rgba) ok(hipMemcpy(out->rgba, d_rgba, pixels * 4, hipMemcpyDeviceToHost), "rgba readback");
-        if (out->accum) ok(hipMemcpy(out->accum, P.accum, pixels * sizeof(float4), hipMemcpyDeviceToHost), "accumulation readback");
+        if (out->accum) ok(hipMemcpy(out->accum, d_accum, pixels * sizeof(float4), hipMemcpyDeviceToHost), "accumulation readback");
         unsigned long long vertices = 0;
         ok(hipMemcpy(&vertices, P.vertices, sizeof(vertices), hipMemcpyDeviceToHost), "counter readback");
         float ms = 0.0f;

@@ -9,9 +9,11 @@
 // FLAT loop whose body is one path vertex: (new camera ray if the previous path ended) -> closest hit -> on a miss
 // add the background and end the path, otherwise next-event estimation with its shadow rays traced on the spot,
 // continuation sample, roulette.  A lane whose path ends starts its next frame's path in the very next iteration, so
-// lanes of a wave never wait for the longest path of a frame; the running sum of the pixel stays in registers for
-// the whole batch, and nothing but the final sums ever reaches HBM.  Contributions are added in the order the
-// reference's stages add them, so the result is the sequential sum oracle/wavefront_oracle.c computes, bit for bit.
+// lanes of a wave never wait for the longest path of a frame.  A frame's contributions are summed from zero in the
+// order the reference's stages add them and the frame totals are folded into the pixel in frame order -- the order
+// oracle/wavefront_oracle.c fixes (the reference's own order is a race) -- so results are the oracle's bit for bit,
+// and because a frame total does not depend on the running sum, frames of one pixel can be traced by different lanes
+// (f3d_wavefront.hip) and folded afterwards.
 // Instanced meshes are walked through the threaded BVH of f3d_bvh.h (one 32-byte record per visited node, no stack)
 // with the reference's two triangle tests: watertight for closest hits (pt_intersect.wgsl:113-178), Moller-Trumbore
 // for shadow rays (pt_shadow.wgsl:205-236); equal-t hits resolve to the lowest triangle index (the oracle's sweep).
@@ -659,31 +661,80 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
     return true;
 }
 
-// A pixel's frames [first, first + count): returns the number of path vertices (closest-hit queries) it traced.
-F3D_HD uint32_t trace_pixel(const SceneDev &S, uint32_t pixel, uint32_t first, uint32_t count, V3 &acc) {
+// How many lanes of the wave could use another closest-hit attempt (the host "wave" is one lane wide).
+struct SoloWave {
+    F3D_HD uint32_t count(bool flag) const { return flag ? 64u : 0u; }
+};
+#if defined(__HIPCC__)
+struct HipWave {
+    __device__ uint32_t count(bool flag) const { return (uint32_t)__popcll(__ballot(flag)); }
+};
+#endif
+
+// A pixel's frames [first, first + count): `sink(frame, total)` receives every frame's contributions, summed from zero
+// in stage order; returns the number of path vertices (closest-hit queries) traced.
+//
+// The loop is FLAT: its body is one path vertex, and a lane whose path ended starts its next frame's camera ray in the
+// same pass, so the lanes of a wave never wait for the longest path of a frame.  It is also TWO-PHASE: about half of
+// all closest-hit queries are misses (every path ends with one), and a miss costs a sixth of a surface vertex; so the
+// cheap phase (camera ray, closest hit, background) is repeated for the lanes without a pending surface hit for as
+// long as at least `kRefill` of them can still use it, and only then do the lanes with a hit run the expensive phase
+// together.  Measured at the adjudication gate: 146 ms without refills, 131 ms with kRefill 6...20, 141 ms at 48.  Each lane's own
+// sequence of operations -- and therefore every result -- is the same for any wave width or refill threshold.
+#ifndef F3D_WF_REFILL
+#define F3D_WF_REFILL 20
+#endif
+constexpr uint32_t kRefill = F3D_WF_REFILL;
+
+template <class Wave, class Sink>
+F3D_HD uint32_t trace_frames(const SceneDev &S, uint32_t pixel, uint32_t first, uint32_t count, Wave wave, Sink &&sink) {
     uint32_t frame = first, vertices = 0u, seed_lo = 0u;
     const uint32_t end = first + count;
-    bool fresh = true;
+    bool fresh = true, pending = false;
     PathState P;
     P.o = P.d = P.thr = V3{0.0f, 0.0f, 0.0f};
     P.tmin = 0.0f;
     P.depth = P.rng_hi = 0u;
-    while (frame < end) {
-        if (fresh) {
-            const uint32_t seed_hi = splitmix32(S.seed_hi ^ frame);
-            seed_lo = splitmix32(S.seed_lo ^ (frame * 0x00009E3Du));
-            camera_ray(S, pixel, frame, seed_hi, seed_lo, P);
-            fresh = false;
+    V3 total{0.0f, 0.0f, 0.0f};
+    SurfaceHitWf H;
+    H.p = H.n = V3{0.0f, 0.0f, 0.0f};
+    H.t = 0.0f;
+    H.mat = 0u;
+    for (;;) {
+        for (;;) {  // cheap phase
+            if (!pending && frame < end) {
+                if (fresh) {
+                    const uint32_t seed_hi = splitmix32(S.seed_hi ^ frame);
+                    seed_lo = splitmix32(S.seed_lo ^ (frame * 0x00009E3Du));
+                    camera_ray(S, pixel, frame, seed_hi, seed_lo, P);
+                    fresh = false;
+                }
+                vertices++;
+                if (closest(S, P.o, P.d, P.tmin, H)) {
+                    pending = true;
+                } else {  // pt_scatter.wgsl:113-131
+                    total = total + P.thr * mix3(S.miss_ground, S.miss_sky, 0.5f * (P.d.y + 1.0f));
+                    sink(frame, total);
+                    total = V3{0.0f, 0.0f, 0.0f};
+                    frame++;
+                    fresh = true;
+                }
+            }
+            if (wave.count(!pending && frame < end) < kRefill) break;
         }
-        vertices++;
-        SurfaceHitWf H;
-        if (!closest(S, P.o, P.d, P.tmin, H)) {  // pt_scatter.wgsl:113-131
-            acc = acc + P.thr * mix3(S.miss_ground, S.miss_sky, 0.5f * (P.d.y + 1.0f));
-            fresh = true;
-        } else if (!surface_vertex(S, pixel, frame, seed_lo, H, P, acc)) {
-            fresh = true;
+        if (wave.count(pending) == 0u) {
+            if (wave.count(frame < end) == 0u) break;
+            continue;
         }
-        if (fresh) frame++;
+        if (pending) {  // expensive phase
+            pending = false;
+            if (!surface_vertex(S, pixel, frame, seed_lo, H, P, total)) {
+                sink(frame, total);
+                total = V3{0.0f, 0.0f, 0.0f};
+                frame++;
+                fresh = true;
+            }
+        }
     }
     return vertices;
 }

@@ -72,13 +72,15 @@ typedef struct f3d_wf_out {
     uint8_t *rgba; /* optional, height x width x 4: Reinhard(hdr * exposure) -> sRGB -> u8, alpha 255 */
     float *accum;  /* optional IN/OUT, height x width x 4: running per-pixel sums (NULL or zeros before frame 0); lets a caller
                       continue a render: pass the sums of frames [0, first_frame) and get those of [0, first + count) */
-    double loop_seconds;    /* device time of the path-tracing launches */
+    double loop_seconds;    /* device time of the path-tracing + fold launches */
     uint64_t paths;         /* camera paths traced (= width * height * frame_count) */
     uint64_t path_vertices; /* closest-hit queries traced (path segments) */
 } f3d_wf_out;
 
 /* Accumulate frames [first_frame, first_frame + frame_count), one sample per pixel per frame.
- * frames_per_launch = 0 picks a launch size automatically; device < 0 keeps the current device. */
+ * frames_per_launch = frames traced per round (a round = one path-tracing launch over all pixels x those frames + one
+ * fold launch; 16 bytes of device memory per pixel-frame of a round); 0 sizes rounds to a 4 GiB buffer.  The result does
+ * not depend on it.  device < 0 keeps the current device. */
 int f3d_wavefront_render(const f3d_wf_scene *scene, uint32_t width, uint32_t height, uint32_t first_frame,
                          uint32_t frame_count, uint32_t frames_per_launch, int32_t device, f3d_wf_out *out, char *err,
                          size_t errlen);

@@ -15,13 +15,16 @@
  *
  * What is restated and what is not.  The reference moves rays through queues with atomics; a pixel's rays never
  * interact with another pixel's, so the queues are a schedule, not part of the result: here every pixel's path is
- * followed from the camera to its end, and its contributions are added to the pixel in the order the stages would
- * add them (emission, environment, directional, area; the miss of the next ray last).  The reference's
- * `accum[p] = accum[p] + c` from several queue items of one pixel in one dispatch is a data race there;
- * the sum is what it means and what is computed here.  ReSTIR guiding, the fog medium and hair segments are
- * switched off / empty in render_pt_reference and are not restated.  Mesh hits: the reference walks a BVH and keeps
- * the first of equal-t hits in ITS visit order; here all triangles of the BLAS are swept in index order (lowest
- * index wins a tie), and the BVH's box test is treated as conservative.
+ * followed from the camera to its end.  Order of the sums: the reference executes `accum[p] = accum[p] + c` once per
+ * contribution, from several queue items of one pixel in one dispatch -- a data race there whose order
+ * (and, when updates collide, outcome) is not defined; the sum is what it means.  This oracle fixes ONE order: the
+ * contributions of a frame's path are summed, starting from zero, in the order the stages would add them (emission,
+ * environment, directional, area at every vertex; the miss of the last ray last), and the frame totals are added to
+ * the pixel in frame order.  Frame totals do not depend on the running sum, which is what lets the device compute
+ * them in any order and fold them afterwards.  ReSTIR guiding, the fog medium and hair segments are switched off /
+ * empty in render_pt_reference and are not restated.  Mesh hits: the reference walks a BVH and keeps the first of
+ * equal-t hits in ITS visit order; here all triangles of the BLAS are swept in index order (lowest index wins a
+ * tie), and the BVH's box test is treated as conservative.
  *
  * Numerics contract (WGSL leaves these to the driver; this file and the HIP kernel fix the same choices):
  * IEEE f32, no contraction (-ffp-contract=off), dot() is the fma chain z,y,x of f3d_math.h, everything else is
@@ -763,19 +766,21 @@ int wfo_render(const wfo_scene *sc, uint32_t width, uint32_t height, uint32_t fi
             u.seed_lo = splitmix32(sc->seed_lo ^ (f * 0x00009E3Du));
             u.origin = ld(sc->cam_origin); u.right = ld(sc->cam_right); u.up = ld(sc->cam_up); u.forward = ld(sc->cam_forward);
             u.half_h = half_h; u.half_w = aspect * half_h;
+            float total[3] = {0.0f, 0.0f, 0.0f};                        /* this frame's contributions, in stage order */
             ray_t ray = raygen(&u, (uint32_t)p);
             for (uint32_t it = 0u; it < 16u; it++) {                   /* MAX_DEPTH * 2 iterations, render.rs:115 */
                 hit_t hit;
                 if (!intersect(sc, &ray, &hit)) {                      /* pt_scatter.wgsl:113-131 */
                     const v3 sky = mix3(ld(sc->miss_ground), ld(sc->miss_sky), 0.5f * (ray.d.y + 1.0f));
                     const v3 c = mul(ray.throughput, sky);
-                    acc[0] = acc[0] + c.x; acc[1] = acc[1] + c.y; acc[2] = acc[2] + c.z;
+                    total[0] = total[0] + c.x; total[1] = total[1] + c.y; total[2] = total[2] + c.z;
                     break;
                 }
                 ray_t next;
-                if (!shade(sc, &u, &hit, acc, &next)) break;
+                if (!shade(sc, &u, &hit, total, &next)) break;
                 ray = next;
             }
+            acc[0] = acc[0] + total[0]; acc[1] = acc[1] + total[1]; acc[2] = acc[2] + total[2];
         }
     }
     return 0;

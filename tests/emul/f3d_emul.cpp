@@ -796,7 +796,7 @@ int emul_wavefront_render(const f3d_wf_scene *scene, uint32_t width, uint32_t he
 #pragma omp parallel for schedule(dynamic, 64) reduction(+ : vertices)
         for (int64_t p = 0; p < pixels; p++) {
             V3 acc{accum[4 * p], accum[4 * p + 1], accum[4 * p + 2]};
-            vertices += wf::trace_pixel(S, (uint32_t)p, first_frame, frame_count, acc);
+            vertices += wf::trace_frames(S, (uint32_t)p, first_frame, frame_count, wf::SoloWave{}, [&](uint32_t, V3 total) { acc = acc + total; });
             accum[4 * p] = acc.x;
             accum[4 * p + 1] = acc.y;
             accum[4 * p + 2] = acc.z;
