@@ -202,6 +202,7 @@ def main():
                             f"= {args.spp * args.steps} spp, sun az302/el24, orbit phi28/theta49 fov42",
                 "parallelism": "1 GPU" if world == 1 else f"{world} row strips, RCCL halo exchange + gather",
                 "kernel_variant": args.variant,
+                "frames_in_flight": r.session.frames_in_flight(),
                 **({"strip_row_bounds": r.bounds, "strip_probe_ms": r.balance_log[-1]["ms"] if r.balance_log else None,
                     "rccl_ranks": world, "halo_bytes_per_frame_rank0": halo_bytes,
                     "dist_backend": os.environ.get("F3D_DIST_BACKEND") or "nccl"} if world > 1 else {}),
@@ -241,7 +242,8 @@ def main():
                 pass
             result["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note, "kernel": "k_frame",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                "kernel": "k_trace" if r.session.frames_in_flight() else "k_frame",
                 "kernel_ms": frame_kernel_ms, "launches": launches, "bytes_per_sample": b_alg, "sample_lanes": lanes,
                 "per_sample_counts": counts,
             }

@@ -80,7 +80,7 @@ class SessionOpts(C.Structure):
         ("row_begin", C.c_uint32), ("row_end", C.c_uint32),
         ("memory_budget_bytes", C.c_uint64), ("kernel_variant", C.c_int32),
         ("ext_reservoirs", C.c_void_p * 2), ("ext_stats", C.c_void_p),
-        ("bands", C.c_uint32), ("band_streams", C.c_uint32), ("mesh_builder", C.c_uint32),
+        ("bands", C.c_uint32), ("band_streams", C.c_uint32), ("mesh_builder", C.c_uint32), ("frames_in_flight", C.c_uint32),
     ]
 
 
@@ -91,6 +91,11 @@ ABI = [
     ("f3d_session_create", C.c_int, [_P(Desc), _P(SessionOpts), _P(C.c_void_p), C.c_char_p, C.c_size_t]),
     ("f3d_session_destroy", None, [C.c_void_p]),
     ("f3d_session_enqueue_frames", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_char_p, C.c_size_t]),
+    ("f3d_session_enqueue_trace", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t]),
+    ("f3d_session_enqueue_merge", C.c_int, [C.c_void_p, C.c_uint32, C.c_int32, C.c_char_p, C.c_size_t]),
+    ("f3d_session_frames_in_flight", C.c_uint32, [C.c_void_p]),
+    ("f3d_session_retraced_pixels", C.c_int, [C.c_void_p, _P(C.c_uint64)]),
+    ("f3d_session_trace_batch", C.c_uint32, [C.c_void_p, C.c_uint32, C.c_uint32]),
     ("f3d_session_window_stats", C.c_int, [C.c_void_p, _P(C.c_float), _P(C.c_int32), C.c_char_p, C.c_size_t]),
     ("f3d_scene_cache_limit", None, [C.c_uint32]),
     ("f3d_scene_cache_entries", C.c_uint32, []),

@@ -276,6 +276,10 @@ struct f3d_session {
     // longest-first dispatch (f3d_kernels.hip k_tile_order): one-band sessions with the default tile map
     uint32_t *tile_cost = nullptr, *tile_order = nullptr;
     int64_t cost_frame = -1, order_frame = -1;  // newest frame whose wave durations are in tile_cost / went into tile_order
+    // frames in flight (f3d_kernels.hip k_trace / k_merge): record buffer for `fd_frames` frames; 0 = the fused path
+    uint32_t fd_frames = 0;
+    int64_t trace_first = -1;
+    uint32_t trace_count = 0;
     // per-launch timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -516,6 +520,32 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
                  "limit %llu",
                  (unsigned long long)planned, (unsigned long long)s.mem.host_visible_peak,
                  (unsigned long long)s.budget);
+        // frames in flight: as many as were asked for and fit the budget; needs one band.  same_sun: the two sun
+        // directions the frame head chooses between (wi, normalize(wi)) are the same bits -- nothing to predict
+        const uint32_t want = opts ? opts->frames_in_flight : 0u;
+        const bool same_sun = f_bits(P.light.wi.x) == f_bits(P.light.wi_reuse.x) && f_bits(P.light.wi.y) == f_bits(P.light.wi_reuse.y) &&
+                              f_bits(P.light.wi.z) == f_bits(P.light.wi_reuse.z);
+        P.same_sun = same_sun ? 1u : 0u;
+        if (want >= 2u && (!opts || opts->bands <= 1u)) {
+            const uint64_t per_frame = (uint64_t)px * P.spp * 2u * sizeof(float4);
+            const uint64_t fit = per_frame ? (s.budget - planned) / per_frame : 0u;
+            s.fd_frames = (uint32_t)std::min<uint64_t>(want, fit);
+            if (s.fd_frames < 2u) s.fd_frames = 0u;
+        }
+    }
+    if (s.fd_frames) {
+        P.trace = (float4 *)s.mem.alloc((size_t)s.fd_frames * P.spp * px * 2u * sizeof(float4), "frames-in-flight records");
+        P.trace_first = 0u;
+        // touch the buffer now: the first write to fresh device memory pays for its page mappings (measured: the first
+        // batch of a strip 0.42 ms per frame against 0.33 ms once the pages exist)
+        hip_check(hipMemsetAsync(P.trace, 0, (size_t)s.fd_frames * P.spp * px * 2u * sizeof(float4), s.stream), "record buffer touch");
+        P.fix_list = (uint32_t *)s.mem.alloc(px * sizeof(uint32_t), "retrace list");
+        P.fix_count = (uint32_t *)s.mem.alloc(4 * sizeof(uint32_t), "retrace counters");
+        hip_check(hipMemsetAsync(P.fix_count, 0, 4 * sizeof(uint32_t), s.stream), "retrace counters clear");
+    } else {
+        P.trace = nullptr;
+        P.trace_first = 0u;
+        P.fix_list = P.fix_count = nullptr;
     }
     for (int i = 0; i < 2; i++) {
         if (opts && opts->ext_reservoirs[i]) {
@@ -526,7 +556,7 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
         }
         hip_check(hipMemsetAsync(s.res[i], 0, res_n * sizeof(PackedReservoir), s.stream), "reservoir clear");
     }
-    if (P.sample_lanes > 1u) P.head = (uint2 *)s.mem.alloc(px * sizeof(uint2), "frame head records");
+    if (P.sample_lanes > 1u || s.fd_frames) P.head = (uint2 *)s.mem.alloc(px * sizeof(uint2), "frame head records");
     P.accum_mean = (float4 *)s.mem.alloc(px * sizeof(float4), "accumulation");
     P.welford_m2 = (float *)s.mem.alloc(px * sizeof(float), "welford");
     s.gbuffer_n = (float4 *)s.mem.alloc(px * sizeof(float4), "g-buffer");
@@ -569,6 +599,11 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
     P.res_out = s.res[0];
     P.collect_stats = 0;
     hip_check(launch_gbuffer(P, s.gbuffer_n, s.depth, s.stream), "g-buffer pass");
+    if (s.fd_frames) {
+        P.band_begin = s.row_begin;
+        P.band_end = s.row_end;
+        hip_check(launch_trace_init(P, s.stream), "trace prediction init");
+    }
 }
 
 // One band of one frame: frame head (sample-lane form) + frame kernel over the band's rows, on the band's
@@ -651,6 +686,72 @@ void join_bands(f3d_session &s, bool edges_only = false) {
             hip_check(hipStreamWaitEvent(s.stream, b.done[b.last & 1], 0), "band join");
             b.unjoined = false;
         }
+}
+
+// How many frames to trace at once from `frame` on: 2, 2, 4, 8, ... up to the session's frames in flight.  A pixel whose
+// sun-direction prediction fails is traced again by k_fix inside the ordered chain of merges (~0.17 ms for one pixel of
+// the headline scene) in every remaining frame of its batch, because the prediction only learns from merges; which
+// direction a pixel's head reads settles within the first few frames (reservoirs spread 3 pixels a frame), so the early
+// batches are short and the long ones start from settled predictions (17 re-traced pixel-frames in 130 frames at 1080p).
+uint32_t trace_batch(const f3d_session &s, uint32_t frame, uint32_t remaining) {
+    uint32_t ramp = 2u;
+    while (ramp * 2u <= frame) ramp *= 2u;  // the largest power of two <= frame (2 for frames 0..3)
+    if (frame < 2u) ramp = 2u - frame;
+    return std::max(1u, std::min(std::min(s.fd_frames, remaining), ramp));
+}
+
+// ---- frames in flight: trace a batch of frames in one launch, then merge them in order ------------------------
+void enqueue_trace(f3d_session &s, uint32_t first, uint32_t count) {
+    if (!s.fd_frames) fail(F3D_STATUS_VALUE, "this session has no frames in flight (f3d_session_opts.frames_in_flight)");
+    if (count == 0u || count > s.fd_frames) fail(F3D_STATUS_VALUE, "a trace batch holds 1..%u frames (got %u)", s.fd_frames, count);
+    FrameParams &P = s.params;
+    P.frame_index = first;
+    P.trace_first = first;
+    P.band_begin = s.row_begin;
+    P.band_end = s.row_end;
+    constexpr int64_t kOrderEvery = 4;
+    P.tile_cost = s.tile_cost;
+    P.tile_order = nullptr;
+    if (s.tile_cost && s.cost_frame >= 0) {
+        if (s.order_frame < 0 || s.cost_frame - s.order_frame >= kOrderEvery) {
+            hip_check(launch_tile_order(P, s.tile_cost, s.tile_order, s.stream), "tile order kernel");
+            s.order_frame = s.cost_frame;
+        }
+        P.tile_order = s.tile_order;
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (s.timing) {
+        hip_check(hipEventCreate(&e0), "event");
+        hip_check(hipEventCreate(&e1), "event");
+        hip_check(hipEventRecord(e0, s.stream), "event record");
+    }
+    hip_check(launch_trace(P, count, s.stream), "trace kernel");
+    if (s.tile_cost) s.cost_frame = (int64_t)first;
+    P.tile_order = nullptr;
+    P.tile_cost = nullptr;
+    if (s.timing) {
+        hip_check(hipEventRecord(e1, s.stream), "event record");
+        s.events.emplace_back(e0, e1);
+    }
+    s.trace_first = first;
+    s.trace_count = count;
+}
+
+void enqueue_merge(f3d_session &s, uint32_t frame, bool collect) {
+    if (!s.fd_frames || s.trace_first < 0 || frame < (uint32_t)s.trace_first || frame >= (uint32_t)s.trace_first + s.trace_count)
+        fail(F3D_STATUS_VALUE, "frame %u is not in the traced batch [%lld, %lld)", frame, (long long)s.trace_first,
+             (long long)s.trace_first + s.trace_count);
+    FrameParams &P = s.params;
+    if (collect) hip_check(hipMemsetAsync(s.stats, 0, 2 * sizeof(uint32_t), s.stream), "stats clear");
+    P.frame_index = frame;
+    P.trace_first = (uint32_t)s.trace_first;
+    P.res_out = s.res[frame & 1u];
+    P.res_in = s.res[(frame & 1u) ^ 1u];
+    P.collect_stats = collect ? 1u : 0u;
+    P.band_begin = s.row_begin;
+    P.band_end = s.row_end;
+    hip_check(launch_merge(P, s.stream), "merge kernel");
+    for (auto &b : s.bands) b.last = frame;
 }
 
 // part: 0 every band; 1 the edge bands (halo donors of a multi-GPU strip), then the session stream is
@@ -770,9 +871,50 @@ int f3d_session_enqueue_frames(f3d_session *s, uint32_t first_frame, uint32_t co
                                char *err, size_t errlen) {
     return c_abi(err, errlen, [&] {
         DeviceGuard g(checked(s).device);
+        if (s->fd_frames) {  // frames in flight: batches of up to fd_frames frames traced at once, merged in order
+            for (uint32_t done = 0; done < count;) {
+                const uint32_t n = trace_batch(*s, first_frame + done, count - done);
+                enqueue_trace(*s, first_frame + done, n);
+                for (uint32_t i = 0; i < n; i++)
+                    enqueue_merge(*s, first_frame + done + i, collect_stats_on_last != 0 && done + i + 1 == count);
+                done += n;
+            }
+            return;
+        }
         if (count) fork_bands(*s, collect_stats_on_last != 0);
         for (uint32_t i = 0; i < count; i++)
             enqueue_frame(*s, first_frame + i, collect_stats_on_last != 0 && i + 1 == count, 0u, false);
+    });
+}
+
+int f3d_session_enqueue_trace(f3d_session *s, uint32_t first_frame, uint32_t count, char *err, size_t errlen) {
+    return c_abi(err, errlen, [&] {
+        DeviceGuard g(checked(s).device);
+        enqueue_trace(*s, first_frame, count);
+    });
+}
+
+int f3d_session_enqueue_merge(f3d_session *s, uint32_t frame, int32_t collect_stats, char *err, size_t errlen) {
+    return c_abi(err, errlen, [&] {
+        DeviceGuard g(checked(s).device);
+        enqueue_merge(*s, frame, collect_stats != 0);
+    });
+}
+
+uint32_t f3d_session_frames_in_flight(f3d_session *s) { return s ? s->fd_frames : 0u; }
+uint32_t f3d_session_trace_batch(f3d_session *s, uint32_t frame, uint32_t remaining) {
+    return (s && s->fd_frames && remaining) ? trace_batch(*s, frame, remaining) : 0u;
+}
+
+int f3d_session_retraced_pixels(f3d_session *s, uint64_t *total) {
+    return c_abi(nullptr, 0, [&] {
+        DeviceGuard g(checked(s).device);
+        uint32_t host[4] = {0, 0, 0, 0};
+        if (s->fd_frames) {
+            hip_check(hipStreamSynchronize(s->stream), "stream sync");
+            hip_check(hipMemcpy(host, s->params.fix_count, sizeof(host), hipMemcpyDeviceToHost), "retrace counters");
+        }
+        if (total) *total = host[2];
     });
 }
 
@@ -781,6 +923,7 @@ int f3d_session_enqueue_frame_part(f3d_session *s, uint32_t frame, uint32_t part
     return c_abi(err, errlen, [&] {
         DeviceGuard g(checked(s).device);
         if (part != 1u && part != 2u) fail(F3D_STATUS_VALUE, "frame part must be 1 (edge rows) or 2 (interior)");
+        if (s->fd_frames) fail(F3D_STATUS_VALUE, "sessions with frames in flight are driven by enqueue_trace / enqueue_merge");
         enqueue_frame(*s, frame, collect_stats != 0, part);
     });
 }

@@ -344,6 +344,187 @@ __device__ __forceinline__ float frame_lanes(const FrameParams &P, uint32_t gx, 
     return frame_tail(P, gx, gy, cand, V3{f_from_bits(park[0]), f_from_bits(park[kWave]), f_from_bits(park[2 * kWave])});
 }
 
+// ---- frames in flight ------------------------------------------------------------------------------
+// Everything a frame TRACES is independent of the frames before it: the RNG stream is keyed by (pixel, frame), the
+// rays by the stream and the scene.  What depends on frame f - 1 is cheap and ordered: the frame head (spatial reuse
+// of the previous reservoirs -> the weight `reuse_w` that multiplies the sun term, and which of the two equal-valued
+// sun directions is read), the order-sensitive sums over the samples, the temporal merge and the accumulation.
+// k_frame runs both per frame, so a render is a chain of launches each as long as its longest wave (a multi-GPU
+// strip: 0.53 ms against 0.32 ms of packed work).  Here the two are separate kernels:
+//   k_trace   one launch for a BATCH of frames (grid.y = frame): per (frame, pixel, sample) the primary, sun and IBL
+//             rays exactly as frame_lanes traces them -- with reuse_w = 1 (x * 1.0f == x) -- and one 32-byte record
+//             {sun term or miss radiance, target pdf; IBL term, hit flag}: W x H x frames independent lanes' worth
+//             of work, no chain, no tail per frame;
+//   k_merge   per frame, in order, one lane per pixel: frame_head, the samples' records through accumulate_sample
+//             with the sun term multiplied by the real reuse_w (the operation k_frame does at that point), frame_tail.
+// The records wait in HBM: 32 B x spp x pixels per frame in flight (0.53 GB at 1080p, 8 spp) -- room the 288 GB have.
+// One thing a frame traces DOES look at the frame before: the head picks the sun direction `wi` or normalize(wi)
+// by whether the merged reservoir is valid, and the two may differ in the last bit.  Validity is persistent (after
+// the first frame it changes for next to no pixel), so k_trace PREDICTS it -- frame 0: invalid (exact); later
+// frames: what k_merge last saw for the pixel (before that: the centre ray faces the sun) -- and notes the prediction
+// in the record; k_merge compares with the real head and, for the rare pixel-frame that was mispredicted, traces
+// the pixel's primary and sun rays again with the right direction in k_fix (the IBL terms do not depend on it).  With equal
+// bits (same_sun) nothing is predicted.  Results are those of k_frame bit for bit either way.
+template <uint32_t S>
+__device__ __forceinline__ void trace_lanes(const FrameParams &P, uint32_t frame, uint32_t gx, uint32_t gy, bool valid,
+                                            LdsPending &pend) {
+    const uint32_t lane = threadIdx.x & (kWave - 1u), j = lane & (S - 1u), base = lane & ~(S - 1u);
+    constexpr uint32_t kGroup = (1u << S) - 1u;
+    const size_t pixels = (size_t)(P.row_end - P.row_begin) * P.cam.width;
+    const size_t lp = valid ? (size_t)(gy - P.row_begin) * P.cam.width + gx : 0u;
+    FrameHead h;
+    h.centre_hit = valid && P.gbuffer_n[lp].w != 0.0f;  // prediction of the hit flags only
+    // which sun direction the head will read: predicted (see above); immaterial when they are the same bits
+    h.prev_valid = valid && frame > 0u && (P.head[lp].y & kHeadPrevValid) != 0u;
+    h.reuse_w = 1.0f;                                  // applied by k_merge
+    h.rng = P.cam.seed_hi ^ (gx * 1664525u) ^ (gy * 1013904223u) ^ (frame * 92837111u) ^ P.cam.seed_lo;
+    uint32_t stream = h.rng;
+    float4 *out = P.trace + 2u * ((size_t)(frame - P.trace_first) * P.spp * pixels + lp);
+    for (uint32_t s0 = 0u; s0 < P.spp; s0 += S) {  // wave-uniform
+        const uint32_t n_act = P.spp - s0 < S ? P.spp - s0 : S;
+        const bool act = valid && j < n_act;
+        uint32_t pred = h.centre_hit ? kGroup : 0u;
+        uint32_t traced = 0xFFFFFFFFu;
+        PrimaryHit ph;
+        ph.hit.kind = 0u;
+        ph.rng = 0u;
+        for (;;) {
+            const uint32_t draws = 2u * j + 2u * (uint32_t)__popc(pred & ((1u << j) - 1u));
+            const bool need = act && draws != traced;
+            if (__ballot(need) == 0ull) break;
+            if (need) {
+                uint32_t st = stream;
+                rng_skip(st, draws);
+                ph = sample_primary(P, gx, gy, st, pend);
+                traced = draws;
+            }
+            pred = (uint32_t)(__ballot(act && ph.hit.kind != 0u) >> base) & kGroup;
+        }
+        SampleOut o;
+        o.a = V3{0.0f, 0.0f, 0.0f};
+        o.b = V3{0.0f, 0.0f, 0.0f};
+        o.target_pdf = 0.0f;
+        IblRay q;
+        q.valid = false;
+        q.o = q.d = q.b0 = V3{0.0f, 0.0f, 0.0f};
+        q.key = 2.0f;
+        if (act) {
+            uint32_t rng = ph.rng;
+            q = sample_shade_sun(P, h, ph, rng, o, pend);
+        }
+        if (q.valid) o.b = q.b0 * (ibl_occluded(P, q.o, q.d, pend) ? 0.0f : 1.0f);
+        if (act) {
+            float4 *rec = out + 2u * (size_t)(s0 + j) * pixels;
+            rec[0] = float4{o.a.x, o.a.y, o.a.z, o.target_pdf};
+            rec[1] = float4{o.b.x, o.b.y, o.b.z, (ph.hit.kind != 0u ? 1.0f : 0.0f) + (h.prev_valid ? 2.0f : 0.0f)};
+        }
+        rng_skip(stream, 2u * n_act + 2u * (uint32_t)__popc(pred));
+    }
+}
+
+template <int MIN_WAVES, uint32_t S>
+__global__ __launch_bounds__(kWave, MIN_WAVES) void k_trace(const FrameParams P) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kLdsWords];
+    const unsigned long long t_start = wall_clock64();
+    LdsPending pend = make_pending(lds, P.terrain);
+    uint32_t gx = 0u, gy = 0u, tile;
+    const bool active = tile_pixel<S>(P, gx, gy, tile, P.tile_order);
+    trace_lanes<S>(P, P.frame_index + blockIdx.y, gx, gy, active, pend);
+    if (threadIdx.x == 0u && blockIdx.y == 0u && P.tile_cost && tile != 0xFFFFFFFFu)
+        P.tile_cost[tile] = (uint32_t)(wall_clock64() - t_start);
+}
+
+// The ordered half of a frame (see above): one lane per pixel, 8x8 tiles.
+__global__ __launch_bounds__(kWave) void k_merge(const FrameParams P) {
+    uint32_t gx = 0u, gy = 0u;
+    const bool active = tile_pixel(P, gx, gy);
+    float m2 = 0.0f;
+    const size_t pixels = (size_t)(P.row_end - P.row_begin) * P.cam.width;
+    const size_t lp = active ? (size_t)(gy - P.row_begin) * P.cam.width + gx : 0u;
+    const float4 *rec = P.trace + 2u * ((size_t)(P.frame_index - P.trace_first) * P.spp * pixels + lp);
+    FrameHead h;
+    h.centre_hit = h.prev_valid = false;
+    h.reuse_w = 1.0f;
+    h.rng = 0u;
+    bool redo = false;
+    if (active) {
+        h = frame_head(P, gx, gy);
+        if (P.same_sun == 0u) {  // was the sun direction of this pixel-frame predicted right?
+            for (uint32_t s = 0u; s < P.spp; s++) {
+                const float code = rec[2u * (size_t)s * pixels + 1u].w;  // 1 = hit, 2 = predicted "valid"
+                if ((code == 1.0f || code == 3.0f) && (code == 3.0f) != h.prev_valid) redo = true;
+#if defined(F3D_TIMING_FD_NO_REDO)  // timing experiment only (wrong image)
+                redo = false;
+#endif
+            }
+            // the prediction for the frames traced next (frame 0 says nothing: there every head is invalid by definition)
+            if (P.frame_index > 0u) P.head[lp].y = h.prev_valid ? kHeadPrevValid : 0u;
+        }
+    }
+    if (active && redo) {  // deferred to k_fix, which runs before the next frame's merge
+        P.fix_list[atomicAdd(&P.fix_count[P.frame_index & 1u], 1u)] = (uint32_t)lp;
+    } else if (active) {
+        V3 radiance = V3{0.0f, 0.0f, 0.0f};
+        Reservoir cand = empty_reservoir();
+        for (uint32_t s = 0u; s < P.spp; s++) {
+            const float4 r0 = rec[2u * (size_t)s * pixels], r1 = rec[2u * (size_t)s * pixels + 1u];
+            V3 a = V3{r0.x, r0.y, r0.z};
+            if (r1.w == 1.0f || r1.w == 3.0f) a = a * h.reuse_w;  // a hit: the sun term goes through the merged reservoir's weight
+            accumulate_sample(cand, radiance, a, V3{r1.x, r1.y, r1.z}, r0.w);
+        }
+        m2 = frame_tail(P, gx, gy, cand, radiance);
+    }
+    if (P.collect_stats != 0u) publish_window_stats(P, active && !redo, m2);
+}
+
+// The mispredicted pixel-frames of k_merge, 64 to a wave: head again (idempotent), the pixel's primary and sun rays
+// with the direction the real head reads -- the sample loop of frame_pixel, its IBL terms taken from the records --
+// and the tail.  A small fixed grid strides over the list.
+__global__ __launch_bounds__(kWave) void k_fix(const FrameParams P) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kLdsWords];
+    LdsPending pend = make_pending(lds, P.terrain);
+    const uint32_t count = P.fix_count[P.frame_index & 1u];
+    if (blockIdx.x == 0u && threadIdx.x == 0u) {
+        P.fix_count[(P.frame_index & 1u) ^ 1u] = 0u;  // the next frame's list starts empty
+        atomicAdd(&P.fix_count[2], count);
+    }
+    const size_t pixels = (size_t)(P.row_end - P.row_begin) * P.cam.width;
+    for (uint32_t i0 = blockIdx.x * kWave; i0 < count; i0 += gridDim.x * kWave) {  // wave-uniform
+        const uint32_t i = i0 + threadIdx.x;
+        const bool active = i < count;
+        float m2 = 0.0f;
+        if (active) {
+            const uint32_t lp = P.fix_list[i];
+            const uint32_t gx = lp % P.cam.width, gy = P.row_begin + lp / P.cam.width;
+            const FrameHead h = frame_head(P, gx, gy);
+            const float4 *rec = P.trace + 2u * ((size_t)(P.frame_index - P.trace_first) * P.spp * pixels + lp);
+            uint32_t rng = h.rng;
+            V3 radiance = V3{0.0f, 0.0f, 0.0f};
+            Reservoir cand = empty_reservoir();
+            for (uint32_t s = 0u; s < P.spp; s++) {
+                const PrimaryHit ph = sample_primary(P, gx, gy, rng, pend);
+                rng = ph.rng;
+                SampleOut o;
+                (void)sample_shade_sun(P, h, ph, rng, o, pend);
+                const float4 r1 = rec[2u * (size_t)s * pixels + 1u];
+                accumulate_sample(cand, radiance, o.a, V3{r1.x, r1.y, r1.z}, o.target_pdf);
+            }
+            m2 = frame_tail(P, gx, gy, cand, radiance);
+        }
+        if (P.collect_stats != 0u) publish_window_stats(P, active, m2);
+    }
+}
+
+// First prediction of "the merged reservoir is valid" for the frames traced before any merge: the centre ray hit a
+// surface that faces the sun.
+__global__ __launch_bounds__(kWave) void k_trace_init(const FrameParams P) {
+    uint32_t gx, gy;
+    if (!tile_pixel(P, gx, gy)) return;
+    const size_t lp = (size_t)(gy - P.row_begin) * P.cam.width + gx;
+    const float4 g = P.gbuffer_n[lp];
+    P.head[lp] = uint2{0u, (g.w != 0.0f && dot(V3{g.x, g.y, g.z}, P.light.wi) > 0.0f) ? kHeadPrevValid : 0u};
+}
+
 // Frame head of the sample-lane form: one lane per pixel (8x8 tiles).
 __global__ __launch_bounds__(kWave) void k_head(const FrameParams P) {
     uint32_t gx, gy;
@@ -486,6 +667,31 @@ hipError_t launch_frame(const FrameParams &p, int variant, hipStream_t stream) {
         case 108: hipLaunchKernelGGL((k_frame<0, 8>), grid, block, 0, stream, p); break;
         default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+// frames [p.frame_index, p.frame_index + frames) of the strip into p.trace (grid.y = frame)
+hipError_t launch_trace(const FrameParams &p, uint32_t frames, hipStream_t stream) {
+    const uint32_t lanes = p.sample_lanes ? p.sample_lanes : 1u;
+    if (frame_grid(p, lanes) == 0u || frames == 0u) return hipSuccess;
+    const dim3 grid(frame_grid(p, lanes), frames), block(kWave);
+    switch (lanes) {
+        case 1: hipLaunchKernelGGL((k_trace<6, 1>), grid, block, 0, stream, p); break;
+        case 2: hipLaunchKernelGGL((k_trace<6, 2>), grid, block, 0, stream, p); break;
+        case 4: hipLaunchKernelGGL((k_trace<6, 4>), grid, block, 0, stream, p); break;
+        case 8: hipLaunchKernelGGL((k_trace<6, 8>), grid, block, 0, stream, p); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+hipError_t launch_trace_init(const FrameParams &p, hipStream_t stream) {
+    if (frame_grid(p) == 0u) return hipSuccess;
+    hipLaunchKernelGGL(k_trace_init, dim3(frame_grid(p)), dim3(kWave), 0, stream, p);
+    return hipGetLastError();
+}
+hipError_t launch_merge(const FrameParams &p, hipStream_t stream) {
+    if (frame_grid(p) == 0u) return hipSuccess;
+    hipLaunchKernelGGL(k_merge, dim3(frame_grid(p)), dim3(kWave), 0, stream, p);
+    if (p.same_sun == 0u) hipLaunchKernelGGL(k_fix, dim3(512), dim3(kWave), 0, stream, p);  // the mispredicted pixel-frames
     return hipGetLastError();
 }
 hipError_t launch_tile_order(const FrameParams &p, const uint32_t *cost, uint32_t *order, hipStream_t stream) {

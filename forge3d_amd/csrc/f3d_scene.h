@@ -156,6 +156,14 @@ struct FrameParams {
     unsigned long long *wave_times;  // diagnostics (builds with -DF3D_WAVE_TIMES): {start, end} clock per workgroup
     uint32_t band_begin, band_end;  // image rows THIS launch covers (a band of the strip; the host pipelines bands
                                     // of consecutive frames over several streams, f3d_host.hip)
+    // frames in flight (f3d_kernels.hip k_trace / k_merge): two float4 per (frame, sample, pixel) -- record r of
+    // sample s of frame f of strip pixel lp is trace[2 * (((f - trace_first) * spp + s) * pixels + lp) + {0, 1}]
+    float4 *trace;
+    uint32_t trace_first;
+    uint32_t same_sun;  // the frame head's two sun directions (wi, normalize(wi)) are the same bits
+    // pixel-frames whose sun direction was mispredicted: k_merge lists them, k_fix re-traces them, 64 to a wave
+    uint32_t *fix_list;   // strip-local pixel indices
+    uint32_t *fix_count;  // [0], [1]: entries for frame parity 0 / 1; [2]: running total (diagnostics)
 };
 
 }  // namespace f3d

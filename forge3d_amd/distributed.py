@@ -158,6 +158,16 @@ class StripRenderer:
         self.width, self.height = int(width), int(height)
         self.backend = backend or HipBackend(device)
         self.balance_log = []
+        # Frames in flight (f3d_session_opts.frames_in_flight): thin strips trace batches of frames in one launch and run
+        # the ordered half per frame, with the halo exchange between merges -- 8 strips of a 1080p frame: 0.40-0.42 ms
+        # per strip-frame against 0.53 ms with one fused launch per frame (tools/strip_balance.py --fd 16).  Fat strips
+        # (2 ranks) keep the fused kernel.  The session lowers the number to what its memory budget holds.
+        fd = kw.pop("frames_in_flight", None)
+        if fd is None:
+            fd = 16 if (world >= 3 and isinstance(self.backend, HipBackend)) else 0
+        if fd:
+            kw = dict(kw, frames_in_flight=int(fd))
+        self.probe_frames = 16 if fd else 4  # batches need a few frames to reach their steady throughput
         if row_bounds is not None:
             self.bounds = [int(b) for b in row_bounds]
             if (len(self.bounds) != world + 1 or self.bounds[0] != 0 or self.bounds[-1] != self.height
@@ -213,7 +223,8 @@ class StripRenderer:
         density = np.ones(self.height)
         best = None
         for it in range(iters + 1):
-            ms = self.backend.probe(dem, self.width, self.height, cam, bounds[self.rank], bounds[self.rank + 1], kw)
+            ms = self.backend.probe(dem, self.width, self.height, cam, bounds[self.rank], bounds[self.rank + 1], kw,
+                                    frames=self.probe_frames)
             times = self._gather_floats(ms)
             if not all(np.isfinite(t) and t > 0.0 for t in times):
                 break  # backend without timing: keep what we have
@@ -305,6 +316,29 @@ class StripRenderer:
         # buffers hold): its neighbours are inside matching send / recv pairs and would wait forever otherwise.
         # The failure is raised at the end of the batch; render() then makes every rank stop (_agree).
         error = None
+        in_flight = getattr(self.session, "frames_in_flight", lambda: 0)()
+        if in_flight:
+            # batches of frames traced in one launch; per frame the ordered half, then the halo rows it produced go to
+            # the neighbours while nothing else of this rank is waiting for them but the next merge
+            f, end = first, first + count
+            while f < end:
+                n = self.session.trace_batch(f, end - f) if error is None else 1
+                if error is None:
+                    try:
+                        self.session.enqueue_trace(f, n)
+                    except Exception as exc:  # noqa: BLE001
+                        error = exc
+                for frame in range(f, f + n):
+                    if error is None:
+                        try:
+                            self.session.enqueue_merge(frame, collect_last and frame + 1 == end)
+                        except Exception as exc:  # noqa: BLE001
+                            error = exc
+                    self.finish_halo_exchange(self.start_halo_exchange(frame & 1))
+                f += n
+            if error is not None:
+                raise error
+            return
         for f in range(first, first + count):
             collect = collect_last and f + 1 == first + count
             for part in (1, 2):

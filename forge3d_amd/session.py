@@ -20,7 +20,7 @@ WELFORD_WINDOW = 32
 class TerrainSession:
     def __init__(self, heightmap, width, height, camera=None, *, row_begin=0, row_end=0, device=-1, stream=0,
                  memory_budget_bytes=0, kernel_variant=0, ext_reservoirs=(None, None), ext_stats=None, bands=0,
-                 band_streams=0, mesh_builder=0,
+                 band_streams=0, mesh_builder=0, frames_in_flight=0,
                  spacing=(1.0, 1.0), exaggeration=1.0, albedo=(0.6, 0.6, 0.6), sun_azimuth_deg=315.0,
                  sun_elevation_deg=45.0, sun_intensity=2.5, sun_color=(1.0, 0.97, 0.92), env_map=None,
                  env_intensity=0.35, mesh_vertices=None, mesh_indices=None, spp=1, max_frames=512, min_frames=32,
@@ -46,6 +46,7 @@ class TerrainSession:
         opts.ext_stats = C.c_void_p(ext_stats or None)
         opts.bands, opts.band_streams = int(bands), int(band_streams)
         opts.mesh_builder = int(mesh_builder)
+        opts.frames_in_flight = int(frames_in_flight)
         err = C.create_string_buffer(1024)
         rc = self._lib.f3d_session_create(C.byref(desc), C.byref(opts), C.byref(self._handle), err, len(err))
         del keep
@@ -86,6 +87,28 @@ class TerrainSession:
         """Asynchronously enqueue accumulation frames on the session stream."""
         self._check(self._lib.f3d_session_enqueue_frames(self._handle, int(first_frame), int(count),
                                                          1 if collect_stats else 0, self._err, len(self._err)))
+
+    def enqueue_trace(self, first_frame: int, count: int):
+        """Frames in flight: trace frames [first_frame, first_frame + count) in one launch (count <= frames_in_flight())."""
+        self._check(self._lib.f3d_session_enqueue_trace(self._handle, int(first_frame), int(count), self._err, len(self._err)))
+
+    def enqueue_merge(self, frame: int, collect_stats: bool = False):
+        """Frames in flight: the ordered half (reservoir chain, accumulation) of one traced frame."""
+        self._check(self._lib.f3d_session_enqueue_merge(self._handle, int(frame), 1 if collect_stats else 0, self._err, len(self._err)))
+
+    def frames_in_flight(self) -> int:
+        """Effective number of frames the session traces per launch (0: every frame is one fused launch)."""
+        return int(self._lib.f3d_session_frames_in_flight(self._handle))
+
+    def trace_batch(self, frame: int, remaining: int) -> int:
+        """Batch size to trace next at `frame` (short batches first, then frames_in_flight())."""
+        return int(self._lib.f3d_session_trace_batch(self._handle, int(frame), int(remaining)))
+
+    def retraced_pixels(self) -> int:
+        """Diagnostics (synchronises): pixel-frames whose sun-direction prediction failed and were traced again."""
+        total = C.c_uint64(0)
+        self._lib.f3d_session_retraced_pixels(self._handle, C.byref(total))
+        return int(total.value)
 
     def enqueue_frame_part(self, frame: int, part: int, collect_stats: bool = False):
         """One frame in two launches: part 1 = head + the strip's edge rows (the halo donors), part 2 = interior."""

@@ -149,6 +149,13 @@ typedef struct f3d_session_opts {
      * 2 = linear BVH built on the GPU (reference src/accel/lbvh_gpu: Morton codes, radix sort, Karras topology,
      * bottom-up refit).  Images do not depend on the choice. */
     uint32_t mesh_builder;
+    /* Frames in flight: 0 / 1 = every frame is one fused launch (the default).  N >= 2: the session keeps a record
+     * buffer for up to N frames (32 B x spp x pixels each, counted against memory_budget_bytes; N is lowered to what
+     * fits) and f3d_session_enqueue_frames traces N frames in ONE launch -- what a frame traces does not depend on
+     * the frames before it -- and then runs the cheap ordered half (reservoir chain, accumulation) per frame.  No
+     * per-frame tail: the way thin multi-GPU strips stay throughput-bound.  Results do not depend on N.
+     * f3d_session_frames_in_flight reports the effective value (0 when the scene is not eligible). */
+    uint32_t frames_in_flight;
 } f3d_session_opts;
 
 int f3d_session_create(const f3d_terrain_ref_desc *desc, const f3d_session_opts *opts,
@@ -162,6 +169,17 @@ void f3d_session_destroy(f3d_session *session);
  * convergence statistic read by f3d_session_window_stats. */
 int f3d_session_enqueue_frames(f3d_session *session, uint32_t first_frame, uint32_t count,
                                int32_t collect_stats_on_last, char *err, size_t errlen);
+/* Sessions with frames in flight, driven frame by frame (multi-GPU strips exchange halos between merges): trace
+ * frames [first_frame, first_frame + count), count <= frames in flight, then merge each of them in order. */
+int f3d_session_enqueue_trace(f3d_session *session, uint32_t first_frame, uint32_t count, char *err, size_t errlen);
+int f3d_session_enqueue_merge(f3d_session *session, uint32_t frame, int32_t collect_stats, char *err, size_t errlen);
+uint32_t f3d_session_frames_in_flight(f3d_session *session);
+/* The batch size f3d_session_enqueue_frames would trace next at `frame` with `remaining` frames to go (short batches
+ * for the first frames, then frames_in_flight): what a frame-by-frame driver passes to f3d_session_enqueue_trace. */
+uint32_t f3d_session_trace_batch(f3d_session *session, uint32_t frame, uint32_t remaining);
+/* Diagnostics (synchronises): pixel-frames traced a second time because the sun direction their frame head read was
+ * mispredicted (see frames_in_flight); a handful per frame after the first two. */
+int f3d_session_retraced_pixels(f3d_session *session, uint64_t *total);
 /* One frame in two steps, for strips of a multi-GPU job: part 1 = the strip's EDGE bands (they contain the
  * first and last 3 pixel rows, the halo a neighbouring strip needs; on return the session stream is ordered
  * after them), part 2 = the interior bands.  The caller starts the halo exchange between the two, so that it

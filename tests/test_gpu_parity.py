@@ -729,3 +729,97 @@ def test_gpu_lbvh_degenerate_meshes(f3d, oracle):
             got = _session_render(dem, 80, 64, scenes.CAM, 2, 0, builder, **kw)
             for key in ("rgba", "albedo", "normal", "depth"):
                 assert np.array_equal(got[key], want[key], equal_nan=True), (len(i), builder, key)
+
+
+@pytest.mark.parametrize("variant,spp,fd,rows", [(0, 8, 5, (0, 0)), (1000000, 3, 2, (0, 0)), (2000000, 5, 7, (0, 0)), (8000000, 8, 3, (13, 58)),
+                                                 (4000000, 6, 4, (0, 0)), (8000000, 19, 16, (0, 0))])
+def test_frames_in_flight_are_bit_identical(f3d, oracle, variant, spp, fd, rows):
+    """f3d_session_opts.frames_in_flight: batches of frames traced in one launch (k_trace, grid.y = frame), then the
+    ordered half per frame (k_merge).  Against the oracle and against the fused kernel: every output, the variance
+    statistic, with and without a mesh, ragged batches (9 frames in batches of fd), a strip with rows of its own."""
+    from forge3d_amd.session import TerrainSession
+
+    dem = scenes.golden_dem()
+    quad_v = np.array([[-18.0, 22.0, -6.0], [18.0, 22.0, -6.0], [18.0, 40.0, -6.0], [-18.0, 40.0, -6.0]], np.float32)
+    quad_i = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+    frames = 9
+    for extra in ({}, {"mesh_vertices": quad_v, "mesh_indices": quad_i}):
+        kw = scenes.fixed_frames(scenes.scene_kwargs(dem), frames, spp=spp, **extra)
+        strip = dict(row_begin=rows[0], row_end=rows[1]) if rows[1] else {}
+        outs = []
+        for in_flight in (0, fd):
+            with TerrainSession(dem, 110, 77, scenes.CAM, kernel_variant=variant, frames_in_flight=in_flight,
+                                memory_budget_bytes=4 << 30, **strip, **kw) as s:
+                assert s.frames_in_flight() == in_flight
+                s.enqueue_frames(0, frames, True)
+                m2, bad = s.window_stats()
+                outs.append((s.resolve(frames), m2, bad))
+        (a, m2a, bada), (b, m2b, badb) = outs
+        assert not bada and not badb and np.float32(m2a) == np.float32(m2b)
+        for key in ("rgba", "albedo", "normal", "depth"):
+            assert np.array_equal(a[key], b[key], equal_nan=True), (variant, key)
+        if not rows[1]:
+            want = oracle.render(dem, 110, 77, scenes.CAM, **kw)
+            assert np.float32(max(0.0, m2b) / np.float32(frames - 1)) == np.float32(want["variance"])
+            for key in ("rgba", "albedo", "normal", "depth"):
+                assert np.array_equal(b[key], want[key], equal_nan=True), (variant, key)
+
+
+def test_frames_in_flight_frame_by_frame_and_limits(f3d):
+    """enqueue_trace / enqueue_merge driven by hand (what the strip driver does), the budget clamp, the errors."""
+    from forge3d_amd.session import TerrainSession
+
+    dem = scenes.golden_dem()
+    kw = scenes.fixed_frames(scenes.scene_kwargs(dem), 6, spp=4)
+    with TerrainSession(dem, 96, 64, scenes.CAM, **kw) as ref:
+        ref.enqueue_frames(0, 6, True)
+        want_m2, _ = ref.window_stats()
+        want = ref.resolve(6)
+    with TerrainSession(dem, 96, 64, scenes.CAM, frames_in_flight=4, **kw) as s:
+        assert s.frames_in_flight() == 4
+        s.enqueue_trace(0, 4)
+        for f in range(4):
+            s.enqueue_merge(f)
+        with pytest.raises(ValueError, match="not in the traced batch"):
+            s.enqueue_merge(4)
+        with pytest.raises(ValueError, match="1..4 frames"):
+            s.enqueue_trace(4, 5)
+        with pytest.raises(ValueError, match="enqueue_trace / enqueue_merge"):
+            s.enqueue_frame_part(4, 1)
+        s.enqueue_trace(4, 2)
+        s.enqueue_merge(4)
+        s.enqueue_merge(5, True)
+        m2, bad = s.window_stats()
+        got = s.resolve(6)
+    assert not bad and np.float32(m2) == np.float32(want_m2)
+    for key in ("rgba", "albedo", "normal", "depth"):
+        assert np.array_equal(got[key], want[key], equal_nan=True), key
+    # 96 x 64 x 4 spp x 32 B = 786 KB per frame in flight: a budget with room for two of the four asked for
+    with TerrainSession(dem, 96, 64, scenes.CAM, **kw) as probe:
+        used = probe.info()["gpu_resource_bytes"]
+    with TerrainSession(dem, 96, 64, scenes.CAM, frames_in_flight=4, memory_budget_bytes=used + 2 * 786432 + 65536, **kw) as s:
+        assert s.frames_in_flight() == 2
+    with TerrainSession(dem, 96, 64, scenes.CAM, frames_in_flight=3, bands=3, **kw) as s:
+        assert s.frames_in_flight() == 0  # band pipelining and frames in flight exclude one another
+
+
+@pytest.mark.parametrize("az,el", [(302.0, 24.0), (135.0, 12.0), (17.0, 61.0), (250.0, 3.0), (90.0, 45.0)])
+def test_frames_in_flight_with_predicted_sun_direction(f3d, az, el):
+    """The frame head reads `wi` or normalize(wi) depending on the previous frame's reservoir; for most sun angles the
+    two differ in the last bit, so k_trace predicts the choice and k_merge re-traces the mispredicted pixel-frames
+    (frames 1.. of the first batch, silhouettes).  Bit-identical to the fused kernel, incl. batches that start at
+    frame 0 and batches that rely on the flags the merges left behind."""
+    from forge3d_amd.session import TerrainSession
+
+    dem = scenes.golden_dem()
+    kw = scenes.fixed_frames(dict(scenes.scene_kwargs(dem), sun_azimuth_deg=az, sun_elevation_deg=el), 11, spp=4)
+    outs = []
+    for in_flight in (0, 4):
+        with TerrainSession(dem, 120, 90, scenes.CAM, frames_in_flight=in_flight, **kw) as s:
+            s.enqueue_frames(0, 11, True)
+            m2, bad = s.window_stats()
+            outs.append((s.resolve(11), m2, bad))
+    (a, m2a, _), (b, m2b, _) = outs
+    assert np.float32(m2a) == np.float32(m2b)
+    for key in ("rgba", "albedo", "normal", "depth"):
+        assert np.array_equal(a[key], b[key], equal_nan=True), (az, el, key)

@@ -29,6 +29,7 @@ ap.add_argument("--variant", type=int, default=0)
 ap.add_argument("--frames", type=int, default=16)
 ap.add_argument("--sweep", action="store_true")
 ap.add_argument("--rounds", type=int, default=4)
+ap.add_argument("--fd", type=int, default=0, help="frames in flight of the strip sessions (f3d_session_opts.frames_in_flight)")
 args = ap.parse_args()
 
 W, H, SPP = 1920, 1080, 8
@@ -44,6 +45,8 @@ def probe(b0, b1, **extra):
 
 full = probe(0, H)
 print(json.dumps({"full_frame_ms": full}), flush=True)
+if args.fd:
+    print(json.dumps({"full_frame_ms_frames_in_flight": probe(0, H, frames_in_flight=min(args.fd, 12)), "fd": min(args.fd, 12)}), flush=True)
 if args.sweep:
     # the balanced 8-strip partition of profiles/r01_strip_balance.log
     bounds = [0, 394, 483, 552, 624, 703, 801, 917, 1080]
@@ -59,7 +62,7 @@ for world in [int(x) for x in args.worlds.split(",")]:
     bounds = [strip_rows(H, world, r)[0] for r in range(world)] + [H]
     density = np.ones(H)
     for it in range(args.rounds):
-        times = [probe(bounds[r], bounds[r + 1], bands=args.bands, band_streams=args.streams) for r in range(world)]
+        times = [probe(bounds[r], bounds[r + 1], bands=args.bands, band_streams=args.streams, frames_in_flight=args.fd) for r in range(world)]
         print(json.dumps({"world": world, "round": it, "bounds": bounds, "ms": [round(t, 3) for t in times],
                           "imbalance": max(times) / (sum(times) / world),
                           "compute_bound_speedup": full / max(times)}), flush=True)
