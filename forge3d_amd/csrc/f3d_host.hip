@@ -522,7 +522,14 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
                  (unsigned long long)s.budget);
         // frames in flight: as many as were asked for and fit the budget; needs one band.  same_sun: the two sun
         // directions the frame head chooses between (wi, normalize(wi)) are the same bits -- nothing to predict
-        const uint32_t want = opts ? opts->frames_in_flight : 0u;
+        uint32_t want = opts ? opts->frames_in_flight : 0u;
+        if (want == F3D_FRAMES_IN_FLIGHT_AUTO) {
+            // images whose frame kernel cannot fill the chip twice are bound by the latency of a wave's ray chain
+            // however many lanes share a pixel: 256 x 256 at 8 spp 1 174 -> 2 177 Msamples/s with 16 frames in flight,
+            // 512 x 512 at 16 spp 3 393 -> 3 596, 1024 x 768 at 8 spp 4 627 -> 4 512 (tools/fd_probe3.py)
+            const uint64_t waves = ((uint64_t)px * P.sample_lanes + 63u) / 64u;
+            want = waves < 2u * 6144u ? 16u : 0u;
+        }
         const bool same_sun = f_bits(P.light.wi.x) == f_bits(P.light.wi_reuse.x) && f_bits(P.light.wi.y) == f_bits(P.light.wi_reuse.y) &&
                               f_bits(P.light.wi.z) == f_bits(P.light.wi_reuse.z);
         P.same_sun = same_sun ? 1u : 0u;
@@ -754,9 +761,26 @@ void enqueue_merge(f3d_session &s, uint32_t frame, bool collect) {
     for (auto &b : s.bands) b.last = frame;
 }
 
+// Frames [first, first + count), the last one closing a convergence window if `collect_last`.
+void enqueue_frame(f3d_session &s, uint32_t frame, bool collect, uint32_t part, bool fork);
+void fork_bands(f3d_session &s, bool clear_stats);
+void enqueue_range(f3d_session &s, uint32_t first, uint32_t count, bool collect_last) {
+    if (s.fd_frames) {  // frames in flight: batches traced in one launch, merged in order
+        for (uint32_t done = 0; done < count;) {
+            const uint32_t n = trace_batch(s, first + done, count - done);
+            enqueue_trace(s, first + done, n);
+            for (uint32_t i = 0; i < n; i++) enqueue_merge(s, first + done + i, collect_last && done + i + 1 == count);
+            done += n;
+        }
+        return;
+    }
+    if (count) fork_bands(s, collect_last);
+    for (uint32_t i = 0; i < count; i++) enqueue_frame(s, first + i, collect_last && i + 1 == count, 0u, false);
+}
+
 // part: 0 every band; 1 the edge bands (halo donors of a multi-GPU strip), then the session stream is
 // ordered after them; 2 the interior bands
-void enqueue_frame(f3d_session &s, uint32_t frame, bool collect, uint32_t part = 0u, bool fork = true) {
+void enqueue_frame(f3d_session &s, uint32_t frame, bool collect, uint32_t part, bool fork) {
     if (fork && part != 2u) fork_bands(s, collect);
     for (size_t i = 0; i < s.bands.size(); i++) {
         f3d_session::Band &b = s.bands[i];
@@ -871,19 +895,7 @@ int f3d_session_enqueue_frames(f3d_session *s, uint32_t first_frame, uint32_t co
                                char *err, size_t errlen) {
     return c_abi(err, errlen, [&] {
         DeviceGuard g(checked(s).device);
-        if (s->fd_frames) {  // frames in flight: batches of up to fd_frames frames traced at once, merged in order
-            for (uint32_t done = 0; done < count;) {
-                const uint32_t n = trace_batch(*s, first_frame + done, count - done);
-                enqueue_trace(*s, first_frame + done, n);
-                for (uint32_t i = 0; i < n; i++)
-                    enqueue_merge(*s, first_frame + done + i, collect_stats_on_last != 0 && done + i + 1 == count);
-                done += n;
-            }
-            return;
-        }
-        if (count) fork_bands(*s, collect_stats_on_last != 0);
-        for (uint32_t i = 0; i < count; i++)
-            enqueue_frame(*s, first_frame + i, collect_stats_on_last != 0 && i + 1 == count, 0u, false);
+        enqueue_range(*s, first_frame, count, collect_stats_on_last != 0);
     });
 }
 
@@ -924,7 +936,7 @@ int f3d_session_enqueue_frame_part(f3d_session *s, uint32_t frame, uint32_t part
         DeviceGuard g(checked(s).device);
         if (part != 1u && part != 2u) fail(F3D_STATUS_VALUE, "frame part must be 1 (edge rows) or 2 (interior)");
         if (s->fd_frames) fail(F3D_STATUS_VALUE, "sessions with frames in flight are driven by enqueue_trace / enqueue_merge");
-        enqueue_frame(*s, frame, collect_stats != 0, part);
+        enqueue_frame(*s, frame, collect_stats != 0, part, true);
     });
 }
 
@@ -1055,7 +1067,10 @@ int f3d_terrain_ref_render(const f3d_terrain_ref_desc *desc, f3d_terrain_ref_out
     int rc = F3D_STATUS_OK;
     try {
         const double t_setup = now_s();
-        session_init(*s, *desc, nullptr);
+        f3d_session_opts one_shot{};
+        one_shot.device = -1;
+        one_shot.frames_in_flight = F3D_FRAMES_IN_FLIGHT_AUTO;  // small images: batches of frames per launch
+        session_init(*s, *desc, &one_shot);
         hip_check(hipStreamSynchronize(s->stream), "setup sync");
         out->setup_seconds = now_s() - t_setup;
 
@@ -1069,7 +1084,7 @@ int f3d_terrain_ref_render(const f3d_terrain_ref_desc *desc, f3d_terrain_ref_out
         while (frames < desc->max_frames) {
             uint32_t stop = (frames / kWelfordWindow + 1u) * kWelfordWindow;
             if (stop > desc->max_frames) stop = desc->max_frames;
-            for (uint32_t f = frames; f < stop; f++) enqueue_frame(*s, f, f + 1 == stop);
+            enqueue_range(*s, frames, stop - frames, true);
             frames = stop;
             const uint32_t n_window = ((frames - 1u) % kWelfordWindow) + 1u;
             if (n_window >= 2u) {

@@ -121,6 +121,7 @@ int f3d_terrain_ref_render(const f3d_terrain_ref_desc *desc, f3d_terrain_ref_out
  * single-GPU image. */
 typedef struct f3d_session f3d_session;
 
+#define F3D_FRAMES_IN_FLIGHT_AUTO 0xFFFFFFFFu
 typedef struct f3d_session_opts {
     int32_t device;      /* HIP device ordinal, -1 = current */
     void *stream;        /* hipStream_t to enqueue on, NULL = the null stream */
@@ -154,7 +155,8 @@ typedef struct f3d_session_opts {
      * fits) and f3d_session_enqueue_frames traces N frames in ONE launch -- what a frame traces does not depend on
      * the frames before it -- and then runs the cheap ordered half (reservoir chain, accumulation) per frame.  No
      * per-frame tail: the way thin multi-GPU strips stay throughput-bound.  Results do not depend on N.
-     * f3d_session_frames_in_flight reports the effective value (0 when the scene is not eligible). */
+     * F3D_FRAMES_IN_FLIGHT_AUTO: 16 for images too small to fill the chip with one frame, else 0 (what
+     * f3d_terrain_ref_render uses).  f3d_session_frames_in_flight reports the effective value. */
     uint32_t frames_in_flight;
 } f3d_session_opts;
 
