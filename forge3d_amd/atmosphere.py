@@ -173,7 +173,10 @@ class AtmosphereLutHandle:
             if t <= b:
                 lower, upper, factor = i, i + 1, (t - a) / (b - a)
                 break
-        bank = find_bank(bank_dir)
+        try:
+            bank = find_bank(bank_dir)
+        except FileNotFoundError:
+            bank = None  # the anchors are baked on the GPU instead (_anchor)
         if lower == upper or factor <= 0.0:
             pick = lower
         elif factor >= 1.0:
@@ -181,9 +184,9 @@ class AtmosphereLutHandle:
         else:
             pick = None
         if pick is not None:
-            tables, deltas = _read_anchor(bank, TURBIDITY_BANK[pick], config.dimensions)
+            tables, deltas = _anchor(bank, TURBIDITY_BANK[pick], config.dimensions)
         else:
-            (ta, da), (tb, db) = (_read_anchor(bank, TURBIDITY_BANK[k], config.dimensions) for k in (lower, upper))
+            (ta, da), (tb, db) = (_anchor(bank, TURBIDITY_BANK[k], config.dimensions) for k in (lower, upper))
             tables = []
             for a, b in zip(ta, tb):
                 fa, fb = a.view(np.float16).astype(np.float32), b.view(np.float16).astype(np.float32)
@@ -205,6 +208,61 @@ class AtmosphereLutHandle:
     def byte_size(self) -> int:
         return 2 * (self.transmittance.size + self.single_scattering.size + self.accumulated_scattering.size
                     + self.aerial_perspective.size)
+
+
+_BAKED_ANCHORS: dict = {}
+
+
+def _anchor(bank, turbidity: float, dims: LutDimensions):
+    """The anchor of the bank at `turbidity`: the reference's shipped file when a bank directory is known (verified
+    against its locked SHA-256), otherwise the same tables baked on the GPU (bake_atmosphere_luts of the default
+    configuration at that turbidity -- what the shipped files are; the bake agrees with them to the last f16 bit in all
+    but a handful of values, tests/test_aether_bake.py) and kept for the process."""
+    if bank is not None:
+        return _read_anchor(bank, turbidity, dims)
+    if turbidity not in _BAKED_ANCHORS:
+        h = atmosphere_bake_luts(AtmosphereConfig(turbidity=float(turbidity), dimensions=dims))
+        _BAKED_ANCHORS[turbidity] = ([h.transmittance, h.single_scattering, h.accumulated_scattering, h.aerial_perspective], h.order_deltas)
+    return _BAKED_ANCHORS[turbidity]
+
+
+def atmosphere_bake_luts(config: "AtmosphereConfig | None" = None, **settings) -> "AtmosphereLutHandle":
+    """bake_atmosphere_luts (reference src/core/atmosphere/bake.rs:1481-1666, Python `atmosphere_bake_luts` of an
+    atmosphere-bake build): the AETHER tables of ANY valid configuration, baked on the GPU (csrc/f3d_aether_bake.hip,
+    ~0.1 s for the default dimensions; minutes of single-thread host code in the reference).  Keyword settings override
+    fields of `config` (default AtmosphereConfig())."""
+    import ctypes as C
+
+    from . import _native
+
+    config = replace(config or AtmosphereConfig(), **settings)
+    problem = config.problem()
+    if problem:
+        raise ValueError(f"invalid atmosphere configuration: {problem}")
+    d = config.dimensions
+
+    class _Cfg(C.Structure):
+        _fields_ = [(n, C.c_float) for n in ("turbidity", "ozone_du", "mie_g", "bottom_radius_m", "top_radius_m", "rayleigh_scale_height_m",
+                                             "mie_scale_height_m", "max_aerial_distance_m", "ground_albedo")] + \
+                   [("scattering_orders", C.c_uint32)] + \
+                   [(n, C.c_uint32) for n in ("transmittance_mu", "transmittance_height", "scattering_mu_view", "scattering_mu_sun",
+                                              "scattering_height", "scattering_nu", "aerial_distance", "aerial_mu_view", "aerial_height")]
+
+    cfg = _Cfg()
+    for name, _t in _Cfg._fields_:
+        setattr(cfg, name, getattr(config, name) if hasattr(config, name) else getattr(d, name))
+    counts = d.texel_counts()
+    tables = [np.zeros(n * 4, np.uint16) for n in counts]
+    deltas = np.zeros(int(config.scattering_orders), np.float32)
+    seconds = C.c_double(0.0)
+    err = C.create_string_buffer(512)
+    rc = _native.lib().f3d_aether_bake(C.byref(cfg), tables[0].ctypes.data, tables[1].ctypes.data, tables[2].ctypes.data,
+                                      tables[3].ctypes.data, deltas.ctypes.data, C.byref(seconds), err, len(err))
+    if rc != 0:
+        _native.raise_status(rc, err.value.decode(errors="replace"))
+    handle = AtmosphereLutHandle(config, tables[0], tables[1], tables[2], tables[3], deltas, False, None)
+    handle.bake_seconds = seconds.value  # device time of the bake kernels
+    return handle
 
 
 _SETTING_KEYS = ("enabled", "lut_handle", "turbidity", "ozone_du", "mie_g", "ground_albedo", "scattering_orders")

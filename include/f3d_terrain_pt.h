@@ -229,6 +229,23 @@ int f3d_atrous_denoise(const float *color, const float *albedo, const float *nor
                        uint32_t width, uint32_t height, int32_t iterations, float sigma_color, float sigma_albedo,
                        float sigma_normal, float sigma_depth, float *out, char *err, size_t errlen);
 
+/* ---- AETHER atmosphere LUT baker (the offline half) ------------------------------------
+ * Replaces bake_atmosphere_luts (reference src/core/atmosphere/bake.rs:1481-1666; cargo feature `atmosphere-bake`,
+ * single-thread host code there): the tables of an f3d_aether_luts for any AtmosphereConfig, not only the five shipped
+ * turbidity anchors.  Outputs are RGBA16F bit patterns in the reference's layouts (x fastest): transmittance
+ * [height][mu]; single and accumulated scattering [height][nu][mu_sun][mu_view]; aerial [height][mu_view][distance];
+ * order_deltas[scattering_orders] = mean |field| of every order (AtmosphereLuts::order_deltas). */
+typedef struct f3d_aether_bake_config { /* AtmosphereConfig + LutDimensions, bake.rs:32-42,132-144 */
+    float turbidity, ozone_du, mie_g, bottom_radius_m, top_radius_m, rayleigh_scale_height_m, mie_scale_height_m,
+        max_aerial_distance_m, ground_albedo;
+    uint32_t scattering_orders; /* 2..8 */
+    uint32_t transmittance_mu, transmittance_height, scattering_mu_view, scattering_mu_sun, scattering_height, scattering_nu,
+        aerial_distance, aerial_mu_view, aerial_height; /* 2..256 each */
+} f3d_aether_bake_config;
+int f3d_aether_bake(const f3d_aether_bake_config *config, uint16_t *transmittance, uint16_t *single_scattering,
+                    uint16_t *accumulated_scattering, uint16_t *aerial, float *order_deltas, double *seconds, char *err,
+                    size_t errlen);
+
 /* ---- smoke volume ray-marcher (BASELINE.json configs[4]) --------------------------
  * Replaces SmokeVolume::raymarch_rgba / raymarch_projection_rgba (reference src/smoke/render.rs:7-178, bound to
  * Python as SmokeDomain.render_rgba / render_projection_rgba, src/smoke/py.rs:531-625).  Fields are the reference's
