@@ -416,7 +416,7 @@ __device__ __forceinline__ void trace_lanes(const FrameParams &P, uint32_t frame
         if (act) {
             float4 *rec = out + 2u * (size_t)(s0 + j) * pixels;
             rec[0] = float4{o.a.x, o.a.y, o.a.z, o.target_pdf};
-            rec[1] = float4{o.b.x, o.b.y, o.b.z, (ph.hit.kind != 0u ? 1.0f : 0.0f) + (h.prev_valid ? 2.0f : 0.0f)};
+            rec[1] = float4{o.b.x, o.b.y, o.b.z, trace_code(ph.hit.kind != 0u, h.prev_valid)};
         }
         rng_skip(stream, 2u * n_act + 2u * (uint32_t)__popc(pred));
     }
@@ -442,37 +442,16 @@ __global__ __launch_bounds__(kWave) void k_merge(const FrameParams P) {
     const size_t pixels = (size_t)(P.row_end - P.row_begin) * P.cam.width;
     const size_t lp = active ? (size_t)(gy - P.row_begin) * P.cam.width + gx : 0u;
     const float4 *rec = P.trace + 2u * ((size_t)(P.frame_index - P.trace_first) * P.spp * pixels + lp);
-    FrameHead h;
-    h.centre_hit = h.prev_valid = false;
-    h.reuse_w = 1.0f;
-    h.rng = 0u;
     bool redo = false;
     if (active) {
-        h = frame_head(P, gx, gy);
-        if (P.same_sun == 0u) {  // was the sun direction of this pixel-frame predicted right?
-            for (uint32_t s = 0u; s < P.spp; s++) {
-                const float code = rec[2u * (size_t)s * pixels + 1u].w;  // 1 = hit, 2 = predicted "valid"
-                if ((code == 1.0f || code == 3.0f) && (code == 3.0f) != h.prev_valid) redo = true;
-#if defined(F3D_TIMING_FD_NO_REDO)  // timing experiment only (wrong image)
-                redo = false;
-#endif
-            }
+        const FrameHead h = frame_head(P, gx, gy);
+        if (P.same_sun == 0u) {
+            redo = merge_mispredicted(P, h, rec, pixels);
             // the prediction for the frames traced next (frame 0 says nothing: there every head is invalid by definition)
             if (P.frame_index > 0u) P.head[lp].y = h.prev_valid ? kHeadPrevValid : 0u;
         }
-    }
-    if (active && redo) {  // deferred to k_fix, which runs before the next frame's merge
-        P.fix_list[atomicAdd(&P.fix_count[P.frame_index & 1u], 1u)] = (uint32_t)lp;
-    } else if (active) {
-        V3 radiance = V3{0.0f, 0.0f, 0.0f};
-        Reservoir cand = empty_reservoir();
-        for (uint32_t s = 0u; s < P.spp; s++) {
-            const float4 r0 = rec[2u * (size_t)s * pixels], r1 = rec[2u * (size_t)s * pixels + 1u];
-            V3 a = V3{r0.x, r0.y, r0.z};
-            if (r1.w == 1.0f || r1.w == 3.0f) a = a * h.reuse_w;  // a hit: the sun term goes through the merged reservoir's weight
-            accumulate_sample(cand, radiance, a, V3{r1.x, r1.y, r1.z}, r0.w);
-        }
-        m2 = frame_tail(P, gx, gy, cand, radiance);
+        if (redo) P.fix_list[atomicAdd(&P.fix_count[P.frame_index & 1u], 1u)] = (uint32_t)lp;  // k_fix runs before the next merge
+        else m2 = merge_pixel(P, gx, gy, h, rec, pixels);
     }
     if (P.collect_stats != 0u) publish_window_stats(P, active && !redo, m2);
 }
@@ -496,20 +475,7 @@ __global__ __launch_bounds__(kWave) void k_fix(const FrameParams P) {
         if (active) {
             const uint32_t lp = P.fix_list[i];
             const uint32_t gx = lp % P.cam.width, gy = P.row_begin + lp / P.cam.width;
-            const FrameHead h = frame_head(P, gx, gy);
-            const float4 *rec = P.trace + 2u * ((size_t)(P.frame_index - P.trace_first) * P.spp * pixels + lp);
-            uint32_t rng = h.rng;
-            V3 radiance = V3{0.0f, 0.0f, 0.0f};
-            Reservoir cand = empty_reservoir();
-            for (uint32_t s = 0u; s < P.spp; s++) {
-                const PrimaryHit ph = sample_primary(P, gx, gy, rng, pend);
-                rng = ph.rng;
-                SampleOut o;
-                (void)sample_shade_sun(P, h, ph, rng, o, pend);
-                const float4 r1 = rec[2u * (size_t)s * pixels + 1u];
-                accumulate_sample(cand, radiance, o.a, V3{r1.x, r1.y, r1.z}, o.target_pdf);
-            }
-            m2 = frame_tail(P, gx, gy, cand, radiance);
+            m2 = fix_pixel(P, gx, gy, P.trace + 2u * ((size_t)(P.frame_index - P.trace_first) * P.spp * pixels + lp), pixels, pend);
         }
         if (P.collect_stats != 0u) publish_window_stats(P, active, m2);
     }

@@ -532,6 +532,75 @@ F3D_HD float frame_tail(const FrameParams &P, uint32_t gx, uint32_t gy, Reservoi
     return m2;
 }
 
+// ---- frames in flight: the per-pixel pieces (f3d_kernels.hip k_trace / k_merge / k_fix) -----------
+// A frame's records: two float4 per (sample, pixel) -- {a without the reuse weight, target pdf} and {b, code} with
+// code = (hit ? 1 : 0) + (the head was PREDICTED to read the reservoir's sun direction ? 2 : 0).
+F3D_HD float trace_code(bool hit, bool predicted_valid) { return (hit ? 1.0f : 0.0f) + (predicted_valid ? 2.0f : 0.0f); }
+F3D_HD bool trace_code_hit(float code) { return code == 1.0f || code == 3.0f; }
+
+// What k_trace leaves for one pixel-frame, one sample after the other on one lane (the sample-lane form is
+// f3d_kernels.hip trace_lanes): frame_pixel's sample loop with reuse_w = 1 and the predicted sun-direction choice.
+template <class Pending>
+F3D_HD void trace_pixel(const FrameParams &P, uint32_t frame, uint32_t gx, uint32_t gy, bool predicted_valid, float4 *rec,
+                        size_t pixels, Pending &pend) {
+    FrameHead h;
+    h.centre_hit = false;
+    h.prev_valid = predicted_valid;
+    h.reuse_w = 1.0f;
+    h.rng = P.cam.seed_hi ^ (gx * 1664525u) ^ (gy * 1013904223u) ^ (frame * 92837111u) ^ P.cam.seed_lo;
+    uint32_t rng = h.rng;
+    for (uint32_t s = 0u; s < P.spp; s++) {
+        const PrimaryHit ph = sample_primary(P, gx, gy, rng, pend);
+        rng = ph.rng;
+        const SampleOut o = sample_shade(P, h, ph, rng, pend);
+        rec[2u * (size_t)s * pixels] = float4{o.a.x, o.a.y, o.a.z, o.target_pdf};
+        rec[2u * (size_t)s * pixels + 1u] = float4{o.b.x, o.b.y, o.b.z, trace_code(ph.hit.kind != 0u, predicted_valid)};
+    }
+}
+
+// Was the sun direction of this pixel-frame predicted wrong (for a sample that used it)?
+F3D_HD bool merge_mispredicted(const FrameParams &P, const FrameHead &h, const float4 *rec, size_t pixels) {
+    bool redo = false;
+    for (uint32_t s = 0u; s < P.spp; s++) {
+        const float code = rec[2u * (size_t)s * pixels + 1u].w;
+        if (trace_code_hit(code) && (code == 3.0f) != h.prev_valid) redo = true;
+    }
+    return redo;
+}
+
+// The ordered half of a pixel-frame whose records are right: the samples through accumulate_sample with the sun term
+// multiplied by the real reuse weight (what sample_shade_sun does at that point in k_frame), then the tail.
+F3D_HD float merge_pixel(const FrameParams &P, uint32_t gx, uint32_t gy, const FrameHead &h, const float4 *rec, size_t pixels) {
+    V3 radiance = V3{0.0f, 0.0f, 0.0f};
+    Reservoir cand = empty_reservoir();
+    for (uint32_t s = 0u; s < P.spp; s++) {
+        const float4 r0 = rec[2u * (size_t)s * pixels], r1 = rec[2u * (size_t)s * pixels + 1u];
+        V3 a = V3{r0.x, r0.y, r0.z};
+        if (trace_code_hit(r1.w)) a = a * h.reuse_w;
+        accumulate_sample(cand, radiance, a, V3{r1.x, r1.y, r1.z}, r0.w);
+    }
+    return frame_tail(P, gx, gy, cand, radiance);
+}
+
+// A mispredicted pixel-frame again: head (idempotent), the pixel's primary and sun rays with the direction the real
+// head reads -- frame_pixel's sample loop, the IBL terms taken from the records -- and the tail.
+template <class Pending>
+F3D_HD float fix_pixel(const FrameParams &P, uint32_t gx, uint32_t gy, const float4 *rec, size_t pixels, Pending &pend) {
+    const FrameHead h = frame_head(P, gx, gy);
+    uint32_t rng = h.rng;
+    V3 radiance = V3{0.0f, 0.0f, 0.0f};
+    Reservoir cand = empty_reservoir();
+    for (uint32_t s = 0u; s < P.spp; s++) {
+        const PrimaryHit ph = sample_primary(P, gx, gy, rng, pend);
+        rng = ph.rng;
+        SampleOut o;
+        (void)sample_shade_sun(P, h, ph, rng, o, pend);
+        const float4 r1 = rec[2u * (size_t)s * pixels + 1u];
+        accumulate_sample(cand, radiance, o.a, V3{r1.x, r1.y, r1.z}, o.target_pdf);
+    }
+    return frame_tail(P, gx, gy, cand, radiance);
+}
+
 // The sample loop of main_terrain (:476-548): primary, sun-shadow and IBL-occlusion rays per sample,
 // one sample after the other on one lane.
 // (A per-lane ray state machine with ballot-gated shading transitions was measured at 0.5-0.7x of

@@ -51,10 +51,12 @@ def render(heightmap, width, height, camera=None, *, spacing=(1.0, 1.0), exagger
            mesh_indices=None, spp=1, max_frames=512, min_frames=32, variance_threshold=1e-3, seed=7,
            observer_latitude_deg=0.0, observer_longitude_deg=0.0, earth_model="ellipsoid",
            sphere_radius_m=6_371_008.8, refraction_model="bennett", refraction_k=0.13,
-           pressure_mbar=1013.25, temperature_c=15.0, rows=None, sample_lanes=1):
+           pressure_mbar=1013.25, temperature_c=15.0, rows=None, sample_lanes=1, frames_in_flight=0):
     """rows=(begin, end): render only that strip of the full image (no halo exchange; statistics runs).
     sample_lanes: 1 = frame_pixel; 2, 4, 8 = CPU mirror of the frame kernel's sample-lane form; the
-    result then carries "retraces" = primary rays traced again after a wrong hit-flag prediction."""
+    result then carries "retraces" = primary rays traced again after a wrong hit-flag prediction.
+    frames_in_flight > 1: batches of frames traced first, then the ordered half per frame (the per-pixel
+    code of k_trace / k_merge / k_fix); "retraced_pixels" = pixel-frames whose sun-direction prediction failed."""
     d, keep = _native.make_desc(heightmap, width, height, dict(camera or {}), spacing, exaggeration, albedo,
                                 sun_azimuth_deg, sun_elevation_deg, sun_intensity, env_map, env_intensity,
                                 mesh_vertices, mesh_indices, spp, max_frames, min_frames, variance_threshold,
@@ -75,15 +77,20 @@ def render(heightmap, width, height, camera=None, *, spacing=(1.0, 1.0), exagger
     lib().emul_set_sample_lanes(C.c_uint32(int(sample_lanes)))
     lib().emul_take_retraces.restype = C.c_uint64
     lib().emul_take_retraces()
+    lib().emul_take_retraced.restype = C.c_uint64
+    lib().emul_take_retraced()
+    lib().emul_set_frames_in_flight(C.c_uint32(int(frames_in_flight)))
     rc = lib().emul_render(C.byref(d), C.c_uint32(row_begin), C.c_uint32(row_end), C.c_void_p(rgba.ctypes.data),
                            C.c_void_p(alb.ctypes.data), C.c_void_p(nrm.ctypes.data), C.c_void_p(dep.ctypes.data),
                            C.byref(frames), C.byref(var), C.byref(conv), C.c_void_p(accum.ctypes.data),
                            C.c_void_p(m2.ctypes.data), C.c_void_p(res.ctypes.data), err, C.c_size_t(len(err)))
     retraces = int(lib().emul_take_retraces())
+    retraced = int(lib().emul_take_retraced())
+    lib().emul_set_frames_in_flight(C.c_uint32(0))
     lib().emul_set_sample_lanes(C.c_uint32(1))
     if rc != 0:
         raise RuntimeError(f"emul status {rc}: {err.value.decode()}")
-    return {"retraces": retraces, "rgba": rgba, "albedo": alb, "normal": nrm, "depth": dep, "frames": frames.value,
+    return {"retraces": retraces, "retraced_pixels": retraced, "rgba": rgba, "albedo": alb, "normal": nrm, "depth": dep, "frames": frames.value,
             "variance": var.value, "converged": bool(conv.value), "accum": accum, "m2": m2, "res": res}
 
 

@@ -325,6 +325,9 @@ static float frame_pixel_lanes(const FrameParams &P, uint32_t gx, uint32_t gy, u
     return frame_tail(P, gx, gy, cand, radiance);
 }
 
+static uint32_t g_frames_in_flight = 0u;  // > 1: the k_trace / k_merge / k_fix structure instead of one fused pass per frame
+static uint64_t g_retraced = 0;           // pixel-frames whose sun-direction prediction failed
+
 template <class Pending>
 static float frame_pixel_any(const FrameParams &P, uint32_t gx, uint32_t gy, Pending &pend) {
     return g_sample_lanes > 1u ? frame_pixel_lanes(P, gx, gy, g_sample_lanes, pend) : frame_pixel(P, gx, gy, pend);
@@ -564,18 +567,88 @@ int emul_render(const f3d_terrain_ref_desc *d, uint32_t row_begin, uint32_t row_
         uint32_t frames = 0;
         float variance = INFINITY;
         bool converged = false;
+        // frames in flight on the host: the same batches (2, 2, 4, 8, ... frames, never across a convergence window), the
+        // same prediction flags, the same three passes as f3d_host.hip / f3d_kernels.hip
+        const bool in_flight = g_frames_in_flight > 1u;
+        std::vector<float4> records;
+        std::vector<uint2> head_flags(in_flight ? px : 0);
+        uint32_t batch_end = 0u;
+        if (in_flight) {
+            P.same_sun = (f_bits(P.light.wi.x) == f_bits(P.light.wi_reuse.x) && f_bits(P.light.wi.y) == f_bits(P.light.wi_reuse.y) &&
+                          f_bits(P.light.wi.z) == f_bits(P.light.wi_reuse.z)) ? 1u : 0u;
+            if (getenv("F3D_EMUL_FORCE_PREDICTION")) P.same_sun = 0u;  // exercise prediction + re-trace even when the directions agree
+            for (size_t lp = 0; lp < px; lp++) {  // k_trace_init
+                const float4 g = gbuf[lp];
+                head_flags[lp] = uint2{0u, (g.w != 0.0f && dot(V3{g.x, g.y, g.z}, P.light.wi) > 0.0f) ? kHeadPrevValid : 0u};
+            }
+            P.head = head_flags.data();
+        }
         while (frames < d->max_frames) {
             P.frame_index = frames;
             P.res_out = res[frames & 1u].data();
             P.res_in = res[(frames & 1u) ^ 1u].data();
             float vmax_m2 = 0.0f;
             bool nonfinite = false;
+            if (in_flight) {
+                if (frames >= batch_end) {  // trace the next batch: every pixel, every frame of the batch
+                    uint32_t stop = (frames / kWelfordWindow + 1u) * kWelfordWindow;
+                    if (stop > d->max_frames) stop = d->max_frames;
+                    uint32_t ramp = 2u;
+                    while (ramp * 2u <= frames) ramp *= 2u;
+                    if (frames < 2u) ramp = 2u - frames;
+                    const uint32_t n = std::max(1u, std::min(std::min(g_frames_in_flight, stop - frames), ramp));
+                    records.assign((size_t)n * P.spp * px * 2u, float4{0.0f, 0.0f, 0.0f, 0.0f});
+                    P.trace = records.data();
+                    P.trace_first = frames;
+                    batch_end = frames + n;
+#pragma omp parallel for schedule(dynamic, 4)
+                    for (long y = row_begin; y < (long)row_end; y++) {
+                        ArrayPending pend;
+                        for (uint32_t x = 0; x < W; x++) {
+                            const size_t lp = (size_t)(y - row_begin) * W + x;
+                            for (uint32_t f = frames; f < batch_end; f++)
+                                trace_pixel(P, f, x, (uint32_t)y, f > 0u && (head_flags[lp].y & kHeadPrevValid) != 0u,
+                                            records.data() + 2u * ((size_t)(f - frames) * P.spp * px + lp), px, pend);
+                        }
+                    }
+                }
+                std::vector<uint32_t> fix_list;
+#pragma omp parallel for schedule(dynamic, 4) reduction(max : vmax_m2) reduction(|| : nonfinite)
+                for (long y = row_begin; y < (long)row_end; y++) {  // k_merge
+                    for (uint32_t x = 0; x < W; x++) {
+                        const size_t lp = (size_t)(y - row_begin) * W + x;
+                        const float4 *rec = records.data() + 2u * ((size_t)(frames - P.trace_first) * P.spp * px + lp);
+                        const FrameHead h = frame_head(P, x, (uint32_t)y);
+                        bool redo = false;
+                        if (P.same_sun == 0u) {
+                            redo = merge_mispredicted(P, h, rec, px);
+                            if (getenv("F3D_EMUL_FORCE_PREDICTION") && (lp % 97u) == (frames % 97u)) redo = true;  // and some re-traces for no reason
+                            if (frames > 0u) head_flags[lp].y = h.prev_valid ? kHeadPrevValid : 0u;
+                        }
+                        if (redo) {
+#pragma omp critical
+                            fix_list.push_back((uint32_t)lp);
+                        } else {
+                            const float v = merge_pixel(P, x, (uint32_t)y, h, rec, px);
+                            if (!f_finite(v)) nonfinite = true;
+                            else vmax_m2 = f_max(vmax_m2, f_max(v, 0.0f));
+                        }
+                    }
+                }
+                g_retraced += fix_list.size();
+                for (uint32_t lp : fix_list) {  // k_fix
+                    ArrayPending pend;
+                    const float v = fix_pixel(P, lp % W, row_begin + lp / W, records.data() + 2u * ((size_t)(frames - P.trace_first) * P.spp * px + lp), px, pend);
+                    if (!f_finite(v)) nonfinite = true;
+                    else vmax_m2 = f_max(vmax_m2, f_max(v, 0.0f));
+                }
+            }
             // F3D_EMUL_RAYLOG=<file>: dump the per-ray step log of the LAST frame
             const char *log_path = getenv("F3D_EMUL_RAYLOG");
             const bool logging = log_path && log_path[0] && frames + 1 == d->max_frames;
             std::vector<std::vector<RayLog>> pixel_logs(logging ? px : 0);
 #pragma omp parallel for schedule(dynamic, 4) reduction(max : vmax_m2) reduction(|| : nonfinite)
-            for (long y = row_begin; y < (long)row_end; y++) {
+            for (long y = row_begin; y < (long)(in_flight ? row_begin : row_end); y++) {
                 ArrayPending pend;
                 for (uint32_t x = 0; x < W; x++) {
                     if (logging) pend.log = &pixel_logs[(size_t)(y - row_begin) * W + x];
@@ -766,6 +839,12 @@ uint64_t emul_bvh_fingerprint(const float *verts, uint32_t nverts, const uint32_
     return h;
 }
 // sample lanes of the frame emulation (1 = frame_pixel; 2, 4, 8 = the frame_lanes mirror)
+void emul_set_frames_in_flight(uint32_t n) { g_frames_in_flight = n; }
+uint64_t emul_take_retraced() {
+    const uint64_t r = g_retraced;
+    g_retraced = 0;
+    return r;
+}
 void emul_set_sample_lanes(uint32_t lanes) { g_sample_lanes = (lanes == 2u || lanes == 4u || lanes == 8u) ? lanes : 1u; }
 uint64_t emul_take_retraces() {
     const uint64_t r = g_retraces;

@@ -210,3 +210,28 @@ def test_600k_triangle_bvh_reproduces_the_sweep():
     want = oracle.render(dem, 24, 24, cam, **kw)
     assert float((want["albedo"][..., 2] > 0.75).mean()) > 0.2  # buildings fill a good part of the view
     _same(emul.render(dem, 24, 24, cam, **kw), want)
+
+
+@pytest.mark.parametrize("size,spp,frames,in_flight,sun,force", [
+    ((96, 64), 4, 11, 4, (315.0, 45.0), False),     # batches 2, 2, 4, 3
+    ((64, 48), 2, 34, 16, (302.0, 24.0), False),    # crosses a Welford window: batches never do; the headline sun angles
+    ((80, 60), 3, 9, 8, (135.0, 12.0), True),       # predictions switched on whatever the bits, plus re-traces for no reason
+    ((72, 40), 1, 6, 2, (17.0, 61.0), True),
+])
+def test_frames_in_flight_structure_matches_the_oracle(monkeypatch, size, spp, frames, in_flight, sun, force):
+    """DESIGN.md 4.7 on the host: the per-pixel code of k_trace (records traced for a whole batch of frames first),
+    k_merge (head, records through the ordered sums with the real reuse weight, tail) and k_fix (mispredicted pixel-frames
+    traced again) -- same batches, same prediction flags as the device path -- reproduces the fused per-frame loop and
+    the oracle bit for bit, state buffers included."""
+    if force:
+        monkeypatch.setenv("F3D_EMUL_FORCE_PREDICTION", "1")
+    dem = scenes.golden_dem()
+    kw = scenes.fixed_frames(dict(scenes.scene_kwargs(dem), sun_azimuth_deg=sun[0], sun_elevation_deg=sun[1]), frames, spp=spp)
+    want = oracle.render(dem, size[0], size[1], scenes.CAM, dump_state=True, **kw)
+    got = emul.render(dem, size[0], size[1], scenes.CAM, frames_in_flight=in_flight, **kw)
+    _same(got, want)
+    assert np.array_equal(got["accum"][:, :3], want["accum"][:, :3])
+    assert np.array_equal(got["accum"][:, 3], want["welford"][:, 0])
+    assert np.array_equal(got["m2"], want["welford"][:, 1])
+    if force:
+        assert got["retraced_pixels"] > frames  # the re-trace pass ran in every frame
