@@ -169,6 +169,7 @@ def main():
     r.barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = r.session.kernel_timing(False)
+    rank_ms = r._gather_floats(elapsed / args.steps * 1e3) if world > 1 else [elapsed / args.steps * 1e3]
     elapsed = r.max_over_ranks(elapsed)
     kernel_ms = r.max_over_ranks(kernel_ms)
     # further windows of the same K frames (the accumulation simply continues): the spread of the measurement
@@ -204,7 +205,7 @@ def main():
                 "kernel_variant": args.variant,
                 "frames_in_flight": r.session.frames_in_flight(),
                 **({"strip_row_bounds": r.bounds, "strip_probe_ms": r.balance_log[-1]["ms"] if r.balance_log else None,
-                    "rccl_ranks": world, "halo_bytes_per_frame_rank0": halo_bytes,
+                    "rccl_ranks": world, "rank_ms_per_step": [round(x, 4) for x in rank_ms], "halo_bytes_per_frame_rank0": halo_bytes,
                     "dist_backend": os.environ.get("F3D_DIST_BACKEND") or "nccl"} if world > 1 else {}),
             },
         }
