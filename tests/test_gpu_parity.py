@@ -823,3 +823,40 @@ def test_frames_in_flight_with_predicted_sun_direction(f3d, az, el):
     assert np.float32(m2a) == np.float32(m2b)
     for key in ("rgba", "albedo", "normal", "depth"):
         assert np.array_equal(a[key], b[key], equal_nan=True), (az, el, key)
+
+
+def test_resolve_into_device_tensors_matches_the_host_resolve(f3d):
+    """The RCCL path of StripRenderer.gather_image: strips are resolved straight into torch device tensors
+    (f3d_session_resolve_device) that the gather then moves, and the validity flags are read from the caller-owned
+    statistics tensor.  Same bytes as the host resolve, for a strip with rows of its own and tensors taller than it."""
+    import torch
+
+    from forge3d_amd.distributed import HALO_ROWS, RES_BYTES, HipBackend
+
+    dem = scenes.golden_dem()
+    kw = scenes.fixed_frames(scenes.scene_kwargs(dem), 5, spp=2)
+    backend = HipBackend(0)
+    w, h, rows = 120, 90, (20, 71)
+    nbytes = (rows[1] - rows[0] + 2 * HALO_ROWS) * w * RES_BYTES
+    res = [backend.empty_bytes(nbytes), backend.empty_bytes(nbytes)]
+    stats = backend.empty_i32(4)
+    s = backend.make_session(dem, w, h, scenes.CAM, rows[0], rows[1], res, stats, dict(kw))
+    try:
+        s.enqueue_frames(0, 5, True)
+        s.window_stats()
+        want = s.resolve(5)
+        n = rows[1] - rows[0]
+        dev = res[0].device
+        t = {"rgba": torch.zeros((n + 7, w, 4), dtype=torch.uint8, device=dev), "albedo": torch.zeros((n + 7, w, 3), device=dev),
+             "normal": torch.zeros((n + 7, w, 3), device=dev), "depth": torch.zeros((n + 7, w, 1), device=dev)}
+        stats.zero_()
+        s.resolve_device(5, *(t[k].data_ptr() for k in ("rgba", "albedo", "normal", "depth")))
+        backend.sync()
+        flags = stats.cpu().numpy()
+        assert flags[2] != 0 and flags[3] == 0  # some reservoir is valid, none is broken
+        for key in ("rgba", "albedo", "normal"):
+            assert np.array_equal(t[key][:n].cpu().numpy(), np.asarray(want[key]).reshape(n, w, -1)), key
+        assert np.array_equal(t["depth"][:n, :, 0].cpu().numpy(), want["depth"], equal_nan=True)
+        assert float(t["albedo"][n:].abs().sum()) == 0.0  # nothing written past the strip
+    finally:
+        s.close()
