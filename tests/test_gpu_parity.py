@@ -429,16 +429,19 @@ def test_scaling_no_per_spp_blowup(f3d):
 # ---------------------------------------------------------------------------------------
 # size-independent properties at larger sizes
 # ---------------------------------------------------------------------------------------
-def test_strips_reproduce_the_full_image(f3d):
+@pytest.mark.parametrize("in_flight,frames", [(0, 6), (5, 11)])
+def test_strips_reproduce_the_full_image(f3d, in_flight, frames):
     """Any row partition must reproduce the single-strip image exactly once the 3-row
     reservoir halos are exchanged after every frame (here: device-to-device copies on one
-    GPU standing in for the RCCL point-to-point exchange)."""
+    GPU standing in for the RCCL point-to-point exchange).  in_flight > 0: the strips trace batches of
+    frames in one launch and exchange the halos between the merges (enqueue_trace / enqueue_merge), as the strip
+    driver does for three ranks and more; the middle strip has a halo on either side."""
     import torch
 
     from forge3d_amd.session import TerrainSession, reservoir_buffer_bytes
 
     dem = scenes.golden_dem()
-    W, H, frames, spp = 160, 96, 6, 2
+    W, H, spp = 160, 96, 2
     kw = scenes.fixed_frames(scenes.scene_kwargs(dem), frames, spp=spp)
     full = f3d.hybrid_render_terrain_reference(dem, W, H, scenes.CAM, **kw)
     bounds = [(0, 29), (29, 64), (64, 96)]
@@ -447,20 +450,37 @@ def test_strips_reproduce_the_full_image(f3d):
     for b, e in bounds:
         res = [torch.zeros(reservoir_buffer_bytes(e - b, W), dtype=torch.uint8, device=dev) for _ in range(2)]
         bufs.append(res)
-        sessions.append(TerrainSession(dem, W, H, scenes.CAM, row_begin=b, row_end=e,
+        sessions.append(TerrainSession(dem, W, H, scenes.CAM, row_begin=b, row_end=e, frames_in_flight=in_flight,
                                        ext_reservoirs=(res[0].data_ptr(), res[1].data_ptr()), **kw))
+        assert sessions[-1].frames_in_flight() == in_flight
     row = W * 16
-    for f in range(frames):
-        for s in sessions:
-            s.enqueue_frames(f, 1, False)
+
+    def exchange(which):
         torch.cuda.synchronize()
-        which = f & 1
         for i in range(len(bounds) - 1):
             up, dn = bufs[i][which], bufs[i + 1][which]
             rows_up = bounds[i][1] - bounds[i][0]
             dn[0:3 * row] = up[rows_up * row:(rows_up + 3) * row]          # my bottom rows -> their top halo
             up[(rows_up + 3) * row:(rows_up + 6) * row] = dn[3 * row:6 * row]  # their top rows -> my bottom halo
         torch.cuda.synchronize()
+
+    f = 0
+    while f < frames:
+        if in_flight:
+            n = sessions[0].trace_batch(f, frames - f)
+            for s in sessions:
+                assert s.trace_batch(f, frames - f) == n
+                s.enqueue_trace(f, n)
+            for g in range(f, f + n):
+                for s in sessions:
+                    s.enqueue_merge(g)
+                exchange(g & 1)
+            f += n
+        else:
+            for s in sessions:
+                s.enqueue_frames(f, 1, False)
+            exchange(f & 1)
+            f += 1
     parts = [s.resolve(frames) for s in sessions]
     for key in ("rgba", "albedo", "normal", "depth"):
         stitched = np.concatenate([p[key] for p in parts], axis=0)
