@@ -57,14 +57,14 @@ def parse_args():
 
 
 def kernel_source_hash() -> str:
-    """SHA-256 over the frame kernel's sources (f3d_kernels.hip, the host driver and every header they include,
-    transitively) plus the build flags: ties a PMC traffic figure under profiles/ to the code it was measured on.
-    Sources of the other rows (smoke, denoiser, LBVH ...) do not enter."""
+    """SHA-256 over the frame kernel's sources (f3d_kernels.hip and every header it includes, transitively) plus the
+    build flags: ties a PMC traffic figure under profiles/ to the device code it was measured on.  The host driver and
+    the sources of the other rows (smoke, denoiser, LBVH ...) do not enter."""
     import hashlib
     import re
 
     csrc = ROOT / "forge3d_amd" / "csrc"
-    todo, seen = ["f3d_kernels.hip", "f3d_host.hip"], set()
+    todo, seen = ["f3d_kernels.hip"], set()
     while todo:
         name = todo.pop()
         if name in seen or not (csrc / name).exists():

@@ -702,7 +702,7 @@ void join_bands(f3d_session &s, bool edges_only = false) {
 // batches are short and the long ones start from settled predictions (17 re-traced pixel-frames in 130 frames at 1080p).
 uint32_t trace_batch(const f3d_session &s, uint32_t frame, uint32_t remaining) {
     uint32_t ramp = 2u;
-    while (ramp * 2u <= frame) ramp *= 2u;  // the largest power of two <= frame (2 for frames 0..3)
+    while (ramp < s.fd_frames && ramp * 2u <= frame) ramp *= 2u;  // the largest power of two <= frame (2 for frames 0..3), capped
     if (frame < 2u) ramp = 2u - frame;
     return std::max(1u, std::min(std::min(s.fd_frames, remaining), ramp));
 }

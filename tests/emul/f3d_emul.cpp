@@ -594,7 +594,7 @@ int emul_render(const f3d_terrain_ref_desc *d, uint32_t row_begin, uint32_t row_
                     uint32_t stop = (frames / kWelfordWindow + 1u) * kWelfordWindow;
                     if (stop > d->max_frames) stop = d->max_frames;
                     uint32_t ramp = 2u;
-                    while (ramp * 2u <= frames) ramp *= 2u;
+                    while (ramp < g_frames_in_flight && ramp * 2u <= frames) ramp *= 2u;
                     if (frames < 2u) ramp = 2u - frames;
                     const uint32_t n = std::max(1u, std::min(std::min(g_frames_in_flight, stop - frames), ramp));
                     records.assign((size_t)n * P.spp * px * 2u, float4{0.0f, 0.0f, 0.0f, 0.0f});
