@@ -104,6 +104,7 @@ ABI = [
     ("f3d_aether_bake", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_double),
                                   C.c_char_p, C.c_size_t]),
     ("f3d_smoke_render", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_double), C.c_char_p, C.c_size_t]),
+    ("f3d_session_fingerprint", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     ("f3d_session_debug_wave_times", C.c_int, [C.c_void_p, C.c_void_p]),
     ("f3d_session_halo", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _P(C.c_void_p), _P(C.c_uint64)]),
     ("f3d_session_resolve", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -76,6 +76,10 @@ struct Ledger {
     void *alloc(size_t bytes, const char *what) {
         void *p = nullptr;
         hip_check(hipMalloc(&p, bytes ? bytes : 16), what);
+#if defined(F3D_DEBUG_POISON)  // debugging aid: F3D_POISON=<substring of the label, or "all"> fills fresh buffers with 0xA5
+        if (const char *pat = getenv("F3D_POISON"))
+            if (!strcmp(pat, "all") || strstr(what, pat)) (void)hipMemset(p, 0xA5, bytes ? bytes : 16);
+#endif
         owned.push_back(p);
         device_bytes += bytes;
         return p;
@@ -1046,6 +1050,56 @@ int f3d_session_kernel_timing(f3d_session *s, int32_t enable, double *avg_ms, ui
 }
 
 uint32_t f3d_session_sample_lanes(f3d_session *s) { return s ? s->params.sample_lanes : 0u; }
+
+// Diagnostics: FNV-style hashes of everything a frame launch reads -- the by-value uniforms (camera, light, terrain and
+// mesh scalars) and the device buffers behind them, plus the per-pixel state.  Equal fingerprints => equal frames.
+int f3d_session_fingerprint(f3d_session *s, uint64_t *out, uint32_t count) {
+    if (!s || !out || count < 16u) return F3D_STATUS_VALUE;
+    try {
+        DeviceGuard guard(s->device);
+        hip_check(hipStreamSynchronize(s->stream), "fingerprint");
+        for (auto &b : s->bands)
+            if (b.stream) hip_check(hipStreamSynchronize(b.stream), "fingerprint");
+        const FrameParams &P = s->params;
+        auto dev = [&](const void *p, size_t bytes) -> uint64_t {
+            if (!p || !bytes) return 0ull;
+            std::vector<uint8_t> host(bytes);
+            hip_check(hipMemcpy(host.data(), p, bytes, hipMemcpyDeviceToHost), "fingerprint download");
+            return hash_bytes(host.data(), bytes, 0x243F6A8885A308D3ull);
+        };
+        const TableLayout &L = s->scene ? s->scene->tables.layout : s->tables.layout;
+        const size_t px = (size_t)s->rows * s->width, res_n = (size_t)(s->rows + 2u * kHaloRows) * s->width;
+        TerrainDev t = P.terrain;
+        t.leaves = nullptr;
+        t.nodes = nullptr;
+        t.bands = nullptr;
+        MeshDev m = P.mesh;
+        m.vertices = nullptr;
+        m.indices = nullptr;
+        m.bvh_nodes = nullptr;
+        m.bvh_tris = nullptr;
+        const uint32_t scalars[8] = {P.spp, P.row_begin, P.row_end, P.tile_map, P.sample_lanes, P.same_sun, P.env.width, P.env.height};
+        out[0] = hash_bytes(&P.cam, sizeof(P.cam), 1);
+        out[1] = hash_bytes(&P.light, sizeof(P.light), 2);
+        out[2] = hash_bytes(&t, sizeof(t), 3);
+        out[3] = hash_bytes(&m, sizeof(m), 4);
+        out[4] = hash_bytes(scalars, sizeof(scalars), 5) ^ hash_bytes(&P.env.intensity, sizeof(float), 6);
+        out[5] = dev(P.terrain.leaves, L.leaf_count * sizeof(LeafRec));
+        out[6] = dev(P.terrain.bands, L.band_count * sizeof(NodeRec));
+        out[7] = dev(P.mesh.vertices, (size_t)P.mesh.vertex_count * sizeof(float4));
+        out[8] = dev(P.mesh.indices, (size_t)P.mesh.index_count * sizeof(uint32_t));
+        out[9] = dev(P.mesh.bvh_nodes, (size_t)P.mesh.bvh_node_count * sizeof(BvhNode));
+        out[10] = dev(P.mesh.bvh_tris, (size_t)P.mesh.index_count * sizeof(float4));
+        out[11] = dev(P.env.texels, (size_t)P.env.width * P.env.height * sizeof(float4));
+        out[12] = dev(s->gbuffer_n, px * sizeof(float4));
+        out[13] = dev(s->res[0], res_n * sizeof(PackedReservoir)) ^ (dev(s->res[1], res_n * sizeof(PackedReservoir)) * 3ull);
+        out[14] = dev(P.accum_mean, px * sizeof(float4)) ^ (dev(P.welford_m2, px * sizeof(float)) * 3ull);
+        out[15] = dev(P.head, P.head ? px * sizeof(uint2) : 0);
+        return F3D_STATUS_OK;
+    } catch (...) {
+        return F3D_STATUS_DEVICE;
+    }
+}
 
 int f3d_session_debug_wave_times(f3d_session *s, void *device_buffer) {
 #if defined(F3D_WAVE_TIMES)

@@ -26,7 +26,10 @@ namespace f3d {
 constexpr uint32_t kMaxLevels = 16;       // 8192-cell DEMs need 14
 constexpr uint32_t kRestirMCap = 512;     // TERRAIN_RESTIR_M_CAP, hybrid_terrain_traversal.wgsl:77
 constexpr uint32_t kWelfordWindow = 32;   // WELFORD_WINDOW, render_terrain.rs:236
-constexpr uint32_t kHaloRows = 3;         // spatial reuse radius R, pt_restir_spatial.wgsl:171
+// Rows of neighbour state a strip keeps above and below its own.  The spatial pass offsets a neighbour by
+// floor(u * 7) - 3 (pt_restir_spatial.wgsl:171-176) and u = f32(x) / 2^32 IS 1.0 for the top 128 values of x, so the
+// reach is [-3, +4], not the nominal radius 3: 2^-25 of the draws look four rows down.
+constexpr uint32_t kHaloRows = 4;
 constexpr uint32_t kDefaultLeafQuorum = 64;  // lanes with a queued leaf that trigger a wave drain
                                              // (64 = only when a FIFO is full or nobody marches; measured best)
 

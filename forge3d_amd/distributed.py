@@ -3,10 +3,10 @@
 The reference is single-device; this is new.  The frame shards by pixel
 rows: rank g owns image rows [g*H/N, (g+1)*H/N).  RNG and all per-pixel state are keyed by
 full-image coordinates, so the strips reproduce the single-GPU image exactly PROVIDED the
-spatial ReSTIR pass sees its +-3 pixel neighbourhood (reference pt_restir_spatial.wgsl:171,
+spatial ReSTIR pass sees its -3 .. +4 pixel neighbourhood (reference pt_restir_spatial.wgsl:171,
 199-204).  That is the one real exchange step of the path:
 
-  per frame   3 rows of packed reservoirs (3*W*16 B = 92 KB at 1080p) to each strip
+  per frame   4 rows of packed reservoirs (4*W*16 B = 123 KB at 1080p) to each strip
               neighbour, point-to-point (batch_isend_irecv);
   per window  all-reduce(MAX) of the 16-byte statistics record (variance gate);
   at the end  gather of the RGBA8 / AOV strips to rank 0.
@@ -28,7 +28,7 @@ import os
 
 import numpy as np
 
-HALO_ROWS = 3
+from .session import HALO_ROWS  # noqa: E402  (4: f3d_scene.h kHaloRows)
 RES_BYTES = 16
 WELFORD_WINDOW = 32
 
@@ -67,9 +67,9 @@ def strip_rows(height: int, world: int, rank: int):
     return begin, end
 
 
-def partition_rows(density, world: int, min_rows: int = 3):
+def partition_rows(density, world: int, min_rows: int = HALO_ROWS):
     """Boundaries b[0..world] of contiguous strips with (nearly) equal summed row density,
-    every strip at least `min_rows` rows (the spatial pass needs a full 3-row halo donor)."""
+    every strip at least `min_rows` rows (the spatial pass needs a full halo donor)."""
     density = np.asarray(density, np.float64)
     height = len(density)
     if height < world * min_rows:

@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _native
 
-HALO_ROWS = 3
+HALO_ROWS = 4  # f3d_scene.h kHaloRows: the spatial pass reaches [-3, +4] rows
 RESERVOIR_BYTES = 16
 WELFORD_WINDOW = 32
 
@@ -110,6 +110,17 @@ class TerrainSession:
         self._lib.f3d_session_retraced_pixels(self._handle, C.byref(total))
         return int(total.value)
 
+    FINGERPRINT_FIELDS = ("camera", "light", "terrain_scalars", "mesh_scalars", "scalars", "leaf_table", "band_tables",
+                          "mesh_vertices", "mesh_indices", "bvh_nodes", "bvh_triangles", "environment", "gbuffer",
+                          "reservoirs", "accumulation", "frame_heads")
+
+    def fingerprint(self) -> dict:
+        """Diagnostics (synchronises): hashes of everything a frame launch reads, by name."""
+        out = (C.c_uint64 * 16)()
+        if self._lib.f3d_session_fingerprint(self._handle, out, 16) != 0:
+            raise RuntimeError("f3d_session_fingerprint failed")
+        return dict(zip(self.FINGERPRINT_FIELDS, (int(v) for v in out)))
+
     def enqueue_frame_part(self, frame: int, part: int, collect_stats: bool = False):
         """One frame in two launches: part 1 = head + the strip's edge rows (the halo donors), part 2 = interior."""
         self._check(self._lib.f3d_session_enqueue_frame_part(self._handle, int(frame), int(part),
@@ -123,7 +134,7 @@ class TerrainSession:
         return float(m2.value), bool(bad.value)
 
     def halo(self, which: int, side: int):
-        """(device pointer, bytes) of a 3-row halo block of reservoir buffer `which`."""
+        """(device pointer, bytes) of a halo block (HALO_ROWS rows) of reservoir buffer `which`."""
         ptr, nbytes = C.c_void_p(None), C.c_uint64(0)
         rc = self._lib.f3d_session_halo(self._handle, int(which), int(side), C.byref(ptr), C.byref(nbytes))
         if rc != 0:

@@ -133,15 +133,15 @@ typedef struct f3d_session_opts {
                                    * (v / 1000000) % 10 sample lanes per pixel (1, 2, 4, 8; 0 = automatic) */
     /* Optional caller-owned DEVICE buffers (NULL -> the library allocates).  The
      * strip driver allocates these as torch tensors so RCCL can move them.
-     *   reservoirs[2]: ping-pong packed reservoirs, each (rows + 6) * width * 16 B,
-     *                  local row r holds image row row_begin - 3 + r;
+     *   reservoirs[2]: ping-pong packed reservoirs, each (rows + 8) * width * 16 B,
+     *                  local row r holds image row row_begin - 4 + r;
      *   stats:         4 x u32 {max m2 bits, nonfinite flag, any_valid flag, bad_reservoir flag}. */
     void *ext_reservoirs[2];
     void *ext_stats;
     /* Band pipelining: the strip is cut into `bands` horizontal bands (0 = automatic: 1 for strips that fill
      * the chip, several for thin multi-GPU strips) whose launches go round-robin to `band_streams` internal
      * HIP streams (0 = automatic); band b of frame f + 1 waits only for bands b - 1, b, b + 1 of frame f (the
-     * spatial reuse reads +-3 rows), so consecutive frames overlap and a thin strip is no longer bound by the
+     * spatial reuse reads -3 .. +4 rows), so consecutive frames overlap and a thin strip is no longer bound by the
      * latency of one wave's ray chain.  Results do not depend on either number. */
     uint32_t bands;
     uint32_t band_streams;
@@ -166,7 +166,7 @@ void f3d_session_destroy(f3d_session *session);
 
 /* Enqueue accumulation frames [first_frame, first_frame + count) on the session
  * stream; asynchronous.  Multi-strip callers enqueue one frame at a time and
- * exchange the 3-row halos of reservoir buffer (frame & 1) between frames.  When
+ * exchange the 4-row halos of reservoir buffer (frame & 1) between frames.  When
  * collect_stats_on_last != 0 the last frame of the batch also publishes the
  * convergence statistic read by f3d_session_window_stats. */
 int f3d_session_enqueue_frames(f3d_session *session, uint32_t first_frame, uint32_t count,
@@ -183,7 +183,7 @@ uint32_t f3d_session_trace_batch(f3d_session *session, uint32_t frame, uint32_t 
  * mispredicted (see frames_in_flight); a handful per frame after the first two. */
 int f3d_session_retraced_pixels(f3d_session *session, uint64_t *total);
 /* One frame in two steps, for strips of a multi-GPU job: part 1 = the strip's EDGE bands (they contain the
- * first and last 3 pixel rows, the halo a neighbouring strip needs; on return the session stream is ordered
+ * first and last 4 pixel rows, the halo a neighbouring strip needs; on return the session stream is ordered
  * after them), part 2 = the interior bands.  The caller starts the halo exchange between the two, so that it
  * overlaps the interior.  Same result as f3d_session_enqueue_frames(frame, 1). */
 int f3d_session_enqueue_frame_part(f3d_session *session, uint32_t frame, uint32_t part, int32_t collect_stats,
@@ -215,6 +215,12 @@ int f3d_session_info(f3d_session *session, uint64_t *gpu_resource_bytes, uint64_
 int f3d_session_kernel_timing(f3d_session *session, int32_t enable, double *avg_ms, uint32_t *launches);
 /* Sample lanes per pixel the frame kernel of this session runs with (1, 2, 4 or 8); 0 on a NULL session. */
 uint32_t f3d_session_sample_lanes(f3d_session *session);
+
+/* Diagnostics: out[0..15] = hashes of everything a frame launch of this session reads.  [0] camera, [1] light,
+ * [2] terrain scalars, [3] mesh scalars, [4] other scalars, [5] leaf table, [6] band tables, [7] mesh vertices,
+ * [8] mesh indices, [9] BVH nodes, [10] BVH triangles, [11] environment, [12] G-buffer, [13] reservoirs,
+ * [14] accumulation + Welford, [15] frame-head records.  Synchronises the session.  count >= 16. */
+int f3d_session_fingerprint(f3d_session *session, uint64_t *out, uint32_t count);
 
 /* Diagnostics (only in builds with -DF3D_WAVE_TIMES; F3D_STATUS_VALUE otherwise): every frame-kernel workgroup
  * writes its {start, end} wall clock (100 MHz ticks) to device_buffer[2 * workgroup]; NULL switches it off. */

@@ -1,7 +1,7 @@
 """world_size-2 (and 3) `gloo` tests of the row-strip driver on the CPU.
 
 forge3d_amd.distributed.StripRenderer is exercised exactly as bench.py / a multi-GPU job
-uses it -- per-frame 3-row reservoir halo exchange (batch_isend_irecv), per-window
+uses it -- per-frame 4-row reservoir halo exchange (batch_isend_irecv), per-window
 all-reduce(MAX) of the statistics record, final gather of the strips -- with the kernel
 emulator standing in for the HIP session.  The stitched image must equal the single-strip
 image bit for bit, because RNG and state are keyed by full-image coordinates.
@@ -57,7 +57,7 @@ def _worker(rank, world, port, out_path, mode):
         backend = CostBackend()
         kw = scenes.fixed_frames(kw, 6, spp=2)
     if mode == "bounds":
-        extra["row_bounds"] = [0, 7, 50] if world == 2 else [0, 3, 41, 50]
+        extra["row_bounds"] = [0, 7, 50] if world == 2 else [0, 4, 41, 50]
         kw = scenes.fixed_frames(kw, 6, spp=2)
     if mode == "noconv":  # the variance gate cannot be met: every rank must raise the reference's message
         kw = {**scenes.scene_kwargs(dem), "variance_threshold": 1e-12, "max_frames": 8, "min_frames": 2, "spp": 1}
@@ -155,14 +155,14 @@ def test_partition_rows_balances_density_and_respects_the_halo_minimum():
     density = np.where(np.arange(h) < 400, 0.2, 1.0)
     for world in (2, 4, 8):
         b = partition_rows(density, world)
-        assert b[0] == 0 and b[-1] == h and all(b1 - b0 >= 3 for b0, b1 in zip(b, b[1:]))
+        assert b[0] == 0 and b[-1] == h and all(b1 - b0 >= 4 for b0, b1 in zip(b, b[1:]))
         cost = [density[b0:b1].sum() for b0, b1 in zip(b, b[1:])]
         assert max(cost) / (sum(cost) / world) < 1.02
-    # degenerate densities fall back to equal strips; tiny images keep >= 3 rows per strip
-    assert partition_rows(np.zeros(12), 4) == [0, 3, 6, 9, 12]
-    assert partition_rows([1e9, 0, 0, 0, 0, 0, 0, 0, 0, 1e9], 3) == [0, 3, 7, 10]
+    # degenerate densities fall back to equal strips; tiny images keep >= HALO_ROWS rows per strip
+    assert partition_rows(np.zeros(16), 4) == [0, 4, 8, 12, 16]
+    assert partition_rows([1e9] + [0] * 11 + [1e9], 3) == [0, 4, 9, 13]
     with pytest.raises(ValueError):
-        partition_rows(np.ones(8), 3)
+        partition_rows(np.ones(11), 3)
     # the multiplicative update converges on a step-shaped cost within a few rounds
     true = np.where(np.arange(h) < 333, 0.15, 1.0)
     est, b = np.ones(h), partition_rows(np.ones(h), 8)

@@ -431,14 +431,14 @@ def test_scaling_no_per_spp_blowup(f3d):
 # ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("in_flight,frames", [(0, 6), (5, 11)])
 def test_strips_reproduce_the_full_image(f3d, in_flight, frames):
-    """Any row partition must reproduce the single-strip image exactly once the 3-row
+    """Any row partition must reproduce the single-strip image exactly once the 4-row
     reservoir halos are exchanged after every frame (here: device-to-device copies on one
     GPU standing in for the RCCL point-to-point exchange).  in_flight > 0: the strips trace batches of
     frames in one launch and exchange the halos between the merges (enqueue_trace / enqueue_merge), as the strip
     driver does for three ranks and more; the middle strip has a halo on either side."""
     import torch
 
-    from forge3d_amd.session import TerrainSession, reservoir_buffer_bytes
+    from forge3d_amd.session import HALO_ROWS as R, TerrainSession, reservoir_buffer_bytes
 
     dem = scenes.golden_dem()
     W, H, spp = 160, 96, 2
@@ -460,8 +460,8 @@ def test_strips_reproduce_the_full_image(f3d, in_flight, frames):
         for i in range(len(bounds) - 1):
             up, dn = bufs[i][which], bufs[i + 1][which]
             rows_up = bounds[i][1] - bounds[i][0]
-            dn[0:3 * row] = up[rows_up * row:(rows_up + 3) * row]          # my bottom rows -> their top halo
-            up[(rows_up + 3) * row:(rows_up + 6) * row] = dn[3 * row:6 * row]  # their top rows -> my bottom halo
+            dn[0:R * row] = up[rows_up * row:(rows_up + R) * row]                    # my bottom rows -> their top halo
+            up[(rows_up + R) * row:(rows_up + 2 * R) * row] = dn[R * row:2 * R * row]  # their top rows -> my bottom halo
         torch.cuda.synchronize()
 
     f = 0

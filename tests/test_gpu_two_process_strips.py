@@ -2,7 +2,7 @@
 backend (HipBackend: libf3dhip sessions on torch-owned device buffers), joined by a `gloo` process
 group.  RCCL refuses two ranks on one device, so the bytes are staged through the host here
 (StripRenderer._comm_device) -- everything else is the multi-GPU path of bench.py: measured load
-balancing with real probe frames, per-frame 3-row reservoir halo exchange, all-reduced variance gate,
+balancing with real probe frames, per-frame 4-row reservoir halo exchange, all-reduced variance gate,
 gathered strips.  The stitched image must equal the single-process image bit for bit."""
 from __future__ import annotations
 

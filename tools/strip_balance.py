@@ -3,7 +3,7 @@
 
 For N strips of the headline frame: time every strip of the equal partition and of each re-balanced
 partition on THIS GPU (one after the other), exactly as the ranks of a real job would, and report the
-compute-only bound on strong scaling T(full frame) / max_i T(strip i).  Communication (92 KB halo per
+compute-only bound on strong scaling T(full frame) / max_i T(strip i).  Communication (123 KB halo per
 neighbour and frame) is not included.
 
     python tools/strip_balance.py [--worlds 2,4,8] [--bands B] [--streams S] [--variant V] [--frames K]
