@@ -50,6 +50,10 @@ def test_a_unit_random_number_reaches_the_fourth_row_below():
     dem, size = scenes.golden_dem(4), (72, 50)
     kw = scenes.fixed_frames(dict(scenes.scene_kwargs(dem), seed=17256), 3, spp=2)
     full = emul.render(dem, size[0], size[1], scenes.CAM, **kw)["rgba"].reshape(size[1], size[0], 4)
+    from oracle import oracle
+
+    # the reference's arithmetic, restated: the oracle walks the full image and makes the same +4 read
+    assert np.array_equal(oracle.render(dem, size[0], size[1], scenes.CAM, **kw)["rgba"].reshape(size[1], size[0], 4), full)
     bounds = [(0, 28), (28, size[1])]  # pixel row 27 is the upper strip's last, row 31 the lower strip's fourth
     assert np.array_equal(_strips(dem, size, scenes.CAM, kw, bounds, 3, 4), full)
     # the nominal radius 3 is not enough: without the fourth row the chain that starts at (18, 27) goes wrong
