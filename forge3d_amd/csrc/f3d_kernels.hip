@@ -444,7 +444,7 @@ __global__ __launch_bounds__(kWave) void k_merge(const FrameParams P) {
     const float4 *rec = P.trace + 2u * ((size_t)(P.frame_index - P.trace_first) * P.spp * pixels + lp);
     bool redo = false;
     if (active) {
-        const FrameHead h = frame_head(P, gx, gy);
+        const FrameHead h = frame_head<true>(P, gx, gy);
         if (P.same_sun == 0u) {
             redo = merge_mispredicted(P, h, rec, pixels);
             // the prediction for the frames traced next (frame 0 says nothing: there every head is invalid by definition)
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(kWave) void k_trace_init(const FrameParams P) {
 // Frame head of the sample-lane form: one lane per pixel (8x8 tiles).
 __global__ __launch_bounds__(kWave) void k_head(const FrameParams P) {
     uint32_t gx, gy;
-    if (tile_pixel(P, gx, gy)) P.head[(size_t)(gy - P.row_begin) * P.cam.width + gx] = pack_head(frame_head(P, gx, gy));
+    if (tile_pixel(P, gx, gy)) P.head[(size_t)(gy - P.row_begin) * P.cam.width + gx] = pack_head(frame_head<true>(P, gx, gy));
 }
 
 // VARIANT is reserved for A/B builds (0 = the shipped kernel).

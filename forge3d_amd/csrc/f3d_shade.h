@@ -270,6 +270,12 @@ F3D_HD size_t reservoir_index(const FrameParams &P, uint32_t x, uint32_t y) {
 // specialised to the light table the driver binds (render_terrain.rs:756-781): one
 // directional light of importance 1 => p_sel = 1; one zeroed area light, never selected.
 // `frame` is the frame whose spatial pass this is.  n_raw = G-buffer normal record.
+// PREFETCH (the pixel-parallel passes: k_head, k_merge, k_resolve): which neighbour comes next depends on the ones
+// before it only through ONE bit each -- did the candidate draw its selection number -- so a lane would wait for
+// nine dependent loads in a row.  Validity is spatially coherent, so the walk is predicted with every neighbour
+// behaving as the pixel itself did, the eight predicted records are fetched at once, and the real walk takes a
+// record from that set whenever it is the one it wants (else it loads it: the result is the same either way).
+template <bool PREFETCH = false>
 F3D_HD Reservoir spatial_reuse(const FrameParams &P, const PackedReservoir *res, uint32_t gx, uint32_t gy,
                                uint32_t frame, V3 n_raw) {
     const uint32_t W = P.cam.width, H = P.cam.height;
@@ -282,32 +288,55 @@ F3D_HD Reservoir spatial_reuse(const FrameParams &P, const PackedReservoir *res,
     float chosen_pdf = self.target_pdf;
     float wsum = 0.0f;
     uint32_t m_total = 0u;
-    auto consider = [&](const Reservoir &r) F3D_LAMBDA {
-        if (r.m == 0u) return;
-        if (!r.directional) return;  // light_type 0: no sample ever stored
-        if (!facing) return;
+    auto consider = [&](const Reservoir &r) F3D_LAMBDA {  // returns whether the candidate drew a number
+        if (r.m == 0u) return false;
+        if (!r.directional) return false;  // light_type 0: no sample ever stored
+        if (!facing) return false;
         const float p_curr = 1.0f;
-        if (r.target_pdf <= 0.0f) return;
+        if (r.target_pdf <= 0.0f) return false;
         const float w = r.w_sum * (p_curr / f_max(r.target_pdf, 1e-6f));
-        if (w <= 0.0f) return;
+        if (w <= 0.0f) return false;
         wsum = wsum + w;
         const float u = rng_next(seed);
         if (u < w / wsum) {
             chosen_directional = true;
             chosen_pdf = p_curr;
         }
+        return true;
     };
-    consider(self);
-    m_total += self.m;
-    for (uint32_t i = 0u; i < 8u; i++) {
-        const int rx = (int)f_floor(rng_next(seed) * 7.0f) - 3;
-        const int ry = (int)f_floor(rng_next(seed) * 7.0f) - 3;
-        if (rx == 0 && ry == 0) continue;
+    auto neighbour = [&](uint32_t &stream, size_t &index) F3D_LAMBDA {  // false: the offset (0, 0) is skipped
+        const int rx = (int)f_floor(rng_next(stream) * 7.0f) - 3;
+        const int ry = (int)f_floor(rng_next(stream) * 7.0f) - 3;
+        if (rx == 0 && ry == 0) return false;
         int qx = (int)gx + rx, qy = (int)gy + ry;
         qx = qx < 0 ? 0 : (qx > (int)W - 1 ? (int)W - 1 : qx);
         qy = qy < 0 ? 0 : (qy > (int)H - 1 ? (int)H - 1 : qy);
-        const Reservoir rn = unpack(res[reservoir_index(P, (uint32_t)qx, (uint32_t)qy)]);
-        consider(rn);
+        index = reservoir_index(P, (uint32_t)qx, (uint32_t)qy);
+        return true;
+    };
+    const bool self_drew = consider(self);
+    m_total += self.m;
+    constexpr size_t kNone = ~(size_t)0;
+    PackedReservoir ahead[PREFETCH ? 8 : 1];
+    size_t ahead_index[PREFETCH ? 8 : 1];
+    if (PREFETCH) {
+        uint32_t stream = seed;
+#pragma unroll
+        for (uint32_t i = 0u; i < 8u; i++) {
+            ahead_index[i] = kNone;
+            size_t index;
+            if (!neighbour(stream, index)) continue;
+            ahead_index[i] = index;
+            ahead[i] = res[index];
+            if (self_drew) (void)rng_next(stream);
+        }
+    }
+#pragma unroll
+    for (uint32_t i = 0u; i < 8u; i++) {
+        size_t index;
+        if (!neighbour(seed, index)) continue;
+        const Reservoir rn = unpack((PREFETCH && ahead_index[PREFETCH ? i : 0u] == index) ? ahead[PREFETCH ? i : 0u] : res[index]);
+        (void)consider(rn);
         m_total += rn.m;
     }
     Reservoir out;
@@ -345,11 +374,12 @@ struct FrameHead {
 // again only by the temporal merge at the very end of the frame, so it is parked in this pixel's
 // slot of the OUTPUT reservoir buffer (which the same lane overwrites in frame_tail) instead of
 // occupying five registers across the whole sample loop.
+template <bool PREFETCH = false>
 F3D_HD FrameHead frame_head(const FrameParams &P, uint32_t gx, uint32_t gy) {
     const size_t lp = (size_t)(gy - P.row_begin) * P.cam.width + gx;  // strip-local pixel
     const float4 g = P.gbuffer_n[lp];
     Reservoir prev = empty_reservoir();
-    if (P.frame_index > 0u) prev = spatial_reuse(P, P.res_in, gx, gy, P.frame_index - 1u, V3{g.x, g.y, g.z});
+    if (P.frame_index > 0u) prev = spatial_reuse<PREFETCH>(P, P.res_in, gx, gy, P.frame_index - 1u, V3{g.x, g.y, g.z});
     // M-clamp, hybrid_terrain_traversal.wgsl:452-462
     if (prev.m > kRestirMCap) {
         const float scale = (float)kRestirMCap / (float)prev.m;
@@ -645,7 +675,7 @@ F3D_HD uint32_t resolve_pixel(const FrameParams &P, uint32_t frames, uint32_t gx
                               const float *depth = nullptr) {
     const size_t lp = (size_t)(gy - P.row_begin) * P.cam.width + gx;
     const float4 g = P.gbuffer_n[lp];
-    const Reservoir r = spatial_reuse(P, P.res_in, gx, gy, frames - 1u, V3{g.x, g.y, g.z});
+    const Reservoir r = spatial_reuse<true>(P, P.res_in, gx, gy, frames - 1u, V3{g.x, g.y, g.z});
     uint32_t flags = 0u;
     if (!(f_finite(r.w_sum) && f_finite(r.weight) && f_finite(r.target_pdf))) flags |= 2u;
     if (r.m > 0u && r.weight > 0.0f && r.target_pdf > 0.0f) flags |= 1u;

@@ -618,7 +618,7 @@ int emul_render(const f3d_terrain_ref_desc *d, uint32_t row_begin, uint32_t row_
                     for (uint32_t x = 0; x < W; x++) {
                         const size_t lp = (size_t)(y - row_begin) * W + x;
                         const float4 *rec = records.data() + 2u * ((size_t)(frames - P.trace_first) * P.spp * px + lp);
-                        const FrameHead h = frame_head(P, x, (uint32_t)y);
+                        const FrameHead h = frame_head<true>(P, x, (uint32_t)y);
                         bool redo = false;
                         if (P.same_sun == 0u) {
                             redo = merge_mispredicted(P, h, rec, px);
