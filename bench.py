@@ -147,7 +147,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     from forge3d_amd import datasets
-    from forge3d_amd.distributed import StripRenderer, init_process_group
+    from forge3d_amd.distributed import HALO_ROWS, StripRenderer, init_process_group
 
     init_process_group(world, rank)
     dem, cam, kw = datasets.rainier_proxy_scene(args.dem)
@@ -184,7 +184,7 @@ def main():
         window_ms.append(r.max_over_ranks(time.perf_counter() - t1) / args.steps * 1e3)
     # final composition (untimed, but exercised): gather strips to rank 0
     image = r.gather_image(total_frames)
-    halo_bytes = 0 if world == 1 else 3 * args.width * 16 * ((1 if rank > 0 else 0) + (1 if rank < world - 1 else 0))
+    halo_bytes = 0 if world == 1 else HALO_ROWS * args.width * 16 * ((1 if rank > 0 else 0) + (1 if rank < world - 1 else 0))
 
     if rank == 0:
         samples_per_step = args.width * args.height * args.spp
