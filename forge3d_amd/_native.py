@@ -129,6 +129,7 @@ ABI = [
     ("f3d_device_count", C.c_int, []),
     ("f3d_device_name", C.c_char_p, [C.c_int32]),
     ("f3d_version", C.c_char_p, []),
+    ("f3d_source_digest", C.c_char_p, []),
 ]
 
 _lib = None
@@ -136,6 +137,33 @@ _lib = None
 
 def library_path() -> Path:
     return Path(os.environ.get("F3D_HIP_LIBRARY", str(LIB_PATH)))
+
+
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # numerics contract: no implicit FMA contraction on host or device
+    "-ffp-contract=off",
+    # the SLP vectoriser pairs independent f32 operations into v_pk_* instructions; on the 80-VGPR frame kernel
+    # that costs register pairs and moves: 5763 -> 6362 Msamples/s without it (profiles/README.md)
+    "-fno-slp-vectorize",
+]
+HIP_SOURCES = ["f3d_kernels.hip", "f3d_host.hip", "f3d_denoise.hip", "f3d_smoke.hip", "f3d_lbvh.hip", "f3d_wavefront.hip",
+               "f3d_aether_bake.hip"]
+
+
+def source_digest() -> str:
+    """What f3d_source_digest() of a library built NOW would return: SHA-256 over the compiler flags, every file of
+    csrc/ and include/ (names and bytes), first 16 hex digits.  None when the sources are not next to the package."""
+    import hashlib
+
+    csrc, inc = _PKG / "csrc", _PKG.parent / "include"
+    if not csrc.is_dir() or not inc.is_dir():
+        return None
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS + HIP_SOURCES).encode())
+    for f in sorted(csrc.glob("*.h")) + sorted(csrc.glob("*.hip")) + sorted(inc.glob("*.h")):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
 
 
 def lib() -> C.CDLL:
@@ -161,6 +189,14 @@ def lib() -> C.CDLL:
             fn = getattr(L, name)  # AttributeError if the export is missing
             fn.restype = restype
             fn.argtypes = argtypes
+        # what runs must be what is in the tree: a library next to its sources has to be built from exactly them
+        # (an A/B library named by F3D_HIP_LIBRARY is the caller's own business)
+        want = source_digest() if "F3D_HIP_LIBRARY" not in os.environ else None
+        have = L.f3d_source_digest().decode()
+        if want is not None and have != want:
+            raise RuntimeError(
+                f"forge3d_amd: {path} was built from other sources (digest {have}, tree {want}) -- run "
+                "`python -c 'import __graft_entry__ as g; g.build()'`")
         _lib = L
     return _lib
 

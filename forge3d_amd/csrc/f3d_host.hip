@@ -1360,4 +1360,11 @@ const char *f3d_device_name(int32_t device) {
 
 const char *f3d_version(void) { return "forge3d_amd 0.1.0 (gfx950 terrain path tracer)"; }
 
+#ifndef F3D_SOURCE_DIGEST
+#define F3D_SOURCE_DIGEST "unknown"
+#endif
+// SHA-256 (first 16 hex digits) of the sources and compiler flags this library was built from: __graft_entry__.build_hip
+// passes it in, forge3d_amd/_native.py compares it with the sources next to the library, so "what ran" is "what is in the tree".
+const char *f3d_source_digest(void) { return F3D_SOURCE_DIGEST; }
+
 }  // extern "C"

@@ -317,6 +317,9 @@ uint32_t f3d_scene_cache_entries(void);
 int f3d_device_count(void);
 const char *f3d_device_name(int32_t device); /* gcnArchName, "" when unavailable */
 const char *f3d_version(void);
+/* First 16 hex digits of the SHA-256 of the sources + compiler flags the library was built from ("unknown" for a
+ * build that did not go through __graft_entry__.build_hip). */
+const char *f3d_source_digest(void);
 
 #ifdef __cplusplus
 }

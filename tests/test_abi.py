@@ -130,3 +130,15 @@ def test_product_package_never_imports_the_oracle():
     # and the shared library links nothing but the HIP runtime / libstdc++
     out = subprocess.run(["ldd", str(ROOT / "forge3d_amd" / "libf3dhip.so")], capture_output=True, text=True).stdout
     assert "oracle" not in out and "emul" not in out
+
+
+def test_the_library_says_which_sources_it_was_built_from():
+    """f3d_source_digest: __graft_entry__.build_hip stamps the SHA-256 of csrc/ + include/ + the compiler flags into
+    the library, _native.lib() refuses a library whose stamp differs from the tree, build_hip rebuilds exactly then."""
+    import __graft_entry__ as entry
+    from forge3d_amd import _native
+
+    digest = _native.source_digest()
+    assert digest and len(digest) == 16
+    assert _native.lib().f3d_source_digest().decode() == digest
+    assert entry._built_digest(entry.LIB) == digest  # so build() has nothing to do
