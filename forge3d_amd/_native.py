@@ -130,6 +130,7 @@ ABI = [
     ("f3d_device_name", C.c_char_p, [C.c_int32]),
     ("f3d_version", C.c_char_p, []),
     ("f3d_source_digest", C.c_char_p, []),
+    ("f3d_debug_poison", None, [C.c_int32]),
 ]
 
 _lib = None
@@ -199,6 +200,12 @@ def lib() -> C.CDLL:
                 "`python -c 'import __graft_entry__ as g; g.build()'`")
         _lib = L
     return _lib
+
+
+def debug_poison(pattern: int) -> None:
+    """Diagnostics: fill every device buffer allocated from now on (and guard regions around it) with this byte;
+    a negative pattern switches it off.  Results must not depend on it (csrc/f3d_devmem.h)."""
+    lib().f3d_debug_poison(int(pattern))
 
 
 def raise_status(status: int, message: str):

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "f3d_setup.h"
+#include "f3d_devmem.h"
 
 using namespace f3d;
 
@@ -475,7 +476,7 @@ extern "C" int f3d_aether_bake(const f3d_aether_bake_config *config, uint16_t *t
 
         auto alloc = [&](size_t bytes, const char *what) {
             void *p = nullptr;
-            hip_ok(hipMalloc(&p, bytes), what);
+            hip_ok(device_alloc(&p, bytes), what);
             owned.push_back(p);
             return p;
         };
@@ -531,6 +532,6 @@ extern "C" int f3d_aether_bake(const f3d_aether_bake_config *config, uint16_t *t
     } catch (...) {
         rc = F3D_STATUS_DEVICE;
     }
-    for (void *p : owned) (void)hipFree(p);
+    for (void *p : owned) (void)device_free(p);
     return rc;
 }

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/f3d_terrain_pt.h"
+#include "f3d_devmem.h"
 
 namespace {
 
@@ -103,11 +104,11 @@ __global__ __launch_bounds__(256) void k_atrous(const AtrousParams P) {
 struct DeviceBuffers {
     std::vector<void *> owned;
     ~DeviceBuffers() {
-        for (void *p : owned) (void)hipFree(p);
+        for (void *p : owned) (void)f3d::device_free(p);
     }
     float *upload(const float *host, size_t floats, std::string &why) {
         void *p = nullptr;
-        if (hipMalloc(&p, floats * sizeof(float)) != hipSuccess) {
+        if (f3d::device_alloc(&p, floats * sizeof(float)) != hipSuccess) {
             why = "device allocation failed";
             return nullptr;
         }

@@ -11,11 +11,14 @@
 // GPU.  There is no CPU fallback: every entry point that computes needs a HIP device.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <exception>
 #include <memory>
 #include <mutex>
 #include <new>
+#include <unordered_map>
 
+#include "f3d_devmem.h"
 #include "f3d_launch.h"
 #include "f3d_lbvh.h"
 #include "f3d_setup.h"
@@ -66,6 +69,32 @@ f3d_session &checked(f3d_session *s) {
 
 }  // namespace
 
+// ---- poison mode of the device allocator (f3d_devmem.h) ----
+namespace f3d {
+namespace {
+int poison_from_env() {  // F3D_POISON=<0..255>: a whole process (e.g. the GPU test suite) in poison mode
+    const char *v = getenv("F3D_POISON");
+    return (v && *v) ? (atoi(v) & 0xFF) : -1;
+}
+std::atomic<int> g_poison_pattern{poison_from_env()};
+std::mutex g_poison_mutex;
+std::unordered_map<void *, void *> g_poison_bases;
+}  // namespace
+int poison_pattern() { return g_poison_pattern.load(); }
+void poison_register(void *user, void *base) {
+    std::lock_guard<std::mutex> lock(g_poison_mutex);
+    g_poison_bases[user] = base;
+}
+void *poison_take(void *user) {
+    std::lock_guard<std::mutex> lock(g_poison_mutex);
+    auto it = g_poison_bases.find(user);
+    if (it == g_poison_bases.end()) return nullptr;
+    void *base = it->second;
+    g_poison_bases.erase(it);
+    return base;
+}
+}  // namespace f3d
+
 namespace {
 
 // ---- device memory ledger (the reference's TrackedGpu / global memory tracker) ----
@@ -75,11 +104,7 @@ struct Ledger {
     uint64_t host_visible_peak = 0;
     void *alloc(size_t bytes, const char *what) {
         void *p = nullptr;
-        hip_check(hipMalloc(&p, bytes ? bytes : 16), what);
-#if defined(F3D_DEBUG_POISON)  // debugging aid: F3D_POISON=<substring of the label, or "all"> fills fresh buffers with 0xA5
-        if (const char *pat = getenv("F3D_POISON"))
-            if (!strcmp(pat, "all") || strstr(what, pat)) (void)hipMemset(p, 0xA5, bytes ? bytes : 16);
-#endif
+        hip_check(device_alloc(&p, bytes), what);
         owned.push_back(p);
         device_bytes += bytes;
         return p;
@@ -88,7 +113,7 @@ struct Ledger {
         for (auto it = owned.begin(); it != owned.end(); ++it)
             if (*it == p) {
                 owned.erase(it);
-                (void)hipFree(p);
+                (void)device_free(p);
                 device_bytes -= bytes;
                 return;
             }
@@ -101,7 +126,7 @@ struct Ledger {
         if (bytes > host_visible_peak) host_visible_peak = bytes;
     }
     void release() {
-        for (void *p : owned) (void)hipFree(p);
+        for (void *p : owned) (void)device_free(p);
         owned.clear();
     }
 };
@@ -1366,5 +1391,9 @@ const char *f3d_version(void) { return "forge3d_amd 0.1.0 (gfx950 terrain path t
 // SHA-256 (first 16 hex digits) of the sources and compiler flags this library was built from: __graft_entry__.build_hip
 // passes it in, forge3d_amd/_native.py compares it with the sources next to the library, so "what ran" is "what is in the tree".
 const char *f3d_source_digest(void) { return F3D_SOURCE_DIGEST; }
+
+// Diagnostics: pattern 0..255 = every device buffer allocated from now on lies between two guard regions and all of it
+// is filled with that byte (f3d_devmem.h); negative = off.  Results must not depend on it.
+void f3d_debug_poison(int32_t pattern) { f3d::g_poison_pattern.store(pattern < 0 ? -1 : (pattern & 0xFF)); }
 
 }  // extern "C"

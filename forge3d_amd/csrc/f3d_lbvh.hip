@@ -26,6 +26,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "f3d_lbvh.h"
+#include "f3d_devmem.h"
 #include "f3d_math.h"
 
 namespace f3d {
@@ -242,12 +243,12 @@ hipError_t build_mesh_lbvh(const float4 *d_vertices, uint32_t vertex_count, cons
     if (ntri == 0u) return hipSuccess;
     std::vector<void *> scratch;
     auto grab = [&](size_t bytes, void **out) {
-        const hipError_t e = hipMalloc(out, bytes ? bytes : 16);
+        const hipError_t e = device_alloc(out, bytes);
         if (e == hipSuccess) scratch.push_back(*out);
         return e;
     };
     auto release = [&]() {
-        for (void *p : scratch) (void)hipFree(p);
+        for (void *p : scratch) (void)device_free(p);
     };
     LbvhParams P{};
     P.vertices = d_vertices;
@@ -309,9 +310,9 @@ hipError_t build_mesh_lbvh(const float4 *d_vertices, uint32_t vertex_count, cons
         // outputs (owned by the caller)
         BvhNode *nodes = nullptr;
         float4 *tris = nullptr;
-        if ((err = hipMalloc((void **)&nodes, (size_t)total * sizeof(BvhNode))) != hipSuccess) break;
-        if ((err = hipMalloc((void **)&tris, (size_t)n * 3 * sizeof(float4))) != hipSuccess) {
-            (void)hipFree(nodes);
+        if ((err = device_alloc((void **)&nodes, (size_t)total * sizeof(BvhNode))) != hipSuccess) break;
+        if ((err = device_alloc((void **)&tris, (size_t)n * 3 * sizeof(float4))) != hipSuccess) {
+            (void)device_free(nodes);
             break;
         }
         P.out_nodes = nodes;
@@ -322,8 +323,8 @@ hipError_t build_mesh_lbvh(const float4 *d_vertices, uint32_t vertex_count, cons
         uint32_t root_size = 0;
         if ((err = hipMemcpyAsync(&root_size, P.size + (n == 1u ? 0u : 0u), sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess ||
             (err = hipStreamSynchronize(stream)) != hipSuccess || (err = hipGetLastError()) != hipSuccess) {
-            (void)hipFree(nodes);
-            (void)hipFree(tris);
+            (void)device_free(nodes);
+            (void)device_free(tris);
             break;
         }
         result->nodes = nodes;

@@ -14,6 +14,7 @@
 #include <exception>
 
 #include "f3d_setup.h"
+#include "f3d_devmem.h"
 
 using namespace f3d;
 
@@ -332,7 +333,7 @@ extern "C" int f3d_smoke_render(const f3d_smoke_volume *vol, const f3d_smoke_vie
 
         auto alloc = [&](size_t bytes, const char *what) {
             void *p = nullptr;
-            hip_ok(hipMalloc(&p, bytes), what);
+            hip_ok(device_alloc(&p, bytes), what);
             owned.push_back(p);
             return p;
         };
@@ -374,6 +375,6 @@ extern "C" int f3d_smoke_render(const f3d_smoke_volume *vol, const f3d_smoke_vie
     } catch (...) {
         rc = F3D_STATUS_DEVICE;
     }
-    for (void *p : owned) (void)hipFree(p);
+    for (void *p : owned) (void)device_free(p);
     return rc;
 }

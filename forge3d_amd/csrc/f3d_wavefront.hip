@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/f3d_wavefront.h"
+#include "f3d_devmem.h"
 #include "f3d_wf_host.h"
 
 using namespace f3d;
@@ -160,7 +161,7 @@ extern "C" int f3d_wavefront_render(const f3d_wf_scene *scene, uint32_t width, u
         DeviceScope scope(device);
         auto alloc = [&](size_t bytes, const char *what) {
             void *p = nullptr;
-            ok(hipMalloc(&p, bytes ? bytes : 16), what);
+            ok(device_alloc(&p, bytes), what);
             owned.push_back(p);
             return p;
         };
@@ -253,6 +254,6 @@ extern "C" int f3d_wavefront_render(const f3d_wf_scene *scene, uint32_t width, u
     }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
-    for (void *p : owned) (void)hipFree(p);
+    for (void *p : owned) (void)device_free(p);
     return rc;
 }

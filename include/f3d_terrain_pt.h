@@ -320,6 +320,11 @@ const char *f3d_version(void);
 /* First 16 hex digits of the SHA-256 of the sources + compiler flags the library was built from ("unknown" for a
  * build that did not go through __graft_entry__.build_hip). */
 const char *f3d_source_digest(void);
+/* Diagnostics (f3d_devmem.h): pattern 0..255 = every device buffer the library allocates from now on lies between two
+ * 256 KiB guard regions and buffer and guards are filled with that byte; negative = off.  No result may depend on the
+ * pattern: a dependence means a kernel reads memory nobody wrote (uninitialised, or beyond a buffer).  The environment
+ * variable F3D_POISON=<0..255> starts a process in this mode. */
+void f3d_debug_poison(int32_t pattern);
 
 #ifdef __cplusplus
 }

@@ -3,6 +3,7 @@
 the oracle, bit for bit (or the same render error).  python tools/gpu_fuzz.py [first_seed] [count]
 (run with OMP_NUM_THREADS=8: the oracle's OpenMP team of a 128-thread host is slower than 8 threads on
 images this small)."""
+import os
 import sys
 import time
 from pathlib import Path
@@ -17,10 +18,19 @@ import scenes  # noqa: E402
 from oracle import oracle  # noqa: E402  (checker only: this is a test tool)
 
 first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 2000), (int(sys.argv[2]) if len(sys.argv) > 2 else 400)
+POISON = [0x00, 0xFF, 0xA5, 0x7F] if os.environ.get("F3D_FUZZ_POISON") else None  # device buffers pre-filled: results must not care
+if POISON:
+    import ctypes
+
+    from forge3d_amd import _native
+
+    _native.lib().f3d_scene_cache_limit(ctypes.c_uint32(0))
 bad, errors, t0 = [], 0, time.time()
 log = open(ROOT / "gpurun_out" / "fuzz_progress.log", "a") if (ROOT / "gpurun_out").exists() else None
 for seed in range(first, first + count):
     dem, size, cam, kw = scenes.random_scene(seed)
+    if POISON:
+        _native.debug_poison(POISON[seed % 4])
     if log:
         print(seed, round(time.time() - t0, 2), file=log, flush=True)
     try:

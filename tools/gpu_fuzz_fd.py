@@ -2,6 +2,7 @@
 """Frames in flight against the fused frame kernel on random configurations (scene, size, strip, spp, sample lanes,
 batch size, frame count): every output and the variance statistic must be the same bits.  No oracle involved: the
 fused kernel is checked against it elsewhere.  python tools/gpu_fuzz_fd.py [first_seed] [count]"""
+import os
 import sys
 import time
 from pathlib import Path
@@ -12,9 +13,16 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 import scenes  # noqa: E402
+from forge3d_amd import _native  # noqa: E402
 from forge3d_amd.session import TerrainSession  # noqa: E402
 
+POISON = [0x00, 0xFF, 0xA5, 0x7F] if os.environ.get("F3D_FUZZ_POISON") else None  # the two sessions of a configuration under different patterns
+
 first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 0), (int(sys.argv[2]) if len(sys.argv) > 2 else 100)
+if POISON:
+    import ctypes
+
+    _native.lib().f3d_scene_cache_limit(ctypes.c_uint32(0))  # every session builds its own tables, under its own pattern
 bad, retraced, t0 = [], 0, time.time()
 for seed in range(first, first + count):
     rng = np.random.default_rng(900000 + seed)
@@ -30,7 +38,9 @@ for seed in range(first, first + count):
     fd = int(rng.choice([2, 3, 5, 8, 16, 32]))
     outs = []
     try:
-        for in_flight in (0, fd):
+        for k, in_flight in enumerate((0, fd)):
+            if POISON:
+                _native.debug_poison(POISON[(seed % 4 + k * (1 + (seed // 4) % 3)) % 4])  # two different patterns
             with TerrainSession(dem, size[0], size[1], cam, kernel_variant=variant, frames_in_flight=in_flight,
                                 memory_budget_bytes=8 << 30, **rows, **kw) as s:
                 s.enqueue_frames(0, frames, True)

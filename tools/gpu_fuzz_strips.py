@@ -15,9 +15,16 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 import scenes  # noqa: E402
+from forge3d_amd import _native  # noqa: E402
 from forge3d_amd.session import HALO_ROWS as R, TerrainSession, reservoir_buffer_bytes  # noqa: E402
 
+POISON = bool(os.environ.get("F3D_FUZZ_POISON"))  # the one-strip render and the strips under different fill patterns
+
 first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 0), (int(sys.argv[2]) if len(sys.argv) > 2 else 100)
+if POISON:
+    import ctypes
+
+    _native.lib().f3d_scene_cache_limit(ctypes.c_uint32(0))  # every session builds its own tables, under its own pattern
 dev = torch.device("cuda", 0)
 bad, done, t0 = [], 0, time.time()
 for seed in range(first, first + count):
@@ -38,6 +45,8 @@ for seed in range(first, first + count):
     variant = int(rng.choice([0, 1000000, 2000000, 4000000, 8000000]))
     mode = str(rng.choice(["fused", "in_flight", "parts"]))
     fd = int(rng.choice([2, 3, 8, 16])) if mode == "in_flight" else 0
+    if POISON:
+        _native.debug_poison((0x00, 0xA5)[seed % 2])
     try:
         with TerrainSession(dem, W, H, cam, kernel_variant=variant, memory_budget_bytes=8 << 30, **kw) as s:
             s.enqueue_frames(0, frames, True)
@@ -45,6 +54,8 @@ for seed in range(first, first + count):
             full = s.resolve(frames)
     except (RuntimeError, ValueError):
         continue
+    if POISON:
+        _native.debug_poison((0xFF, 0x7F)[(seed // 2) % 2])
     sessions, bufs = [], []
     for b, e in bounds:
         res = [torch.zeros(reservoir_buffer_bytes(e - b, W), dtype=torch.uint8, device=dev) for _ in range(2)]
