@@ -880,3 +880,39 @@ def test_resolve_into_device_tensors_matches_the_host_resolve(f3d):
         assert float(t["albedo"][n:].abs().sum()) == 0.0  # nothing written past the strip
     finally:
         s.close()
+
+
+def test_results_do_not_depend_on_what_the_allocator_hands_out(f3d, oracle):
+    """Poison mode (csrc/f3d_devmem.h): every device buffer between guard regions, all of it pre-filled with a byte
+    pattern.  A lone strip of the scene whose spatial pass looks four rows down (tests/test_halo_reach.py), a mesh scene
+    and the fingerprints: same bits under zeros, NaNs and 0xA5 -- and equal to the oracle."""
+    import ctypes
+
+    from forge3d_amd import _native
+    from forge3d_amd.session import TerrainSession
+
+    L = _native.lib()
+    L.f3d_scene_cache_limit(ctypes.c_uint32(0))  # tables rebuilt under every pattern
+    try:
+        dem, size, cam, kw = scenes.random_scene(4237)
+        kw = dict(kw, max_frames=22, min_frames=22, variance_threshold=1e30)
+        images, prints = [], []
+        for pattern, in_flight in ((0x00, 0), (0xFF, 16), (0xA5, 0), (0x7F, 3)):
+            _native.debug_poison(pattern)
+            with TerrainSession(dem, size[0], size[1], cam, kernel_variant=4000000, frames_in_flight=in_flight,
+                                memory_budget_bytes=8 << 30, row_begin=4, row_end=11, **kw) as s:
+                fp = s.fingerprint()
+                prints.append({k: v for k, v in fp.items() if k != "frame_heads"})  # (written by the first frame)
+                s.enqueue_frames(0, 22, True)
+                s.window_stats()
+                images.append(s.resolve(22)["rgba"])
+        assert all(np.array_equal(images[0], im) for im in images[1:])
+        assert all(prints[0] == p for p in prints[1:])
+        mdem, msize, mcam, mkw = scenes.random_scene(101)  # a scene with a mesh: BVH upload, mesh buffers
+        want = oracle.render(mdem, msize[0], msize[1], mcam, **mkw)
+        for pattern in (0xFF, 0x00):
+            _native.debug_poison(pattern)
+            _same(f3d.hybrid_render_terrain_reference(mdem, msize[0], msize[1], mcam, **mkw), want)
+    finally:
+        _native.debug_poison(-1)
+        L.f3d_scene_cache_limit(ctypes.c_uint32(2))
