@@ -167,6 +167,49 @@ def source_digest() -> str:
     return h.hexdigest()[:16]
 
 
+def _hipcc() -> str:
+    import shutil
+
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found (expected /opt/rocm/bin/hipcc)")
+
+
+def built_digest(path: Path = None):
+    """f3d_source_digest() of an existing library, asked in a child process (loading needs no GPU); None if it cannot say."""
+    import subprocess
+    import sys
+
+    path = Path(path or LIB_PATH)
+    if not path.exists():
+        return None
+    probe = ("import ctypes, sys; L = ctypes.CDLL(sys.argv[1]); L.f3d_source_digest.restype = ctypes.c_char_p; "
+             "print(L.f3d_source_digest().decode())")
+    proc = subprocess.run([sys.executable, "-c", probe, str(path)], capture_output=True, text=True)
+    return proc.stdout.strip() if proc.returncode == 0 else None
+
+
+def build_library(force: bool = False) -> Path:
+    """Compile libf3dhip.so for gfx950 next to the package (hipcc cross-compiles without a GPU) unless the one that is
+    there was built from exactly these sources and flags."""
+    import subprocess
+
+    digest = source_digest()
+    if digest is None:
+        raise RuntimeError("forge3d_amd: the sources (forge3d_amd/csrc, include/) are not next to the package")
+    if force or built_digest(LIB_PATH) != digest:
+        csrc = _PKG / "csrc"
+        tmp = LIB_PATH.with_name(f"{LIB_PATH.name}.{os.getpid()}.tmp")  # several ranks may find the library stale at once
+        cmd = [_hipcc(), *HIPCC_FLAGS, f'-DF3D_SOURCE_DIGEST="{digest}"', *(str(csrc / n) for n in HIP_SOURCES), "-o", str(tmp)]
+        proc = subprocess.run(cmd, capture_output=True, text=True)
+        if proc.returncode != 0:
+            tmp.unlink(missing_ok=True)
+            raise RuntimeError("hipcc failed:\n" + proc.stdout + proc.stderr)
+        os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
 def lib() -> C.CDLL:
     """Load libf3dhip.so (once).  Fails loudly when it has not been built."""
     global _lib
@@ -185,19 +228,28 @@ def lib() -> C.CDLL:
             import torch  # noqa: F401
         except ImportError:
             pass
+        # what runs must be what is in the tree: a library next to its sources has to be built from exactly them (an
+        # A/B library named by F3D_HIP_LIBRARY is the caller's own business).  A stale one is rebuilt here and now --
+        # before it is loaded, a loaded library cannot be replaced -- and the rebuild says so on stderr.
+        if "F3D_HIP_LIBRARY" not in os.environ:
+            want = source_digest()
+            if want is not None:
+                have = built_digest(path)
+                if have != want:
+                    import sys
+
+                    print(f"forge3d_amd: {path.name} was built from other sources (digest {have}, tree {want}): rebuilding",
+                          file=sys.stderr, flush=True)
+                    build_library(force=True)
         L = C.CDLL(str(path))
         for name, restype, argtypes in ABI:
             fn = getattr(L, name)  # AttributeError if the export is missing
             fn.restype = restype
             fn.argtypes = argtypes
-        # what runs must be what is in the tree: a library next to its sources has to be built from exactly them
-        # (an A/B library named by F3D_HIP_LIBRARY is the caller's own business)
         want = source_digest() if "F3D_HIP_LIBRARY" not in os.environ else None
         have = L.f3d_source_digest().decode()
         if want is not None and have != want:
-            raise RuntimeError(
-                f"forge3d_amd: {path} was built from other sources (digest {have}, tree {want}) -- run "
-                "`python -c 'import __graft_entry__ as g; g.build()'`")
+            raise RuntimeError(f"forge3d_amd: {path} was built from other sources (digest {have}, tree {want}) and could not be rebuilt")
         _lib = L
     return _lib
 
