@@ -1075,6 +1075,7 @@ int f3d_session_kernel_timing(f3d_session *s, int32_t enable, double *avg_ms, ui
 }
 
 uint32_t f3d_session_sample_lanes(f3d_session *s) { return s ? s->params.sample_lanes : 0u; }
+uint32_t f3d_halo_rows(void) { return kHaloRows; }
 
 // Diagnostics: FNV-style hashes of everything a frame launch reads -- the by-value uniforms (camera, light, terrain and
 // mesh scalars) and the device buffers behind them, plus the per-pixel state.  Equal fingerprints => equal frames.

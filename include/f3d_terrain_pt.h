@@ -215,6 +215,9 @@ int f3d_session_info(f3d_session *session, uint64_t *gpu_resource_bytes, uint64_
 int f3d_session_kernel_timing(f3d_session *session, int32_t enable, double *avg_ms, uint32_t *launches);
 /* Sample lanes per pixel the frame kernel of this session runs with (1, 2, 4 or 8); 0 on a NULL session. */
 uint32_t f3d_session_sample_lanes(f3d_session *session);
+/* Rows of neighbour state a strip keeps above and below its own (4: the spatial pass reaches -3 .. +4 rows); the halo
+ * blocks of f3d_session_halo and the extra rows of ext_reservoirs are this many rows. */
+uint32_t f3d_halo_rows(void);
 
 /* Diagnostics: out[0..15] = hashes of everything a frame launch of this session reads.  [0] camera, [1] light,
  * [2] terrain scalars, [3] mesh scalars, [4] other scalars, [5] leaf table, [6] band tables, [7] mesh vertices,

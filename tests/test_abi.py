@@ -142,3 +142,13 @@ def test_the_library_says_which_sources_it_was_built_from():
     assert digest and len(digest) == 16
     assert _native.lib().f3d_source_digest().decode() == digest
     assert entry._built_digest(entry.LIB) == digest  # so build() has nothing to do
+
+
+def test_python_and_library_agree_on_the_halo():
+    from forge3d_amd import _native
+    from forge3d_amd.distributed import HALO_ROWS, RES_BYTES
+    from forge3d_amd.session import HALO_ROWS as session_rows, RESERVOIR_BYTES, reservoir_buffer_bytes
+
+    assert _native.lib().f3d_halo_rows() == HALO_ROWS == session_rows == 4
+    assert RES_BYTES == RESERVOIR_BYTES == 16
+    assert reservoir_buffer_bytes(10, 7) == (10 + 2 * 4) * 7 * 16
