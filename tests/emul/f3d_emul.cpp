@@ -728,6 +728,12 @@ void *emul_session_create(const f3d_terrain_ref_desc *d, uint32_t row_begin, uin
         s->require_valid = fill_uniforms(*d, s->P);
         s->tables = build_tables_host(d->heights, d->dem_width, d->dem_height, d->exaggeration);
         s->tables.attach(s->P.terrain);
+        if (d->env_map) {
+            s->env4 = pad_rgb_to_rgba(d->env_map, (size_t)d->env_width * d->env_height, 1.0f);
+            s->P.env.texels = (const float4 *)s->env4.data();
+            s->P.env.width = d->env_width;
+            s->P.env.height = d->env_height;
+        }
         if (d->mesh_vertices) {
             s->mesh4 = pad_rgb_to_rgba(d->mesh_vertices, d->mesh_vertex_count, 0.0f);
             s->mesh_idx.assign(d->mesh_indices, d->mesh_indices + d->mesh_index_count);
