@@ -1,0 +1,131 @@
+// forge3d_amd/csrc/f3d_cone.h
+// Where the primary rays of a pixel can start.
+//
+// The camera does not move between the frames of a render and the jitter of a sample stays inside +-0.5 px, so all
+// spp x frames camera rays of a pixel lie in one thin cone with its apex at the camera.  primary_start() marches that
+// CONE once (k_gbuffer) and returns a parameter t_clear such that every ray of the pixel, at every parameter up to
+// t_clear, is above the highest point of every cell it is over -- by a margin far above the rounding of the march's
+// band test.  The nodes a camera ray passes before t_clear are then exactly nodes whose band test rejects the ray
+// (`lo > mx`: no leaf is ever solved in them; a bilinear patch along a straight ray is a quadratic, and a ray above
+// the cell's maximum has no root), so a march that starts at t_clear (f3d_march.h march_begin_at) returns what a march
+// from the root returns.  The certificate only has to be conservative, not bit-exact with anything: a shorter t_clear
+// costs steps, never a result.
+#pragma once
+
+// (included by f3d_shade.h after camera_dir, which it uses)
+
+namespace f3d {
+
+struct PrimaryStart {
+    float t_clear;   // 0: no certificate (march from the root); 3e38: no ray of the pixel ever meets terrain
+    uint32_t level;  // level of the node the certificate stopped at: where to drop the rays in
+};
+
+// Largest band maximum of the 3 x 3 nodes of `level` around (nx, nz) (nodes outside the grid hold no terrain).
+F3D_HD float cone_max9(const TerrainDev &T, uint32_t level, uint32_t nx, uint32_t nz) {
+    float mx = -3.0e38f;
+    for (int dz = -1; dz <= 1; dz++)
+        for (int dx = -1; dx <= 1; dx++) {
+            const uint32_t qx = nx + (uint32_t)dx, qz = nz + (uint32_t)dz;  // -1 wraps and fails the range test
+            if ((qx << level) < T.cell_w && (qz << level) < T.cell_h && qx <= nx + 1u && qz <= nz + 1u)
+                mx = f_max(mx, T.bands[T.band_offset[level] + (qz << T.band_shift[level]) + qx].mx);
+        }
+    return mx;
+}
+
+F3D_HD PrimaryStart primary_start(const FrameParams &P, uint32_t gx, uint32_t gy) {
+    const TerrainDev &T = P.terrain;
+    const uint32_t top = T.mip_count - 1u;
+    PrimaryStart out{0.0f, top};
+    // |d - d_centre| of any ray of the pixel: the jitter moves the point on the z = -1 plane by at most
+    // (half_w / W, half_h / H); sin(angle) <= |delta| / |v| <= |delta|, chord <= angle, asin(x) <= x (1 + x^2)
+    const float px = P.cam.half_w / (float)P.cam.width, py = P.cam.half_h / (float)P.cam.height;
+    const float plane = f_sqrt(px * px + py * py);
+    if (!(plane < 0.25f)) return out;
+    const float delta = 1.01f * plane * (1.0f + plane * plane);
+    const V3 d = camera_dir(P.cam, gx, gy, 0.0f, 0.0f);
+    const RayCtx r = make_ray(T, P.cam.origin, 1e-3f, d, 1e30f, false);
+    float t_in, t_out;
+    march_root_interval(T, r, t_in, t_out);
+    if (t_in > t_out) return out;  // the centre ray misses the footprint; its neighbours may not: no certificate
+    const float cell = f_min(T.spacing_x, T.spacing_z);
+    // height margin: the band test compares f32 heights of the order of the ray's and the terrain's
+    const float y_scale = f_abs(r.o.y) + f_abs(T.bands[T.band_offset[top]].mx) + f_abs(T.bands[T.band_offset[top]].mn);
+    auto lowest = [&](float t) F3D_LAMBDA {  // height of the lowest ray of the cone at parameter t, minus the margin
+        return f_fma(t, r.d.y, r.o.y) - t * delta - (1e-4f * y_scale + 1e-5f * t + 1e-3f);
+    };
+    // before the centre ray enters the footprint the cone may already be over it: clear only above everything
+    if (t_in > r.tmin && !(f_min(lowest(r.tmin), lowest(t_in)) > T.bands[T.band_offset[top]].mx)) return out;
+    // The centre ray has left the footprint at parameter b; the far side of the cone may still be over it.  The pixel sees
+    // no terrain at all only if the cone never comes down again: its lowest ray does not descend and is above everything.
+    auto beyond_is_clear = [&](float b) F3D_LAMBDA {
+        return r.d.y - delta >= 0.0f && lowest(b) > T.bands[T.band_offset[top]].mx;
+    };
+    const bool x_forward = !(r.d.x < 0.0f), z_forward = !(r.d.z < 0.0f);
+    uint32_t level = top, nx = 0u, nz = 0u;
+    float clear = t_in;
+    for (uint32_t iter = 0u; iter < 512u; iter++) {
+        uint32_t cx1 = (nx + 1u) << level, cz1 = (nz + 1u) << level;
+        cx1 = cx1 < T.cell_w ? cx1 : T.cell_w;
+        cz1 = cz1 < T.cell_h ? cz1 : T.cell_h;
+        const float tx0 = (plane_at(T.origin_x, nx << level, T.spacing_x) - r.o.x) * r.inv_x;
+        const float tx1 = (plane_at(T.origin_x, cx1, T.spacing_x) - r.o.x) * r.inv_x;
+        const float tz0 = (plane_at(T.origin_z, nz << level, T.spacing_z) - r.o.z) * r.inv_z;
+        const float tz1 = (plane_at(T.origin_z, cz1, T.spacing_z) - r.o.z) * r.inv_z;
+        const float x_out = f_max(tx0, tx1), z_out = f_max(tz0, tz1);
+        const float enter = f_max(f_min(tx0, tx1), f_min(tz0, tz1)), exit = f_min(x_out, z_out);
+#if defined(F3D_CONE_DEBUG)
+        fprintf(stderr, "  iter %u level %u node (%u,%u) enter %.3f exit %.3f clear %.3f\n", iter, level, nx, nz, enter, exit, clear);
+#endif
+        if (!(enter <= clear && clear <= exit)) break;  // lost the ray (rounding at a boundary): stop here
+        const float b = f_min(exit, t_out);
+        // the cone's radius over [clear, b], plus slack for the ray sitting a hair outside the node
+        const float radius = b * delta + 0.02f * cell;
+        uint32_t need = 0u;  // finest level whose nodes are wider than the radius: the 3 x 3 block of such nodes holds the dilated node
+        while (need < top && cell * (float)(1u << need) < radius) need++;
+        const uint32_t ql = need > level ? need : level;
+        const bool wide_enough = cell * (float)(1u << ql) >= radius;
+        const float y_low = f_min(lowest(clear), lowest(b));
+#if defined(F3D_CONE_DEBUG)
+        fprintf(stderr, "    b %.3f radius %.3f ql %u y_low %.3f max9 %.3f\n", b, radius, ql, y_low, wide_enough ? cone_max9(T, ql, nx >> (ql - level), nz >> (ql - level)) : -1.0f);
+#endif
+        if (wide_enough && y_low > cone_max9(T, ql, nx >> (ql - level), nz >> (ql - level))) {
+            clear = b;
+            if (!(b < t_out)) {
+                if (beyond_is_clear(b)) clear = 3.0e38f;
+                break;
+            }
+            const bool cross_x = x_out <= z_out, cross_z = z_out <= x_out;
+            const uint32_t qx = nx + ((cross_x && x_forward) ? 1u : 0u) - ((cross_x && !x_forward) ? 1u : 0u);
+            const uint32_t qz = nz + ((cross_z && z_forward) ? 1u : 0u) - ((cross_z && !z_forward) ? 1u : 0u);
+            if ((qx << level) >= T.cell_w || (qz << level) >= T.cell_h) {
+                if (beyond_is_clear(b)) clear = 3.0e38f;
+                break;
+            }
+            const bool up = level < top && (((qx ^ nx) | (qz ^ nz)) > 1u);
+            nx = up ? qx >> 1 : qx;
+            nz = up ? qz >> 1 : qz;
+            level = up ? level + 1u : level;
+        } else if (level > 0u && need < level) {
+            // a finer node can still hold the cone: down into the child the centre ray is in at `clear`
+            const uint32_t cl = level - 1u;
+            const uint32_t xm = (2u * nx + 1u) << cl, zm = (2u * nz + 1u) << cl;
+            const float txm = (plane_at(T.origin_x, xm, T.spacing_x) - r.o.x) * r.inv_x;
+            const float tzm = (plane_at(T.origin_z, zm, T.spacing_z) - r.o.z) * r.inv_z;
+            uint32_t ix = (x_forward != (txm <= clear)) ? 0u : 1u;
+            uint32_t iz = (z_forward != (tzm <= clear)) ? 0u : 1u;
+            if (!(xm < T.cell_w)) ix = 0u;
+            if (!(zm < T.cell_h)) iz = 0u;
+            nx = 2u * nx + ix;
+            nz = 2u * nz + iz;
+            level = cl;
+        } else {
+            break;  // the terrain is too close to the cone here: the rays take over
+        }
+    }
+    out.t_clear = clear > t_in ? clear : 0.0f;
+    out.level = level;
+    return out;
+}
+
+}  // namespace f3d

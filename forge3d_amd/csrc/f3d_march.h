@@ -472,20 +472,45 @@ F3D_HD bool march_shared(const TerrainDev &T, const RayCtx &own_ray, MarchState 
     return ctx.verdict_get(ctx.lane());
 }
 
+// A camera ray whose pixel holds a certificate (f3d_cone.h primary_start): every ray of the pixel is above every cell it
+// passes up to t_clear, so the nodes before it are exactly those the march would reject without solving a leaf.  The
+// lane starts in the node of `level` that contains the ray at t_clear -- located from the position and validated by
+// that node's own interval on the first step, like the in-cell start of the secondary rays.
+F3D_HD MarchState march_begin_at(const TerrainDev &T, const RayCtx &r, float t_clear, uint32_t level) {
+    MarchState m;
+    float hi;
+    march_root_interval(T, r, m.t_cur, hi);
+    m.marching = !(m.t_cur > hi);
+    m.level = T.mip_count - 1u;
+    m.nx = 0u;
+    m.nz = 0u;
+    m.unverified_start = false;
+    if (m.marching && t_clear > m.t_cur) {
+        if (!(t_clear < hi)) {
+            m.marching = false;  // clear until the ray leaves the footprint (or reaches tmax): no terrain hit
+        } else {
+            m.t_cur = t_clear;
+            m.level = level < m.level ? level : m.level;
+            march_locate(T, r, t_clear, m.level, m.nx, m.nz);
+            m.unverified_start = true;
+        }
+    }
+    return m;
+}
+
 // CURVED: the sun-ray curvature policy is active for this ray (compile-time so that the other
 // two thirds of the rays do not carry the parabola arithmetic).  start_in_cell: begin in the cell
 // the ray is in (secondary rays) instead of at the root (camera rays entering from outside).
 // Ctx provides: note(), band_entry(), the FIFO storage fifo_put/fifo_get, the wave votes
 // flush_now(queued, marching) / any(pred), and share_now / deal / verdict_* (ray sharing).
 template <bool CURVED, class Ctx>
-F3D_HD TraceHit march_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit, bool start_in_cell, Ctx &ctx) {
+F3D_HD TraceHit march_terrain_from(const TerrainDev &T, const RayCtx &r, bool any_hit, MarchState m, Ctx &ctx) {
     TraceHit res;
     res.hit = false;
     res.t = r.tmax;
     res.n = V3{0.0f, 0.0f, 0.0f};
     ctx.note(2 | (any_hit ? 1 : 0) | (CURVED ? 4 : 0));  // statistics hook: a new ray starts
     ctx.feature(r.d.y);
-    MarchState m = march_begin(T, r, start_in_cell);
     uint32_t queued = 0u;
     bool deal = false;
     for (;;) {
@@ -507,6 +532,11 @@ F3D_HD TraceHit march_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit
         res.t = r.tmin;  // any-hit callers read only `hit` (and t < tmax)
     }
     return res;
+}
+
+template <bool CURVED, class Ctx>
+F3D_HD TraceHit march_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit, bool start_in_cell, Ctx &ctx) {
+    return march_terrain_from<CURVED>(T, r, any_hit, march_begin(T, r, start_in_cell), ctx);
 }
 
 // Curvature is a per-ray policy AND a per-render switch (wave-uniform): pick the instantiation.

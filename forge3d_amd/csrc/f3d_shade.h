@@ -131,8 +131,10 @@ F3D_HD bool mesh_closest(const MeshDev &M, V3 o, float tmin, V3 d, float tmax, f
 }
 
 // intersect_hybrid, hybrid_traversal.wgsl:175-201 (closest hit, curvature off)
+// t_clear / level: a certificate for camera rays (f3d_cone.h); t_clear = 0 starts the march at the root.
 template <class Pending>
-F3D_HD SurfaceHit closest_hit(const FrameParams &P, V3 o, float tmin, V3 d, float tmax, Pending &pend) {
+F3D_HD SurfaceHit closest_hit(const FrameParams &P, V3 o, float tmin, V3 d, float tmax, Pending &pend, float t_clear = 0.0f,
+                              uint32_t start_level = 0u) {
     SurfaceHit best;
     best.kind = 0u;
     best.t = tmax;
@@ -152,8 +154,8 @@ F3D_HD SurfaceHit closest_hit(const FrameParams &P, V3 o, float tmin, V3 d, floa
 #if defined(F3D_TRAVERSAL_DESCENT)
     TraceHit th = trace_terrain(P.terrain, r, false, pend);  // the reference-shaped sorted descent
 #else
-    // camera rays enter the footprint from outside: the march starts at the root
-    TraceHit th = march_terrain<false>(P.terrain, r, false, false, pend);
+    // camera rays enter the footprint from outside: the march starts at the root, or where the pixel's certificate ends
+    TraceHit th = march_terrain_from<false>(P.terrain, r, false, march_begin_at(P.terrain, r, t_clear, start_level), pend);
 #endif
     if (th.hit && th.t < best.t) {
         best.kind = 1u;
@@ -244,6 +246,10 @@ F3D_HD V3 camera_dir(const CameraDev &C, uint32_t gx, uint32_t gy, float jx, flo
     V3 rd = normalize(V3{ndc_x * C.half_w, ndc_y * C.half_h, -1.0f});
     return normalize(combine(rd.x, C.right, rd.y, C.up, rd.z, neg(C.forward)));
 }
+
+}  // namespace f3d
+#include "f3d_cone.h"  // primary_start: where the camera rays of a pixel may start
+namespace f3d {
 
 // ---- reservoirs -------------------------------------------------------------------
 struct Reservoir {  // register form of PackedReservoir
@@ -432,7 +438,9 @@ F3D_HD PrimaryHit sample_primary(const FrameParams &P, uint32_t gx, uint32_t gy,
     const float jx = tent_offset(rng_next(rng)) * 0.5f;
     const float jy = tent_offset(rng_next(rng)) * 0.5f;
     ph.rd = camera_dir(P.cam, gx, gy, jx, jy);
-    ph.hit = closest_hit(P, P.cam.origin, 1e-3f, ph.rd, 1e30f, pend);
+    uint2 start = uint2{0u, 0u};
+    if (P.primary_start) start = P.primary_start[(size_t)(gy - P.row_begin) * P.cam.width + gx];
+    ph.hit = closest_hit(P, P.cam.origin, 1e-3f, ph.rd, 1e30f, pend, f_from_bits(start.x), start.y);
     ph.rng = rng;
     return ph;
 }
@@ -656,6 +664,10 @@ F3D_HD void gbuffer_pixel(const FrameParams &P, uint32_t gx, uint32_t gy, float4
                           Pending &pend) {
     const size_t lp = (size_t)(gy - P.row_begin) * P.cam.width + gx;
     const V3 rd = camera_dir(P.cam, gx, gy, 0.0f, 0.0f);
+    if (P.primary_start) {
+        const PrimaryStart ps = primary_start(P, gx, gy);
+        P.primary_start[lp] = uint2{f_bits(ps.t_clear), ps.level};
+    }
     const SurfaceHit hit = closest_hit(P, P.cam.origin, 1e-3f, rd, 1e30f, pend);
     if (hit.kind != 0u) {
         gbuffer_n[lp] = float4{hit.n.x, hit.n.y, hit.n.z, (float)hit.kind};

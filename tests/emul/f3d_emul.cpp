@@ -559,10 +559,28 @@ int emul_render(const f3d_terrain_ref_desc *d, uint32_t row_begin, uint32_t row_
         P.accum_mean = accum.data();
         P.welford_m2 = m2.data();
         P.gbuffer_n = gbuf.data();
+        std::vector<uint2> starts(getenv("F3D_EMUL_NO_PRIMARY_START") ? 0 : px);  // f3d_cone.h certificates
+        P.primary_start = starts.empty() ? nullptr : starts.data();
 #pragma omp parallel for schedule(dynamic, 4)
         for (long y = row_begin; y < (long)row_end; y++) {
             ArrayPending pend;
             for (uint32_t x = 0; x < W; x++) gbuffer_pixel(P, x, (uint32_t)y, gbuf.data(), dep.data(), pend);
+        }
+        if (getenv("F3D_EMUL_START_STATS") && P.primary_start) {  // how far do the certificates of f3d_cone.h reach?
+            size_t none = 0, sky = 0, some = 0;
+            double frac = 0.0, lvl = 0.0;
+            for (size_t i = 0; i < px; i++) {
+                const float t = f_from_bits(starts[i].x);
+                if (t == 0.0f) none++;
+                else if (t > 1e37f) sky++;
+                else {
+                    some++;
+                    lvl += starts[i].y;
+                    if (gbuf[i].w != 0.0f) frac += t / dep[i];
+                }
+            }
+            fprintf(stderr, "certificates: none %zu, whole ray %zu, partial %zu (mean t_clear / depth %.3f, mean level %.2f)\n", none, sky, some,
+                    some ? frac / (double)some : 0.0, some ? lvl / (double)some : 0.0);
         }
         uint32_t frames = 0;
         float variance = INFINITY;
@@ -713,6 +731,7 @@ struct EmulSession {
     std::vector<uint32_t> mesh_idx;
     MeshBvh bvh;
     std::vector<float4> accum, gbuf;
+    std::vector<uint2> starts;
     std::vector<float> m2, depth;
     PackedReservoir *res[2] = {nullptr, nullptr};
     uint32_t rows = 0, width = 0;
@@ -764,6 +783,8 @@ void *emul_session_create(const f3d_terrain_ref_desc *d, uint32_t row_begin, uin
         s->P.accum_mean = s->accum.data();
         s->P.welford_m2 = s->m2.data();
         s->P.gbuffer_n = s->gbuf.data();
+        s->starts.assign(px, uint2{0u, 0u});
+        s->P.primary_start = s->starts.data();
         for (uint32_t y = row_begin; y < row_end; y++) {
             ArrayPending pend;
             for (uint32_t x = 0; x < s->width; x++) gbuffer_pixel(s->P, x, y, s->gbuf.data(), s->depth.data(), pend);
@@ -828,6 +849,24 @@ int emul_session_resolve(void *h, uint32_t frames, uint8_t *rgba, float *albedo,
 }
 
 void emul_session_destroy(void *h) { delete (EmulSession *)h; }
+
+// debugging aid: the certificate of one pixel (build with -DF3D_CONE_DEBUG for the walk)
+int emul_primary_start(const f3d_terrain_ref_desc *d, uint32_t gx, uint32_t gy, float *t_clear, uint32_t *level) {
+    try {
+        FrameParams P{};
+        (void)fill_uniforms(*d, P);
+        HostTables t = build_tables_host(d->heights, d->dem_width, d->dem_height, d->exaggeration);
+        t.attach(P.terrain);
+        P.row_begin = 0;
+        P.row_end = d->height;
+        const PrimaryStart ps = primary_start(P, gx, gy);
+        *t_clear = ps.t_clear;
+        *level = ps.level;
+        return 0;
+    } catch (const Failure &) {
+        return 1;
+    }
+}
 
 void emul_set_use_bvh(int32_t on) { g_use_bvh = on != 0; }
 // FNV-1a over the node and triangle arrays of the mesh BVH built with / without worker threads
