@@ -128,4 +128,97 @@ F3D_HD PrimaryStart primary_start(const FrameParams &P, uint32_t gx, uint32_t gy
     return out;
 }
 
+// ---- where the sun rays of a pixel can stop -------------------------------------------------------------------------
+// The sun rays of a pixel's samples are parallel and start within a short distance of one another (the samples' hit
+// points lie in the pixel's cone, at depths the caller checks against the centre ray's: sun_depth_slack), so they
+// fill a CYLINDER around the centre sample's sun ray.  sun_clear_from() walks that cylinder through the footprint and
+// returns the parameter after which it stays above every cell it is over: beyond it no sun ray of the pixel can meet
+// terrain, so their marches may stop there (the terrain ray's tmax; the mesh test keeps the full range).  The sun
+// rays' curvature policy only LIFTS a ray (c2 >= 0), so the straight centre line is a lower bound.
+#ifndef F3D_SUN_SLACK
+#define F3D_SUN_SLACK 1.0f
+#endif
+F3D_HD float pixel_cone_delta(const CameraDev &C) {
+    const float px = C.half_w / (float)C.width, py = C.half_h / (float)C.height;
+    const float plane = f_sqrt(px * px + py * py);
+    return plane < 0.25f ? 1.01f * plane * (1.0f + plane * plane) : -1.0f;  // < 0: pixels too wide for certificates
+}
+// Samples whose primary hit lies within this distance (along the ray) of the centre ray's hit use the certificate.
+F3D_HD float sun_depth_slack(float centre_depth, float delta, float cell) { return F3D_SUN_SLACK * centre_depth * delta + 0.5f * cell; }
+
+F3D_HD float sun_clear_from(const FrameParams &P, V3 origin, float centre_depth) {
+    const TerrainDev &T = P.terrain;
+    const uint32_t top = T.mip_count - 1u;
+    const float none = 3.0e38f;
+    const float delta = pixel_cone_delta(P.cam);
+    const V3 d = P.light.wi;
+    if (delta < 0.0f || !(d.y >= 0.0f)) return none;
+    const float cell = f_min(T.spacing_x, T.spacing_z);
+    // |sample origin - centre origin| <= depth difference + the cone's width there + the two offsets along the normals
+    const float slack = sun_depth_slack(centre_depth, delta, cell);
+    const float rho = slack + (centre_depth + slack) * delta + 4e-3f;
+    const RayCtx r = make_ray(T, origin, 1e-3f, d, 1e30f, false);
+    float t_in, t_out;
+    march_root_interval(T, r, t_in, t_out);
+    if (t_in > t_out || t_in > r.tmin) return none;  // a mesh hit beside the footprint: the usual march
+    const float y_scale = f_abs(r.o.y) + f_abs(T.bands[T.band_offset[top]].mx) + f_abs(T.bands[T.band_offset[top]].mn);
+    auto lowest = [&](float t) F3D_LAMBDA { return f_fma(t, r.d.y, r.o.y) - rho - (1e-4f * y_scale + 1e-5f * t + 1e-3f); };
+    const float radius = rho + 0.02f * cell;
+    uint32_t need = 0u;
+    while (need < top && cell * (float)(1u << need) < radius) need++;
+    if (cell * (float)(1u << need) < radius) return none;
+    const bool x_forward = !(r.d.x < 0.0f), z_forward = !(r.d.z < 0.0f);
+    uint32_t level = top, nx = 0u, nz = 0u;
+    float at = t_in, clear_from = t_in;  // the cylinder is known to be clear on [clear_from, at]
+    for (uint32_t iter = 0u; iter < 1024u; iter++) {
+        uint32_t cx1 = (nx + 1u) << level, cz1 = (nz + 1u) << level;
+        cx1 = cx1 < T.cell_w ? cx1 : T.cell_w;
+        cz1 = cz1 < T.cell_h ? cz1 : T.cell_h;
+        const float tx0 = (plane_at(T.origin_x, nx << level, T.spacing_x) - r.o.x) * r.inv_x;
+        const float tx1 = (plane_at(T.origin_x, cx1, T.spacing_x) - r.o.x) * r.inv_x;
+        const float tz0 = (plane_at(T.origin_z, nz << level, T.spacing_z) - r.o.z) * r.inv_z;
+        const float tz1 = (plane_at(T.origin_z, cz1, T.spacing_z) - r.o.z) * r.inv_z;
+        const float x_out = f_max(tx0, tx1), z_out = f_max(tz0, tz1);
+        const float enter = f_max(f_min(tx0, tx1), f_min(tz0, tz1)), exit = f_min(x_out, z_out);
+        if (!(enter <= at && at <= exit)) return none;  // lost the ray: no certificate
+        const float b = f_min(exit, t_out);
+        const uint32_t ql = need > level ? need : level;
+        const bool pass = f_min(lowest(at), lowest(b)) > cone_max9(T, ql, nx >> (ql - level), nz >> (ql - level));
+#if defined(F3D_CONE_DEBUG)
+        fprintf(stderr, "  sun iter %u level %u node (%u,%u) [%.3f, %.3f] at %.3f b %.3f lowest %.3f max9 %.3f pass %d need %u\n", iter, level, nx, nz, enter, exit, at, b,
+                f_min(lowest(at), lowest(b)), cone_max9(T, ql, nx >> (ql - level), nz >> (ql - level)), (int)pass, need);
+#endif
+        if (!pass && level > 0u && need < level) {  // a finer node may still be under the cylinder: down
+            const uint32_t cl = level - 1u;
+            const uint32_t xm = (2u * nx + 1u) << cl, zm = (2u * nz + 1u) << cl;
+            const float txm = (plane_at(T.origin_x, xm, T.spacing_x) - r.o.x) * r.inv_x;
+            const float tzm = (plane_at(T.origin_z, zm, T.spacing_z) - r.o.z) * r.inv_z;
+            uint32_t ix = (x_forward != (txm <= at)) ? 0u : 1u;
+            uint32_t iz = (z_forward != (tzm <= at)) ? 0u : 1u;
+            if (!(xm < T.cell_w)) ix = 0u;
+            if (!(zm < T.cell_h)) iz = 0u;
+            nx = 2u * nx + ix;
+            nz = 2u * nz + iz;
+            level = cl;
+            continue;
+        }
+        if (!pass) clear_from = b;  // terrain reaches the cylinder in this node: whatever is clear starts after it
+        at = b;
+        if (!(b < t_out)) break;
+        const bool cross_x = x_out <= z_out, cross_z = z_out <= x_out;
+        const uint32_t qx = nx + ((cross_x && x_forward) ? 1u : 0u) - ((cross_x && !x_forward) ? 1u : 0u);
+        const uint32_t qz = nz + ((cross_z && z_forward) ? 1u : 0u) - ((cross_z && !z_forward) ? 1u : 0u);
+        if ((qx << level) >= T.cell_w || (qz << level) >= T.cell_h) break;
+        const bool up = level < top && (((qx ^ nx) | (qz ^ nz)) > 1u);
+        nx = up ? qx >> 1 : qx;
+        nz = up ? qz >> 1 : qz;
+        level = up ? level + 1u : level;
+    }
+    // The centre line has left the footprint, but one side of the cylinder may run on over it (a ray leaving through a
+    // side at a shallow angle travels along the edge): certified only if the cylinder is above EVERYTHING from here on --
+    // the rays only rise (d.y >= 0).
+    if (!(lowest(at) > T.bands[T.band_offset[top]].mx)) return none;
+    return clear_from < at ? clear_from : none;
+}
+
 }  // namespace f3d

@@ -504,7 +504,8 @@ F3D_HD MarchState march_begin_at(const TerrainDev &T, const RayCtx &r, float t_c
 // Ctx provides: note(), band_entry(), the FIFO storage fifo_put/fifo_get, the wave votes
 // flush_now(queued, marching) / any(pred), and share_now / deal / verdict_* (ray sharing).
 template <bool CURVED, class Ctx>
-F3D_HD TraceHit march_terrain_from(const TerrainDev &T, const RayCtx &r, bool any_hit, MarchState m, Ctx &ctx) {
+F3D_HD TraceHit march_terrain_from(const TerrainDev &T, const RayCtx &r, bool any_hit, MarchState m, Ctx &ctx,
+                                   float t_stop = 3.0e38f) {
     TraceHit res;
     res.hit = false;
     res.t = r.tmax;
@@ -514,7 +515,10 @@ F3D_HD TraceHit march_terrain_from(const TerrainDev &T, const RayCtx &r, bool an
     uint32_t queued = 0u;
     bool deal = false;
     for (;;) {
-        if (m.marching) march_step<CURVED, false>(T, r, m, queued, ctx, any_hit);
+        // t_stop (sun rays, f3d_cone.h sun_clear_from): no terrain beyond it, so the lane stops after the node that
+        // contains it -- the SLICED rule; node and leaf intervals are NOT clipped by it, every visited node is judged
+        // exactly as the unbounded march judges it
+        if (m.marching) march_step<CURVED, CURVED>(T, r, m, queued, ctx, any_hit, t_stop);
 #if !defined(F3D_NO_SHARE)
 #if defined(F3D_SHARE_CURVED)  // A/B: sun rays too, with their own threshold (profiles/README.md)
         if (any_hit) deal = CURVED ? ctx.share_now(m.marching, F3D_SHARE_CURVED) : ctx.share_now(m.marching);
@@ -535,8 +539,9 @@ F3D_HD TraceHit march_terrain_from(const TerrainDev &T, const RayCtx &r, bool an
 }
 
 template <bool CURVED, class Ctx>
-F3D_HD TraceHit march_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit, bool start_in_cell, Ctx &ctx) {
-    return march_terrain_from<CURVED>(T, r, any_hit, march_begin(T, r, start_in_cell), ctx);
+F3D_HD TraceHit march_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit, bool start_in_cell, Ctx &ctx,
+                              float t_stop = 3.0e38f) {
+    return march_terrain_from<CURVED>(T, r, any_hit, march_begin(T, r, start_in_cell), ctx, t_stop);
 }
 
 // Curvature is a per-ray policy AND a per-render switch (wave-uniform): pick the instantiation.

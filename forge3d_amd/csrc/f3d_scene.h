@@ -152,6 +152,7 @@ struct FrameParams {
     uint32_t tile_map;              // workgroup -> tile mapping (f3d_kernels.hip tile_pixel)
     uint32_t sample_lanes;          // lanes per pixel in the frame kernel: 1 (frame_pixel), 2, 4, 8 (frame_lanes)
     uint2 *head;                    // sample-lane form only: per-pixel record of k_head {reuse_w bits, flags}
+    float2 *sun_clear;              // per pixel {parameter after which no sun ray of the pixel meets terrain, depth of the centre hit}; null = off
     uint2 *primary_start;           // per pixel {t_clear bits, level}: where its camera rays may start (f3d_cone.h); null = at the root
     // longest-first dispatch (f3d_kernels.hip k_tile_order): frame-kernel workgroup b renders tile tile_order[b]
     // (null: the tile_map formula); every wave leaves its duration in tile_cost[tile] for the next ordering

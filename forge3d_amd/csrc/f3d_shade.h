@@ -170,7 +170,7 @@ F3D_HD SurfaceHit closest_hit(const FrameParams &P, V3 o, float tmin, V3 d, floa
 // hybrid_traversal.wgsl:204-259 (any hit; early_exit 0.01; max_distance 1e30)
 template <class Pending>
 F3D_HD bool occluded(const FrameParams &P, V3 o, float tmin, V3 d, float tmax, bool apply_curvature,
-                     Pending &pend) {
+                     Pending &pend, float terrain_tmax = 1e30f) {
     float best_t = tmax;
     bool hit = false;
     if (P.mesh.traversal_mode == 0u) {
@@ -189,6 +189,8 @@ F3D_HD bool occluded(const FrameParams &P, V3 o, float tmin, V3 d, float tmax, b
             }
         }
     }
+    // terrain_tmax: a certificate that no terrain lies beyond it on this ray (f3d_cone.h sun_clear_from): the march stops
+    // after the node that contains it (sun rays only: the curved instantiation carries the stop rule)
     RayCtx r = make_ray(P.terrain, o, tmin, d, best_t, apply_curvature);
 #if defined(F3D_TRAVERSAL_DESCENT)
     TraceHit th = trace_terrain(P.terrain, r, true, pend);  // the reference-shaped sorted descent
@@ -197,7 +199,7 @@ F3D_HD bool occluded(const FrameParams &P, V3 o, float tmin, V3 d, float tmax, b
     // rays carry the curvature policy (apply_curvature is a compile-time constant per call site).
     // (with the curvature policy switched off for the whole render, c2 = 0 and fma(t*t, 0, y) == y: the
     // curved instantiation then computes the flat answers exactly, so there is no third copy of the march)
-    TraceHit th = apply_curvature ? march_terrain<true>(P.terrain, r, true, true, pend)
+    TraceHit th = apply_curvature ? march_terrain<true>(P.terrain, r, true, true, pend, terrain_tmax)
                                   : march_terrain<false>(P.terrain, r, true, true, pend);
 #endif
     if (th.hit && th.t < best_t) {
@@ -429,7 +431,8 @@ F3D_HD FrameHead unpack_head(const FrameParams &P, uint32_t gx, uint32_t gy, uin
 struct PrimaryHit {
     SurfaceHit hit;
     V3 rd;
-    uint32_t rng;  // stream state after the two jitter draws
+    uint32_t rng;    // stream state after the two jitter draws
+    float sun_tmax;  // the sample's sun ray meets no terrain beyond this parameter (1e30: no certificate)
 };
 
 template <class Pending>
@@ -439,8 +442,18 @@ F3D_HD PrimaryHit sample_primary(const FrameParams &P, uint32_t gx, uint32_t gy,
     const float jy = tent_offset(rng_next(rng)) * 0.5f;
     ph.rd = camera_dir(P.cam, gx, gy, jx, jy);
     uint2 start = uint2{0u, 0u};
+#if !defined(F3D_NO_PRIMARY_START)  // A/B builds (tools/build_variant.sh)
     if (P.primary_start) start = P.primary_start[(size_t)(gy - P.row_begin) * P.cam.width + gx];
+#endif
     ph.hit = closest_hit(P, P.cam.origin, 1e-3f, ph.rd, 1e30f, pend, f_from_bits(start.x), start.y);
+    ph.sun_tmax = 1e30f;
+#if !defined(F3D_NO_SUN_CLEAR)  // A/B builds
+    if (P.sun_clear && ph.hit.kind != 0u) {
+        const float2 c = P.sun_clear[(size_t)(gy - P.row_begin) * P.cam.width + gx];
+        const float cell = f_min(P.terrain.spacing_x, P.terrain.spacing_z);
+        if (c.x < 1e30f && f_abs(ph.hit.t - c.y) <= sun_depth_slack(c.y, pixel_cone_delta(P.cam), cell)) ph.sun_tmax = c.x;
+    }
+#endif
     ph.rng = rng;
     return ph;
 }
@@ -488,7 +501,7 @@ F3D_HD IblRay sample_shade_sun(const FrameParams &P, const FrameHead &h, const P
         pend.hint(F3D_MODEL_HINT_SUN);
 #endif
 #if !defined(F3D_TIMING_NO_SHADOW)  // timing experiment only (wrong image): tools/gpu_build_ab.sh
-        if (P.light.shadows_enabled != 0u && occluded(P, so, 1e-3f, sun_dir, 1e30f, true, pend)) vis = 0.0f;
+        if (P.light.shadows_enabled != 0u && occluded(P, so, 1e-3f, sun_dir, 1e30f, true, pend, ph.sun_tmax)) vis = 0.0f;
 #endif
         o.a = (((albedo * P.light.color) * nd) * vis) * h.reuse_w;
     }
@@ -669,6 +682,11 @@ F3D_HD void gbuffer_pixel(const FrameParams &P, uint32_t gx, uint32_t gy, float4
         P.primary_start[lp] = uint2{f_bits(ps.t_clear), ps.level};
     }
     const SurfaceHit hit = closest_hit(P, P.cam.origin, 1e-3f, rd, 1e30f, pend);
+    if (P.sun_clear) {
+        float2 c = float2{3.0e38f, 0.0f};
+        if (hit.kind != 0u) c = float2{sun_clear_from(P, along(hit.p, 1e-3f, hit.n), hit.t), hit.t};
+        P.sun_clear[lp] = c;
+    }
     if (hit.kind != 0u) {
         gbuffer_n[lp] = float4{hit.n.x, hit.n.y, hit.n.z, (float)hit.kind};
         depth[lp] = hit.t;

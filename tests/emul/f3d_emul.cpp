@@ -561,6 +561,8 @@ int emul_render(const f3d_terrain_ref_desc *d, uint32_t row_begin, uint32_t row_
         P.gbuffer_n = gbuf.data();
         std::vector<uint2> starts(getenv("F3D_EMUL_NO_PRIMARY_START") ? 0 : px);  // f3d_cone.h certificates
         P.primary_start = starts.empty() ? nullptr : starts.data();
+        std::vector<float2> sun_clear(getenv("F3D_EMUL_NO_SUN_CLEAR") ? 0 : px);
+        P.sun_clear = sun_clear.empty() ? nullptr : sun_clear.data();
 #pragma omp parallel for schedule(dynamic, 4)
         for (long y = row_begin; y < (long)row_end; y++) {
             ArrayPending pend;
@@ -732,6 +734,7 @@ struct EmulSession {
     MeshBvh bvh;
     std::vector<float4> accum, gbuf;
     std::vector<uint2> starts;
+    std::vector<float2> sun_clear;
     std::vector<float> m2, depth;
     PackedReservoir *res[2] = {nullptr, nullptr};
     uint32_t rows = 0, width = 0;
@@ -785,6 +788,8 @@ void *emul_session_create(const f3d_terrain_ref_desc *d, uint32_t row_begin, uin
         s->P.gbuffer_n = s->gbuf.data();
         s->starts.assign(px, uint2{0u, 0u});
         s->P.primary_start = s->starts.data();
+        s->sun_clear.assign(px, float2{3.0e38f, 0.0f});
+        s->P.sun_clear = s->sun_clear.data();
         for (uint32_t y = row_begin; y < row_end; y++) {
             ArrayPending pend;
             for (uint32_t x = 0; x < s->width; x++) gbuffer_pixel(s->P, x, y, s->gbuf.data(), s->depth.data(), pend);
@@ -849,6 +854,37 @@ int emul_session_resolve(void *h, uint32_t frames, uint8_t *rgba, float *albedo,
 }
 
 void emul_session_destroy(void *h) { delete (EmulSession *)h; }
+
+// debugging aid: the sun-ray certificate of one pixel: {clear_from, centre depth, centre origin xyz}
+int emul_sun_clear(const f3d_terrain_ref_desc *d, uint32_t gx, uint32_t gy, float *out) {
+    try {
+        FrameParams P{};
+        (void)fill_uniforms(*d, P);
+        HostTables t = build_tables_host(d->heights, d->dem_width, d->dem_height, d->exaggeration);
+        t.attach(P.terrain);
+        P.row_begin = 0;
+        P.row_end = d->height;
+        ArrayPending pend;
+        const V3 rd = camera_dir(P.cam, gx, gy, 0.0f, 0.0f);
+        const SurfaceHit hit = closest_hit(P, P.cam.origin, 1e-3f, rd, 1e30f, pend);
+        out[0] = 3.0e38f;
+        out[1] = 0.0f;
+        if (hit.kind != 0u) {
+            const V3 o = along(hit.p, 1e-3f, hit.n);
+            out[0] = sun_clear_from(P, o, hit.t);
+            out[1] = hit.t;
+            out[2] = o.x;
+            out[3] = o.y;
+            out[4] = o.z;
+            out[5] = P.light.wi.x;
+            out[6] = P.light.wi.y;
+            out[7] = P.light.wi.z;
+        }
+        return 0;
+    } catch (const Failure &) {
+        return 1;
+    }
+}
 
 // debugging aid: the certificate of one pixel (build with -DF3D_CONE_DEBUG for the walk)
 int emul_primary_start(const f3d_terrain_ref_desc *d, uint32_t gx, uint32_t gy, float *t_clear, uint32_t *level) {

@@ -16,14 +16,16 @@ from oracle import oracle
 def _render_both(dem, size, cam, kw, **extra):
     outs = []
     for off in ("1", None):
-        if off:
-            os.environ["F3D_EMUL_NO_PRIMARY_START"] = off
-        else:
-            os.environ.pop("F3D_EMUL_NO_PRIMARY_START", None)
+        for name in ("F3D_EMUL_NO_PRIMARY_START", "F3D_EMUL_NO_SUN_CLEAR"):
+            if off:
+                os.environ[name] = off
+            else:
+                os.environ.pop(name, None)
         try:
             outs.append(emul.render(dem, size[0], size[1], cam, **kw, **extra))
         finally:
             os.environ.pop("F3D_EMUL_NO_PRIMARY_START", None)
+            os.environ.pop("F3D_EMUL_NO_SUN_CLEAR", None)
     return outs
 
 
@@ -102,6 +104,47 @@ def test_certificates_are_conservative_and_do_something():
     for (t_clear, level), (gx, gy) in zip(starts, pixels):
         partial += 0.0 < t_clear < 1e37
     assert partial >= len(pixels) // 3, (partial, len(pixels))
+
+
+def test_sun_certificates_are_conservative_and_do_something():
+    """Sun rays from points around the centre sample's origin (within the radius the certificate allows for) meet no
+    terrain beyond the pixel's clear_from: the oracle's closest hits along them say where they do."""
+    dem = _cliff_dem()
+    W, H = 64, 48
+    rng = np.random.default_rng(5)
+    total = certified = 0
+    for (name, cam), (az, el) in zip(CAMERAS[:5], ((200.0, 30.0), (90.0, 6.0), (178.0, 4.3), (300.0, 55.0), (45.0, 15.0))):
+        cam = {**cam, "up": (0.0, 1.0, 0.0), "fov_y": 40.0, "exposure": 1.0}
+        kw = dict(spacing=(1.0, 1.0), exaggeration=1.0, sun_azimuth_deg=az, sun_elevation_deg=el, earth_model="flat", refraction_model="none")
+        pixels = [(x, y) for y in range(2, H, 6) for x in range(2, W, 7)]
+        recs = emul.sun_clear(dem, W, H, cam, pixels, **kw)
+        half_h = np.tan(np.radians(cam["fov_y"]) / 2)
+        plane = np.hypot(half_h * W / H / W, half_h / H)
+        delta = 1.01 * plane * (1 + plane * plane)
+        rays, owner = [], []
+        for i, rec in enumerate(recs):
+            if rec["depth"] == 0.0:
+                continue
+            total += 1
+            if rec["clear_from"] > 1e37:
+                continue
+            certified += 1
+            slack = 1.0 * rec["depth"] * delta + 0.5
+            rho = slack + (rec["depth"] + slack) * delta
+            for _ in range(24):
+                off = rng.normal(size=3)
+                off *= rng.uniform(0.0, rho) / np.linalg.norm(off)
+                rays.append([*(np.array(rec["origin"]) + off), 1e-3, *rec["wi"], 1e30])
+                owner.append(i)
+        if not rays:
+            continue
+        n = dem.shape[0]
+        hit = oracle.terrain_trace_batch(dem, np.array(rays, np.float32), origin=(-0.5 * (n - 1), -0.5 * (n - 1)), any_hit=False,
+                                         apply_curvature=False)
+        for k, i in enumerate(owner):
+            if hit["hit"][k]:
+                assert hit["t"][k] <= recs[i]["clear_from"] + 1e-3, (name, pixels[i], recs[i], float(hit["t"][k]))
+    assert certified >= 10, (certified, total)  # (a small footprint and low suns: most cylinders leave it below the top)
 
 
 @pytest.mark.gpu

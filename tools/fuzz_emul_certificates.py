@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Primary-ray certificates (csrc/f3d_cone.h) on the host emulator: every random scene rendered with the camera rays
-starting where the pixel's certificate ends and again with all of them starting at the root (F3D_EMUL_NO_PRIMARY_START):
+"""Certificates (csrc/f3d_cone.h) on the host emulator: every random scene rendered with the camera rays starting where
+the pixel's cone certificate ends and the sun rays stopping where the pixel's cylinder certificate begins, and again
+with neither (F3D_EMUL_NO_PRIMARY_START, F3D_EMUL_NO_SUN_CLEAR):
 every output must be the same bits.  python tools/fuzz_emul_certificates.py [first_seed] [count]"""
 import os
 import sys
@@ -26,15 +27,17 @@ for seed in range(first, first + count):
     outs = []
     try:
         for off in ("1", None):
-            if off:
-                os.environ["F3D_EMUL_NO_PRIMARY_START"] = off
-            else:
-                os.environ.pop("F3D_EMUL_NO_PRIMARY_START", None)
+            for name in ("F3D_EMUL_NO_PRIMARY_START", "F3D_EMUL_NO_SUN_CLEAR"):
+                if off:
+                    os.environ[name] = off
+                else:
+                    os.environ.pop(name, None)
             outs.append(emul.render(dem, size[0], size[1], cam, sample_lanes=lanes, **kw))
     except RuntimeError:
         continue
     finally:
         os.environ.pop("F3D_EMUL_NO_PRIMARY_START", None)
+        os.environ.pop("F3D_EMUL_NO_SUN_CLEAR", None)
     done += 1
     if not all(np.array_equal(outs[0][k], outs[1][k], equal_nan=True) for k in ("rgba", "albedo", "normal", "depth", "accum", "m2", "res")):
         bad.append(seed)
