@@ -221,4 +221,101 @@ F3D_HD float sun_clear_from(const FrameParams &P, V3 origin, float centre_depth)
     return clear_from < at ? clear_from : none;
 }
 
+// ---- where the IBL rays of a pixel can stop -------------------------------------------------------------------------
+// An IBL ray has a random direction, but its origin is a sample's hit point, within `rho` of the centre sample's.  For
+// each of 8 azimuth sectors ibl_far_horizon() finds the steepest slope under which anything of the terrain FARTHER than
+// `near` (horizontally) is seen from the lowest of those origins: a ray of that sector that climbs more steeply is above
+// every cell beyond `near`, so its march may stop once it has left the near cells behind (f3d_march.h t_stop).  Nodes
+// are taken whole as soon as they are small against their distance; the bound of a node (its maximum over its nearest
+// point) bounds all its cells, so coarse nodes only make the horizon more cautious.
+F3D_HD uint32_t ibl_sector(float dx, float dz) {
+    return (dx < 0.0f ? 1u : 0u) | (dz < 0.0f ? 2u : 0u) | (f_abs(dz) > f_abs(dx) ? 4u : 0u);
+}
+F3D_HD float ibl_rho(float centre_depth, float delta, float cell) {
+    const float slack = sun_depth_slack(centre_depth, delta, cell);
+    return slack + (centre_depth + slack) * delta + 4e-3f;
+}
+F3D_HD float ibl_near(float rho, float cell) { return 4.0f * (cell + 2.0f * rho); }           // cells nearer than this are the march's
+F3D_HD float ibl_stop_distance(float rho, float cell) { return ibl_near(rho, cell) + 2.0f * cell + 2.0f * rho; }
+
+// out[8]: the far horizon's slope per sector (3e38: no certificate for that sector)
+F3D_HD void ibl_far_horizon(const FrameParams &P, V3 origin, float centre_depth, float *out) {
+    const TerrainDev &T = P.terrain;
+    const uint32_t top = T.mip_count - 1u;
+    for (uint32_t s = 0u; s < kIblSectors; s++) out[s] = 3.0e38f;
+    const float delta = pixel_cone_delta(P.cam);
+    if (delta < 0.0f) return;
+    const float cell_min = f_min(T.spacing_x, T.spacing_z), cell_max = f_max(T.spacing_x, T.spacing_z);
+    const float rho = ibl_rho(centre_depth, delta, cell_min);
+    const float near = ibl_near(rho, cell_max);
+    const float y_scale = f_abs(origin.y) + f_abs(T.bands[T.band_offset[top]].mx) + f_abs(T.bands[T.band_offset[top]].mn);
+    const float y_lo = origin.y - rho - (1e-4f * y_scale + 1e-3f);
+    float best[kIblSectors];
+    for (uint32_t s = 0u; s < kIblSectors; s++) best[s] = -3.0e38f;
+    uint32_t stack[64];
+    uint32_t sp = 0u;
+    stack[sp++] = top << 26;
+    uint32_t visited = 0u;
+    while (sp != 0u) {
+        if (++visited > 20000u) return;  // (never seen; a pathological DEM simply gets no certificate)
+        const uint32_t e = stack[--sp];
+        const uint32_t l = e >> 26, nz = (e >> 13) & 0x1FFFu, nx = e & 0x1FFFu;
+        if ((nx << l) >= T.cell_w || (nz << l) >= T.cell_h) continue;
+        uint32_t cx1 = (nx + 1u) << l, cz1 = (nz + 1u) << l;
+        cx1 = cx1 < T.cell_w ? cx1 : T.cell_w;
+        cz1 = cz1 < T.cell_h ? cz1 : T.cell_h;
+        const float x0 = plane_at(T.origin_x, nx << l, T.spacing_x) - origin.x, x1 = plane_at(T.origin_x, cx1, T.spacing_x) - origin.x;
+        const float z0 = plane_at(T.origin_z, nz << l, T.spacing_z) - origin.z, z1 = plane_at(T.origin_z, cz1, T.spacing_z) - origin.z;
+        // nearest and farthest point of the rectangle from the origin (in the plane)
+        const float nxp = f_max(f_max(x0, -x1), 0.0f), nzp = f_max(f_max(z0, -z1), 0.0f);
+        const float fxp = f_max(f_abs(x0), f_abs(x1)), fzp = f_max(f_abs(z0), f_abs(z1));
+        const float dmin = f_sqrt(nxp * nxp + nzp * nzp), dmax = f_sqrt(fxp * fxp + fzp * fzp);
+        if (!(dmax > near)) continue;  // a near node: the march sees it
+        const float mx = T.bands[T.band_offset[l] + (nz << T.band_shift[l]) + nx].mx;
+        const float den = f_max(dmin, near) - rho - 0.02f * cell_min;  // > 0: near > 2 rho + cell
+        const float bound = (mx - y_lo) / den;
+        const float size = f_max(x1 - x0, z1 - z0) + 2.0f * rho;
+        const bool small = size * 4.0f <= dmin;  // under ~14 degrees as seen from the origin: its corners tell its sectors
+        uint32_t touched = 0xFFu;
+        if (small) {
+            const float ax0 = x0 - rho, ax1 = x1 + rho, az0 = z0 - rho, az1 = z1 + rho;
+            touched = (1u << ibl_sector(ax0, az0)) | (1u << ibl_sector(ax1, az0)) | (1u << ibl_sector(ax0, az1)) | (1u << ibl_sector(ax1, az1));
+        }
+        float need = 3.0e38f;
+        for (uint32_t s = 0u; s < kIblSectors; s++)
+            if (touched & (1u << s)) need = f_min(need, best[s]);
+        if (!(bound > need)) continue;  // cannot raise any horizon it is part of
+        const bool take = small && (l == 0u || size * 8.0f <= dmin) && dmin >= near;
+        if (take) {
+            for (uint32_t s = 0u; s < kIblSectors; s++)
+                if (touched & (1u << s)) best[s] = f_max(best[s], bound);
+        } else if (l > 0u) {
+            if (sp + 4u > 64u) return;  // (cannot happen: depth-first, at most 3 siblings wait per level)
+            const uint32_t c = ((l - 1u) << 26) | ((2u * nz) << 13) | (2u * nx);
+            stack[sp++] = c;
+            stack[sp++] = c + 1u;
+            stack[sp++] = c + (1u << 13);
+            stack[sp++] = c + (1u << 13) + 1u;
+        } else if (dmin >= near) {
+            // a level-0 cell beyond `near` that is not small cannot exist (near >= 4 (cell + 2 rho)); be safe
+            for (uint32_t s = 0u; s < kIblSectors; s++) best[s] = f_max(best[s], bound);
+        }
+        // (a level-0 cell with dmin < near <= dmax is a near cell: the march's)
+    }
+    for (uint32_t s = 0u; s < kIblSectors; s++) out[s] = best[s];
+}
+
+// The parameter after which the IBL ray (origin within rho of the certificate's, unit direction d) meets no terrain,
+// or 3e38 when its slope does not clear the far horizon of its sector.
+F3D_HD float ibl_stop(const float *far, V3 d, float rho, float cell_max) {
+    const float hlen = f_sqrt(d.x * d.x + d.z * d.z);
+    if (!(hlen > 1e-6f)) return 3.0e38f;
+    const float horizon = far[ibl_sector(d.x, d.z)];
+    if (!(horizon < 1e30f)) return 3.0e38f;
+    const float slope = d.y / hlen;
+    if (!(slope >= 0.0f)) return 3.0e38f;  // (a descending ray is lowest at the FAR edge of a cell: not what the horizon bounds)
+    if (!(slope > horizon + 1e-4f * f_abs(horizon) + 1e-5f)) return 3.0e38f;
+    return ibl_stop_distance(rho, cell_max) / hlen;
+}
+
 }  // namespace f3d

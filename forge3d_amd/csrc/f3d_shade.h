@@ -155,7 +155,7 @@ F3D_HD SurfaceHit closest_hit(const FrameParams &P, V3 o, float tmin, V3 d, floa
     TraceHit th = trace_terrain(P.terrain, r, false, pend);  // the reference-shaped sorted descent
 #else
     // camera rays enter the footprint from outside: the march starts at the root, or where the pixel's certificate ends
-    TraceHit th = march_terrain_from<false>(P.terrain, r, false, march_begin_at(P.terrain, r, t_clear, start_level), pend);
+    TraceHit th = march_terrain_from<false, false>(P.terrain, r, false, march_begin_at(P.terrain, r, t_clear, start_level), pend);
 #endif
     if (th.hit && th.t < best.t) {
         best.kind = 1u;
@@ -200,7 +200,7 @@ F3D_HD bool occluded(const FrameParams &P, V3 o, float tmin, V3 d, float tmax, b
     // (with the curvature policy switched off for the whole render, c2 = 0 and fma(t*t, 0, y) == y: the
     // curved instantiation then computes the flat answers exactly, so there is no third copy of the march)
     TraceHit th = apply_curvature ? march_terrain<true>(P.terrain, r, true, true, pend, terrain_tmax)
-                                  : march_terrain<false>(P.terrain, r, true, true, pend);
+                                  : march_terrain<false>(P.terrain, r, true, true, pend, terrain_tmax);
 #endif
     if (th.hit && th.t < best_t) {
         best_t = th.t;
@@ -433,6 +433,7 @@ struct PrimaryHit {
     V3 rd;
     uint32_t rng;    // stream state after the two jitter draws
     float sun_tmax;  // the sample's sun ray meets no terrain beyond this parameter (1e30: no certificate)
+    uint32_t cert;   // strip-local pixel whose certificates cover this sample's hit point; 0xFFFFFFFF: none
 };
 
 template <class Pending>
@@ -447,11 +448,16 @@ F3D_HD PrimaryHit sample_primary(const FrameParams &P, uint32_t gx, uint32_t gy,
 #endif
     ph.hit = closest_hit(P, P.cam.origin, 1e-3f, ph.rd, 1e30f, pend, f_from_bits(start.x), start.y);
     ph.sun_tmax = 1e30f;
+    ph.cert = 0xFFFFFFFFu;
 #if !defined(F3D_NO_SUN_CLEAR)  // A/B builds
     if (P.sun_clear && ph.hit.kind != 0u) {
-        const float2 c = P.sun_clear[(size_t)(gy - P.row_begin) * P.cam.width + gx];
+        const uint32_t lp = (gy - P.row_begin) * P.cam.width + gx;
+        const float2 c = P.sun_clear[lp];
         const float cell = f_min(P.terrain.spacing_x, P.terrain.spacing_z);
-        if (c.x < 1e30f && f_abs(ph.hit.t - c.y) <= sun_depth_slack(c.y, pixel_cone_delta(P.cam), cell)) ph.sun_tmax = c.x;
+        if (c.y > 0.0f && f_abs(ph.hit.t - c.y) <= sun_depth_slack(c.y, pixel_cone_delta(P.cam), cell)) {
+            ph.cert = lp;  // the sample's hit point is within the radius the pixel's certificates allow for
+            if (c.x < 1e30f) ph.sun_tmax = c.x;
+        }
     }
 #endif
     ph.rng = rng;
@@ -469,6 +475,7 @@ struct IblRay {
     V3 o, d;     // origin (hit point lifted off the surface), cosine-weighted direction
     V3 b0;       // albedo * env(d)
     float key;   // cos(normal, d): small = grazing = a long march (scheduling hint only)
+    float t_stop;  // no terrain beyond this parameter (f3d_cone.h ibl_stop); 3e38: no certificate
 };
 
 // First half of the shading of a sample whose primary hit is known (:486-536): candidate, sun term
@@ -480,6 +487,7 @@ F3D_HD IblRay sample_shade_sun(const FrameParams &P, const FrameHead &h, const P
     q.valid = false;
     q.o = q.d = q.b0 = V3{0.0f, 0.0f, 0.0f};
     q.key = 2.0f;
+    q.t_stop = 3.0e38f;
     o.b = V3{0.0f, 0.0f, 0.0f};
     o.target_pdf = 0.0f;
     if (ph.hit.kind == 0u) {
@@ -517,16 +525,22 @@ F3D_HD IblRay sample_shade_sun(const FrameParams &P, const FrameHead &h, const P
     q.d = ei;
     q.b0 = albedo * env_radiance(P.env, ei);
     q.key = dot(n, ei);
+#if !defined(F3D_NO_IBL_STOP)  // A/B builds
+    if (P.ibl_far && ph.cert != 0xFFFFFFFFu) {
+        const float cell_min = f_min(P.terrain.spacing_x, P.terrain.spacing_z), cell_max = f_max(P.terrain.spacing_x, P.terrain.spacing_z);
+        q.t_stop = ibl_stop(P.ibl_far + (size_t)ph.cert * kIblSectors, ei, ibl_rho(P.sun_clear[ph.cert].y, pixel_cone_delta(P.cam), cell_min), cell_max);
+    }
+#endif
     return q;
 }
 
 // The verdict of an IBL ray (intersect_ibl_occlusion_ray, hybrid_traversal.wgsl:250-259).
 template <class Pending>
-F3D_HD bool ibl_occluded(const FrameParams &P, V3 o, V3 d, Pending &pend) {
+F3D_HD bool ibl_occluded(const FrameParams &P, V3 o, V3 d, Pending &pend, float t_stop = 3.0e38f) {
 #if defined(F3D_TIMING_NO_IBL)  // timing experiment only (wrong image): tools/gpu_build_ab.sh, profiles/README.md
     return false;
 #else
-    return occluded(P, o, 1e-3f, d, 1e30f, false, pend);
+    return occluded(P, o, 1e-3f, d, 1e30f, false, pend, t_stop);
 #endif
 }
 
@@ -536,7 +550,7 @@ F3D_HD SampleOut sample_shade(const FrameParams &P, const FrameHead &h, const Pr
                               Pending &pend) {
     SampleOut o;
     const IblRay q = sample_shade_sun(P, h, ph, rng, o, pend);
-    if (q.valid) o.b = q.b0 * (ibl_occluded(P, q.o, q.d, pend) ? 0.0f : 1.0f);
+    if (q.valid) o.b = q.b0 * (ibl_occluded(P, q.o, q.d, pend, q.t_stop) ? 0.0f : 1.0f);
     return o;
 }
 
@@ -686,6 +700,12 @@ F3D_HD void gbuffer_pixel(const FrameParams &P, uint32_t gx, uint32_t gy, float4
         float2 c = float2{3.0e38f, 0.0f};
         if (hit.kind != 0u) c = float2{sun_clear_from(P, along(hit.p, 1e-3f, hit.n), hit.t), hit.t};
         P.sun_clear[lp] = c;
+        if (P.ibl_far) {
+            float far[kIblSectors];
+            for (uint32_t s = 0u; s < kIblSectors; s++) far[s] = 3.0e38f;
+            if (hit.kind != 0u) ibl_far_horizon(P, along(hit.p, 1e-3f, hit.n), hit.t, far);
+            for (uint32_t s = 0u; s < kIblSectors; s++) P.ibl_far[lp * kIblSectors + s] = far[s];
+        }
     }
     if (hit.kind != 0u) {
         gbuffer_n[lp] = float4{hit.n.x, hit.n.y, hit.n.z, (float)hit.kind};

@@ -563,6 +563,8 @@ int emul_render(const f3d_terrain_ref_desc *d, uint32_t row_begin, uint32_t row_
         P.primary_start = starts.empty() ? nullptr : starts.data();
         std::vector<float2> sun_clear(getenv("F3D_EMUL_NO_SUN_CLEAR") ? 0 : px);
         P.sun_clear = sun_clear.empty() ? nullptr : sun_clear.data();
+        std::vector<float> ibl_far((getenv("F3D_EMUL_NO_IBL_STOP") || sun_clear.empty()) ? 0 : px * kIblSectors);
+        P.ibl_far = ibl_far.empty() ? nullptr : ibl_far.data();
 #pragma omp parallel for schedule(dynamic, 4)
         for (long y = row_begin; y < (long)row_end; y++) {
             ArrayPending pend;
@@ -735,6 +737,7 @@ struct EmulSession {
     std::vector<float4> accum, gbuf;
     std::vector<uint2> starts;
     std::vector<float2> sun_clear;
+    std::vector<float> ibl_far;
     std::vector<float> m2, depth;
     PackedReservoir *res[2] = {nullptr, nullptr};
     uint32_t rows = 0, width = 0;
@@ -790,6 +793,8 @@ void *emul_session_create(const f3d_terrain_ref_desc *d, uint32_t row_begin, uin
         s->P.primary_start = s->starts.data();
         s->sun_clear.assign(px, float2{3.0e38f, 0.0f});
         s->P.sun_clear = s->sun_clear.data();
+        s->ibl_far.assign(px * kIblSectors, 3.0e38f);
+        s->P.ibl_far = s->ibl_far.data();
         for (uint32_t y = row_begin; y < row_end; y++) {
             ArrayPending pend;
             for (uint32_t x = 0; x < s->width; x++) gbuffer_pixel(s->P, x, y, s->gbuf.data(), s->depth.data(), pend);
@@ -854,6 +859,35 @@ int emul_session_resolve(void *h, uint32_t frames, uint8_t *rgba, float *albedo,
 }
 
 void emul_session_destroy(void *h) { delete (EmulSession *)h; }
+
+// debugging aid: the IBL certificate of one pixel: out[0..7] far-horizon slopes, [8] rho, [9] stop distance, [10..12] origin
+int emul_ibl_far(const f3d_terrain_ref_desc *d, uint32_t gx, uint32_t gy, float *out) {
+    try {
+        FrameParams P{};
+        (void)fill_uniforms(*d, P);
+        HostTables t = build_tables_host(d->heights, d->dem_width, d->dem_height, d->exaggeration);
+        t.attach(P.terrain);
+        P.row_begin = 0;
+        P.row_end = d->height;
+        ArrayPending pend;
+        const V3 rd = camera_dir(P.cam, gx, gy, 0.0f, 0.0f);
+        const SurfaceHit hit = closest_hit(P, P.cam.origin, 1e-3f, rd, 1e30f, pend);
+        for (int i = 0; i < 13; i++) out[i] = 3.0e38f;
+        if (hit.kind != 0u) {
+            const V3 o = along(hit.p, 1e-3f, hit.n);
+            ibl_far_horizon(P, o, hit.t, out);
+            const float cell_min = f_min(P.terrain.spacing_x, P.terrain.spacing_z), cell_max = f_max(P.terrain.spacing_x, P.terrain.spacing_z);
+            out[8] = ibl_rho(hit.t, pixel_cone_delta(P.cam), cell_min);
+            out[9] = ibl_stop_distance(out[8], cell_max);
+            out[10] = o.x;
+            out[11] = o.y;
+            out[12] = o.z;
+        }
+        return 0;
+    } catch (const Failure &) {
+        return 1;
+    }
+}
 
 // debugging aid: the sun-ray certificate of one pixel: {clear_from, centre depth, centre origin xyz}
 int emul_sun_clear(const f3d_terrain_ref_desc *d, uint32_t gx, uint32_t gy, float *out) {

@@ -16,7 +16,7 @@ from oracle import oracle
 def _render_both(dem, size, cam, kw, **extra):
     outs = []
     for off in ("1", None):
-        for name in ("F3D_EMUL_NO_PRIMARY_START", "F3D_EMUL_NO_SUN_CLEAR"):
+        for name in ("F3D_EMUL_NO_PRIMARY_START", "F3D_EMUL_NO_SUN_CLEAR", "F3D_EMUL_NO_IBL_STOP"):
             if off:
                 os.environ[name] = off
             else:
@@ -26,6 +26,7 @@ def _render_both(dem, size, cam, kw, **extra):
         finally:
             os.environ.pop("F3D_EMUL_NO_PRIMARY_START", None)
             os.environ.pop("F3D_EMUL_NO_SUN_CLEAR", None)
+            os.environ.pop("F3D_EMUL_NO_IBL_STOP", None)
     return outs
 
 
@@ -145,6 +146,44 @@ def test_sun_certificates_are_conservative_and_do_something():
             if hit["hit"][k]:
                 assert hit["t"][k] <= recs[i]["clear_from"] + 1e-3, (name, pixels[i], recs[i], float(hit["t"][k]))
     assert certified >= 10, (certified, total)  # (a small footprint and low suns: most cylinders leave it below the top)
+
+
+def test_ibl_certificates_are_conservative_and_do_something():
+    """A ray that starts within rho of the certificate's origin and climbs more steeply than the far horizon of its
+    sector meets no terrain beyond the stop distance (the oracle's closest hit along it says where it does)."""
+    dem = scenes.golden_dem()
+    kw = scenes.scene_kwargs(dem)
+    geo = {k: kw[k] for k in ("spacing", "exaggeration")}
+    W, H = 96, 64
+    pixels = [(x, y) for y in range(3, H, 5) for x in range(2, W, 7)]
+    recs = emul.ibl_far(dem, W, H, scenes.CAM, pixels, **geo)
+    rng = np.random.default_rng(9)
+    rays, meta = [], []
+    sectors_with_horizon = 0
+    for rec in recs:
+        if rec["rho"] > 1e37:
+            continue
+        sectors_with_horizon += sum(1 for h in rec["far"] if h < 1e30)
+        for _ in range(40):
+            az = rng.uniform(0, 2 * np.pi)
+            dx, dz = np.cos(az), np.sin(az)
+            sector = (1 if dx < 0 else 0) | (2 if dz < 0 else 0) | (4 if abs(dz) > abs(dx) else 0)
+            horizon = rec["far"][sector]
+            if not horizon < 1e30:
+                continue
+            slope = max(horizon, 0.0) * 1.001 + 2e-4 + rng.exponential(0.3)
+            d = np.array([dx, slope, dz]) / np.sqrt(1 + slope * slope)
+            off = rng.normal(size=3)
+            off *= rng.uniform(0.0, rec["rho"]) / np.linalg.norm(off)
+            rays.append([*(np.array(rec["origin"]) + off), 1e-3, *d, 1e30])
+            meta.append(rec["stop_distance"] / np.hypot(d[0], d[2]))
+    sx, sz = kw["spacing"]
+    hit = oracle.terrain_trace_batch(dem, np.array(rays, np.float32), origin=(-0.5 * (dem.shape[1] - 1) * sx, -0.5 * (dem.shape[0] - 1) * sz),
+                                     spacing=kw["spacing"], exaggeration=kw["exaggeration"], any_hit=False, apply_curvature=False)
+    for k, t_stop in enumerate(meta):
+        if hit["hit"][k]:
+            assert hit["t"][k] <= t_stop, (rays[k], float(hit["t"][k]), t_stop)
+    assert sectors_with_horizon > 2 * len(recs) and len(rays) > 500
 
 
 @pytest.mark.gpu

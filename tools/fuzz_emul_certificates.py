@@ -27,7 +27,7 @@ for seed in range(first, first + count):
     outs = []
     try:
         for off in ("1", None):
-            for name in ("F3D_EMUL_NO_PRIMARY_START", "F3D_EMUL_NO_SUN_CLEAR"):
+            for name in ("F3D_EMUL_NO_PRIMARY_START", "F3D_EMUL_NO_SUN_CLEAR", "F3D_EMUL_NO_IBL_STOP"):
                 if off:
                     os.environ[name] = off
                 else:
@@ -38,6 +38,7 @@ for seed in range(first, first + count):
     finally:
         os.environ.pop("F3D_EMUL_NO_PRIMARY_START", None)
         os.environ.pop("F3D_EMUL_NO_SUN_CLEAR", None)
+        os.environ.pop("F3D_EMUL_NO_IBL_STOP", None)
     done += 1
     if not all(np.array_equal(outs[0][k], outs[1][k], equal_nan=True) for k in ("rgba", "albedo", "normal", "depth", "accum", "m2", "res")):
         bad.append(seed)
