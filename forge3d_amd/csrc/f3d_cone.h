@@ -170,6 +170,8 @@ F3D_HD float sun_clear_from(const FrameParams &P, V3 origin, float centre_depth)
     const bool x_forward = !(r.d.x < 0.0f), z_forward = !(r.d.z < 0.0f);
     uint32_t level = top, nx = 0u, nz = 0u;
     float at = t_in, clear_from = t_in;  // the cylinder is known to be clear on [clear_from, at]
+    float last_width = 0.0f;
+    bool exit_x = false, exit_z = false;
     for (uint32_t iter = 0u; iter < 1024u; iter++) {
         uint32_t cx1 = (nx + 1u) << level, cz1 = (nz + 1u) << level;
         cx1 = cx1 < T.cell_w ? cx1 : T.cell_w;
@@ -204,8 +206,11 @@ F3D_HD float sun_clear_from(const FrameParams &P, V3 origin, float centre_depth)
         }
         if (!pass) clear_from = b;  // terrain reaches the cylinder in this node: whatever is clear starts after it
         at = b;
-        if (!(b < t_out)) break;
         const bool cross_x = x_out <= z_out, cross_z = z_out <= x_out;
+        last_width = cell * (float)(1u << ql);
+        exit_x = cross_x;
+        exit_z = cross_z;
+        if (!(b < t_out)) break;
         const uint32_t qx = nx + ((cross_x && x_forward) ? 1u : 0u) - ((cross_x && !x_forward) ? 1u : 0u);
         const uint32_t qz = nz + ((cross_z && z_forward) ? 1u : 0u) - ((cross_z && !z_forward) ? 1u : 0u);
         if ((qx << level) >= T.cell_w || (qz << level) >= T.cell_h) break;
@@ -214,11 +219,19 @@ F3D_HD float sun_clear_from(const FrameParams &P, V3 origin, float centre_depth)
         nz = up ? qz >> 1 : qz;
         level = up ? level + 1u : level;
     }
-    // The centre line has left the footprint, but one side of the cylinder may run on over it (a ray leaving through a
-    // side at a shallow angle travels along the edge): certified only if the cylinder is above EVERYTHING from here on --
-    // the rays only rise (d.y >= 0).
-    if (!(lowest(at) > T.bands[T.band_offset[top]].mx)) return none;
-    return clear_from < at ? clear_from : none;
+    if (!(clear_from < at)) return none;  // the last node was not clear
+    // The centre line has left the footprint, but one side of the cylinder may run on over it for a while: a line
+    // leaving through one edge is `radius` away from it after radius / |d_perp|, having moved radius |d_par| / |d_perp|
+    // along it.  If that stretch (plus the radius) is shorter than the nodes of the last test, every cell the cylinder
+    // is still over lay in that test's 3 x 3 block, and the rays only rise (d.y >= 0).  Else -- a shallow exit, or
+    // through a corner -- certified only if the cylinder is above EVERYTHING from here on.
+    bool edge_ok = false;
+    if (exit_x != exit_z) {
+        const float perp = f_abs(exit_x ? r.d.x : r.d.z), par = f_abs(exit_x ? r.d.z : r.d.x);
+        edge_ok = perp > 0.0f && radius * (par / perp) + radius <= last_width;
+    }
+    if (!edge_ok && !(lowest(at) > T.bands[T.band_offset[top]].mx)) return none;
+    return clear_from;
 }
 
 // ---- where the IBL rays of a pixel can stop -------------------------------------------------------------------------

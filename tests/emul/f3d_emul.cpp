@@ -585,6 +585,22 @@ int emul_render(const f3d_terrain_ref_desc *d, uint32_t row_begin, uint32_t row_
             }
             fprintf(stderr, "certificates: none %zu, whole ray %zu, partial %zu (mean t_clear / depth %.3f, mean level %.2f)\n", none, sky, some,
                     some ? frac / (double)some : 0.0, some ? lvl / (double)some : 0.0);
+            if (P.sun_clear) {
+                size_t hits = 0, with = 0, sectors = 0;
+                double mean_from = 0.0;
+                for (size_t i = 0; i < px; i++) {
+                    if (gbuf[i].w == 0.0f) continue;
+                    hits++;
+                    if (sun_clear[i].x < 1e30f) {
+                        with++;
+                        mean_from += sun_clear[i].x;
+                    }
+                    if (P.ibl_far)
+                        for (uint32_t k = 0; k < kIblSectors; k++) sectors += ibl_far[i * kIblSectors + k] < 1e30f;
+                }
+                fprintf(stderr, "sun certificates: %zu of %zu hit pixels (mean clear_from %.1f); IBL sectors with a horizon: %.2f of 8\n", with, hits,
+                        with ? mean_from / (double)with : 0.0, hits ? (double)sectors / (double)hits : 0.0);
+            }
         }
         uint32_t frames = 0;
         float variance = INFINITY;
