@@ -248,7 +248,9 @@ F3D_HD float ibl_rho(float centre_depth, float delta, float cell) {
     const float slack = sun_depth_slack(centre_depth, delta, cell);
     return slack + (centre_depth + slack) * delta + 4e-3f;
 }
-F3D_HD float ibl_near(float rho, float cell) { return 4.0f * (cell + 2.0f * rho); }           // cells nearer than this are the march's
+// cells nearer than this are the march's; beyond it a cell (dilated by rho) is seen under less than ~35 degrees, so its
+// four corners tell which of the 45-degree sectors it is part of
+F3D_HD float ibl_near(float rho, float cell) { return 2.5f * (cell + 2.0f * rho); }
 F3D_HD float ibl_stop_distance(float rho, float cell) { return ibl_near(rho, cell) + 2.0f * cell + 2.0f * rho; }
 
 // out[8]: the far horizon's slope per sector (3e38: no certificate for that sector)
@@ -288,7 +290,7 @@ F3D_HD void ibl_far_horizon(const FrameParams &P, V3 origin, float centre_depth,
         const float den = f_max(dmin, near) - rho - 0.02f * cell_min;  // > 0: near > 2 rho + cell
         const float bound = (mx - y_lo) / den;
         const float size = f_max(x1 - x0, z1 - z0) + 2.0f * rho;
-        const bool small = size * 4.0f <= dmin;  // under ~14 degrees as seen from the origin: its corners tell its sectors
+        const bool small = size * 2.5f <= dmin;  // under ~35 degrees (diagonal) as seen from the origin: its corners tell its sectors
         uint32_t touched = 0xFFu;
         if (small) {
             const float ax0 = x0 - rho, ax1 = x1 + rho, az0 = z0 - rho, az1 = z1 + rho;
@@ -310,7 +312,7 @@ F3D_HD void ibl_far_horizon(const FrameParams &P, V3 origin, float centre_depth,
             stack[sp++] = c + (1u << 13);
             stack[sp++] = c + (1u << 13) + 1u;
         } else if (dmin >= near) {
-            // a level-0 cell beyond `near` that is not small cannot exist (near >= 4 (cell + 2 rho)); be safe
+            // a level-0 cell beyond `near` that is not small cannot exist (near >= 2.5 (cell + 2 rho)); be safe
             for (uint32_t s = 0u; s < kIblSectors; s++) best[s] = f_max(best[s], bound);
         }
         // (a level-0 cell with dmin < near <= dmax is a near cell: the march's)
