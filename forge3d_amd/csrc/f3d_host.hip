@@ -596,6 +596,9 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
     P.accum_mean = (float4 *)s.mem.alloc(px * sizeof(float4), "accumulation");
     P.welford_m2 = (float *)s.mem.alloc(px * sizeof(float), "welford");
     s.gbuffer_n = (float4 *)s.mem.alloc(px * sizeof(float4), "g-buffer");
+    P.primary_start = (uint2 *)s.mem.alloc(px * sizeof(uint2), "primary-ray certificates");
+    P.sun_clear = (float2 *)s.mem.alloc(px * sizeof(float2), "sun-ray certificates");
+    P.ibl_far = (float *)s.mem.alloc(px * kIblSectors * sizeof(float), "IBL-ray certificates");
     s.depth = (float *)s.mem.alloc(px * sizeof(float), "depth AOV");
     s.d_rgba = (uint8_t *)s.mem.alloc(px * 4, "rgba8 output");
     s.d_albedo = (float *)s.mem.alloc(px * 3 * sizeof(float), "albedo AOV");

@@ -301,6 +301,7 @@ __device__ __forceinline__ float frame_lanes(const FrameParams &P, uint32_t gx, 
         q.valid = false;
         q.o = q.d = q.b0 = V3{0.0f, 0.0f, 0.0f};
         q.key = 2.0f;
+        q.t_stop = 3.0e38f;
         if (act) {
             uint32_t rng = ph.rng;
             q = sample_shade_sun(P, h, ph, rng, o, pend);
@@ -309,7 +310,7 @@ __device__ __forceinline__ float frame_lanes(const FrameParams &P, uint32_t gx, 
         // length, 1.6x fewer IBL wave iterations in the step-log model -- was built and measured: bit-identical,
         // but 0.81x: the waves that finish early wait at the workgroup barrier and the occupancy the kernel
         // lives on is gone.  profiles/README.md)
-        if (q.valid) o.b = q.b0 * (ibl_occluded(P, q.o, q.d, pend) ? 0.0f : 1.0f);
+        if (q.valid) o.b = q.b0 * (ibl_occluded(P, q.o, q.d, pend, q.t_stop) ? 0.0f : 1.0f);
         V3 radiance = V3{f_from_bits(park[0]), f_from_bits(park[kWave]), f_from_bits(park[2 * kWave])};
         Reservoir cand;
         cand.w_sum = f_from_bits(park[3 * kWave]);
@@ -408,11 +409,12 @@ __device__ __forceinline__ void trace_lanes(const FrameParams &P, uint32_t frame
         q.valid = false;
         q.o = q.d = q.b0 = V3{0.0f, 0.0f, 0.0f};
         q.key = 2.0f;
+        q.t_stop = 3.0e38f;
         if (act) {
             uint32_t rng = ph.rng;
             q = sample_shade_sun(P, h, ph, rng, o, pend);
         }
-        if (q.valid) o.b = q.b0 * (ibl_occluded(P, q.o, q.d, pend) ? 0.0f : 1.0f);
+        if (q.valid) o.b = q.b0 * (ibl_occluded(P, q.o, q.d, pend, q.t_stop) ? 0.0f : 1.0f);
         if (act) {
             float4 *rec = out + 2u * (size_t)(s0 + j) * pixels;
             rec[0] = float4{o.a.x, o.a.y, o.a.z, o.target_pdf};

@@ -439,10 +439,10 @@ F3D_HD void march_deal(const TerrainDev &T, MarchSlice &s, MarchState &m, const 
 // Phase 2 of an any-hit march (see above).  `m` holds the lane's position on its own ray, own_hit its
 // verdict so far; returns the final verdict of the lane's OWN ray.
 template <bool CURVED, class Ctx>
-F3D_HD bool march_shared(const TerrainDev &T, const RayCtx &own_ray, MarchState m, bool own_hit, Ctx &ctx) {
+F3D_HD bool march_shared(const TerrainDev &T, const RayCtx &own_ray, MarchState m, bool own_hit, Ctx &ctx, float t_stop = 3.0e38f) {
     MarchSlice s;
     s.r = own_ray;
-    s.t_stop = 3.0e38f;
+    s.t_stop = t_stop;  // (a certificate that nothing lies beyond: the last slice ends there)
     s.owner = ctx.lane();
     {
         float lo;
@@ -472,24 +472,53 @@ F3D_HD bool march_shared(const TerrainDev &T, const RayCtx &own_ray, MarchState 
     return ctx.verdict_get(ctx.lane());
 }
 
+// A camera ray whose pixel holds a certificate (f3d_cone.h primary_start): every ray of the pixel is above every cell it
+// passes up to t_clear, so the nodes before it are exactly those the march would reject without solving a leaf.  The
+// lane starts in the node of `level` that contains the ray at t_clear -- located from the position and validated by
+// that node's own interval on the first step, like the in-cell start of the secondary rays.
+F3D_HD MarchState march_begin_at(const TerrainDev &T, const RayCtx &r, float t_clear, uint32_t level) {
+    MarchState m;
+    float hi;
+    march_root_interval(T, r, m.t_cur, hi);
+    m.marching = !(m.t_cur > hi);
+    m.level = T.mip_count - 1u;
+    m.nx = 0u;
+    m.nz = 0u;
+    m.unverified_start = false;
+    if (m.marching && t_clear > m.t_cur) {
+        if (!(t_clear < hi)) {
+            m.marching = false;  // clear until the ray leaves the footprint (or reaches tmax): no terrain hit
+        } else {
+            m.t_cur = t_clear;
+            m.level = level < m.level ? level : m.level;
+            march_locate(T, r, t_clear, m.level, m.nx, m.nz);
+            m.unverified_start = true;
+        }
+    }
+    return m;
+}
+
 // CURVED: the sun-ray curvature policy is active for this ray (compile-time so that the other
 // two thirds of the rays do not carry the parabola arithmetic).  start_in_cell: begin in the cell
 // the ray is in (secondary rays) instead of at the root (camera rays entering from outside).
 // Ctx provides: note(), band_entry(), the FIFO storage fifo_put/fifo_get, the wave votes
 // flush_now(queued, marching) / any(pred), and share_now / deal / verdict_* (ray sharing).
-template <bool CURVED, class Ctx>
-F3D_HD TraceHit march_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit, bool start_in_cell, Ctx &ctx) {
+template <bool CURVED, bool STOP = CURVED, class Ctx>
+F3D_HD TraceHit march_terrain_from(const TerrainDev &T, const RayCtx &r, bool any_hit, MarchState m, Ctx &ctx,
+                                   float t_stop = 3.0e38f) {
     TraceHit res;
     res.hit = false;
     res.t = r.tmax;
     res.n = V3{0.0f, 0.0f, 0.0f};
     ctx.note(2 | (any_hit ? 1 : 0) | (CURVED ? 4 : 0));  // statistics hook: a new ray starts
     ctx.feature(r.d.y);
-    MarchState m = march_begin(T, r, start_in_cell);
     uint32_t queued = 0u;
     bool deal = false;
     for (;;) {
-        if (m.marching) march_step<CURVED, false>(T, r, m, queued, ctx, any_hit);
+        // t_stop (occlusion rays, f3d_cone.h sun_clear_from / ibl_stop): no terrain beyond it, so the lane stops after the node that
+        // contains it -- the SLICED rule; node and leaf intervals are NOT clipped by it, every visited node is judged
+        // exactly as the unbounded march judges it
+        if (m.marching) march_step<CURVED, STOP>(T, r, m, queued, ctx, any_hit, t_stop);
 #if !defined(F3D_NO_SHARE)
 #if defined(F3D_SHARE_CURVED)  // A/B: sun rays too, with their own threshold (profiles/README.md)
         if (any_hit) deal = CURVED ? ctx.share_now(m.marching, F3D_SHARE_CURVED) : ctx.share_now(m.marching);
@@ -503,10 +532,16 @@ F3D_HD TraceHit march_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit
         if (deal || !ctx.any(m.marching || queued != 0u)) break;
     }
     if (deal) {
-        res.hit = march_shared<CURVED>(T, r, m, res.hit, ctx);
+        res.hit = march_shared<CURVED>(T, r, m, res.hit, ctx, t_stop);
         res.t = r.tmin;  // any-hit callers read only `hit` (and t < tmax)
     }
     return res;
+}
+
+template <bool CURVED, class Ctx>
+F3D_HD TraceHit march_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit, bool start_in_cell, Ctx &ctx,
+                              float t_stop = 3.0e38f) {
+    return march_terrain_from<CURVED, true>(T, r, any_hit, march_begin(T, r, start_in_cell), ctx, t_stop);
 }
 
 // Curvature is a per-ray policy AND a per-render switch (wave-uniform): pick the instantiation.

@@ -35,6 +35,9 @@ struct alignas(16) float4 {
 struct alignas(8) uint2 {
     unsigned int x, y;
 };
+struct alignas(8) float2 {
+    float x, y;
+};
 #endif
 
 namespace f3d {

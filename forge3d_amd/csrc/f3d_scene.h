@@ -30,6 +30,7 @@ constexpr uint32_t kWelfordWindow = 32;   // WELFORD_WINDOW, render_terrain.rs:2
 // floor(u * 7) - 3 (pt_restir_spatial.wgsl:171-176) and u = f32(x) / 2^32 IS 1.0 for the top 128 values of x, so the
 // reach is [-3, +4], not the nominal radius 3: 2^-25 of the draws look four rows down.
 constexpr uint32_t kHaloRows = 4;
+constexpr uint32_t kIblSectors = 8;      // azimuth sectors of the IBL rays' far-horizon certificate (f3d_cone.h)
 constexpr uint32_t kDefaultLeafQuorum = 64;  // lanes with a queued leaf that trigger a wave drain
                                              // (64 = only when a FIFO is full or nobody marches; measured best)
 
@@ -152,6 +153,9 @@ struct FrameParams {
     uint32_t tile_map;              // workgroup -> tile mapping (f3d_kernels.hip tile_pixel)
     uint32_t sample_lanes;          // lanes per pixel in the frame kernel: 1 (frame_pixel), 2, 4, 8 (frame_lanes)
     uint2 *head;                    // sample-lane form only: per-pixel record of k_head {reuse_w bits, flags}
+    float *ibl_far;                 // per pixel 8 floats: far-horizon slope per azimuth sector (f3d_cone.h ibl_far_horizon); needs sun_clear
+    float2 *sun_clear;              // per pixel {parameter after which no sun ray of the pixel meets terrain, depth of the centre hit}; null = off
+    uint2 *primary_start;           // per pixel {t_clear bits, level}: where its camera rays may start (f3d_cone.h); null = at the root
     // longest-first dispatch (f3d_kernels.hip k_tile_order): frame-kernel workgroup b renders tile tile_order[b]
     // (null: the tile_map formula); every wave leaves its duration in tile_cost[tile] for the next ordering
     const uint32_t *tile_order;

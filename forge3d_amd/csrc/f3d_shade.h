@@ -131,8 +131,10 @@ F3D_HD bool mesh_closest(const MeshDev &M, V3 o, float tmin, V3 d, float tmax, f
 }
 
 // intersect_hybrid, hybrid_traversal.wgsl:175-201 (closest hit, curvature off)
+// t_clear / level: a certificate for camera rays (f3d_cone.h); t_clear = 0 starts the march at the root.
 template <class Pending>
-F3D_HD SurfaceHit closest_hit(const FrameParams &P, V3 o, float tmin, V3 d, float tmax, Pending &pend) {
+F3D_HD SurfaceHit closest_hit(const FrameParams &P, V3 o, float tmin, V3 d, float tmax, Pending &pend, float t_clear = 0.0f,
+                              uint32_t start_level = 0u) {
     SurfaceHit best;
     best.kind = 0u;
     best.t = tmax;
@@ -152,8 +154,8 @@ F3D_HD SurfaceHit closest_hit(const FrameParams &P, V3 o, float tmin, V3 d, floa
 #if defined(F3D_TRAVERSAL_DESCENT)
     TraceHit th = trace_terrain(P.terrain, r, false, pend);  // the reference-shaped sorted descent
 #else
-    // camera rays enter the footprint from outside: the march starts at the root
-    TraceHit th = march_terrain<false>(P.terrain, r, false, false, pend);
+    // camera rays enter the footprint from outside: the march starts at the root, or where the pixel's certificate ends
+    TraceHit th = march_terrain_from<false, false>(P.terrain, r, false, march_begin_at(P.terrain, r, t_clear, start_level), pend);
 #endif
     if (th.hit && th.t < best.t) {
         best.kind = 1u;
@@ -168,7 +170,7 @@ F3D_HD SurfaceHit closest_hit(const FrameParams &P, V3 o, float tmin, V3 d, floa
 // hybrid_traversal.wgsl:204-259 (any hit; early_exit 0.01; max_distance 1e30)
 template <class Pending>
 F3D_HD bool occluded(const FrameParams &P, V3 o, float tmin, V3 d, float tmax, bool apply_curvature,
-                     Pending &pend) {
+                     Pending &pend, float terrain_tmax = 1e30f) {
     float best_t = tmax;
     bool hit = false;
     if (P.mesh.traversal_mode == 0u) {
@@ -187,6 +189,8 @@ F3D_HD bool occluded(const FrameParams &P, V3 o, float tmin, V3 d, float tmax, b
             }
         }
     }
+    // terrain_tmax: a certificate that no terrain lies beyond it on this ray (f3d_cone.h sun_clear_from): the march stops
+    // after the node that contains it (sun rays only: the curved instantiation carries the stop rule)
     RayCtx r = make_ray(P.terrain, o, tmin, d, best_t, apply_curvature);
 #if defined(F3D_TRAVERSAL_DESCENT)
     TraceHit th = trace_terrain(P.terrain, r, true, pend);  // the reference-shaped sorted descent
@@ -195,8 +199,8 @@ F3D_HD bool occluded(const FrameParams &P, V3 o, float tmin, V3 d, float tmax, b
     // rays carry the curvature policy (apply_curvature is a compile-time constant per call site).
     // (with the curvature policy switched off for the whole render, c2 = 0 and fma(t*t, 0, y) == y: the
     // curved instantiation then computes the flat answers exactly, so there is no third copy of the march)
-    TraceHit th = apply_curvature ? march_terrain<true>(P.terrain, r, true, true, pend)
-                                  : march_terrain<false>(P.terrain, r, true, true, pend);
+    TraceHit th = apply_curvature ? march_terrain<true>(P.terrain, r, true, true, pend, terrain_tmax)
+                                  : march_terrain<false>(P.terrain, r, true, true, pend, terrain_tmax);
 #endif
     if (th.hit && th.t < best_t) {
         best_t = th.t;
@@ -244,6 +248,10 @@ F3D_HD V3 camera_dir(const CameraDev &C, uint32_t gx, uint32_t gy, float jx, flo
     V3 rd = normalize(V3{ndc_x * C.half_w, ndc_y * C.half_h, -1.0f});
     return normalize(combine(rd.x, C.right, rd.y, C.up, rd.z, neg(C.forward)));
 }
+
+}  // namespace f3d
+#include "f3d_cone.h"  // primary_start: where the camera rays of a pixel may start
+namespace f3d {
 
 // ---- reservoirs -------------------------------------------------------------------
 struct Reservoir {  // register form of PackedReservoir
@@ -423,7 +431,9 @@ F3D_HD FrameHead unpack_head(const FrameParams &P, uint32_t gx, uint32_t gy, uin
 struct PrimaryHit {
     SurfaceHit hit;
     V3 rd;
-    uint32_t rng;  // stream state after the two jitter draws
+    uint32_t rng;    // stream state after the two jitter draws
+    float sun_tmax;  // the sample's sun ray meets no terrain beyond this parameter (1e30: no certificate)
+    uint32_t cert;   // strip-local pixel whose certificates cover this sample's hit point; 0xFFFFFFFF: none
 };
 
 template <class Pending>
@@ -432,7 +442,24 @@ F3D_HD PrimaryHit sample_primary(const FrameParams &P, uint32_t gx, uint32_t gy,
     const float jx = tent_offset(rng_next(rng)) * 0.5f;
     const float jy = tent_offset(rng_next(rng)) * 0.5f;
     ph.rd = camera_dir(P.cam, gx, gy, jx, jy);
-    ph.hit = closest_hit(P, P.cam.origin, 1e-3f, ph.rd, 1e30f, pend);
+    uint2 start = uint2{0u, 0u};
+#if !defined(F3D_NO_PRIMARY_START)  // A/B builds (tools/build_variant.sh)
+    if (P.primary_start) start = P.primary_start[(size_t)(gy - P.row_begin) * P.cam.width + gx];
+#endif
+    ph.hit = closest_hit(P, P.cam.origin, 1e-3f, ph.rd, 1e30f, pend, f_from_bits(start.x), start.y);
+    ph.sun_tmax = 1e30f;
+    ph.cert = 0xFFFFFFFFu;
+#if !defined(F3D_NO_SUN_CLEAR)  // A/B builds
+    if (P.sun_clear && ph.hit.kind != 0u) {
+        const uint32_t lp = (gy - P.row_begin) * P.cam.width + gx;
+        const float2 c = P.sun_clear[lp];
+        const float cell = f_min(P.terrain.spacing_x, P.terrain.spacing_z);
+        if (c.y > 0.0f && f_abs(ph.hit.t - c.y) <= sun_depth_slack(c.y, pixel_cone_delta(P.cam), cell)) {
+            ph.cert = lp;  // the sample's hit point is within the radius the pixel's certificates allow for
+            if (c.x < 1e30f) ph.sun_tmax = c.x;
+        }
+    }
+#endif
     ph.rng = rng;
     return ph;
 }
@@ -448,6 +475,7 @@ struct IblRay {
     V3 o, d;     // origin (hit point lifted off the surface), cosine-weighted direction
     V3 b0;       // albedo * env(d)
     float key;   // cos(normal, d): small = grazing = a long march (scheduling hint only)
+    float t_stop;  // no terrain beyond this parameter (f3d_cone.h ibl_stop); 3e38: no certificate
 };
 
 // First half of the shading of a sample whose primary hit is known (:486-536): candidate, sun term
@@ -459,6 +487,7 @@ F3D_HD IblRay sample_shade_sun(const FrameParams &P, const FrameHead &h, const P
     q.valid = false;
     q.o = q.d = q.b0 = V3{0.0f, 0.0f, 0.0f};
     q.key = 2.0f;
+    q.t_stop = 3.0e38f;
     o.b = V3{0.0f, 0.0f, 0.0f};
     o.target_pdf = 0.0f;
     if (ph.hit.kind == 0u) {
@@ -480,7 +509,7 @@ F3D_HD IblRay sample_shade_sun(const FrameParams &P, const FrameHead &h, const P
         pend.hint(F3D_MODEL_HINT_SUN);
 #endif
 #if !defined(F3D_TIMING_NO_SHADOW)  // timing experiment only (wrong image): tools/gpu_build_ab.sh
-        if (P.light.shadows_enabled != 0u && occluded(P, so, 1e-3f, sun_dir, 1e30f, true, pend)) vis = 0.0f;
+        if (P.light.shadows_enabled != 0u && occluded(P, so, 1e-3f, sun_dir, 1e30f, true, pend, ph.sun_tmax)) vis = 0.0f;
 #endif
         o.a = (((albedo * P.light.color) * nd) * vis) * h.reuse_w;
     }
@@ -496,16 +525,22 @@ F3D_HD IblRay sample_shade_sun(const FrameParams &P, const FrameHead &h, const P
     q.d = ei;
     q.b0 = albedo * env_radiance(P.env, ei);
     q.key = dot(n, ei);
+#if !defined(F3D_NO_IBL_STOP)  // A/B builds
+    if (P.ibl_far && ph.cert != 0xFFFFFFFFu) {
+        const float cell_min = f_min(P.terrain.spacing_x, P.terrain.spacing_z), cell_max = f_max(P.terrain.spacing_x, P.terrain.spacing_z);
+        q.t_stop = ibl_stop(P.ibl_far + (size_t)ph.cert * kIblSectors, ei, ibl_rho(P.sun_clear[ph.cert].y, pixel_cone_delta(P.cam), cell_min), cell_max);
+    }
+#endif
     return q;
 }
 
 // The verdict of an IBL ray (intersect_ibl_occlusion_ray, hybrid_traversal.wgsl:250-259).
 template <class Pending>
-F3D_HD bool ibl_occluded(const FrameParams &P, V3 o, V3 d, Pending &pend) {
+F3D_HD bool ibl_occluded(const FrameParams &P, V3 o, V3 d, Pending &pend, float t_stop = 3.0e38f) {
 #if defined(F3D_TIMING_NO_IBL)  // timing experiment only (wrong image): tools/gpu_build_ab.sh, profiles/README.md
     return false;
 #else
-    return occluded(P, o, 1e-3f, d, 1e30f, false, pend);
+    return occluded(P, o, 1e-3f, d, 1e30f, false, pend, t_stop);
 #endif
 }
 
@@ -515,7 +550,7 @@ F3D_HD SampleOut sample_shade(const FrameParams &P, const FrameHead &h, const Pr
                               Pending &pend) {
     SampleOut o;
     const IblRay q = sample_shade_sun(P, h, ph, rng, o, pend);
-    if (q.valid) o.b = q.b0 * (ibl_occluded(P, q.o, q.d, pend) ? 0.0f : 1.0f);
+    if (q.valid) o.b = q.b0 * (ibl_occluded(P, q.o, q.d, pend, q.t_stop) ? 0.0f : 1.0f);
     return o;
 }
 
@@ -656,7 +691,22 @@ F3D_HD void gbuffer_pixel(const FrameParams &P, uint32_t gx, uint32_t gy, float4
                           Pending &pend) {
     const size_t lp = (size_t)(gy - P.row_begin) * P.cam.width + gx;
     const V3 rd = camera_dir(P.cam, gx, gy, 0.0f, 0.0f);
+    if (P.primary_start) {
+        const PrimaryStart ps = primary_start(P, gx, gy);
+        P.primary_start[lp] = uint2{f_bits(ps.t_clear), ps.level};
+    }
     const SurfaceHit hit = closest_hit(P, P.cam.origin, 1e-3f, rd, 1e30f, pend);
+    if (P.sun_clear) {
+        float2 c = float2{3.0e38f, 0.0f};
+        if (hit.kind != 0u) c = float2{sun_clear_from(P, along(hit.p, 1e-3f, hit.n), hit.t), hit.t};
+        P.sun_clear[lp] = c;
+        if (P.ibl_far) {
+            float far[kIblSectors];
+            for (uint32_t s = 0u; s < kIblSectors; s++) far[s] = 3.0e38f;
+            if (hit.kind != 0u) ibl_far_horizon(P, along(hit.p, 1e-3f, hit.n), hit.t, far);
+            for (uint32_t s = 0u; s < kIblSectors; s++) P.ibl_far[lp * kIblSectors + s] = far[s];
+        }
+    }
     if (hit.kind != 0u) {
         gbuffer_n[lp] = float4{hit.n.x, hit.n.y, hit.n.z, (float)hit.kind};
         depth[lp] = hit.t;

@@ -135,6 +135,69 @@ def terrain_trace_batch_wave(heights, rays, *, origin=(0.0, 0.0), spacing=(1.0, 
     return {"hit": hit, "t": t, "normal": nrm, "exchanges": int(stats[0]), "deals": int(stats[1])}
 
 
+def primary_start(heightmap, width, height, camera, pixels, **kw):
+    """(t_clear, level) of the primary-ray certificate (csrc/f3d_cone.h) for each (gx, gy) of `pixels`."""
+    defaults = dict(spacing=(1.0, 1.0), exaggeration=1.0, albedo=(0.6, 0.6, 0.6), sun_azimuth_deg=315.0,
+                    sun_elevation_deg=45.0, sun_intensity=2.5, env_map=None, env_intensity=0.35,
+                    mesh_vertices=None, mesh_indices=None, spp=1, max_frames=512, min_frames=32,
+                    variance_threshold=1e-3, seed=7, sun_color=(1.0, 0.97, 0.92), observer_latitude_deg=0.0,
+                    observer_longitude_deg=0.0, earth_model="ellipsoid", sphere_radius_m=6_371_008.8,
+                    refraction_model="bennett", refraction_k=0.13, pressure_mbar=1013.25, temperature_c=15.0)
+    defaults.update(kw)
+    d, keep = _native.make_desc(heightmap, width, height, dict(camera or {}), **defaults)
+    out = []
+    for gx, gy in pixels:
+        t, level = C.c_float(0), C.c_uint32(0)
+        if lib().emul_primary_start(C.byref(d), C.c_uint32(int(gx)), C.c_uint32(int(gy)), C.byref(t), C.byref(level)) != 0:
+            raise RuntimeError("emul_primary_start failed")
+        out.append((float(t.value), int(level.value)))
+    del keep
+    return out
+
+
+def sun_clear(heightmap, width, height, camera, pixels, **kw):
+    """Per (gx, gy): dict(clear_from, depth, origin, wi) of the sun-ray certificate (csrc/f3d_cone.h sun_clear_from);
+    clear_from > 1e37 = no certificate (or the centre ray misses)."""
+    defaults = dict(spacing=(1.0, 1.0), exaggeration=1.0, albedo=(0.6, 0.6, 0.6), sun_azimuth_deg=315.0,
+                    sun_elevation_deg=45.0, sun_intensity=2.5, env_map=None, env_intensity=0.35,
+                    mesh_vertices=None, mesh_indices=None, spp=1, max_frames=512, min_frames=32,
+                    variance_threshold=1e-3, seed=7, sun_color=(1.0, 0.97, 0.92), observer_latitude_deg=0.0,
+                    observer_longitude_deg=0.0, earth_model="ellipsoid", sphere_radius_m=6_371_008.8,
+                    refraction_model="bennett", refraction_k=0.13, pressure_mbar=1013.25, temperature_c=15.0)
+    defaults.update(kw)
+    d, keep = _native.make_desc(heightmap, width, height, dict(camera or {}), **defaults)
+    out = []
+    for gx, gy in pixels:
+        rec = (C.c_float * 8)()
+        if lib().emul_sun_clear(C.byref(d), C.c_uint32(int(gx)), C.c_uint32(int(gy)), rec) != 0:
+            raise RuntimeError("emul_sun_clear failed")
+        out.append({"clear_from": float(rec[0]), "depth": float(rec[1]), "origin": tuple(float(v) for v in rec[2:5]),
+                    "wi": tuple(float(v) for v in rec[5:8])})
+    del keep
+    return out
+
+
+def ibl_far(heightmap, width, height, camera, pixels, **kw):
+    """Per (gx, gy): dict(far[8], rho, stop_distance, origin) of the IBL certificate (csrc/f3d_cone.h ibl_far_horizon)."""
+    defaults = dict(spacing=(1.0, 1.0), exaggeration=1.0, albedo=(0.6, 0.6, 0.6), sun_azimuth_deg=315.0,
+                    sun_elevation_deg=45.0, sun_intensity=2.5, env_map=None, env_intensity=0.35,
+                    mesh_vertices=None, mesh_indices=None, spp=1, max_frames=512, min_frames=32,
+                    variance_threshold=1e-3, seed=7, sun_color=(1.0, 0.97, 0.92), observer_latitude_deg=0.0,
+                    observer_longitude_deg=0.0, earth_model="ellipsoid", sphere_radius_m=6_371_008.8,
+                    refraction_model="bennett", refraction_k=0.13, pressure_mbar=1013.25, temperature_c=15.0)
+    defaults.update(kw)
+    d, keep = _native.make_desc(heightmap, width, height, dict(camera or {}), **defaults)
+    out = []
+    for gx, gy in pixels:
+        rec = (C.c_float * 13)()
+        if lib().emul_ibl_far(C.byref(d), C.c_uint32(int(gx)), C.c_uint32(int(gy)), rec) != 0:
+            raise RuntimeError("emul_ibl_far failed")
+        out.append({"far": [float(v) for v in rec[0:8]], "rho": float(rec[8]), "stop_distance": float(rec[9]),
+                    "origin": tuple(float(v) for v in rec[10:13])})
+    del keep
+    return out
+
+
 def bvh_fingerprint(vertices, indices, threaded: bool):
     """(FNV-1a of the node + triangle arrays, node count) of the mesh BVH, built on one thread or with
     the worker threads of the large-mesh path (forced on for any size)."""

@@ -559,10 +559,48 @@ int emul_render(const f3d_terrain_ref_desc *d, uint32_t row_begin, uint32_t row_
         P.accum_mean = accum.data();
         P.welford_m2 = m2.data();
         P.gbuffer_n = gbuf.data();
+        std::vector<uint2> starts(getenv("F3D_EMUL_NO_PRIMARY_START") ? 0 : px);  // f3d_cone.h certificates
+        P.primary_start = starts.empty() ? nullptr : starts.data();
+        std::vector<float2> sun_clear(getenv("F3D_EMUL_NO_SUN_CLEAR") ? 0 : px);
+        P.sun_clear = sun_clear.empty() ? nullptr : sun_clear.data();
+        std::vector<float> ibl_far((getenv("F3D_EMUL_NO_IBL_STOP") || sun_clear.empty()) ? 0 : px * kIblSectors);
+        P.ibl_far = ibl_far.empty() ? nullptr : ibl_far.data();
 #pragma omp parallel for schedule(dynamic, 4)
         for (long y = row_begin; y < (long)row_end; y++) {
             ArrayPending pend;
             for (uint32_t x = 0; x < W; x++) gbuffer_pixel(P, x, (uint32_t)y, gbuf.data(), dep.data(), pend);
+        }
+        if (getenv("F3D_EMUL_START_STATS") && P.primary_start) {  // how far do the certificates of f3d_cone.h reach?
+            size_t none = 0, sky = 0, some = 0;
+            double frac = 0.0, lvl = 0.0;
+            for (size_t i = 0; i < px; i++) {
+                const float t = f_from_bits(starts[i].x);
+                if (t == 0.0f) none++;
+                else if (t > 1e37f) sky++;
+                else {
+                    some++;
+                    lvl += starts[i].y;
+                    if (gbuf[i].w != 0.0f) frac += t / dep[i];
+                }
+            }
+            fprintf(stderr, "certificates: none %zu, whole ray %zu, partial %zu (mean t_clear / depth %.3f, mean level %.2f)\n", none, sky, some,
+                    some ? frac / (double)some : 0.0, some ? lvl / (double)some : 0.0);
+            if (P.sun_clear) {
+                size_t hits = 0, with = 0, sectors = 0;
+                double mean_from = 0.0;
+                for (size_t i = 0; i < px; i++) {
+                    if (gbuf[i].w == 0.0f) continue;
+                    hits++;
+                    if (sun_clear[i].x < 1e30f) {
+                        with++;
+                        mean_from += sun_clear[i].x;
+                    }
+                    if (P.ibl_far)
+                        for (uint32_t k = 0; k < kIblSectors; k++) sectors += ibl_far[i * kIblSectors + k] < 1e30f;
+                }
+                fprintf(stderr, "sun certificates: %zu of %zu hit pixels (mean clear_from %.1f); IBL sectors with a horizon: %.2f of 8\n", with, hits,
+                        with ? mean_from / (double)with : 0.0, hits ? (double)sectors / (double)hits : 0.0);
+            }
         }
         uint32_t frames = 0;
         float variance = INFINITY;
@@ -713,6 +751,9 @@ struct EmulSession {
     std::vector<uint32_t> mesh_idx;
     MeshBvh bvh;
     std::vector<float4> accum, gbuf;
+    std::vector<uint2> starts;
+    std::vector<float2> sun_clear;
+    std::vector<float> ibl_far;
     std::vector<float> m2, depth;
     PackedReservoir *res[2] = {nullptr, nullptr};
     uint32_t rows = 0, width = 0;
@@ -764,6 +805,12 @@ void *emul_session_create(const f3d_terrain_ref_desc *d, uint32_t row_begin, uin
         s->P.accum_mean = s->accum.data();
         s->P.welford_m2 = s->m2.data();
         s->P.gbuffer_n = s->gbuf.data();
+        s->starts.assign(px, uint2{0u, 0u});
+        s->P.primary_start = s->starts.data();
+        s->sun_clear.assign(px, float2{3.0e38f, 0.0f});
+        s->P.sun_clear = s->sun_clear.data();
+        s->ibl_far.assign(px * kIblSectors, 3.0e38f);
+        s->P.ibl_far = s->ibl_far.data();
         for (uint32_t y = row_begin; y < row_end; y++) {
             ArrayPending pend;
             for (uint32_t x = 0; x < s->width; x++) gbuffer_pixel(s->P, x, y, s->gbuf.data(), s->depth.data(), pend);
@@ -828,6 +875,84 @@ int emul_session_resolve(void *h, uint32_t frames, uint8_t *rgba, float *albedo,
 }
 
 void emul_session_destroy(void *h) { delete (EmulSession *)h; }
+
+// debugging aid: the IBL certificate of one pixel: out[0..7] far-horizon slopes, [8] rho, [9] stop distance, [10..12] origin
+int emul_ibl_far(const f3d_terrain_ref_desc *d, uint32_t gx, uint32_t gy, float *out) {
+    try {
+        FrameParams P{};
+        (void)fill_uniforms(*d, P);
+        HostTables t = build_tables_host(d->heights, d->dem_width, d->dem_height, d->exaggeration);
+        t.attach(P.terrain);
+        P.row_begin = 0;
+        P.row_end = d->height;
+        ArrayPending pend;
+        const V3 rd = camera_dir(P.cam, gx, gy, 0.0f, 0.0f);
+        const SurfaceHit hit = closest_hit(P, P.cam.origin, 1e-3f, rd, 1e30f, pend);
+        for (int i = 0; i < 13; i++) out[i] = 3.0e38f;
+        if (hit.kind != 0u) {
+            const V3 o = along(hit.p, 1e-3f, hit.n);
+            ibl_far_horizon(P, o, hit.t, out);
+            const float cell_min = f_min(P.terrain.spacing_x, P.terrain.spacing_z), cell_max = f_max(P.terrain.spacing_x, P.terrain.spacing_z);
+            out[8] = ibl_rho(hit.t, pixel_cone_delta(P.cam), cell_min);
+            out[9] = ibl_stop_distance(out[8], cell_max);
+            out[10] = o.x;
+            out[11] = o.y;
+            out[12] = o.z;
+        }
+        return 0;
+    } catch (const Failure &) {
+        return 1;
+    }
+}
+
+// debugging aid: the sun-ray certificate of one pixel: {clear_from, centre depth, centre origin xyz}
+int emul_sun_clear(const f3d_terrain_ref_desc *d, uint32_t gx, uint32_t gy, float *out) {
+    try {
+        FrameParams P{};
+        (void)fill_uniforms(*d, P);
+        HostTables t = build_tables_host(d->heights, d->dem_width, d->dem_height, d->exaggeration);
+        t.attach(P.terrain);
+        P.row_begin = 0;
+        P.row_end = d->height;
+        ArrayPending pend;
+        const V3 rd = camera_dir(P.cam, gx, gy, 0.0f, 0.0f);
+        const SurfaceHit hit = closest_hit(P, P.cam.origin, 1e-3f, rd, 1e30f, pend);
+        out[0] = 3.0e38f;
+        out[1] = 0.0f;
+        if (hit.kind != 0u) {
+            const V3 o = along(hit.p, 1e-3f, hit.n);
+            out[0] = sun_clear_from(P, o, hit.t);
+            out[1] = hit.t;
+            out[2] = o.x;
+            out[3] = o.y;
+            out[4] = o.z;
+            out[5] = P.light.wi.x;
+            out[6] = P.light.wi.y;
+            out[7] = P.light.wi.z;
+        }
+        return 0;
+    } catch (const Failure &) {
+        return 1;
+    }
+}
+
+// debugging aid: the certificate of one pixel (build with -DF3D_CONE_DEBUG for the walk)
+int emul_primary_start(const f3d_terrain_ref_desc *d, uint32_t gx, uint32_t gy, float *t_clear, uint32_t *level) {
+    try {
+        FrameParams P{};
+        (void)fill_uniforms(*d, P);
+        HostTables t = build_tables_host(d->heights, d->dem_width, d->dem_height, d->exaggeration);
+        t.attach(P.terrain);
+        P.row_begin = 0;
+        P.row_end = d->height;
+        const PrimaryStart ps = primary_start(P, gx, gy);
+        *t_clear = ps.t_clear;
+        *level = ps.level;
+        return 0;
+    } catch (const Failure &) {
+        return 1;
+    }
+}
 
 void emul_set_use_bvh(int32_t on) { g_use_bvh = on != 0; }
 // FNV-1a over the node and triangle arrays of the mesh BVH built with / without worker threads

@@ -18,7 +18,7 @@ python -c "import sys; sys.path.insert(0, 'tests'); from emul import emul; emul.
 rc=0
 LD_PRELOAD="$PRE" ASAN_OPTIONS=detect_leaks=0 \
     python -m pytest tests/test_emul_parity.py tests/test_halo_reach.py tests/test_adversarial_march.py tests/test_wavefront.py \
-    tests/test_distributed_gloo.py -q -m "not gpu" -p no:cacheprovider "$@" || rc=$?
+    tests/test_distributed_gloo.py tests/test_primary_start.py -q -m "not gpu" -p no:cacheprovider "$@" || rc=$?
 unset F3D_EMUL_CXXFLAGS
 python -c "import sys; sys.path.insert(0, 'tests'); from emul import emul; emul.build(force=True)"
 exit $rc
