@@ -151,6 +151,13 @@ F3D_HD float cos_quarter(float x) {  // |x| <= pi/4
 }
 // sin, cos of 2*pi*u for u in [0, 1]
 F3D_HD void sincos_turn(float u, float &s_out, float &c_out) {
+#if defined(F3D_FAST_NUMERICS) && defined(__HIP_DEVICE_COMPILE__)
+    // Tolerance tier (opt-in build, never the parity anchor -- DESIGN.md 5): v_sin_f32 / v_cos_f32 take their
+    // argument in revolutions; the library is then also compiled with contraction on and 2.5-ulp divide / sqrt.
+    s_out = __builtin_amdgcn_sinf(u);
+    c_out = __builtin_amdgcn_cosf(u);
+    return;
+#endif
     float a = 4.0f * u;
     float k = f_rint(a);
     float x = (a - k) * kHalfPi;
