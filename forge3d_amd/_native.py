@@ -18,6 +18,7 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libf3dhip.so"
 
 STATUS_OK, STATUS_VALUE, STATUS_RENDER, STATUS_UPLOAD, STATUS_DEVICE = 0, 1, 2, 3, 4
+ABI_VERSION = 3  # F3D_ABI_VERSION of include/f3d_terrain_pt.h this mirror was written against
 
 _EARTH = {"flat": 0, "sphere": 1, "ellipsoid": 2, "wgs84": 2}
 _REFRACTION = {"none": 0, "bennett": 1, "saemundsson": 2, "effective_radius": 3}
@@ -26,6 +27,7 @@ _REFRACTION = {"none": 0, "bennett": 1, "saemundsson": 2, "effective_radius": 3}
 class Desc(C.Structure):
     """f3d_terrain_ref_desc"""
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("heights", C.c_void_p), ("dem_width", C.c_uint32), ("dem_height", C.c_uint32),
         ("spacing_x", C.c_float), ("spacing_z", C.c_float), ("exaggeration", C.c_float),
         ("albedo", C.c_float * 3),
@@ -76,6 +78,7 @@ class Out(C.Structure):
 class SessionOpts(C.Structure):
     """f3d_session_opts"""
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("device", C.c_int32), ("stream", C.c_void_p),
         ("row_begin", C.c_uint32), ("row_end", C.c_uint32),
         ("memory_budget_bytes", C.c_uint64), ("kernel_variant", C.c_int32),
@@ -130,6 +133,7 @@ ABI = [
     ("f3d_device_count", C.c_int, []),
     ("f3d_device_name", C.c_char_p, [C.c_int32]),
     ("f3d_version", C.c_char_p, []),
+    ("f3d_abi_version", C.c_uint32, []),
     ("f3d_source_digest", C.c_char_p, []),
     ("f3d_debug_poison", None, [C.c_int32]),
 ]
@@ -247,6 +251,8 @@ def lib() -> C.CDLL:
             fn = getattr(L, name)  # AttributeError if the export is missing
             fn.restype = restype
             fn.argtypes = argtypes
+        if L.f3d_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"forge3d_amd: {path} speaks ABI version {L.f3d_abi_version()}, this binding {ABI_VERSION}")
         want = source_digest() if "F3D_HIP_LIBRARY" not in os.environ else None
         have = L.f3d_source_digest().decode()
         if want is not None and have != want:
@@ -341,6 +347,7 @@ def make_desc(heightmap, width, height, cam, spacing, exaggeration, albedo, sun_
         raise ValueError(f"unsupported refraction_model {refraction_model!r}")
     keep = [dem]
     d = Desc()
+    d.struct_size = C.sizeof(Desc)
     d.heights = dem.ctypes.data
     d.dem_height, d.dem_width = dem.shape
     d.spacing_x, d.spacing_z = float(spacing[0]), float(spacing[1])

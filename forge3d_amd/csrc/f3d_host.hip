@@ -406,7 +406,24 @@ void upload_aether(f3d_session &s, const f3d_aether_luts &L, const f3d_terrain_r
     A.enabled = 1u;
 }
 
+// A caller compiled against another revision of the header passes structs of another size: refuse them before a
+// single member is read (include/f3d_terrain_pt.h F3D_ABI_VERSION).
+void check_abi(const f3d_terrain_ref_desc *d, const f3d_session_opts *opts) {
+    char msg[256];
+    if (d && d->struct_size != sizeof(f3d_terrain_ref_desc)) {
+        snprintf(msg, sizeof msg, "f3d_terrain_ref_desc.struct_size is %u, this library (ABI version %u) expects %zu: the caller "
+                 "was built against another revision of f3d_terrain_pt.h", d->struct_size, F3D_ABI_VERSION, sizeof(f3d_terrain_ref_desc));
+        fail(F3D_STATUS_VALUE, msg);
+    }
+    if (opts && opts->struct_size != sizeof(f3d_session_opts)) {
+        snprintf(msg, sizeof msg, "f3d_session_opts.struct_size is %u, this library (ABI version %u) expects %zu: the caller "
+                 "was built against another revision of f3d_terrain_pt.h", opts->struct_size, F3D_ABI_VERSION, sizeof(f3d_session_opts));
+        fail(F3D_STATUS_VALUE, msg);
+    }
+}
+
 void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_session_opts *opts) {
+    check_abi(&d, opts);
     validate_desc(d);
     validate_scene(d);
 
@@ -1151,6 +1168,7 @@ int f3d_terrain_ref_render(const f3d_terrain_ref_desc *desc, f3d_terrain_ref_out
     try {
         const double t_setup = now_s();
         f3d_session_opts one_shot{};
+        one_shot.struct_size = (uint32_t)sizeof(one_shot);
         one_shot.device = -1;
         one_shot.frames_in_flight = F3D_FRAMES_IN_FLIGHT_AUTO;  // small images: batches of frames per launch
         session_init(*s, *desc, &one_shot);
@@ -1387,7 +1405,8 @@ const char *f3d_device_name(int32_t device) {
     return name;
 }
 
-const char *f3d_version(void) { return "forge3d_amd 0.1.0 (gfx950 terrain path tracer)"; }
+const char *f3d_version(void) { return "forge3d_amd 0.3.0 (gfx950 terrain path tracer)"; }
+uint32_t f3d_abi_version(void) { return F3D_ABI_VERSION; }
 
 #ifndef F3D_SOURCE_DIGEST
 #define F3D_SOURCE_DIGEST "unknown"

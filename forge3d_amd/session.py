@@ -36,6 +36,7 @@ class TerrainSession:
                                        observer_longitude_deg, earth_model, sphere_radius_m, refraction_model,
                                        refraction_k, pressure_mbar, temperature_c, atmosphere)
         opts = _native.SessionOpts()
+        opts.struct_size = C.sizeof(_native.SessionOpts)
         opts.device = int(device)
         opts.stream = C.c_void_p(int(stream) or None)
         opts.row_begin, opts.row_end = int(row_begin), int(row_end)

@@ -24,6 +24,14 @@
 extern "C" {
 #endif
 
+/* ABI version: bumped whenever a struct of this header changes size or layout.  Every struct that has grown
+ * (or may grow) carries its own size as its FIRST member; the caller sets it to sizeof(the struct it was compiled
+ * against) and the library refuses a size it does not know (status 1) instead of reading past the caller's struct.
+ *   1  round 1: f3d_terrain_ref_desc without `atmosphere`, no struct_size members
+ *   2  round 2: + f3d_terrain_ref_desc.atmosphere (binary-incompatible, unversioned -- the reason for this scheme)
+ *   3  round 3: + struct_size first in f3d_terrain_ref_desc / f3d_session_opts, f3d_abi_version(),
+ *               f3d_session_enqueue_batch_strip / f3d_session_connect_halo */
+#define F3D_ABI_VERSION 3u
 #define F3D_STATUS_OK 0
 #define F3D_STATUS_VALUE 1
 #define F3D_STATUS_RENDER 2
@@ -60,6 +68,7 @@ typedef struct f3d_aether_luts {
  * terrain_reference.rs:295-312).  All pointers are HOST pointers that are only read
  * during the call. */
 typedef struct f3d_terrain_ref_desc {
+    uint32_t struct_size; /* = sizeof(f3d_terrain_ref_desc) of the caller's header (see F3D_ABI_VERSION) */
     const float *heights; /* (dem_height, dem_width) row-major f32 */
     uint32_t dem_width, dem_height;
     float spacing_x, spacing_z;
@@ -123,6 +132,7 @@ typedef struct f3d_session f3d_session;
 
 #define F3D_FRAMES_IN_FLIGHT_AUTO 0xFFFFFFFFu
 typedef struct f3d_session_opts {
+    uint32_t struct_size; /* = sizeof(f3d_session_opts) of the caller's header */
     int32_t device;      /* HIP device ordinal, -1 = current */
     void *stream;        /* hipStream_t to enqueue on, NULL = the null stream */
     uint32_t row_begin;  /* first owned image row */
@@ -320,6 +330,8 @@ uint32_t f3d_scene_cache_entries(void);
 int f3d_device_count(void);
 const char *f3d_device_name(int32_t device); /* gcnArchName, "" when unavailable */
 const char *f3d_version(void);
+/* F3D_ABI_VERSION the library was built with: a binding checks it once after loading. */
+uint32_t f3d_abi_version(void);
 /* First 16 hex digits of the SHA-256 of the sources + compiler flags the library was built from ("unknown" for a
  * build that did not go through __graft_entry__.build_hip). */
 const char *f3d_source_digest(void);

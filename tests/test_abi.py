@@ -71,6 +71,86 @@ int main(void) {
                                                  native.Out.gpu_resource_bytes.offset]
 
 
+def _rust_structs_of_integration_md():
+    """{Rust struct name: [(field, rust type)]} of every #[repr(C)] struct in INTEGRATION.md."""
+    import re
+
+    text = (ROOT / "INTEGRATION.md").read_text()
+    out = {}
+    for m in re.finditer(r"#\[repr\(C\)\]\s*pub struct (\w+) \{(.*?)\n\}", text, re.S):
+        body = re.sub(r"//[^\n]*", "", m.group(2))
+        out[m.group(1)] = [(f, t.strip()) for f, t in re.findall(r"pub (\w+):\s*([^,]+?),", body + ",")]
+    return out
+
+
+_RUST_TO_C = {"u32": "uint32_t", "i32": "int32_t", "f32": "float", "f64": "double", "u64": "uint64_t", "u16": "uint16_t", "u8": "uint8_t"}
+
+
+def _c_decl(field, rust):
+    import re
+
+    m = re.fullmatch(r"\[(\w+);\s*(\d+)\]", rust)
+    if m:
+        return f"{_RUST_TO_C[m.group(1)]} {field}[{m.group(2)}];"
+    m = re.fullmatch(r"\*(const|mut) (\w+)", rust)
+    if m:
+        return f"const void *{field};"  # every data pointer has one size and alignment
+    return f"{_RUST_TO_C[rust]} {field};"
+
+
+def test_integration_md_rust_structs_match_the_header():
+    """The binding INTEGRATION.md shows must be the binding that works (round-2 verdict: the Rust struct lacked
+    `atmosphere`): its #[repr(C)] field lists, transcribed to C, have the header's size and the header's offset for
+    EVERY field."""
+    rust = _rust_structs_of_integration_md()
+    pairs = {"F3dTerrainRefDesc": "f3d_terrain_ref_desc", "F3dTerrainRefOut": "f3d_terrain_ref_out", "F3dAetherLuts": "f3d_aether_luts"}
+    assert set(pairs) <= set(rust), sorted(rust)
+    assert rust["F3dTerrainRefDesc"][0][0] == "struct_size" and rust["F3dTerrainRefDesc"][-1][0] == "atmosphere"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "f3d_terrain_pt.h"']
+    for rname in pairs:
+        lines.append(f"typedef struct {{ {' '.join(_c_decl(f, t) for f, t in rust[rname])} }} md_{rname};")
+    lines.append("int main(void) { int bad = 0;")
+    for rname, cname in pairs.items():
+        lines.append(f'  if (sizeof(md_{rname}) != sizeof({cname})) {{ printf("size of {rname}: %zu vs %zu\\n", sizeof(md_{rname}), sizeof({cname})); bad++; }}')
+        for f, _ in rust[rname]:
+            lines.append(f'  if (offsetof(md_{rname}, {f}) != offsetof({cname}, {f})) {{ printf("{rname}.{f}: %zu vs %zu\\n", '
+                         f'offsetof(md_{rname}, {f}), offsetof({cname}, {f})); bad++; }}')
+    lines.append("  return bad; }")
+    with tempfile.TemporaryDirectory() as tmp:
+        c = Path(tmp) / "md_layout.c"
+        c.write_text("\n".join(lines))
+        exe = Path(tmp) / "md_layout"
+        subprocess.run(["gcc", "-I", str(ROOT / "include"), str(c), "-o", str(exe)], check=True)
+        run = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert run.returncode == 0, run.stdout
+    text = (ROOT / "INTEGRATION.md").read_text()
+    assert "f3d_abi_version" in text and "F3D_ABI_VERSION: u32 = 3" in text
+
+
+def test_abi_version_and_struct_size_are_enforced(native):
+    """A caller built against another revision of the header (round 1 -> 2 grew the descriptor by a pointer) is refused
+    with a value error before the library reads a member."""
+    L = native.lib()
+    assert L.f3d_abi_version() == native.ABI_VERSION == 3
+    header = (ROOT / "include" / "f3d_terrain_pt.h").read_text()
+    assert "#define F3D_ABI_VERSION 3u" in header
+    dem = np.zeros((4, 4), np.float32)
+    desc, keep = native.make_desc(dem, 8, 8, {}, (1.0, 1.0), 1.0, (0.6, 0.6, 0.6), 315.0, 45.0, 2.5, None, 0.35, None, None, 1, 2, 2,
+                                  1e30, 7, (1.0, 1.0, 1.0), 0.0, 0.0, "ellipsoid", 6371008.8, "bennett", 0.13, 1013.25, 15.0)
+    assert desc.struct_size == C.sizeof(native.Desc)
+    out = native.Out()
+    err = C.create_string_buffer(512)
+    for wrong in (0, C.sizeof(native.Desc) - 8, C.sizeof(native.Desc) + 8):  # unset / the round-1 struct / a future one
+        desc.struct_size = wrong
+        assert L.f3d_terrain_ref_render(C.byref(desc), C.byref(out), err, 512) == native.STATUS_VALUE
+        assert b"struct_size" in err.value and b"another revision" in err.value
+    desc.struct_size = C.sizeof(native.Desc)
+    opts = native.SessionOpts()  # struct_size left 0
+    handle = C.c_void_p(None)
+    assert L.f3d_session_create(C.byref(desc), C.byref(opts), C.byref(handle), err, 512) == native.STATUS_VALUE
+    assert b"f3d_session_opts.struct_size" in err.value and not handle.value
+
+
 def test_version_and_device_probe(native):
     L = native.lib()
     assert b"gfx950" in L.f3d_version()
