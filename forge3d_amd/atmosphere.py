@@ -10,7 +10,12 @@ Where the tables come from.  The reference compiles its bank (5 x 598 032 bytes,
 into the extension module.  This package does not ship that data: ``load_shipped`` reads the bank from a directory
 -- ``bank_dir=``, ``$FORGE3D_AETHER_LUT_DIR``, or ``$FORGE3D_REPO_ROOT/src/core/atmosphere/precomputed`` (a forge3d
 checkout) -- verifies every anchor it touches against the reference's locked SHA-256 (precomputed.rs:36-43) and
-applies the reference's bracket interpolation.  Nothing is substituted: a missing bank is an error.
+applies the reference's bracket interpolation.  When NO bank directory is known the anchors are baked on the GPU by
+this package's own baker (``atmosphere_bake_luts``, csrc/f3d_aether_bake.hip) -- which reproduces the shipped anchors
+to the last f16 bit in 99.99 % of the values and within 1 f16 ulp in the rest (tests/test_aether_bake.py) -- and that
+provenance is VISIBLE: the handle says ``precomputed=False`` / ``provenance="baked"`` and a ``RuntimeWarning`` is
+emitted once per process.  ``load_shipped(..., require_bank=True)`` (or ``$FORGE3D_AETHER_REQUIRE_BANK=1``) turns the
+missing bank into the error the reference's "no nearby or default LUT was substituted" rule asks for.
 """
 from __future__ import annotations
 
@@ -145,11 +150,14 @@ class AtmosphereLutHandle:
     order_deltas: np.ndarray
     precomputed: bool = True
     precomputed_turbidity_bracket: "tuple | None" = None
+    provenance: str = "shipped"  # "shipped": the reference's SHA-locked anchors; "baked": this package's GPU baker
 
     @classmethod
-    def load_shipped(cls, config: "AtmosphereConfig | None" = None, bank_dir=None) -> "AtmosphereLutHandle":
+    def load_shipped(cls, config: "AtmosphereConfig | None" = None, bank_dir=None, require_bank: "bool | None" = None) -> "AtmosphereLutHandle":
         """load_precomputed_atmosphere_luts, bake.rs:690-769: only the turbidity may differ from the shipped
-        physical inputs; between anchors every f16 texel is interpolated in f32 and rounded back to f16."""
+        physical inputs; between anchors every f16 texel is interpolated in f32 and rounded back to f16.
+        Without a bank directory the anchors are baked on the GPU and the handle says so (module docstring);
+        require_bank=True raises FileNotFoundError instead."""
         config = config or AtmosphereConfig()
         problem = config.problem()
         if problem:
@@ -173,10 +181,15 @@ class AtmosphereLutHandle:
             if t <= b:
                 lower, upper, factor = i, i + 1, (t - a) / (b - a)
                 break
+        if require_bank is None:
+            require_bank = os.environ.get("FORGE3D_AETHER_REQUIRE_BANK", "") not in ("", "0")
         try:
             bank = find_bank(bank_dir)
         except FileNotFoundError:
-            bank = None  # the anchors are baked on the GPU instead (_anchor)
+            if require_bank:
+                raise
+            bank = None  # the anchors are baked on the GPU instead (_anchor); the handle and a warning say so
+            _warn_baked_once()
         if lower == upper or factor <= 0.0:
             pick = lower
         elif factor >= 1.0:
@@ -192,8 +205,8 @@ class AtmosphereLutHandle:
                 fa, fb = a.view(np.float16).astype(np.float32), b.view(np.float16).astype(np.float32)
                 tables.append((fa + (fb - fa) * factor).astype(np.float16).view(np.uint16))
             deltas = (da + (db - da) * factor).astype(np.float32)
-        return cls(config, tables[0], tables[1], tables[2], tables[3], deltas, True,
-                   (TURBIDITY_BANK[lower], TURBIDITY_BANK[upper]))
+        return cls(config, tables[0], tables[1], tables[2], tables[3], deltas, bank is not None,
+                   (TURBIDITY_BANK[lower], TURBIDITY_BANK[upper]), "shipped" if bank is not None else "baked")
 
     def deterministic_sha256_hex(self) -> str:
         """A stable key of payload + configuration (the reference hashes its own serialisation; this key is this
@@ -211,6 +224,19 @@ class AtmosphereLutHandle:
 
 
 _BAKED_ANCHORS: dict = {}
+_WARNED_BAKED = False
+
+
+def _warn_baked_once() -> None:
+    global _WARNED_BAKED
+    if not _WARNED_BAKED:
+        _WARNED_BAKED = True
+        import warnings
+
+        warnings.warn("forge3d_amd.atmosphere: no AETHER LUT bank directory found (bank_dir, $FORGE3D_AETHER_LUT_DIR, "
+                      "$FORGE3D_REPO_ROOT): the turbidity anchors are baked on the GPU by this package's baker instead of read "
+                      "from the reference's SHA-locked files (<= 1 f16 ulp apart; handle.provenance == 'baked'). "
+                      "Set FORGE3D_AETHER_REQUIRE_BANK=1 to make this an error.", RuntimeWarning, stacklevel=3)
 
 
 def _anchor(bank, turbidity: float, dims: LutDimensions):

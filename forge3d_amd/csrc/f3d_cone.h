@@ -12,6 +12,10 @@
 // costs steps, never a result.
 #pragma once
 
+#ifndef F3D_HORIZON_THETA
+#define F3D_HORIZON_THETA 8.0f  // a node is taken whole when it is this many times smaller than its distance (A/B: 4, 6)
+#endif
+
 // (included by f3d_shade.h after camera_dir, which it uses)
 
 namespace f3d {
@@ -234,39 +238,53 @@ F3D_HD float sun_clear_from(const FrameParams &P, V3 origin, float centre_depth)
     return clear_from;
 }
 
-// ---- where the IBL rays of a pixel can stop -------------------------------------------------------------------------
-// An IBL ray has a random direction, but its origin is a sample's hit point, within `rho` of the centre sample's.  For
-// each of 8 azimuth sectors ibl_far_horizon() finds the steepest slope under which anything of the terrain FARTHER than
-// `near` (horizontally) is seen from the lowest of those origins: a ray of that sector that climbs more steeply is above
-// every cell beyond `near`, so its march may stop once it has left the near cells behind (f3d_march.h t_stop).  Nodes
-// are taken whole as soon as they are small against their distance; the bound of a node (its maximum over its nearest
-// point) bounds all its cells, so coarse nodes only make the horizon more cautious.
+// ---- where the IBL rays can stop: a far-horizon table of the DEM ---------------------------------------------------
+// An IBL ray has a random direction and starts on the terrain.  For every BLOCK of 2^B x 2^B cells and each of 8 azimuth
+// sectors the table holds the steepest slope under which anything of the terrain FARTHER than `near` (horizontally, from
+// the block's centre) is seen from ANY point of the block's surface: a ray that starts on the block and climbs more
+// steeply is above every cell beyond `near`, so its march may stop once it has left the near cells behind
+// (f3d_march.h t_stop, the SLICED rule).  Nodes of the pyramid are taken whole as soon as they are small against their
+// distance; the bound of a node (its maximum over its nearest point) bounds all its cells, so coarse nodes only make the
+// horizon more cautious.  A certificate only has to be conservative, never bit-exact with anything.
+// Round 2 computed such horizons per PIXEL in the G-buffer pass: 26 ms per render at 1080p (a quadtree walk per pixel) for
+// 0.13 ms saved per frame.  The table depends on the DEM and its spacing only -- not on camera, sun or image -- so it is
+// built once per scene (k_horizon_build, ~one walk per block), lives in the scene cache next to the band tables, and at
+// the headline camera its blocks (rho = 28 m) are tighter than the pixel cones' footprints there (rho ~ 55 m).
 F3D_HD uint32_t ibl_sector(float dx, float dz) {
     return (dx < 0.0f ? 1u : 0u) | (dz < 0.0f ? 2u : 0u) | (f_abs(dz) > f_abs(dx) ? 4u : 0u);
-}
-F3D_HD float ibl_rho(float centre_depth, float delta, float cell) {
-    const float slack = sun_depth_slack(centre_depth, delta, cell);
-    return slack + (centre_depth + slack) * delta + 4e-3f;
 }
 // cells nearer than this are the march's; beyond it a cell (dilated by rho) is seen under less than ~35 degrees, so its
 // four corners tell which of the 45-degree sectors it is part of
 F3D_HD float ibl_near(float rho, float cell) { return 2.5f * (cell + 2.0f * rho); }
 F3D_HD float ibl_stop_distance(float rho, float cell) { return ibl_near(rho, cell) + 2.0f * cell + 2.0f * rho; }
 
-// out[8]: the far horizon's slope per sector (3e38: no certificate for that sector)
-F3D_HD void ibl_far_horizon(const FrameParams &P, V3 origin, float centre_depth, float *out) {
-    const TerrainDev &T = P.terrain;
+// Blocks: the nodes of pyramid level B, B the smallest level with at most 2^18 of them (one walk each at build time).
+constexpr uint32_t kHorizonMaxBlocks = 1u << 18;
+F3D_HD uint32_t horizon_block_level(uint32_t cell_w, uint32_t cell_h) {
+    uint32_t b = 0u;
+    while ((uint64_t)((cell_w + (1u << b) - 1u) >> b) * (uint64_t)((cell_h + (1u << b) - 1u) >> b) > kHorizonMaxBlocks) b++;
+    return b;
+}
+// horizontal radius around a block's centre that holds every IBL-ray origin on the block: half its diagonal, the 1e-3
+// lift off the surface, and slack for a hit point rounded across the block's border
+F3D_HD float horizon_block_rho(const TerrainDev &T, uint32_t level) {
+    const float w = T.spacing_x * (float)(1u << level), d = T.spacing_z * (float)(1u << level);
+    return 0.5f * f_sqrt(w * w + d * d) + 0.02f * f_max(T.spacing_x, T.spacing_z) + 4e-3f;
+}
+// how far below the block's lowest corner an IBL-ray origin may lie (solver rounding + the lift along a normal)
+F3D_HD float horizon_y_margin(const TerrainDev &T) {
     const uint32_t top = T.mip_count - 1u;
-    for (uint32_t s = 0u; s < kIblSectors; s++) out[s] = 3.0e38f;
-    const float delta = pixel_cone_delta(P.cam);
-    if (delta < 0.0f) return;
+    return 1e-4f * (f_abs(T.bands[T.band_offset[top]].mx) + f_abs(T.bands[T.band_offset[top]].mn)) + 4e-3f;
+}
+
+// out[8]: the far horizon's slope per sector, for origins within `rho` (horizontally) of (ox, oz) and not below y_lo.
+F3D_HD void far_horizon_from(const TerrainDev &T, float ox, float oz, float rho, float y_lo, float *out) {
+    const uint32_t top = T.mip_count - 1u;
     const float cell_min = f_min(T.spacing_x, T.spacing_z), cell_max = f_max(T.spacing_x, T.spacing_z);
-    const float rho = ibl_rho(centre_depth, delta, cell_min);
     const float near = ibl_near(rho, cell_max);
-    const float y_scale = f_abs(origin.y) + f_abs(T.bands[T.band_offset[top]].mx) + f_abs(T.bands[T.band_offset[top]].mn);
-    const float y_lo = origin.y - rho - (1e-4f * y_scale + 1e-3f);
     float best[kIblSectors];
     for (uint32_t s = 0u; s < kIblSectors; s++) best[s] = -3.0e38f;
+    for (uint32_t s = 0u; s < kIblSectors; s++) out[s] = 3.0e38f;
     uint32_t stack[64];
     uint32_t sp = 0u;
     stack[sp++] = top << 26;
@@ -279,8 +297,8 @@ F3D_HD void ibl_far_horizon(const FrameParams &P, V3 origin, float centre_depth,
         uint32_t cx1 = (nx + 1u) << l, cz1 = (nz + 1u) << l;
         cx1 = cx1 < T.cell_w ? cx1 : T.cell_w;
         cz1 = cz1 < T.cell_h ? cz1 : T.cell_h;
-        const float x0 = plane_at(T.origin_x, nx << l, T.spacing_x) - origin.x, x1 = plane_at(T.origin_x, cx1, T.spacing_x) - origin.x;
-        const float z0 = plane_at(T.origin_z, nz << l, T.spacing_z) - origin.z, z1 = plane_at(T.origin_z, cz1, T.spacing_z) - origin.z;
+        const float x0 = plane_at(T.origin_x, nx << l, T.spacing_x) - ox, x1 = plane_at(T.origin_x, cx1, T.spacing_x) - ox;
+        const float z0 = plane_at(T.origin_z, nz << l, T.spacing_z) - oz, z1 = plane_at(T.origin_z, cz1, T.spacing_z) - oz;
         // nearest and farthest point of the rectangle from the origin (in the plane)
         const float nxp = f_max(f_max(x0, -x1), 0.0f), nzp = f_max(f_max(z0, -z1), 0.0f);
         const float fxp = f_max(f_abs(x0), f_abs(x1)), fzp = f_max(f_abs(z0), f_abs(z1));
@@ -300,7 +318,7 @@ F3D_HD void ibl_far_horizon(const FrameParams &P, V3 origin, float centre_depth,
         for (uint32_t s = 0u; s < kIblSectors; s++)
             if (touched & (1u << s)) need = f_min(need, best[s]);
         if (!(bound > need)) continue;  // cannot raise any horizon it is part of
-        const bool take = small && (l == 0u || size * 8.0f <= dmin) && dmin >= near;
+        const bool take = small && (l == 0u || size * F3D_HORIZON_THETA <= dmin) && dmin >= near;
         if (take) {
             for (uint32_t s = 0u; s < kIblSectors; s++)
                 if (touched & (1u << s)) best[s] = f_max(best[s], bound);
@@ -320,17 +338,52 @@ F3D_HD void ibl_far_horizon(const FrameParams &P, V3 origin, float centre_depth,
     for (uint32_t s = 0u; s < kIblSectors; s++) out[s] = best[s];
 }
 
-// The parameter after which the IBL ray (origin within rho of the certificate's, unit direction d) meets no terrain,
-// or 3e38 when its slope does not clear the far horizon of its sector.
-F3D_HD float ibl_stop(const float *far, V3 d, float rho, float cell_max) {
+// Centre of block (bx, bz) of level B in the plane, and the height no origin on it lies below.
+F3D_HD void horizon_block_frame(const TerrainDev &T, uint32_t level, uint32_t bx, uint32_t bz, float &cx, float &cz, float &y_lo) {
+    cx = plane_at(T.origin_x, bx << level, T.spacing_x) + 0.5f * T.spacing_x * (float)(1u << level);
+    cz = plane_at(T.origin_z, bz << level, T.spacing_z) + 0.5f * T.spacing_z * (float)(1u << level);
+    y_lo = T.bands[T.band_offset[level] + (bz << T.band_shift[level]) + bx].mn - horizon_y_margin(T);
+}
+// One table record (k_horizon_build; the host emulator builds the same table with the same function).
+F3D_HD void horizon_block_build(const TerrainDev &T, uint32_t level, uint32_t bx, uint32_t bz, float *out) {
+    float cx, cz, y_lo;
+    horizon_block_frame(T, level, bx, bz, cx, cz, y_lo);
+    far_horizon_from(T, cx, cz, horizon_block_rho(T, level), y_lo - 1e-3f, out);
+}
+
+// The parameter after which the IBL ray (origin `o` on the terrain near surface point p, unit direction d) meets no
+// terrain, or 3e38: no table, the origin is not where its block says it is (verified, not assumed), or the ray's slope
+// does not clear the far horizon of its sector.
+F3D_HD float ibl_stop(const TerrainDev &T, V3 o, V3 d) {
+    if (!T.horizon) return 3.0e38f;
     const float hlen = f_sqrt(d.x * d.x + d.z * d.z);
     if (!(hlen > 1e-6f)) return 3.0e38f;
-    const float horizon = far[ibl_sector(d.x, d.z)];
-    if (!(horizon < 1e30f)) return 3.0e38f;
     const float slope = d.y / hlen;
     if (!(slope >= 0.0f)) return 3.0e38f;  // (a descending ray is lowest at the FAR edge of a cell: not what the horizon bounds)
+    const uint32_t level = T.horizon_level;
+    uint32_t cx = sat_u32(f_floor((o.x - T.origin_x) * T.inv_spacing_x)), cz = sat_u32(f_floor((o.z - T.origin_z) * T.inv_spacing_z));
+    cx = cx < T.cell_w - 1u ? cx : T.cell_w - 1u;
+    cz = cz < T.cell_h - 1u ? cz : T.cell_h - 1u;
+    const uint32_t bx = cx >> level, bz = cz >> level;
+    float mx, mz, y_lo;
+    horizon_block_frame(T, level, bx, bz, mx, mz, y_lo);
+    const float rho = horizon_block_rho(T, level);
+    const float ex = o.x - mx, ez = o.z - mz;
+    if (!(ex * ex + ez * ez <= rho * rho) || !(o.y >= y_lo)) return 3.0e38f;  // the certificate's preconditions
+#if defined(F3D_HORIZON_LAZY)  // host emulator: records are built when first read (NaN = not yet; racing threads write equal values)
+    {
+        float *rec = const_cast<float *>(T.horizon) + ((size_t)bz * T.horizon_bx + bx) * kIblSectors;
+        if (rec[0] != rec[0]) {
+            float tmp[kIblSectors];
+            horizon_block_build(T, level, bx, bz, tmp);
+            for (uint32_t k = kIblSectors; k-- > 0u;) rec[k] = tmp[k];  // rec[0] last: it is the "built" flag
+        }
+    }
+#endif
+    const float horizon = T.horizon[((size_t)bz * T.horizon_bx + bx) * kIblSectors + ibl_sector(d.x, d.z)];
+    if (!(horizon < 1e30f)) return 3.0e38f;
     if (!(slope > horizon + 1e-4f * f_abs(horizon) + 1e-5f)) return 3.0e38f;
-    return ibl_stop_distance(rho, cell_max) / hlen;
+    return ibl_stop_distance(rho, f_max(T.spacing_x, T.spacing_z)) / hlen;
 }
 
 }  // namespace f3d

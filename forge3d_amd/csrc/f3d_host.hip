@@ -191,9 +191,17 @@ struct CachedTables {
     uint64_t key = 0, dem_bytes = 0;
     uint32_t w = 0, h = 0;
     float exaggeration = 0.0f;
-    Ledger mem;  // owns leaf + band tables
+    Ledger mem;  // owns leaf + band tables (+ the far-horizon tables)
     TerrainTables tables;
     uint64_t stamp = 0;
+    // far-horizon tables of the IBL rays (f3d_cone.h): they depend on the heights AND on the cell spacing, which is not
+    // part of the cache key (the band tables do not care), so one table per spacing this DEM has been rendered with
+    struct Horizon {
+        float spacing_x, spacing_z;
+        float *table;
+        uint32_t level, bx, bz;
+    };
+    std::vector<Horizon> horizons;
     ~CachedTables() {
         int prev = -1;
         (void)hipGetDevice(&prev);
@@ -456,6 +464,30 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
     P.terrain.leaves = s.tables.leaves;
     P.terrain.nodes = s.tables.nodes;
     P.terrain.bands = s.tables.bands;
+#if !defined(F3D_NO_IBL_STOP)  // A/B builds (tools/build_variant.sh)
+    {   // far-horizon table of this DEM at this spacing: from the scene cache, or built now (one quadtree walk per block)
+        std::lock_guard<std::mutex> lock(g_scene_mutex);
+        const CachedTables::Horizon *have = nullptr;
+        for (const auto &hz : s.scene->horizons)
+            if (hz.spacing_x == P.terrain.spacing_x && hz.spacing_z == P.terrain.spacing_z) have = &hz;
+        if (!have) {
+            CachedTables::Horizon hz{};
+            hz.spacing_x = P.terrain.spacing_x;
+            hz.spacing_z = P.terrain.spacing_z;
+            horizon_table_dims(P.terrain.cell_w, P.terrain.cell_h, &hz.level, &hz.bx, &hz.bz);
+            const size_t bytes = (size_t)hz.bx * hz.bz * kIblSectors * sizeof(float);
+            hz.table = (float *)s.scene->mem.alloc(bytes, "far-horizon table");
+            hip_check(launch_horizon_build(P.terrain, hz.table, s.stream), "far-horizon table build");
+            hip_check(hipStreamSynchronize(s.stream), "far-horizon table build");  // other sessions may use it from their streams
+            s.mem.device_bytes += bytes;
+            s.scene->horizons.push_back(hz);
+            have = &s.scene->horizons.back();
+        }
+        P.terrain.horizon = have->table;
+        P.terrain.horizon_level = have->level;
+        P.terrain.horizon_bx = have->bx;
+    }
+#endif
 
     // environment map as rgb+pad texels (the reference uploads RGBA32F, terrain_heightfield.rs:443-482)
     if (d.env_map) {
@@ -613,9 +645,13 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
     P.accum_mean = (float4 *)s.mem.alloc(px * sizeof(float4), "accumulation");
     P.welford_m2 = (float *)s.mem.alloc(px * sizeof(float), "welford");
     s.gbuffer_n = (float4 *)s.mem.alloc(px * sizeof(float4), "g-buffer");
+    // ray certificates (f3d_cone.h), computed by the G-buffer pass; the A/B switches leave the pointer null = off
+#if !defined(F3D_NO_PRIMARY_START)
     P.primary_start = (uint2 *)s.mem.alloc(px * sizeof(uint2), "primary-ray certificates");
+#endif
+#if !defined(F3D_NO_SUN_CLEAR)
     P.sun_clear = (float2 *)s.mem.alloc(px * sizeof(float2), "sun-ray certificates");
-    P.ibl_far = (float *)s.mem.alloc(px * kIblSectors * sizeof(float), "IBL-ray certificates");
+#endif
     s.depth = (float *)s.mem.alloc(px * sizeof(float), "depth AOV");
     s.d_rgba = (uint8_t *)s.mem.alloc(px * 4, "rgba8 output");
     s.d_albedo = (float *)s.mem.alloc(px * 3 * sizeof(float), "albedo AOV");

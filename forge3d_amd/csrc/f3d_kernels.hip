@@ -587,7 +587,38 @@ __global__ void k_level_build(const LevelBuildParams B) {
     if (x < B.dst_dim_x && y < B.dst_dim_y) level_build_at(B, x, y);
 }
 
+// ---- far-horizon table of the IBL rays (f3d_cone.h): one lane per DEM block, 8 x 8 neighbouring blocks to a wave ------
+struct HorizonBuildParams {
+    TerrainDev terrain;
+    uint32_t level, bx, bz;
+    float *table;  // [bz][bx][kIblSectors]
+};
+__global__ __launch_bounds__(kWave) void k_horizon_build(const HorizonBuildParams B) {
+    const uint32_t tiles_x = (B.bx + 7u) >> 3;
+    const uint32_t x = (blockIdx.x % tiles_x) * 8u + (threadIdx.x & 7u), z = (blockIdx.x / tiles_x) * 8u + (threadIdx.x >> 3);
+    if (x >= B.bx || z >= B.bz) return;
+    float out[kIblSectors];
+    horizon_block_build(B.terrain, B.level, x, z, out);
+    float4 *dst = reinterpret_cast<float4 *>(B.table + ((size_t)z * B.bx + x) * kIblSectors);
+    dst[0] = float4{out[0], out[1], out[2], out[3]};
+    dst[1] = float4{out[4], out[5], out[6], out[7]};
+}
+
 // ---- launchers ---------------------------------------------------------------------
+void horizon_table_dims(uint32_t cell_w, uint32_t cell_h, uint32_t *level, uint32_t *bx, uint32_t *bz) {
+    *level = horizon_block_level(cell_w, cell_h);
+    *bx = (cell_w + (1u << *level) - 1u) >> *level;
+    *bz = (cell_h + (1u << *level) - 1u) >> *level;
+}
+hipError_t launch_horizon_build(const TerrainDev &terrain, float *table, hipStream_t stream) {
+    HorizonBuildParams B{};
+    B.terrain = terrain;
+    B.terrain.horizon = nullptr;
+    horizon_table_dims(terrain.cell_w, terrain.cell_h, &B.level, &B.bx, &B.bz);
+    B.table = table;
+    hipLaunchKernelGGL(k_horizon_build, dim3(((B.bx + 7u) >> 3) * ((B.bz + 7u) >> 3)), dim3(kWave), 0, stream, B);
+    return hipGetLastError();
+}
 static inline uint32_t frame_grid(const FrameParams &p, uint32_t lanes = 1u) {
     const uint32_t log_s = lanes == 1u ? 0u : (lanes == 2u ? 1u : (lanes == 4u ? 2u : 3u));
 #if defined(F3D_TILE_LOGW_S4)

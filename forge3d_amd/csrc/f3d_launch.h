@@ -43,5 +43,9 @@ hipError_t launch_ray_batch(const RayBatchParams &p, hipStream_t stream);
 hipError_t launch_leaf_build(const PyramidBuildParams &p, hipStream_t stream);
 hipError_t launch_level_build(const LevelBuildParams &p, hipStream_t stream);
 hipError_t launch_band_build(const BandBuildParams &p, hipStream_t stream);
+// far-horizon table of the IBL rays (f3d_cone.h): block level and block counts for a cell grid; the build (terrain
+// must hold layout, bands, origin and spacing); table = bx * bz * 8 floats
+void horizon_table_dims(uint32_t cell_w, uint32_t cell_h, uint32_t *level, uint32_t *bx, uint32_t *bz);
+hipError_t launch_horizon_build(const TerrainDev &terrain, float *table, hipStream_t stream);
 
 }  // namespace f3d

@@ -71,6 +71,9 @@ struct TerrainDev {
     float origin_x, origin_z, spacing_x, spacing_z, inv_spacing_x, inv_spacing_z;
     float inv_two_r_prime;  // EarthCurvatureUniforms, terrain_heightfield.rs:42-84
     uint32_t curvature_enabled;
+    // far-horizon table of the IBL rays (f3d_cone.h): per block of 2^horizon_level cells 8 sector slopes; null = off
+    const float *horizon;
+    uint32_t horizon_level, horizon_bx;
     uint32_t leaf_quorum;   // lanes of a wave that must hold a fat leaf before the leaf body runs
     uint32_t share_below;   // ray sharing (f3d_march.h): deal when at most this many lanes still march; 0 = default
 };
@@ -153,7 +156,6 @@ struct FrameParams {
     uint32_t tile_map;              // workgroup -> tile mapping (f3d_kernels.hip tile_pixel)
     uint32_t sample_lanes;          // lanes per pixel in the frame kernel: 1 (frame_pixel), 2, 4, 8 (frame_lanes)
     uint2 *head;                    // sample-lane form only: per-pixel record of k_head {reuse_w bits, flags}
-    float *ibl_far;                 // per pixel 8 floats: far-horizon slope per azimuth sector (f3d_cone.h ibl_far_horizon); needs sun_clear
     float2 *sun_clear;              // per pixel {parameter after which no sun ray of the pixel meets terrain, depth of the centre hit}; null = off
     uint2 *primary_start;           // per pixel {t_clear bits, level}: where its camera rays may start (f3d_cone.h); null = at the root
     // longest-first dispatch (f3d_kernels.hip k_tile_order): frame-kernel workgroup b renders tile tile_order[b]

@@ -526,10 +526,7 @@ F3D_HD IblRay sample_shade_sun(const FrameParams &P, const FrameHead &h, const P
     q.b0 = albedo * env_radiance(P.env, ei);
     q.key = dot(n, ei);
 #if !defined(F3D_NO_IBL_STOP)  // A/B builds
-    if (P.ibl_far && ph.cert != 0xFFFFFFFFu) {
-        const float cell_min = f_min(P.terrain.spacing_x, P.terrain.spacing_z), cell_max = f_max(P.terrain.spacing_x, P.terrain.spacing_z);
-        q.t_stop = ibl_stop(P.ibl_far + (size_t)ph.cert * kIblSectors, ei, ibl_rho(P.sun_clear[ph.cert].y, pixel_cone_delta(P.cam), cell_min), cell_max);
-    }
+    if (ph.hit.kind == 1u) q.t_stop = ibl_stop(P.terrain, so, ei);  // (a mesh hit may lie below the terrain: no certificate)
 #endif
     return q;
 }
@@ -700,12 +697,6 @@ F3D_HD void gbuffer_pixel(const FrameParams &P, uint32_t gx, uint32_t gy, float4
         float2 c = float2{3.0e38f, 0.0f};
         if (hit.kind != 0u) c = float2{sun_clear_from(P, along(hit.p, 1e-3f, hit.n), hit.t), hit.t};
         P.sun_clear[lp] = c;
-        if (P.ibl_far) {
-            float far[kIblSectors];
-            for (uint32_t s = 0u; s < kIblSectors; s++) far[s] = 3.0e38f;
-            if (hit.kind != 0u) ibl_far_horizon(P, along(hit.p, 1e-3f, hit.n), hit.t, far);
-            for (uint32_t s = 0u; s < kIblSectors; s++) P.ibl_far[lp * kIblSectors + s] = far[s];
-        }
     }
     if (hit.kind != 0u) {
         gbuffer_n[lp] = float4{hit.n.x, hit.n.y, hit.n.z, (float)hit.kind};

@@ -1295,6 +1295,24 @@ static v3 ae_post_pixel(const f3do_aether *A, const uniforms_t *un, uint32_t gx,
     return v3_make(e.x / (1.0f + e.x), e.y / (1.0f + e.y), e.z / (1.0f + e.z));
 }
 
+/* Test hooks: the two transport terms of the post for one view ray, without an image around them -- what
+ * tests/test_aether.py compares with the vectors of the reference's own independent spectral oracle
+ * (tests/golden/make_aether_independent_vectors.py).  f3do_aether_segment_transmittance = ae_segment_transmittance
+ * (evaluation_core.wgsl:238-344); f3do_aether_sky = the sky branch of prometheus_aerial.wgsl (:150-158) for unit sun
+ * intensity, before exposure / Reinhard. */
+void f3do_aether_segment_transmittance(float dist, float cam_h, float mu, float bottom_radius_m, float turbidity, float ozone_du,
+                                       float *rgb_out) {
+    v3 t = ae_segment_transmittance(dist, cam_h, mu, bottom_radius_m, 1.0f, turbidity, ozone_du);
+    rgb_out[0] = t.x; rgb_out[1] = t.y; rgb_out[2] = t.z;
+}
+void f3do_aether_sky(const f3do_aether *A, float cam_h, const float *ray, const float *sun, float *rgb_out) {
+    v3 r = normalize3(v3_make(ray[0], ray[1], ray[2])), s = normalize3(v3_make(sun[0], sun[1], sun[2]));
+    float atm_h = fmaxf(A->top_radius_m - A->bottom_radius_m, 1.0f);
+    float cam_unit = clampf(fmaxf(cam_h, 0.0f) / atm_h, 0.0f, 1.0f);
+    v3 c = ae_clamp_hdr(ae_scattering(A, cam_unit, s.y, r.y, dot3(r, s)));
+    rgb_out[0] = c.x; rgb_out[1] = c.y; rgb_out[2] = c.z;
+}
+
 int f3do_render(const f3do_desc *d, f3do_out *out, char *err, size_t errlen) {
     int rc = 0;
     mips_t mips;

@@ -124,6 +124,21 @@ def aether_struct(handle):
     return a, keep
 
 
+def aether_segment_transmittance(distance_m, altitude_m, mu, turbidity, ozone_du=300.0, bottom_radius_m=6_360_000.0):
+    """ae_segment_transmittance of the post (linear sRGB, white-normalised)."""
+    out = (C.c_float * 3)()
+    lib().f3do_aether_segment_transmittance(distance_m, altitude_m, mu, bottom_radius_m, turbidity, ozone_du, out)
+    return np.array(out[:], np.float32)
+
+
+def aether_sky(handle, altitude_m, view, sun):
+    """Sky radiance of the post for unit sun intensity (accumulated-scattering LUT tap), before exposure / Reinhard."""
+    a, keep = aether_struct(handle)
+    out = (C.c_float * 3)()
+    lib().f3do_aether_sky(C.byref(a), float(altitude_m), (C.c_float * 3)(*map(float, view)), (C.c_float * 3)(*map(float, sun)), out)
+    return np.array(out[:], np.float32)
+
+
 class Out(C.Structure):
     _fields_ = [
         ("rgba", C.c_void_p),
@@ -184,6 +199,10 @@ def lib():
                                               C.c_double, C.c_double, C.c_double, C.c_double,
                                               C.POINTER(C.c_double), C.c_char_p, C.c_size_t]
         L.f3do_effective_radius_m.restype = C.c_int
+        L.f3do_aether_segment_transmittance.argtypes = [C.c_float] * 6 + [C.POINTER(C.c_float)]
+        L.f3do_aether_segment_transmittance.restype = None
+        L.f3do_aether_sky.argtypes = [C.POINTER(Aether), C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.f3do_aether_sky.restype = None
         L.f3do_f16_round.argtypes = [C.c_float]
         L.f3do_f16_round.restype = C.c_float
         L.f3do_sincos_2pi.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]

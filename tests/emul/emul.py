@@ -26,7 +26,7 @@ def build(force=False):
     if force or not _LIB.exists() or _LIB.stat().st_mtime < max(s.stat().st_mtime for s in srcs):
         extra = os.environ.get("F3D_EMUL_CXXFLAGS", "").split()  # experiment switches (-DF3D_...)
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-march=x86-64-v3",
-                        "-ffp-contract=off", *extra, str(_HERE / "f3d_emul.cpp"), "-o", str(_LIB)],
+                        "-ffp-contract=off", "-DF3D_HORIZON_LAZY", *extra, str(_HERE / "f3d_emul.cpp"), "-o", str(_LIB)],
                        check=True, capture_output=True)
     return _LIB
 
@@ -177,8 +177,9 @@ def sun_clear(heightmap, width, height, camera, pixels, **kw):
     return out
 
 
-def ibl_far(heightmap, width, height, camera, pixels, **kw):
-    """Per (gx, gy): dict(far[8], rho, stop_distance, origin) of the IBL certificate (csrc/f3d_cone.h ibl_far_horizon)."""
+def horizon_blocks(heightmap, cells, **kw):
+    """Per DEM cell (cx, cz): the far-horizon record of the block that holds it (csrc/f3d_cone.h horizon_block_build):
+    dict(far[8], rho, stop_distance, level, centre (x, z), y_lo, size (x, z))."""
     defaults = dict(spacing=(1.0, 1.0), exaggeration=1.0, albedo=(0.6, 0.6, 0.6), sun_azimuth_deg=315.0,
                     sun_elevation_deg=45.0, sun_intensity=2.5, env_map=None, env_intensity=0.35,
                     mesh_vertices=None, mesh_indices=None, spp=1, max_frames=512, min_frames=32,
@@ -186,16 +187,14 @@ def ibl_far(heightmap, width, height, camera, pixels, **kw):
                     observer_longitude_deg=0.0, earth_model="ellipsoid", sphere_radius_m=6_371_008.8,
                     refraction_model="bennett", refraction_k=0.13, pressure_mbar=1013.25, temperature_c=15.0)
     defaults.update(kw)
-    d, keep = _native.make_desc(heightmap, width, height, dict(camera or {}), **defaults)
-    out = []
-    for gx, gy in pixels:
-        rec = (C.c_float * 13)()
-        if lib().emul_ibl_far(C.byref(d), C.c_uint32(int(gx)), C.c_uint32(int(gy)), rec) != 0:
-            raise RuntimeError("emul_ibl_far failed")
-        out.append({"far": [float(v) for v in rec[0:8]], "rho": float(rec[8]), "stop_distance": float(rec[9]),
-                    "origin": tuple(float(v) for v in rec[10:13])})
+    d, keep = _native.make_desc(heightmap, 8, 8, {}, **defaults)
+    cells = np.ascontiguousarray(cells, np.uint32).reshape(-1, 2)
+    rec = np.zeros((cells.shape[0], 16), np.float32)
+    if lib().emul_horizon_blocks(C.byref(d), C.c_uint32(cells.shape[0]), cells.ctypes.data_as(C.c_void_p), rec.ctypes.data_as(C.c_void_p)) != 0:
+        raise RuntimeError("emul_horizon_blocks failed")
     del keep
-    return out
+    return [{"far": [float(v) for v in r[0:8]], "rho": float(r[8]), "stop_distance": float(r[9]), "level": int(r[10]),
+             "centre": (float(r[11]), float(r[12])), "y_lo": float(r[13]), "size": (float(r[14]), float(r[15]))} for r in rec]
 
 
 def bvh_fingerprint(vertices, indices, threaded: bool):

@@ -231,11 +231,21 @@ struct HostTables {
     TableLayout L;
     std::vector<LeafRec> leaves;
     std::vector<NodeRec> nodes, bands;
+    std::vector<float> horizon;  // far-horizon table of the IBL rays (f3d_cone.h), records built on first use (F3D_HORIZON_LAZY)
     void attach(TerrainDev &T) const {
         apply_layout(L, T);
         T.leaves = leaves.data();
         T.nodes = nodes.data();
         T.bands = bands.data();
+    }
+    // after attach() and fill_uniforms(): the table depends on the spacing too
+    void attach_horizon(TerrainDev &T) {
+        if (getenv("F3D_EMUL_NO_IBL_STOP")) return;
+        T.horizon_level = horizon_block_level(T.cell_w, T.cell_h);
+        T.horizon_bx = (T.cell_w + (1u << T.horizon_level) - 1u) >> T.horizon_level;
+        const uint32_t bz = (T.cell_h + (1u << T.horizon_level) - 1u) >> T.horizon_level;
+        horizon.assign((size_t)T.horizon_bx * bz * kIblSectors, std::nanf(""));
+        T.horizon = horizon.data();
     }
 };
 
@@ -523,6 +533,7 @@ int emul_render(const f3d_terrain_ref_desc *d, uint32_t row_begin, uint32_t row_
         const bool require_valid = fill_uniforms(*d, P);
         HostTables t = build_tables_host(d->heights, d->dem_width, d->dem_height, d->exaggeration);
         t.attach(P.terrain);
+        t.attach_horizon(P.terrain);
         std::vector<float> env4, mesh4;
         MeshBvh bvh;
         if (d->env_map) {
@@ -563,8 +574,6 @@ int emul_render(const f3d_terrain_ref_desc *d, uint32_t row_begin, uint32_t row_
         P.primary_start = starts.empty() ? nullptr : starts.data();
         std::vector<float2> sun_clear(getenv("F3D_EMUL_NO_SUN_CLEAR") ? 0 : px);
         P.sun_clear = sun_clear.empty() ? nullptr : sun_clear.data();
-        std::vector<float> ibl_far((getenv("F3D_EMUL_NO_IBL_STOP") || sun_clear.empty()) ? 0 : px * kIblSectors);
-        P.ibl_far = ibl_far.empty() ? nullptr : ibl_far.data();
 #pragma omp parallel for schedule(dynamic, 4)
         for (long y = row_begin; y < (long)row_end; y++) {
             ArrayPending pend;
@@ -595,8 +604,6 @@ int emul_render(const f3d_terrain_ref_desc *d, uint32_t row_begin, uint32_t row_
                         with++;
                         mean_from += sun_clear[i].x;
                     }
-                    if (P.ibl_far)
-                        for (uint32_t k = 0; k < kIblSectors; k++) sectors += ibl_far[i * kIblSectors + k] < 1e30f;
                 }
                 fprintf(stderr, "sun certificates: %zu of %zu hit pixels (mean clear_from %.1f); IBL sectors with a horizon: %.2f of 8\n", with, hits,
                         with ? mean_from / (double)with : 0.0, hits ? (double)sectors / (double)hits : 0.0);
@@ -753,7 +760,6 @@ struct EmulSession {
     std::vector<float4> accum, gbuf;
     std::vector<uint2> starts;
     std::vector<float2> sun_clear;
-    std::vector<float> ibl_far;
     std::vector<float> m2, depth;
     PackedReservoir *res[2] = {nullptr, nullptr};
     uint32_t rows = 0, width = 0;
@@ -769,6 +775,7 @@ void *emul_session_create(const f3d_terrain_ref_desc *d, uint32_t row_begin, uin
         s->require_valid = fill_uniforms(*d, s->P);
         s->tables = build_tables_host(d->heights, d->dem_width, d->dem_height, d->exaggeration);
         s->tables.attach(s->P.terrain);
+        s->tables.attach_horizon(s->P.terrain);
         if (d->env_map) {
             s->env4 = pad_rgb_to_rgba(d->env_map, (size_t)d->env_width * d->env_height, 1.0f);
             s->P.env.texels = (const float4 *)s->env4.data();
@@ -809,8 +816,6 @@ void *emul_session_create(const f3d_terrain_ref_desc *d, uint32_t row_begin, uin
         s->P.primary_start = s->starts.data();
         s->sun_clear.assign(px, float2{3.0e38f, 0.0f});
         s->P.sun_clear = s->sun_clear.data();
-        s->ibl_far.assign(px * kIblSectors, 3.0e38f);
-        s->P.ibl_far = s->ibl_far.data();
         for (uint32_t y = row_begin; y < row_end; y++) {
             ArrayPending pend;
             for (uint32_t x = 0; x < s->width; x++) gbuffer_pixel(s->P, x, y, s->gbuf.data(), s->depth.data(), pend);
@@ -876,28 +881,27 @@ int emul_session_resolve(void *h, uint32_t frames, uint8_t *rgba, float *albedo,
 
 void emul_session_destroy(void *h) { delete (EmulSession *)h; }
 
-// debugging aid: the IBL certificate of one pixel: out[0..7] far-horizon slopes, [8] rho, [9] stop distance, [10..12] origin
-int emul_ibl_far(const f3d_terrain_ref_desc *d, uint32_t gx, uint32_t gy, float *out) {
+// debugging aid: the far-horizon record of the block that holds cell (cx, cz): out[0..7] slopes, [8] rho, [9] stop distance,
+// [10] block level, [11..12] block centre x z, [13] the height no origin of the block lies below, [14..15] block size x z
+int emul_horizon_blocks(const f3d_terrain_ref_desc *d, uint32_t n, const uint32_t *cells, float *out_all) {
     try {
         FrameParams P{};
         (void)fill_uniforms(*d, P);
         HostTables t = build_tables_host(d->heights, d->dem_width, d->dem_height, d->exaggeration);
         t.attach(P.terrain);
-        P.row_begin = 0;
-        P.row_end = d->height;
-        ArrayPending pend;
-        const V3 rd = camera_dir(P.cam, gx, gy, 0.0f, 0.0f);
-        const SurfaceHit hit = closest_hit(P, P.cam.origin, 1e-3f, rd, 1e30f, pend);
-        for (int i = 0; i < 13; i++) out[i] = 3.0e38f;
-        if (hit.kind != 0u) {
-            const V3 o = along(hit.p, 1e-3f, hit.n);
-            ibl_far_horizon(P, o, hit.t, out);
-            const float cell_min = f_min(P.terrain.spacing_x, P.terrain.spacing_z), cell_max = f_max(P.terrain.spacing_x, P.terrain.spacing_z);
-            out[8] = ibl_rho(hit.t, pixel_cone_delta(P.cam), cell_min);
-            out[9] = ibl_stop_distance(out[8], cell_max);
-            out[10] = o.x;
-            out[11] = o.y;
-            out[12] = o.z;
+        const TerrainDev &T = P.terrain;
+        const uint32_t level = horizon_block_level(T.cell_w, T.cell_h);
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t cx = cells[2 * i], cz = cells[2 * i + 1];
+            float *out = out_all + 16 * (size_t)i;
+            if (cx >= T.cell_w || cz >= T.cell_h) return 1;
+            horizon_block_build(T, level, cx >> level, cz >> level, out);
+            out[8] = horizon_block_rho(T, level);
+            out[9] = ibl_stop_distance(out[8], f_max(T.spacing_x, T.spacing_z));
+            out[10] = (float)level;
+            horizon_block_frame(T, level, cx >> level, cz >> level, out[11], out[12], out[13]);
+            out[14] = T.spacing_x * (float)(1u << level);
+            out[15] = T.spacing_z * (float)(1u << level);
         }
         return 0;
     } catch (const Failure &) {

@@ -148,22 +148,43 @@ def test_sun_certificates_are_conservative_and_do_something():
     assert certified >= 10, (certified, total)  # (a small footprint and low suns: most cylinders leave it below the top)
 
 
-def test_ibl_certificates_are_conservative_and_do_something():
-    """A ray that starts within rho of the certificate's origin and climbs more steeply than the far horizon of its
-    sector meets no terrain beyond the stop distance (the oracle's closest hit along it says where it does)."""
-    dem = scenes.golden_dem()
-    kw = scenes.scene_kwargs(dem)
-    geo = {k: kw[k] for k in ("spacing", "exaggeration")}
-    W, H = 96, 64
-    pixels = [(x, y) for y in range(3, H, 5) for x in range(2, W, 7)]
-    recs = emul.ibl_far(dem, W, H, scenes.CAM, pixels, **geo)
+def _surface_height(dem, spacing, exaggeration, x, z):
+    """Bilinear terrain height at world (x, z) (DEM centred on the origin, row = +z)."""
+    h, w = dem.shape
+    u = (x + 0.5 * (w - 1) * spacing[0]) / spacing[0]
+    v = (z + 0.5 * (h - 1) * spacing[1]) / spacing[1]
+    i, j = int(np.clip(np.floor(u), 0, w - 2)), int(np.clip(np.floor(v), 0, h - 2))
+    fu, fv = u - i, v - j
+    c = dem[j:j + 2, i:i + 2].astype(np.float64) * exaggeration
+    return (c[0, 0] * (1 - fu) + c[0, 1] * fu) * (1 - fv) + (c[1, 0] * (1 - fu) + c[1, 1] * fu) * fv
+
+
+@pytest.mark.parametrize("case", ["golden", "cliff", "ragged"])
+def test_ibl_certificates_are_conservative_and_do_something(case):
+    """The far-horizon table (f3d_cone.h): a ray that starts ANYWHERE on a block's surface (lifted 1e-3 like the IBL rays)
+    and climbs more steeply than the block's horizon of its sector meets no terrain beyond the stop distance -- the
+    oracle's closest hit along it says where it does."""
+    if case == "golden":
+        dem = scenes.golden_dem()
+        kw = scenes.scene_kwargs(dem)
+        geo = {k: kw[k] for k in ("spacing", "exaggeration")}
+    elif case == "cliff":
+        dem, geo = _cliff_dem(), dict(spacing=(1.0, 1.0), exaggeration=1.0)
+    else:
+        rng0 = np.random.default_rng(4)
+        dem = (np.cumsum(rng0.normal(size=(37, 53)), axis=1) * 3.0 + 40.0 * rng0.random((37, 53))).astype(np.float32)
+        geo = dict(spacing=(2.5, 1.5), exaggeration=1.7)
+    h, w = dem.shape
     rng = np.random.default_rng(9)
+    cells = [(int(rng.integers(0, w - 1)), int(rng.integers(0, h - 1))) for _ in range(150)]
+    recs = emul.horizon_blocks(dem, cells, **geo)
+    sx, sz = geo["spacing"]
     rays, meta = [], []
     sectors_with_horizon = 0
-    for rec in recs:
-        if rec["rho"] > 1e37:
-            continue
-        sectors_with_horizon += sum(1 for h in rec["far"] if h < 1e30)
+    for (cx, cz), rec in zip(cells, recs):
+        sectors_with_horizon += sum(1 for hz in rec["far"] if hz < 1e30)
+        side = 1 << rec["level"]
+        bx0, bz0 = (cx >> rec["level"]) * side, (cz >> rec["level"]) * side
         for _ in range(40):
             az = rng.uniform(0, 2 * np.pi)
             dx, dz = np.cos(az), np.sin(az)
@@ -173,16 +194,21 @@ def test_ibl_certificates_are_conservative_and_do_something():
                 continue
             slope = max(horizon, 0.0) * 1.001 + 2e-4 + rng.exponential(0.3)
             d = np.array([dx, slope, dz]) / np.sqrt(1 + slope * slope)
-            off = rng.normal(size=3)
-            off *= rng.uniform(0.0, rec["rho"]) / np.linalg.norm(off)
-            rays.append([*(np.array(rec["origin"]) + off), 1e-3, *d, 1e30])
+            # an origin on the block's surface, lifted along a random unit vector like the 1e-3 normal offset
+            u = rng.uniform(bx0, min(bx0 + side, w - 1)), rng.uniform(bz0, min(bz0 + side, h - 1))
+            x, z = -0.5 * (w - 1) * sx + u[0] * sx, -0.5 * (h - 1) * sz + u[1] * sz
+            y = _surface_height(dem, (sx, sz), geo["exaggeration"], x, z)
+            lift = rng.normal(size=3)
+            lift *= 1e-3 / np.linalg.norm(lift)
+            o = np.array([x, y, z]) + lift
+            assert np.hypot(o[0] - rec["centre"][0], o[2] - rec["centre"][1]) <= rec["rho"] and o[1] >= rec["y_lo"]
+            rays.append([*o, 1e-3, *d, 1e30])
             meta.append(rec["stop_distance"] / np.hypot(d[0], d[2]))
-    sx, sz = kw["spacing"]
-    hit = oracle.terrain_trace_batch(dem, np.array(rays, np.float32), origin=(-0.5 * (dem.shape[1] - 1) * sx, -0.5 * (dem.shape[0] - 1) * sz),
-                                     spacing=kw["spacing"], exaggeration=kw["exaggeration"], any_hit=False, apply_curvature=False)
+    hit = oracle.terrain_trace_batch(dem, np.array(rays, np.float32), origin=(-0.5 * (w - 1) * sx, -0.5 * (h - 1) * sz),
+                                     spacing=geo["spacing"], exaggeration=geo["exaggeration"], any_hit=False, apply_curvature=False)
     for k, t_stop in enumerate(meta):
         if hit["hit"][k]:
-            assert hit["t"][k] <= t_stop, (rays[k], float(hit["t"][k]), t_stop)
+            assert hit["t"][k] <= t_stop, (case, rays[k], float(hit["t"][k]), t_stop)
     assert sectors_with_horizon > 2 * len(recs) and len(rays) > 500
 
 
