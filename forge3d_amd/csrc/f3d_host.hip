@@ -315,6 +315,9 @@ struct f3d_session {
     int64_t cost_frame = -1, order_frame = -1;  // newest frame whose wave durations are in tile_cost / went into tile_order
     // frames in flight (f3d_kernels.hip k_trace / k_merge): record buffer for `fd_frames` frames; 0 = the fused path
     uint32_t fd_frames = 0;
+    // wavefront form of the trace batches (f3d_kernels.hip k_wf_primary / k_wf_occl): occlusion rays through queues in HBM
+    bool wavefront = false;
+    uint32_t wf_quorum = 0;
     int64_t trace_first = -1;
     uint32_t trace_count = 0;
     // per-launch timing
@@ -465,7 +468,12 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
     P.terrain.nodes = s.tables.nodes;
     P.terrain.bands = s.tables.bands;
 #if !defined(F3D_NO_IBL_STOP)  // A/B builds (tools/build_variant.sh)
-    {   // far-horizon table of this DEM at this spacing: from the scene cache, or built now (one quadtree walk per block)
+    // Opt-in (F3D_IBL_HORIZON=1): measured on MI355X, the table costs 12.9 ms to build for the 2048^2 headline DEM and
+    // saves 0.03 ms per 8-spp 1080p frame (+1.2 %) -- its blocks' lowest points see higher horizons than the hit points
+    // themselves; the per-pixel form of round 2's branch saved 0.13 ms per frame for 26 ms per render.  Neither pays
+    // for itself below several hundred frames, so sessions do not build it unless asked (profiles/README.md).
+    if (const char *hz_env = getenv("F3D_IBL_HORIZON"); hz_env && hz_env[0] == '1') {
+        // far-horizon table of this DEM at this spacing: from the scene cache, or built now (one quadtree walk per block)
         std::lock_guard<std::mutex> lock(g_scene_mutex);
         const CachedTables::Horizon *have = nullptr;
         for (const auto &hz : s.scene->horizons)
@@ -611,11 +619,29 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
         const bool same_sun = f_bits(P.light.wi.x) == f_bits(P.light.wi_reuse.x) && f_bits(P.light.wi.y) == f_bits(P.light.wi_reuse.y) &&
                               f_bits(P.light.wi.z) == f_bits(P.light.wi_reuse.z);
         P.same_sun = same_sun ? 1u : 0u;
+        // Wavefront trace (terrain-only scenes: the mesh walk stays in the fused kernels): F3D_WAVEFRONT=1 asks for it,
+        // =0 forbids it; it needs frames in flight (F3D_WF_FRAMES, default 2) and 84 instead of 32 bytes per sample in flight.
+        const char *wf_env = getenv("F3D_WAVEFRONT");
+        const bool wf_want = wf_env && wf_env[0] == '1' && P.mesh.traversal_mode != 0u;
+        if (wf_want && want < 2u) {
+            const char *n = getenv("F3D_WF_FRAMES");
+            want = n ? (uint32_t)std::max(2, atoi(n)) : 2u;
+        }
         if (want >= 2u && (!opts || opts->bands <= 1u)) {
-            const uint64_t per_frame = (uint64_t)px * P.spp * 2u * sizeof(float4);
-            const uint64_t fit = per_frame ? (s.budget - planned) / per_frame : 0u;
+            const uint64_t rec_bytes = 2u * sizeof(float4), ray_bytes = 2u * sizeof(float4) + sizeof(float4) + sizeof(float);
+            uint64_t per_frame = (uint64_t)px * P.spp * (rec_bytes + (wf_want ? ray_bytes : 0u));
+            uint64_t fit = per_frame ? (s.budget - planned) / per_frame : 0u;
+            s.wavefront = wf_want && fit >= 2u;
+            if (wf_want && !s.wavefront) {  // the queues do not fit the budget: plain frames in flight, if those do
+                per_frame = (uint64_t)px * P.spp * rec_bytes;
+                fit = per_frame ? (s.budget - planned) / per_frame : 0u;
+                if (opts && opts->frames_in_flight < 2u) fit = 0u;  // (they were only asked for as part of the wavefront form)
+            }
             s.fd_frames = (uint32_t)std::min<uint64_t>(want, fit);
-            if (s.fd_frames < 2u) s.fd_frames = 0u;
+            if (s.fd_frames < 2u) {
+                s.fd_frames = 0u;
+                s.wavefront = false;
+            }
         }
     }
     if (s.fd_frames) {
@@ -627,6 +653,21 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
         P.fix_list = (uint32_t *)s.mem.alloc(px * sizeof(uint32_t), "retrace list");
         P.fix_count = (uint32_t *)s.mem.alloc(4 * sizeof(uint32_t), "retrace counters");
         hip_check(hipMemsetAsync(P.fix_count, 0, 4 * sizeof(uint32_t), s.stream), "retrace counters clear");
+        if (s.wavefront) {
+            const size_t cap = (size_t)s.fd_frames * P.spp * px;
+            P.wf.cap = (uint32_t)cap;
+            P.wf.sun_o = (float4 *)s.mem.alloc(cap * sizeof(float4), "wavefront sun-ray queue");
+            P.wf.sun_stop = (float *)s.mem.alloc(cap * sizeof(float), "wavefront sun-ray queue");
+            P.wf.ibl_o = (float4 *)s.mem.alloc(cap * sizeof(float4), "wavefront IBL-ray queue");
+            P.wf.ibl_d = (float4 *)s.mem.alloc(cap * sizeof(float4), "wavefront IBL-ray queue");
+            P.wf.counters = (uint32_t *)s.mem.alloc(8 * sizeof(uint32_t), "wavefront queue counters");
+            hip_check(hipMemsetAsync(P.wf.sun_o, 0, cap * sizeof(float4), s.stream), "queue touch");  // page mappings, as above
+            hip_check(hipMemsetAsync(P.wf.sun_stop, 0, cap * sizeof(float), s.stream), "queue touch");
+            hip_check(hipMemsetAsync(P.wf.ibl_o, 0, cap * sizeof(float4), s.stream), "queue touch");
+            hip_check(hipMemsetAsync(P.wf.ibl_d, 0, cap * sizeof(float4), s.stream), "queue touch");
+            const char *q = getenv("F3D_WF_QUORUM");
+            s.wf_quorum = q ? (uint32_t)std::max(1, std::min(64, atoi(q))) : 0u;
+        }
     } else {
         P.trace = nullptr;
         P.trace_first = 0u;
@@ -817,7 +858,8 @@ void enqueue_trace(f3d_session &s, uint32_t first, uint32_t count) {
         hip_check(hipEventCreate(&e1), "event");
         hip_check(hipEventRecord(e0, s.stream), "event record");
     }
-    hip_check(launch_trace(P, count, s.stream), "trace kernel");
+    if (s.wavefront) hip_check(launch_trace_wavefront(P, count, s.wf_quorum, s.stream), "wavefront trace kernels");
+    else hip_check(launch_trace(P, count, s.stream), "trace kernel");
     if (s.tile_cost) s.cost_frame = (int64_t)first;
     P.tile_order = nullptr;
     P.tile_cost = nullptr;

@@ -32,6 +32,7 @@ struct ResolveParams {
 hipError_t launch_head(const FrameParams &p, hipStream_t stream);  // sample-lane form: before launch_frame
 hipError_t launch_frame(const FrameParams &p, int variant, hipStream_t stream);
 hipError_t launch_trace(const FrameParams &p, uint32_t frames, hipStream_t stream);  // frames in flight: a batch of frames
+hipError_t launch_trace_wavefront(const FrameParams &p, uint32_t frames, uint32_t quorum, hipStream_t stream);  // same records, rays through queues
 hipError_t launch_merge(const FrameParams &p, hipStream_t stream);
 hipError_t launch_trace_init(const FrameParams &p, hipStream_t stream);               // first sun-direction predictions                   // ... and the ordered half of one
 // longest-first dispatch of the frame kernel: tile count (and grid) of the current band, and the ordering kernel

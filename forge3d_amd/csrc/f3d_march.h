@@ -241,8 +241,9 @@ F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint
             // (cell_w <= 2^13, level <= 15), so one unsigned comparison covers both directions
             const uint32_t qx = nx + ((cross_x && x_forward) ? 1u : 0u) - ((cross_x && !x_forward) ? 1u : 0u);
             const uint32_t qz = nz + ((cross_z && z_forward) ? 1u : 0u) - ((cross_z && !z_forward) ? 1u : 0u);
+            // above the whole terrain and climbing (RayCtx::y_exit): nothing ahead can pass its band test
             const bool left = !(exit < r.tmax) || (SLICED && !(exit < t_stop)) || (qx << level) >= T.cell_w ||
-                              (qz << level) >= T.cell_h;
+                              (qz << level) >= T.cell_h || march_height<CURVED>(r, exit) > r.y_exit;
             // leaving the parent as well: continue one level up (jumping h > 1 levels when the crossing
             // leaves h ancestors was modelled on the emulator's step logs: fewer IBL steps, but more
             // shadow steps and 7-17 % more wave iterations -- tools/march_model.py)
@@ -403,6 +404,7 @@ F3D_HD void march_deal(const TerrainDev &T, MarchSlice &s, MarchState &m, const 
         r.vertex = 0.0f;
         r.has_vertex = false;
     }
+    r.y_exit = ctx.shfl(s.r.y_exit, src);
     const float t0 = ctx.shfl(m.t_cur, src), t_end = ctx.shfl(s.t_end, src);
     const float stop_src = ctx.shfl(s.t_stop, src);
     const float t1 = f_min(stop_src, t_end);  // the slice being cut again ends here
@@ -542,6 +544,68 @@ template <bool CURVED, class Ctx>
 F3D_HD TraceHit march_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit, bool start_in_cell, Ctx &ctx,
                               float t_stop = 3.0e38f) {
     return march_terrain_from<CURVED, true>(T, r, any_hit, march_begin(T, r, start_in_cell), ctx, t_stop);
+}
+
+// ---- a STREAM of occlusion rays through the lanes of a wave (wavefront kernels, f3d_kernels.hip k_wf_occl) -----------
+// The fused frame kernel marches the rays of a wave in lockstep: one sun ray (then one IBL ray) per lane, and the wave
+// iterates until its longest ray is done -- measured on the headline frame, a lane-step of the two occlusion phases costs
+// 1.8x what a lane-step of the primary phase costs, because most iterations run with a few lanes (tools/march_model.py:
+// lockstep utilisation 0.32 / 0.21 against 0.70).  Here the rays come from a queue: a lane whose ray is done takes the
+// next one, so the wave stays full until the queue is empty.  Per-ray arithmetic is march_step / march_drain unchanged --
+// the verdict of a ray does not depend on which lane walks it or on what its neighbours do (3.1 of DESIGN.md).
+// Lanes finish one by one; retiring and refilling them one by one would run the (divergent) drain and ray set-up code
+// at 1 / 64 utilisation, so a STALLED lane (no ray, or a ray that has stopped marching but may have leaves waiting in its
+// FIFO) waits until `quorum` lanes are stalled; then the wave drains all FIFOs, retires the finished rays and deals new
+// ones to every idle lane, together.
+// Source:  bool refill(bool &have, RayCtx &r, float &t_stop, uint32_t &tag, Ctx &ctx)  -- give a ray to every lane with
+//          !have that can get one; returns false once the queue is exhausted (wave-uniform);
+//          void verdict(uint32_t tag, bool occluded)
+#ifndef F3D_STREAM_QUORUM
+#define F3D_STREAM_QUORUM 16
+#endif
+template <bool CURVED, class Ctx, class Source>
+F3D_HD void march_stream(const TerrainDev &T, Source &src, Ctx &ctx, uint32_t quorum = F3D_STREAM_QUORUM) {
+    bool have = false;
+    MarchState m;
+    m.marching = false;
+    m.unverified_start = false;
+    m.t_cur = 0.0f;
+    m.level = m.nx = m.nz = 0u;
+    RayCtx r = make_ray(T, V3{0.0f, 0.0f, 0.0f}, 0.0f, V3{0.0f, 1.0f, 0.0f}, 0.0f, false);
+    TraceHit res;
+    res.hit = false;
+    res.t = 0.0f;
+    res.n = V3{0.0f, 0.0f, 0.0f};
+    float t_stop = 3.0e38f;
+    uint32_t tag = 0u, queued = 0u;
+    bool more = true;  // wave-uniform: the source may still have rays
+    const uint32_t lanes = bits_set(ctx.ballot(true));
+    for (;;) {
+        const uint32_t stalled = bits_set(ctx.ballot(!have || !m.marching));
+        if (stalled >= quorum || stalled == lanes) {
+            if (ctx.any(queued != 0u)) march_drain(T, r, true, m, queued, res, ctx);
+            if (have && !m.marching) {  // (a drain may have stopped further lanes: they retire now too)
+                src.verdict(tag, res.hit);
+                have = false;
+            }
+            if (more) {
+                const bool was = have;
+                more = src.refill(have, r, t_stop, tag, ctx);
+                if (have && !was) {
+                    m = march_begin(T, r, true);  // occlusion rays start on the surface: in the origin's cell
+                    res.hit = false;
+                    res.t = r.tmax;
+                    queued = 0u;
+                }
+            }
+            if (!ctx.any(have)) {
+                if (!more) break;
+                continue;  // (a refill that handed out nothing although rays remain: ask again)
+            }
+        }
+        if (have && m.marching) march_step<CURVED, true>(T, r, m, queued, ctx, true, t_stop);
+        if (ctx.flush_now(queued, true)) march_drain(T, r, true, m, queued, res, ctx);  // a FIFO is full
+    }
 }
 
 // Curvature is a per-ray policy AND a per-render switch (wave-uniform): pick the instantiation.

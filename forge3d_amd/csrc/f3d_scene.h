@@ -134,6 +134,19 @@ struct alignas(16) PackedReservoir {
 };
 constexpr uint32_t kLightTypeBit = 0x80000000u;
 
+// Ray queues of the wavefront form of a trace batch (f3d_kernels.hip k_wf_primary -> k_wf_occl): k_wf_primary leaves
+// every sample's record with both occlusion verdicts assumed "visible" and appends the occlusion rays that have to be
+// decided; k_wf_occl streams them through persistent waves and zeroes the term of a record whose ray is blocked.
+// `tag` of a ray = index of its sample's record pair in FrameParams::trace.
+struct WfQueues {
+    float4 *sun_o;       // [cap] {origin, tag bits}: rays along light.wi fill from the FRONT, rays along light.wi_reuse
+    float *sun_stop;     // [cap] from the BACK (the two directions differ in the last bit for most suns); t_stop per ray
+    float4 *ibl_o;       // [cap] {origin, tag bits}
+    float4 *ibl_d;       // [cap] {direction, t_stop}
+    uint32_t *counters;  // [0] sun front count, [1] sun back count, [2] ibl count, [3..5] the consumers' cursors
+    uint32_t cap;        // entries per queue = samples of a trace batch
+};
+
 // Per-frame kernel parameters.
 struct FrameParams {
     TerrainDev terrain;
@@ -173,6 +186,7 @@ struct FrameParams {
     // pixel-frames whose sun direction was mispredicted: k_merge lists them, k_fix re-traces them, 64 to a wave
     uint32_t *fix_list;   // strip-local pixel indices
     uint32_t *fix_count;  // [0], [1]: entries for frame parity 0 / 1; [2]: running total (diagnostics)
+    WfQueues wf;          // wavefront form of the trace batch (sun_o == null: k_trace traces the rays itself)
 };
 
 }  // namespace f3d

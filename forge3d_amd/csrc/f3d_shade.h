@@ -478,21 +478,32 @@ struct IblRay {
     float t_stop;  // no terrain beyond this parameter (f3d_cone.h ibl_stop); 3e38: no certificate
 };
 
-// First half of the shading of a sample whose primary hit is known (:486-536): candidate, sun term
-// (with its shadow ray), and the IBL ray to trace; draws u1, u2 from `rng` on a hit.
-template <class Pending>
-F3D_HD IblRay sample_shade_sun(const FrameParams &P, const FrameHead &h, const PrimaryHit &ph, uint32_t &rng,
-                               SampleOut &o, Pending &pend) {
-    IblRay q;
+// What the shading of a sample needs from its two occlusion rays, with everything else already evaluated (:486-545):
+// radiance = (Y * vis_sun) * reuse_w + b0 * vis_ibl.  The fused kernels trace the two rays on the spot; the wavefront
+// kernels (f3d_kernels.hip k_wf_primary / k_wf_occl) put them into queues.
+struct ShadeSetup {
+    IblRay q;        // the IBL ray (valid = the primary ray hit); q.o is the origin of BOTH occlusion rays
+    bool need_sun;   // the surface faces the sun: a shadow ray decides vis_sun (else the sun term is 0)
+    V3 sun_dir;      // direction of the shadow ray (the candidate's or the reservoir's: equal up to the last bit)
+    V3 y;            // (albedo * light colour) * max(n . sun_dir, 0): the sun term before visibility and reuse weight
+};
+
+// Everything of a sample's shading except the two occlusion rays; draws u1, u2 from `rng` on a hit; o.a = the miss
+// radiance on a miss, o.target_pdf = the candidate weight.
+F3D_HD ShadeSetup sample_shade_setup(const FrameParams &P, const FrameHead &h, const PrimaryHit &ph, uint32_t &rng, SampleOut &o) {
+    ShadeSetup su;
+    IblRay &q = su.q;
     q.valid = false;
     q.o = q.d = q.b0 = V3{0.0f, 0.0f, 0.0f};
     q.key = 2.0f;
     q.t_stop = 3.0e38f;
-    o.b = V3{0.0f, 0.0f, 0.0f};
+    su.need_sun = false;
+    su.sun_dir = su.y = V3{0.0f, 0.0f, 0.0f};
+    o.a = o.b = V3{0.0f, 0.0f, 0.0f};
     o.target_pdf = 0.0f;
     if (ph.hit.kind == 0u) {
         o.a = env_radiance(P.env, ph.rd);
-        return q;
+        return su;
     }
     const V3 n = ph.hit.n;
     const V3 albedo = ph.hit.kind == 1u ? P.light.albedo : V3{0.7f, 0.7f, 0.8f};
@@ -500,26 +511,16 @@ F3D_HD IblRay sample_shade_sun(const FrameParams &P, const FrameHead &h, const P
     // candidate generation for this hit (:500-512)
     o.target_pdf = luminance((albedo * P.light.color) * f_max(dot(n, P.light.wi), 0.0f));
     // sun through the merged reservoir, :517-532
-    const V3 sun_dir = h.prev_valid ? P.light.wi_reuse : P.light.wi;
-    const float nd = f_max(dot(n, sun_dir), 0.0f);
-    o.a = V3{0.0f, 0.0f, 0.0f};
+    su.sun_dir = h.prev_valid ? P.light.wi_reuse : P.light.wi;
+    const float nd = f_max(dot(n, su.sun_dir), 0.0f);
     if (nd > 0.0f) {
-        float vis = 1.0f;
-#if defined(F3D_MODEL_HINT_SUN)  // scheduling-model builds of the emulator only
-        pend.hint(F3D_MODEL_HINT_SUN);
-#endif
-#if !defined(F3D_TIMING_NO_SHADOW)  // timing experiment only (wrong image): tools/gpu_build_ab.sh
-        if (P.light.shadows_enabled != 0u && occluded(P, so, 1e-3f, sun_dir, 1e30f, true, pend, ph.sun_tmax)) vis = 0.0f;
-#endif
-        o.a = (((albedo * P.light.color) * nd) * vis) * h.reuse_w;
+        su.need_sun = true;
+        su.y = (albedo * P.light.color) * nd;
     }
     // one cosine-weighted IBL sample, :537-545
     const float u1 = rng_next(rng);
     const float u2 = rng_next(rng);
     const V3 ei = cosine_dir(n, u1, u2);
-#if defined(F3D_MODEL_HINT)  // scheduling-model builds of the emulator only (tools/march_model.py predictor)
-    pend.hint(F3D_MODEL_HINT);
-#endif
     q.valid = true;
     q.o = so;
     q.d = ei;
@@ -528,7 +529,29 @@ F3D_HD IblRay sample_shade_sun(const FrameParams &P, const FrameHead &h, const P
 #if !defined(F3D_NO_IBL_STOP)  // A/B builds
     if (ph.hit.kind == 1u) q.t_stop = ibl_stop(P.terrain, so, ei);  // (a mesh hit may lie below the terrain: no certificate)
 #endif
-    return q;
+    return su;
+}
+
+// First half of the shading of a sample whose primary hit is known (:486-536): candidate, sun term
+// (with its shadow ray), and the IBL ray to trace; draws u1, u2 from `rng` on a hit.
+template <class Pending>
+F3D_HD IblRay sample_shade_sun(const FrameParams &P, const FrameHead &h, const PrimaryHit &ph, uint32_t &rng,
+                               SampleOut &o, Pending &pend) {
+    const ShadeSetup su = sample_shade_setup(P, h, ph, rng, o);
+    if (su.need_sun) {
+        float vis = 1.0f;
+#if defined(F3D_MODEL_HINT_SUN)  // scheduling-model builds of the emulator only
+        pend.hint(F3D_MODEL_HINT_SUN);
+#endif
+#if !defined(F3D_TIMING_NO_SHADOW)  // timing experiment only (wrong image): tools/gpu_build_ab.sh
+        if (P.light.shadows_enabled != 0u && occluded(P, su.q.o, 1e-3f, su.sun_dir, 1e30f, true, pend, ph.sun_tmax)) vis = 0.0f;
+#endif
+        o.a = (su.y * vis) * h.reuse_w;
+    }
+#if defined(F3D_MODEL_HINT)  // scheduling-model builds of the emulator only (tools/march_model.py predictor)
+    if (su.q.valid) pend.hint(F3D_MODEL_HINT);
+#endif
+    return su.q;
 }
 
 // The verdict of an IBL ray (intersect_ibl_occlusion_ray, hybrid_traversal.wgsl:250-259).

@@ -39,6 +39,10 @@ struct RayCtx {
     float c2;            // dot(d.xz, d.xz) * inv_two_r_prime when the curvature policy is on, else 0
     float vertex;        // parameter of the parabola's minimum (:120)
     bool has_vertex;
+    // March only (f3d_march.h): the height above which this ray can stop -- the maximum of the whole terrain for a ray
+    // that only climbs (d.y > 0; the curvature policy lifts it further, c2 >= 0), 3e38 otherwise.  Heights are monotone
+    // in t (correctly rounded fma), so once the ray is above it every cell still ahead fails its band test (:301-304).
+    float y_exit;
 };
 
 F3D_HD float safe_inv(float d) {
@@ -59,6 +63,11 @@ F3D_HD RayCtx make_ray(const TerrainDev &T, V3 o, float tmin, V3 d, float tmax, 
     r.c2 = curved ? hd2 * T.inv_two_r_prime : 0.0f;
     r.has_vertex = curved && r.c2 > 0.0f;
     r.vertex = r.has_vertex ? -d.y / (2.0f * r.c2) : 0.0f;
+#if !defined(F3D_NO_ASCEND_EXIT)  // A/B builds (tools/build_variant.sh)
+    r.y_exit = (d.y > 0.0f && r.c2 >= 0.0f && T.bands) ? T.bands[T.band_offset[T.mip_count - 1u]].mx : 3.0e38f;
+#else
+    r.y_exit = 3.0e38f;
+#endif
     return r;
 }
 

@@ -25,9 +25,11 @@ def build(force=False):
     srcs = [_HERE / "f3d_emul.cpp"] + sorted(_CSRC.glob("*.h"))
     if force or not _LIB.exists() or _LIB.stat().st_mtime < max(s.stat().st_mtime for s in srcs):
         extra = os.environ.get("F3D_EMUL_CXXFLAGS", "").split()  # experiment switches (-DF3D_...)
+        tmp = _LIB.with_suffix(f".{os.getpid()}.tmp")  # parallel test workers may all find the library stale: build aside, then rename
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-march=x86-64-v3",
-                        "-ffp-contract=off", "-DF3D_HORIZON_LAZY", *extra, str(_HERE / "f3d_emul.cpp"), "-o", str(_LIB)],
+                        "-ffp-contract=off", "-DF3D_HORIZON_LAZY", *extra, str(_HERE / "f3d_emul.cpp"), "-o", str(tmp)],
                        check=True, capture_output=True)
+        os.replace(tmp, _LIB)
     return _LIB
 
 

@@ -39,6 +39,9 @@ for seed in range(first, first + count):
     outs = []
     try:
         for k, in_flight in enumerate((0, fd)):
+            if os.environ.get("F3D_FUZZ_WAVEFRONT"):  # the batched session traces through the wavefront kernels (terrain-only scenes)
+                os.environ["F3D_WAVEFRONT"] = "1" if in_flight else "0"
+                os.environ["F3D_WF_QUORUM"] = str(int(rng.choice([1, 8, 16, 32, 64])))
             if POISON:
                 _native.debug_poison(POISON[(seed % 4 + k * (1 + (seed // 4) % 3)) % 4])  # two different patterns
             with TerrainSession(dem, size[0], size[1], cam, kernel_variant=variant, frames_in_flight=in_flight,
