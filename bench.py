@@ -53,6 +53,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--extra-windows", type=int, default=4, help="further timed windows of --steps frames (spread report)")
     ap.add_argument("--no-terrain-filling", action="store_true", help="skip the second, terrain-filling camera")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short timed windows of BASELINE.json's other configurations")
     return ap.parse_args()
 
 
@@ -89,6 +90,94 @@ def terrain_filling_camera(dem, kw):
     top = float(dem.max())
     return {"origin": (-0.30 * span, 0.62 * top, -0.34 * span), "look_at": (0.02 * span, 0.30 * top, 0.03 * span),
             "up": (0.0, 1.0, 0.0), "fov_y": 38.0, "exposure": 1.0}
+
+
+def other_configs(dem, cam, kw, args, device):
+    """Short timed windows of BASELINE.json's OTHER configurations, so that their rates are driver-observed and not
+    only tool logs (round-2 verdict item 7).  Synthetic stand-ins as in BASELINE.md; the headline stays configs[1]."""
+    import torch
+
+    from forge3d_amd import atmosphere, datasets
+    from forge3d_amd.session import TerrainSession
+
+    out = {}
+
+    def window(session, warm, frames, samples_per_frame):
+        session.enqueue_frames(0, warm)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        session.enqueue_frames(warm, frames, True)
+        session.window_stats()
+        dt = time.perf_counter() - t0
+        return {"value": samples_per_frame * frames / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt / frames * 1e3, "steps": frames}
+
+    # C1: the reference's locked mini-DEM scene at 512 x 512, 16 spp per frame (its CPU-snapshot configuration)
+    try:
+        mini = np.load(ROOT / "tests" / "golden" / "mini_dem.npy")
+        d1, c1, k1 = datasets.mini_dem_scene(mini)
+        k1 = dict(k1, spp=16, max_frames=20, min_frames=20, variance_threshold=1e30)
+        with TerrainSession(d1, 512, 512, c1, device=device, memory_budget_bytes=8 << 30, frames_in_flight=0xFFFFFFFF, **k1) as s:
+            r = window(s, 4, 16, 512 * 512 * 16)
+            r["frames_in_flight"] = s.frames_in_flight()
+        r["config"] = "BASELINE.json configs[0]: mini-DEM golden scene 128^2 DEM, 512x512, 16 spp/frame x 16 frames"
+        out["C1"] = r
+    except Exception as exc:  # noqa: BLE001
+        out["C1"] = {"error": str(exc)[:200]}
+    # C3: configs[1] + the AETHER aerial-perspective post at turbidity 2 (the post runs inside the resolve kernel)
+    try:
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)  # (no bank directory on the GPU box: anchors baked, handle says so)
+            handle = atmosphere.AtmosphereLutHandle.load_shipped(atmosphere.AtmosphereConfig(turbidity=2.0))
+        k3 = dict(kw, max_frames=20, min_frames=20)
+        with TerrainSession(dem, args.width, args.height, cam, device=device, memory_budget_bytes=8 << 30, kernel_variant=args.variant,
+                            atmosphere=handle, **k3) as s:
+            r = window(s, 4, 16, args.width * args.height * args.spp)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            img = s.resolve(20)
+            r["resolve_with_post_and_readback_ms"] = (time.perf_counter() - t0) * 1e3
+        r["hit_fraction"] = float(np.isfinite(img["depth"]).mean())
+        r["lut_provenance"] = handle.provenance
+        r["config"] = (f"BASELINE.json configs[2] stand-in: configs[1] workload + AETHER post (turbidity 2), {args.width}x{args.height}, "
+                       f"{args.spp} spp/frame x 16 frames; GI (terrain in the PBR tracer) is not part of this number")
+        out["C3"] = r
+    except Exception as exc:  # noqa: BLE001
+        out["C3"] = {"error": str(exc)[:200]}
+    # C4 stand-in: 600 000 triangles (50 000 extruded boxes) on the proxy DEM at 4096 x 4096
+    try:
+        v, i = datasets.proxy_buildings(dem, kw["spacing"][0])
+        k4 = dict(kw, max_frames=6, min_frames=6)
+        with TerrainSession(dem, 4096, 4096, cam, device=device, memory_budget_bytes=16 << 30, mesh_vertices=v, mesh_indices=i, **k4) as s:
+            r = window(s, 2, 4, 4096 * 4096 * args.spp)
+        r["triangles"] = int(i.shape[0])
+        r["config"] = f"BASELINE.json configs[3] stand-in: proxy DEM + 600 000 triangles, 4096x4096, {args.spp} spp/frame x 4 frames, 1 GPU"
+        out["C4_standin"] = r
+    except Exception as exc:  # noqa: BLE001
+        out["C4_standin"] = {"error": str(exc)[:200]}
+    # C5: one frame of the smoke volume ray-marcher at 1080p (a 96 x 64 x 128 synthetic plume)
+    try:
+        from forge3d_amd import smoke
+
+        rng = np.random.default_rng(9)
+        nx, ny, nz = 96, 64, 128
+        zz, yy, xx = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+        core = np.exp(-(((xx - 48) / 14.0) ** 2 + ((zz - 64) / 22.0) ** 2)) * np.clip(1.2 - yy / 56.0, 0.0, 1.0)
+        dens = (core * (0.6 + 0.4 * rng.random(core.shape))).astype(np.float32)
+        dom = smoke.SmokeDomain.from_density(dens)
+        dom.set_temperature((300.0 + 500.0 * dens).astype(np.float32))
+        dom.set_soot((0.3 * dens).astype(np.float32))
+        dom.set_emission((0.1 * dens).astype(np.float32))
+        view = dict(camera_pos=(48.0, 70.0, -120.0), target=(48.0, 28.0, 64.0), up=(0.0, 1.0, 0.0), fovy_deg=40.0)
+        dom.render_rgba(args.width, args.height, **view)
+        t0 = time.perf_counter()
+        dom.render_rgba(args.width, args.height, **view)
+        out["C5"] = {"value": (time.perf_counter() - t0) * 1e3, "unit": "ms/frame (upload + march + read-back)", "kernel_ms": dom.last_kernel_seconds * 1e3,
+                     "config": f"BASELINE.json configs[4] stand-in: one {args.width}x{args.height} frame of the smoke ray-marcher, 96x64x128 plume"}
+    except Exception as exc:  # noqa: BLE001
+        out["C5"] = {"error": str(exc)[:200]}
+    return out
 
 
 def cpu_baseline(dem, cam, kw, args, world=1):
@@ -278,6 +367,8 @@ def main():
             "shaded_msamples_per_s": rate2 * hit2, "grays_per_s": rate2 * 1e6 * (1.0 + 2.0 * hit2) / 1e9,
             "camera": {k: [float(x) for x in v] if isinstance(v, tuple) else v for k, v in cam2.items()},
         }
+    if rank == 0 and world == 1 and not args.no_configs:
+        result["configs"] = other_configs(dem, cam, kw, args, local_rank)
     if rank == 0:
         print(json.dumps(result))
 

@@ -75,6 +75,12 @@ class Out(C.Structure):
     ]
 
 
+class HaloExport(C.Structure):
+    """f3d_halo_export"""
+    _fields_ = [("handle", (C.c_uint8 * 64) * 3), ("offset", C.c_uint64 * 3), ("address", C.c_uint64 * 3),
+                ("rows", C.c_uint32), ("width", C.c_uint32), ("device", C.c_int32), ("pid", C.c_uint32)]
+
+
 class SessionOpts(C.Structure):
     """f3d_session_opts"""
     _fields_ = [
@@ -96,6 +102,10 @@ ABI = [
     ("f3d_session_enqueue_frames", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_char_p, C.c_size_t]),
     ("f3d_session_enqueue_trace", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t]),
     ("f3d_session_enqueue_merge", C.c_int, [C.c_void_p, C.c_uint32, C.c_int32, C.c_char_p, C.c_size_t]),
+    ("f3d_session_halo_export", C.c_int, [C.c_void_p, _P(HaloExport), C.c_char_p, C.c_size_t]),
+    ("f3d_session_halo_connect", C.c_int, [C.c_void_p, C.c_int32, _P(HaloExport), C.c_char_p, C.c_size_t]),
+    ("f3d_session_halo_status", C.c_int, [C.c_void_p, _P(C.c_uint32), C.c_char_p, C.c_size_t]),
+    ("f3d_session_enqueue_batch_strip", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_char_p, C.c_size_t]),
     ("f3d_session_frames_in_flight", C.c_uint32, [C.c_void_p]),
     ("f3d_session_retraced_pixels", C.c_int, [C.c_void_p, _P(C.c_uint64)]),
     ("f3d_session_trace_batch", C.c_uint32, [C.c_void_p, C.c_uint32, C.c_uint32]),

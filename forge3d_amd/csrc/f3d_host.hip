@@ -18,6 +18,8 @@
 #include <new>
 #include <unordered_map>
 
+#include <unistd.h>
+
 #include "f3d_devmem.h"
 #include "f3d_launch.h"
 #include "f3d_lbvh.h"
@@ -292,6 +294,16 @@ struct f3d_session {
     float *depth = nullptr;
     uint32_t *stats = nullptr;
     uint32_t *host_stats = nullptr;  // pinned
+    // peer halos (include/f3d_terrain_pt.h): [0] frames merged (neighbours poll it), [1] wait time-outs of this strip
+    uint32_t *halo_flags = nullptr;
+    struct PeerLink {
+        void *opened[3] = {nullptr, nullptr, nullptr};  // hipIpcOpenMemHandle results (closed with the session)
+        const PackedReservoir *res[2] = {nullptr, nullptr};
+        const uint32_t *flags = nullptr;
+        uint32_t rows = 0;
+        bool connected = false;
+    } peer[2];  // 0 = the strip above, 1 = the strip below
+    bool owns_reservoirs = false;
     uint8_t *d_rgba = nullptr;
     float *d_albedo = nullptr, *d_normal = nullptr;
     int variant = 0;
@@ -334,6 +346,10 @@ struct f3d_session {
         if (fork) (void)hipEventDestroy(fork);
         for (hipStream_t st : band_streams) (void)hipStreamDestroy(st);
         if (host_stats) (void)hipHostFree(host_stats);
+        for (auto &link : peer)
+            for (void *base : link.opened)
+                if (base) (void)hipIpcCloseMemHandle(base);
+        if (halo_flags) (void)hipFree(halo_flags);
         mem.release();
     }
 };
@@ -629,7 +645,7 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
         }
         if (want >= 2u && (!opts || opts->bands <= 1u)) {
             const uint64_t rec_bytes = 2u * sizeof(float4), ray_bytes = 2u * sizeof(float4) + sizeof(float4) + sizeof(float);
-            uint64_t per_frame = (uint64_t)px * P.spp * (rec_bytes + (wf_want ? ray_bytes : 0u));
+            uint64_t per_frame = (uint64_t)px * P.spp * (rec_bytes + (wf_want ? ray_bytes + ray_bytes / 4u : 0u));  // (+ a quarter: regions of partly filled edge tiles and rounds)
             uint64_t fit = per_frame ? (s.budget - planned) / per_frame : 0u;
             s.wavefront = wf_want && fit >= 2u;
             if (wf_want && !s.wavefront) {  // the queues do not fit the budget: plain frames in flight, if those do
@@ -654,17 +670,23 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
         P.fix_count = (uint32_t *)s.mem.alloc(4 * sizeof(uint32_t), "retrace counters");
         hip_check(hipMemsetAsync(P.fix_count, 0, 4 * sizeof(uint32_t), s.stream), "retrace counters clear");
         if (s.wavefront) {
-            const size_t cap = (size_t)s.fd_frames * P.spp * px;
-            P.wf.cap = (uint32_t)cap;
+            // one region of 64 slots per (frame in flight, tile, round of the tile's wave): f3d_scene.h WfQueues
+            P.band_begin = s.row_begin;
+            P.band_end = s.row_end;
+            const uint32_t lanes = P.sample_lanes ? P.sample_lanes : 1u;
+            P.wf.regions_per_frame = frame_tile_count(P, nullptr) * ((P.spp + lanes - 1u) / lanes);
+            const size_t regions = (size_t)s.fd_frames * P.wf.regions_per_frame, cap = regions * kWfRegion;
             P.wf.sun_o = (float4 *)s.mem.alloc(cap * sizeof(float4), "wavefront sun-ray queue");
             P.wf.sun_stop = (float *)s.mem.alloc(cap * sizeof(float), "wavefront sun-ray queue");
             P.wf.ibl_o = (float4 *)s.mem.alloc(cap * sizeof(float4), "wavefront IBL-ray queue");
             P.wf.ibl_d = (float4 *)s.mem.alloc(cap * sizeof(float4), "wavefront IBL-ray queue");
-            P.wf.counters = (uint32_t *)s.mem.alloc(8 * sizeof(uint32_t), "wavefront queue counters");
+            P.wf.counts = (uint32_t *)s.mem.alloc(regions * sizeof(uint32_t), "wavefront region counts");
+            P.wf.cursors = (uint32_t *)s.mem.alloc(4 * sizeof(uint32_t), "wavefront chunk cursors");
             hip_check(hipMemsetAsync(P.wf.sun_o, 0, cap * sizeof(float4), s.stream), "queue touch");  // page mappings, as above
             hip_check(hipMemsetAsync(P.wf.sun_stop, 0, cap * sizeof(float), s.stream), "queue touch");
             hip_check(hipMemsetAsync(P.wf.ibl_o, 0, cap * sizeof(float4), s.stream), "queue touch");
             hip_check(hipMemsetAsync(P.wf.ibl_d, 0, cap * sizeof(float4), s.stream), "queue touch");
+            hip_check(hipMemsetAsync(P.wf.counts, 0, regions * sizeof(uint32_t), s.stream), "queue touch");
             const char *q = getenv("F3D_WF_QUORUM");
             s.wf_quorum = q ? (uint32_t)std::max(1, std::min(64, atoi(q))) : 0u;
         }
@@ -679,6 +701,7 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
             s.mem.device_bytes += res_n * sizeof(PackedReservoir);  // caller-owned, still part of the working set
         } else {
             s.res[i] = (PackedReservoir *)s.mem.alloc(res_n * sizeof(PackedReservoir), "reservoirs");
+            s.owns_reservoirs = true;
         }
         hip_check(hipMemsetAsync(s.res[i], 0, res_n * sizeof(PackedReservoir), s.stream), "reservoir clear");
     }
@@ -986,6 +1009,91 @@ void resolve(f3d_session &s, uint32_t frames, uint8_t *d_rgba, float *d_albedo, 
 
 }  // namespace
 
+// ---- peer halos --------------------------------------------------------------------------------------------------
+namespace {
+__global__ void k_halo_flag(uint32_t *flag, uint32_t frames_merged) {
+    __hip_atomic_store(flag, frames_merged, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+struct HaloPullParams {
+    const uint32_t *flag[2];  // the neighbours' "frames merged" counters (null: no neighbour on that side)
+    const unsigned long long *src[2];
+    unsigned long long *dst[2];
+    uint32_t words;           // 8-byte words per halo block
+    uint32_t want;            // frames the neighbour must have merged
+    uint32_t *timeouts;
+};
+// One workgroup per neighbour: wait until it has merged `want` frames, then copy its edge rows into my halo rows.
+// Every access to the neighbour's memory is a system-scope load that bypasses this device's caches.
+__global__ __launch_bounds__(1024) void k_halo_pull(const HaloPullParams H) {
+    const uint32_t side = blockIdx.x;
+    if (!H.flag[side]) return;
+    __shared__ uint32_t ok;
+    if (threadIdx.x == 0u) {
+        const unsigned long long t0 = wall_clock64();  // 100 MHz
+        ok = __hip_atomic_load(H.timeouts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u ? 1u : 0u;  // a neighbour is gone: do not wait again
+        while (ok != 0u && __hip_atomic_load(H.flag[side], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < H.want) {
+            __builtin_amdgcn_s_sleep(16);
+            if (wall_clock64() - t0 > 400000000ull) {  // ~4 s: the neighbour is gone
+                ok = 0u;
+                atomicAdd(H.timeouts, 1u);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    if (ok == 0u) return;
+    for (uint32_t i = threadIdx.x; i < H.words; i += blockDim.x)
+        H.dst[side][i] = __hip_atomic_load(H.src[side] + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+void enqueue_halo_sync(f3d_session &s, uint32_t frame) {  // behind the kernels of `frame`
+    hipLaunchKernelGGL(k_halo_flag, dim3(1), dim3(1), 0, s.stream, s.halo_flags, frame + 1u);
+    if (!s.peer[0].connected && !s.peer[1].connected) return;
+    HaloPullParams H{};
+    const size_t row = (size_t)s.width, block = (size_t)kHaloRows * row;
+    const uint32_t which = frame & 1u;
+    H.words = (uint32_t)(block * sizeof(PackedReservoir) / 8u);
+    H.want = frame + 1u;
+    H.timeouts = s.halo_flags + 1;
+    if (s.peer[0].connected) {  // the strip above: its BOTTOM owned rows -> my halo above
+        H.flag[0] = s.peer[0].flags;
+        H.src[0] = (const unsigned long long *)(s.peer[0].res[which] + (size_t)s.peer[0].rows * row);
+        H.dst[0] = (unsigned long long *)(s.res[which]);
+    }
+    if (s.peer[1].connected) {  // the strip below: its TOP owned rows -> my halo below
+        H.flag[1] = s.peer[1].flags;
+        H.src[1] = (const unsigned long long *)(s.peer[1].res[which] + block);
+        H.dst[1] = (unsigned long long *)(s.res[which] + ((size_t)s.rows + kHaloRows) * row);
+    }
+    hipLaunchKernelGGL(k_halo_pull, dim3(2), dim3(1024), 0, s.stream, H);
+    hip_check(hipGetLastError(), "halo pull kernel");
+}
+
+// Frames [first, first + count) of a strip whose neighbours are connected: enqueue_range with the halo step after
+// every frame.
+void enqueue_batch_strip(f3d_session &s, uint32_t first, uint32_t count, bool collect_last) {
+    if (!s.halo_flags) fail(F3D_STATUS_VALUE, "f3d_session_halo_export has not been called for this session");
+    if (s.fd_frames) {
+        for (uint32_t done = 0; done < count;) {
+            const uint32_t n = trace_batch(s, first + done, count - done);
+            enqueue_trace(s, first + done, n);
+            for (uint32_t i = 0; i < n; i++) {
+                enqueue_merge(s, first + done + i, collect_last && done + i + 1 == count);
+                enqueue_halo_sync(s, first + done + i);
+            }
+            done += n;
+        }
+        return;
+    }
+    for (uint32_t i = 0; i < count; i++) {
+        fork_bands(s, collect_last && i + 1 == count);
+        enqueue_frame(s, first + i, collect_last && i + 1 == count, 0u, false);
+        join_bands(s);
+        enqueue_halo_sync(s, first + i);
+    }
+}
+}  // namespace
+
 // ---------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------
@@ -1076,6 +1184,86 @@ int f3d_session_window_stats(f3d_session *s, float *max_m2, int32_t *nonfinite, 
         hip_check(hipStreamSynchronize(s->stream), "stream sync");
         if (max_m2) *max_m2 = f_from_bits(s->host_stats[0]);
         if (nonfinite) *nonfinite = s->host_stats[1] != 0u;
+    });
+}
+
+int f3d_session_halo_export(f3d_session *s, f3d_halo_export *out, char *err, size_t errlen) {
+    return c_abi(err, errlen, [&] {
+        DeviceGuard g(checked(s).device);
+        if (!out) fail(F3D_STATUS_VALUE, "null export record");
+        if (!s->owns_reservoirs) fail(F3D_STATUS_VALUE, "peer halos need reservoirs owned by the session (no ext_reservoirs)");
+        if (!s->halo_flags) {
+            hip_check(hipMalloc((void **)&s->halo_flags, 256), "halo counters");
+            hip_check(hipMemset(s->halo_flags, 0, 256), "halo counters");
+        }
+        memset(out, 0, sizeof(*out));
+        void *objects[3] = {s->res[0], s->res[1], s->halo_flags};
+        for (int i = 0; i < 3; i++) {
+            void *base = nullptr;
+            size_t size = 0;
+            hip_check(hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)objects[i]), "allocation of a halo object");
+            hipIpcMemHandle_t h;
+            hip_check(hipIpcGetMemHandle(&h, base), "hipIpcGetMemHandle");
+            static_assert(sizeof(h) == 64, "hipIpcMemHandle_t is 64 bytes");
+            memcpy(out->handle[i], &h, 64);
+            out->offset[i] = (uint64_t)((char *)objects[i] - (char *)base);
+            out->address[i] = (uint64_t)(uintptr_t)objects[i];
+        }
+        out->rows = s->rows;
+        out->width = s->width;
+        out->device = s->device;
+        out->pid = (uint32_t)getpid();
+        hip_check(hipStreamSynchronize(s->stream), "export sync");
+    });
+}
+
+int f3d_session_halo_connect(f3d_session *s, int32_t side, const f3d_halo_export *peer, char *err, size_t errlen) {
+    return c_abi(err, errlen, [&] {
+        DeviceGuard g(checked(s).device);
+        if (side < 0 || side > 1 || !peer) fail(F3D_STATUS_VALUE, "halo connect: side must be 0 (above) or 1 (below)");
+        if (peer->width != s->width) fail(F3D_STATUS_VALUE, "halo connect: the neighbour renders another image width");
+        if (!s->halo_flags) fail(F3D_STATUS_VALUE, "f3d_session_halo_export has not been called for this session");
+        f3d_session::PeerLink &L = s->peer[side];
+        if (L.connected) fail(F3D_STATUS_VALUE, "halo connect: side %d is connected already", side);
+        void *mapped[3];
+        for (int i = 0; i < 3; i++) {
+            hipIpcMemHandle_t h;
+            memcpy(&h, peer->handle[i], 64);
+            void *base = nullptr;
+            if (peer->pid == (uint32_t)getpid()) {
+                mapped[i] = (void *)(uintptr_t)peer->address[i];  // a process cannot open its own handles: same address space
+                continue;
+            } else {
+                hip_check(hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess), "hipIpcOpenMemHandle");
+                L.opened[i] = base;
+            }
+            mapped[i] = (char *)base + peer->offset[i];
+        }
+        L.res[0] = (const PackedReservoir *)mapped[0];
+        L.res[1] = (const PackedReservoir *)mapped[1];
+        L.flags = (const uint32_t *)mapped[2];
+        L.rows = peer->rows;
+        L.connected = true;
+    });
+}
+
+int f3d_session_halo_status(f3d_session *s, uint32_t *timeouts, char *err, size_t errlen) {
+    return c_abi(err, errlen, [&] {
+        DeviceGuard g(checked(s).device);
+        if (!timeouts) fail(F3D_STATUS_VALUE, "null output");
+        *timeouts = 0u;
+        if (s->halo_flags) {
+            hip_check(hipStreamSynchronize(s->stream), "halo status");
+            hip_check(hipMemcpy(timeouts, s->halo_flags + 1, sizeof(uint32_t), hipMemcpyDeviceToHost), "halo status");
+        }
+    });
+}
+
+int f3d_session_enqueue_batch_strip(f3d_session *s, uint32_t first_frame, uint32_t count, int32_t collect_stats_on_last, char *err,
+                                    size_t errlen) {
+    return c_abi(err, errlen, [&] {
+        DeviceGuard g(checked(s).device);
+        enqueue_batch_strip(*s, first_frame, count, collect_stats_on_last != 0);
     });
 }
 

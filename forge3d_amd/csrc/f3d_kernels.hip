@@ -434,19 +434,8 @@ __device__ __forceinline__ void trace_lanes(const FrameParams &P, uint32_t frame
 // persistent waves that stream a queue through march_stream (f3d_march.h) -- a lane takes the next ray when its own is
 // done -- and zero the term of a record whose ray is blocked.  Records and merges are those of the frames-in-flight
 // pipeline, bit for bit: y * 0.0f where the fused kernel multiplies by vis = 0, untouched where it multiplies by 1.
-__device__ __forceinline__ uint32_t wf_push(uint32_t *counter, bool want) {
-    const unsigned long long mask = __ballot(want);
-    if (mask == 0ull) return 0u;
-    const uint32_t lane = threadIdx.x & (kWave - 1u);
-    const int first = __ffsll((long long)mask) - 1;
-    uint32_t base = 0u;
-    if ((int)lane == first) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = (uint32_t)__shfl((int)base, first, kWave);
-    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-}
-
 template <uint32_t S>
-__device__ __forceinline__ void wf_primary_lanes(const FrameParams &P, uint32_t frame, uint32_t gx, uint32_t gy, bool valid,
+__device__ __forceinline__ void wf_primary_lanes(const FrameParams &P, uint32_t frame, uint32_t tile, uint32_t gx, uint32_t gy, bool valid,
                                                  LdsPending &pend) {
     const uint32_t lane = threadIdx.x & (kWave - 1u), j = lane & (S - 1u), base = lane & ~(S - 1u);
     constexpr uint32_t kGroup = (1u << S) - 1u;
@@ -459,6 +448,7 @@ __device__ __forceinline__ void wf_primary_lanes(const FrameParams &P, uint32_t 
     h.rng = P.cam.seed_hi ^ (gx * 1664525u) ^ (gy * 1013904223u) ^ (frame * 92837111u) ^ P.cam.seed_lo;
     uint32_t stream = h.rng;
     const size_t frame_base = (size_t)(frame - P.trace_first) * P.spp * pixels;
+    const uint32_t rounds = (P.spp + S - 1u) / S;
     for (uint32_t s0 = 0u; s0 < P.spp; s0 += S) {  // wave-uniform
         const uint32_t n_act = P.spp - s0 < S ? P.spp - s0 : S;
         const bool act = valid && j < n_act;
@@ -493,25 +483,28 @@ __device__ __forceinline__ void wf_primary_lanes(const FrameParams &P, uint32_t 
             su = sample_shade_setup(P, h, ph, rng, o);
             if (su.need_sun) o.a = su.y;  // (y * 1.0f) * 1.0f: k_wf_occl makes it (y * 0.0f) * 1.0f if the ray is blocked
             sun_ray = su.need_sun && P.light.shadows_enabled != 0u;
-            sun_back = h.prev_valid;  // the ray runs along light.wi_reuse
+            sun_back = h.prev_valid && P.same_sun == 0u;  // the ray runs along light.wi_reuse (when that differs from light.wi at all)
             ibl_ray = su.q.valid;
             if (ibl_ray) o.b = su.q.b0;
             float4 *rec = P.trace + 2u * (size_t)tag;
             rec[0] = float4{o.a.x, o.a.y, o.a.z, o.target_pdf};
             rec[1] = float4{o.b.x, o.b.y, o.b.z, trace_code(ph.hit.kind != 0u, h.prev_valid)};
         }
-        const uint32_t front = wf_push(P.wf.counters + 0, sun_ray && !sun_back);
-        const uint32_t back = wf_push(P.wf.counters + 1, sun_ray && sun_back);
-        const uint32_t islot = wf_push(P.wf.counters + 2, ibl_ray);
+        // this wave-round's region of the queues: compacted by ballots, counts in one word
+        const size_t region = ((size_t)(frame - P.trace_first) * (P.wf.regions_per_frame / rounds) + tile) * rounds + s0 / S;
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const unsigned long long m_front = __ballot(sun_ray && !sun_back), m_back = __ballot(sun_ray && sun_back), m_ibl = __ballot(ibl_ray);
         if (sun_ray) {
-            const uint32_t slot = sun_back ? P.wf.cap - 1u - back : front;
+            const size_t slot = region * kWfRegion + (sun_back ? kWfRegion - 1u - (uint32_t)__popcll(m_back & below) : (uint32_t)__popcll(m_front & below));
             P.wf.sun_o[slot] = float4{su.q.o.x, su.q.o.y, su.q.o.z, f_from_bits(tag)};
             P.wf.sun_stop[slot] = ph.sun_tmax;
         }
         if (ibl_ray) {
-            P.wf.ibl_o[islot] = float4{su.q.o.x, su.q.o.y, su.q.o.z, f_from_bits(tag)};
-            P.wf.ibl_d[islot] = float4{su.q.d.x, su.q.d.y, su.q.d.z, su.q.t_stop};
+            const size_t slot = region * kWfRegion + (uint32_t)__popcll(m_ibl & below);
+            P.wf.ibl_o[slot] = float4{su.q.o.x, su.q.o.y, su.q.o.z, f_from_bits(tag)};
+            P.wf.ibl_d[slot] = float4{su.q.d.x, su.q.d.y, su.q.d.z, su.q.t_stop};
         }
+        if (lane == 0u) P.wf.counts[region] = (uint32_t)__popcll(m_front) | ((uint32_t)__popcll(m_back) << 8) | ((uint32_t)__popcll(m_ibl) << 16);
         rng_skip(stream, 2u * n_act + 2u * (uint32_t)__popc(pred));
     }
 }
@@ -523,7 +516,8 @@ __global__ __launch_bounds__(kWave, MIN_WAVES) void k_wf_primary(const FramePara
     LdsPending pend = make_pending(lds, P.terrain);
     uint32_t gx = 0u, gy = 0u, tile;
     const bool active = tile_pixel<S>(P, gx, gy, tile, P.tile_order);
-    wf_primary_lanes<S>(P, P.frame_index + blockIdx.y, gx, gy, active, pend);
+    if (tile == 0xFFFFFFFFu) return;  // a padding workgroup: no tile, no region
+    wf_primary_lanes<S>(P, P.frame_index + blockIdx.y, tile, gx, gy, active, pend);
     if (threadIdx.x == 0u && blockIdx.y == 0u && P.tile_cost && tile != 0xFFFFFFFFu)
         P.tile_cost[tile] = (uint32_t)(wall_clock64() - t_start);
 }
@@ -534,48 +528,79 @@ struct WfOcclParams {
     float4 *trace;
     const float4 *ray_o, *ray_d;  // ray_d: IBL rays only
     const float *ray_stop;        // sun rays only
-    const uint32_t *count;
-    uint32_t *cursor;
-    uint32_t cap, reverse;        // reverse: entry i sits at cap - 1 - i (the sun queue's back half)
+    const uint32_t *counts;       // per region (WfQueues::counts)
+    uint32_t *cursor;             // chunks handed out beyond each wave's first one
+    uint32_t regions;             // of this batch
+    uint32_t kind;                // 0 sun rays from the front of a region, 1 sun rays from its back, 2 IBL rays
     V3 dir;                       // sun rays
     uint32_t quorum;
 };
-constexpr uint32_t kWfChunk = 256u;  // rays a wave takes from the queue per atomic
+constexpr uint32_t kWfChunk = 8u;  // regions a wave takes at a time: its first chunk is its own index, the next ones come from the cursor
 template <bool SUN>
 struct WfSource {
     const WfOcclParams &W;
-    uint32_t total, next, end;
+    uint32_t chunk, chunks;  // current chunk (>= chunks: exhausted)
+    uint32_t k, used, have_n;  // region of the chunk, rays of it handed out, rays it holds
+    uint32_t my_count;       // lane l < kWfChunk: the count of region l of the current chunk
+    bool first;
+    __device__ __forceinline__ void load_chunk(uint32_t lane) {
+        const uint32_t region = chunk * kWfChunk + lane;
+        const uint32_t word = (lane < kWfChunk && region < W.regions) ? W.counts[region] : 0u;
+        my_count = (word >> (8u * W.kind)) & 0xFFu;
+        k = 0u;
+        used = 0u;
+        have_n = (uint32_t)__shfl((int)my_count, 0, kWave);
+    }
+    __device__ __forceinline__ bool next_chunk(uint32_t lane) {
+        uint32_t id = 0u;
+        if (lane == 0u) id = gridDim.x + atomicAdd(W.cursor, 1u);
+        chunk = (uint32_t)__shfl((int)id, 0, kWave);
+        if (chunk >= chunks) return false;
+        load_chunk(lane);
+        return true;
+    }
     __device__ __forceinline__ bool refill(bool &have, RayCtx &r, float &t_stop, uint32_t &tag, LdsPending &ctx) {
         const uint32_t lane = ctx.lane();
-        if (next == end) {
-            const unsigned long long all = __ballot(true);
-            const int first = __ffsll((long long)all) - 1;
-            uint32_t base = 0u;
-            if ((int)lane == first) base = atomicAdd(W.cursor, kWfChunk);
-            base = (uint32_t)__shfl((int)base, first, kWave);
-            if (base >= total) return false;
-            next = base;
-            end = base + kWfChunk < total ? base + kWfChunk : total;
+        if (first) {  // the wave's own chunk: no atomic for it (8 192 waves asking one counter at once: 60 ns each)
+            first = false;
+            chunk = blockIdx.x;
+            if (chunk >= chunks) return false;
+            load_chunk(lane);
         }
         const unsigned long long idle = __ballot(!have);
-        const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull)), avail = end - next;
-        if (!have && rank < avail) {
-            const uint32_t i = next + rank, slot = W.reverse ? W.cap - 1u - i : i;
-            const float4 o = W.ray_o[slot];
-            V3 d = W.dir;
-            if (SUN) {
-                t_stop = W.ray_stop[slot];
-            } else {
-                const float4 dd = W.ray_d[slot];
-                d = V3{dd.x, dd.y, dd.z};
-                t_stop = dd.w;
+        const uint32_t n_idle = (uint32_t)__popcll(idle), rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+        const bool was_idle = !have;
+        uint32_t given = 0u;
+        while (given < n_idle) {  // wave-uniform
+            if (used == have_n) {
+                if (++k == kWfChunk) {
+                    if (!next_chunk(lane)) return false;
+                } else {
+                    used = 0u;
+                    have_n = (uint32_t)__shfl((int)my_count, (int)k, kWave);
+                }
+                continue;
             }
-            tag = f_bits(o.w);
-            r = make_ray(W.terrain, V3{o.x, o.y, o.z}, 1e-3f, d, 1e30f, SUN);  // occluded(): tmin 1e-3, max distance 1e30
-            have = true;
+            const uint32_t give = have_n - used < n_idle - given ? have_n - used : n_idle - given;
+            if (was_idle && rank >= given && rank < given + give) {
+                const uint32_t j = used + (rank - given);
+                const size_t slot = (size_t)(chunk * kWfChunk + k) * kWfRegion + (W.kind == 1u ? kWfRegion - 1u - j : j);
+                const float4 o = W.ray_o[slot];
+                V3 d = W.dir;
+                if (SUN) {
+                    t_stop = W.ray_stop[slot];
+                } else {
+                    const float4 dd = W.ray_d[slot];
+                    d = V3{dd.x, dd.y, dd.z};
+                    t_stop = dd.w;
+                }
+                tag = f_bits(o.w);
+                r = make_ray(W.terrain, V3{o.x, o.y, o.z}, 1e-3f, d, 1e30f, SUN);  // occluded(): tmin 1e-3, max distance 1e30
+                have = true;
+            }
+            used += give;
+            given += give;
         }
-        const uint32_t n_idle = (uint32_t)__popcll(idle);
-        next += avail < n_idle ? avail : n_idle;
         return true;
     }
     __device__ __forceinline__ void verdict(uint32_t tag, bool blocked) const {
@@ -592,8 +617,7 @@ __global__ __launch_bounds__(kWave, MIN_WAVES) void k_wf_occl(const WfOcclParams
     constexpr uint32_t kRows = 3u * kLeafFifoRows;  // the leaf FIFO; no park rows, no verdict board: 4 KiB a wave
     __shared__ __attribute__((aligned(16))) uint32_t lds[kRows * kWave + 4 * kMaxLevels];
     LdsPending pend = make_pending(lds, W.terrain, kRows);
-    WfSource<SUN> src{W, *W.count, 0u, 0u};
-    if (src.total == 0u) return;
+    WfSource<SUN> src{W, 0u, (W.regions + kWfChunk - 1u) / kWfChunk, 0u, 0u, 0u, 0u, true};
     march_stream<SUN>(W.terrain, src, pend, W.quorum ? W.quorum : (uint32_t)F3D_STREAM_QUORUM);
 }
 
@@ -855,11 +879,19 @@ hipError_t launch_trace(const FrameParams &p, uint32_t frames, hipStream_t strea
     }
     return hipGetLastError();
 }
-// the wavefront form of launch_trace: counters cleared, primaries + queues, then the three queues
+// the wavefront form of launch_trace: primaries + queues, then the three queues through persistent waves
+template <class K>
+static uint32_t persistent_grid(K kernel) {
+    int device = 0, cus = 256, per_cu = 0;
+    (void)hipGetDevice(&device);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kWave, 0) != hipSuccess || per_cu <= 0) per_cu = 16;
+    return (uint32_t)cus * (uint32_t)per_cu;
+}
 hipError_t launch_trace_wavefront(const FrameParams &p, uint32_t frames, uint32_t quorum, hipStream_t stream) {
     const uint32_t lanes = p.sample_lanes ? p.sample_lanes : 1u;
     if (frame_grid(p, lanes) == 0u || frames == 0u) return hipSuccess;
-    hipError_t err = hipMemsetAsync(p.wf.counters, 0, 8u * sizeof(uint32_t), stream);
+    hipError_t err = hipMemsetAsync(p.wf.cursors, 0, 4u * sizeof(uint32_t), stream);
     if (err != hipSuccess) return err;
     const dim3 grid(frame_grid(p, lanes), frames), block(kWave);
     switch (lanes) {
@@ -869,33 +901,29 @@ hipError_t launch_trace_wavefront(const FrameParams &p, uint32_t frames, uint32_
         case 8: hipLaunchKernelGGL((k_wf_primary<6, 8>), grid, block, 0, stream, p); break;
         default: return hipErrorInvalidValue;
     }
-    int device = 0, cus = 256;
-    (void)hipGetDevice(&device);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-    constexpr int kOcclWaves = 8;  // per SIMD
-    const dim3 pgrid((uint32_t)cus * 4u * (uint32_t)kOcclWaves);
+    static const uint32_t sun_grid = persistent_grid(k_wf_occl<true, 7>), ibl_grid = persistent_grid(k_wf_occl<false, 8>);
     WfOcclParams W{};
     W.terrain = p.terrain;
     W.trace = p.trace;
-    W.cap = p.wf.cap;
+    W.counts = p.wf.counts;
+    W.regions = frames * p.wf.regions_per_frame;
     W.quorum = quorum;
-    for (uint32_t q = 0u; q < 2u; q++) {  // sun rays along light.wi (front of the queue), along light.wi_reuse (back)
+    for (uint32_t q = 0u; q < 2u; q++) {  // sun rays along light.wi (front of the regions), along light.wi_reuse (back)
+        if (q == 1u && p.same_sun != 0u) break;  // (the same bits: k_wf_primary files every sun ray at the front then)
         W.ray_o = p.wf.sun_o;
         W.ray_d = nullptr;
         W.ray_stop = p.wf.sun_stop;
-        W.count = p.wf.counters + q;
-        W.cursor = p.wf.counters + 3u + q;
-        W.reverse = q;
+        W.cursor = p.wf.cursors + q;
+        W.kind = q;
         W.dir = q ? p.light.wi_reuse : p.light.wi;
-        hipLaunchKernelGGL((k_wf_occl<true, kOcclWaves>), pgrid, block, 0, stream, W);
+        hipLaunchKernelGGL((k_wf_occl<true, 7>), dim3(sun_grid), block, 0, stream, W);
     }
     W.ray_o = p.wf.ibl_o;
     W.ray_d = p.wf.ibl_d;
     W.ray_stop = nullptr;
-    W.count = p.wf.counters + 2u;
-    W.cursor = p.wf.counters + 5u;
-    W.reverse = 0u;
-    hipLaunchKernelGGL((k_wf_occl<false, kOcclWaves>), pgrid, block, 0, stream, W);
+    W.cursor = p.wf.cursors + 2u;
+    W.kind = 2u;
+    hipLaunchKernelGGL((k_wf_occl<false, 8>), dim3(ibl_grid), block, 0, stream, W);
     return hipGetLastError();
 }
 hipError_t launch_trace_init(const FrameParams &p, hipStream_t stream) {

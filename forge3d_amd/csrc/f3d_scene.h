@@ -135,17 +135,23 @@ struct alignas(16) PackedReservoir {
 constexpr uint32_t kLightTypeBit = 0x80000000u;
 
 // Ray queues of the wavefront form of a trace batch (f3d_kernels.hip k_wf_primary -> k_wf_occl): k_wf_primary leaves
-// every sample's record with both occlusion verdicts assumed "visible" and appends the occlusion rays that have to be
+// every sample's record with both occlusion verdicts assumed "visible" and files the occlusion rays that have to be
 // decided; k_wf_occl streams them through persistent waves and zeroes the term of a record whose ray is blocked.
-// `tag` of a ray = index of its sample's record pair in FrameParams::trace.
+// The queues are REGIONS of 64 slots, one per (frame of the batch, tile, round of the tile's wave): the wave compacts
+// its rays into its own region (ballot + prefix count, no atomic -- a counter shared by the 130 000 waves of a frame was
+// measured at 3 ns per atomic, 2.5 ms a frame) and leaves the three counts in one word.  Regions are numbered by TILE,
+// so consecutive regions hold rays that start next to one another.  `tag` of a ray = index of its sample's record pair
+// in FrameParams::trace.
 struct WfQueues {
-    float4 *sun_o;       // [cap] {origin, tag bits}: rays along light.wi fill from the FRONT, rays along light.wi_reuse
-    float *sun_stop;     // [cap] from the BACK (the two directions differ in the last bit for most suns); t_stop per ray
-    float4 *ibl_o;       // [cap] {origin, tag bits}
-    float4 *ibl_d;       // [cap] {direction, t_stop}
-    uint32_t *counters;  // [0] sun front count, [1] sun back count, [2] ibl count, [3..5] the consumers' cursors
-    uint32_t cap;        // entries per queue = samples of a trace batch
+    float4 *sun_o;     // [regions][64] {origin, tag bits}: rays along light.wi fill a region from its FRONT, rays along
+    float *sun_stop;   // [regions][64] light.wi_reuse from its BACK (the two differ in the last bit for most suns); t_stop
+    float4 *ibl_o;     // [regions][64] {origin, tag bits}
+    float4 *ibl_d;     // [regions][64] {direction, t_stop}
+    uint32_t *counts;  // [regions] front sun rays | back sun rays << 8 | IBL rays << 16
+    uint32_t *cursors; // [3] chunk cursors of the three consumer launches (cleared per batch)
+    uint32_t regions_per_frame;  // tiles * rounds
 };
+constexpr uint32_t kWfRegion = 64u;
 
 // Per-frame kernel parameters.
 struct FrameParams {

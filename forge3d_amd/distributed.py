@@ -118,9 +118,9 @@ class HipBackend:
         from .session import TerrainSession
 
         stream = self.torch.cuda.current_stream(self.device).cuda_stream
+        ext = (res[0].data_ptr(), res[1].data_ptr()) if res is not None else (None, None)  # None: the session owns them (peer halos)
         return TerrainSession(dem, width, height, cam, row_begin=row_begin, row_end=row_end,
-                              device=self.device.index, stream=stream,
-                              ext_reservoirs=(res[0].data_ptr(), res[1].data_ptr()), ext_stats=stats.data_ptr(),
+                              device=self.device.index, stream=stream, ext_reservoirs=ext, ext_stats=stats.data_ptr(),
                               **kw)
 
     def sync(self):
@@ -150,7 +150,7 @@ class HipBackend:
 
 class StripRenderer:
     def __init__(self, dem, width, height, cam, *, rank=0, world=1, device=0, backend=None, row_bounds=None,
-                 balance_iters=5, **kw):
+                 balance_iters=5, peer_halos=None, **kw):
         import torch
 
         self.torch = torch
@@ -183,7 +183,6 @@ class StripRenderer:
         self.row_begin, self.row_end = self.bounds[rank], self.bounds[rank + 1]
         self.rows = self.row_end - self.row_begin
         nbytes = (self.rows + 2 * HALO_ROWS) * self.width * RES_BYTES
-        self.res = [self.backend.empty_bytes(nbytes), self.backend.empty_bytes(nbytes)]
         self.stats = self.backend.empty_i32(4)
         # render_terrain.rs:465-471: a sun-lit scene must end with valid reservoirs
         sun_rgb = kw.get("sun_color", (1.0, 0.97, 0.92))
@@ -192,8 +191,57 @@ class StripRenderer:
         self.max_frames = int(kw.get("max_frames", 512))
         self.min_frames = int(kw.get("min_frames", 32))
         self.variance_threshold = float(kw.get("variance_threshold", 1e-3))
-        self.session = self.backend.make_session(dem, self.width, self.height, cam, self.row_begin, self.row_end,
-                                                 self.res, self.stats, kw)
+        # Peer halos (include/f3d_terrain_pt.h): the strips pull their neighbours' edge rows themselves, on the device,
+        # and a whole window of frames is ONE call into the library -- no Python and no collective per frame.  Tried
+        # first on the product backend; if any rank cannot map its neighbours (no IPC between the devices, an old
+        # driver) every rank falls back to the RCCL point-to-point exchange below.
+        if peer_halos is None:
+            peer_halos = os.environ.get("F3D_PEER_HALOS", "1") != "0"
+        self.peer_halos = False
+        self.session = None
+        if world > 1 and peer_halos and isinstance(self.backend, HipBackend):
+            self.session = self._connect_peers(dem, cam, kw)
+            self.peer_halos = self.session is not None
+        if self.session is None:
+            self.res = [self.backend.empty_bytes(nbytes), self.backend.empty_bytes(nbytes)]
+            self.session = self.backend.make_session(dem, self.width, self.height, cam, self.row_begin, self.row_end,
+                                                     self.res, self.stats, kw)
+
+    def _connect_peers(self, dem, cam, kw):
+        """A session that owns its reservoirs, its export gathered over the process group, the neighbours mapped;
+        None (on every rank) unless every rank succeeded."""
+        import torch.distributed as dist
+
+        torch = self.torch
+        session, export, ok = None, b"", 1
+        try:
+            session = self.backend.make_session(dem, self.width, self.height, cam, self.row_begin, self.row_end, None, self.stats, kw)
+            export = session.halo_export()
+        except Exception:  # noqa: BLE001 -- the classic path reports what is wrong with the scene
+            ok = 0
+        dev = self._comm_device()
+        size = 512
+        mine = torch.zeros(size, dtype=torch.uint8)
+        mine[: len(export)] = torch.frombuffer(bytearray(export), dtype=torch.uint8) if export else mine[:0]
+        parts = [torch.empty(size, dtype=torch.uint8, device=dev) for _ in range(self.world)]
+        dist.all_gather(parts, mine.to(dev))
+        if ok:
+            try:
+                n = len(export)
+                if self.rank > 0:
+                    session.halo_connect(0, bytes(parts[self.rank - 1].cpu().numpy()[:n].tobytes()))
+                if self.rank < self.world - 1:
+                    session.halo_connect(1, bytes(parts[self.rank + 1].cpu().numpy()[:n].tobytes()))
+            except Exception:  # noqa: BLE001
+                ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) != 1:
+            if session is not None:
+                session.close()
+            return None
+        dist.barrier()  # nobody starts rendering (and polling counters) before every neighbour is mapped
+        return session
 
     # -- communication device ---------------------------------------------------------
     def _comm_device(self):
@@ -312,6 +360,12 @@ class StripRenderer:
         if self.world == 1:
             self.session.enqueue_frames(first, count, collect_last)
             return
+        if self.peer_halos:
+            # one call: per frame its kernels, the frame counter, the pull of the neighbours' rows -- all on the device.
+            # A rank that fails here simply stops raising its counter; its neighbours' waits give up (halo_timeouts) and
+            # render() makes every rank stop through _agree.
+            self.session.enqueue_batch_strip(first, count, collect_last)
+            return
         # A rank whose session fails keeps posting its halo transfers for the rest of the batch (with whatever its
         # buffers hold): its neighbours are inside matching send / recv pairs and would wait forever otherwise.
         # The failure is raised at the end of the batch; render() then makes every rank stop (_agree).
@@ -364,6 +418,8 @@ class StripRenderer:
             import torch.distributed as dist
 
             self.backend.sync()
+            if self.peer_halos and self.session.halo_timeouts():
+                raise RuntimeError("[Render] Render error: a neighbouring strip stopped raising its frame counter (halo wait timed out)")
             stats = self.stats.to(self._comm_device())
             dist.all_reduce(stats, op=dist.ReduceOp.MAX)
             host = stats.cpu().numpy().astype(np.uint32)
@@ -435,7 +491,7 @@ class StripRenderer:
 
         torch = self.torch
         dev = self._comm_device()
-        on_device = dev == self.res[0].device and dev.type != "cpu" and hasattr(self.session, "resolve_device")
+        on_device = dev == self.stats.device and dev.type != "cpu" and hasattr(self.session, "resolve_device")
         max_rows = max(b1 - b0 for b0, b1 in zip(self.bounds, self.bounds[1:]))
         specs = (("rgba", 4, torch.uint8), ("albedo", 3, torch.float32), ("normal", 3, torch.float32),
                  ("depth", 1, torch.float32))

@@ -127,6 +127,30 @@ class TerrainSession:
         self._check(self._lib.f3d_session_enqueue_frame_part(self._handle, int(frame), int(part),
                                                              1 if collect_stats else 0, self._err, len(self._err)))
 
+    # -- peer halos (strips of one node without the host or a collective in the frame chain) -------------
+    def halo_export(self) -> bytes:
+        """What a neighbouring strip needs to map this strip's reservoirs and its frame counter (f3d_halo_export bytes)."""
+        rec = _native.HaloExport()
+        self._check(self._lib.f3d_session_halo_export(self._handle, C.byref(rec), self._err, len(self._err)))
+        return bytes(rec)
+
+    def halo_connect(self, side: int, export: bytes):
+        """side 0: the strip above (smaller rows), 1: the strip below; export = that strip's halo_export()."""
+        rec = _native.HaloExport.from_buffer_copy(export)
+        self._check(self._lib.f3d_session_halo_connect(self._handle, int(side), C.byref(rec), self._err, len(self._err)))
+
+    def halo_timeouts(self) -> int:
+        """Device-side halo waits that gave up (a neighbour that stopped); synchronises."""
+        n = C.c_uint32(0)
+        self._check(self._lib.f3d_session_halo_status(self._handle, C.byref(n), self._err, len(self._err)))
+        return int(n.value)
+
+    def enqueue_batch_strip(self, first_frame: int, count: int, collect_stats: bool = False):
+        """Frames [first_frame, first_frame + count) of a connected strip in ONE call: per frame its kernels, the frame
+        counter, the pull of both neighbours' edge rows -- no host synchronisation, no collective."""
+        self._check(self._lib.f3d_session_enqueue_batch_strip(self._handle, int(first_frame), int(count), 1 if collect_stats else 0,
+                                                              self._err, len(self._err)))
+
     def window_stats(self):
         """(max Welford m2 over the owned pixels, saw non-finite) -- synchronises the stream."""
         m2, bad = C.c_float(0.0), C.c_int32(0)

@@ -207,6 +207,35 @@ int f3d_session_window_stats(f3d_session *session, float *max_m2, int32_t *nonfi
  * side 0 = the 3 owned rows at the top (to send up), 1 = the 3 owned rows at the
  * bottom (to send down), 2 = halo above the strip (to receive), 3 = halo below. */
 int f3d_session_halo(f3d_session *session, int32_t which, int32_t side, void **ptr, uint64_t *bytes);
+/* ---- peer halos: the strips of one node without the host or a collective in the frame chain --------------------
+ * The classic strip loop (forge3d_amd/distributed.py) posts an RCCL send / recv pair from Python after every frame.
+ * Here a strip PULLS its neighbours' edge rows itself: every session keeps a counter "frames merged" in device memory;
+ * after a frame the library raises it (a one-thread kernel behind the frame's kernels) and launches k_halo_pull, which
+ * waits -- on the device -- until the neighbour's counter says its frame is done, then copies the neighbour's 4 edge
+ * rows (peer memory mapped with hipIpcOpenMemHandle, read over xGMI with cache-bypassing loads) into the strip's own
+ * halo rows.  Only READS cross the link and every strip writes nothing but its own memory, so no cache of another
+ * device can hold a stale line.  f3d_session_enqueue_batch_strip enqueues a whole window of frames that way in one
+ * call; RCCL is left with the per-window all-reduce and the final gather.
+ *   f3d_session_halo_export   what a neighbour needs to map this strip (the session must own its reservoirs: no
+ *                             ext_reservoirs); plain bytes, moved between the ranks by any means (all_gather)
+ *   f3d_session_halo_connect  side 0 = the strip above (smaller rows), 1 = the strip below; peer = its export
+ *   f3d_session_halo_status   device-side wait time-outs so far (a dead neighbour must not hang the GPU: a wait gives
+ *                             up after ~4 s and counts here; the caller turns a non-zero count into an error) */
+typedef struct f3d_halo_export {
+    uint8_t handle[3][64]; /* hipIpcMemHandle_t of reservoir buffer 0, 1 and of the counter block */
+    uint64_t offset[3];    /* byte offset of the object inside the exported allocation */
+    uint64_t address[3];   /* the objects' addresses in the exporting process (what a neighbour of the SAME process uses) */
+    uint32_t rows, width;  /* owned rows of the strip, image width */
+    int32_t device;        /* HIP device ordinal of the exporting process */
+    uint32_t pid;          /* exporting process: a process cannot open its own handles */
+} f3d_halo_export;
+int f3d_session_halo_export(f3d_session *session, f3d_halo_export *out, char *err, size_t errlen);
+int f3d_session_halo_connect(f3d_session *session, int32_t side, const f3d_halo_export *peer, char *err, size_t errlen);
+int f3d_session_halo_status(f3d_session *session, uint32_t *timeouts, char *err, size_t errlen);
+/* Frames [first, first + count) of a connected strip: per frame the frame's kernels (fused, or trace batch + merge with
+ * frames in flight), the counter, the pull of both neighbours' rows.  One call, no host synchronisation. */
+int f3d_session_enqueue_batch_strip(f3d_session *session, uint32_t first_frame, uint32_t count, int32_t collect_stats_on_last,
+                                    char *err, size_t errlen);
 /* Final resolve (last spatial reuse pass, reservoir validity, Reinhard + f16 + u8
  * quantisation, AOV conversion) and copy of the owned rows into host buffers that
  * cover ONLY the strip ((rows, width, C) each).  frames = accumulated frame count. */

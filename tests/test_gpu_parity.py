@@ -489,6 +489,44 @@ def test_strips_reproduce_the_full_image(f3d, in_flight, frames):
         s.close()
 
 
+@pytest.mark.parametrize("in_flight,frames", [(0, 9), (4, 11)])
+def test_peer_halo_strips_reproduce_the_full_image(f3d, in_flight, frames):
+    """Peer halos (f3d_session_halo_export / _connect / _enqueue_batch_strip): three strips, each on its own stream, every
+    frame of every strip enqueued up front in ONE call per strip; the strips find each other's edge rows through their
+    frame counters on the device (here neighbours of one process, linked by address; tests/test_gpu_two_process_strips.py
+    maps them across processes).  The stitched image equals the one-strip image, the middle strip pulls from both sides."""
+    import torch
+
+    from forge3d_amd.session import TerrainSession
+
+    dem = scenes.golden_dem()
+    W, H, spp = 160, 96, 2
+    kw = scenes.fixed_frames(scenes.scene_kwargs(dem), frames, spp=spp)
+    full = f3d.hybrid_render_terrain_reference(dem, W, H, scenes.CAM, **kw)
+    bounds = [(0, 29), (29, 64), (64, 96)]
+    streams = [torch.cuda.Stream() for _ in bounds]
+    sessions = [TerrainSession(dem, W, H, scenes.CAM, row_begin=b, row_end=e, frames_in_flight=in_flight, stream=st.cuda_stream, **kw)
+                for (b, e), st in zip(bounds, streams)]
+    exports = [s.halo_export() for s in sessions]
+    for i, s in enumerate(sessions):
+        if i > 0:
+            s.halo_connect(0, exports[i - 1])
+        if i + 1 < len(sessions):
+            s.halo_connect(1, exports[i + 1])
+    with pytest.raises(ValueError):
+        sessions[0].halo_connect(1, exports[1])  # connected already
+    for s in reversed(sessions):  # (the last strip first: nobody's wait may depend on the order of the enqueues)
+        s.enqueue_batch_strip(0, frames, True)
+    torch.cuda.synchronize()
+    assert all(s.halo_timeouts() == 0 for s in sessions)
+    parts = [s.resolve(frames) for s in sessions]
+    for key in ("rgba", "albedo", "normal", "depth"):
+        stitched = np.concatenate([p[key] for p in parts], axis=0)
+        assert np.array_equal(stitched, full[key], equal_nan=True), key
+    for s in sessions:
+        s.close()
+
+
 @pytest.mark.parametrize("variant,rows", [(0, (0, 0)), (1000000, (0, 0)), (8000000, (16, 61)), (4000000, (7, 12)),
                                           (2000000, (30, 33))])
 def test_frame_in_two_parts_equals_the_whole_frame(f3d, variant, rows):
@@ -749,6 +787,43 @@ def test_gpu_lbvh_degenerate_meshes(f3d, oracle):
             got = _session_render(dem, 80, 64, scenes.CAM, 2, 0, builder, **kw)
             for key in ("rgba", "albedo", "normal", "depth"):
                 assert np.array_equal(got[key], want[key], equal_nan=True), (len(i), builder, key)
+
+
+@pytest.mark.parametrize("variant,spp,quorum,rows", [(0, 8, 16, (0, 0)), (1000000, 3, 1, (0, 0)), (8000000, 5, 64, (13, 61)), (2000000, 2, 32, (0, 0))])
+def test_wavefront_trace_is_bit_identical(f3d, oracle, monkeypatch, variant, spp, quorum, rows):
+    """The wavefront form of a trace batch (F3D_WAVEFRONT=1: k_wf_primary files the occlusion rays in region queues,
+    persistent k_wf_occl waves stream them -- a lane takes the next ray when its own is done -- and zero the blocked
+    terms of the records) against the fused kernel and the oracle: every output and the variance statistic, for every
+    sample-lane form, ragged rounds (spp not a multiple of the lanes), stall quorums 1 .. 64, a strip, and -- with a
+    mesh in the scene -- the fall-back to the plain frames-in-flight trace."""
+    from forge3d_amd.session import TerrainSession
+
+    dem = scenes.golden_dem()
+    frames = 7
+    quad_v = np.array([[-18.0, 22.0, -6.0], [18.0, 22.0, -6.0], [18.0, 40.0, -6.0], [-18.0, 40.0, -6.0]], np.float32)
+    quad_i = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+    for extra in ({}, {"mesh_vertices": quad_v, "mesh_indices": quad_i}):
+        kw = scenes.fixed_frames(scenes.scene_kwargs(dem), frames, spp=spp, **extra)
+        strip = dict(row_begin=rows[0], row_end=rows[1]) if rows[1] else {}
+        outs = []
+        for wavefront in ("0", "1"):
+            monkeypatch.setenv("F3D_WAVEFRONT", wavefront)
+            monkeypatch.setenv("F3D_WF_QUORUM", str(quorum))
+            monkeypatch.setenv("F3D_WF_FRAMES", "3")
+            with TerrainSession(dem, 110, 77, scenes.CAM, kernel_variant=variant, memory_budget_bytes=4 << 30, **strip, **kw) as s:
+                assert s.frames_in_flight() == (3 if wavefront == "1" and not extra else 0)
+                s.enqueue_frames(0, frames, True)
+                m2, bad = s.window_stats()
+                outs.append((s.resolve(frames), m2, bad))
+        (a, m2a, bada), (b, m2b, badb) = outs
+        assert not bada and not badb and np.float32(m2a) == np.float32(m2b)
+        for key in ("rgba", "albedo", "normal", "depth"):
+            assert np.array_equal(a[key], b[key], equal_nan=True), (variant, key)
+        if not rows[1]:
+            want = oracle.render(dem, 110, 77, scenes.CAM, **kw)
+            for key in ("rgba", "albedo", "normal", "depth"):
+                assert np.array_equal(b[key], want[key], equal_nan=True), (variant, key)
+
 
 
 @pytest.mark.parametrize("variant,spp,fd,rows", [(0, 8, 5, (0, 0)), (1000000, 3, 2, (0, 0)), (2000000, 5, 7, (0, 0)), (8000000, 8, 3, (13, 58)),

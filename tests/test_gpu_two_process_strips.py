@@ -19,7 +19,7 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def _worker(rank, world, port, out_path, in_flight=0):
+def _worker(rank, world, port, out_path, in_flight=0, peer_halos=True):
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -34,12 +34,13 @@ def _worker(rank, world, port, out_path, in_flight=0):
     init_process_group(world, rank, backend="gloo")
     dem = scenes.golden_dem()
     kw = scenes.fixed_frames(scenes.scene_kwargs(dem), 34, spp=4)  # crosses a Welford window
-    r = StripRenderer(dem, 256, 200, scenes.CAM, rank=rank, world=world, device=0, frames_in_flight=in_flight, **kw)
+    r = StripRenderer(dem, 256, 200, scenes.CAM, rank=rank, world=world, device=0, frames_in_flight=in_flight, peer_halos=peer_halos, **kw)
     r.run_frames(0, 34, collect_last=True)
     var = r.window_variance(34)
     image = r.gather_image(34)
     info = {"bounds": r.bounds, "balance_rounds": len(r.balance_log), "lanes": r.session.sample_lanes(),
-            "in_flight": r.session.frames_in_flight()}
+            "in_flight": r.session.frames_in_flight(), "peer_halos": r.peer_halos,
+            "halo_timeouts": r.session.halo_timeouts() if r.peer_halos else 0}
     r.close()
     if rank == 0:
         image["variance"] = var
@@ -51,8 +52,11 @@ def _worker(rank, world, port, out_path, in_flight=0):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("in_flight", [0, 6])
-def test_two_processes_on_one_gpu_reproduce_the_single_process_image(in_flight):
+@pytest.mark.parametrize("in_flight,peer_halos", [(0, False), (6, False), (0, True), (6, True)])
+def test_two_processes_on_one_gpu_reproduce_the_single_process_image(in_flight, peer_halos):
+    """peer_halos: the strips pull each other's edge rows on the device (reservoirs mapped with hipIpcOpenMemHandle, frame
+    counters polled by k_halo_pull) and a window of frames is one call into the library; else the classic exchange
+    (point-to-point after every frame, staged through the host here)."""
     import torch.multiprocessing as mp
 
     sys.path.insert(0, str(ROOT / "tests"))
@@ -64,7 +68,7 @@ def test_two_processes_on_one_gpu_reproduce_the_single_process_image(in_flight):
     port = s.getsockname()[1]
     s.close()
     out = tempfile.mktemp(suffix=".pkl")
-    mp.spawn(_worker, args=(2, port, out, in_flight), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, out, in_flight, peer_halos), nprocs=2, join=True)
     with open(out, "rb") as f:
         multi = pickle.load(f)
     os.unlink(out)
@@ -75,6 +79,7 @@ def test_two_processes_on_one_gpu_reproduce_the_single_process_image(in_flight):
         m2, bad = sess.window_stats()
         single = sess.resolve(34)
     assert not bad
+    assert multi["info"]["peer_halos"] == peer_halos and multi["info"]["halo_timeouts"] == 0
     assert multi["info"]["in_flight"] == in_flight  # 6: batches traced in one launch, halos exchanged between the merges
     assert multi["info"]["balance_rounds"] >= 2 and multi["info"]["bounds"][0] == 0 and multi["info"]["bounds"][-1] == 200
     assert np.float32(multi["variance"]) == np.float32(max(0.0, m2) / np.float32(1.0))  # frame 34: window of 2
