@@ -1,0 +1,107 @@
+// forge3d_amd/csrc/f3d_lds.h -- the per-wave LDS context of the terrain march on the device (gfx950 only).
+// Shared by the terrain path tracer's kernels (f3d_kernels.hip) and the PBR path tracer's terrain primitive
+// (f3d_wavefront.hip): leaf FIFO columns, park rows, the verdict board of the ray sharing and the level table.
+#pragma once
+
+#include "f3d_march.h"
+
+namespace f3d {
+
+constexpr int kWave = 64;
+
+// Per-wave LDS scratch of the traversal: a copy of the per-level layout tables, so that a lane
+// can look its (per-lane) level up with one ds_read_b64 instead of a vector load from the kernarg
+// segment, and -- only for the sorted descent kept for the test hook / A-B builds -- the
+// pending-sibling words as a [level][lane] column (bank = lane, conflict-free).
+// Rows kParkRow.. of the column hold the sample-lane frame's accumulators between rounds.
+constexpr int kParkRow = 3 * kLeafFifoRows, kParkWords = 7;
+constexpr int kBoardRow = kParkRow + kParkWords;  // verdict board of the ray sharing (f3d_march.h): one word per lane
+constexpr int kLdsRows = kBoardRow + 1 > kMaxLevels ? kBoardRow + 1 : kMaxLevels;
+constexpr int kLdsWords = kLdsRows * kWave + 4 * kMaxLevels;
+struct LdsPending {
+    uint32_t *col;          // lds + lane
+    const uint32_t *table;  // lds + kLdsRows * kWave: {band_offset, band_shift, node_offset, tiles_x} per level
+    uint32_t leaf_quorum, share_below;
+    __device__ __forceinline__ void put(uint32_t level, uint32_t word) { col[level * kWave] = word; }
+    __device__ __forceinline__ uint32_t get(uint32_t level) const { return col[level * kWave]; }
+    __device__ __forceinline__ void note(int) const {}  // step-statistics hook (host emulator only)
+    __device__ __forceinline__ void feature(float) const {}
+    __device__ __forceinline__ void hint(float) const {}
+    // (leaf-gate A/B build only) may the lanes that hold a fat leaf solve it now?
+    __device__ __forceinline__ bool leaf_gate(bool at_leaf) const {
+        const unsigned long long leaf = __ballot(at_leaf), inner = __ballot(!at_leaf);
+        return (uint32_t)__popcll(leaf) >= leaf_quorum || inner == 0ull;
+    }
+    // ---- deferred leaf FIFO of the march (f3d_march.h): 3 words per entry in the lane's column ----
+    __device__ __forceinline__ void fifo_put(uint32_t k, uint32_t cell, float lo, float hi) {
+        col[(3u * k) * kWave] = cell;
+        col[(3u * k + 1u) * kWave] = f_bits(lo);
+        col[(3u * k + 2u) * kWave] = f_bits(hi);
+    }
+    __device__ __forceinline__ void fifo_retag(uint32_t k, uint32_t cell) { col[(3u * k) * kWave] = cell; }
+    __device__ __forceinline__ void fifo_get(uint32_t k, uint32_t &cell, float &lo, float &hi) const {
+        cell = col[(3u * k) * kWave];
+        lo = f_from_bits(col[(3u * k + 1u) * kWave]);
+        hi = f_from_bits(col[(3u * k + 2u) * kWave]);
+    }
+    // drain now?  enough lanes have a leaf queued, or a FIFO is full, or nobody marches any more
+    __device__ __forceinline__ bool flush_now(uint32_t queued, bool marching) const {
+        const unsigned long long have = __ballot(queued != 0u);
+        if (have == 0ull) return false;
+        return (uint32_t)__popcll(have) >= leaf_quorum || __ballot(queued >= kLeafFifo) != 0ull ||
+               __ballot(marching) == 0ull;
+    }
+    __device__ __forceinline__ bool any(bool pred) const { return __ballot(pred) != 0ull; }
+    // ---- ray sharing (f3d_march.h march_shared) ----
+    __device__ __forceinline__ uint32_t lane() const { return threadIdx.x & (kWave - 1u); }
+    __device__ __forceinline__ bool share_now(bool marching) const { return share_now(marching, share_below); }
+    __device__ __forceinline__ bool share_now(bool marching, uint32_t below) const {
+        const uint32_t n = (uint32_t)__popcll(__ballot(marching));
+        return n != 0u && n <= below && (uint32_t)__popcll(__ballot(true)) >= kShareAvail * n;
+    }
+    // the verdict board lives in row kBoardRow of the WAVE's columns: board[l] = col[l - lane]
+    // (volatile: lanes talk to each other through it without a barrier -- one wave, LDS operations in order)
+    __device__ __forceinline__ volatile uint32_t *board() const { return col - lane() + kBoardRow * kWave; }
+    __device__ __forceinline__ void verdict_post(bool hit) const { board()[lane()] = hit ? 1u : 0u; }
+    __device__ __forceinline__ void verdict_set(uint32_t owner) const { board()[owner & (kWave - 1u)] = 1u; }
+    __device__ __forceinline__ bool verdict_get(uint32_t owner) const { return board()[owner & (kWave - 1u)] != 0u; }
+    // wave primitives of march_deal (f3d_march.h)
+    __device__ __forceinline__ unsigned long long ballot(bool pred) const { return __ballot(pred); }
+    __device__ __forceinline__ float shfl(float v, int src) const { return __shfl(v, src, kWave); }
+    __device__ __forceinline__ uint32_t shfl(uint32_t v, int src) const { return (uint32_t)__shfl((int)v, src, kWave); }
+    __device__ __forceinline__ float fast_log2(float x) const { return __builtin_amdgcn_logf(x); }
+    __device__ __forceinline__ float fast_exp2(float x) const { return __builtin_amdgcn_exp2f(x); }
+    template <bool CURVED>
+    __device__ __forceinline__ void deal(const TerrainDev &T, MarchSlice &s, MarchState &m) const {
+        march_deal<CURVED>(T, s, m, *this);
+    }
+    __device__ __forceinline__ void band_entry(const TerrainDev &, uint32_t level, uint32_t &offset,
+                                               uint32_t &shift) const {
+        const uint2 e = *reinterpret_cast<const uint2 *>(table + 4u * level);
+        offset = e.x;
+        shift = e.y;
+    }
+    __device__ __forceinline__ void level_entry(const TerrainDev &, uint32_t level, uint32_t &offset,
+                                                uint32_t &tiles_x) const {
+        const uint2 e = *reinterpret_cast<const uint2 *>(table + 4u * level + 2u);
+        offset = e.x;
+        tiles_x = e.y;
+    }
+};
+// rows: lane-column rows in front of the level table (the occlusion-stream kernels need the leaf FIFO only)
+__device__ __forceinline__ LdsPending make_pending(uint32_t *lds, const TerrainDev &T, uint32_t rows = kLdsRows) {
+    const uint32_t lane = threadIdx.x & (kWave - 1u);  // `lds` is this WAVE's block (workgroups may hold several)
+    if (lane < kMaxLevels) {
+        uint32_t *e = lds + rows * kWave + 4 * lane;
+        e[0] = T.band_offset[lane];
+        e[1] = T.band_shift[lane];
+        e[2] = T.node_offset[lane];
+        e[3] = T.tiles_x[lane];
+    }
+    __syncthreads();
+    return LdsPending{lds + lane, lds + rows * kWave, T.leaf_quorum ? T.leaf_quorum : kDefaultLeafQuorum,
+                      T.share_below ? (T.share_below < 64u ? T.share_below : 64u) : kShareBelow};
+}
+
+
+}  // namespace f3d
