@@ -24,6 +24,7 @@
 #include "f3d_launch.h"
 #include "f3d_lbvh.h"
 #include "f3d_setup.h"
+#include "f3d_tables.h"
 
 using namespace f3d;
 
@@ -277,6 +278,24 @@ std::shared_ptr<CachedTables> acquire_tables(int device, const float *heights, u
 }
 
 }  // namespace
+
+namespace f3d {
+SharedTerrain acquire_shared_terrain(const float *heights, uint32_t w, uint32_t h, float exaggeration, hipStream_t stream) {
+    int device = 0;
+    hip_check(hipGetDevice(&device), "hipGetDevice");
+    bool was_cached = false;
+    std::shared_ptr<CachedTables> e = acquire_tables(device, heights, w, h, exaggeration, stream, &was_cached);
+    SharedTerrain out;
+    out.dev = TerrainDev{};
+    apply_layout(e->tables.layout, out.dev);
+    out.dev.leaves = e->tables.leaves;
+    out.dev.nodes = e->tables.nodes;
+    out.dev.bands = e->tables.bands;
+    out.bytes = e->mem.device_bytes;
+    out.keep = e;
+    return out;
+}
+}  // namespace f3d
 
 // ---------------------------------------------------------------------------------------
 // session

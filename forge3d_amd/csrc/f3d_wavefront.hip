@@ -17,6 +17,8 @@
 
 #include "../../include/f3d_wavefront.h"
 #include "f3d_devmem.h"
+#include "f3d_lds.h"
+#include "f3d_tables.h"
 #include "f3d_wf_host.h"
 
 using namespace f3d;
@@ -38,7 +40,12 @@ struct WfParams {
 #ifndef F3D_WF_WAVES
 #define F3D_WF_WAVES 4
 #endif
+template <bool TERRAIN>  // scenes with the heightfield primitive (f3d_wf_path.h) run their own instantiation
 __global__ __launch_bounds__(64, F3D_WF_WAVES) void k_wf_paths(const WfParams P) {
+    // traversal context of the terrain march (f3d_lds.h)
+    __shared__ __attribute__((aligned(16))) uint32_t lds[TERRAIN ? kLdsWords : 1];
+    LdsPending pend{};
+    if (TERRAIN) pend = make_pending(lds, P.S.terrain);
     const uint32_t tiles_x = (P.S.width + 7u) / 8u, tiles = tiles_x * ((P.S.height + 7u) / 8u);
     const uint32_t tile = blockIdx.x % tiles, group = blockIdx.x / tiles;
     const uint32_t x = (tile % tiles_x) * 8u + (threadIdx.x & 7u), y = (tile / tiles_x) * 8u + (threadIdx.x >> 3);
@@ -49,7 +56,7 @@ __global__ __launch_bounds__(64, F3D_WF_WAVES) void k_wf_paths(const WfParams P)
         const uint32_t n = P.count - begin < P.frames_per_lane ? P.count - begin : P.frames_per_lane;
         float4 *out = P.totals + (size_t)begin * pixels + pixel;
         const uint32_t first = P.first + begin;
-        vertices = wf::trace_frames(P.S, pixel, first, n, wf::HipWave{}, [&](uint32_t frame, V3 total) {
+        vertices = wf::trace_frames(P.S, pixel, first, n, wf::HipWave<LdsPending, TERRAIN>{&pend}, [&](uint32_t frame, V3 total) {
             out[(size_t)(frame - first) * pixels] = float4{total.x, total.y, total.z, 0.0f};
         });
     }
@@ -188,6 +195,19 @@ extern "C" int f3d_wavefront_render(const f3d_wf_scene *scene, uint32_t width, u
         S.inst = (const wf::InstanceDev *)upload(prep.inst.data(), prep.inst.size() * sizeof(wf::InstanceDev), "instances");
         S.dir = (const wf::DirLightDev *)upload(prep.dir.data(), prep.dir.size() * sizeof(wf::DirLightDev), "directional lights");
         S.area = (const wf::AreaLightDev *)upload(prep.area.data(), prep.area.size() * sizeof(wf::AreaLightDev), "area lights");
+        SharedTerrain terrain;  // the heightfield primitive: the terrain tracer's tables (scene cache), its placement from prepare_scene
+        if (scene->terrain) {
+            terrain = acquire_shared_terrain(scene->terrain->heights, scene->terrain->dem_width, scene->terrain->dem_height,
+                                             scene->terrain->exaggeration, nullptr);
+            const TerrainDev placed = S.terrain;
+            S.terrain = terrain.dev;
+            S.terrain.origin_x = placed.origin_x;
+            S.terrain.origin_z = placed.origin_z;
+            S.terrain.spacing_x = placed.spacing_x;
+            S.terrain.spacing_z = placed.spacing_z;
+            S.terrain.inv_spacing_x = placed.inv_spacing_x;
+            S.terrain.inv_spacing_z = placed.inv_spacing_z;
+        }
 
         const size_t pixels = (size_t)width * height;
         float4 *d_accum = (float4 *)alloc(pixels * sizeof(float4), "accumulation");
@@ -218,7 +238,8 @@ extern "C" int f3d_wavefront_render(const f3d_wf_scene *scene, uint32_t width, u
             P.first = first_frame + done;
             P.count = std::min(round_frames, frame_count - done);
             const uint32_t groups = (P.count + fpl - 1u) / fpl;
-            hipLaunchKernelGGL(k_wf_paths, dim3(tiles * groups), dim3(64), 0, nullptr, P);
+            if (S.has_terrain) hipLaunchKernelGGL(k_wf_paths<true>, dim3(tiles * groups), dim3(64), 0, nullptr, P);
+            else hipLaunchKernelGGL(k_wf_paths<false>, dim3(tiles * groups), dim3(64), 0, nullptr, P);
             ok(hipGetLastError(), "path tracing kernel");
             const FoldParams F{P.totals, d_accum, (uint32_t)pixels, P.count};
             hipLaunchKernelGGL(k_wf_fold, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, nullptr, F);

@@ -23,6 +23,9 @@ inline bool finite_n(const float *v, int n) {
 }
 
 inline void validate_scene(const f3d_wf_scene &s, uint32_t width, uint32_t height, uint32_t frame_count) {
+    if (s.struct_size != sizeof(f3d_wf_scene))
+        fail(F3D_STATUS_VALUE, "f3d_wf_scene.struct_size is %u, this library expects %zu: the caller was built against another revision of f3d_wavefront.h",
+             s.struct_size, sizeof(f3d_wf_scene));
     if (width == 0u || height == 0u || frame_count == 0u)  // adjudication.rs:85-89
         fail(F3D_STATUS_RENDER, "adjudication PT reference requires non-zero width/height/spp");
     if ((uint64_t)width * height > (1ull << 31)) fail(F3D_STATUS_VALUE, "image too large");
@@ -62,6 +65,16 @@ inline void validate_scene(const f3d_wf_scene &s, uint32_t width, uint32_t heigh
         fail(F3D_STATUS_VALUE, "camera vectors must be finite");
     if (!(std::isfinite(s.cam_fov_y) && s.cam_fov_y > 0.0f && s.cam_fov_y < 3.14159265f)) fail(F3D_STATUS_VALUE, "cam_fov_y must be in (0, pi) radians");
     if (!(std::isfinite(s.cam_exposure) && s.cam_exposure >= 0.0f)) fail(F3D_STATUS_VALUE, "cam_exposure must be finite and >= 0");
+    if (s.terrain) {  // the heightfield primitive: the terrain tracer's own input rules (render_terrain.rs:474-557)
+        const f3d_wf_terrain &t = *s.terrain;
+        if (!t.heights || t.dem_width < 2u || t.dem_height < 2u) fail(F3D_STATUS_UPLOAD, "terrain heightfield must be at least 2x2 texels, got %ux%u", t.dem_width, t.dem_height);
+        if (t.dem_width > 8193u || t.dem_height > 8193u) fail(F3D_STATUS_UPLOAD, "terrain heightfield is limited to 8193 texels a side, got %ux%u", t.dem_width, t.dem_height);
+        if (!(std::isfinite(t.spacing_x) && t.spacing_x > 0.0f && std::isfinite(t.spacing_z) && t.spacing_z > 0.0f))
+            fail(F3D_STATUS_RENDER, "terrain spacing must be finite and positive");
+        if (!(std::isfinite(t.exaggeration) && t.exaggeration > 0.0f)) fail(F3D_STATUS_RENDER, "terrain exaggeration must be finite and positive");
+        for (size_t i = 0; i < (size_t)t.dem_width * t.dem_height; i++)
+            if (!std::isfinite(t.heights[i])) fail(F3D_STATUS_UPLOAD, "terrain heightfield contains non-finite samples");
+    }
 }
 
 inline V3 v3p(const float *p) { return V3{p[0], p[1], p[2]}; }
@@ -145,6 +158,20 @@ inline PreparedScene prepare_scene(const f3d_wf_scene &s, uint32_t width, uint32
     S.height = height;
     S.seed_hi = s.seed_hi;
     S.seed_lo = s.seed_lo;
+    S.has_terrain = 0u;
+    if (s.terrain) {  // placement and scalars as fill_uniforms (f3d_setup.h); tables are the caller's to attach
+        const f3d_wf_terrain &t = *s.terrain;
+        S.has_terrain = 1u;
+        S.terrain_mat = t.material_id < s.sphere_count - 1u ? t.material_id : s.sphere_count - 1u;
+        S.terrain.origin_x = -0.5f * ((float)t.dem_width - 1.0f) * t.spacing_x;
+        S.terrain.origin_z = -0.5f * ((float)t.dem_height - 1.0f) * t.spacing_z;
+        S.terrain.spacing_x = t.spacing_x;
+        S.terrain.spacing_z = t.spacing_z;
+        S.terrain.inv_spacing_x = 1.0f / t.spacing_x;
+        S.terrain.inv_spacing_z = 1.0f / t.spacing_z;
+        S.terrain.inv_two_r_prime = 0.0f;
+        S.terrain.curvature_enabled = 0u;
+    }
     return out;
 }
 

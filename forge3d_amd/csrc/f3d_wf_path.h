@@ -18,10 +18,18 @@
 // with the reference's two triangle tests: watertight for closest hits (pt_intersect.wgsl:113-178), Moller-Trumbore
 // for shadow rays (pt_shadow.wgsl:205-236); equal-t hits resolve to the lowest triangle index (the oracle's sweep).
 //
+// Terrain primitive (NOT in the reference: its wavefront tracer traces spheres and instanced meshes only,
+// pt_intersect.wgsl:431-558, and its terrain tracer shades one bounce; BASELINE.json configs[2] asks for both, "GI" over
+// a DEM): an optional heightfield whose closest / any hit is the terrain tracer's `terrain_trace`
+// (hybrid_terrain_traversal.wgsl:254-372) -- here the stackless min-max march of f3d_march.h on the same tables, with the
+// same results -- entered into closest() after spheres and meshes with the closest t so far as its tmax, and into
+// shadowed() as one more any-hit test.  The hit carries the bilinear patch's normal and the scene's terrain material slot.
+//
 // Not here (off / empty in render_pt_reference): ReSTIR guiding, fog medium, hair segments.
 // Numerics: f3d_math.h contract (no contraction; dot = fma chain; fixed-polynomial sincos/atan/exp/log).
 #pragma once
 
+#include "f3d_march.h"
 #include "f3d_math.h"
 #include "f3d_scene.h"
 
@@ -79,6 +87,9 @@ struct SceneDev {
     V3 cam_origin, cam_right, cam_up, cam_neg_forward;
     float half_w, half_h;
     uint32_t width, height, seed_hi, seed_lo;
+    // optional heightfield primitive (see the header): tables as the terrain tracer builds them, material slot of its hits
+    TerrainDev terrain;
+    uint32_t has_terrain, terrain_mat;
 };
 
 constexpr float kTwoPiInv = 0.15915494309189533577f;
@@ -315,8 +326,9 @@ struct SurfaceHitWf {
     uint32_t mat;
 };
 
-// pt_intersect.wgsl main, :431-558
-F3D_HD bool closest(const SceneDev &S, V3 o, V3 d, float tmin, SurfaceHitWf &H) {
+// pt_intersect.wgsl main, :431-558 (+ the terrain primitive)
+template <class Wave>
+F3D_HD bool closest(const SceneDev &S, V3 o, V3 d, float tmin, SurfaceHitWf &H, Wave &wave) {
     const float tmax = 1e30f;
     float t_best = 1e30f;
     V3 n = V3{0.0f, 1.0f, 0.0f};
@@ -362,6 +374,15 @@ F3D_HD bool closest(const SceneDev &S, V3 o, V3 d, float tmin, SurfaceHitWf &H) 
             }
         }
     }
+    if (Wave::kTerrain && S.has_terrain != 0u) {  // terrain_trace(ray with tmax = the closest hit so far), curvature off
+        const RayCtx r = make_ray(S.terrain, o, tmin, d, t_best, false);
+        const TraceHit th = march_terrain<false>(S.terrain, r, false, true, *wave.pend);
+        if (th.hit && th.t < t_best) {
+            t_best = th.t;
+            n = th.n;
+            mat = S.terrain_mat;
+        }
+    }
     if (!(t_best < 1e20f)) return false;
     H.p = o + d * t_best;
     H.t = t_best;
@@ -370,8 +391,13 @@ F3D_HD bool closest(const SceneDev &S, V3 o, V3 d, float tmin, SurfaceHitWf &H) 
     return true;
 }
 
-// pt_shadow.wgsl main, :248-294
-F3D_HD bool shadowed(const SceneDev &S, V3 ro, V3 rd, float tmin, float tmax) {
+// pt_shadow.wgsl main, :248-294 (+ the terrain primitive)
+template <class Wave>
+F3D_HD bool shadowed(const SceneDev &S, V3 ro, V3 rd, float tmin, float tmax, Wave &wave) {
+    if (Wave::kTerrain && S.has_terrain != 0u) {  // any hit of the heightfield in (tmin, tmax)
+        const RayCtx r = make_ray(S.terrain, ro, tmin, rd, tmax, false);
+        if (march_terrain<false>(S.terrain, r, true, true, *wave.pend).hit) return true;
+    }
     for (uint32_t i = 0u; i < S.sphere_count; i++) {
         const SphereDev s = S.spheres[i];
         const V3 oc = ro - s.c;
@@ -501,8 +527,9 @@ F3D_HD uint32_t pick(uint32_t count, float sum_imp, uint32_t &rng, Imp imp) {
 
 // One surface vertex: emission, NEE (environment / directional / area) with its shadow rays, continuation sample,
 // roulette (pt_shade.wgsl main :460-862 + pt_shadow.wgsl main).  Returns true when the path continues in P.
+template <class Wave>
 F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, uint32_t seed_lo, const SurfaceHitWf &H, PathState &P,
-                           V3 &acc) {
+                           V3 &acc, Wave &wave) {
     (void)seed_lo;
     const MaterialDev md = S.mats[H.mat];
     MatCtx M;
@@ -544,7 +571,7 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
             const float w_mis = pdf_light / f_max(pdf_light + br.pdf, 1e-8f);
             const float k = (((cos_surf / f_max(pdf_light, 1e-8f)) * w_mis) * M.imp) * 1.0f;
             const V3 contrib = ((P.thr * br.f) * L_env) * k;
-            if (!shadowed(S, so, wi, 1e-3f, 1e30f)) acc = acc + contrib;
+            if (!shadowed(S, so, wi, 1e-3f, 1e30f, wave)) acc = acc + contrib;
         }
     }
     if (S.dir_count > 0u) {  // delta lights: weight 1
@@ -556,7 +583,7 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
             const float p_sel = S.dir_sum_imp > 0.0f ? L.importance / f_max(S.dir_sum_imp, 1e-8f) : 1.0f / (float)S.dir_count;
             const float k = ((cos_surf / f_max(p_sel, 1e-8f)) * M.imp) * 1.0f;
             const V3 contrib = ((P.thr * br.f) * L.Li) * k;
-            if (!shadowed(S, so, L.wi, 1e-3f, 1e30f)) acc = acc + contrib;
+            if (!shadowed(S, so, L.wi, 1e-3f, 1e30f, wave)) acc = acc + contrib;
         }
     }
     if (S.area_count > 0u) {  // discs, sampled uniformly by area, balance heuristic
@@ -581,7 +608,7 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
                     const float w_mis = pdf_light / f_max(pdf_light + br.pdf, 1e-8f);
                     const float k = (((cos_surf / f_max(pdf_light, 1e-8f)) * w_mis) * M.imp) * 1.0f;
                     const V3 contrib = ((P.thr * br.f) * L.Li) * k;
-                    if (!shadowed(S, so, wi, 1e-3f, dist - 1e-3f)) acc = acc + contrib;
+                    if (!shadowed(S, so, wi, 1e-3f, dist - 1e-3f, wave)) acc = acc + contrib;
                 }
             }
         }
@@ -661,12 +688,20 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
     return true;
 }
 
-// How many lanes of the wave could use another closest-hit attempt (the host "wave" is one lane wide).
+// How many lanes of the wave could use another closest-hit attempt (the host "wave" is one lane wide), and the
+// traversal context of the terrain primitive (f3d_march.h Ctx: the device's LDS block, the emulator's arrays).
+// kTerrain: the kernel was compiled with the heightfield primitive (scenes without one run a build without it).
+template <class Pend>
 struct SoloWave {
+    static constexpr bool kTerrain = true;
+    Pend *pend;
     F3D_HD uint32_t count(bool flag) const { return flag ? 64u : 0u; }
 };
 #if defined(__HIPCC__)
+template <class Pend, bool TERRAIN>
 struct HipWave {
+    static constexpr bool kTerrain = TERRAIN;
+    Pend *pend;
     __device__ uint32_t count(bool flag) const { return (uint32_t)__popcll(__ballot(flag)); }
 };
 #endif
@@ -710,7 +745,7 @@ F3D_HD uint32_t trace_frames(const SceneDev &S, uint32_t pixel, uint32_t first, 
                     fresh = false;
                 }
                 vertices++;
-                if (closest(S, P.o, P.d, P.tmin, H)) {
+                if (closest(S, P.o, P.d, P.tmin, H, wave)) {
                     pending = true;
                 } else {  // pt_scatter.wgsl:113-131
                     total = total + P.thr * mix3(S.miss_ground, S.miss_sky, 0.5f * (P.d.y + 1.0f));
@@ -728,7 +763,7 @@ F3D_HD uint32_t trace_frames(const SceneDev &S, uint32_t pixel, uint32_t first, 
         }
         if (pending) {  // expensive phase
             pending = false;
-            if (!surface_vertex(S, pixel, frame, seed_lo, H, P, total)) {
+            if (!surface_vertex(S, pixel, frame, seed_lo, H, P, total, wave)) {
                 sink(frame, total);
                 total = V3{0.0f, 0.0f, 0.0f};
                 frame++;

@@ -78,7 +78,19 @@ class Instance:
 
 
 @dataclass
+class Terrain:
+    """Heightfield primitive of the PBR tracer (f3d_wf_terrain): the DEM of hybrid_render_terrain_reference -- same
+    placement (centred on the world origin, y up, row = +z) -- with the material of slot `material_id`.  Not in the
+    reference's wavefront tracer; BASELINE.json configs[2] ("atmosphere + GI" over a DEM) needs it."""
+    heights: Any = None
+    spacing: Sequence[float] = (1.0, 1.0)
+    exaggeration: float = 1.0
+    material_id: int = 0
+
+
+@dataclass
 class WavefrontScene:
+    terrain: Optional[Terrain] = None
     spheres: List[Sphere] = field(default_factory=list)
     meshes: List[Tuple[np.ndarray, np.ndarray]] = field(default_factory=list)
     instances: List[Instance] = field(default_factory=list)
@@ -126,6 +138,9 @@ class WavefrontScene:
             "cam_up": tuple(float(x) for x in up), "cam_forward": tuple(float(x) for x in forward),
             "cam_fov_y": float(np.float32(np.deg2rad(np.float32(self.fov_y_deg)))), "cam_exposure": float(self.exposure),
             "seed_hi": int(self.seed_hi) & 0xFFFFFFFF, "seed_lo": int(self.seed_lo) & 0xFFFFFFFF,
+            "terrain": None if self.terrain is None else {
+                "heights": np.ascontiguousarray(self.terrain.heights, np.float32), "spacing": tuple(float(v) for v in self.terrain.spacing),
+                "exaggeration": float(self.terrain.exaggeration), "material_id": int(self.terrain.material_id)},
         }
 
 
@@ -222,8 +237,14 @@ class _Mesh(C.Structure):
     _fields_ = [("vertices", C.c_void_p), ("vertex_count", C.c_uint32), ("indices", C.c_void_p), ("triangle_count", C.c_uint32)]
 
 
+class _Terrain(C.Structure):
+    _fields_ = [("heights", C.c_void_p), ("dem_width", C.c_uint32), ("dem_height", C.c_uint32), ("spacing_x", C.c_float),
+                ("spacing_z", C.c_float), ("exaggeration", C.c_float), ("material_id", C.c_uint32)]
+
+
 class _Scene(C.Structure):
-    _fields_ = [("spheres", C.POINTER(_Sphere)), ("sphere_count", C.c_uint32),
+    _fields_ = [("struct_size", C.c_uint32),
+                ("spheres", C.POINTER(_Sphere)), ("sphere_count", C.c_uint32),
                 ("meshes", C.POINTER(_Mesh)), ("mesh_count", C.c_uint32),
                 ("instances", C.POINTER(_Instance)), ("instance_count", C.c_uint32),
                 ("dir_lights", C.POINTER(_DirLight)), ("dir_light_count", C.c_uint32),
@@ -231,7 +252,8 @@ class _Scene(C.Structure):
                 ("object_importance", C.POINTER(C.c_float)), ("importance_count", C.c_uint32),
                 ("env_ground", C.c_float * 4), ("env_sky", C.c_float * 4), ("miss_ground", C.c_float * 4), ("miss_sky", C.c_float * 4),
                 ("cam_origin", C.c_float * 3), ("cam_right", C.c_float * 3), ("cam_up", C.c_float * 3), ("cam_forward", C.c_float * 3),
-                ("cam_fov_y", C.c_float), ("cam_exposure", C.c_float), ("seed_hi", C.c_uint32), ("seed_lo", C.c_uint32)]
+                ("cam_fov_y", C.c_float), ("cam_exposure", C.c_float), ("seed_hi", C.c_uint32), ("seed_lo", C.c_uint32),
+                ("terrain", C.POINTER(_Terrain))]
 
 
 class _Out(C.Structure):
@@ -248,6 +270,7 @@ def _set_vec(dst, values):
 def _marshal(scene: Dict[str, Any]):
     keep: list = []
     s = _Scene()
+    s.struct_size = C.sizeof(_Scene)
 
     def array(cls, items, vectors):
         arr = (cls * max(1, len(items)))()
@@ -280,6 +303,15 @@ def _marshal(scene: Dict[str, Any]):
         _set_vec(getattr(s, name), scene[name])
     s.cam_fov_y, s.cam_exposure = float(scene["cam_fov_y"]), float(scene["cam_exposure"])
     s.seed_hi, s.seed_lo = int(scene["seed_hi"]) & 0xFFFFFFFF, int(scene["seed_lo"]) & 0xFFFFFFFF
+    if scene.get("terrain") is not None:
+        t = scene["terrain"]
+        dem = np.ascontiguousarray(t["heights"], np.float32)
+        if dem.ndim != 2:
+            raise TypeError("terrain heights must be a 2-D float32 array")
+        rec = _Terrain(dem.ctypes.data, dem.shape[1], dem.shape[0], float(t["spacing"][0]), float(t["spacing"][1]),
+                       float(t["exaggeration"]), int(t["material_id"]))
+        keep += [dem, rec]
+        s.terrain = C.pointer(rec)
     return s, keep
 
 

@@ -46,7 +46,19 @@ typedef struct f3d_wf_mesh { /* one BLAS */
     uint32_t triangle_count;
 } f3d_wf_mesh;
 
+/* Optional heightfield primitive: the terrain of f3d_terrain_ref_desc (same placement: centred on the world origin, y up,
+ * DEM row = +z, heights * exaggeration) as one more object of the PBR tracer's scene.  NOT in the reference's wavefront
+ * tracer (spheres + instanced meshes only, pt_intersect.wgsl:431-558); BASELINE.json configs[2] ("atmosphere + GI" over a
+ * DEM) needs it.  Closest / any hits are those of terrain_trace (hybrid_terrain_traversal.wgsl:254-372), curvature off. */
+typedef struct f3d_wf_terrain {
+    const float *heights; /* (dem_height, dem_width) row-major f32 */
+    uint32_t dem_width, dem_height;
+    float spacing_x, spacing_z, exaggeration;
+    uint32_t material_id; /* slot of the sphere / material table; clamped to sphere_count - 1 like instance materials */
+} f3d_wf_terrain;
+
 typedef struct f3d_wf_scene {
+    uint32_t struct_size; /* = sizeof(f3d_wf_scene) of the caller's header (F3D_ABI_VERSION, f3d_terrain_pt.h) */
     const f3d_wf_sphere *spheres;
     uint32_t sphere_count; /* >= 1: the material table */
     const f3d_wf_mesh *meshes;
@@ -65,6 +77,7 @@ typedef struct f3d_wf_scene {
     float cam_fov_y;                                             /* radians */
     float cam_exposure;
     uint32_t seed_hi, seed_lo; /* ReferenceSceneDesc seeds; frame f runs with splitmix32(seed ^ f ...) (adjudication.rs:231) */
+    const f3d_wf_terrain *terrain; /* NULL: no heightfield */
 } f3d_wf_scene;
 
 typedef struct f3d_wf_out {

@@ -1630,6 +1630,52 @@ int f3do_terrain_trace_batch(const float *heights, uint32_t w, uint32_t h, float
     return 0;
 }
 
+/* A heightfield that other oracles trace (oracle/wavefront_oracle.c: the PBR tracer's terrain primitive): placement as
+ * f3do_render (centred on the world origin, y up, row = +z), terrain_trace with the curvature policy off. */
+typedef struct {
+    mips_t mips;
+    scene_t sc;
+    float *heights;
+} f3do_terrain;
+void *f3do_terrain_open(const float *heights, uint32_t w, uint32_t h, float spacing_x, float spacing_z, float exaggeration) {
+    if (!heights || w < 2 || h < 2) return NULL;
+    f3do_terrain *t = (f3do_terrain *)calloc(1, sizeof(f3do_terrain));
+    if (!t) return NULL;
+    t->heights = (float *)malloc((size_t)w * h * sizeof(float));
+    if (!t->heights) { free(t); return NULL; }
+    memcpy(t->heights, heights, (size_t)w * h * sizeof(float));
+    if (mips_build(t->heights, w, h, &t->mips) != 0) { mips_free(&t->mips); free(t->heights); free(t); return NULL; }
+    scene_t *sc = &t->sc;
+    sc->origin_x = -0.5f * ((float)w - 1.0f) * spacing_x; /* terrain_heightfield.rs:359-362 */
+    sc->origin_z = -0.5f * ((float)h - 1.0f) * spacing_z;
+    sc->spacing_x = spacing_x; sc->spacing_z = spacing_z;
+    sc->inv_spacing_x = 1.0f / spacing_x; sc->inv_spacing_z = 1.0f / spacing_z;
+    sc->exaggeration = exaggeration;
+    sc->dem_w = w; sc->dem_h = h; sc->cell_w = t->mips.cell_w; sc->cell_h = t->mips.cell_h;
+    sc->mip_count = t->mips.count; sc->enabled = 1u;
+    sc->inv_two_r_prime = 0.0f; sc->curvature_enabled = 0u;
+    sc->heights = t->heights; sc->mips = &t->mips; sc->traversal_mode = 3u;
+    return t;
+}
+void f3do_terrain_close(void *handle) {
+    f3do_terrain *t = (f3do_terrain *)handle;
+    if (!t) return;
+    mips_free(&t->mips);
+    free(t->heights);
+    free(t);
+}
+/* closest hit in (tmin, tmax): returns 1 and t / normal; any_hit != 0: the first hit found decides */
+int f3do_terrain_trace(const void *handle, const float *o, float tmin, const float *d, float tmax, int32_t any_hit, float *t_out, float *n_out) {
+    const f3do_terrain *t = (const f3do_terrain *)handle;
+    ray_t ray = {v3_make(o[0], o[1], o[2]), tmin, v3_make(d[0], d[1], d[2]), tmax};
+    counters_t cn = {0, 0, 0, 0};
+    hit_t hit = terrain_trace(&t->sc, &ray, any_hit != 0, 0, &cn);
+    if (!hit.hit) return 0;
+    if (t_out) *t_out = hit.t;
+    if (n_out) { n_out[0] = hit.normal.x; n_out[1] = hit.normal.y; n_out[2] = hit.normal.z; }
+    return 1;
+}
+
 int f3do_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

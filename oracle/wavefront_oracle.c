@@ -63,7 +63,13 @@ typedef struct {
     float cam_origin[3], cam_right[3], cam_up[3], cam_forward[3]; /* WavefrontUniforms, adjudication.rs:22-38 */
     float cam_fov_y, cam_exposure;
     uint32_t seed_hi, seed_lo;
+    /* Heightfield primitive (NOT in the reference's wavefront tracer; BASELINE.json configs[2] "GI" over a DEM): a handle of
+     * f3do_terrain_open (oracle/f3d_oracle.c, linked into this library) = the terrain tracer's own terrain_trace
+     * (hybrid_terrain_traversal.wgsl:254-372), curvature off; NULL = none.  Its hits use material slot terrain_material. */
+    const void *terrain;
+    uint32_t terrain_material;
 } wfo_scene;
+extern int f3do_terrain_trace(const void *handle, const float *o, float tmin, const float *d, float tmax, int32_t any_hit, float *t_out, float *n_out);
 
 /* ---- helpers --------------------------------------------------------------------------------- */
 static inline v3 mk(float x, float y, float z) { v3 r = {x, y, z}; return r; }
@@ -362,6 +368,14 @@ static int intersect(const wfo_scene *sc, const ray_t *ray, hit_t *hit) {
             }
         }
     }
+    if (sc->terrain) { /* the heightfield: terrain_trace with tmax = the closest hit so far */
+        const float o[3] = {ray->o.x, ray->o.y, ray->o.z}, d[3] = {ray->d.x, ray->d.y, ray->d.z};
+        float t, n[3];
+        if (f3do_terrain_trace(sc->terrain, o, ray->tmin, d, t_best, 0, &t, n) && t < t_best) {
+            t_best = t; hit_normal = mk(n[0], n[1], n[2]);
+            material_idx = sc->sphere_count > 0u ? (sc->terrain_material < sc->sphere_count - 1u ? sc->terrain_material : sc->sphere_count - 1u) : 0u;
+        }
+    }
     if (!(t_best < 1e20f)) return 0;
     hit->p = add(ray->o, scale(ray->d, t_best));
     hit->t = t_best;
@@ -407,6 +421,10 @@ static int mesh_any_hit(const wfo_mesh *m, v3 ro, v3 rd, float tmin, float tmax)
     return 0;
 }
 static int occluded(const wfo_scene *sc, v3 ro, v3 rd, float tmin, float tmax) {     /* main, :248-294 */
+    if (sc->terrain) {
+        const float o[3] = {ro.x, ro.y, ro.z}, d[3] = {rd.x, rd.y, rd.z};
+        if (f3do_terrain_trace(sc->terrain, o, tmin, d, tmax, 1, NULL, NULL)) return 1;
+    }
     for (uint32_t i = 0u; i < sc->sphere_count; i++)
         if (ray_sphere_any(ro, rd, ld(sc->spheres[i].center), sc->spheres[i].radius, tmin, tmax)) return 1;
     if (sc->instance_count == 0u) return sc->mesh_count > 0u && mesh_any_hit(&sc->meshes[0], ro, rd, tmin, tmax);

@@ -20,6 +20,7 @@ import numpy as np
 
 _HERE = Path(__file__).resolve().parent
 _SRC, _LIB = _HERE / "wavefront_oracle.c", _HERE / "libwavefront_oracle.so"
+_TERRAIN_SRC = _HERE / "f3d_oracle.c"  # the terrain tracer's oracle: terrain_trace for the heightfield primitive
 
 
 class Sphere(C.Structure):
@@ -54,13 +55,18 @@ class Scene(C.Structure):
                 ("object_importance", C.POINTER(C.c_float)), ("importance_count", C.c_uint32),
                 ("env_ground", C.c_float * 4), ("env_sky", C.c_float * 4), ("miss_ground", C.c_float * 4), ("miss_sky", C.c_float * 4),
                 ("cam_origin", C.c_float * 3), ("cam_right", C.c_float * 3), ("cam_up", C.c_float * 3), ("cam_forward", C.c_float * 3),
-                ("cam_fov_y", C.c_float), ("cam_exposure", C.c_float), ("seed_hi", C.c_uint32), ("seed_lo", C.c_uint32)]
+                ("cam_fov_y", C.c_float), ("cam_exposure", C.c_float), ("seed_hi", C.c_uint32), ("seed_lo", C.c_uint32),
+                ("terrain", C.c_void_p), ("terrain_material", C.c_uint32)]
 
 
 def build(force: bool = False) -> Path:
-    if force or not _LIB.exists() or _LIB.stat().st_mtime < _SRC.stat().st_mtime:
-        subprocess.run(["gcc", "-O2", "-fopenmp", "-ffp-contract=off", "-fPIC", "-shared", str(_SRC), "-o", str(_LIB), "-lm"],
+    if force or not _LIB.exists() or _LIB.stat().st_mtime < max(_SRC.stat().st_mtime, _TERRAIN_SRC.stat().st_mtime):
+        import os
+
+        tmp = _LIB.with_suffix(f".{os.getpid()}.tmp")
+        subprocess.run(["gcc", "-O2", "-fopenmp", "-ffp-contract=off", "-fPIC", "-shared", str(_SRC), str(_TERRAIN_SRC), "-o", str(tmp), "-lm"],
                        check=True, capture_output=True)
+        os.replace(tmp, _LIB)
     return _LIB
 
 
@@ -73,6 +79,9 @@ def lib():
         build()
         _lib = C.CDLL(str(_LIB))
         _lib.wfo_render.restype = C.c_int
+        _lib.f3do_terrain_open.restype = C.c_void_p
+        _lib.f3do_terrain_open.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float]
+        _lib.f3do_terrain_close.argtypes = [C.c_void_p]
     return _lib
 
 
@@ -131,7 +140,27 @@ def scene_struct(scene: dict):
         _vec(getattr(s, name), scene[name])
     s.cam_fov_y, s.cam_exposure = float(scene["cam_fov_y"]), float(scene.get("cam_exposure", 1.0))
     s.seed_hi, s.seed_lo = int(scene["seed_hi"]) & 0xFFFFFFFF, int(scene["seed_lo"]) & 0xFFFFFFFF
+    if scene.get("terrain") is not None:
+        t = scene["terrain"]
+        dem = np.ascontiguousarray(t["heights"], np.float32)
+        handle = lib().f3do_terrain_open(dem.ctypes.data, dem.shape[1], dem.shape[0], float(t["spacing"][0]), float(t["spacing"][1]),
+                                         float(t["exaggeration"]))
+        if not handle:
+            raise ValueError("wavefront oracle: the terrain could not be opened")
+        keep.append(_TerrainHandle(handle))
+        s.terrain, s.terrain_material = handle, int(t["material_id"])
     return s, keep
+
+
+class _TerrainHandle:
+    def __init__(self, handle):
+        self.handle = handle
+
+    def __del__(self):
+        try:
+            lib().f3do_terrain_close(self.handle)
+        except Exception:  # noqa: BLE001
+            pass
 
 
 def render(scene: dict, width: int, height: int, frames: int, first_frame: int = 0, accum=None):

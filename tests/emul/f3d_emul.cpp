@@ -1005,12 +1005,18 @@ int emul_wavefront_render(const f3d_wf_scene *scene, uint32_t width, uint32_t he
         S.inst = prep.inst.data();
         S.dir = prep.dir.data();
         S.area = prep.area.data();
+        HostTables terrain;  // the heightfield primitive: the terrain tracer's tables, its placement from prepare_scene
+        if (scene->terrain) {
+            terrain = build_tables_host(scene->terrain->heights, scene->terrain->dem_width, scene->terrain->dem_height, scene->terrain->exaggeration);
+            terrain.attach(S.terrain);
+        }
         const int64_t pixels = (int64_t)width * height;
         uint64_t vertices = 0;
 #pragma omp parallel for schedule(dynamic, 64) reduction(+ : vertices)
         for (int64_t p = 0; p < pixels; p++) {
             V3 acc{accum[4 * p], accum[4 * p + 1], accum[4 * p + 2]};
-            vertices += wf::trace_frames(S, (uint32_t)p, first_frame, frame_count, wf::SoloWave{}, [&](uint32_t, V3 total) { acc = acc + total; });
+            ArrayPending pend;
+            vertices += wf::trace_frames(S, (uint32_t)p, first_frame, frame_count, wf::SoloWave<ArrayPending>{&pend}, [&](uint32_t, V3 total) { acc = acc + total; });
             accum[4 * p] = acc.x;
             accum[4 * p + 1] = acc.y;
             accum[4 * p + 2] = acc.z;

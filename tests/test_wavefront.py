@@ -184,6 +184,61 @@ def test_emulated_device_path_equals_the_oracle_on_random_scenes(wfo, emul, seed
     assert np.array_equal(a["accum"], b["accum"])
 
 
+# ---- the terrain primitive: "GI" over a DEM (BASELINE.json configs[2]) ---------------------------------------------------
+def terrain_gi_scene(seed=0, size=(96, 64), frames=4):
+    """The terrain tracer's golden DEM as a heightfield in the PBR tracer's scene: a rough metal-ish and a Lambert sphere
+    standing on it, a low sun (long terrain shadows), a sky environment, the camera of the terrain tests.  Paths bounce
+    between terrain, spheres and sky -- the multi-bounce light transport the one-bounce terrain tracer does not have."""
+    from forge3d_amd.wavefront import DirectionalLight, Sphere, Terrain, WavefrontScene
+
+    rng = np.random.default_rng(700 + seed)
+    dem = scenes.golden_dem()
+    kw = scenes.scene_kwargs(dem)
+    if seed % 3 == 1:  # a ragged DEM with unequal spacings, camera inside the footprint
+        dem = (np.cumsum(rng.normal(size=(37, 53)), axis=1) * 0.4 + 6.0 * rng.random((37, 53))).astype(np.float32)
+        kw = dict(spacing=(2.5, 1.5), exaggeration=1.7)
+    sx, sz = kw["spacing"]
+    span = (dem.shape[1] - 1) * sx
+    top = float(dem.max()) * kw["exaggeration"]
+    spheres = [Sphere(center=(0.1 * span, top + 0.05 * span, 0.05 * span), radius=0.06 * span, albedo=(0.8, 0.6, 0.3), metallic=1.0, roughness=0.3),
+               Sphere(center=(-0.2 * span, 0.6 * top + 0.04 * span, 0.2 * span), radius=0.04 * span, albedo=(0.7, 0.2, 0.2), roughness=0.8),
+               Sphere(center=(0.0, -1000.0, 0.0), radius=0.0, albedo=(0.55, 0.52, 0.48), roughness=0.9)]  # slot 2: the terrain's material
+    cam = scenes.CAM if seed % 3 != 1 else {"origin": (0.3 * span, top * 1.4, 0.45 * span), "look_at": (0.0, 0.4 * top, 0.0), "up": (0.0, 1.0, 0.0), "fov_y": 50.0}
+    el, az = np.deg2rad(18.0 + 10.0 * (seed % 4)), np.deg2rad(225.0 + 40.0 * seed)
+    to_sun = np.array([np.cos(az) * np.cos(el), np.sin(el), np.sin(az) * np.cos(el)])
+    return WavefrontScene(
+        terrain=Terrain(heights=dem, spacing=(sx, sz), exaggeration=kw["exaggeration"], material_id=2),
+        spheres=spheres, dir_lights=[DirectionalLight(tuple(-to_sun), 3.0, (1.0, 0.97, 0.92), 1.0)],
+        object_importance=[1.0, 1.0, 1.0], env_ground=(0.25, 0.3, 0.4), env_sky=(0.35, 0.45, 0.7), miss_ground=(0.2, 0.2, 0.25),
+        miss_sky=(0.35, 0.45, 0.7), cam_origin=cam["origin"], cam_look_at=cam["look_at"], cam_up=cam["up"], fov_y_deg=cam["fov_y"],
+        seed_hi=0x9E3779B9 ^ seed, seed_lo=0x85EBCA6B), size[0], size[1], frames
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_emulated_terrain_primitive_equals_the_oracle(wfo, emul, seed):
+    """Closest and any hits of the heightfield through the device's stackless march (host-compiled) against the oracle's
+    terrain_trace inside the multi-bounce loop: every pixel's running sums, bit for bit; and the terrain does something:
+    it is seen, it receives shadows, and light bounces between it and the spheres."""
+    scene, w, h, frames = terrain_gi_scene(seed)
+    d = scene.as_dict()
+    a = wfo.render(d, w, h, frames)
+    b = emul.wavefront_render(d, w, h, frames)
+    assert np.isfinite(a["accum"]).all()
+    assert np.array_equal(a["accum"], b["accum"])
+    assert b["path_vertices"] > 1.5 * w * h * frames  # paths continue after their first terrain hit
+    bare = dict(d, terrain=None)
+    assert not np.array_equal(wfo.render(bare, w, h, frames)["accum"], a["accum"])
+
+
+def test_terrain_primitive_validation():
+    from forge3d_amd import wavefront
+
+    scene, w, h, frames = terrain_gi_scene(0)
+    scene.terrain.heights = np.zeros((1, 5), np.float32)
+    with pytest.raises((RuntimeError, ValueError), match="at least 2x2|no CPU fallback|HIP"):
+        wavefront.render_scene(scene, w, h, 1)
+
+
 # ---- HIP -----------------------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def hip():
@@ -248,3 +303,19 @@ def test_hip_errors(hip):
     sc["spheres"][0]["albedo"] = (float("nan"), 0.5, 0.5)
     with pytest.raises(ValueError, match="sphere 0"):
         hip.render_scene(sc, 16, 16, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+def test_hip_terrain_primitive_equals_the_oracle(hip, wfo, seed):
+    """BASELINE.json configs[2]'s "GI": the heightfield primitive on the device (the terrain tracer's tables and march inside
+    the PBR tracer's closest-hit and shadow queries) against the oracle, bit for bit, incl. continued renders."""
+    scene, w, h, frames = terrain_gi_scene(seed, size=(160, 96), frames=6)
+    d = scene.as_dict()
+    want = wfo.render(d, w, h, frames)
+    got = hip.render_scene(d, w, h, frames)
+    for key in ("accum", "hdr", "rgba"):
+        assert np.array_equal(got[key], want[key]), (seed, key)
+    first = hip.render_scene(d, w, h, 2, frames_per_launch=1)
+    rest = hip.render_scene(d, w, h, frames - 2, first_frame=2, accum=first["accum"])
+    assert np.array_equal(rest["accum"], want["accum"])
