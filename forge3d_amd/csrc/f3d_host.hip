@@ -1301,6 +1301,24 @@ int f3d_session_halo(f3d_session *s, int32_t which, int32_t side, void **ptr, ui
     return F3D_STATUS_OK;
 }
 
+int f3d_session_set_accumulation(f3d_session *s, const float *sums_rgba, char *err, size_t errlen) {
+    return c_abi(err, errlen, [&] {
+        DeviceGuard g(checked(s).device);
+        if (!sums_rgba) fail(F3D_STATUS_VALUE, "null accumulation");
+        const size_t px = (size_t)s->rows * s->width;
+        // accum_mean holds (sum r, sum g, sum b, Welford mean): the radiance sums are replaced, the statistic is kept
+        std::vector<float4> host(px);
+        hip_check(hipStreamSynchronize(s->stream), "accumulation sync");
+        hip_check(hipMemcpy(host.data(), s->params.accum_mean, px * sizeof(float4), hipMemcpyDeviceToHost), "accumulation read-back");
+        for (size_t i = 0; i < px; i++) {
+            host[i].x = sums_rgba[4 * i];
+            host[i].y = sums_rgba[4 * i + 1];
+            host[i].z = sums_rgba[4 * i + 2];
+        }
+        hip_check(hipMemcpy(s->params.accum_mean, host.data(), px * sizeof(float4), hipMemcpyHostToDevice), "accumulation upload");
+    });
+}
+
 int f3d_session_resolve_device(f3d_session *s, uint32_t frames, void *d_rgba, void *d_albedo, void *d_normal,
                                void *d_depth, char *err, size_t errlen) {
     return c_abi(err, errlen, [&] {

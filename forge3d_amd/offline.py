@@ -84,3 +84,47 @@ class OfflineTerrainViewer:
     def snapshot(self, path: Union[str, Path], width: Optional[int] = None, height: Optional[int] = None) -> None:
         """Path trace the current scene and write the RGBA8 result as a PNG."""
         _io.numpy_to_png(path, self.render(width, height)["rgba"])
+
+
+def render_terrain_gi(heightmap, width: int, height: int, camera=None, *, spacing=(1.0, 1.0), exaggeration: float = 1.0,
+                      albedo=(0.6, 0.6, 0.6), roughness: float = 0.9, sun_azimuth_deg: float = 315.0, sun_elevation_deg: float = 45.0,
+                      sun_intensity: float = 2.5, sun_color=(1.0, 0.97, 0.92), sky_color=(0.35, 0.45, 0.70), ambient_color=(0.40, 0.48, 0.62),
+                      spp: int = 256, atmosphere=None, seed: int = 7, extra_spheres=(), memory_budget_bytes: int = 0) -> dict:
+    """BASELINE.json configs[2]: a DEM rendered with MULTI-BOUNCE light transport ("GI") and, optionally, the AETHER
+    aerial-perspective post.  Neither half is new arithmetic: the radiance is the PBR path tracer's (forge3d_amd.wavefront,
+    the reference's wavefront tracer re-designed for MI355X) with the DEM as its heightfield primitive -- one sun, a sky
+    environment, Lambert/GGX terrain material -- and the post is the terrain tracer's own (prometheus_aerial.wgsl through
+    f3d_session_resolve) applied to that radiance over the terrain tracer's depth and hit mask for the same camera.
+    The reference has no such combination (its wavefront tracer has no terrain hook); parity for it is
+    the composition of the two oracles (tests/test_offline_gi.py).
+
+    Returns dict(rgba u8 (H,W,4), hdr f32 (H,W,4) mean radiance, depth, normal, albedo, frames, gi_seconds)."""
+    from .session import TerrainSession
+    from .wavefront import DirectionalLight, Sphere, Terrain, WavefrontScene, render_scene
+
+    dem = np.ascontiguousarray(heightmap, np.float32)
+    cam = dict(camera or {})
+    origin, look_at = cam.get("origin", (0.0, 50.0, 120.0)), cam.get("look_at", (0.0, 0.0, 0.0))
+    up, fov, exposure = cam.get("up", (0.0, 1.0, 0.0)), float(cam.get("fov_y", 45.0)), float(cam.get("exposure", 1.0))
+    az, el = np.deg2rad(np.float32(sun_azimuth_deg)), np.deg2rad(np.float32(sun_elevation_deg))
+    to_sun = (float(np.cos(az) * np.cos(el)), float(np.sin(el)), float(np.sin(az) * np.cos(el)))  # render_terrain.rs:639-642
+    spheres = [Sphere(**s) if isinstance(s, dict) else s for s in extra_spheres]
+    spheres.append(Sphere(center=(0.0, -1.0e9, 0.0), radius=0.0, albedo=tuple(albedo), metallic=0.0, roughness=float(roughness)))  # the terrain's material
+    scene = WavefrontScene(
+        terrain=Terrain(heights=dem, spacing=tuple(spacing), exaggeration=float(exaggeration), material_id=len(spheres) - 1),
+        spheres=spheres, dir_lights=[DirectionalLight(tuple(-c for c in to_sun), float(sun_intensity), tuple(sun_color), 1.0)],
+        object_importance=[1.0] * len(spheres), env_ground=tuple(ambient_color), env_sky=tuple(ambient_color), miss_ground=tuple(sky_color),
+        miss_sky=tuple(sky_color), cam_origin=tuple(origin), cam_look_at=tuple(look_at), cam_up=tuple(up), fov_y_deg=fov, exposure=exposure,
+        seed_hi=(0x9E3779B9 ^ int(seed)) & 0xFFFFFFFF, seed_lo=0x85EBCA6B)
+    gi = render_scene(scene, int(width), int(height), int(spp))
+    # the terrain tracer's session for the same camera: depth / hit mask / AOVs of the centre rays, its resolve and post
+    kw = dict(spacing=tuple(spacing), exaggeration=float(exaggeration), albedo=tuple(albedo), sun_azimuth_deg=float(sun_azimuth_deg),
+              sun_elevation_deg=float(sun_elevation_deg), sun_intensity=float(sun_intensity), sun_color=tuple(sun_color), spp=1,
+              max_frames=2, min_frames=2, variance_threshold=1e30, seed=int(seed), atmosphere=atmosphere)
+    with TerrainSession(dem, int(width), int(height), {"origin": origin, "look_at": look_at, "up": up, "fov_y": fov, "exposure": exposure},
+                        memory_budget_bytes=int(memory_budget_bytes), **kw) as s:
+        s.enqueue_frames(0, 2)  # (reservoirs for the resolve's validity pass; their radiance is replaced below)
+        s.set_accumulation(gi["accum"])
+        out = s.resolve(int(spp))
+    out.update(hdr=gi["hdr"], frames=int(spp), gi_seconds=gi["loop_seconds"], path_vertices=gi["path_vertices"])
+    return out

@@ -166,6 +166,14 @@ class TerrainSession:
             raise ValueError("invalid halo query")
         return int(ptr.value), int(nbytes.value)
 
+    def set_accumulation(self, sums_rgba):
+        """Replace the accumulated radiance sums by (rows, width, 4) f32 sums of the caller's (composition hook: the PBR
+        tracer's radiance through this session's resolve and AETHER post)."""
+        arr = np.ascontiguousarray(sums_rgba, np.float32)
+        if arr.shape != (self.rows, self.width, 4):
+            raise ValueError(f"accumulation must have shape ({self.rows}, {self.width}, 4)")
+        self._check(self._lib.f3d_session_set_accumulation(self._handle, arr.ctypes.data, self._err, len(self._err)))
+
     def resolve(self, frames: int):
         """Final resolve of the owned rows into host arrays."""
         rows, w = self.rows, self.width

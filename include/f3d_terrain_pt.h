@@ -242,6 +242,12 @@ int f3d_session_enqueue_batch_strip(f3d_session *session, uint32_t first_frame, 
 int f3d_session_resolve(f3d_session *session, uint32_t frames, uint8_t *rgba, float *albedo,
                         float *normal, float *depth, int32_t *any_valid_reservoir, char *err,
                         size_t errlen);
+/* Composition hook: replace the session's accumulated radiance sums by caller-supplied ones ((rows, width, 4) f32 host
+ * memory: rgb = sums over `frames` frames, a ignored); the next f3d_session_resolve(frames) then tone-maps -- and, with
+ * desc.atmosphere, sends through the AETHER post -- THAT radiance over the session's own depth / G-buffer.  How
+ * BASELINE.json configs[2] combines the PBR tracer's multi-bounce radiance over the DEM (f3d_wavefront.h terrain
+ * primitive) with the atmosphere post: forge3d_amd.offline.render_terrain_gi. */
+int f3d_session_set_accumulation(f3d_session *session, const float *sums_rgba, char *err, size_t errlen);
 /* Same, but leaves the results in caller-owned DEVICE buffers (for an RCCL gather). */
 int f3d_session_resolve_device(f3d_session *session, uint32_t frames, void *d_rgba, void *d_albedo,
                                void *d_normal, void *d_depth, char *err, size_t errlen);

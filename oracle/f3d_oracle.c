@@ -1553,6 +1553,20 @@ int f3do_render(const f3do_desc *d, f3do_out *out, char *err, size_t errlen) {
                  "temporal/spatial reuse is broken");
     }
 
+    /* composition hook: an external accumulation (f3d_oracle.h accum_override) takes the place of this render's own;
+     * the RGBA16F target is rewritten exactly as main_terrain writes it (:557-579: Reinhard of the mean times exposure) */
+    if (d->accum_override) {
+        memcpy(st.accum, d->accum_override, P * 4 * sizeof(float));
+        for (size_t i = 0; i < P; i++) {
+            const float *acc = &st.accum[4 * i];
+            v3 mean_rgb = v3_make(acc[0] / acc[3], acc[1] / acc[3], acc[2] / acc[3]);
+            v3 ldr = reinhard_tonemap(mean_rgb, un.cam_exposure);
+            st.out_tex[4 * i + 0] = f32_to_f16_bits(ldr.x);
+            st.out_tex[4 * i + 1] = f32_to_f16_bits(ldr.y);
+            st.out_tex[4 * i + 2] = f32_to_f16_bits(ldr.z);
+        }
+    }
+
     /* AETHER aerial-perspective post over the converged accumulation (render_terrain.rs:1249-1310) */
     if (d->atmosphere) {
         uniforms_t pu = un;

@@ -78,6 +78,11 @@ typedef struct {
     uint32_t seed, spp, max_frames, min_frames;
     float variance_threshold;
     const f3do_aether *atmosphere; /* NULL = no aerial-perspective post */
+    /* Composition hook (no counterpart in the reference): (H*W, 4) radiance sums + frame count that REPLACE the path
+     * tracer's own accumulation before the resolve / the AETHER post -- how BASELINE.json configs[2] combines the PBR
+     * tracer's multi-bounce radiance over the DEM ("GI") with the atmosphere post (forge3d_amd.offline.render_terrain_gi).
+     * NULL = the terrain tracer's own accumulation. */
+    const float *accum_override;
 } f3do_desc;
 
 typedef struct {

@@ -96,6 +96,7 @@ class Desc(C.Structure):
         ("min_frames", C.c_uint32),
         ("variance_threshold", C.c_float),
         ("atmosphere", C.c_void_p),
+        ("accum_override", C.c_void_p),
     ]
 
 
@@ -229,7 +230,7 @@ def render(heightmap, width, height, camera=None, *, spacing=(1.0, 1.0), exagger
            variance_threshold=1e-3, seed=7, observer_latitude_deg=0.0,
            observer_longitude_deg=0.0, earth_model="ellipsoid", sphere_radius_m=6_371_008.8,
            refraction_model="bennett", refraction_k=0.13, pressure_mbar=1013.25,
-           temperature_c=15.0, dump_state=False, atmosphere=None):
+           temperature_c=15.0, dump_state=False, atmosphere=None, accum_override=None):
     """Run the CPU oracle; returns the reference's result dict (+ counters).  atmosphere: an
     AtmosphereLutHandle-like object (the AETHER aerial-perspective post) or None."""
     L = lib()
@@ -281,6 +282,10 @@ def render(heightmap, width, height, camera=None, *, spacing=(1.0, 1.0), exagger
         aether, aether_keep = aether_struct(atmosphere)
         keep += aether_keep + [aether]
         d.atmosphere = C.addressof(aether)
+    if accum_override is not None:  # (H, W, 4) radiance sums + frame count replacing the render's own accumulation
+        override = np.ascontiguousarray(accum_override, np.float32).reshape(int(height) * int(width), 4)
+        keep.append(override)
+        d.accum_override = override.ctypes.data
 
     P = int(width) * int(height)
     rgba = np.zeros((height, width, 4), np.uint8)
