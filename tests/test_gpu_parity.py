@@ -991,3 +991,124 @@ def test_results_do_not_depend_on_what_the_allocator_hands_out(f3d, oracle):
     finally:
         _native.debug_poison(-1)
         L.f3d_scene_cache_limit(ctypes.c_uint32(2))
+
+
+# ---------------------------------------------------------------------------------------
+# BASELINE.json configs[3] at FULL size (round-2 verdict item 5)
+# ---------------------------------------------------------------------------------------
+def test_config4_full_size_4096_with_600k_triangles(f3d, oracle):
+    """4096 x 4096, the 2048^2 proxy DEM, 50 000 extruded boxes = 600 000 triangles, 2 spp x 2 frames:
+    the GPU LBVH and the host SAH tree give the same image bit for bit; the image is deterministic; eight row strips
+    (eight sessions on the one GPU, peer halos) stitch to the one-strip image; and a 4096-wide 16-row strip through the
+    buildings equals the CPU oracle on the triangles that can matter to it."""
+    import torch
+
+    from forge3d_amd import datasets
+    from forge3d_amd.session import TerrainSession
+
+    dem, cam, kw = datasets.rainier_proxy_scene(2048)
+    v, i = datasets.proxy_buildings(dem, kw["spacing"][0])
+    assert i.shape[0] == 600_000
+    W = H = 4096
+    frames = 2
+    k = dict(kw, spp=2, max_frames=frames, min_frames=frames, variance_threshold=1e30, mesh_vertices=v, mesh_indices=i)
+
+    def whole(builder):
+        with TerrainSession(dem, W, H, cam, memory_budget_bytes=16 << 30, mesh_builder=builder, **k) as s:
+            s.enqueue_frames(0, frames, True)
+            m2, bad = s.window_stats()
+            assert not bad
+            return s.resolve(frames), m2
+
+    (sah, m2a), (lbvh, m2b), (again, m2c) = whole(1), whole(2), whole(1)
+    assert m2a == m2b == m2c
+    for key in ("rgba", "albedo", "normal", "depth"):
+        assert np.array_equal(sah[key], lbvh[key], equal_nan=True), key
+        assert np.array_equal(sah[key], again[key], equal_nan=True), key
+    hit = np.isfinite(sah["depth"])
+    assert 0.3 < hit.mean() < 0.9 and np.isclose(sah["albedo"][..., 2], 0.8, atol=2e-3).any()  # buildings are in view (mesh albedo 0.7, 0.7, 0.8)
+    # eight strips (eight sessions on the one GPU), the 4-row halos copied between them after every frame
+    from forge3d_amd.session import HALO_ROWS as R, reservoir_buffer_bytes
+
+    bounds = [0, 700, 1300, 1800, 2200, 2600, 3000, 3500, 4096]
+    dev = torch.device("cuda", 0)
+    bufs = [[torch.zeros(reservoir_buffer_bytes(e - b, W), dtype=torch.uint8, device=dev) for _ in range(2)] for b, e in zip(bounds[:-1], bounds[1:])]
+    sessions = [TerrainSession(dem, W, H, cam, row_begin=b, row_end=e, memory_budget_bytes=16 << 30, ext_reservoirs=(r[0].data_ptr(), r[1].data_ptr()), **k)
+                for b, e, r in zip(bounds[:-1], bounds[1:], bufs)]
+    row = W * 16
+    for f in range(frames):
+        for s in sessions:
+            s.enqueue_frames(f, 1, f + 1 == frames)
+        torch.cuda.synchronize()
+        for n in range(7):
+            up, dn, rows_up = bufs[n][f & 1], bufs[n + 1][f & 1], bounds[n + 1] - bounds[n]
+            dn[0:R * row] = up[rows_up * row:(rows_up + R) * row]
+            up[(rows_up + R) * row:(rows_up + 2 * R) * row] = dn[R * row:2 * R * row]
+        torch.cuda.synchronize()
+    parts = [s.resolve(frames) for s in sessions]
+    for s in sessions:
+        s.close()
+    for key in ("rgba", "albedo", "normal", "depth"):
+        assert np.array_equal(np.concatenate([p[key] for p in parts], 0), sah[key], equal_nan=True), key
+    # ... and three strips that pull their halos themselves (peer halos; one stream each -- a spin-waiting pull kernel
+    # needs its neighbour's stream to run beside it, and one process has only a few hardware queues: in production every
+    # strip is its own process on its own GPU)
+    bounds = [0, 1500, 2600, 4096]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    sessions = [TerrainSession(dem, W, H, cam, row_begin=b, row_end=e, memory_budget_bytes=16 << 30, stream=st.cuda_stream, **k)
+                for b, e, st in zip(bounds[:-1], bounds[1:], streams)]
+    exports = [s.halo_export() for s in sessions]
+    for n, s in enumerate(sessions):
+        if n > 0:
+            s.halo_connect(0, exports[n - 1])
+        if n < 2:
+            s.halo_connect(1, exports[n + 1])
+    for s in sessions:
+        s.enqueue_batch_strip(0, frames, True)
+    torch.cuda.synchronize()
+    assert all(s.halo_timeouts() == 0 for s in sessions)
+    parts = [s.resolve(frames) for s in sessions]
+    for s in sessions:
+        s.close()
+    for key in ("rgba", "albedo", "normal", "depth"):
+        assert np.array_equal(np.concatenate([p[key] for p in parts], 0), sah[key], equal_nan=True), key
+
+
+def test_config4_strip_of_4096_pixels_matches_the_oracle(f3d, oracle):
+    """A 4096-wide strip of 16 rows through the middle of the 4096^2 frame, with the triangles of two buildings placed in
+    its view, against the CPU oracle's full image (terrain + its brute-force sweep over those 24 triangles): the strip's
+    rows, bit for bit.  One frame: a lone strip has no halo donors, and the first frame reads no halos."""
+    from forge3d_amd import datasets
+    from forge3d_amd.session import TerrainSession
+
+    dem, cam, kw = datasets.rainier_proxy_scene(2048)
+    W = H = 4096
+    k = dict(kw, spp=1, max_frames=2, min_frames=2, variance_threshold=1e30)
+    probe = f3d.hybrid_render_terrain_reference(dem, 256, 256, cam, **k)  # where does the middle row look at the terrain?
+    mid = probe["depth"][128]
+    col = int(np.nanargmin(np.where(np.isfinite(mid), np.abs(np.arange(256) - 128), np.inf)))
+    assert np.isfinite(mid[col])
+    # the surface point under that pixel, from the camera model of render_terrain.rs:635-642
+    o = np.array(cam["origin"]); f = np.array(cam["look_at"]) - o; f /= np.linalg.norm(f)
+    r = np.cross(f, cam["up"]); r /= np.linalg.norm(r); u = np.cross(r, f)
+    th = np.tan(np.deg2rad(cam["fov_y"]) / 2)
+    d = r * (((col + 0.5) / 256) * 2 - 1) * th + u * ((1 - (128 + 0.5) / 256) * 2 - 1) * th + f
+    p = o + d / np.linalg.norm(d) * mid[col]
+    boxes = []
+    for dx in (-60.0, 70.0):
+        c = p + np.array([dx, 0.0, 15.0])
+        x0, x1, y0, y1, z0, z1 = c[0] - 20, c[0] + 20, c[1] - 30, c[1] + 90, c[2] - 20, c[2] + 20
+        boxes.append(np.array([[x0, y0, z0], [x1, y0, z0], [x1, y0, z1], [x0, y0, z1], [x0, y1, z0], [x1, y1, z0], [x1, y1, z1], [x0, y1, z1]], np.float32))
+    quads = ((0, 1, 2, 3), (7, 6, 5, 4), (0, 4, 5, 1), (1, 5, 6, 2), (2, 6, 7, 3), (3, 7, 4, 0))
+    local = np.array([t for a, b, c, dd in quads for t in ((a, b, c), (a, c, dd))], np.uint32)
+    v = np.concatenate(boxes)
+    i = np.concatenate([local, local + 8])
+    k = dict(k, mesh_vertices=v, mesh_indices=i, max_frames=1, min_frames=1)
+    want = oracle.render(dem, W, H, cam, **dict(k, max_frames=2, min_frames=2))  # (the oracle wants two frames for its window; frame 0 AOVs are what is compared)
+    rows = (2040, 2056)
+    with TerrainSession(dem, W, H, cam, row_begin=rows[0], row_end=rows[1], memory_budget_bytes=8 << 30, **dict(k, max_frames=2, min_frames=2)) as s:
+        s.enqueue_frames(0, 1)
+        got = s.resolve(1)
+    for key in ("albedo", "normal", "depth"):  # frame-0 AOVs of the strip: the oracle's rows
+        assert np.array_equal(got[key], want[key][rows[0]:rows[1]], equal_nan=True), key
+    assert np.isclose(got["albedo"][..., 2], 0.8, atol=2e-3).any()  # a building is in the strip

@@ -198,3 +198,77 @@ def test_hip_smoke_errors_are_the_reference_errors():
         dom.render_projection_rgba(8, 8, (0.0, 0.0, 0.0))
     with pytest.raises(RuntimeError, match="width and height"):
         dom.render_rgba(0, 8, (4.0, 4.0, -9.0), (4.0, 4.0, 4.0))
+
+
+# ---- BASELINE.json configs[4]: a 120-frame sequence, time-sliced over the ranks -----------------------------------------
+class _OracleFrame:
+    """Stands in for a SmokeDomain on a box without a GPU: render_rgba through the oracle (render_sequence only needs that)."""
+
+    def __init__(self, fields, frame_index):
+        self.fields, self.frame_index = fields, frame_index
+
+    def render_rgba(self, width, height, camera_pos, target, **kw):
+        return smoke_oracle.render_rgba(self.fields, width, height, camera_pos=camera_pos, target=target, frame_index=self.frame_index, **kw)
+
+
+def _sequence_fields(i):
+    return plume(seed=9 + i % 5, dims=(24, 16, 32))  # (five distinct states: the sequence's fields come from elsewhere, see DESIGN.md 9.5)
+
+
+def _sequence_worker(rank, world, port, out_path):
+    import os
+    import pickle
+    import sys
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch.distributed as dist
+
+    from forge3d_amd import smoke
+
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    frames = [_OracleFrame(_sequence_fields(i), i) for i in range(120)]
+    seq = smoke.render_sequence(frames, 48, 27, (16.0, 18.0, -30.0), (16.0, 7.0, 12.0), rank=rank, world=world, fovy_deg=40.0)
+    if rank == 0:
+        with open(out_path, "wb") as f:
+            pickle.dump(seq, f)
+    else:
+        assert seq is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sequence_of_120_frames_over_eight_ranks():
+    """render_sequence: frames r, r + 8, ... on rank r, gathered in frame order on rank 0 (gloo, world 8; the frames go
+    through the oracle here, the distribution is what is under test)."""
+    import pickle
+    import socket
+    import tempfile
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = tempfile.mktemp(suffix=".pkl")
+    mp.spawn(_sequence_worker, args=(8, port, out), nprocs=8, join=True)
+    with open(out, "rb") as f:
+        seq = pickle.load(f)
+    assert len(seq) == 120
+    for i in (0, 1, 7, 8, 63, 119):
+        want = smoke_oracle.render_rgba(_sequence_fields(i), 48, 27, camera_pos=(16.0, 18.0, -30.0), target=(16.0, 7.0, 12.0), frame_index=i, fovy_deg=40.0)
+        assert np.array_equal(seq[i], want), i
+
+
+@pytest.mark.gpu
+def test_config5_sequence_of_120_frames_matches_the_oracle():
+    """BASELINE.json configs[4]: 120 frames (frame_index 0..119, five field states) through render_sequence at 240 x 135,
+    every frame against the oracle."""
+    from forge3d_amd import smoke
+
+    cam = dict(camera_pos=(16.0, 18.0, -30.0), target=(16.0, 7.0, 12.0))
+    frames = [_domain(_sequence_fields(i), frame_index=i) for i in range(120)]
+    seq = smoke.render_sequence(frames, 240, 135, cam["camera_pos"], cam["target"], fovy_deg=40.0)
+    assert len(seq) == 120
+    for i, img in enumerate(seq):
+        assert np.array_equal(img, smoke_oracle.render_rgba(_sequence_fields(i), 240, 135, frame_index=i, fovy_deg=40.0, **cam)), i
