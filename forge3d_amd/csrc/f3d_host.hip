@@ -191,7 +191,7 @@ namespace {
 
 struct CachedTables {
     int device = 0;
-    uint64_t key = 0, dem_bytes = 0;
+    uint64_t key = 0, key2 = 0, dem_bytes = 0;  // two independent 64-bit hashes of the DEM bytes
     uint32_t w = 0, h = 0;
     float exaggeration = 0.0f;
     Ledger mem;  // owns leaf + band tables (+ the far-horizon tables)
@@ -215,7 +215,9 @@ struct CachedTables {
 };
 
 std::mutex g_scene_mutex;
-std::vector<std::shared_ptr<CachedTables>> g_scene_cache;
+// deliberately never destroyed: a static destructor would call hipFree after the HIP runtime has been torn down at
+// interpreter exit (the process's memory goes back to the driver anyway)
+std::vector<std::shared_ptr<CachedTables>> &g_scene_cache = *new std::vector<std::shared_ptr<CachedTables>>();
 uint64_t g_scene_stamp = 0;
 size_t g_scene_limit = 2;  // f3d_scene_cache_limit
 
@@ -239,10 +241,11 @@ std::shared_ptr<CachedTables> acquire_tables(int device, const float *heights, u
     const uint64_t bytes = (uint64_t)w * h * sizeof(float);
     uint64_t key = hash_bytes(heights, bytes, 0x6a09e667f3bcc908ull);
     key = hash_bytes(&exaggeration, sizeof(float), key ^ ((uint64_t)w << 32 | h));
+    const uint64_t key2 = hash_bytes(heights, bytes, 0xbb67ae8584caa73bull) + 0x3c6ef372fe94f82bull * (uint64_t)w;
     {
         std::lock_guard<std::mutex> lock(g_scene_mutex);
         for (auto &e : g_scene_cache)
-            if (e->device == device && e->key == key && e->w == w && e->h == h && e->exaggeration == exaggeration &&
+            if (e->device == device && e->key == key && e->key2 == key2 && e->w == w && e->h == h && e->exaggeration == exaggeration &&
                 e->dem_bytes == bytes) {
                 e->stamp = ++g_scene_stamp;
                 *was_cached = true;
@@ -253,6 +256,7 @@ std::shared_ptr<CachedTables> acquire_tables(int device, const float *heights, u
     auto e = std::make_shared<CachedTables>();
     e->device = device;
     e->key = key;
+    e->key2 = key2;
     e->dem_bytes = bytes;
     e->w = w;
     e->h = h;
@@ -663,13 +667,16 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
             want = n ? (uint32_t)std::max(2, atoi(n)) : 2u;
         }
         if (want >= 2u && (!opts || opts->bands <= 1u)) {
+            // what frames in flight allocate besides the records: re-trace list and counters, head records, tile costs
+            const uint64_t fd_fixed = (uint64_t)px * sizeof(uint32_t) + (P.sample_lanes > 1u ? 0u : (uint64_t)px * sizeof(uint2)) + (1u << 20);
+            const uint64_t room = s.budget > planned + fd_fixed ? s.budget - planned - fd_fixed : 0u;
             const uint64_t rec_bytes = 2u * sizeof(float4), ray_bytes = 2u * sizeof(float4) + sizeof(float4) + sizeof(float);
             uint64_t per_frame = (uint64_t)px * P.spp * (rec_bytes + (wf_want ? ray_bytes + ray_bytes / 4u : 0u));  // (+ a quarter: regions of partly filled edge tiles and rounds)
-            uint64_t fit = per_frame ? (s.budget - planned) / per_frame : 0u;
+            uint64_t fit = per_frame ? room / per_frame : 0u;
             s.wavefront = wf_want && fit >= 2u;
             if (wf_want && !s.wavefront) {  // the queues do not fit the budget: plain frames in flight, if those do
                 per_frame = (uint64_t)px * P.spp * rec_bytes;
-                fit = per_frame ? (s.budget - planned) / per_frame : 0u;
+                fit = per_frame ? room / per_frame : 0u;
                 if (opts && opts->frames_in_flight < 2u) fit = 0u;  // (they were only asked for as part of the wavefront form)
             }
             s.fd_frames = (uint32_t)std::min<uint64_t>(want, fit);

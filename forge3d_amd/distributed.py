@@ -204,8 +204,13 @@ class StripRenderer:
             self.peer_halos = self.session is not None
         if self.session is None:
             self.res = [self.backend.empty_bytes(nbytes), self.backend.empty_bytes(nbytes)]
-            self.session = self.backend.make_session(dem, self.width, self.height, cam, self.row_begin, self.row_end,
-                                                     self.res, self.stats, kw)
+            error = None
+            try:
+                self.session = self.backend.make_session(dem, self.width, self.height, cam, self.row_begin, self.row_end,
+                                                         self.res, self.stats, kw)
+            except Exception as exc:  # noqa: BLE001 -- agreed on by every rank before anybody enters a collective
+                error = exc
+            self._agree(error)
 
     def _connect_peers(self, dem, cam, kw):
         """A session that owns its reservoirs, its export gathered over the process group, the neighbours mapped;
@@ -271,8 +276,15 @@ class StripRenderer:
         density = np.ones(self.height)
         best = None
         for it in range(iters + 1):
-            ms = self.backend.probe(dem, self.width, self.height, cam, bounds[self.rank], bounds[self.rank + 1], kw,
-                                    frames=self.probe_frames)
+            # a probe that fails on one rank (a fat strip over the memory budget, a stale library) must not leave the
+            # others waiting in the all-gather: the failure is agreed on first, then raised everywhere
+            ms, error = float("nan"), None
+            try:
+                ms = self.backend.probe(dem, self.width, self.height, cam, bounds[self.rank], bounds[self.rank + 1], kw,
+                                        frames=self.probe_frames)
+            except Exception as exc:  # noqa: BLE001
+                error = exc
+            self._agree(error)
             times = self._gather_floats(ms)
             if not all(np.isfinite(t) and t > 0.0 for t in times):
                 break  # backend without timing: keep what we have
@@ -297,7 +309,7 @@ class StripRenderer:
         """Post the sends of my edge rows of reservoir buffer `which` and the receives into my halo rows
         (point-to-point over the direct xGMI link); returns what finish_halo_exchange needs.  With RCCL
         the transfers run on its own stream, ordered after the work already enqueued on the session's
-        stream -- i.e. after the EDGE rows of the frame -- and overlap what is enqueued next."""
+        stream (the frame, or its edge bands when the session was cut into three or more bands)."""
         if self.world == 1:
             return None
         import torch.distributed as dist
@@ -354,9 +366,11 @@ class StripRenderer:
 
     # -- rendering ----------------------------------------------------------------------
     def run_frames(self, first: int, count: int, collect_last: bool = False):
-        """Enqueue `count` accumulation frames.  Strips render each frame in two launches -- the edge
-        rows (the neighbours' halos) first, then the interior -- and exchange the halos in between, so
-        that the transfer overlaps the interior; the next frame waits for the halos only."""
+        """Enqueue `count` accumulation frames.  Peer halos (the default on the product backend): one call into the
+        library, the strips pull their neighbours' rows on the device.  Classic exchange (the fall-back, and the CPU
+        emulator's path): per frame a point-to-point exchange posted from here -- with frames in flight between the
+        merges; with the fused kernel after the frame (a one-band session renders the whole strip in part 1 of
+        enqueue_frame_part, so the transfer does NOT overlap the frame; bands >= 3 would split edge and interior)."""
         if self.world == 1:
             self.session.enqueue_frames(first, count, collect_last)
             return

@@ -568,6 +568,24 @@ def test_random_scenes_are_bit_identical_to_the_oracle(f3d, oracle, seed):
     _same(f3d.hybrid_render_terrain_reference(dem, size[0], size[1], cam, **kw), want)
 
 
+def test_dem_just_past_a_power_of_two_at_the_default_budget(f3d, oracle):
+    """A 2050-texel DEM (2049 cells: the pitch of every table rounds up to 4096) rendered through the one-shot ABI at the
+    DEFAULT 512 MiB budget (the reference's MEMORY_BUDGET_LIMIT): it fits -- 157 MB of tables here, 196 MB in the
+    reference's layout -- and equals the oracle (round-1 advice: no test rendered such a DEM under the default gate)."""
+    n = 2050
+    t = np.arange(n, dtype=np.float32)
+    dem = (700.0 + 500.0 * np.sin(t * 0.0123)[None, :] * np.cos(t * 0.0071)[:, None] + 30.0 * np.sin(t * 0.19)[:, None] * np.sin(t * 0.23)[None, :]).astype(np.float32)
+    span = (n - 1) * 10.0
+    cam = {"origin": (0.4 * span, 2400.0, 0.45 * span), "look_at": (0.0, 600.0, 0.0), "up": (0.0, 1.0, 0.0), "fov_y": 48.0, "exposure": 1.0}
+    kw = dict(spacing=(10.0, 10.0), exaggeration=1.0, sun_azimuth_deg=210.0, sun_elevation_deg=22.0, spp=2, max_frames=3, min_frames=3,
+              variance_threshold=1e30)
+    got = f3d.hybrid_render_terrain_reference(dem, 200, 120, cam, **kw)
+    want = oracle.render(dem, 200, 120, cam, **kw)
+    assert got["gpu_resource_bytes"] <= 512 << 20 and got["minmax_pyramid_bytes"] > 100_000_000
+    for key in ("rgba", "albedo", "normal", "depth"):
+        assert np.array_equal(got[key], want[key], equal_nan=True), key
+
+
 def test_maximum_dem_size_matches_the_oracle(f3d, oracle):
     """The largest heightfield the reference accepts (8193 texels per side = 8192 cells, the 13-bit node
     packing of hybrid_terrain_traversal.wgsl:143-146): 14 levels, 67 M cells, ~2 GB of tables -- index
