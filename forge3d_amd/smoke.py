@@ -121,6 +121,77 @@ class SmokeRenderSettings:
         return f"SmokeRenderSettings(extinction={self.extinction}, phase_g={self.phase_g}, max_steps={self.max_steps})"
 
 
+_STATE_FIELDS = ("density", "temperature", "fuel", "soot", "humidity", "emission_rate", "particle_age", "velocity", "pressure")
+
+
+class _State(C.Structure):
+    """f3d_smoke_state"""
+    _fields_ = [(name, C.c_void_p) for name in _STATE_FIELDS] + [("dims", C.c_uint32 * 3), ("voxel_size", C.c_float * 3), ("origin", C.c_float * 3),
+                                                                 ("sparse_threshold", C.c_float), ("time_seconds", C.c_float), ("frame_index", C.c_uint32)]
+
+
+class _StepSettings(C.Structure):
+    """f3d_smoke_step_settings"""
+    _fields_ = [("dt", C.c_float), ("density_decay", C.c_float), ("temperature_decay", C.c_float), ("velocity_damping", C.c_float),
+                ("diffusion", C.c_float), ("buoyancy", C.c_float), ("vorticity", C.c_float), ("pressure_iterations", C.c_uint32),
+                ("turbulence_strength", C.c_float), ("turbulence_seed", C.c_uint32), ("mac_cormack", C.c_int32), ("mass_conservation", C.c_int32),
+                ("terrain_collision", C.c_int32), ("boundary_damping", C.c_float), ("wind", C.c_float * 3)]
+
+
+class _Emitter(C.Structure):
+    """f3d_smoke_emitter"""
+    _fields_ = [("center", C.c_float * 3), ("radius", C.c_float), ("density_rate", C.c_float), ("temperature_rate", C.c_float), ("fuel_rate", C.c_float),
+                ("soot_rate", C.c_float), ("humidity_rate", C.c_float), ("emission_rate", C.c_float), ("velocity", C.c_float * 3),
+                ("start_time", C.c_float), ("end_time", C.c_float)]
+
+
+@dataclass
+class SmokeStepSettings:
+    """SmokeStepSettings (reference src/smoke/types.rs:142-226, Python class src/smoke/py.rs:195-265): defaults and validation."""
+    dt: float = 1.0 / 30.0
+    density_decay: float = 0.015
+    temperature_decay: float = 0.08
+    velocity_damping: float = 0.01
+    diffusion: float = 0.0005
+    buoyancy: float = 0.7
+    vorticity: float = 0.12
+    pressure_iterations: int = 20
+    turbulence_strength: float = 0.0
+    turbulence_seed: int = 0
+    mac_cormack: bool = False
+    mass_conservation: bool = True
+    terrain_collision: bool = True
+    boundary_damping: float = 0.0
+    wind: tuple = (0.0, 0.0, 0.0)
+
+    def __post_init__(self):
+        for name in ("dt", "density_decay", "temperature_decay", "velocity_damping", "diffusion", "buoyancy", "vorticity", "turbulence_strength",
+                     "boundary_damping"):
+            if not math.isfinite(getattr(self, name)):
+                raise ValueError(f"{name} must be finite")
+        if self.dt <= 0.0:
+            raise ValueError("dt must be > 0")
+        if min(self.density_decay, self.temperature_decay, self.velocity_damping, self.diffusion, self.vorticity, self.turbulence_strength) < 0.0:
+            raise ValueError("decay, damping, diffusion, vorticity, and turbulence must be >= 0")
+        if not 0.0 <= self.boundary_damping <= 1.0:
+            raise ValueError("boundary_damping must be in [0, 1]")
+        self.wind = _f3(self.wind, "wind")
+
+    def _native(self) -> _StepSettings:
+        s = _StepSettings()
+        for name, _t in _StepSettings._fields_:
+            v = getattr(self, name)
+            if name == "wind":
+                s.wind = (C.c_float * 3)(*v)
+            elif name in ("mac_cormack", "mass_conservation", "terrain_collision"):
+                setattr(s, name, 1 if v else 0)
+            elif name in ("pressure_iterations", "turbulence_seed"):
+                setattr(s, name, int(v))
+            else:
+                setattr(s, name, float(v))
+        return s
+
+
 @dataclass
 class SmokeEmitter:
     """src/smoke/py.rs:20-61 (defaults types.rs:85-101)."""
@@ -176,6 +247,8 @@ class SmokeDomain:
         self.density = np.zeros(shape, np.float32)
         self.temperature = np.zeros(shape, np.float32)
         self.soot = np.zeros(shape, np.float32)
+        self.fuel = np.zeros(shape, np.float32)
+        self.pressure = np.zeros(shape, np.float32)
         self.humidity = np.zeros(shape, np.float32)
         self.emission_rate = np.zeros(shape, np.float32)
         self.particle_age = np.full(shape, -1.0, np.float32)
@@ -252,7 +325,7 @@ class SmokeDomain:
         t = np.clip(d / np.maximum(radius, f(1.0e-6)), f(0.0), f(1.0)).astype(np.float32)
         falloff = (f(1.0) - t * t * (f(3.0) - f(2.0) * t)).astype(np.float32)
         amount = (f(dt) * falloff).astype(np.float32)
-        for name, rate in (("density", emitter.density_rate), ("temperature", emitter.temperature_rate),
+        for name, rate in (("density", emitter.density_rate), ("temperature", emitter.temperature_rate), ("fuel", emitter.fuel_rate),
                            ("soot", emitter.soot_rate), ("humidity", emitter.humidity_rate)):
             field = getattr(self, name)
             field[inside] = np.maximum(field[inside] + f(rate) * amount[inside], f(0.0))
@@ -261,10 +334,42 @@ class SmokeDomain:
         for c in range(3):
             self.velocity[..., c][inside] += f(emitter.velocity[c]) * amount[inside]
 
-    def step(self, settings=None, emitters=None) -> None:
-        raise NotImplementedError(
-            "SmokeDomain.step (the transport solver, reference src/smoke/sim.rs) is outside the offline render path "
-            "forge3d_amd replaces; advance the state with the reference package or load precomputed fields")
+    def step(self, settings: "SmokeStepSettings | None" = None, emitters=None, steps: int = 1) -> None:
+        """SmokeVolume::step (reference src/smoke/sim.rs:47-139, Python SmokeDomain.step, py.rs:466-480) x `steps`, on the
+        GPU (csrc/f3d_smoke_sim.hip: one launch per pass, a lane per voxel): emitters, forces, advection, diffusion,
+        vorticity confinement, pressure projection, boundaries, sub-grid eddies, decay and ageing.  The state is updated
+        in place; `last_kernel_seconds` holds the device time."""
+        settings = settings or SmokeStepSettings()
+        emitters = list(emitters or [])
+        st = _State()
+        keep = []
+        for name in _STATE_FIELDS:
+            arr = np.ascontiguousarray(getattr(self, name), dtype=np.float32)
+            setattr(self, name, arr)
+            keep.append(arr)
+            setattr(st, name, arr.ctypes.data)
+        st.dims = (C.c_uint32 * 3)(*self._dims)
+        st.voxel_size = (C.c_float * 3)(*self._voxel)
+        st.origin = (C.c_float * 3)(*self._origin)
+        st.sparse_threshold, st.time_seconds, st.frame_index = float(self.sparse_threshold), float(self.time_seconds), int(self.frame_index) & 0xFFFFFFFF
+        em = (_Emitter * max(1, len(emitters)))()
+        for dst, e in zip(em, emitters):
+            for name, _t in _Emitter._fields_:
+                v = getattr(e, name)
+                setattr(dst, name, (C.c_float * 3)(*v) if name in ("center", "velocity") else float(v))
+        err = C.create_string_buffer(512)
+        seconds = C.c_double(0.0)
+        rc = _native.lib().f3d_smoke_step(C.byref(st), C.byref(settings._native()), em, C.c_uint32(len(emitters)), C.c_uint32(int(steps)),
+                                          C.byref(seconds), err, len(err))
+        if rc != 0:
+            message = err.value.decode("utf-8", "replace")
+            raise (ValueError if rc == _native.STATUS_VALUE else RuntimeError)(message)
+        self.time_seconds, self.frame_index = float(st.time_seconds), int(st.frame_index)
+        self.last_kernel_seconds = float(seconds.value)
+
+    def mass(self) -> float:
+        """SmokeVolume::mass (types.rs:407-409)."""
+        return float(np.sum(self.density, dtype=np.float64))
 
     def to_density_numpy(self) -> np.ndarray:
         return self.density.copy()

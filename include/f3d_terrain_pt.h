@@ -335,6 +335,36 @@ typedef struct f3d_smoke_settings { /* SmokeRenderSettings, reference src/smoke/
 int f3d_smoke_render(const f3d_smoke_volume *volume, const f3d_smoke_view *view, const f3d_smoke_settings *settings,
                      uint8_t *rgba, double *kernel_seconds, char *err, size_t errlen);
 
+/* ---- smoke transport solver (the 120-frame sequence of BASELINE.json configs[4] needs its fields from somewhere) -----------
+ * Replaces SmokeVolume::step / add_emitter (reference src/smoke/sim.rs:7-139, bound to Python as SmokeDomain.step,
+ * src/smoke/py.rs:459-480; single-threaded host code there): `steps` steps of the solver on the device -- emitters,
+ * forces (wind, buoyancy, procedural turbulence), semi-Lagrangian / MacCormack advection, diffusion, vorticity
+ * confinement, Jacobi pressure projection, boundary damping, sub-grid density eddies, decay and ageing.  All fields are
+ * caller-owned HOST arrays, read and written in place ((nz, ny, nx) f32, velocity (nz, ny, nx, 3)). */
+typedef struct f3d_smoke_state {
+    float *density, *temperature, *fuel, *soot, *humidity, *emission_rate, *particle_age, *velocity, *pressure;
+    uint32_t dims[3];
+    float voxel_size[3], origin[3];
+    float sparse_threshold; /* SmokeDomainConfig::sparse_threshold (default 1e-5) */
+    float time_seconds;     /* in/out */
+    uint32_t frame_index;   /* in/out */
+} f3d_smoke_state;
+typedef struct f3d_smoke_step_settings { /* SmokeStepSettings, reference src/smoke/types.rs:142-180 */
+    float dt, density_decay, temperature_decay, velocity_damping, diffusion, buoyancy, vorticity;
+    uint32_t pressure_iterations;
+    float turbulence_strength;
+    uint32_t turbulence_seed;
+    int32_t mac_cormack, mass_conservation, terrain_collision;
+    float boundary_damping;
+    float wind[3];
+} f3d_smoke_step_settings;
+typedef struct f3d_smoke_emitter { /* SmokeEmitter, reference src/smoke/types.rs:69-99 */
+    float center[3], radius, density_rate, temperature_rate, fuel_rate, soot_rate, humidity_rate, emission_rate, velocity[3], start_time,
+        end_time;
+} f3d_smoke_emitter;
+int f3d_smoke_step(f3d_smoke_state *state, const f3d_smoke_step_settings *settings, const f3d_smoke_emitter *emitters,
+                   uint32_t emitter_count, uint32_t steps, double *device_seconds, char *err, size_t errlen);
+
 /* ---- test hooks (KATs restated from the reference's Rust unit tests) ----------- */
 /* build_minmax_mips on the GPU (reference terrain_heightfield.rs:132-202); output in
  * the reference's layout: levels back to back, finest first, each (ph, pw, 2) f32;

@@ -335,3 +335,20 @@ def wavefront_render(scene, width, height, frames, first_frame=0, accum=None):
     if rc != 0:
         _native.raise_status(rc, err.value.decode(errors="replace"))
     return {"accum": acc, "path_vertices": int(vertices.value)}
+
+
+def smoke_step(state, emitters=(), steps=1, **settings):
+    """The smoke solver's device code (csrc/f3d_smoke_sim.h) compiled for the host: `steps` steps in place on a
+    smoke_oracle.new_state() dict."""
+    from forge3d_amd import smoke as product
+    from oracle import smoke_oracle as so
+
+    v, keep = so.sim_structs(state, product._State)
+    s = so.settings_struct(product._StepSettings, **settings)
+    em = so.emitter_array(list(emitters), product._Emitter)
+    L = lib()
+    L.emul_smoke_step.restype = C.c_int
+    if L.emul_smoke_step(C.byref(v), C.byref(s), em, C.c_uint32(len(emitters)), C.c_uint32(int(steps))) != 0:
+        raise RuntimeError("emul_smoke_step failed")
+    state["time_seconds"], state["frame_index"] = float(v.time_seconds), int(v.frame_index)
+    return state

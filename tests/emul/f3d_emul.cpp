@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../forge3d_amd/csrc/f3d_setup.h"
+#include "../../forge3d_amd/csrc/f3d_smoke_sim.h"
 #include "../../forge3d_amd/csrc/f3d_shade.h"
 #include "../../forge3d_amd/csrc/f3d_wf_host.h"
 
@@ -1026,6 +1027,110 @@ int emul_wavefront_render(const f3d_wf_scene *scene, uint32_t width, uint32_t he
     } catch (const Failure &f) {
         return report(f, err, errlen);
     }
+}
+
+// The smoke transport solver's per-voxel code (f3d_smoke_sim.h) on the host, the passes in the order f3d_smoke_sim.hip
+// launches them (SmokeVolume::step, sim.rs:47-139).
+int emul_smoke_step(f3d_smoke_state *st, const f3d_smoke_step_settings *settings, const f3d_smoke_emitter *emitters, uint32_t emitter_count,
+                    uint32_t steps) {
+    using namespace f3d::smoke;
+    SimGrid G{st->dims[0], st->dims[1], st->dims[2], st->voxel_size[0], st->voxel_size[1], st->voxel_size[2], st->origin[0], st->origin[1], st->origin[2],
+              st->sparse_threshold, st->time_seconds, st->frame_index};
+    SimFields F{st->density, st->temperature, st->fuel, st->soot, st->humidity, st->emission_rate, st->particle_age, st->velocity, st->pressure};
+    SimSettings S;
+    static_assert(sizeof(SimSettings) == sizeof(f3d_smoke_step_settings) && sizeof(SimEmitter) == sizeof(f3d_smoke_emitter), "layouts differ");
+    memcpy(&S, settings, sizeof(S));
+    const size_t n = (size_t)G.nx * G.ny * G.nz;
+    std::vector<float> tmp_a(n), tmp_b(n), vec_a(3 * n), curl(3 * n), div(n), rows(4 * (size_t)G.ny * G.nz), slabs(4 * (size_t)G.nz);
+    float sums[4] = {0, 0, 0, 0};
+    auto each = [&](auto &&fn) {
+        for (uint32_t z = 0; z < G.nz; z++)
+            for (uint32_t y = 0; y < G.ny; y++)
+                for (uint32_t x = 0; x < G.nx; x++) fn(x, y, z);
+    };
+    auto sum = [&](uint32_t kind) {
+        for (uint32_t z = 0; z < G.nz; z++) {
+            for (uint32_t y = 0; y < G.ny; y++) rows[(size_t)z * G.ny + y] = sim_sum_row(G, F.density, kind, y, z);
+            slabs[z] = sim_sum_seq(rows.data() + (size_t)z * G.ny, G.ny);
+        }
+        return sim_sum_seq(slabs.data(), G.nz);
+    };
+    auto project = [&](uint32_t iterations) {
+        each([&](uint32_t x, uint32_t y, uint32_t z) { sim_divergence(G, F.velocity, div.data(), x, y, z); });
+        std::fill(F.pressure, F.pressure + n, 0.0f);
+        float *cur = F.pressure, *next = tmp_a.data();
+        for (uint32_t it = 0; it < iterations; it++) {
+            each([&](uint32_t x, uint32_t y, uint32_t z) { sim_jacobi(G, cur, div.data(), next, x, y, z); });
+            std::swap(cur, next);
+        }
+        if (cur != F.pressure) memcpy(F.pressure, cur, n * sizeof(float));
+        each([&](uint32_t x, uint32_t y, uint32_t z) { sim_subtract_gradient(G, F.pressure, F.velocity, x, y, z); });
+    };
+    auto advect = [&](float *field) {
+        each([&](uint32_t x, uint32_t y, uint32_t z) { sim_advect_predict(G, field, F.velocity, tmp_a.data(), S.dt, x, y, z); });
+        if (S.mac_cormack) {
+            each([&](uint32_t x, uint32_t y, uint32_t z) { sim_advect_correct(G, field, F.velocity, tmp_a.data(), tmp_b.data(), S.dt, x, y, z); });
+            memcpy(field, tmp_b.data(), n * sizeof(float));
+        } else {
+            memcpy(field, tmp_a.data(), n * sizeof(float));
+        }
+    };
+    for (uint32_t step = 0; step < steps; step++) {
+        std::fill(F.emission_rate, F.emission_rate + n, 0.0f);
+        for (uint32_t e = 0; e < emitter_count; e++)
+            if (G.time_seconds >= emitters[e].start_time && G.time_seconds <= emitters[e].end_time) {
+                SimEmitter E;
+                memcpy(&E, &emitters[e], sizeof(E));
+                each([&](uint32_t x, uint32_t y, uint32_t z) { sim_emit(G, F, E, S.dt, x, y, z); });
+            }
+        each([&](uint32_t x, uint32_t y, uint32_t z) { sim_forces(G, F, S, x, y, z); });
+        memcpy(vec_a.data(), F.velocity, 3 * n * sizeof(float));
+        each([&](uint32_t x, uint32_t y, uint32_t z) { sim_advect_vector(G, vec_a.data(), F.velocity, S.dt, x, y, z); });
+        if (S.diffusion > 0.0f) {
+            memcpy(vec_a.data(), F.velocity, 3 * n * sizeof(float));
+            for (uint32_t c = 0; c < 3u; c++)
+                each([&](uint32_t x, uint32_t y, uint32_t z) { sim_diffuse(G, vec_a.data(), F.velocity, S.diffusion * S.dt, 3u, c, x, y, z); });
+        }
+        if (S.vorticity > 0.0f) {
+            each([&](uint32_t x, uint32_t y, uint32_t z) { sim_curl(G, F.velocity, curl.data(), tmp_a.data(), x, y, z); });
+            each([&](uint32_t x, uint32_t y, uint32_t z) { sim_confine(G, curl.data(), tmp_a.data(), F.velocity, S.vorticity, S.dt, x, y, z); });
+        }
+        project(std::max(1u, S.pressure_iterations));
+        each([&](uint32_t x, uint32_t y, uint32_t z) { sim_boundary(G, F, S, x, y, z); });
+        if (S.turbulence_strength > 0.0f) {
+            sums[0] = sum(1u);
+            sums[1] = sum(2u);
+            sums[2] = sum(3u);
+            each([&](uint32_t x, uint32_t y, uint32_t z) { sim_lane_shear(G, F, S, sums, x, y, z); });
+        }
+        if (S.mass_conservation) sums[3] = sum(0u);
+        advect(F.density);
+        if (S.mass_conservation) {
+            sums[0] = sum(0u);
+            if (sums[3] > 0.0f && sums[0] > 1.0e-12f)
+                for (size_t i = 0; i < n; i++) F.density[i] *= sums[3] / sums[0];
+        }
+        advect(F.temperature);
+        advect(F.fuel);
+        advect(F.soot);
+        advect(F.humidity);
+        each([&](uint32_t x, uint32_t y, uint32_t z) { sim_subgrid(G, F, S, x, y, z); });
+        if (S.diffusion > 0.0f) {
+            float *fields[5] = {F.density, F.temperature, F.fuel, F.soot, F.humidity};
+            for (float *f : fields) {
+                each([&](uint32_t x, uint32_t y, uint32_t z) { sim_diffuse(G, f, tmp_a.data(), S.diffusion * S.dt, 1u, 0u, x, y, z); });
+                memcpy(f, tmp_a.data(), n * sizeof(float));
+            }
+        }
+        for (size_t i = 0; i < n; i++) sim_decay(G, F, S, i);
+        project(std::max(1u, S.pressure_iterations / 2u));
+        each([&](uint32_t x, uint32_t y, uint32_t z) { sim_boundary(G, F, S, x, y, z); });
+        G.time_seconds += S.dt;
+        G.frame_index += 1u;
+    }
+    st->time_seconds = G.time_seconds;
+    st->frame_index = G.frame_index;
+    return 0;
 }
 
 }  // extern "C"
