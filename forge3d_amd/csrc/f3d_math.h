@@ -231,6 +231,39 @@ F3D_HD float exp_det(float x) {
     return y * f_from_bits((uint32_t)(e + 127) << 23);
 }
 
+// natural log of a positive normal float (cephes logf scheme), every operation spelled
+F3D_HD float log_det(float x) {
+    const uint32_t b = f_bits(x);
+    int e = (int)(b >> 23) - 126;
+    float m = f_from_bits((b & 0x007FFFFFu) | 0x3F000000u);
+    if (m < 0.707106781186547524f) {
+        e -= 1;
+        m = (m + m) - 1.0f;
+    } else {
+        m = m - 1.0f;
+    }
+    const float z = m * m;
+    float p = f_fma(7.0376836292e-2f, m, -1.1514610310e-1f);
+    p = f_fma(p, m, 1.1676998740e-1f);
+    p = f_fma(p, m, -1.2420140846e-1f);
+    p = f_fma(p, m, 1.4249322787e-1f);
+    p = f_fma(p, m, -1.6668057665e-1f);
+    p = f_fma(p, m, 2.0000714765e-1f);
+    p = f_fma(p, m, -2.4999993993e-1f);
+    p = f_fma(p, m, 3.3333331174e-1f);
+    float y = (p * m) * z;
+    const float fe = (float)e;
+    y = f_fma(-2.12194440e-4f, fe, y);
+    y = f_fma(-0.5f, z, y);
+    const float r = m + y;
+    return f_fma(0.693359375f, fe, r);
+}
+F3D_HD float pow_det(float x, float y) {  // x >= 0, y > 0
+    if (!(x > 0.0f)) return 0.0f;
+    if (x < 1.17549435e-38f) return 0.0f;
+    return exp_det(y * log_det(x));
+}
+
 // ---- IEEE binary16 storage rounding (RGBA16F targets of the reference) ----
 F3D_HD uint16_t half_bits(float f) {
     uint32_t x = f_bits(f);

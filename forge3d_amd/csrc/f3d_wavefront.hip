@@ -120,7 +120,7 @@ __global__ void k_wf_resolve(const ResolveParamsWf R) {
         for (int k = 0; k < 3; k++) {
             const float x = f_max(m[k], 0.0f) * R.exposure;
             const float t = x / (1.0f + x);
-            const float s = t <= 0.0031308f ? 12.92f * t : 1.055f * wf::pow_det(t, 1.0f / 2.4f) - 0.055f;
+            const float s = t <= 0.0031308f ? 12.92f * t : 1.055f * pow_det(t, 1.0f / 2.4f) - 0.055f;
             c[k] = (uint8_t)(f_clamp(s, 0.0f, 1.0f) * 255.0f + 0.5f);
         }
         R.rgba[i] = uchar4{c[0], c[1], c[2], 255};

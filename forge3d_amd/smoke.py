@@ -436,6 +436,94 @@ def domain_from_density(density, voxel_size=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0
     return SmokeDomain.from_density(density, voxel_size, origin)
 
 
+class _CompositeDesc(C.Structure):
+    """f3d_composite_desc"""
+    _fields_ = [("struct_size", C.c_uint32), ("mode", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32), ("layer_width", C.c_uint32),
+                ("layer_height", C.c_uint32), ("offset_x", C.c_int32), ("offset_y", C.c_int32), ("base", C.c_void_p), ("layer", C.c_void_p),
+                ("base_alpha", C.c_float), ("layer_alpha", C.c_float), ("max_alpha", C.c_uint32)]
+
+
+COMPOSITE_ATMOSPHERIC, COMPOSITE_SMOKE_MAPS, COMPOSITE_OVER = 0, 1, 2
+HYBRID_SMOKE_MAX_ALPHA = 168  # reference examples/california_cigar_smoke_demo.py:58
+
+
+def _rgba8(image, name):
+    arr = np.ascontiguousarray(np.asarray(image), dtype=np.uint8)
+    if arr.ndim != 3 or arr.shape[2] != 4:
+        raise ValueError(f"{name} must be an (H, W, 4) uint8 RGBA image")
+    return arr
+
+
+def composite_desc(mode, base, layer, offset=(0, 0), base_alpha=0.0, layer_alpha=0.0, max_alpha=HYBRID_SMOKE_MAX_ALPHA):
+    """f3d_composite_desc over two numpy images (the arrays must outlive the call that uses it)."""
+    d = _CompositeDesc()
+    d.struct_size, d.mode = C.sizeof(_CompositeDesc), int(mode)
+    d.height, d.width = base.shape[:2]
+    d.base = base.ctypes.data
+    if layer is not None:
+        d.layer_height, d.layer_width = layer.shape[:2]
+        d.layer = layer.ctypes.data
+    d.offset_x, d.offset_y = int(offset[0]), int(offset[1])
+    d.base_alpha, d.layer_alpha, d.max_alpha = float(base_alpha), float(layer_alpha), int(max_alpha)
+    return d
+
+
+def _composite(mode, base, layer, **kw):
+    base = _rgba8(base, "base")
+    layer = None if layer is None else _rgba8(layer, "layer")
+    desc = composite_desc(mode, base, layer, **kw)
+    out = np.empty_like(base)
+    err = C.create_string_buffer(512)
+    seconds = C.c_double(0.0)
+    rc = _native.lib().f3d_smoke_composite(C.byref(desc), out.ctypes.data, C.byref(seconds), err, len(err))
+    if rc != 0:
+        message = err.value.decode("utf-8", "replace")
+        raise (ValueError if rc == _native.STATUS_VALUE else RuntimeError)(message)
+    _composite.last_kernel_seconds = float(seconds.value)
+    return out
+
+
+def composite_atmospheric_smoke(base_rgba, smoke_rgba) -> np.ndarray:
+    """A smoke layer (SmokeDomain.render_rgba / render_projection_rgba) as an optical veil over a terrain frame:
+    transmittance, back-scatter and warm glow-through per pixel; the result is opaque.  Reference
+    examples/california_cigar_smoke_demo.py:8527-8544 (which takes and returns PIL images of the same bytes)."""
+    return _composite(COMPOSITE_ATMOSPHERIC, base_rgba, smoke_rgba)
+
+
+def composite_main_smoke_maps(atmospheric_rgba, physical_rgba=None, *, atmospheric_alpha=0.42, physical_alpha=0.92,
+                              max_alpha=HYBRID_SMOKE_MAX_ALPHA) -> np.ndarray:
+    """The atmospheric blanket with the physical (solver) detail over it, alpha capped (reference :3367-3380)."""
+    return _composite(COMPOSITE_SMOKE_MAPS, atmospheric_rgba, physical_rgba, base_alpha=atmospheric_alpha, layer_alpha=physical_alpha,
+                      max_alpha=max_alpha)
+
+
+def alpha_composite(base_rgba, layer_rgba, offset=(0, 0)) -> np.ndarray:
+    """PIL.Image.alpha_composite(base, layer) with the layer's top-left corner at `offset` (clipped to the base), the
+    operation composite_volume_detail (:8721-8725) and _shift_rgba (:3335-3349) of the reference example end in."""
+    return _composite(COMPOSITE_OVER, base_rgba, layer_rgba, offset=offset)
+
+
+def render_over_terrain(terrain_rgba, domain: "SmokeDomain", camera_pos, target, **kwargs) -> np.ndarray:
+    """One frame of BASELINE.json configs[4]: `domain` ray-marched from the camera of the terrain frame and laid over it
+    (terrain_rgba: the (H, W, 4) uint8 image of hybrid_render_terrain_reference for the same camera)."""
+    terrain_rgba = _rgba8(terrain_rgba, "terrain_rgba")
+    h, w = terrain_rgba.shape[:2]
+    return composite_atmospheric_smoke(terrain_rgba, domain.render_rgba(w, h, camera_pos, target, **kwargs))
+
+
+def simulate_over_terrain(terrain_rgba, domain: "SmokeDomain", settings, emitters, frames, camera_pos, target, *, steps_per_frame=1, rank=0,
+                          world=1, **kwargs):
+    """configs[4] end to end: `frames` frames of emitters -> solver -> ray-marcher -> composite over one terrain frame.
+    The solver is sequential in time, so every rank advances the same state (identical bits on every GPU) and renders
+    only frames rank, rank + world, ...: returns {frame index: (H, W, 4) uint8} for this rank."""
+    out = {}
+    for f in range(int(frames)):
+        domain.step(settings, emitters, steps=steps_per_frame)
+        if f % world == rank:
+            out[f] = render_over_terrain(terrain_rgba, domain, camera_pos, target, **kwargs)
+    return out
+
+
 def render_sequence(frames: "Sequence[SmokeDomain]", width, height, camera_pos, target, *, rank=0, world=1, **kwargs):
     """Frames of an animation are independent: rank r renders frames r, r + world, ...; with an initialised
     torch.distributed process group the images are gathered on rank 0 (list in frame order; None elsewhere)."""

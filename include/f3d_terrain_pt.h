@@ -365,6 +365,34 @@ typedef struct f3d_smoke_emitter { /* SmokeEmitter, reference src/smoke/types.rs
 int f3d_smoke_step(f3d_smoke_state *state, const f3d_smoke_step_settings *settings, const f3d_smoke_emitter *emitters,
                    uint32_t emitter_count, uint32_t steps, double *device_seconds, char *err, size_t errlen);
 
+/* ---- smoke over terrain: the per-pixel composites of BASELINE.json configs[4] ----
+ * The reference builds each frame of its smoke sequence on the host with numpy and Pillow
+ * (examples/california_cigar_smoke_demo.py, tested by tests/test_california_cigar_smoke_hybrid.py);
+ * these are the same three operations as one device pass over RGBA8 images:
+ *   F3D_COMPOSITE_ATMOSPHERIC  composite_atmospheric_smoke(base, layer)   :8527-8544 -- a ray-marched smoke layer
+ *                              (f3d_smoke_render) over a path-traced terrain frame; the output alpha is 255
+ *   F3D_COMPOSITE_SMOKE_MAPS   composite_main_smoke_maps(base = atmospheric, layer = physical or NULL,
+ *                              base_alpha, layer_alpha) :3367-3380, alpha capped at max_alpha
+ *   F3D_COMPOSITE_OVER         PIL.Image.alpha_composite(base, layer placed at offset) (:8721-8725, :3335-3349);
+ *                              the layer may have its own size and is clipped to the base
+ * base, layer and out may be host or device pointers (width * height * 4 bytes, rows tightly packed); out may
+ * alias base.  kernel_seconds (may be NULL) receives the device time of the pass. */
+#define F3D_COMPOSITE_ATMOSPHERIC 0u
+#define F3D_COMPOSITE_SMOKE_MAPS 1u
+#define F3D_COMPOSITE_OVER 2u
+typedef struct f3d_composite_desc {
+    uint32_t struct_size; /* sizeof(f3d_composite_desc) of the caller's header */
+    uint32_t mode;
+    uint32_t width, height;             /* base and output */
+    uint32_t layer_width, layer_height; /* must equal width, height except in F3D_COMPOSITE_OVER */
+    int32_t offset_x, offset_y;         /* F3D_COMPOSITE_OVER only, else 0 */
+    const uint8_t *base;
+    const uint8_t *layer; /* NULL only in F3D_COMPOSITE_SMOKE_MAPS (`physical_rgba is None`) */
+    float base_alpha, layer_alpha; /* F3D_COMPOSITE_SMOKE_MAPS: atmospheric_alpha (0.42), physical_alpha (0.92) */
+    uint32_t max_alpha;            /* F3D_COMPOSITE_SMOKE_MAPS: HYBRID_SMOKE_MAX_ALPHA (168) */
+} f3d_composite_desc;
+int f3d_smoke_composite(const f3d_composite_desc *desc, uint8_t *out_rgba, double *kernel_seconds, char *err, size_t errlen);
+
 /* ---- test hooks (KATs restated from the reference's Rust unit tests) ----------- */
 /* build_minmax_mips on the GPU (reference terrain_heightfield.rs:132-202); output in
  * the reference's layout: levels back to back, finest first, each (ph, pw, 2) f32;

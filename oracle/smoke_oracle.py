@@ -10,6 +10,7 @@ import numpy as np
 _HERE = Path(__file__).resolve().parent
 _SRC, _LIB = _HERE / "smoke_oracle.c", _HERE / "libsmoke_oracle.so"
 _SIM_SRC = _HERE / "smoke_sim_oracle.c"  # the transport solver (SmokeVolume::step)
+_COMPOSITE_SRC = _HERE / "composite_oracle.c"  # smoke over terrain (the example's numpy / Pillow composites)
 
 
 class Volume(C.Structure):
@@ -32,11 +33,11 @@ DEFAULTS = dict(density_scale=1.0, extinction=2.6, scattering=0.85, absorption=0
 
 
 def build(force: bool = False) -> Path:
-    if force or not _LIB.exists() or _LIB.stat().st_mtime < max(_SRC.stat().st_mtime, _SIM_SRC.stat().st_mtime):
+    if force or not _LIB.exists() or _LIB.stat().st_mtime < max(f.stat().st_mtime for f in (_SRC, _SIM_SRC, _COMPOSITE_SRC)):
         import os
 
         tmp = _LIB.with_suffix(f".{os.getpid()}.tmp")
-        subprocess.run(["gcc", "-O2", "-fopenmp", "-ffp-contract=off", "-fPIC", "-shared", str(_SRC), str(_SIM_SRC), "-o", str(tmp), "-lm"],
+        subprocess.run(["gcc", "-O2", "-fopenmp", "-ffp-contract=off", "-fPIC", "-shared", str(_SRC), str(_SIM_SRC), str(_COMPOSITE_SRC), "-o", str(tmp), "-lm"],
                        check=True, capture_output=True)
         os.replace(tmp, _LIB)
     return _LIB
@@ -224,3 +225,38 @@ def mass(state):
 def divergence_l2(state):
     v, keep = sim_structs(state)
     return float(lib().smoke_sim_divergence_l2(C.byref(v)))
+
+
+# ---- smoke over terrain (composite_oracle.c) ----
+def _img(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    assert a.ndim == 3 and a.shape[2] == 4
+    return a
+
+
+def composite_atmospheric(base, smoke) -> np.ndarray:
+    base, smoke = _img(base), _img(smoke)
+    assert base.shape == smoke.shape
+    out = np.empty_like(base)
+    lib().composite_oracle_atmospheric(C.c_void_p(base.ctypes.data), C.c_void_p(smoke.ctypes.data), C.c_uint32(base.shape[1]), C.c_uint32(base.shape[0]),
+                                       C.c_void_p(out.ctypes.data))
+    return out
+
+
+def composite_smoke_maps(atmospheric, physical=None, atmospheric_alpha=0.42, physical_alpha=0.92, max_alpha=168) -> np.ndarray:
+    atmospheric = _img(atmospheric)
+    physical = None if physical is None else _img(physical)
+    out = np.empty_like(atmospheric)
+    lib().composite_oracle_smoke_maps(C.c_void_p(atmospheric.ctypes.data), C.c_void_p(physical.ctypes.data if physical is not None else None),
+                                      C.c_uint32(atmospheric.shape[1]), C.c_uint32(atmospheric.shape[0]), C.c_float(atmospheric_alpha),
+                                      C.c_float(physical_alpha), C.c_uint32(max_alpha), C.c_void_p(out.ctypes.data))
+    return out
+
+
+def composite_over(base, layer, offset=(0, 0)) -> np.ndarray:
+    base, layer = _img(base), _img(layer)
+    out = np.empty_like(base)
+    lib().composite_oracle_over(C.c_void_p(base.ctypes.data), C.c_uint32(base.shape[1]), C.c_uint32(base.shape[0]), C.c_void_p(layer.ctypes.data),
+                                C.c_uint32(layer.shape[1]), C.c_uint32(layer.shape[0]), C.c_int32(int(offset[0])), C.c_int32(int(offset[1])),
+                                C.c_void_p(out.ctypes.data))
+    return out

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../forge3d_amd/csrc/f3d_setup.h"
+#include "../../forge3d_amd/csrc/f3d_composite.h"
 #include "../../forge3d_amd/csrc/f3d_smoke_sim.h"
 #include "../../forge3d_amd/csrc/f3d_shade.h"
 #include "../../forge3d_amd/csrc/f3d_wf_host.h"
@@ -1130,6 +1131,29 @@ int emul_smoke_step(f3d_smoke_state *st, const f3d_smoke_step_settings *settings
     }
     st->time_seconds = G.time_seconds;
     st->frame_index = G.frame_index;
+    return 0;
+}
+
+// The composite pass's per-pixel code (f3d_composite.h) on the host, parameters as f3d_smoke_composite fills them.
+int emul_composite(const f3d_composite_desc *d, uint8_t *out) {
+    using namespace f3d::composite;
+    Params P{};
+    P.mode = d->mode;
+    P.width = d->width;
+    P.height = d->height;
+    P.has_layer = d->layer ? 1u : 0u;
+    P.layer_width = d->layer ? d->layer_width : 0u;
+    P.layer_height = d->layer ? d->layer_height : 0u;
+    P.offset_x = d->offset_x;
+    P.offset_y = d->offset_y;
+    P.base_alpha = d->base_alpha;
+    P.layer_alpha = d->layer_alpha;
+    P.max_alpha = d->max_alpha;
+    P.max_alpha_fraction = (float)((double)d->max_alpha / 255.0);
+    for (uint32_t y = 0; y < P.height; y++)
+        for (uint32_t x = 0; x < P.width; x++)
+            reinterpret_cast<uint32_t *>(out)[(size_t)y * P.width + x] =
+                pixel(P, reinterpret_cast<const uint32_t *>(d->base), reinterpret_cast<const uint32_t *>(d->layer), x, y);
     return 0;
 }
 
