@@ -95,7 +95,25 @@ struct MarchState {
     float t_cur;
     uint32_t level, nx, nz;
     bool marching, unverified_start;
+#if !defined(F3D_NO_BAND_PREFETCH)
+    float band_mn, band_mx;  // the (min,max) band of the node the lane stands in, fetched when it moved there
+#endif
 };
+
+// The band of a node is the one memory access of a step, and the step cannot decide anything before it has arrived.
+// The lane therefore asks for it as soon as it knows where it goes next -- at the END of the previous step -- and the
+// wave votes, the FIFO bookkeeping and the next step's plane arithmetic run while it is on its way
+// (-DF3D_NO_BAND_PREFETCH: fetched where it is needed, the round-2 form; profiles/README.md).
+template <class Ctx>
+F3D_HD void march_fetch(const TerrainDev &T, MarchState &m, Ctx &ctx) {
+#if !defined(F3D_NO_BAND_PREFETCH)
+    uint32_t band_offset, band_shift;
+    ctx.band_entry(T, m.level, band_offset, band_shift);
+    const NodeRec band = T.bands[band_offset + (m.nz << band_shift) + m.nx];
+    m.band_mn = band.mn;
+    m.band_mx = band.mx;
+#endif
+}
 
 // Root slab interval of a ray (:288-297 for the root node): [lo, hi], empty when lo > hi.
 F3D_HD void march_root_interval(const TerrainDev &T, const RayCtx &r, float &lo, float &hi) {
@@ -172,9 +190,13 @@ F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint
     } else {
         const float lo = f_max(enter, r.tmin), hi = f_min(exit, r.tmax);
         // the node's (min,max) band: one 8-byte record of the row-major table of its level
+#if !defined(F3D_NO_BAND_PREFETCH)
+        const NodeRec band{m.band_mn, m.band_mx};
+#else
         uint32_t band_offset, band_shift;
         ctx.band_entry(T, level, band_offset, band_shift);
         const NodeRec band = T.bands[band_offset + (nz << band_shift) + nx];
+#endif
         const bool pass = !(lo > hi) && !march_band_rejects<CURVED>(r, lo, hi, band.mn, band.mx);  // :297-304
         if (pass) ctx.note(-1);  // statistics hook (host emulator only): the last step whose band test passed
         if (pass && level > 0u) {
@@ -256,6 +278,7 @@ F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint
         }
     }
     m.unverified_start = false;
+    if (m.marching) march_fetch(T, m, ctx);
 }
 
 // Drain the lane's leaf FIFO: solve the queued leaves in ray order until one hits.  A TIE entry (any-hit
@@ -456,6 +479,7 @@ F3D_HD bool march_shared(const TerrainDev &T, const RayCtx &own_ray, MarchState 
     res.n = V3{0.0f, 0.0f, 0.0f};
     for (uint32_t round = 0u;; round++) {
         ctx.template deal<CURVED>(T, s, m);  // m.marching now says whether this lane got a slice
+        if (m.marching) march_fetch(T, m, ctx);
         res.hit = false;
         res.t = s.r.tmax;
         bool again = false;
@@ -516,6 +540,7 @@ F3D_HD TraceHit march_terrain_from(const TerrainDev &T, const RayCtx &r, bool an
     ctx.feature(r.d.y);
     uint32_t queued = 0u;
     bool deal = false;
+    if (m.marching) march_fetch(T, m, ctx);
     for (;;) {
         // t_stop (occlusion rays, f3d_cone.h sun_clear_from / ibl_stop): no terrain beyond it, so the lane stops after the node that
         // contains it -- the SLICED rule; node and leaf intervals are NOT clipped by it, every visited node is judged
@@ -593,6 +618,7 @@ F3D_HD void march_stream(const TerrainDev &T, Source &src, Ctx &ctx, uint32_t qu
                 more = src.refill(have, r, t_stop, tag, ctx);
                 if (have && !was) {
                     m = march_begin(T, r, true);  // occlusion rays start on the surface: in the origin's cell
+                    if (m.marching) march_fetch(T, m, ctx);
                     res.hit = false;
                     res.t = r.tmax;
                     queued = 0u;

@@ -394,6 +394,7 @@ int emul_trace_batch(const float *heights, uint32_t w, uint32_t h, float origin_
                         m.unverified_start = true;
                         m.marching = begin <= hi;
                     }
+                    if (m.marching) march_fetch(T, m, pend);  // (what march_terrain_from / march_shared do after placing a lane)
                     uint32_t queued = 0u;
                     TraceHit res;
                     res.hit = false;

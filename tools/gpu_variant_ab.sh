@@ -4,7 +4,7 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 for spec in "$@"; do
   name=${spec%%:*}; v=0; [[ "$spec" == *:* ]] && v=${spec##*:}
-  F3D_HIP_LIBRARY=$PWD/build_ab/libf3dhip_$name.so python bench.py --steps ${STEPS:-16} --warmup 4 --variant $v --no-cpu-baseline --extra-windows 2 --no-terrain-filling 2>&1 | tail -1 | python -c "
+  F3D_HIP_LIBRARY=$PWD/build_ab/libf3dhip_$name.so python bench.py --steps ${STEPS:-16} --warmup 4 --variant $v --no-cpu-baseline --extra-windows 2 --no-terrain-filling --no-configs 2>&1 | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); print('%-10s variant %-8s %.1f Msamples/s  windows %s  rgb %s' % ('$name', '$v', d['value'], d.get('windows_ms_per_step'), d['config']['image_mean_rgb']))" | tee -a gpurun_out/variant_ab.log
 done
