@@ -258,3 +258,116 @@ def load_heightmap(path, fill_nodata: bool = True) -> np.ndarray:
     if dem.ndim != 2:
         raise ValueError("heightmap must be a 2-D array")
     return np.ascontiguousarray(dem, np.float32)
+
+
+# ---- Radiance .hdr / .rgbe environment maps ---------------------------------------------------------------------------
+class HdrError(ValueError):
+    """A file that is not a readable Radiance picture."""
+
+
+def _hdr_rows(buf: memoryview, pos: int, width: int, height: int) -> np.ndarray:
+    """(height, width, 4) uint8 RGBE from the scanline section: per row either the adaptive run-length form (2, 2,
+    width hi, width lo, then the four components one after the other as runs: count > 128 repeats one byte count - 128
+    times, otherwise `count` literal bytes) or `width` flat pixels."""
+    out = np.empty((height, width, 4), np.uint8)
+    n = len(buf)
+    for y in range(height):
+        if pos + 4 > n:
+            raise HdrError(f"Failed to read scanline header at row {y}: file ends")
+        head = bytes(buf[pos:pos + 4])
+        if head[0] == 2 and head[1] == 2 and head[2] == ((width >> 8) & 0xFF) and head[3] == (width & 0xFF):
+            pos += 4
+            for c in range(4):
+                x = 0
+                row = out[y, :, c]
+                while x < width:
+                    if pos >= n:
+                        raise HdrError("Failed to read RLE run info: file ends")
+                    count = buf[pos]
+                    pos += 1
+                    if count > 128:
+                        count -= 128
+                        if x + count > width:
+                            raise HdrError("HDR RLE run exceeds scanline width")
+                        if pos >= n:
+                            raise HdrError("Failed to read RLE repeat value: file ends")
+                        row[x:x + count] = buf[pos]
+                        pos += 1
+                    else:
+                        if x + count > width:
+                            raise HdrError("HDR literal run exceeds scanline width")
+                        if pos + count > n:
+                            raise HdrError("Failed to read literal value: file ends")
+                        row[x:x + count] = np.frombuffer(buf[pos:pos + count], np.uint8)
+                        pos += count
+                    x += count
+        else:
+            if pos + 4 * width > n:
+                raise HdrError(f"Failed to read pixel data at row {y}: file ends")
+            out[y] = np.frombuffer(buf[pos:pos + 4 * width], np.uint8).reshape(width, 4)
+            pos += 4 * width
+    return out
+
+
+def read_hdr(path) -> np.ndarray:
+    """A Radiance picture as (H, W, 3) float32 linear RGB, rows in file order.  Behaviour of the reference's loader
+    (src/formats/hdr.rs:49-288): magic `#?RADIANCE` or `#?RGBE`; a FORMAT= line is required and must be
+    32-bit_rle_rgbe or 32-bit_rle_xyze; the resolution line is four tokens of which the second is the height and the
+    fourth the width (orientation flags are not interpreted); a pixel (r, g, b, e) is (r, g, b) * 2^(e - 136), all
+    zero when e == 0 (no half-step offset)."""
+    data = Path(path).read_bytes()
+    end = data.find(b"\n")
+    first = data[:end + 1 if end >= 0 else len(data)]
+    if not (first.startswith(b"#?RADIANCE") or first.startswith(b"#?RGBE")):
+        raise HdrError("Invalid HDR file: missing magic header")
+    pos, fmt = len(first), False
+    while pos < len(data):
+        end = data.find(b"\n", pos)
+        end = len(data) if end < 0 else end + 1
+        line = data[pos:end].decode("latin-1").strip()
+        pos = end
+        if not line:
+            break
+        if line.startswith("FORMAT="):
+            if line not in ("FORMAT=32-bit_rle_rgbe", "FORMAT=32-bit_rle_xyze"):
+                raise HdrError(f"Unsupported HDR format: {line}")
+            fmt = True
+    if not fmt:
+        raise HdrError("HDR file missing FORMAT specification")
+    end = data.find(b"\n", pos)
+    end = len(data) if end < 0 else end + 1
+    resolution = data[pos:end].decode("latin-1").strip()
+    parts = resolution.split()
+    if len(parts) != 4:
+        raise HdrError(f"Invalid HDR resolution line: {resolution}")
+    try:
+        height = int(parts[1])
+    except ValueError:
+        raise HdrError(f"Invalid HDR height: {parts[1]}") from None
+    try:
+        width = int(parts[3])
+    except ValueError:
+        raise HdrError(f"Invalid HDR width: {parts[3]}") from None
+    if width <= 0 or height <= 0:
+        raise HdrError("HDR image dimensions cannot be zero")
+    rgbe = _hdr_rows(memoryview(data), end, width, height)
+    scale = np.ldexp(np.float32(1.0), rgbe[..., 3].astype(np.int32) - 136).astype(np.float32)
+    scale[rgbe[..., 3] == 0] = 0.0
+    return rgbe[..., :3].astype(np.float32) * scale[..., None]
+
+
+def write_hdr(path, rgb: np.ndarray) -> None:
+    """(H, W, 3) float32 -> flat (uncompressed) Radiance picture; the shared exponent is that of the largest channel,
+    mantissas truncated (what `read_hdr` inverts up to the 8-bit mantissa)."""
+    rgb = np.ascontiguousarray(rgb, np.float32)
+    if rgb.ndim != 3 or rgb.shape[2] != 3:
+        raise ValueError("rgb must be (H, W, 3)")
+    top = np.max(rgb, axis=2)
+    mant, exp = np.frexp(top)  # top = mant * 2^exp, mant in [0.5, 1)
+    valid = top > 1e-32
+    scale = np.where(valid, np.ldexp(np.float32(1.0), 8 - exp), 0.0).astype(np.float32)
+    out = np.zeros(rgb.shape[:2] + (4,), np.uint8)
+    out[..., :3] = np.clip(rgb * scale[..., None], 0.0, 255.0).astype(np.uint8)
+    out[..., 3] = np.where(valid, exp + 128, 0).astype(np.uint8)
+    h, w = rgb.shape[:2]
+    Path(path).write_bytes(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n" + f"-Y {h} +X {w}\n".encode() + out.tobytes())

@@ -69,8 +69,19 @@ class ViewerHandle(OfflineTerrainViewer):
         self._revision += 1
 
     def set_ibl(self, path: Union[str, Path, np.ndarray], intensity: float = 1.0) -> None:
-        """Environment map: an (H, W, 3) float32 array or a .npy file of one (the reference loads .hdr files)."""
-        env = path if isinstance(path, np.ndarray) else np.load(Path(path))
+        """Environment map: a Radiance .hdr / .rgbe file (reference viewer.py:1147, loader src/formats/hdr.rs), an
+        (H, W, 3) float32 array, or a .npy file of one."""
+        if isinstance(path, np.ndarray):
+            env = path
+        elif Path(path).suffix.lower() in (".hdr", ".rgbe"):
+            try:
+                env = _io.read_hdr(path)
+            except (OSError, _io.HdrError) as exc:
+                raise ViewerError(str(exc)) from exc
+        elif Path(path).suffix.lower() == ".npy":
+            env = np.load(Path(path))
+        else:
+            raise ViewerError(f"Unsupported environment map format '{Path(path).suffix}' for '{path}': expected .hdr, .rgbe or .npy")
         env = np.ascontiguousarray(env, np.float32)
         if env.ndim != 3 or env.shape[2] != 3:
             raise ViewerError(f"environment map must be (H, W, 3) float32, got {env.shape}")

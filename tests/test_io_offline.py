@@ -245,3 +245,94 @@ def test_viewer_handle_animation_reuses_the_cached_scene(tmp_path):
     L.f3d_scene_cache_limit(0)
     assert L.f3d_scene_cache_entries() == 0
     L.f3d_scene_cache_limit(2)
+
+
+# ---- Radiance .hdr environment maps (reference src/formats/hdr.rs; its unit tests :290-378 restated) ----
+def _hdr_file(tmp_path, body: bytes, header=b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n", res=b"-Y 2 +X 4\n", name="e.hdr"):
+    p = tmp_path / name
+    p.write_bytes(header + res + body)
+    return p
+
+
+def test_hdr_pixel_rule_and_flat_files(tmp_path):
+    from forge3d_amd import io
+
+    # load_hdr_uncompressed_round_trip_dims_and_values (:345-378): 4 x 2 pixels of (128, 64, 32, 129)
+    img = io.read_hdr(_hdr_file(tmp_path, bytes([128, 64, 32, 129]) * 8))
+    assert img.shape == (2, 4, 3) and img.dtype == np.float32
+    exp = 2.0 ** (129 - 128 - 8)
+    assert np.array_equal(img, np.broadcast_to(np.float32([128 * exp, 64 * exp, 32 * exp]), (2, 4, 3)))
+    # test_rgbe_to_rgb_zero / _nonzero / _bright (:292-326)
+    px = io.read_hdr(_hdr_file(tmp_path, bytes([10, 20, 30, 0, 128, 128, 128, 128, 255, 128, 64, 140]), res=b"-Y 1 +X 3\n"))
+    assert np.array_equal(px[0, 0], [0.0, 0.0, 0.0])
+    assert np.array_equal(px[0, 1], [0.5, 0.5, 0.5])
+    assert np.array_equal(px[0, 2], [255 * 16.0, 128 * 16.0, 64 * 16.0])
+    # `#?RGBE` magic and the xyze format name are accepted too; the resolution tokens are positional
+    io.read_hdr(_hdr_file(tmp_path, bytes(4 * 8), header=b"#?RGBE\nEXPOSURE=1\nFORMAT=32-bit_rle_xyze\n\n", res=b"+Y 2 +X 4\n"))
+
+
+def test_hdr_run_length_scanlines(tmp_path):
+    from forge3d_amd import io
+
+    w, h = 40, 3
+    rng = np.random.default_rng(4)
+    rgbe = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    rgbe[1, 5:30, 0] = 77  # a run worth encoding
+    body = b""
+    for y in range(h):
+        if y == 2:  # a flat row between run-length rows (its first two bytes must not look like the marker)
+            rgbe[y, 0, 0] = 9
+            body += rgbe[y].tobytes()
+            continue
+        body += bytes([2, 2, w >> 8, w & 255])
+        for c in range(4):
+            col = rgbe[y, :, c]
+            x = 0
+            while x < w:
+                run = 1
+                while x + run < w and run < 127 and col[x + run] == col[x]:
+                    run += 1
+                if run >= 3:
+                    body += bytes([128 + run, col[x]])
+                else:
+                    run = min(w - x, 7)
+                    body += bytes([run]) + col[x:x + run].tobytes()
+                x += run
+    got = io.read_hdr(_hdr_file(tmp_path, body, res=f"-Y {h} +X {w}\n".encode()))
+    scale = np.where(rgbe[..., 3] == 0, 0.0, np.exp2(rgbe[..., 3].astype(np.float64) - 136.0)).astype(np.float32)
+    assert np.array_equal(got, rgbe[..., :3].astype(np.float32) * scale[..., None])
+
+
+def test_hdr_errors_and_round_trip(tmp_path):
+    from forge3d_amd import io
+
+    for kw, message in ((dict(header=b"P6\n\n"), "missing magic header"), (dict(header=b"#?RADIANCE\n\n"), "missing FORMAT"),
+                        (dict(header=b"#?RADIANCE\nFORMAT=32-bit_rle_foo\n\n"), "Unsupported HDR format"),
+                        (dict(res=b"-Y 2\n"), "Invalid HDR resolution line"), (dict(res=b"-Y two +X 4\n"), "Invalid HDR height"),
+                        (dict(res=b"-Y 0 +X 4\n"), "cannot be zero"), (dict(body=bytes(12)), "Failed to read pixel data at row 0"),
+                        (dict(body=bytes([2, 2, 0, 4, 200, 1])), "RLE run exceeds scanline width")):
+        body = kw.pop("body", bytes(32))
+        with pytest.raises(io.HdrError, match=message):
+            io.read_hdr(_hdr_file(tmp_path, body, **kw))
+    rng = np.random.default_rng(2)
+    env = (rng.random((6, 12, 3)) * np.float32(40.0)).astype(np.float32)
+    env[0, 0] = 0.0
+    io.write_hdr(tmp_path / "env.hdr", env)
+    back = io.read_hdr(tmp_path / "env.hdr")
+    assert np.all(np.abs(back - env) <= np.max(env, axis=2, keepdims=True) / 128.0 + 1e-30)  # 8-bit mantissa of the largest channel
+    assert np.array_equal(back[0, 0], [0.0, 0.0, 0.0])
+
+
+def test_viewer_set_ibl_reads_hdr_files(tmp_path):
+    from forge3d_amd import io, viewer
+
+    env = np.full((4, 8, 3), 0.5, np.float32)
+    io.write_hdr(tmp_path / "sky.hdr", env)
+    v = viewer.ViewerHandle.__new__(viewer.ViewerHandle)
+    v._revision = 0
+    v.set_ibl(tmp_path / "sky.hdr", intensity=2.0)
+    assert np.array_equal(v._env, env) and v._env_intensity == 2.0
+    with pytest.raises(viewer.ViewerError, match="Unsupported environment map format"):
+        v.set_ibl(tmp_path / "sky.png")
+    with pytest.raises(viewer.ViewerError):
+        v.set_ibl(tmp_path / "missing.hdr")
