@@ -19,10 +19,11 @@ Everything else forge3d offers (raster viewer, cartography, GIS, ...) is out of 
 """
 from . import atmosphere, denoise, io, offline, smoke, viewer, wavefront  # noqa: F401
 from .io import numpy_to_png, png_to_numpy
+from .atmosphere import hybrid_render_aether_spectral_reference
 from .path_tracing import hybrid_render_terrain_reference
 from .viewer import Renderer, ViewerHandle, open_viewer, open_viewer_async
 from .wavefront import render_adjudication_pt
 
-__all__ = ["hybrid_render_terrain_reference", "atmosphere", "denoise", "io", "offline", "smoke", "viewer", "numpy_to_png",
+__all__ = ["hybrid_render_terrain_reference", "hybrid_render_aether_spectral_reference", "atmosphere", "denoise", "io", "offline", "smoke", "viewer", "numpy_to_png",
            "png_to_numpy", "wavefront", "render_adjudication_pt", "Renderer", "ViewerHandle", "open_viewer", "open_viewer_async"]
 __version__ = "0.1.0"

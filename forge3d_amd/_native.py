@@ -119,6 +119,7 @@ ABI = [
                                   C.c_char_p, C.c_size_t]),
     ("f3d_smoke_render", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_double), C.c_char_p, C.c_size_t]),
     ("f3d_smoke_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, _P(C.c_double), C.c_char_p, C.c_size_t]),
+    ("f3d_aether_reference_render", C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]),
     ("f3d_smoke_composite", C.c_int, [C.c_void_p, C.c_void_p, _P(C.c_double), C.c_char_p, C.c_size_t]),
     ("f3d_session_fingerprint", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     ("f3d_session_debug_wave_times", C.c_int, [C.c_void_p, C.c_void_p]),
@@ -167,7 +168,7 @@ HIPCC_FLAGS = [
     "-fno-slp-vectorize",
 ]
 HIP_SOURCES = ["f3d_kernels.hip", "f3d_host.hip", "f3d_denoise.hip", "f3d_smoke.hip", "f3d_smoke_sim.hip", "f3d_composite.hip", "f3d_lbvh.hip", "f3d_wavefront.hip",
-               "f3d_aether_bake.hip"]
+               "f3d_aether_bake.hip", "f3d_aether_ref.hip"]
 
 
 def source_digest() -> str:

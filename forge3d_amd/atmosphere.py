@@ -19,6 +19,7 @@ missing bank into the error the reference's "no nearby or default LUT was substi
 """
 from __future__ import annotations
 
+import ctypes as C
 import hashlib
 import math
 import os
@@ -344,3 +345,64 @@ def resolve_setting(atmosphere, bank_dir=None) -> "AtmosphereLutHandle | None":
         raise RuntimeError(
             f"PROMETHEUS AETHER could not resolve the shipped LUT bank: {error}. Custom physical inputs require "
             "lut_handle=atmosphere_bake_luts(...) from an atmosphere-bake build; no nearby or default LUT was substituted.")
+
+
+# ---- the stochastic spectral acceptance reference ---------------------------------------------------------------------
+class _RefDesc(C.Structure):
+    """f3d_aether_ref_desc"""
+    _fields_ = [("struct_size", C.c_uint32), ("dem_width", C.c_uint32), ("dem_height", C.c_uint32), ("heights", C.c_void_p), ("spacing_x", C.c_float),
+                ("spacing_z", C.c_float), ("exaggeration", C.c_float), ("cam_origin", C.c_float * 3), ("cam_look_at", C.c_float * 3),
+                ("cam_up", C.c_float * 3), ("fov_y_deg", C.c_float), ("sun_azimuth_deg", C.c_float), ("sun_elevation_deg", C.c_float),
+                ("sun_intensity", C.c_float), ("turbidity", C.c_float), ("ozone_du", C.c_float), ("mie_g", C.c_float), ("ground_albedo", C.c_float),
+                ("width", C.c_uint32), ("height", C.c_uint32), ("seed", C.c_uint32), ("spp", C.c_uint32), ("enabled", C.c_int32),
+                ("variance_threshold", C.c_float)]
+
+
+class _RefOut(C.Structure):
+    """f3d_aether_ref_out"""
+    _fields_ = [("mean_xyz", C.c_void_p), ("linear_rgb", C.c_void_p), ("variance", C.c_float), ("converged", C.c_int32),
+                ("terrain_primary_hits", C.c_uint64), ("gpu_resource_bytes", C.c_uint64), ("kernel_seconds", C.c_double)]
+
+
+def hybrid_render_aether_spectral_reference(heightmap, width, height, cam, spacing=(1.0, 1.0), exaggeration=1.0, sun_azimuth_deg=90.0,
+                                            sun_elevation_deg=10.0, sun_intensity=20.0, turbidity=2.0, ozone_du=300.0, mie_g=0.8,
+                                            ground_albedo=0.3, spp=64, seed=7, enabled=True, variance_threshold=1e-3, certificate=None,
+                                            cache=None) -> dict:
+    """The independent GPU spectral atmosphere reference over a real DEM -- the acceptance check of the LUT post pass
+    (reference `_forge3d.hybrid_render_aether_spectral_reference`, src/py_functions/path_tracing/aether_reference.rs:
+    same signature, defaults, camera keys `origin` / `look_at` / `up` / `fov_y`, and result keys).  `mean_xyz` is the
+    unclipped per-pixel estimator, `linear_rgb` its untonemapped non-negative form, `variance` the largest per-pixel
+    estimated variance of the sample-mean luminance.  `certificate` and `cache` are accepted for signature parity (this
+    build emits no render certificates; the reference is always recomputed); `kernel_seconds` is an extra key."""
+    from . import _native
+
+    del certificate, cache
+    if not isinstance(cam, dict):
+        raise TypeError("cam must be a dict")
+    dem = np.ascontiguousarray(heightmap, dtype=np.float32)
+    if dem.ndim != 2:
+        raise TypeError("heightmap must be a 2-D float32 array")
+    d = _RefDesc()
+    d.struct_size = C.sizeof(_RefDesc)
+    d.dem_height, d.dem_width = dem.shape
+    d.heights = dem.ctypes.data
+    d.spacing_x, d.spacing_z, d.exaggeration = float(spacing[0]), float(spacing[1]), float(exaggeration)
+    d.cam_origin = (C.c_float * 3)(*cam.get("origin", (0.0, 1.0, 0.0)))
+    d.cam_look_at = (C.c_float * 3)(*cam.get("look_at", (1.0, 1.0, 0.0)))
+    d.cam_up = (C.c_float * 3)(*cam.get("up", (0.0, 1.0, 0.0)))
+    d.fov_y_deg = float(cam.get("fov_y", 20.0))
+    d.sun_azimuth_deg, d.sun_elevation_deg, d.sun_intensity = float(sun_azimuth_deg), float(sun_elevation_deg), float(sun_intensity)
+    d.turbidity, d.ozone_du, d.mie_g, d.ground_albedo = float(turbidity), float(ozone_du), float(mie_g), float(ground_albedo)
+    d.width, d.height, d.seed, d.spp = int(width), int(height), int(seed) & 0xFFFFFFFF, int(spp)
+    d.enabled, d.variance_threshold = 1 if enabled else 0, float(variance_threshold)
+    mean_xyz = np.zeros((max(0, int(height)), max(0, int(width)), 3), np.float32)
+    rgb = np.zeros_like(mean_xyz)
+    out = _RefOut()
+    out.mean_xyz, out.linear_rgb = mean_xyz.ctypes.data, rgb.ctypes.data
+    err = C.create_string_buffer(512)
+    rc = _native.lib().f3d_aether_reference_render(C.byref(d), C.byref(out), err, len(err))
+    if rc != 0:
+        _native.raise_status(rc, err.value.decode("utf-8", "replace"))
+    return {"mean_xyz": mean_xyz, "linear_rgb": rgb, "variance": float(out.variance), "converged": bool(out.converged), "seed": int(d.seed),
+            "spp": int(d.spp), "terrain_primary_hits": int(out.terrain_primary_hits), "gpu_resource_bytes": int(out.gpu_resource_bytes),
+            "environment": "black", "wavelength_count": 11, "max_depth": 6, "kernel_seconds": float(out.kernel_seconds)}

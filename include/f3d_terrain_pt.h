@@ -393,6 +393,38 @@ typedef struct f3d_composite_desc {
 } f3d_composite_desc;
 int f3d_smoke_composite(const f3d_composite_desc *desc, uint8_t *out_rgba, double *kernel_seconds, char *err, size_t errlen);
 
+/* ---- AETHER acceptance reference: stochastic spectral transport (no LUT, black environment) ----
+ * Replaces _forge3d.hybrid_render_aether_spectral_reference (reference src/py_functions/path_tracing/
+ * aether_reference.rs:14-146 -> HybridPathTracer::render_aether_spectral_reference, hybrid_compute/
+ * aether_reference.rs:203-560 -> WGSL main_aether_spectral_reference, shaders/atmosphere/
+ * prometheus_spectral_reference.wgsl:423-480): delta-tracking paths at 11 wavelengths over the terrain tracer's own
+ * camera rays, heightfield hits and sun visibility; the acceptance check of the LUT post pass (f3d_terrain_ref_desc.
+ * atmosphere).  Same validation and messages as the reference (status F3D_STATUS_RENDER), plus: the DEM must lie
+ * inside the top of the atmosphere (a terrain hit then always precedes the top-of-atmosphere exit, which the
+ * reference's shadow test assumes).  At most 8 000 000 wavelength paths (width * height * spp * 11). */
+typedef struct f3d_aether_ref_desc { /* AetherSpectralReferenceDesc, aether_reference.rs:14-43 */
+    uint32_t struct_size;            /* sizeof(f3d_aether_ref_desc) of the caller's header */
+    uint32_t dem_width, dem_height;
+    const float *heights;            /* row-major (dem_height, dem_width) */
+    float spacing_x, spacing_z, exaggeration;
+    float cam_origin[3], cam_look_at[3], cam_up[3], fov_y_deg;
+    float sun_azimuth_deg, sun_elevation_deg, sun_intensity;
+    float turbidity, ozone_du, mie_g, ground_albedo;
+    uint32_t width, height, seed, spp;
+    int32_t enabled;                 /* 0: explicit black (all outputs zero, converged) */
+    float variance_threshold;
+} f3d_aether_ref_desc;
+typedef struct f3d_aether_ref_out { /* AetherSpectralReferenceOutput, aether_reference.rs:46-60 */
+    float *mean_xyz;   /* width * height * 3: unclipped per-pixel mean CIE XYZ */
+    float *linear_rgb; /* width * height * 3: max(signed linear RGB of the mean, 0) */
+    float variance;    /* max over pixels of the estimated variance of the sample-mean CIE Y */
+    int32_t converged;
+    uint64_t terrain_primary_hits; /* camera samples whose primary ray hit the terrain */
+    uint64_t gpu_resource_bytes;
+    double kernel_seconds;         /* device time of the three launches */
+} f3d_aether_ref_out;
+int f3d_aether_reference_render(const f3d_aether_ref_desc *desc, f3d_aether_ref_out *out, char *err, size_t errlen);
+
 /* ---- test hooks (KATs restated from the reference's Rust unit tests) ----------- */
 /* build_minmax_mips on the GPU (reference terrain_heightfield.rs:132-202); output in
  * the reference's layout: levels back to back, finest first, each (ph, pw, 2) f32;

@@ -367,3 +367,26 @@ def composite(mode, base, layer, **kw):
     if L.emul_composite(C.byref(desc), C.c_void_p(out.ctypes.data)) != 0:
         raise RuntimeError("emul_composite failed")
     return out
+
+
+def aether_reference(heightmap, width, height, cam, **kw) -> dict:
+    """The AETHER acceptance reference's device code (csrc/f3d_aether_ref.h) compiled for the host."""
+    from forge3d_amd import atmosphere as product
+    from oracle import aether_ref_oracle as ao
+
+    d = product._RefDesc()
+    d.struct_size = C.sizeof(product._RefDesc)
+    keep = ao.fill_desc(d, heightmap, width, height, cam, **kw)
+    mean_xyz = np.zeros((height, width, 3), np.float32)
+    rgb = np.zeros_like(mean_xyz)
+    out = product._RefOut()
+    out.mean_xyz, out.linear_rgb = mean_xyz.ctypes.data, rgb.ctypes.data
+    err = C.create_string_buffer(512)
+    L = lib()
+    L.emul_aether_reference.restype = C.c_int
+    rc = L.emul_aether_reference(C.byref(d), C.byref(out), err, len(err))
+    del keep
+    if rc != 0:
+        raise RuntimeError(err.value.decode())
+    return {"mean_xyz": mean_xyz, "linear_rgb": rgb, "variance": float(out.variance), "converged": bool(out.converged),
+            "terrain_primary_hits": int(out.terrain_primary_hits)}

@@ -18,6 +18,7 @@
 #include "../../forge3d_amd/csrc/f3d_smoke_sim.h"
 #include "../../forge3d_amd/csrc/f3d_shade.h"
 #include "../../forge3d_amd/csrc/f3d_wf_host.h"
+#include "../../forge3d_amd/csrc/f3d_aether_ref_host.h"
 
 using namespace f3d;
 
@@ -1156,6 +1157,55 @@ int emul_composite(const f3d_composite_desc *d, uint8_t *out) {
             reinterpret_cast<uint32_t *>(out)[(size_t)y * P.width + x] =
                 pixel(P, reinterpret_cast<const uint32_t *>(d->base), reinterpret_cast<const uint32_t *>(d->layer), x, y);
     return 0;
+}
+
+// The AETHER acceptance reference's device code (f3d_aether_ref.h) on the host, in the three passes of f3d_aether_ref.hip:
+// stream positions, one call per (pixel, sample, wavelength) path, ordered fold.
+int emul_aether_reference(const f3d_aether_ref_desc *d, f3d_aether_ref_out *out, char *err, size_t errlen) {
+    using namespace f3d::aref;
+    try {
+        validate_ref_desc(*d);
+        check_ref_terrain(*d);
+        const size_t pixels = (size_t)d->width * d->height;
+        out->variance = 0.0f;
+        out->terrain_primary_hits = 0;
+        if (!d->enabled) {
+            std::fill(out->mean_xyz, out->mean_xyz + 3 * pixels, 0.0f);
+            std::fill(out->linear_rgb, out->linear_rgb + 3 * pixels, 0.0f);
+            out->converged = 1;
+            return 0;
+        }
+        HostTables t = build_tables_host(d->heights, d->dem_width, d->dem_height, d->exaggeration);
+        RefScene S{};
+        t.attach(S.terrain);
+        fill_ref_scene(*d, S);
+        const size_t samples = pixels * d->spp;
+        std::vector<uint32_t> states(samples), hits(samples);
+        std::vector<float> values(samples * kWavelengths), accum(4 * pixels), welford(2 * pixels);
+        for (size_t p = 0; p < pixels; p++) {
+            uint32_t state = pixel_seed(S, (uint32_t)(p % d->width), (uint32_t)(p / d->width));
+            for (uint32_t s = 0; s < d->spp; s++) {
+                states[p * d->spp + s] = state;
+                rng_skip(state, kDrawsPerSample);
+            }
+        }
+#pragma omp parallel for schedule(dynamic, 64)
+        for (int64_t path = 0; path < (int64_t)(samples * kWavelengths); path++) {
+            const uint32_t w = (uint32_t)(path % kWavelengths);
+            const size_t ps = (size_t)path / kWavelengths;
+            const uint32_t pixel = (uint32_t)(ps / d->spp);
+            ArrayPending pend;
+            bool primary = false;
+            values[path] = sample_path(S, pixel % d->width, pixel / d->width, states[ps], w, w == 0u, primary, pend);
+            if (w == 0u) hits[ps] = primary ? 1u : 0u;
+        }
+        for (size_t p = 0; p < pixels; p++)
+            fold_pixel(values.data() + p * d->spp * kWavelengths, hits.data() + p * d->spp, d->spp, accum.data() + 4 * p, welford.data() + 2 * p);
+        finalize_ref(*d, accum.data(), welford.data(), *out);
+        return 0;
+    } catch (const Failure &f) {
+        return report(f, err, errlen);
+    }
 }
 
 }  // extern "C"

@@ -1,0 +1,278 @@
+"""The AETHER acceptance reference: stochastic spectral transport with no LUT and a black environment
+(reference prometheus_spectral_reference.wgsl + hybrid_compute/aether_reference.rs; `hybrid_render_aether_spectral_reference`).
+
+The tracer is stochastic and its transcendentals are the GPU's, so the reference ships no golden output for it.  Pins:
+  * the reference's own tests of it (tests/test_atmosphere_pt_reference.py:54-205 and the Rust unit tests of
+    aether_reference.rs) restated on the oracle;
+  * the reference's ACCEPTANCE GATE (tests/test_atmosphere_reference.py:249-400): over the sun-elevation sweep
+    -5 ... 89 degrees and 27 (sun azimuth, pixel) cases, the LUT sky and the spectral reference -- 4 seeds x 4096 spp,
+    combined in XYZ -- differ by CIEDE2000 < 2 after the display transform.  The LUT side here is the post pass's own
+    sky tap on the reference's shipped anchors (tests/golden/atmosphere), so the gate ties the spectral tracer to a
+    transport whose oracle is pinned by vectors (tests/test_aether.py), and ties that transport to physics that shares
+    no table with it;
+  * the product's device code, compiled for the host, equals the oracle bit for bit (the product runs every wavelength
+    path as its own lane and folds afterwards; the oracle is the reference's loop nest);
+  * `-m gpu`: the HIP path equals the oracle bit for bit, runs the gate itself, and reports what a sweep costs.
+"""
+from __future__ import annotations
+
+import math
+from concurrent.futures import ProcessPoolExecutor
+
+import numpy as np
+import pytest
+
+import metrics
+import scenes
+from forge3d_amd import atmosphere as atm
+from oracle import aether_ref_oracle as ao
+from oracle import oracle
+
+FLAT = np.zeros((8, 8), np.float32)
+HORIZON_CAM = {"origin": (0.0, 2.0, 0.0), "look_at": (1.0, 2.0, 0.0), "up": (0.0, 1.0, 0.0), "fov_y": 8.0}
+XYZ_TO_RGB = np.asarray([[3.2404542 / 3.2613921, -1.5371385 / 3.2613921, -0.4985314 / 3.2613921],
+                         [-0.9692660 / 2.5069624, 1.8760108 / 2.5069624, 0.0415560 / 2.5069624],
+                         [0.0556434 / 2.3679786, -0.2040259 / 2.3679786, 1.0572252 / 2.3679786]], np.float64)
+
+
+def _render(backend, *, spp, seed, enabled=True):  # tests/test_atmosphere_pt_reference.py:90-111
+    return backend(FLAT, 1, 1, HORIZON_CAM, spacing=(1000.0, 1000.0), sun_azimuth_deg=60.0, sun_elevation_deg=10.0, sun_intensity=20.0, spp=spp,
+                   seed=seed, enabled=enabled, variance_threshold=5.0e-3)
+
+
+def rough_scene():
+    dem = scenes.golden_dem(8) * np.float32(900.0)
+    cam = {"origin": (-2500.0, 1400.0, 1800.0), "look_at": (0.0, 300.0, 0.0), "up": (0.0, 1.0, 0.0), "fov_y": 40.0}
+    return dem, cam, dict(spacing=(6000.0 / (dem.shape[1] - 1), 6000.0 / (dem.shape[0] - 1)), exaggeration=1.5, sun_azimuth_deg=250.0,
+                          sun_elevation_deg=18.0, sun_intensity=5.0, turbidity=3.5, ozone_du=280.0, mie_g=0.76, ground_albedo=0.25)
+
+
+# ---- the reference's own tests -----------------------------------------------------------------------------------------
+def test_final_conversion_commutes_with_split_xyz_accumulation():  # :54-76 (and aether_reference.rs:637-668)
+    samples = np.asarray([[0.0, 1.0, 0.0], [1.0, 0.0, 0.0]], np.float64)
+
+    def finalize(sum_xyz, count):
+        return np.maximum(XYZ_TO_RGB @ (sum_xyz / float(count)), 0.0)
+
+    whole = finalize(samples.sum(axis=0), len(samples))
+    assert np.array_equal(whole, finalize(samples[:1].sum(axis=0) + samples[1:].sum(axis=0), len(samples)))
+    assert np.max(np.abs(whole - np.stack([finalize(s, 1) for s in samples]).mean(axis=0))) > 1.0e-3
+
+
+def test_disabled_reference_is_explicit_black():  # :114-120
+    out = _render(ao.render, spp=2, seed=11, enabled=False)
+    assert np.array_equal(out["mean_xyz"], np.zeros((1, 1, 3), np.float32)) and np.array_equal(out["linear_rgb"], np.zeros((1, 1, 3), np.float32))
+    assert out["environment"] == "black" and out["variance"] == 0.0 and out["converged"] is True
+
+
+def test_low_spp_changes_with_seed():  # :142-154
+    first, repeated, second = _render(ao.render, spp=2, seed=11), _render(ao.render, spp=2, seed=11), _render(ao.render, spp=2, seed=97)
+    assert first["seed"] == 11 and second["seed"] == 97 and first["spp"] == second["spp"] == 2
+    assert first["wavelength_count"] == 11 and first["max_depth"] >= 4
+    assert np.array_equal(first["mean_xyz"], repeated["mean_xyz"]) and np.array_equal(first["linear_rgb"], repeated["linear_rgb"])
+    assert first["variance"] == repeated["variance"]
+    assert not np.array_equal(first["mean_xyz"], second["mean_xyz"]) and not np.array_equal(first["linear_rgb"], second["linear_rgb"])
+
+
+def test_public_rgb_is_finalized_once_from_unclipped_mean_xyz():  # :157-170
+    out = _render(ao.render, spp=16, seed=23)
+    expected = np.maximum(np.asarray(out["mean_xyz"], np.float64) @ XYZ_TO_RGB.T, 0.0)
+    np.testing.assert_allclose(out["linear_rgb"], expected, rtol=2e-6, atol=1e-8)
+
+
+def test_more_samples_improve_reported_mean_variance():  # :173-184 (seed 7 is locked there for its noisy prefix)
+    low, high = _render(ao.render, spp=4, seed=7), _render(ao.render, spp=64, seed=7)
+    assert np.isfinite(low["linear_rgb"]).all() and np.isfinite(high["linear_rgb"]).all()
+    assert np.isfinite(low["variance"]) and np.isfinite(high["variance"]) and high["variance"] < low["variance"]
+
+
+def test_primary_rays_report_real_terrain_classification():  # :187-204
+    cam = {"origin": (0.0, 20.0, 25.0), "look_at": (0.0, 0.0, 0.0), "up": (0.0, 1.0, 0.0), "fov_y": 5.0}
+    assert ao.render(FLAT, 1, 1, cam, spacing=(10.0, 10.0), spp=4, seed=5)["terrain_primary_hits"] == 4
+
+
+def test_validation_is_the_references():  # validate_desc, aether_reference.rs:83-153 and its tests :670-738
+    base = dict(spacing=(1.0, 1.0), sun_intensity=1.0, spp=1, ozone_du=0.0, mie_g=0.0)
+    cam = {"origin": (0.0, 1.0, 0.0), "look_at": (1.0, 1.0, 0.0), "fov_y": 45.0}
+    two = np.zeros((2, 2), np.float32)
+    ao.render(two, 1, 1, cam, **base)
+    ao.render(two, 1, 1, cam, **{**base, "ozone_du": 600.0, "mie_g": 0.99})
+    cases = [({"mie_g": -0.001}, cam, "mie_g must be in"), ({"ozone_du": 600.001}, cam, "ozone must be in"), ({"turbidity": 0.5}, cam, "turbidity must be in"),
+             ({}, {**cam, "origin": (0.0, 100_001.0, 0.0), "look_at": (1.0, 100_001.0, 0.0)}, "inside the 0..100 km atmosphere"),
+             ({"spp": 4097}, cam, r"spp must be in 1\.\.=4096"), ({"spp": 0}, cam, "spp must be in"), ({}, {**cam, "look_at": (0.0, 1.0, 0.0)}, "camera basis is degenerate"),
+             ({}, {**cam, "up": (1.0, 0.0, 0.0)}, "camera basis is degenerate"), ({}, {**cam, "fov_y": 180.0}, "fov_y_deg must be in"),
+             ({"spacing": (0.0, 1.0)}, cam, "spacing must be finite and positive"), ({"exaggeration": float("nan")}, cam, "exaggeration must be finite and positive"),
+             ({"sun_intensity": -1.0}, cam, "intensity non-negative"), ({"variance_threshold": 0.0}, cam, "variance_threshold must be finite and positive")]
+    for change, camera, message in cases:
+        with pytest.raises(RuntimeError, match=message):
+            ao.render(two, 1, 1, camera, **{**base, **change})
+    with pytest.raises(RuntimeError, match="has 8000300 wavelength paths; acceptance lane limit is 8000000"):
+        ao.render(two, 727300, 1, cam, **base)
+    with pytest.raises(RuntimeError, match="non-zero width and height"):
+        ao.render(two, 0, 1, cam, **base)
+
+
+# ---- the acceptance gate: LUT sky against the spectral reference ----------------------------------------------------------
+SIZE = 65
+SUN_ELEVATIONS_DEG = (-5.0, 0.0, 5.0, 10.0, 30.0, 60.0, 89.0)  # tests/_aether_quadrature.py:19
+SKY_CASES = tuple((az, x, y) for az in (20.0, 90.0, 160.0) for y in (8, 20, 28) for x in (8, SIZE // 2, 56))  # test_atmosphere_reference.py:47-52
+REFERENCE_SEEDS, REFERENCE_SPP_PER_SEED = (17, 23, 41, 97), 4096
+BATCH_VARIANCE_LIMIT, DELTA_E_LIMIT = 1.0e-3, 2.0
+
+
+def pixel_ray(x, y):  # the 65 x 65, 20-degree camera of the gate looking along +x (:262-270)
+    t = math.tan(math.radians(20.0) * 0.5)
+    r = np.asarray([1.0, (1.0 - ((y + 0.5) / SIZE) * 2.0) * t, -(((x + 0.5) / SIZE) * 2.0 - 1.0) * t], np.float64)
+    return r / np.linalg.norm(r)
+
+
+def reference_sample(backend, elevation, case, seeds=REFERENCE_SEEDS, spp=REFERENCE_SPP_PER_SEED):
+    """One scored sky sample the way the gate takes it (:249-340): a 1 x 1 pinhole along the pixel-centre ray, one render
+    per seed, the unclipped XYZ means averaged, ONE conversion and clip.  Returns (linear RGB, variance of the mean)."""
+    az, x, y = case
+    ray, origin = pixel_ray(x, y), np.asarray((-10.0, 1.0, 0.0))
+    xyz, variances = [], []
+    for seed in seeds:
+        out = backend(FLAT, 1, 1, {"origin": tuple(origin), "look_at": tuple(origin + ray), "up": (0.0, 1.0, 0.0), "fov_y": 0.001},
+                      spacing=(3.0 / 7.0, 3.0 / 7.0), exaggeration=0.1, sun_azimuth_deg=az, sun_elevation_deg=float(elevation), sun_intensity=1.0,
+                      turbidity=2.0, ozone_du=300.0, mie_g=0.8, ground_albedo=0.3, spp=spp, seed=seed, enabled=True,
+                      variance_threshold=BATCH_VARIANCE_LIMIT)
+        assert out["environment"] == "black" and out["terrain_primary_hits"] == 0 and out["spp"] == spp and out["seed"] == seed
+        assert out["converged"] and out["variance"] <= BATCH_VARIANCE_LIMIT, out
+        mean = np.asarray(out["mean_xyz"][0, 0], np.float64)
+        np.testing.assert_allclose(out["linear_rgb"][0, 0], np.maximum(XYZ_TO_RGB @ mean, 0.0), rtol=2e-6, atol=1e-8)
+        xyz.append(mean)
+        variances.append(out["variance"])
+    return np.maximum(XYZ_TO_RGB @ np.mean(xyz, axis=0), 0.0), sum(variances) / len(variances) ** 2
+
+
+def _oracle_sample(args):
+    return reference_sample(ao.render, *args)
+
+
+def lut_sky(handle, elevation, case):
+    az, x, y = case
+    el, a = math.radians(elevation), math.radians(az)
+    sun = (math.cos(a) * math.cos(el), math.sin(el), math.sin(a) * math.cos(el))
+    return oracle.aether_sky(handle, 1.0, pixel_ray(x, y), sun).astype(np.float64)
+
+
+def display(linear):
+    return np.rint(metrics.filmic_terrain_srgb(linear) * 255.0).clip(0.0, 255.0) / 255.0
+
+
+def gate_scores(samples, handle):
+    """{(elevation, case): CIEDE2000 between the displayed LUT sky and the displayed spectral reference}"""
+    return {key: float(metrics.delta_e_2000(metrics.srgb_to_lab(display(lut_sky(handle, key[0], key[1]))), metrics.srgb_to_lab(display(lin))))
+            for key, (lin, _) in samples.items()}
+
+
+def shipped_handle():
+    return atm.AtmosphereLutHandle.load_shipped(atm.AtmosphereConfig(turbidity=2.0), bank_dir=scenes.GOLDEN_DIR / "atmosphere")
+
+
+def test_sky_delta_e2000_under_two_for_full_sun_elevation_sweep():
+    keys = [(el, case) for el in SUN_ELEVATIONS_DEG for case in SKY_CASES]
+    import multiprocessing as mp
+
+    # (spawn: the oracle library is OpenMP code, and a forked child of a process that has run it would wait for threads it
+    # does not have)
+    with ProcessPoolExecutor(8, mp_context=mp.get_context("spawn")) as pool:
+        samples = dict(zip(keys, pool.map(_oracle_sample, keys, chunksize=4)))
+    assert max(v for _, v in samples.values()) <= BATCH_VARIANCE_LIMIT / len(REFERENCE_SEEDS)
+    scores = gate_scores(samples, shipped_handle())
+    worst = max(scores, key=scores.get)
+    print("AETHER_DELTA_E_SWEEP worst", worst, round(scores[worst], 3), "per elevation",
+          {el: round(max(s for (e, _), s in scores.items() if e == el), 2) for el in SUN_ELEVATIONS_DEG})
+    assert len(scores) == 189 and scores[worst] < DELTA_E_LIMIT, (worst, scores[worst])
+    # and the gate can fail: a LUT of the wrong turbidity is told apart
+    hazy = atm.AtmosphereLutHandle.load_shipped(atm.AtmosphereConfig(turbidity=10.0), bank_dir=scenes.GOLDEN_DIR / "atmosphere")
+    assert max(gate_scores(samples, hazy).values()) > 3.0 * DELTA_E_LIMIT
+
+
+# ---- the product's device code against the oracle -------------------------------------------------------------------------
+def _same(a, b):
+    assert np.array_equal(a["mean_xyz"], b["mean_xyz"]) and np.array_equal(a["linear_rgb"], b["linear_rgb"])
+    assert a["variance"] == b["variance"] and a["converged"] == b["converged"] and a["terrain_primary_hits"] == b["terrain_primary_hits"]
+
+
+def parity_cases():
+    dem, cam, kw = rough_scene()
+    yield "rough 6x4 px", (dem, 6, 4, cam), dict(kw, spp=24, seed=3)
+    yield "rough low sun", (dem, 5, 3, cam), dict(kw, spp=16, seed=41, sun_elevation_deg=1.5, sun_azimuth_deg=100.0)
+    yield "rough no ozone, isotropic mie", (dem, 3, 3, cam), dict(kw, spp=16, seed=9, ozone_du=0.0, mie_g=0.0)
+    yield "horizon 1 px", (FLAT, 1, 1, HORIZON_CAM), dict(spacing=(1000.0, 1000.0), sun_azimuth_deg=60.0, sun_elevation_deg=10.0, spp=200, seed=7)
+    yield "sun below the horizon", (FLAT, 2, 2, HORIZON_CAM), dict(spacing=(1000.0, 1000.0), sun_elevation_deg=-5.0, spp=64, seed=2)
+    yield "one sample", (dem, 4, 2, cam), dict(kw, spp=1, seed=5)
+    high = {"origin": (0.0, 60_000.0, 0.0), "look_at": (1.0, 59_999.0, 0.2), "up": (0.0, 1.0, 0.0), "fov_y": 60.0}
+    yield "camera at 60 km", (FLAT, 4, 4, high), dict(spacing=(1000.0, 1000.0), sun_elevation_deg=40.0, spp=32, seed=77)
+
+
+@pytest.mark.parametrize("name", [c[0] for c in parity_cases()])
+def test_device_code_on_the_host_equals_the_oracle(name):
+    from tests.emul import emul
+
+    args, kw = next((a, k) for n, a, k in parity_cases() if n == name)
+    want = ao.render(*args, **kw)
+    _same(emul.aether_reference(*args, **kw), want)
+    if name.startswith("rough 6x4"):
+        assert 0 < want["terrain_primary_hits"] < 6 * 4 * 24 and float(want["linear_rgb"].min()) >= 0.0 and float(want["mean_xyz"].max()) > 0.01
+
+
+def test_python_surface_without_a_gpu():
+    import torch
+
+    import forge3d_amd as f3d
+
+    assert f3d.hybrid_render_aether_spectral_reference is atm.hybrid_render_aether_spectral_reference
+    with pytest.raises(TypeError):
+        f3d.hybrid_render_aether_spectral_reference(FLAT, 1, 1, [0, 1, 2])
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            _render(f3d.hybrid_render_aether_spectral_reference, spp=2, seed=1)
+        out = _render(f3d.hybrid_render_aether_spectral_reference, spp=2, seed=1, enabled=False)  # needs no device: explicit black
+        assert out["converged"] is True and not out["mean_xyz"].any()
+        with pytest.raises(RuntimeError, match=r"\[Render\] Render error: AETHER spectral reference spp must be in 1\.\.=4096"):
+            _render(f3d.hybrid_render_aether_spectral_reference, spp=5000, seed=1)
+
+
+# ---- GPU ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", [c[0] for c in parity_cases()])
+def test_hip_equals_the_oracle(name):
+    args, kw = next((a, k) for n, a, k in parity_cases() if n == name)
+    got = atm.hybrid_render_aether_spectral_reference(*args, **kw)
+    _same(got, ao.render(*args, **kw))
+    assert got["gpu_resource_bytes"] > 0
+
+
+@pytest.mark.gpu
+def test_hip_runs_the_acceptance_gate():
+    """The whole sweep on the device: 756 renders of 4096 spp x 11 wavelengths; three of them also against the oracle."""
+    import time
+
+    backend = atm.hybrid_render_aether_spectral_reference
+    t0 = time.perf_counter()
+    samples = {(el, case): reference_sample(backend, el, case) for el in SUN_ELEVATIONS_DEG for case in SKY_CASES}
+    seconds = time.perf_counter() - t0
+    scores = gate_scores(samples, shipped_handle())
+    worst = max(scores, key=scores.get)
+    print(f"AETHER acceptance sweep on the device: {len(scores)} samples, {len(scores) * len(REFERENCE_SEEDS)} renders in {seconds:.1f} s; "
+          f"worst CIEDE2000 {scores[worst]:.2f} at {worst}")
+    assert scores[worst] < DELTA_E_LIMIT
+    for key in ((10.0, SKY_CASES[0]), (-5.0, SKY_CASES[13]), (89.0, SKY_CASES[26])):
+        want, _ = reference_sample(ao.render, *key)
+        assert np.array_equal(samples[key][0], want)
+
+
+@pytest.mark.gpu
+def test_hip_errors_and_the_largest_request():
+    cam = {"origin": (0.0, 1.0, 0.0), "look_at": (1.0, 1.0, 0.0), "fov_y": 45.0}
+    with pytest.raises(RuntimeError, match="inside the 100 km atmosphere"):
+        atm.hybrid_render_aether_spectral_reference(np.full((4, 4), 120_000.0, np.float32), 1, 1, cam, spp=2)
+    with pytest.raises(RuntimeError, match="at least 2x2"):
+        atm.hybrid_render_aether_spectral_reference(np.zeros((1, 4), np.float32), 1, 1, cam, spp=2)
+    dem, camera, kw = rough_scene()
+    out = atm.hybrid_render_aether_spectral_reference(dem, 64, 44, camera, **dict(kw, spp=256, seed=1))  # 7.9 M wavelength paths
+    assert out["variance"] > 0.0 and np.isfinite(out["linear_rgb"]).all() and 0 < out["terrain_primary_hits"] < 64 * 44 * 256
+    print(f"64 x 44 x 256 spp x 11 wavelengths: {out['kernel_seconds'] * 1e3:.1f} ms on the device")

@@ -8,5 +8,5 @@ NAME=$1; shift
 mkdir -p build_ab
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-slp-vectorize "$@" \
     forge3d_amd/csrc/f3d_kernels.hip forge3d_amd/csrc/f3d_host.hip forge3d_amd/csrc/f3d_denoise.hip forge3d_amd/csrc/f3d_smoke.hip forge3d_amd/csrc/f3d_smoke_sim.hip forge3d_amd/csrc/f3d_composite.hip \
-    forge3d_amd/csrc/f3d_lbvh.hip forge3d_amd/csrc/f3d_wavefront.hip forge3d_amd/csrc/f3d_aether_bake.hip -o build_ab/libf3dhip_$NAME.so 2> build_ab/$NAME.err
+    forge3d_amd/csrc/f3d_lbvh.hip forge3d_amd/csrc/f3d_wavefront.hip forge3d_amd/csrc/f3d_aether_bake.hip forge3d_amd/csrc/f3d_aether_ref.hip -o build_ab/libf3dhip_$NAME.so 2> build_ab/$NAME.err
 ls -la build_ab/libf3dhip_$NAME.so
