@@ -1244,6 +1244,35 @@ static v3 ae_segment_transmittance(float dist, float cam_h, float mu, float bott
                      dot3(v3_make(0.0556434f, -0.2040259f, 1.0572252f), xyz) / 2.3679786f);
     return v3_make(clampf(rgb.x, 0.0f, 1.0f), clampf(rgb.y, 0.0f, 1.0f), clampf(rgb.z, 0.0f, 1.0f));
 }
+/* the terrain-hit branch of prometheus_aerial.wgsl main (:160-226): surface radiance carried over `depth` along `ray` */
+static v3 ae_transport(const f3do_aether *A, v3 surface, float cam_h, v3 ray, v3 sun, float depth, float sun_i) {
+    float atm_h = fmaxf(A->top_radius_m - A->bottom_radius_m, 1.0f), cam_unit = clampf(cam_h / atm_h, 0.0f, 1.0f);
+    float nu = dot3(ray, sun);
+    float end_h = ae_altitude(cam_h, ray.y, depth, A->bottom_radius_m);
+    float r = fmaxf(A->bottom_radius_m, 1.0f) + clampf(cam_h, 0.0f, 100000.0f), bd = clampf(depth, 0.0f, 20000000.0f);
+    float end_r = fmaxf(ae_radius(cam_h, ray.y, bd, A->bottom_radius_m), 1.0f);
+    float end_view_mu = clampf((r * clampf(ray.y, -1.0f, 1.0f) + bd) / end_r, -1.0f, 1.0f);
+    float end_sun_mu = clampf((r * clampf(sun.y, -1.0f, 1.0f) + bd * clampf(nu, -1.0f, 1.0f)) / end_r, -1.0f, 1.0f);
+    v3 seg = ae_segment_transmittance(depth, cam_h, ray.y, A->bottom_radius_m, 1.0f, A->turbidity, A->ozone_du);
+    int bx = ae_round_index(0.5f * (clampf(ray.y, -1.0f, 1.0f) + 1.0f), A->dims[0]), by = ae_round_index(clampf(cam_unit, 0.0f, 1.0f), A->dims[1]);
+    const float *bt = A->transmittance + 4 * ((size_t)by * A->dims[0] + (size_t)bx);
+    v3 boundary = v3_make(clampf(bt[0], 0.0f, 1.0f), clampf(bt[1], 0.0f, 1.0f), clampf(bt[2], 0.0f, 1.0f));
+    v3 cs = ae_scattering(A, cam_unit, sun.y, ray.y, nu);
+    cs = v3_make(cs.x * sun_i, cs.y * sun_i, cs.z * sun_i);
+    float end_unit = clampf(end_h / atm_h, 0.0f, 1.0f);
+    v3 es = ae_scattering(A, end_unit, end_sun_mu, end_view_mu, nu);
+    es = v3_make(es.x * sun_i, es.y * sun_i, es.z * sun_i);
+    float dist_unit = depth / fmaxf(A->max_aerial_distance_m, 1.0f);
+    int ax = ae_round_index(clampf(dist_unit, 0.0f, 1.0f), A->dims[6]), ay = ae_round_index(0.5f * (clampf(ray.y, -1.0f, 1.0f) + 1.0f), A->dims[7]),
+        az = ae_round_index(clampf(cam_unit, 0.0f, 1.0f), A->dims[8]);
+    float aerial_t = clampf(A->aerial[4 * (((size_t)az * A->dims[7] + (size_t)ay) * A->dims[6] + (size_t)ax) + 3], 0.0f, 1.0f);
+    float mean_t = dot3(seg, v3_make(0.2126f, 0.7152f, 0.0722f));
+    float k = aerial_t / fmaxf(mean_t, 1.0e-6f);
+    v3 tr = v3_make(fmaxf(clampf(seg.x * k, 0.0f, 1.0f), boundary.x), fmaxf(clampf(seg.y * k, 0.0f, 1.0f), boundary.y),
+                    fmaxf(clampf(seg.z * k, 0.0f, 1.0f), boundary.z));
+    v3 ins = v3_make(fmaxf(cs.x - tr.x * es.x, 0.0f), fmaxf(cs.y - tr.y * es.y, 0.0f), fmaxf(cs.z - tr.z * es.z, 0.0f));
+    return ae_clamp_hdr(v3_make(surface.x * tr.x + ins.x, surface.y * tr.y + ins.y, surface.z * tr.z + ins.z));
+}
 /* prometheus_aerial.wgsl main, :99-231: returns the Reinhard-mapped colour stored to the RGBA16F output */
 static v3 ae_post_pixel(const f3do_aether *A, const uniforms_t *un, uint32_t gx, uint32_t gy, const float *acc, float depth,
                         int visible, float sun_intensity_in) {
@@ -1260,36 +1289,12 @@ static v3 ae_post_pixel(const f3do_aether *A, const uniforms_t *un, uint32_t gx,
     float sun_i = ae_clamp_scale(sun_intensity_in), exposure = ae_clamp_scale(un->cam_exposure);
     float atm_h = fmaxf(A->top_radius_m - A->bottom_radius_m, 1.0f);
     float cam_h = fmaxf(un->cam_origin.y, 0.0f), cam_unit = clampf(cam_h / atm_h, 0.0f, 1.0f);
-    float nu = dot3(ray, sun);
     v3 hdr;
     if (!visible) {
-        v3 s = ae_scattering(A, cam_unit, sun.y, ray.y, nu);
+        v3 s = ae_scattering(A, cam_unit, sun.y, ray.y, dot3(ray, sun));
         hdr = ae_clamp_hdr(v3_make(s.x * sun_i, s.y * sun_i, s.z * sun_i));
     } else {
-        float end_h = ae_altitude(cam_h, ray.y, depth, A->bottom_radius_m);
-        float r = fmaxf(A->bottom_radius_m, 1.0f) + clampf(cam_h, 0.0f, 100000.0f), bd = clampf(depth, 0.0f, 20000000.0f);
-        float end_r = fmaxf(ae_radius(cam_h, ray.y, bd, A->bottom_radius_m), 1.0f);
-        float end_view_mu = clampf((r * clampf(ray.y, -1.0f, 1.0f) + bd) / end_r, -1.0f, 1.0f);
-        float end_sun_mu = clampf((r * clampf(sun.y, -1.0f, 1.0f) + bd * clampf(nu, -1.0f, 1.0f)) / end_r, -1.0f, 1.0f);
-        v3 seg = ae_segment_transmittance(depth, cam_h, ray.y, A->bottom_radius_m, 1.0f, A->turbidity, A->ozone_du);
-        int bx = ae_round_index(0.5f * (clampf(ray.y, -1.0f, 1.0f) + 1.0f), A->dims[0]), by = ae_round_index(clampf(cam_unit, 0.0f, 1.0f), A->dims[1]);
-        const float *bt = A->transmittance + 4 * ((size_t)by * A->dims[0] + (size_t)bx);
-        v3 boundary = v3_make(clampf(bt[0], 0.0f, 1.0f), clampf(bt[1], 0.0f, 1.0f), clampf(bt[2], 0.0f, 1.0f));
-        v3 cs = ae_scattering(A, cam_unit, sun.y, ray.y, nu);
-        cs = v3_make(cs.x * sun_i, cs.y * sun_i, cs.z * sun_i);
-        float end_unit = clampf(end_h / atm_h, 0.0f, 1.0f);
-        v3 es = ae_scattering(A, end_unit, end_sun_mu, end_view_mu, nu);
-        es = v3_make(es.x * sun_i, es.y * sun_i, es.z * sun_i);
-        float dist_unit = depth / fmaxf(A->max_aerial_distance_m, 1.0f);
-        int ax = ae_round_index(clampf(dist_unit, 0.0f, 1.0f), A->dims[6]), ay = ae_round_index(0.5f * (clampf(ray.y, -1.0f, 1.0f) + 1.0f), A->dims[7]),
-            az = ae_round_index(clampf(cam_unit, 0.0f, 1.0f), A->dims[8]);
-        float aerial_t = clampf(A->aerial[4 * (((size_t)az * A->dims[7] + (size_t)ay) * A->dims[6] + (size_t)ax) + 3], 0.0f, 1.0f);
-        float mean_t = dot3(seg, v3_make(0.2126f, 0.7152f, 0.0722f));
-        float k = aerial_t / fmaxf(mean_t, 1.0e-6f);
-        v3 tr = v3_make(fmaxf(clampf(seg.x * k, 0.0f, 1.0f), boundary.x), fmaxf(clampf(seg.y * k, 0.0f, 1.0f), boundary.y),
-                        fmaxf(clampf(seg.z * k, 0.0f, 1.0f), boundary.z));
-        v3 ins = v3_make(fmaxf(cs.x - tr.x * es.x, 0.0f), fmaxf(cs.y - tr.y * es.y, 0.0f), fmaxf(cs.z - tr.z * es.z, 0.0f));
-        hdr = ae_clamp_hdr(v3_make(surface.x * tr.x + ins.x, surface.y * tr.y + ins.y, surface.z * tr.z + ins.z));
+        hdr = ae_transport(A, surface, cam_h, ray, sun, depth, sun_i);
     }
     v3 e = v3_make(hdr.x * exposure, hdr.y * exposure, hdr.z * exposure);
     return v3_make(e.x / (1.0f + e.x), e.y / (1.0f + e.y), e.z / (1.0f + e.z));
@@ -1310,6 +1315,14 @@ void f3do_aether_sky(const f3do_aether *A, float cam_h, const float *ray, const 
     float atm_h = fmaxf(A->top_radius_m - A->bottom_radius_m, 1.0f);
     float cam_unit = clampf(fmaxf(cam_h, 0.0f) / atm_h, 0.0f, 1.0f);
     v3 c = ae_clamp_hdr(ae_scattering(A, cam_unit, s.y, r.y, dot3(r, s)));
+    rgb_out[0] = c.x; rgb_out[1] = c.y; rgb_out[2] = c.z;
+}
+
+/* ... and the whole terrain-hit transport (surface * T + inscatter) for one ray, before exposure / Reinhard */
+void f3do_aether_aerial(const f3do_aether *A, const float *surface, float cam_h, float depth, const float *ray, const float *sun, float sun_intensity,
+                        float *rgb_out) {
+    v3 c = ae_transport(A, v3_make(surface[0], surface[1], surface[2]), fmaxf(cam_h, 0.0f), normalize3(v3_make(ray[0], ray[1], ray[2])),
+                        normalize3(v3_make(sun[0], sun[1], sun[2])), depth, ae_clamp_scale(sun_intensity));
     rgb_out[0] = c.x; rgb_out[1] = c.y; rgb_out[2] = c.z;
 }
 

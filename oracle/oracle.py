@@ -140,6 +140,15 @@ def aether_sky(handle, altitude_m, view, sun):
     return np.array(out[:], np.float32)
 
 
+def aether_aerial(handle, surface, altitude_m, depth_m, view, sun, sun_intensity=1.0):
+    """The post's terrain-hit transport for one ray: surface * T(segment) + inscatter * sun intensity, before exposure / Reinhard."""
+    a, keep = aether_struct(handle)
+    out = (C.c_float * 3)()
+    lib().f3do_aether_aerial(C.byref(a), (C.c_float * 3)(*map(float, surface)), C.c_float(float(altitude_m)), C.c_float(float(depth_m)),
+                             (C.c_float * 3)(*map(float, view)), (C.c_float * 3)(*map(float, sun)), C.c_float(float(sun_intensity)), out)
+    return np.array(out[:], np.float32)
+
+
 class Out(C.Structure):
     _fields_ = [
         ("rgba", C.c_void_p),

@@ -52,6 +52,51 @@ for turbidity in (2.0, 10.0):
                     out["sky"].append({"rgb_single": [float(v) for v in single], "turbidity": turbidity, "sun_elevation_deg": sun_el, "altitude_m": altitude,
                                        "view_elevation_deg": view_el, "relative_azimuth_deg": rel_az, "sun_azimuth_deg": 90.0,
                                        "view": [float(v) for v in view], "rgb": [float(v) for v in rgb]})
+# ---- the flat-terrain fixture of the reference's two quantitative terrain gates (tests/test_atmosphere_reference.py:405-500:
+# Z-up camera at radius 40 km, phi 180, theta 70, fov 52, 64 x 64 over a 60 km plane at z = 0, sun azimuth 90 / elevation 10):
+# for hit pixels at the 10th ... 90th percentile of distance, the independent oracle's segment transmittance and its single
+# scattering along the ray down to the ground ("aerial": what a surface colour carried over that segment becomes)
+def fixture_hits(size=64, radius=40_000.0, span=60_000.0):
+    phi, theta = math.radians(180.0), math.radians(70.0)
+    eye = np.array([radius * math.sin(theta) * math.cos(phi), radius * math.sin(theta) * math.sin(phi), radius * math.cos(theta)])
+    forward = -eye / np.linalg.norm(eye)
+    right = np.cross(forward, np.array([0.0, 0.0, 1.0]))
+    right /= np.linalg.norm(right)
+    up = np.cross(right, forward)
+    half = math.tan(math.radians(52.0) * 0.5)
+    xs = (np.arange(size) + 0.5) / size * 2.0 - 1.0
+    ys = 1.0 - (np.arange(size) + 0.5) / size * 2.0
+    xx, yy = np.meshgrid(xs, ys)
+    rays = forward + xx[..., None] * half * right + yy[..., None] * half * up
+    rays /= np.linalg.norm(rays, axis=-1, keepdims=True)
+    dist = np.full(rays.shape[:2], np.nan)
+    down = rays[..., 2] < -1.0e-8
+    dist[down] = -eye[2] / rays[..., 2][down]
+    at = eye + rays * dist[..., None]
+    hit = np.isfinite(dist) & (dist > 0.0) & (np.abs(at[..., 0]) < span * 0.49) & (np.abs(at[..., 1]) < span * 0.49)
+    return eye, rays, dist, hit
+
+
+eye, rays, dist, hit = fixture_hits()
+idx = np.argwhere(hit)
+order = np.argsort(dist[hit])
+out["aerial"] = {"eye_altitude_m": float(eye[2]), "hit_count": int(hit.sum()), "sun_elevation_deg": 10.0, "sun_azimuth_deg": 90.0, "turbidity": 2.0,
+                 "ozone_du": 300.0, "mie_g": 0.8, "cases": []}
+for tenth in range(1, 10):
+    y, x = idx[order[tenth * len(order) // 10]]
+    ray = rays[y, x]
+    ray_yup = np.array([ray[0], ray[2], ray[1]])
+    distance = float(dist[y, x])
+    cols = ref._optical_columns(float(eye[2]), float(ray_yup[1]), distance, 64, 300.0)
+    t_rgb = ref._spectral_to_linear_rgb(ref._transmittance(cols, 2.0))
+    albedo = ref.GROUND_ALBEDO
+    ref.GROUND_ALBEDO = 0.0
+    s_rgb = ref.independent_reference_radiance(ray_yup, 10.0, turbidity=2.0, ozone_du=300.0, mie_g=0.8, observer_altitude_m=float(eye[2]),
+                                               sun_azimuth_deg=90.0)
+    ref.GROUND_ALBEDO = albedo
+    out["aerial"]["cases"].append({"percentile": 10 * tenth, "pixel": [int(x), int(y)], "distance_m": distance, "view": [float(v) for v in ray_yup],
+                                   "ground_distance_m": float(ref._distance_to_boundary(float(eye[2]), float(ray_yup[1]))),
+                                   "transmittance_rgb": [float(v) for v in t_rgb], "inscatter_single_rgb": [float(v) for v in s_rgb]})
 dst = Path(__file__).resolve().parent / "atmosphere" / "independent_oracle_vectors.json"
 dst.write_text(json.dumps(out, indent=0))
-print(f"wrote {len(out['transmittance'])} transmittance and {len(out['sky'])} sky vectors to {dst}")
+print(f"wrote {len(out['transmittance'])} transmittance, {len(out['sky'])} sky and {len(out['aerial']['cases'])} aerial vectors to {dst}")

@@ -8,6 +8,7 @@ oracle, and `-m gpu` the HIP resolve equals the oracle bit for bit."""
 from __future__ import annotations
 
 import hashlib
+import math
 
 import numpy as np
 import pytest
@@ -98,6 +99,70 @@ def test_scattering_lut_sampling_reproduces_independent_single_scattering():
     assert 0.88 < ratio_single.min() and ratio_single.max() < 1.40                # grazing views / 35 km: 8 height samples
     assert np.median(chroma) < 0.005 and max(chroma) < 0.1
     assert ratio_accum.min() > 0.95 and 1.2 < np.median(ratio_accum) < 1.8        # + orders 2..4 of multiple scattering
+
+
+# ---- the reference's two QUANTITATIVE terrain gates (tests/test_atmosphere_reference.py:717-778), restated on the post -------
+# There they measure the raster renderer against `atmosphere_reference_aerial`; both are outside this path.  Their content
+# is a property of the transport the post applies to a terrain hit -- surface * T(segment) + inscatter * sun intensity
+# (prometheus_aerial.wgsl:160-226) -- on the same fixture: the camera 40 km from a flat 60 km plane, sun at 10 degrees.
+def _fixture_cases():
+    v = _independent_vectors()["aerial"]
+    el, az = math.radians(v["sun_elevation_deg"]), math.radians(v["sun_azimuth_deg"])
+    return v, (math.cos(el) * math.cos(az), math.sin(el), math.cos(el) * math.sin(az))
+
+
+def test_terrain_inscatter_scales_with_sun_intensity():
+    """:717-732 -- inscatter energy at twice the intensity is twice the energy (1.80 ... 2.20 there), midpoint error <= 0.20."""
+    v, sun = _fixture_cases()
+    assert v["hit_count"] > 64
+    h = handle(2.0)
+    black = (0.0, 0.0, 0.0)
+    ins = [np.stack([oracle.aether_aerial(h, black, v["eye_altitude_m"], c["distance_m"], c["view"], sun, i) for c in v["cases"]]).astype(np.float64)
+           for i in (0.0, 1.0, 2.0)]
+    one, two = np.maximum(ins[1] - ins[0], 0.0), np.maximum(ins[2] - ins[0], 0.0)
+    assert not ins[0].any() and one.sum() > 0.0 and two.sum() > one.sum()
+    assert 1.80 <= two.sum() / one.sum() <= 2.20
+    assert np.abs(two - 2.0 * one).sum() / two.sum() <= 0.20
+    assert abs(two.sum() / one.sum() - 2.0) < 1e-5  # (the post's inscatter is exactly linear below its HDR clamp)
+
+
+def test_terrain_saturation_falloff_matches_scattering_law_within_ten_percent():
+    """:735-778 -- a saturated surface colour seen over the near (20th percentile of distance) and the far (80th) part of the
+    plane: its display saturation falls with distance, and the far / near ratio agrees within 10 % with the prediction.  The
+    prediction here is the reference's INDEPENDENT spectral oracle (segment transmittance + single scattering along the ray,
+    tests/golden/make_aether_independent_vectors.py), which shares no table and no code with the post."""
+    import metrics
+
+    v, sun = _fixture_cases()
+    h = handle(2.0)
+    surface = np.asarray((0.78, 0.24, 0.08)) * 0.25  # the fixture's material colour under a quarter unit of light
+
+    def saturation(rgb):
+        hi = float(np.max(rgb))
+        return 0.0 if hi <= 1.0e-12 else float((hi - np.min(rgb)) / hi)
+
+    cases = {c["percentile"]: c for c in v["cases"]}
+    measured, predicted, distances = [], [], []
+    for pct in (20, 80):
+        c = cases[pct]
+        post = oracle.aether_aerial(h, surface, v["eye_altitude_m"], c["distance_m"], c["view"], sun, 1.0).astype(np.float64)
+        law = surface * np.asarray(c["transmittance_rgb"]) + np.asarray(c["inscatter_single_rgb"])
+        measured.append(saturation(metrics.filmic_terrain_srgb(post)))
+        predicted.append(saturation(metrics.filmic_terrain_srgb(law)))
+        distances.append(c["distance_m"])
+    assert distances[1] > distances[0] * 1.10
+    assert measured[0] > 0.05 and predicted[0] > 0.05
+    assert 0.0 <= measured[1] < measured[0] and 0.0 <= predicted[1] < predicted[0]
+    assert measured[0] - measured[1] > 0.005 and predicted[0] - predicted[1] > 0.005
+    measured_ratio, predicted_ratio = measured[1] / measured[0], predicted[1] / predicted[0]
+    relative_error = abs(measured_ratio - predicted_ratio) / predicted_ratio
+    print("AETHER_SATURATION_FALLOFF", dict(distances_m=distances, measured=measured, predicted=predicted, relative_error=relative_error))
+    assert relative_error <= 0.10
+    # the whole distance range, not just the two scored points (the post reads its aerial table at the nearest entry, so
+    # the curve has steps): the far half is less saturated than the near half
+    sat_post = [saturation(metrics.filmic_terrain_srgb(oracle.aether_aerial(h, surface, v["eye_altitude_m"], c["distance_m"], c["view"], sun, 1.0)))
+                for c in v["cases"]]
+    assert np.mean(sat_post[5:]) < np.mean(sat_post[:4]) - 0.02 and sat_post[-1] < sat_post[0]
 
 
 def test_missing_bank_is_visible_or_an_error(monkeypatch):
