@@ -103,7 +103,8 @@ def test_integration_md_rust_structs_match_the_header():
     `atmosphere`): its #[repr(C)] field lists, transcribed to C, have the header's size and the header's offset for
     EVERY field."""
     rust = _rust_structs_of_integration_md()
-    pairs = {"F3dTerrainRefDesc": "f3d_terrain_ref_desc", "F3dTerrainRefOut": "f3d_terrain_ref_out", "F3dAetherLuts": "f3d_aether_luts"}
+    pairs = {"F3dTerrainRefDesc": "f3d_terrain_ref_desc", "F3dTerrainRefOut": "f3d_terrain_ref_out", "F3dAetherLuts": "f3d_aether_luts",
+             "F3dAetherRefDesc": "f3d_aether_ref_desc", "F3dAetherRefOut": "f3d_aether_ref_out"}
     assert set(pairs) <= set(rust), sorted(rust)
     assert rust["F3dTerrainRefDesc"][0][0] == "struct_size" and rust["F3dTerrainRefDesc"][-1][0] == "atmosphere"
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "f3d_terrain_pt.h"']
