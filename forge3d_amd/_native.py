@@ -105,6 +105,7 @@ ABI = [
     ("f3d_session_set_accumulation", C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]),
     ("f3d_session_halo_export", C.c_int, [C.c_void_p, _P(HaloExport), C.c_char_p, C.c_size_t]),
     ("f3d_session_halo_connect", C.c_int, [C.c_void_p, C.c_int32, _P(HaloExport), C.c_char_p, C.c_size_t]),
+    ("f3d_session_halo_probe", C.c_int, [C.c_void_p, C.c_int32, C.c_uint32, _P(C.c_uint32), C.c_char_p, C.c_size_t]),
     ("f3d_session_halo_status", C.c_int, [C.c_void_p, _P(C.c_uint32), C.c_char_p, C.c_size_t]),
     ("f3d_session_enqueue_batch_strip", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_char_p, C.c_size_t]),
     ("f3d_session_frames_in_flight", C.c_uint32, [C.c_void_p]),

@@ -1072,6 +1072,13 @@ __global__ __launch_bounds__(1024) void k_halo_pull(const HaloPullParams H) {
         H.dst[side][i] = __hip_atomic_load(H.src[side] + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Link check (f3d_session_halo_probe): word 2 of a strip's counter block is a nonce its owner stores and its
+// neighbours read back, with the accesses the frame loop uses.
+__global__ void k_halo_probe_read(const uint32_t *above, const uint32_t *below, uint32_t *out) {
+    out[0] = above ? __hip_atomic_load(above + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+    out[1] = below ? __hip_atomic_load(below + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+}
+
 void enqueue_halo_sync(f3d_session &s, uint32_t frame) {  // behind the kernels of `frame`
     hipLaunchKernelGGL(k_halo_flag, dim3(1), dim3(1), 0, s.stream, s.halo_flags, frame + 1u);
     if (!s.peer[0].connected && !s.peer[1].connected) return;
@@ -1258,6 +1265,11 @@ int f3d_session_halo_connect(f3d_session *s, int32_t side, const f3d_halo_export
             void *base = nullptr;
             if (peer->pid == (uint32_t)getpid()) {
                 mapped[i] = (void *)(uintptr_t)peer->address[i];  // a process cannot open its own handles: same address space
+                if (peer->device != s->device) {  // (one process driving several GPUs: map the neighbour's memory here)
+                    const hipError_t e = hipDeviceEnablePeerAccess(peer->device, 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) hip_check(e, "hipDeviceEnablePeerAccess");
+                    (void)hipGetLastError();
+                }
                 continue;
             } else {
                 hip_check(hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess), "hipIpcOpenMemHandle");
@@ -1270,6 +1282,25 @@ int f3d_session_halo_connect(f3d_session *s, int32_t side, const f3d_halo_export
         L.flags = (const uint32_t *)mapped[2];
         L.rows = peer->rows;
         L.connected = true;
+    });
+}
+
+int f3d_session_halo_probe(f3d_session *s, int32_t mode, uint32_t nonce, uint32_t *seen, char *err, size_t errlen) {
+    return c_abi(err, errlen, [&] {
+        DeviceGuard g(checked(s).device);
+        if (!s->halo_flags) fail(F3D_STATUS_VALUE, "f3d_session_halo_export has not been called for this session");
+        if (mode == 0) {  // publish: the store the frame loop uses for its counter
+            hipLaunchKernelGGL(k_halo_flag, dim3(1), dim3(1), 0, s->stream, s->halo_flags + 2, nonce);
+            hip_check(hipStreamSynchronize(s->stream), "halo probe store");
+        } else if (mode == 1) {  // read the neighbours' words with the loads the pull uses
+            if (!seen) fail(F3D_STATUS_VALUE, "null output");
+            hipLaunchKernelGGL(k_halo_probe_read, dim3(1), dim3(1), 0, s->stream, s->peer[0].connected ? s->peer[0].flags : nullptr,
+                               s->peer[1].connected ? s->peer[1].flags : nullptr, s->halo_flags + 4);
+            hip_check(hipStreamSynchronize(s->stream), "halo probe load");
+            hip_check(hipMemcpy(seen, s->halo_flags + 4, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost), "halo probe read-back");
+        } else {
+            fail(F3D_STATUS_VALUE, "halo probe: mode must be 0 (publish) or 1 (read)");
+        }
     });
 }
 

@@ -239,12 +239,36 @@ class StripRenderer:
                     session.halo_connect(1, bytes(parts[self.rank + 1].cpu().numpy()[:n].tobytes()))
             except Exception:  # noqa: BLE001
                 ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) != 1:
+        def agreed(value):
+            flag = torch.tensor([value], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag.item()) == 1
+
+        if not agreed(ok):
             if session is not None:
                 session.close()
             return None
+        # Link check before a frame depends on it: every strip publishes a word the way it will publish its frame counter,
+        # and reads its neighbours' words the way it will read their counters and rows -- twice, so that a value cached
+        # from the first round would be caught.  Anything but the expected words on any rank: everybody falls back.
+        for salt in (0x5EED0000, 0x0BEEF000):
+            try:
+                session.halo_probe_publish(salt + self.rank + 1)
+            except Exception:  # noqa: BLE001
+                ok = 0
+            dist.barrier()
+            if ok:
+                try:
+                    above, below = session.halo_probe_read()
+                    if self.rank > 0 and above != salt + self.rank:
+                        ok = 0
+                    if self.rank < self.world - 1 and below != salt + self.rank + 2:
+                        ok = 0
+                except Exception:  # noqa: BLE001
+                    ok = 0
+            if not agreed(ok):
+                session.close()
+                return None
         dist.barrier()  # nobody starts rendering (and polling counters) before every neighbour is mapped
         return session
 

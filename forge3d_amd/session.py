@@ -139,6 +139,16 @@ class TerrainSession:
         rec = _native.HaloExport.from_buffer_copy(export)
         self._check(self._lib.f3d_session_halo_connect(self._handle, int(side), C.byref(rec), self._err, len(self._err)))
 
+    def halo_probe_publish(self, nonce: int):
+        """Link check, step 1: store `nonce` into this strip's counter block (the store the frame counter uses)."""
+        self._check(self._lib.f3d_session_halo_probe(self._handle, 0, int(nonce) & 0xFFFFFFFF, None, self._err, len(self._err)))
+
+    def halo_probe_read(self):
+        """Link check, step 2 (after a barrier): the neighbours' words as this device reads them: (above, below)."""
+        seen = (C.c_uint32 * 2)()
+        self._check(self._lib.f3d_session_halo_probe(self._handle, 1, 0, seen, self._err, len(self._err)))
+        return int(seen[0]), int(seen[1])
+
     def halo_timeouts(self) -> int:
         """Device-side halo waits that gave up (a neighbour that stopped); synchronises."""
         n = C.c_uint32(0)

@@ -219,6 +219,11 @@ int f3d_session_halo(f3d_session *session, int32_t which, int32_t side, void **p
  *   f3d_session_halo_export   what a neighbour needs to map this strip (the session must own its reservoirs: no
  *                             ext_reservoirs); plain bytes, moved between the ranks by any means (all_gather)
  *   f3d_session_halo_connect  side 0 = the strip above (smaller rows), 1 = the strip below; peer = its export
+ *   f3d_session_halo_probe    link check before the first frame: mode 0 stores `nonce` into this strip's counter block the
+ *                             way the frame counter is stored, mode 1 reads the neighbours' words back (seen[0] = above,
+ *                             seen[1] = below; 0 where there is no neighbour) with the loads the pull uses.  With a barrier
+ *                             of the caller's between the two, a neighbour whose word does not read back (no peer access
+ *                             between the devices, a stale mapping) is found before a frame depends on it
  *   f3d_session_halo_status   device-side wait time-outs so far (a dead neighbour must not hang the GPU: a wait gives
  *                             up after ~4 s and counts here; the caller turns a non-zero count into an error) */
 typedef struct f3d_halo_export {
@@ -231,6 +236,7 @@ typedef struct f3d_halo_export {
 } f3d_halo_export;
 int f3d_session_halo_export(f3d_session *session, f3d_halo_export *out, char *err, size_t errlen);
 int f3d_session_halo_connect(f3d_session *session, int32_t side, const f3d_halo_export *peer, char *err, size_t errlen);
+int f3d_session_halo_probe(f3d_session *session, int32_t mode, uint32_t nonce, uint32_t *seen, char *err, size_t errlen);
 int f3d_session_halo_status(f3d_session *session, uint32_t *timeouts, char *err, size_t errlen);
 /* Frames [first, first + count) of a connected strip: per frame the frame's kernels (fused, or trace batch + merge with
  * frames in flight), the counter, the pull of both neighbours' rows.  One call, no host synchronisation. */

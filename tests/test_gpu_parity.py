@@ -515,6 +515,11 @@ def test_peer_halo_strips_reproduce_the_full_image(f3d, in_flight, frames):
             s.halo_connect(1, exports[i + 1])
     with pytest.raises(ValueError):
         sessions[0].halo_connect(1, exports[1])  # connected already
+    for round_, salt in enumerate((0x5EED0000, 0x0BEEF000)):  # the link check of StripRenderer._connect_peers: publish, then read
+        for i, s in enumerate(sessions):
+            s.halo_probe_publish(salt + i + 1)
+        seen = [s.halo_probe_read() for s in sessions]
+        assert seen == [(0, salt + 2), (salt + 1, salt + 3), (salt + 2, 0)], (round_, seen)
     for s in reversed(sessions):  # (the last strip first: nobody's wait may depend on the order of the enqueues)
         s.enqueue_batch_strip(0, frames, True)
     torch.cuda.synchronize()
