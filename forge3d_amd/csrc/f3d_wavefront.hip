@@ -195,6 +195,7 @@ extern "C" int f3d_wavefront_render(const f3d_wf_scene *scene, uint32_t width, u
         S.inst = (const wf::InstanceDev *)upload(prep.inst.data(), prep.inst.size() * sizeof(wf::InstanceDev), "instances");
         S.dir = (const wf::DirLightDev *)upload(prep.dir.data(), prep.dir.size() * sizeof(wf::DirLightDev), "directional lights");
         S.area = (const wf::AreaLightDev *)upload(prep.area.data(), prep.area.size() * sizeof(wf::AreaLightDev), "area lights");
+        S.hair = (const wf::HairDev *)upload(prep.hair.data(), prep.hair.size() * sizeof(wf::HairDev), "hair segments");
         SharedTerrain terrain;  // the heightfield primitive: the terrain tracer's tables (scene cache), its placement from prepare_scene
         if (scene->terrain) {
             terrain = acquire_shared_terrain(scene->terrain->heights, scene->terrain->dem_width, scene->terrain->dem_height,

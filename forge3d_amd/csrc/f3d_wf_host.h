@@ -65,6 +65,12 @@ inline void validate_scene(const f3d_wf_scene &s, uint32_t width, uint32_t heigh
         fail(F3D_STATUS_VALUE, "camera vectors must be finite");
     if (!(std::isfinite(s.cam_fov_y) && s.cam_fov_y > 0.0f && s.cam_fov_y < 3.14159265f)) fail(F3D_STATUS_VALUE, "cam_fov_y must be in (0, pi) radians");
     if (!(std::isfinite(s.cam_exposure) && s.cam_exposure >= 0.0f)) fail(F3D_STATUS_VALUE, "cam_exposure must be finite and >= 0");
+    if (s.hair_count && !s.hair) fail(F3D_STATUS_VALUE, "hair_count is %u but hair is null", s.hair_count);
+    for (uint32_t i = 0; i < s.hair_count; i++)
+        if (!finite_n(s.hair[i].p0, 3) || !finite_n(s.hair[i].p1, 3) || !std::isfinite(s.hair[i].r0) || !std::isfinite(s.hair[i].r1))
+            fail(F3D_STATUS_VALUE, "hair segment %u has non-finite parameters", i);
+    if (!std::isfinite(s.medium.g) || !std::isfinite(s.medium.sigma_t) || !std::isfinite(s.medium.density) || !std::isfinite(s.medium.enabled))
+        fail(F3D_STATUS_VALUE, "medium parameters must be finite");
     if (s.terrain) {  // the heightfield primitive: the terrain tracer's own input rules (render_terrain.rs:474-557)
         const f3d_wf_terrain &t = *s.terrain;
         if (!t.heights || t.dem_width < 2u || t.dem_height < 2u) fail(F3D_STATUS_UPLOAD, "terrain heightfield must be at least 2x2 texels, got %ux%u", t.dem_width, t.dem_height);
@@ -87,6 +93,7 @@ struct PreparedScene {
     std::vector<InstanceDev> inst;
     std::vector<DirLightDev> dir;
     std::vector<AreaLightDev> area;
+    std::vector<HairDev> hair;
     SceneDev S;  // counts and scalars filled in; the array pointers are the caller's to set
 };
 
@@ -158,6 +165,12 @@ inline PreparedScene prepare_scene(const f3d_wf_scene &s, uint32_t width, uint32
     S.height = height;
     S.seed_hi = s.seed_hi;
     S.seed_lo = s.seed_lo;
+    out.hair.resize(s.hair_count);
+    for (uint32_t i = 0; i < s.hair_count; i++)
+        out.hair[i] = HairDev{v3p(s.hair[i].p0), s.hair[i].r0, v3p(s.hair[i].p1), s.hair[i].r1, s.hair[i].material_id, 0u, 0u, 0u};
+    S.hair_count = s.hair_count;
+    S.medium_on = s.medium.enabled > 0.5f ? 1u : 0u;  // pt_shade.wgsl:500-502
+    S.medium_mu = f_max(s.medium.sigma_t * s.medium.density, 0.0f);
     S.has_terrain = 0u;
     if (s.terrain) {  // placement and scalars as fill_uniforms (f3d_setup.h); tables are the caller's to attach
         const f3d_wf_terrain &t = *s.terrain;

@@ -56,6 +56,13 @@ struct InstanceDev {
     float w2o[16];  // world_to_object, column-major
     uint32_t blas, material, pad0, pad1;
 };
+struct HairDev {  // HairSegment, pt_intersect.wgsl:60-69
+    V3 p0;
+    float r0;
+    V3 p1;
+    float r1;
+    uint32_t material, pad0, pad1, pad2;
+};
 struct DirLightDev {
     V3 wi;  // normalize(-direction)
     float importance;
@@ -90,6 +97,11 @@ struct SceneDev {
     // optional heightfield primitive (see the header): tables as the terrain tracer builds them, material slot of its hits
     TerrainDev terrain;
     uint32_t has_terrain, terrain_mat;
+    // hair strands (closest hits only) and the homogeneous fog (pt_shade.wgsl:328-338, :500-520)
+    const HairDev *hair;
+    uint32_t hair_count;
+    float medium_mu;      // max(sigma_t * density, 0)
+    uint32_t medium_on;
 };
 
 constexpr float kTwoPiInv = 0.15915494309189533577f;
@@ -292,7 +304,35 @@ struct SurfaceHitWf {
     V3 p, n;
     float t;
     uint32_t mat;
+    bool hair;   // Hit.flags bit 0
+    V3 tangent;  // strand axis (hair hits only)
 };
+
+// ray_cylinder_segment, pt_intersect.wgsl:21-57: the open cylinder of radius r around p0 p1
+F3D_HD bool hair_segment(V3 o, V3 d, float tmin, float tmax, V3 p0, V3 p1, float r, float &t_out, V3 &n_out) {
+    const V3 axis = p1 - p0;
+    const float L = f_sqrt(dot(axis, axis));
+    if (L < 1e-6f || r <= 0.0f) return false;
+    const V3 n{axis.x / L, axis.y / L, axis.z / L};
+    const V3 w0 = o - p0;
+    const float d_par = dot(d, n);
+    const V3 d_perp = d - n * d_par, w_perp = w0 - n * dot(w0, n);
+    const float A = dot(d_perp, d_perp), B = 2.0f * dot(d_perp, w_perp), C = dot(w_perp, w_perp) - r * r;
+    if (A < 1e-12f) return false;
+    const float disc = B * B - (4.0f * A) * C;
+    if (disc < 0.0f) return false;
+    const float sdisc = f_sqrt(f_max(disc, 0.0f));
+    const float t0 = (-B - sdisc) / (2.0f * A), t1 = (-B + sdisc) / (2.0f * A);
+    float thit = 1e30f;
+    if (t0 > tmin && t0 < tmax) thit = t0;
+    if (t1 > tmin && t1 < thit) thit = t1;
+    if (thit >= 1e20f) return false;
+    const float along_axis = dot(w0 + d * thit, n);
+    if (along_axis < 0.0f || along_axis > L) return false;
+    t_out = thit;
+    n_out = normalize(w_perp + d_perp * thit);
+    return true;
+}
 
 // pt_intersect.wgsl main, :431-558 (+ the terrain primitive)
 template <class Wave>
@@ -342,6 +382,20 @@ F3D_HD bool closest(const SceneDev &S, V3 o, V3 d, float tmin, SurfaceHitWf &H, 
             }
         }
     }
+    bool hair = false;
+    V3 tangent{0.0f, 0.0f, 0.0f};
+    for (uint32_t i = 0u; i < S.hair_count; i++) {  // hair strands, :499-521 (after spheres and meshes, like the reference)
+        const HairDev seg = S.hair[i];
+        float t;
+        V3 nn;
+        if (hair_segment(o, d, tmin, tmax, seg.p0, seg.p1, f_max(0.0f, (0.5f * (seg.r0 + seg.r1)) * 1.0f), t, nn) && t < t_best) {
+            t_best = t;
+            n = nn;
+            mat = S.sphere_count > 0u ? (seg.material < S.sphere_count - 1u ? seg.material : S.sphere_count - 1u) : 0u;
+            hair = true;
+            tangent = normalize(seg.p1 - seg.p0);
+        }
+    }
     if (Wave::kTerrain && S.has_terrain != 0u) {  // terrain_trace(ray with tmax = the closest hit so far), curvature off
         const RayCtx r = make_ray(S.terrain, o, tmin, d, t_best, false);
         const TraceHit th = march_terrain<false>(S.terrain, r, false, true, *wave.pend);
@@ -349,6 +403,7 @@ F3D_HD bool closest(const SceneDev &S, V3 o, V3 d, float tmin, SurfaceHitWf &H, 
             t_best = th.t;
             n = th.n;
             mat = S.terrain_mat;
+            hair = false;
         }
     }
     if (!(t_best < 1e20f)) return false;
@@ -356,6 +411,8 @@ F3D_HD bool closest(const SceneDev &S, V3 o, V3 d, float tmin, SurfaceHitWf &H, 
     H.t = t_best;
     H.n = n;
     H.mat = mat;
+    H.hair = hair;
+    H.tangent = tangent;
     return true;
 }
 
@@ -517,6 +574,13 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
     const float n_dot_v = f_max(dot(n, wo), 0.0f);
     const Frame3 basis = tangent_frame(n);
     const V3 so = H.p + n * 1e-3f;
+    // homogeneous fog, :328-338 / :500-520: next-event contributions of this vertex are attenuated over the segment that
+    // reached it; a PRIMARY hit also adds the environment seen through the fog it looks through
+    const float mtrans = S.medium_on != 0u ? exp_det(-f_max(H.t, 0.0f) * S.medium_mu) : 1.0f;
+    if (S.medium_on != 0u && P.depth == 0u) {
+        const V3 back = neg(wo);
+        acc = acc + mix3(S.env_ground, S.env_sky, 0.5f * (back.y + 1.0f)) * (1.0f - mtrans);
+    }
 
     {  // environment, mixture of a power-cosine lobe about +Y and the cosine hemisphere, balance heuristic
         const float u1 = rng_next(rng), u2 = rng_next(rng), u3 = rng_next(rng);
@@ -537,7 +601,7 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
             const V3 L_env = mix3(S.env_ground, S.env_sky, 0.5f * (wi.y + 1.0f));
             const Bsdf br = bsdf_eval(M, wo, wi, n);
             const float w_mis = pdf_light / f_max(pdf_light + br.pdf, 1e-8f);
-            const float k = (((cos_surf / f_max(pdf_light, 1e-8f)) * w_mis) * M.imp) * 1.0f;
+            const float k = (((cos_surf / f_max(pdf_light, 1e-8f)) * w_mis) * M.imp) * mtrans;
             const V3 contrib = ((P.thr * br.f) * L_env) * k;
             if (!shadowed(S, so, wi, 1e-3f, 1e30f, wave)) acc = acc + contrib;
         }
@@ -549,7 +613,7 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
         if (cos_surf > 0.0f) {
             const Bsdf br = bsdf_eval(M, wo, L.wi, n);
             const float p_sel = S.dir_sum_imp > 0.0f ? L.importance / f_max(S.dir_sum_imp, 1e-8f) : 1.0f / (float)S.dir_count;
-            const float k = ((cos_surf / f_max(p_sel, 1e-8f)) * M.imp) * 1.0f;
+            const float k = ((cos_surf / f_max(p_sel, 1e-8f)) * M.imp) * mtrans;
             const V3 contrib = ((P.thr * br.f) * L.Li) * k;
             if (!shadowed(S, so, L.wi, 1e-3f, 1e30f, wave)) acc = acc + contrib;
         }
@@ -574,7 +638,7 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
                     const float p_sel = S.area_sum_imp > 0.0f ? L.importance / f_max(S.area_sum_imp, 1e-8f) : 1.0f / (float)S.area_count;
                     const float pdf_light = p_sel * pdf;
                     const float w_mis = pdf_light / f_max(pdf_light + br.pdf, 1e-8f);
-                    const float k = (((cos_surf / f_max(pdf_light, 1e-8f)) * w_mis) * M.imp) * 1.0f;
+                    const float k = (((cos_surf / f_max(pdf_light, 1e-8f)) * w_mis) * M.imp) * mtrans;
                     const V3 contrib = ((P.thr * br.f) * L.Li) * k;
                     if (!shadowed(S, so, wi, 1e-3f, dist - 1e-3f, wave)) acc = acc + contrib;
                 }
@@ -583,7 +647,19 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
     }
 
     V3 wi, thr;
-    if (md.metallic > 0.5f) {  // GGX half-vector sampling
+    if (H.hair) {  // Kajiya-Kay, :708-729: cosine-hemisphere continuation weighted by a diffuse term and two lobes about the strand
+        const V3 T = normalize(H.tangent);
+        const float u1 = rng_next(rng), u2 = rng_next(rng);
+        wi = normalize(to_world(basis, cosine_hemisphere(u1, u2)));
+        const float lobe = f_max(0.0f, dot(normalize(reflect3(neg(wo), T)), wi));
+        const float l2 = lobe * lobe, l4 = l2 * l2, l16 = pow16(lobe), l64 = (l16 * l16) * (l16 * l16);
+        const float f1 = l16 * l4, f2 = l64 * l16;  // exponents 20 and 80
+        const float kd = 0.2f, ks = 1.0f - kd, spec = ks * (0.6f * f1 + 0.4f * f2);
+        const V3 f{kd * (md.albedo.x / kPi) + M.F0.x * spec, kd * (md.albedo.y / kPi) + M.F0.y * spec, kd * (md.albedo.z / kPi) + M.F0.z * spec};
+        const float cos_theta = f_max(0.0f, dot(n, wi));
+        const float pdf = cos_theta / kPi + 1e-8f;
+        thr = (P.thr * f) * (cos_theta / pdf);
+    } else if (md.metallic > 0.5f) {  // GGX half-vector sampling
         const float u1 = rng_next(rng), u2 = rng_next(rng);
         const float a = f_max(0.02f, md.roughness * md.roughness);
         const V3 t{basis.t.x, basis.b.x, basis.n.x}, bb{basis.t.y, basis.b.y, basis.n.y}, nn{basis.t.z, basis.b.z, basis.n.z};

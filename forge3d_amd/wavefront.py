@@ -89,8 +89,32 @@ class Terrain:
 
 
 @dataclass
+class HairSegment:
+    """A strand segment: the open cylinder of radius (r0 + r1) / 2 around p0 p1 (reference HairSegment, pt_intersect.wgsl:
+    60-69); visible to closest-hit rays, shaded with the Kajiya-Kay continuation (pt_shade.wgsl:708-729)."""
+    p0: Sequence[float] = (0.0, 0.0, 0.0)
+    r0: float = 0.01
+    p1: Sequence[float] = (0.0, 1.0, 0.0)
+    r1: float = 0.01
+    material_id: int = 0
+
+
+@dataclass
+class Medium:
+    """Homogeneous fog of the PBR tracer (reference MediumParams + WavefrontScheduler::set_medium_params): extinction
+    sigma_t * density; next-event contributions are attenuated over the segment that reached the vertex and a primary
+    hit adds env(-wo) * (1 - T).  `g` is carried but unused, like in the reference's shader."""
+    g: float = 0.0
+    sigma_t: float = 0.0
+    density: float = 0.0
+    enabled: bool = False
+
+
+@dataclass
 class WavefrontScene:
     terrain: Optional[Terrain] = None
+    hair: List[HairSegment] = field(default_factory=list)
+    medium: Optional[Medium] = None
     spheres: List[Sphere] = field(default_factory=list)
     meshes: List[Tuple[np.ndarray, np.ndarray]] = field(default_factory=list)
     instances: List[Instance] = field(default_factory=list)
@@ -141,6 +165,9 @@ class WavefrontScene:
             "terrain": None if self.terrain is None else {
                 "heights": np.ascontiguousarray(self.terrain.heights, np.float32), "spacing": tuple(float(v) for v in self.terrain.spacing),
                 "exaggeration": float(self.terrain.exaggeration), "material_id": int(self.terrain.material_id)},
+            "hair": [vars(h) for h in self.hair],
+            "medium": None if self.medium is None else {"g": float(self.medium.g), "sigma_t": float(self.medium.sigma_t),
+                                                        "density": float(self.medium.density), "enabled": 1.0 if self.medium.enabled else 0.0},
         }
 
 
@@ -242,6 +269,14 @@ class _Terrain(C.Structure):
                 ("spacing_z", C.c_float), ("exaggeration", C.c_float), ("material_id", C.c_uint32)]
 
 
+class _Hair(C.Structure):
+    _fields_ = [("p0", C.c_float * 3), ("r0", C.c_float), ("p1", C.c_float * 3), ("r1", C.c_float), ("material_id", C.c_uint32), ("pad", C.c_uint32 * 3)]
+
+
+class _Medium(C.Structure):
+    _fields_ = [("g", C.c_float), ("sigma_t", C.c_float), ("density", C.c_float), ("enabled", C.c_float)]
+
+
 class _Scene(C.Structure):
     _fields_ = [("struct_size", C.c_uint32),
                 ("spheres", C.POINTER(_Sphere)), ("sphere_count", C.c_uint32),
@@ -253,7 +288,7 @@ class _Scene(C.Structure):
                 ("env_ground", C.c_float * 4), ("env_sky", C.c_float * 4), ("miss_ground", C.c_float * 4), ("miss_sky", C.c_float * 4),
                 ("cam_origin", C.c_float * 3), ("cam_right", C.c_float * 3), ("cam_up", C.c_float * 3), ("cam_forward", C.c_float * 3),
                 ("cam_fov_y", C.c_float), ("cam_exposure", C.c_float), ("seed_hi", C.c_uint32), ("seed_lo", C.c_uint32),
-                ("terrain", C.POINTER(_Terrain))]
+                ("terrain", C.POINTER(_Terrain)), ("hair", C.POINTER(_Hair)), ("hair_count", C.c_uint32), ("medium", _Medium)]
 
 
 class _Out(C.Structure):
@@ -312,6 +347,17 @@ def _marshal(scene: Dict[str, Any]):
                        float(t["exaggeration"]), int(t["material_id"]))
         keep += [dem, rec]
         s.terrain = C.pointer(rec)
+    hair = scene.get("hair") or []
+    hair_arr = (_Hair * max(1, len(hair)))()
+    for dst, src in zip(hair_arr, hair):
+        _set_vec(dst.p0, src["p0"])
+        _set_vec(dst.p1, src["p1"])
+        dst.r0, dst.r1, dst.material_id = float(src["r0"]), float(src["r1"]), int(src["material_id"])
+    keep.append(hair_arr)
+    s.hair, s.hair_count = hair_arr, len(hair)
+    if scene.get("medium") is not None:
+        m = scene["medium"]
+        s.medium = _Medium(float(m["g"]), float(m["sigma_t"]), float(m["density"]), float(m["enabled"]))
     return s, keep
 
 

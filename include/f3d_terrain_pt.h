@@ -29,8 +29,10 @@ extern "C" {
  * against) and the library refuses a size it does not know (status 1) instead of reading past the caller's struct.
  *   1  round 1: f3d_terrain_ref_desc without `atmosphere`, no struct_size members
  *   2  round 2: + f3d_terrain_ref_desc.atmosphere (binary-incompatible, unversioned -- the reason for this scheme)
- *   3  round 3: + struct_size first in f3d_terrain_ref_desc / f3d_session_opts, f3d_abi_version(),
- *               f3d_session_enqueue_batch_strip / f3d_session_connect_halo */
+ *   3  round 3: + struct_size first in f3d_terrain_ref_desc / f3d_session_opts / f3d_wf_scene (and in the new
+ *               f3d_composite_desc, f3d_aether_ref_desc), f3d_abi_version(); f3d_wf_scene + terrain, hair, medium;
+ *               new entry points: peer halos (f3d_session_halo_*, f3d_session_enqueue_batch_strip),
+ *               f3d_session_set_accumulation, f3d_smoke_step, f3d_smoke_composite, f3d_aether_reference_render */
 #define F3D_ABI_VERSION 3u
 #define F3D_STATUS_OK 0
 #define F3D_STATUS_VALUE 1

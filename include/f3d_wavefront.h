@@ -57,6 +57,20 @@ typedef struct f3d_wf_terrain {
     uint32_t material_id; /* slot of the sphere / material table; clamped to sphere_count - 1 like instance materials */
 } f3d_wf_terrain;
 
+typedef struct f3d_wf_hair_segment { /* HairSegment, pt_intersect.wgsl:60-69: a world-space cylinder between p0 and p1 */
+    float p0[3], r0, p1[3], r1; /* the radius traced is max(0, (r0 + r1) / 2) (HAIR_RADIUS_SCALE = 1) */
+    uint32_t material_id;       /* slot of the sphere / material table, clamped to sphere_count - 1 */
+    uint32_t pad[3];
+} f3d_wf_hair_segment;
+
+typedef struct f3d_wf_medium { /* MediumParams, pt_shade.wgsl:34-39 (WavefrontScheduler::set_medium_params, control.rs:114) */
+    float g;       /* Henyey-Greenstein anisotropy: carried, unused by the reference's shader */
+    float sigma_t; /* extinction coefficient */
+    float density; /* scale: the homogeneous fog has mu = sigma_t * density */
+    float enabled; /* > 0.5: every next-event contribution of a vertex is attenuated over the segment that reached it,
+                      and a primary hit adds env(-wo) * (1 - T) */
+} f3d_wf_medium;
+
 typedef struct f3d_wf_scene {
     uint32_t struct_size; /* = sizeof(f3d_wf_scene) of the caller's header (F3D_ABI_VERSION, f3d_terrain_pt.h) */
     const f3d_wf_sphere *spheres;
@@ -78,6 +92,9 @@ typedef struct f3d_wf_scene {
     float cam_exposure;
     uint32_t seed_hi, seed_lo; /* ReferenceSceneDesc seeds; frame f runs with splitmix32(seed ^ f ...) (adjudication.rs:231) */
     const f3d_wf_terrain *terrain; /* NULL: no heightfield */
+    const f3d_wf_hair_segment *hair; /* hair strands as cylinder segments (Kajiya-Kay continuation, pt_shade.wgsl:708-729); they */
+    uint32_t hair_count;             /* are visible to closest-hit rays only: the reference's shadow stage does not test them */
+    f3d_wf_medium medium;            /* all zero: no fog */
 } f3d_wf_scene;
 
 typedef struct f3d_wf_out {

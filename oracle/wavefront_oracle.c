@@ -21,8 +21,10 @@
  * contributions of a frame's path are summed, starting from zero, in the order the stages would add them (emission,
  * environment, directional, area at every vertex; the miss of the last ray last), and the frame totals are added to
  * the pixel in frame order.  Frame totals do not depend on the running sum, which is what lets the device compute
- * them in any order and fold them afterwards.  ReSTIR guiding, the fog medium and hair segments are switched off /
- * empty in render_pt_reference and are not restated.  Mesh hits: the reference walks a BVH and keeps the first of
+ * them in any order and fold them afterwards.  ReSTIR guiding is switched off in render_pt_reference and is not restated;
+ * the fog medium (pt_shade.wgsl:328-338, :500-520) and hair segments (pt_intersect.wgsl:21-57, :499-544; pt_shade.wgsl:
+ * 708-729) are off / empty there too and are restated here behind scene fields that default to off (no golden of the
+ * reference exercises them: pinned by properties only, tests/test_wavefront.py).  Mesh hits: the reference walks a BVH and keeps the first of
  * equal-t hits in ITS visit order; here all triangles of the BLAS are swept in index order (lowest index wins a
  * tie), and the BVH's box test is treated as conservative.
  *
@@ -52,6 +54,7 @@ typedef struct {                                                                
     uint32_t blas_index, material_id;
 } wfo_instance;
 typedef struct { const float *vertices; uint32_t vertex_count; const uint32_t *indices; uint32_t triangle_count; } wfo_mesh;
+struct wfo_hair { float p0[3], r0, p1[3], r1; uint32_t material_id, pad[3]; }; /* HairSegment, pt_intersect.wgsl:60-69 */
 typedef struct {
     const wfo_sphere *spheres; uint32_t sphere_count;
     const wfo_mesh *meshes; uint32_t mesh_count;
@@ -68,6 +71,8 @@ typedef struct {
      * (hybrid_terrain_traversal.wgsl:254-372), curvature off; NULL = none.  Its hits use material slot terrain_material. */
     const void *terrain;
     uint32_t terrain_material;
+    const struct wfo_hair *hair; uint32_t hair_count;  /* HairSegment buffer, pt_intersect.wgsl:330 */
+    float medium_g, medium_sigma_t, medium_density, medium_enabled; /* MediumParams, pt_shade.wgsl:34-39 */
 } wfo_scene;
 extern int f3do_terrain_trace(const void *handle, const float *o, float tmin, const float *d, float tmax, int32_t any_hit, float *t_out, float *n_out);
 
@@ -330,7 +335,35 @@ typedef struct {
     v3 p, n, wo, throughput;
     float t, pdf;
     uint32_t mat, pixel, depth, rng_hi, rng_lo;
+    uint32_t flags; /* bit 0 = is_hair */
+    v3 tangent;
 } hit_t;
+
+/* ray_cylinder_segment, pt_intersect.wgsl:21-57 */
+static int ray_cylinder_segment(const ray_t *ray, v3 p0, v3 p1, float r, float *t_out, v3 *n_out) {
+    const v3 axis = sub(p1, p0);
+    const float L = length3(axis);
+    if (L < 1e-6f || r <= 0.0f) return 0;
+    const v3 n = mk(axis.x / L, axis.y / L, axis.z / L);
+    const v3 w0 = sub(ray->o, p0);
+    const float d_par = dot3(ray->d, n);
+    const v3 d_perp = sub(ray->d, scale(n, d_par)), w_perp = sub(w0, scale(n, dot3(w0, n)));
+    const float A = dot3(d_perp, d_perp), B = 2.0f * dot3(d_perp, w_perp), C = dot3(w_perp, w_perp) - r * r;
+    if (A < 1e-12f) return 0;
+    const float disc = B * B - (4.0f * A) * C;
+    if (disc < 0.0f) return 0;
+    const float sdisc = sqrtf(fmaxf(disc, 0.0f));
+    const float t0 = (-B - sdisc) / (2.0f * A), t1 = (-B + sdisc) / (2.0f * A);
+    float thit = 1e30f;
+    if (t0 > ray->tmin && t0 < ray->tmax) thit = t0;
+    if (t1 > ray->tmin && t1 < thit) thit = t1;
+    if (thit >= 1e20f) return 0;
+    const float s = dot3(add(w0, scale(ray->d, thit)), n);
+    if (s < 0.0f || s > L) return 0;
+    *t_out = thit;
+    *n_out = normalize3(add(w_perp, scale(d_perp, thit)));
+    return 1;
+}
 
 /* main, :431-558.  Returns 1 on hit. */
 static int intersect(const wfo_scene *sc, const ray_t *ray, hit_t *hit) {
@@ -368,12 +401,27 @@ static int intersect(const wfo_scene *sc, const ray_t *ray, hit_t *hit) {
             }
         }
     }
+    int is_hair = 0;
+    v3 hair_tangent = mk(0.0f, 0.0f, 0.0f);
+    for (uint32_t hi = 0u; hi < sc->hair_count; hi++) { /* :499-521 */
+        const struct wfo_hair *seg = &sc->hair[hi];
+        const float r = fmaxf(0.0f, (0.5f * (seg->r0 + seg->r1)) * 1.0f); /* HAIR_RADIUS_SCALE = 1.0 */
+        float t;
+        v3 n;
+        if (ray_cylinder_segment(ray, ld(seg->p0), ld(seg->p1), r, &t, &n) && t < t_best) {
+            t_best = t; hit_normal = n;
+            material_idx = sc->sphere_count > 0u ? (seg->material_id < sc->sphere_count - 1u ? seg->material_id : sc->sphere_count - 1u) : 0u;
+            is_hair = 1;
+            hair_tangent = normalize3(sub(ld(seg->p1), ld(seg->p0)));
+        }
+    }
     if (sc->terrain) { /* the heightfield: terrain_trace with tmax = the closest hit so far */
         const float o[3] = {ray->o.x, ray->o.y, ray->o.z}, d[3] = {ray->d.x, ray->d.y, ray->d.z};
         float t, n[3];
         if (f3do_terrain_trace(sc->terrain, o, ray->tmin, d, t_best, 0, &t, n) && t < t_best) {
             t_best = t; hit_normal = mk(n[0], n[1], n[2]);
             material_idx = sc->sphere_count > 0u ? (sc->terrain_material < sc->sphere_count - 1u ? sc->terrain_material : sc->sphere_count - 1u) : 0u;
+            is_hair = 0;
         }
     }
     if (!(t_best < 1e20f)) return 0;
@@ -384,7 +432,8 @@ static int intersect(const wfo_scene *sc, const ray_t *ray, hit_t *hit) {
     hit->mat = material_idx;
     hit->throughput = ray->throughput; hit->pdf = ray->pdf; hit->pixel = ray->pixel; hit->depth = ray->depth;
     hit->rng_hi = ray->rng_hi; hit->rng_lo = ray->rng_lo;
-    (void)tangent_from_normal;
+    hit->flags = is_hair ? 1u : 0u;                       /* :538-544 */
+    hit->tangent = is_hair ? hair_tangent : tangent_from_normal(hit_normal);
     return 1;
 }
 
@@ -636,7 +685,14 @@ static int shade(const wfo_scene *sc, const frame_t *u, const hit_t *h, float *a
     uint32_t rng_state = h->rng_hi ^ (h->pixel * 26699u) ^ (u->frame_index * 30977u);
     const v3 n = normalize3(h->n), wo = normalize3(h->wo);
     const float n_dot_v = fmaxf(dot3(n, wo), 0.0f);
-    const float mtrans = 1.0f;                                /* medium_params.enabled = 0 (wavefront/mod.rs:199) */
+    /* homogeneous medium, :328-338 / :500-520 (media_transmittance = exp(-max(d, 0) max(mu, 0)); fixed-polynomial exp) */
+    const int medium_on = sc->medium_enabled > 0.5f;
+    const float mu = sc->medium_sigma_t * sc->medium_density;
+    const float mtrans = medium_on ? det_exp(-fmaxf(h->t, 0.0f) * fmaxf(mu, 0.0f)) : 1.0f;
+    if (medium_on && h->depth == 0u) { /* in-scattered environment on the primary segment */
+        const v3 fog_col = scale(env_color(sc, neg(wo)), 1.0f - mtrans);
+        accum[0] = accum[0] + fog_col.x; accum[1] = accum[1] + fog_col.y; accum[2] = accum[2] + fog_col.z;
+    }
     const basis_t basis = make_tangent_basis(n);
     const float a = fmaxf(0.02f, roughness * roughness);
     const float ax = fmaxf(0.002f, M->ax), ay = fmaxf(0.002f, M->ay);
@@ -700,10 +756,22 @@ static int shade(const wfo_scene *sc, const frame_t *u, const hit_t *h, float *a
             }
         }
     }
-    /* continuation, :699-806 (hair: no segments in this build) */
+    /* continuation, :699-806 */
     v3 wi, new_throughput;
     float pdf;
-    if (metallic > 0.5f) {
+    if ((h->flags & 1u) == 1u) { /* Kajiya-Kay, :708-729 (pow(x, 20) and pow(x, 80) by squaring) */
+        const v3 T = normalize3(h->tangent);
+        const float u1 = xorshift32(&rng_state), u2 = xorshift32(&rng_state);
+        wi = normalize3(to_world(&basis, sample_cosine_hemisphere(u1, u2)));
+        const float lobe = fmaxf(0.0f, dot3(normalize3(reflect3(neg(wo), T)), wi));
+        const float l2 = lobe * lobe, l4 = l2 * l2, l8 = l4 * l4, l16 = l8 * l8, l64 = (l16 * l16) * (l16 * l16);
+        const float f1 = l16 * l4, f2 = l64 * l16;
+        const float kd = 0.2f, ks = 1.0f - kd, spec = ks * (0.6f * f1 + 0.4f * f2);
+        const v3 f = mk(kd * (albedo.x / WF_PI) + F0.x * spec, kd * (albedo.y / WF_PI) + F0.y * spec, kd * (albedo.z / WF_PI) + F0.z * spec);
+        const float cos_theta = fmaxf(0.0f, dot3(n, wi));
+        pdf = cos_theta / WF_PI + 1e-8f;
+        new_throughput = scale(mul(h->throughput, f), cos_theta / pdf);
+    } else if (metallic > 0.5f) {
         const float u1 = xorshift32(&rng_state), u2 = xorshift32(&rng_state);
         const v3 t = mk(basis.t.x, basis.b.x, basis.n.x), bb = mk(basis.t.y, basis.b.y, basis.n.y), nn = mk(basis.t.z, basis.b.z, basis.n.z);
         const int aniso = !(fabsf(ax - ay) < 1e-4f);

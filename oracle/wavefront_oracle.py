@@ -46,6 +46,10 @@ class Mesh(C.Structure):
     _fields_ = [("vertices", C.c_void_p), ("vertex_count", C.c_uint32), ("indices", C.c_void_p), ("triangle_count", C.c_uint32)]
 
 
+class Hair(C.Structure):
+    _fields_ = [("p0", C.c_float * 3), ("r0", C.c_float), ("p1", C.c_float * 3), ("r1", C.c_float), ("material_id", C.c_uint32), ("pad", C.c_uint32 * 3)]
+
+
 class Scene(C.Structure):
     _fields_ = [("spheres", C.POINTER(Sphere)), ("sphere_count", C.c_uint32),
                 ("meshes", C.POINTER(Mesh)), ("mesh_count", C.c_uint32),
@@ -56,7 +60,8 @@ class Scene(C.Structure):
                 ("env_ground", C.c_float * 4), ("env_sky", C.c_float * 4), ("miss_ground", C.c_float * 4), ("miss_sky", C.c_float * 4),
                 ("cam_origin", C.c_float * 3), ("cam_right", C.c_float * 3), ("cam_up", C.c_float * 3), ("cam_forward", C.c_float * 3),
                 ("cam_fov_y", C.c_float), ("cam_exposure", C.c_float), ("seed_hi", C.c_uint32), ("seed_lo", C.c_uint32),
-                ("terrain", C.c_void_p), ("terrain_material", C.c_uint32)]
+                ("terrain", C.c_void_p), ("terrain_material", C.c_uint32), ("hair", C.POINTER(Hair)), ("hair_count", C.c_uint32),
+                ("medium_g", C.c_float), ("medium_sigma_t", C.c_float), ("medium_density", C.c_float), ("medium_enabled", C.c_float)]
 
 
 def build(force: bool = False) -> Path:
@@ -149,6 +154,11 @@ def scene_struct(scene: dict):
             raise ValueError("wavefront oracle: the terrain could not be opened")
         keep.append(_TerrainHandle(handle))
         s.terrain, s.terrain_material = handle, int(t["material_id"])
+    hair = array(Hair, scene.get("hair") or [], ("p0", "p1"))
+    s.hair, s.hair_count = hair, len(scene.get("hair") or [])
+    if scene.get("medium") is not None:
+        m = scene["medium"]
+        s.medium_g, s.medium_sigma_t, s.medium_density, s.medium_enabled = float(m["g"]), float(m["sigma_t"]), float(m["density"]), float(m["enabled"])
     return s, keep
 
 

@@ -1009,6 +1009,7 @@ int emul_wavefront_render(const f3d_wf_scene *scene, uint32_t width, uint32_t he
         S.inst = prep.inst.data();
         S.dir = prep.dir.data();
         S.area = prep.area.data();
+        S.hair = prep.hair.data();
         HostTables terrain;  // the heightfield primitive: the terrain tracer's tables, its placement from prepare_scene
         if (scene->terrain) {
             terrain = build_tables_host(scene->terrain->heights, scene->terrain->dem_width, scene->terrain->dem_height, scene->terrain->exaggeration);

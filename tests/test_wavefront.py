@@ -230,6 +230,79 @@ def test_emulated_terrain_primitive_equals_the_oracle(wfo, emul, seed):
     assert not np.array_equal(wfo.render(bare, w, h, frames)["accum"], a["accum"])
 
 
+# ---- the fog medium and hair segments (reference features of this tracer that its one driver leaves off) ------------------
+def hair_fog_scene(seed, fog=True, hair=True):
+    """A random scene of the material zoo plus a fan of hair strands over it (two materials, radii from a hair's to a rope's,
+    one degenerate segment, one of zero radius) and a fog thick enough to matter over the scene's few metres."""
+    from forge3d_amd.wavefront import HairSegment, Medium
+
+    scene, w, h, frames = scenes.wavefront_random_scene(seed)
+    rng = np.random.default_rng(4200 + seed)
+    if hair:
+        root = np.array([0.0, 2.2, 0.5])
+        for k in range(24):
+            tip = root + np.array([rng.uniform(-2.0, 2.0), rng.uniform(-2.0, -0.6), rng.uniform(-1.5, 1.5)])
+            mid = 0.5 * (root + tip) + rng.normal(size=3) * 0.15
+            r = float(rng.choice([0.004, 0.02, 0.06]))
+            mat = int(rng.integers(0, len(scene.spheres) + 2))  # (beyond the table: clamped like instance materials)
+            scene.hair += [HairSegment(tuple(root), r, tuple(mid), r * 0.8, mat), HairSegment(tuple(mid), r * 0.8, tuple(tip), r * 0.5, mat)]
+        scene.hair += [HairSegment((0.5, 1.0, 0.5), 0.05, (0.5, 1.0, 0.5), 0.05, 0), HairSegment((0.0, 1.0, 0.0), 0.0, (1.0, 1.0, 0.0), 0.0, 0)]
+    if fog:
+        scene.medium = Medium(g=0.3, sigma_t=float(rng.uniform(0.05, 0.3)), density=float(rng.uniform(0.5, 1.5)), enabled=True)
+    return scene, w, h, frames
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_emulated_hair_and_fog_equal_the_oracle(wfo, emul, seed):
+    scene, w, h, frames = hair_fog_scene(seed)
+    d = scene.as_dict()
+    a = wfo.render(d, w, h, frames)
+    b = emul.wavefront_render(d, w, h, frames)
+    assert np.isfinite(a["accum"]).all() and np.array_equal(a["accum"], b["accum"])
+    # both features do something, separately
+    plain = wfo.render(hair_fog_scene(seed, fog=False, hair=False)[0].as_dict(), w, h, frames)["accum"]
+    only_hair = wfo.render(hair_fog_scene(seed, fog=False)[0].as_dict(), w, h, frames)["accum"]
+    only_fog = wfo.render(hair_fog_scene(seed, hair=False)[0].as_dict(), w, h, frames)["accum"]
+    assert not np.array_equal(plain, only_hair) and not np.array_equal(plain, only_fog) and not np.array_equal(only_hair, a["accum"])
+    assert np.array_equal(only_hair, emul.wavefront_render(hair_fog_scene(seed, fog=False)[0].as_dict(), w, h, frames)["accum"])
+    assert np.array_equal(only_fog, emul.wavefront_render(hair_fog_scene(seed, hair=False)[0].as_dict(), w, h, frames)["accum"])
+
+
+def test_fog_and_hair_behave_like_the_references(wfo):
+    """media_transmittance / media_fog_factor (pt_shade.wgsl:328-338), the primary in-scatter (:515-519), the medium switch
+    (:500-502) and ray_cylinder_segment (pt_intersect.wgsl:21-57), as properties."""
+    from forge3d_amd.wavefront import DirectionalLight, HairSegment, Medium, Sphere, WavefrontScene
+
+    def scene(**kw):
+        return WavefrontScene(spheres=[Sphere(center=(0.0, 0.0, 0.0), radius=1.0, albedo=(0.8, 0.8, 0.8), roughness=0.9)],
+                              dir_lights=[DirectionalLight((0.0, -1.0, -0.2), 3.0, (1.0, 1.0, 1.0), 1.0)], object_importance=[1.0],
+                              env_ground=(0.2, 0.2, 0.2), env_sky=(0.6, 0.7, 0.9), miss_ground=(0.0, 0.0, 0.0), miss_sky=(0.0, 0.0, 0.0),
+                              cam_origin=(0.0, 0.0, 6.0), cam_look_at=(0.0, 0.0, 0.0), fov_y_deg=30.0, **kw)
+
+    def mean(sc, frames=24):
+        return wfo.render(sc.as_dict(), 48, 48, frames)["hdr"][..., :3]
+
+    clear = mean(scene())
+    assert np.array_equal(mean(scene(medium=Medium(sigma_t=0.3, density=1.0, enabled=False))), clear)  # enabled <= 0.5: off
+    assert np.array_equal(mean(scene(medium=Medium(sigma_t=0.0, density=1.0, enabled=True))), clear)   # mu = 0: T = 1, fog factor 0
+    assert np.array_equal(mean(scene(medium=Medium(sigma_t=-1.0, density=1.0, enabled=True))), clear)  # max(mu, 0)
+    disc = (np.hypot(*np.meshgrid(np.arange(48) - 23.5, np.arange(48) - 23.5)) < 12)  # pixels well inside the sphere's image
+    light, heavy = mean(scene(medium=Medium(sigma_t=0.05, density=1.0, enabled=True))), mean(scene(medium=Medium(sigma_t=2.0, density=1.0, enabled=True)))
+    # thick fog: direct light is gone and a primary hit shows the environment behind the camera, env(-wo) = env(ray direction)
+    assert np.allclose(heavy[disc], 0.5 * (np.asarray((0.2, 0.2, 0.2)) + np.asarray((0.6, 0.7, 0.9))), atol=0.06)
+    assert np.all(np.abs(light[disc] - clear[disc]).mean(0) < np.abs(heavy[disc] - clear[disc]).mean(0))
+    outside = np.hypot(*np.meshgrid(np.arange(48) - 23.5, np.arange(48) - 23.5)) > 19  # the sphere's image has a radius of 15.4 px
+    assert not clear[outside].any() and np.array_equal(heavy[outside], clear[outside])  # misses are not fogged (the reference's MVP)
+    # a strand across the top of the view: its band of pixels shows it over the whole width (elsewhere only bounce rays can
+    # meet it); the cylinder is open and finite: a strand that ends before the view does reaches only that far
+    strand = HairSegment((-3.0, 1.5, 0.0), 0.08, (3.0, 1.5, 0.0), 0.08, 0)
+    band = np.any(mean(scene(hair=[strand])) != clear, axis=-1)[:4]
+    assert band.any(axis=0).sum() >= 44
+    short = np.any(mean(scene(hair=[HairSegment((-3.0, 1.5, 0.0), 0.08, (-0.8, 1.5, 0.0), 0.08, 0)])) != clear, axis=-1)[:4]
+    assert short[:, :14].any() and not short[:, 22:].any()
+    assert np.array_equal(mean(scene(hair=[HairSegment((-3.0, 1.5, 0.0), 0.0, (3.0, 1.5, 0.0), 0.0, 0)])), clear)  # radius 0: nothing to hit
+
+
 def test_terrain_primitive_validation():
     from forge3d_amd import wavefront
 
@@ -319,3 +392,12 @@ def test_hip_terrain_primitive_equals_the_oracle(hip, wfo, seed):
     first = hip.render_scene(d, w, h, 2, frames_per_launch=1)
     rest = hip.render_scene(d, w, h, frames - 2, first_frame=2, accum=first["accum"])
     assert np.array_equal(rest["accum"], want["accum"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(4))
+def test_hip_hair_and_fog_equal_the_oracle(hip, wfo, seed):
+    scene, w, h, frames = hair_fog_scene(seed)
+    got = hip.render_scene(scene, w, h, frames)
+    want = wfo.render(scene.as_dict(), w, h, frames)
+    assert np.array_equal(got["accum"], want["accum"])
