@@ -83,6 +83,19 @@ constexpr uint32_t kLeafFifo = F3D_LEAF_FIFO;  // entries per lane (A/B: 2, 3, 6
 // A step queues at most two entries (a leaf AND the corner it leaves through) and the wave drains as soon
 // as one lane holds kLeafFifo: storage for one more.
 constexpr uint32_t kLeafFifoRows = kLeafFifo + 1u;
+// A lane takes up to kStepsPerVote march steps between two wave votes (the flush / share / done ballots and their
+// branches are about a seventh of an iteration's serial latency); it stops early when its ray ends or its FIFO could
+// overflow (a step queues at most two entries).  Results do not depend on it (3.1 of DESIGN.md: verdicts do not depend
+// on when leaves are evaluated).  Measured on the headline frame: 1 / 2 / 4 / 6 / 8 / 12 / 16 steps -> 6 989 / 7 270 /
+// 7 422 / 7 529 / 7 514 / 7 368 / 7 095 Msamples/s (profiles/r03_variant_ab.log); 4 inside the ray-sharing rounds.
+#ifndef F3D_STEPS_PER_VOTE
+#define F3D_STEPS_PER_VOTE 6
+#endif
+constexpr uint32_t kStepsPerVote = F3D_STEPS_PER_VOTE;
+#ifndef F3D_STEPS_PER_VOTE_SHARED
+#define F3D_STEPS_PER_VOTE_SHARED 4
+#endif
+constexpr uint32_t kStepsPerVoteShared = F3D_STEPS_PER_VOTE_SHARED;  // ... inside the ray-sharing rounds (march_shared)
 // TIE entry (see "Corners" above): corner lattice point (X, Z) <= 8192 in 14 bits each, the ray's x / z
 // direction, which side cell is next, and the flag; its `lo` word holds the corner's ray parameter T.
 constexpr uint32_t kTieFlag = 0x80000000u, kTieSecond = 0x40000000u, kTieZFwd = 0x20000000u, kTieXFwd = 0x10000000u;
@@ -290,6 +303,7 @@ template <class Ctx>
 F3D_HD void march_drain(const TerrainDev &T, const RayCtx &r, bool any_hit, MarchState &m, uint32_t &queued,
                         TraceHit &res, Ctx &ctx) {
     uint32_t k = 0u;  // per lane: a tie entry is visited twice
+    // (a plain divergent `while (k < queued && !res.hit)` measured 0.5 % slower than this vote per entry)
     while (ctx.any(k < queued && !res.hit)) {
         if (k < queued && !res.hit) {
             uint32_t cell;
@@ -485,6 +499,15 @@ F3D_HD bool march_shared(const TerrainDev &T, const RayCtx &own_ray, MarchState 
         bool again = false;
         for (;;) {
             if (m.marching) march_step<CURVED, true>(T, s.r, m, queued, ctx, true, s.t_stop);
+#if !defined(F3D_STEPS_UNROLLED)
+#pragma unroll 1
+            for (uint32_t extra = 1u; extra < kStepsPerVoteShared && m.marching && queued + 2u <= kLeafFifoRows; extra++)
+                march_step<CURVED, true>(T, s.r, m, queued, ctx, true, s.t_stop);
+#else
+#pragma unroll
+            for (uint32_t extra = 1u; extra < kStepsPerVoteShared; extra++)
+                if (m.marching && queued + 2u <= kLeafFifoRows) march_step<CURVED, true>(T, s.r, m, queued, ctx, true, s.t_stop);
+#endif
             again = round + 1u < kShareRounds && ctx.share_now(m.marching);
             if (again || ctx.flush_now(queued, m.marching)) {
                 march_drain(T, s.r, true, m, queued, res, ctx);
@@ -546,6 +569,16 @@ F3D_HD TraceHit march_terrain_from(const TerrainDev &T, const RayCtx &r, bool an
         // contains it -- the SLICED rule; node and leaf intervals are NOT clipped by it, every visited node is judged
         // exactly as the unbounded march judges it
         if (m.marching) march_step<CURVED, STOP>(T, r, m, queued, ctx, any_hit, t_stop);
+        // further steps before the wave votes again (kStepsPerVote above)
+#if !defined(F3D_STEPS_UNROLLED)  // a real loop (A/B: unrolled copies of the step -- bigger code, 1-2 % slower)
+#pragma unroll 1
+        for (uint32_t extra = 1u; extra < kStepsPerVote && m.marching && queued + 2u <= kLeafFifoRows; extra++)
+            march_step<CURVED, STOP>(T, r, m, queued, ctx, any_hit, t_stop);
+#else
+#pragma unroll
+        for (uint32_t extra = 1u; extra < kStepsPerVote; extra++)
+            if (m.marching && queued + 2u <= kLeafFifoRows) march_step<CURVED, STOP>(T, r, m, queued, ctx, any_hit, t_stop);
+#endif
 #if !defined(F3D_NO_SHARE)
 #if defined(F3D_SHARE_CURVED)  // A/B: sun rays too, with their own threshold (profiles/README.md)
         if (any_hit) deal = CURVED ? ctx.share_now(m.marching, F3D_SHARE_CURVED) : ctx.share_now(m.marching);
