@@ -168,7 +168,10 @@ F3D_HD MarchState march_begin(const TerrainDev &T, const RayCtx &r, bool start_i
 // SLICED: the lane walks a slice of a ray (march_shared below): nodes entered at or beyond t_stop
 // belong to the next slice.
 // any_hit: the ray is an occlusion ray (corner ties matter, see the header); a constant at every call site.
-template <bool CURVED, bool SLICED, class Ctx>
+// VERIFY: the lane may stand in a node that was located from a rounded position (m.unverified_start).  Only the FIRST
+// step of a ray or slice can: the march loops take that step through the verifying instantiation (march_first_step)
+// and every later one through VERIFY = false, which carries neither the flag nor its test.
+template <bool CURVED, bool SLICED, bool VERIFY = true, class Ctx>
 F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint32_t &queued, Ctx &ctx, bool any_hit,
                        float t_stop = 3.0e38f) {
     ctx.note(0);
@@ -195,7 +198,7 @@ F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint
 #endif
     const float x_out = f_max(tx0, tx1), z_out = f_max(tz0, tz1);
     const float enter = f_max(f_min(tx0, tx1), f_min(tz0, tz1)), exit = f_min(x_out, z_out);
-    if (m.unverified_start && !(enter <= m.t_cur && m.t_cur <= exit)) {
+    if (VERIFY && m.unverified_start && !(enter <= m.t_cur && m.t_cur <= exit)) {
         // the position was rounded across a cell boundary: walk down from the root instead
         m.level = top;
         m.nx = 0u;
@@ -290,9 +293,21 @@ F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint
             m.marching = !left;  // out of the footprint, or past tmax
         }
     }
-    m.unverified_start = false;
+    if (VERIFY) m.unverified_start = false;
     if (m.marching) march_fetch(T, m, ctx);
 }
+// The first step of the lanes whose start node still has to be validated (see VERIFY above).
+template <bool CURVED, bool SLICED, class Ctx>
+F3D_HD void march_first_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint32_t &queued, Ctx &ctx, bool any_hit, float t_stop) {
+#if !defined(F3D_VERIFY_EVERY_STEP)  // (A/B: the round-2 form tests the flag in every step)
+    if (m.marching && m.unverified_start) march_step<CURVED, SLICED, true>(T, r, m, queued, ctx, any_hit, t_stop);
+#endif
+}
+#if !defined(F3D_VERIFY_EVERY_STEP)
+constexpr bool kVerifyInLoop = false;
+#else
+constexpr bool kVerifyInLoop = true;
+#endif
 
 // Drain the lane's leaf FIFO: solve the queued leaves in ray order until one hits.  A TIE entry (any-hit
 // rays only) stands for the two cells beside a lattice corner the ray passes exactly through: each is
@@ -494,19 +509,20 @@ F3D_HD bool march_shared(const TerrainDev &T, const RayCtx &own_ray, MarchState 
     for (uint32_t round = 0u;; round++) {
         ctx.template deal<CURVED>(T, s, m);  // m.marching now says whether this lane got a slice
         if (m.marching) march_fetch(T, m, ctx);
+        march_first_step<CURVED, true>(T, s.r, m, queued, ctx, true, s.t_stop);  // slices other than a ray's first start in a located node
         res.hit = false;
         res.t = s.r.tmax;
         bool again = false;
         for (;;) {
-            if (m.marching) march_step<CURVED, true>(T, s.r, m, queued, ctx, true, s.t_stop);
+            if (m.marching) march_step<CURVED, true, kVerifyInLoop>(T, s.r, m, queued, ctx, true, s.t_stop);
 #if !defined(F3D_STEPS_UNROLLED)
 #pragma unroll 1
             for (uint32_t extra = 1u; extra < kStepsPerVoteShared && m.marching && queued + 2u <= kLeafFifoRows; extra++)
-                march_step<CURVED, true>(T, s.r, m, queued, ctx, true, s.t_stop);
+                march_step<CURVED, true, kVerifyInLoop>(T, s.r, m, queued, ctx, true, s.t_stop);
 #else
 #pragma unroll
             for (uint32_t extra = 1u; extra < kStepsPerVoteShared; extra++)
-                if (m.marching && queued + 2u <= kLeafFifoRows) march_step<CURVED, true>(T, s.r, m, queued, ctx, true, s.t_stop);
+                if (m.marching && queued + 2u <= kLeafFifoRows) march_step<CURVED, true, kVerifyInLoop>(T, s.r, m, queued, ctx, true, s.t_stop);
 #endif
             again = round + 1u < kShareRounds && ctx.share_now(m.marching);
             if (again || ctx.flush_now(queued, m.marching)) {
@@ -564,20 +580,21 @@ F3D_HD TraceHit march_terrain_from(const TerrainDev &T, const RayCtx &r, bool an
     uint32_t queued = 0u;
     bool deal = false;
     if (m.marching) march_fetch(T, m, ctx);
+    march_first_step<CURVED, STOP>(T, r, m, queued, ctx, any_hit, t_stop);
     for (;;) {
         // t_stop (occlusion rays, f3d_cone.h sun_clear_from / ibl_stop): no terrain beyond it, so the lane stops after the node that
         // contains it -- the SLICED rule; node and leaf intervals are NOT clipped by it, every visited node is judged
         // exactly as the unbounded march judges it
-        if (m.marching) march_step<CURVED, STOP>(T, r, m, queued, ctx, any_hit, t_stop);
+        if (m.marching) march_step<CURVED, STOP, kVerifyInLoop>(T, r, m, queued, ctx, any_hit, t_stop);
         // further steps before the wave votes again (kStepsPerVote above)
 #if !defined(F3D_STEPS_UNROLLED)  // a real loop (A/B: unrolled copies of the step -- bigger code, 1-2 % slower)
 #pragma unroll 1
         for (uint32_t extra = 1u; extra < kStepsPerVote && m.marching && queued + 2u <= kLeafFifoRows; extra++)
-            march_step<CURVED, STOP>(T, r, m, queued, ctx, any_hit, t_stop);
+            march_step<CURVED, STOP, kVerifyInLoop>(T, r, m, queued, ctx, any_hit, t_stop);
 #else
 #pragma unroll
         for (uint32_t extra = 1u; extra < kStepsPerVote; extra++)
-            if (m.marching && queued + 2u <= kLeafFifoRows) march_step<CURVED, STOP>(T, r, m, queued, ctx, any_hit, t_stop);
+            if (m.marching && queued + 2u <= kLeafFifoRows) march_step<CURVED, STOP, kVerifyInLoop>(T, r, m, queued, ctx, any_hit, t_stop);
 #endif
 #if !defined(F3D_NO_SHARE)
 #if defined(F3D_SHARE_CURVED)  // A/B: sun rays too, with their own threshold (profiles/README.md)
