@@ -63,7 +63,7 @@ F3D_HD bool march_band_rejects(const RayCtx &r, float t0, float t1, float mn, fl
     if (CURVED) {
         if (r.has_vertex && r.vertex >= t0 && r.vertex <= t1) lo = f_min(lo, march_height<true>(r, r.vertex));
     }
-    return lo > mx || f_max(y0, y1) < mn;
+    return (lo > mx) | (f_max(y0, y1) < mn);
 }
 
 // Leaf solves are DEFERRED.  The solve (~170 VALU instructions with its divisions and square
@@ -213,7 +213,7 @@ F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint
         ctx.band_entry(T, level, band_offset, band_shift);
         const NodeRec band = T.bands[band_offset + (nz << band_shift) + nx];
 #endif
-        const bool pass = !(lo > hi) && !march_band_rejects<CURVED>(r, lo, hi, band.mn, band.mx);  // :297-304
+        const bool pass = !(lo > hi) & !march_band_rejects<CURVED>(r, lo, hi, band.mn, band.mx);  // :297-304 (bitwise: no branch)
         if (pass) ctx.note(-1);  // statistics hook (host emulator only): the last step whose band test passed
         if (pass && level > 0u) {
             // DOWN into the child the ray is in at t_cur: it has passed the child boundary plane
@@ -280,8 +280,9 @@ F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint
             const uint32_t qx = nx + ((cross_x && x_forward) ? 1u : 0u) - ((cross_x && !x_forward) ? 1u : 0u);
             const uint32_t qz = nz + ((cross_z && z_forward) ? 1u : 0u) - ((cross_z && !z_forward) ? 1u : 0u);
             // above the whole terrain and climbing (RayCtx::y_exit): nothing ahead can pass its band test
-            const bool left = !(exit < r.tmax) || (SLICED && !(exit < t_stop)) || (qx << level) >= T.cell_w ||
-                              (qz << level) >= T.cell_h || march_height<CURVED>(r, exit) > r.y_exit;
+            // (bitwise | on purpose: every term is a couple of vector compares, cheaper than the branches of a short-circuit)
+            const bool left = !(exit < r.tmax) | (SLICED & !(exit < t_stop)) | ((qx << level) >= T.cell_w) |
+                              ((qz << level) >= T.cell_h) | (march_height<CURVED>(r, exit) > r.y_exit);
             // leaving the parent as well: continue one level up (jumping h > 1 levels when the crossing
             // leaves h ancestors was modelled on the emulator's step logs: fewer IBL steps, but more
             // shadow steps and 7-17 % more wave iterations -- tools/march_model.py)
