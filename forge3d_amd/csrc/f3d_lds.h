@@ -34,15 +34,17 @@ struct LdsPending {
     }
     // ---- deferred leaf FIFO of the march (f3d_march.h): 3 words per entry in the lane's column ----
     __device__ __forceinline__ void fifo_put(uint32_t k, uint32_t cell, float lo, float hi) {
-        col[(3u * k) * kWave] = cell;
-        col[(3u * k + 1u) * kWave] = f_bits(lo);
-        col[(3u * k + 2u) * kWave] = f_bits(hi);
+        uint32_t *e = col + mul24(k, 3u * kWave);
+        e[0] = cell;
+        e[kWave] = f_bits(lo);
+        e[2 * kWave] = f_bits(hi);
     }
-    __device__ __forceinline__ void fifo_retag(uint32_t k, uint32_t cell) { col[(3u * k) * kWave] = cell; }
+    __device__ __forceinline__ void fifo_retag(uint32_t k, uint32_t cell) { col[mul24(k, 3u * kWave)] = cell; }
     __device__ __forceinline__ void fifo_get(uint32_t k, uint32_t &cell, float &lo, float &hi) const {
-        cell = col[(3u * k) * kWave];
-        lo = f_from_bits(col[(3u * k + 1u) * kWave]);
-        hi = f_from_bits(col[(3u * k + 2u) * kWave]);
+        const uint32_t *e = col + mul24(k, 3u * kWave);
+        cell = e[0];
+        lo = f_from_bits(e[kWave]);
+        hi = f_from_bits(e[2 * kWave]);
     }
     // drain now?  enough lanes have a leaf queued, or a FIFO is full, or nobody marches any more
     __device__ __forceinline__ bool flush_now(uint32_t queued, bool marching) const {

@@ -73,6 +73,9 @@ F3D_HD float f_rint(float a) { return __builtin_rintf(a); }
 F3D_HD float f_floor(float a) { return __builtin_floorf(a); }
 F3D_HD float f_clamp(float x, float lo, float hi) { return f_min(f_max(x, lo), hi); }
 
+// a * b for factors below 2^24: v_mul_u32_u24 issues at full rate, v_mul_lo_u32 at a quarter of it
+// (the masks tell the compiler what the callers guarantee)
+F3D_HD uint32_t mul24(uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
 F3D_HD uint32_t f_bits(float f) { return __builtin_bit_cast(uint32_t, f); }
 F3D_HD float f_from_bits(uint32_t u) { return __builtin_bit_cast(float, u); }
 F3D_HD bool f_finite(float f) { return (f_bits(f) & 0x7F800000u) != 0x7F800000u; }

@@ -45,7 +45,7 @@ struct alignas(8) NodeRec {
 // 8x8 tiles per row of the CHILD level.  Children follow in (cx, cy) = (0,0),(1,0),(0,1),(1,1)
 // order = the reference's scan order (cy outer, cx inner).
 F3D_HD uint32_t child_group_index(uint32_t px, uint32_t py, uint32_t tiles_x) {
-    uint32_t tile = (py >> 2) * tiles_x + (px >> 2);
+    uint32_t tile = mul24((py >> 2), tiles_x) + (px >> 2);  // (both factors < 2^13: the full-rate 24-bit multiply)
     uint32_t g = (px & 1u) | ((py & 1u) << 1) | ((px & 2u) << 1) | ((py & 2u) << 2);
     return (tile << 6) | (g << 2);
 }
