@@ -269,6 +269,14 @@ def main():
     windows = 1 + max(0, args.extra_windows)
     total_frames = args.warmup + args.steps * windows
     kw = dict(kw, max_frames=max(total_frames, 2), min_frames=max(total_frames, 2))
+    if world == 1:  # a throw-away session of another DEM first: module load and allocator start-up are not set-up of THIS render
+        from forge3d_amd.session import TerrainSession
+
+        warm = np.zeros((64, 64), np.float32)
+        warm[::3, ::5] = 1.0
+        with TerrainSession(warm, 64, 64, cam, device=local_rank, **dict(kw, max_frames=2, min_frames=2)) as ws:
+            ws.enqueue_frames(0, 2)
+        torch.cuda.synchronize()
     torch.cuda.synchronize()
     t_setup = time.perf_counter()
     r = StripRenderer(dem, args.width, args.height, cam, rank=rank, world=world, device=local_rank,

@@ -5,7 +5,7 @@
 V=${1:-0}; TAG=${2:-r02}
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --extra-windows 0 --no-terrain-filling --variant $V"
+BENCH="python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --extra-windows 0 --no-terrain-filling --no-configs --variant $V"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $BENCH > $OUT/trace.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU -d $OUT/pmc1 -o bench -- $BENCH > $OUT/pmc1.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -d $OUT/pmc2 -o bench -- $BENCH > $OUT/pmc2.log 2>&1
@@ -26,10 +26,10 @@ def avg(db, counter, like):
 out = {"kernel_source_hash": bench.kernel_source_hash(), "variant": int("$V"), "workload": "rainier-proxy 2048^2, 1920x1080, 8 spp/frame, 1 GPU",
        "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE TCC_HIT_sum / --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum, separate passes, bench.py --steps 8 --warmup 2"}
 try:
-    f = avg(glob.glob("$OUT/pmc3/*.db")[0], "FETCH_SIZE", "%k_frame%")
-    w = avg(glob.glob("$OUT/pmc4/*.db")[0], "WRITE_SIZE", "%k_frame%")
-    h = avg(glob.glob("$OUT/pmc3/*.db")[0], "TCC_HIT_sum", "%k_frame%")
-    m = avg(glob.glob("$OUT/pmc4/*.db")[0], "TCC_MISS_sum", "%k_frame%")
+    f = avg(glob.glob("$OUT/pmc3/*.db")[0], "FETCH_SIZE", "%k_frame<0, 6, 4u>%")
+    w = avg(glob.glob("$OUT/pmc4/*.db")[0], "WRITE_SIZE", "%k_frame<0, 6, 4u>%")
+    h = avg(glob.glob("$OUT/pmc3/*.db")[0], "TCC_HIT_sum", "%k_frame<0, 6, 4u>%")
+    m = avg(glob.glob("$OUT/pmc4/*.db")[0], "TCC_MISS_sum", "%k_frame<0, 6, 4u>%")
     out.update(FETCH_SIZE_KB_per_dispatch=f[0], WRITE_SIZE_KB_per_dispatch=w[0], dispatches=f[1], gfx950_fetch_correction=2.0,
                hbm_bytes_per_launch=int((2.0 * f[0] + w[0]) * 1024), l2_hit_rate=h[0] / (h[0] + m[0]), sample_lanes=4,
                note="MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE count KB; gfx950 FETCH_SIZE under-reports wide reads, doubled (upper bound)")
