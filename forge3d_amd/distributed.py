@@ -159,12 +159,13 @@ class StripRenderer:
         self.backend = backend or HipBackend(device)
         self.balance_log = []
         # Frames in flight (f3d_session_opts.frames_in_flight): thin strips trace batches of frames in one launch and run
-        # the ordered half per frame, with the halo exchange between merges -- 8 strips of a 1080p frame: 0.40-0.42 ms
-        # per strip-frame against 0.53 ms with one fused launch per frame (tools/strip_balance.py --fd 16).  Fat strips
-        # (2 ranks) keep the fused kernel.  The session lowers the number to what its memory budget holds.
+        # the ordered half per frame, with the halo exchange between merges.  Measured per strip-frame of the 1080p headline
+        # (tools/strip_balance.py, profiles/r03_strip_balance.log; fused / 16 in flight): 2 strips 1.13 / 1.23 ms, 4 strips
+        # 0.62 / 0.65, 6 strips 0.49 / 0.45, 8 strips 0.42 / 0.36 -- so from 5 ranks on.  Fatter strips keep the fused
+        # kernel.  The session lowers the number to what its memory budget holds.
         fd = kw.pop("frames_in_flight", None)
         if fd is None:
-            fd = 16 if (world >= 3 and isinstance(self.backend, HipBackend)) else 0
+            fd = 16 if (world >= 5 and isinstance(self.backend, HipBackend)) else 0
         if fd:
             kw = dict(kw, frames_in_flight=int(fd))
         self.probe_frames = 16 if fd else 4  # batches need a few frames to reach their steady throughput
