@@ -1047,11 +1047,13 @@ struct HaloPullParams {
     uint32_t words;           // 8-byte words per halo block
     uint32_t want;            // frames the neighbour must have merged
     uint32_t *timeouts;
+    uint32_t *publish;        // this strip's own counter: set to `want` first (the kernels of the frame are behind us on the stream)
 };
 // One workgroup per neighbour: wait until it has merged `want` frames, then copy its edge rows into my halo rows.
 // Every access to the neighbour's memory is a system-scope load that bypasses this device's caches.
 __global__ __launch_bounds__(1024) void k_halo_pull(const HaloPullParams H) {
     const uint32_t side = blockIdx.x;
+    if (side == 0u && threadIdx.x == 0u) __hip_atomic_store(H.publish, H.want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (!H.flag[side]) return;
     __shared__ uint32_t ok;
     if (threadIdx.x == 0u) {
@@ -1080,9 +1082,12 @@ __global__ void k_halo_probe_read(const uint32_t *above, const uint32_t *below, 
 }
 
 void enqueue_halo_sync(f3d_session &s, uint32_t frame) {  // behind the kernels of `frame`
-    hipLaunchKernelGGL(k_halo_flag, dim3(1), dim3(1), 0, s.stream, s.halo_flags, frame + 1u);
-    if (!s.peer[0].connected && !s.peer[1].connected) return;
-    HaloPullParams H{};
+    if (!s.peer[0].connected && !s.peer[1].connected) {  // nobody to pull from: publish only
+        hipLaunchKernelGGL(k_halo_flag, dim3(1), dim3(1), 0, s.stream, s.halo_flags, frame + 1u);
+        return;
+    }
+    HaloPullParams H{};  // one launch: publish my counter, then wait for and copy the neighbours' rows
+    H.publish = s.halo_flags;
     const size_t row = (size_t)s.width, block = (size_t)kHaloRows * row;
     const uint32_t which = frame & 1u;
     H.words = (uint32_t)(block * sizeof(PackedReservoir) / 8u);
