@@ -212,7 +212,7 @@ int f3d_session_halo(f3d_session *session, int32_t which, int32_t side, void **p
 /* ---- peer halos: the strips of one node without the host or a collective in the frame chain --------------------
  * The classic strip loop (forge3d_amd/distributed.py) posts an RCCL send / recv pair from Python after every frame.
  * Here a strip PULLS its neighbours' edge rows itself: every session keeps a counter "frames merged" in device memory;
- * after a frame the library raises it (a one-thread kernel behind the frame's kernels) and launches k_halo_pull, which
+ * after a frame the library launches k_halo_pull, which raises that counter (it runs behind the frame's kernels) and
  * waits -- on the device -- until the neighbour's counter says its frame is done, then copies the neighbour's 4 edge
  * rows (peer memory mapped with hipIpcOpenMemHandle, read over xGMI with cache-bypassing loads) into the strip's own
  * halo rows.  Only READS cross the link and every strip writes nothing but its own memory, so no cache of another
