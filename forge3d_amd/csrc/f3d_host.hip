@@ -875,11 +875,15 @@ void join_bands(f3d_session &s, bool edges_only = false) {
 // the headline scene) in every remaining frame of its batch, because the prediction only learns from merges; which
 // direction a pixel's head reads settles within the first few frames (reservoirs spread 3 pixels a frame), so the early
 // batches are short and the long ones start from settled predictions (17 re-traced pixel-frames in 130 frames at 1080p).
+// Frames of the next trace batch.  The first two batches are two frames each: the sun-direction choice k_trace predicts
+// (wi or normalize(wi), from the flags the merges leave behind) settles within the first frames, and a mispredicted
+// pixel-frame is traced again one lane at a time.  From frame 4 on the batches are as large as the session holds (round 2
+// ramped 4, 8, 16 with the frame number: measured 3 % slower over frames 4..35 of a thin strip, with no fewer re-traces --
+// tools/experiments/strip_ramp.py; F3D_FD_FULL_FROM=<frame> moves the switch for experiments).
 uint32_t trace_batch(const f3d_session &s, uint32_t frame, uint32_t remaining) {
-    uint32_t ramp = 2u;
-    while (ramp < s.fd_frames && ramp * 2u <= frame) ramp *= 2u;  // the largest power of two <= frame (2 for frames 0..3), capped
-    if (frame < 2u) ramp = 2u - frame;
-    return std::max(1u, std::min(std::min(s.fd_frames, remaining), ramp));
+    static const uint32_t full_from = getenv("F3D_FD_FULL_FROM") ? (uint32_t)std::max(2, atoi(getenv("F3D_FD_FULL_FROM"))) : 4u;
+    if (frame >= full_from) return std::max(1u, std::min(s.fd_frames, remaining));
+    return std::max(1u, std::min(std::min(s.fd_frames, remaining), frame < 2u ? 2u - frame : 2u));
 }
 
 // ---- frames in flight: trace a batch of frames in one launch, then merge them in order ------------------------
