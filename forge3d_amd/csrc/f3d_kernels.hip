@@ -164,8 +164,8 @@ __device__ __forceinline__ void publish_window_stats(const FrameParams &P, bool 
 // pixel-parallel launch (k_head) and leaves an 8-byte record per pixel; the short tail runs on
 // sample lane 0.
 // (`valid` masks the lanes outside the image: every lane of the wave runs the function to its end.)
-template <uint32_t S>
-__device__ __forceinline__ float frame_lanes(const FrameParams &P, uint32_t gx, uint32_t gy, bool valid, LdsPending &pend) {
+template <uint32_t S, class Pending>
+__device__ __forceinline__ float frame_lanes(const FrameParams &P, uint32_t gx, uint32_t gy, bool valid, Pending &pend) {
     const uint32_t lane = threadIdx.x & (kWave - 1u), j = lane & (S - 1u), base = lane & ~(S - 1u);
     constexpr uint32_t kGroup = (1u << S) - 1u;
     FrameHead h;
@@ -273,9 +273,9 @@ __device__ __forceinline__ float frame_lanes(const FrameParams &P, uint32_t gx, 
 // in the record; k_merge compares with the real head and, for the rare pixel-frame that was mispredicted, traces
 // the pixel's primary and sun rays again with the right direction in k_fix (the IBL terms do not depend on it).  With equal
 // bits (same_sun) nothing is predicted.  Results are those of k_frame bit for bit either way.
-template <uint32_t S>
+template <uint32_t S, class Pending>
 __device__ __forceinline__ void trace_lanes(const FrameParams &P, uint32_t frame, uint32_t gx, uint32_t gy, bool valid,
-                                            LdsPending &pend) {
+                                            Pending &pend) {
     const uint32_t lane = threadIdx.x & (kWave - 1u), j = lane & (S - 1u), base = lane & ~(S - 1u);
     constexpr uint32_t kGroup = (1u << S) - 1u;
     const size_t pixels = (size_t)(P.row_end - P.row_begin) * P.cam.width;
@@ -527,11 +527,11 @@ __global__ __launch_bounds__(kWave, MIN_WAVES) void k_wf_occl(const WfOcclParams
     march_stream<SUN>(W.terrain, src, pend, W.quorum ? W.quorum : (uint32_t)F3D_STREAM_QUORUM);
 }
 
-template <int MIN_WAVES, uint32_t S>
+template <int MIN_WAVES, uint32_t S, bool MESH = false>
 __global__ __launch_bounds__(kWave, MIN_WAVES) void k_trace(const FrameParams P) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[kLdsWords];
     const unsigned long long t_start = wall_clock64();
-    LdsPending pend = make_pending(lds, P.terrain);
+    typename PendingFor<MESH>::type pend{make_pending(lds, P.terrain)};
     uint32_t gx = 0u, gy = 0u, tile;
     const bool active = tile_pixel<S>(P, gx, gy, tile, P.tile_order);
     trace_lanes<S>(P, P.frame_index + blockIdx.y, gx, gy, active, pend);
@@ -605,11 +605,13 @@ __global__ __launch_bounds__(kWave) void k_head(const FrameParams P) {
 // VARIANT is reserved for A/B builds (0 = the shipped kernel).
 // MIN_WAVES: waves per SIMD the register allocator must leave room for (1 = unconstrained).
 // S: sample lanes per pixel (1 = frame_pixel; 2, 4, 8 = frame_lanes).
-template <int VARIANT, int MIN_WAVES = 1, uint32_t S = 1u>
+// MESH: the scene may hold a mesh (FrameParams::mesh.traversal_mode == 0); terrain-only renders run the instantiation
+// without the mesh walk.
+template <int VARIANT, int MIN_WAVES = 1, uint32_t S = 1u, bool MESH = false>
 __global__ __launch_bounds__(kWave, MIN_WAVES) void k_frame(const FrameParams P) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[kLdsWords];
     const unsigned long long t_start = wall_clock64();  // 100 MHz: the wave's cost for the next tile ordering
-    LdsPending pend = make_pending(lds, P.terrain);
+    typename PendingFor<MESH>::type pend{make_pending(lds, P.terrain)};
     uint32_t gx = 0u, gy = 0u, tile;
     const bool active = tile_pixel<S>(P, gx, gy, tile, P.tile_order);
     float m2 = 0.0f;
@@ -746,27 +748,72 @@ hipError_t launch_frame(const FrameParams &p, int variant, hipStream_t stream) {
     const uint32_t lanes = p.sample_lanes ? p.sample_lanes : 1u;
     if (frame_grid(p, lanes) == 0u) return hipSuccess;  // an empty band
     const dim3 grid(frame_grid(p, lanes)), block(kWave);
+    // (F3D_FORCE_MESH_KERNEL=1: A/B switch, the mesh-capable instantiation for a terrain-only scene -- same results)
+    static const bool force_mesh = getenv("F3D_FORCE_MESH_KERNEL") != nullptr;
+    const bool mesh = p.mesh.traversal_mode == 0u || force_mesh;
     if (lanes != 1u) {  // one wave per workgroup (register-budget A/B variants for 4 and 8 lanes only)
         switch (lanes * 1000 + (uint32_t)(variant % 1000)) {
-            case 2000: hipLaunchKernelGGL((k_frame<0, 6, 2>), grid, block, 0, stream, p); break;
-            case 4000: hipLaunchKernelGGL((k_frame<0, 6, 4>), grid, block, 0, stream, p); break;
-            case 4104: hipLaunchKernelGGL((k_frame<0, 4, 4>), grid, block, 0, stream, p); break;
-            case 4105: hipLaunchKernelGGL((k_frame<0, 5, 4>), grid, block, 0, stream, p); break;
-            case 4107: hipLaunchKernelGGL((k_frame<0, 7, 4>), grid, block, 0, stream, p); break;
-            case 4108: hipLaunchKernelGGL((k_frame<0, 8, 4>), grid, block, 0, stream, p); break;
-            case 8000: hipLaunchKernelGGL((k_frame<0, 6, 8>), grid, block, 0, stream, p); break;
-            case 8104: hipLaunchKernelGGL((k_frame<0, 4, 8>), grid, block, 0, stream, p); break;
-            case 8105: hipLaunchKernelGGL((k_frame<0, 5, 8>), grid, block, 0, stream, p); break;
+            case 2000:
+                if (mesh) hipLaunchKernelGGL((k_frame<0, 6, 2, true>), grid, block, 0, stream, p);
+                else hipLaunchKernelGGL((k_frame<0, 6, 2>), grid, block, 0, stream, p);
+                break;
+            case 4000:
+                if (mesh) hipLaunchKernelGGL((k_frame<0, 6, 4, true>), grid, block, 0, stream, p);
+                else hipLaunchKernelGGL((k_frame<0, 6, 4>), grid, block, 0, stream, p);
+                break;
+            case 4104:
+                if (mesh) hipLaunchKernelGGL((k_frame<0, 4, 4, true>), grid, block, 0, stream, p);
+                else hipLaunchKernelGGL((k_frame<0, 4, 4>), grid, block, 0, stream, p);
+                break;
+            case 4105:
+                if (mesh) hipLaunchKernelGGL((k_frame<0, 5, 4, true>), grid, block, 0, stream, p);
+                else hipLaunchKernelGGL((k_frame<0, 5, 4>), grid, block, 0, stream, p);
+                break;
+            case 4107:
+                if (mesh) hipLaunchKernelGGL((k_frame<0, 7, 4, true>), grid, block, 0, stream, p);
+                else hipLaunchKernelGGL((k_frame<0, 7, 4>), grid, block, 0, stream, p);
+                break;
+            case 4108:
+                if (mesh) hipLaunchKernelGGL((k_frame<0, 8, 4, true>), grid, block, 0, stream, p);
+                else hipLaunchKernelGGL((k_frame<0, 8, 4>), grid, block, 0, stream, p);
+                break;
+            case 8000:
+                if (mesh) hipLaunchKernelGGL((k_frame<0, 6, 8, true>), grid, block, 0, stream, p);
+                else hipLaunchKernelGGL((k_frame<0, 6, 8>), grid, block, 0, stream, p);
+                break;
+            case 8104:
+                if (mesh) hipLaunchKernelGGL((k_frame<0, 4, 8, true>), grid, block, 0, stream, p);
+                else hipLaunchKernelGGL((k_frame<0, 4, 8>), grid, block, 0, stream, p);
+                break;
+            case 8105:
+                if (mesh) hipLaunchKernelGGL((k_frame<0, 5, 8, true>), grid, block, 0, stream, p);
+                else hipLaunchKernelGGL((k_frame<0, 5, 8>), grid, block, 0, stream, p);
+                break;
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();
     }
     switch (variant % 1000) {
-        case 0: hipLaunchKernelGGL((k_frame<0, 6>), grid, block, 0, stream, p); break;  // default: 80 VGPRs, 6 waves/SIMD
-        case 101: hipLaunchKernelGGL((k_frame<0, 1>), grid, block, 0, stream, p); break;
-        case 104: hipLaunchKernelGGL((k_frame<0, 4>), grid, block, 0, stream, p); break;
-        case 105: hipLaunchKernelGGL((k_frame<0, 5>), grid, block, 0, stream, p); break;
-        case 108: hipLaunchKernelGGL((k_frame<0, 8>), grid, block, 0, stream, p); break;
+        case 0:
+            if (mesh) hipLaunchKernelGGL((k_frame<0, 6, 1u, true>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((k_frame<0, 6>), grid, block, 0, stream, p);
+            break;  // default: 80 VGPRs, 6 waves/SIMD
+        case 101:
+            if (mesh) hipLaunchKernelGGL((k_frame<0, 1, 1u, true>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((k_frame<0, 1>), grid, block, 0, stream, p);
+            break;
+        case 104:
+            if (mesh) hipLaunchKernelGGL((k_frame<0, 4, 1u, true>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((k_frame<0, 4>), grid, block, 0, stream, p);
+            break;
+        case 105:
+            if (mesh) hipLaunchKernelGGL((k_frame<0, 5, 1u, true>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((k_frame<0, 5>), grid, block, 0, stream, p);
+            break;
+        case 108:
+            if (mesh) hipLaunchKernelGGL((k_frame<0, 8, 1u, true>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((k_frame<0, 8>), grid, block, 0, stream, p);
+            break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -776,11 +823,24 @@ hipError_t launch_trace(const FrameParams &p, uint32_t frames, hipStream_t strea
     const uint32_t lanes = p.sample_lanes ? p.sample_lanes : 1u;
     if (frame_grid(p, lanes) == 0u || frames == 0u) return hipSuccess;
     const dim3 grid(frame_grid(p, lanes), frames), block(kWave);
+    const bool mesh = p.mesh.traversal_mode == 0u;
     switch (lanes) {
-        case 1: hipLaunchKernelGGL((k_trace<6, 1>), grid, block, 0, stream, p); break;
-        case 2: hipLaunchKernelGGL((k_trace<6, 2>), grid, block, 0, stream, p); break;
-        case 4: hipLaunchKernelGGL((k_trace<6, 4>), grid, block, 0, stream, p); break;
-        case 8: hipLaunchKernelGGL((k_trace<6, 8>), grid, block, 0, stream, p); break;
+        case 1:
+            if (mesh) hipLaunchKernelGGL((k_trace<6, 1, true>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((k_trace<6, 1>), grid, block, 0, stream, p);
+            break;
+        case 2:
+            if (mesh) hipLaunchKernelGGL((k_trace<6, 2, true>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((k_trace<6, 2>), grid, block, 0, stream, p);
+            break;
+        case 4:
+            if (mesh) hipLaunchKernelGGL((k_trace<6, 4, true>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((k_trace<6, 4>), grid, block, 0, stream, p);
+            break;
+        case 8:
+            if (mesh) hipLaunchKernelGGL((k_trace<6, 8, true>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((k_trace<6, 8>), grid, block, 0, stream, p);
+            break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -889,3 +949,13 @@ hipError_t launch_level_build(const LevelBuildParams &p, hipStream_t stream) {
 }
 
 }  // namespace f3d
+
+#if defined(F3D_MESH_STATS)  // diagnostics build only (tools/experiments/c4_window.py): not part of the ABI
+extern "C" int f3d_debug_mesh_stats(unsigned long long *out, int reset) {
+    if (reset) {
+        unsigned long long zero[8] = {};
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(f3d::g_mesh_stats), zero, sizeof(zero));
+    }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(f3d::g_mesh_stats), 8 * sizeof(unsigned long long));
+}
+#endif

@@ -19,6 +19,9 @@ constexpr int kBoardRow = kParkRow + kParkWords;  // verdict board of the ray sh
 constexpr int kLdsRows = kBoardRow + 1 > kMaxLevels ? kBoardRow + 1 : kMaxLevels;
 constexpr int kLdsWords = kLdsRows * kWave + 4 * kMaxLevels;
 struct LdsPending {
+    // may the scene hold a mesh?  (closest_hit / occluded, f3d_shade.h: the terrain-only frame kernels are compiled without
+    // the mesh walk, so nothing the mesh path needs can move their register allocation -- and the other way round)
+    static constexpr bool kMesh = true;
     uint32_t *col;          // lds + lane
     const uint32_t *table;  // lds + kLdsRows * kWave: {band_offset, band_shift, node_offset, tiles_x} per level
     uint32_t leaf_quorum, share_below;
@@ -91,6 +94,18 @@ struct LdsPending {
     }
 };
 // rows: lane-column rows in front of the level table (the occlusion-stream kernels need the leaf FIFO only)
+struct LdsPendingTerrainOnly : LdsPending {
+    static constexpr bool kMesh = false;
+};
+template <bool MESH>
+struct PendingFor {
+    using type = LdsPending;
+};
+template <>
+struct PendingFor<false> {
+    using type = LdsPendingTerrainOnly;
+};
+
 __device__ __forceinline__ LdsPending make_pending(uint32_t *lds, const TerrainDev &T, uint32_t rows = kLdsRows) {
     const uint32_t lane = threadIdx.x & (kWave - 1u);  // `lds` is this WAVE's block (workgroups may hold several)
     if (lane < kMaxLevels) {

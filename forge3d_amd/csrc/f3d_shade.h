@@ -73,55 +73,83 @@ F3D_HD bool mesh_sweep(const MeshDev &M, V3 o, float tmin, V3 d, float tmax, flo
 // ray touches is put through the sweep's own ray_triangle; the sweep keeps the first triangle in
 // index order among those with the smallest t (`t < t_best` is strict), hence the tie rule below.
 // ANY: stop at the first accepted triangle (occlusion rays only need existence).
+#if defined(F3D_MESH_STATS) && defined(__HIPCC__)  // diagnostics build: what a WAVE pays for the walk
+static __device__ unsigned long long g_mesh_stats[8];  // [0] wave iterations, [1] lane iterations, [2] wave leaf blocks, [3] lane leaf blocks, [4] walks (waves), [5] walks (lanes)
+__device__ __forceinline__ void mesh_stat(int slot) {
+    const unsigned long long m = __ballot(true);
+    if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m) - 1u) {
+        atomicAdd(&g_mesh_stats[slot], 1ull);
+        atomicAdd(&g_mesh_stats[slot + 1], (unsigned long long)__popcll(m));
+    }
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+#define F3D_MESH_STAT(slot) mesh_stat(slot)
+#else
+#define F3D_MESH_STAT(slot) (void)0
+#endif
+#else
+#define F3D_MESH_STAT(slot) (void)0
+#endif
+// Shape of the loop (round 3; gpurun logs in profiles/r03_variant_ab.log): the walk is bound by the scattered
+// record loads of the 64 lanes (their latency: half of a wave's iterations hold a lane that misses the L2), not by arithmetic.
+// The whole 32-byte record is requested at once (left to itself the compiler fetches the leaf word after the box test: a
+// second latency on every entered node); there is ONE divergent region per node -- the triangles of an entered leaf, met in 7 % of a wave's iterations -- and the successor is
+// a select (no `continue` / `return` inside the loops: each of those is a lane-mask merge per node); "found one" lives in
+// best_tri, not in a boolean carried through the regions; an occlusion ray that has its answer leaves by setting node past
+// the end.
 template <bool ANY>
 F3D_HD bool mesh_bvh(const MeshDev &M, V3 o, float tmin, V3 d, float tmax, float &t_best, V3 &n_best) {
     const float ix = (d.x < 0.0f ? -1.0f : 1.0f) / f_max(f_abs(d.x), 1e-12f);
     const float iy = (d.y < 0.0f ? -1.0f : 1.0f) / f_max(f_abs(d.y), 1e-12f);
     const float iz = (d.z < 0.0f ? -1.0f : 1.0f) / f_max(f_abs(d.z), 1e-12f);
-    const float4 *nodes = reinterpret_cast<const float4 *>(M.bvh_nodes);
     bool any = false;
     uint32_t best_tri = 0xFFFFFFFFu;
     t_best = tmax;
     uint32_t node = 0u;
+    F3D_MESH_STAT(4);
+    // plane parameters as one fma each: plane * (1/d) - o * (1/d).  In space units the rounding is |o| * 2^-24 where
+    // (plane - o) * (1/d) has |plane - o| * 2^-24 -- both far inside the padding of the boxes (f3d_bvh.h), and the test only
+    // has to be conservative: the triangles decide.
+    const float oix = o.x * ix, oiy = o.y * iy, oiz = o.z * iz;
+    const float4 *nodes = reinterpret_cast<const float4 *>(M.bvh_nodes);
     while (node < M.bvh_node_count) {
-        const float4 lo = nodes[2u * node], hi = nodes[2u * node + 1u];
-        const float ax = (lo.x - o.x) * ix, bx = (hi.x - o.x) * ix;
-        const float ay = (lo.y - o.y) * iy, by = (hi.y - o.y) * iy;
-        const float az = (lo.z - o.z) * iz, bz = (hi.z - o.z) * iz;
+        const float4 lo = nodes[2u * node];
+        float4 hi = nodes[2u * node + 1u];
+        F3D_OPAQUE(hi.w);  // the whole record at once: the leaf word is not fetched after the box test
+        F3D_MESH_STAT(0);
+        const float ax = f_fma(lo.x, ix, -oix), bx = f_fma(hi.x, ix, -oix);
+        const float ay = f_fma(lo.y, iy, -oiy), by = f_fma(hi.y, iy, -oiy);
+        const float az = f_fma(lo.z, iz, -oiz), bz = f_fma(hi.z, iz, -oiz);
         const float enter = f_max(f_max(f_min(ax, bx), f_min(ay, by)), f_max(f_min(az, bz), tmin));
         const float exit = f_min(f_min(f_max(ax, bx), f_max(ay, by)), f_min(f_max(az, bz), t_best));
-        if (!(enter <= exit * 1.00001f)) {  // conservative: boxes are padded, ties are kept
-            node = f_bits(lo.w);
-            continue;
-        }
+        const bool inside = enter <= exit * 1.00001f;  // conservative: boxes are padded, ties are kept
         const uint32_t leaf = f_bits(hi.w);
-        if (leaf == 0u) {
-            node = node + 1u;
-            continue;
-        }
-        const uint32_t first = leaf >> 3, count = leaf & 7u;
-        for (uint32_t k = 0u; k < count; k++) {
-            const float4 a = M.bvh_tris[3u * (first + k)], b = M.bvh_tris[3u * (first + k) + 1u],
-                         c = M.bvh_tris[3u * (first + k) + 2u];
-            float t;
-            V3 n;
-            if (ray_triangle(o, tmin, d, tmax, V3{a.x, a.y, a.z}, V3{b.x, b.y, b.z}, V3{c.x, c.y, c.z}, t, n)) {
-                if (ANY) {
-                    t_best = t;
-                    n_best = n;
-                    return true;
-                }
-                const uint32_t tri = f_bits(a.w);
-                if (t < t_best || (t == t_best && tri < best_tri)) {
-                    t_best = t;
-                    n_best = n;
-                    best_tri = tri;
-                    any = true;
+        // into the first child (the next record), or past the subtree: a missed box, or a leaf once its triangles are done
+        uint32_t next = (inside & (leaf == 0u)) ? node + 1u : f_bits(lo.w);
+        if (inside & (leaf != 0u)) {
+            F3D_MESH_STAT(2);
+            const uint32_t first = leaf >> 3, count = leaf & 7u;
+            for (uint32_t k = 0u; k < count; k++) {
+                const float4 a = M.bvh_tris[3u * (first + k)], b = M.bvh_tris[3u * (first + k) + 1u],
+                             c = M.bvh_tris[3u * (first + k) + 2u];
+                float t;
+                V3 n;
+                if (ray_triangle(o, tmin, d, tmax, V3{a.x, a.y, a.z}, V3{b.x, b.y, b.z}, V3{c.x, c.y, c.z}, t, n)) {
+                    const uint32_t tri = f_bits(a.w);
+                    // (best_tri doubles as the "found one" flag: a boolean carried through the divergent regions costs the
+                    // wave a lane-mask merge per region and node)
+                    if (ANY ? best_tri == 0xFFFFFFFFu : (t < t_best || (t == t_best && tri < best_tri))) {
+                        t_best = t;
+                        n_best = n;
+                        best_tri = tri;
+                    }
                 }
             }
+            if (ANY && best_tri != 0xFFFFFFFFu) next = M.bvh_node_count;  // existence is all an occlusion ray asks for
         }
-        node = f_bits(lo.w);
+        node = next;
     }
+    any = best_tri != 0xFFFFFFFFu;
     return any;
 }
 
@@ -140,7 +168,7 @@ F3D_HD SurfaceHit closest_hit(const FrameParams &P, V3 o, float tmin, V3 d, floa
     best.t = tmax;
     best.p = V3{0, 0, 0};
     best.n = V3{0, 0, 0};
-    if (P.mesh.traversal_mode == 0u) {
+    if (Pending::kMesh && P.mesh.traversal_mode == 0u) {
         float t;
         V3 n;
         if (mesh_closest(P.mesh, o, tmin, d, tmax, t, n) && t < best.t) {
@@ -168,30 +196,26 @@ F3D_HD SurfaceHit closest_hit(const FrameParams &P, V3 o, float tmin, V3 d, floa
 
 // intersect_hybrid_optimized + intersect_shadow_ray / intersect_ibl_occlusion_ray,
 // hybrid_traversal.wgsl:204-259 (any hit; early_exit 0.01; max_distance 1e30)
+// The answer is an OR: any accepted triangle makes the reference return true whatever the terrain does (:204-259 -- it takes
+// the closest mesh hit, returns at once when that is nearer than its early-exit distance and otherwise keeps hit = true),
+// and without one the terrain is asked with the ray's own tmax.  So the order is free, and the terrain goes FIRST: the
+// rays with the longest mesh walks are the flat ones that run through the building layer for kilometres -- which are the
+// ones the terrain stops.  On the S4 stand-in (600 000 triangles) the longest walk of a wave of IBL rays halves
+// (DESIGN.md 9.1).  -DF3D_MESH_FIRST is the A/B switch for the reference's order.
 template <class Pending>
 F3D_HD bool occluded(const FrameParams &P, V3 o, float tmin, V3 d, float tmax, bool apply_curvature,
                      Pending &pend, float terrain_tmax = 1e30f) {
-    float best_t = tmax;
-    bool hit = false;
-    if (P.mesh.traversal_mode == 0u) {
+#if defined(F3D_MESH_FIRST)
+    if (Pending::kMesh && P.mesh.traversal_mode == 0u) {
         float t;
         V3 n;
-        if (P.mesh.bvh_nodes) {
-            // Any triangle hit already decides the answer: the reference takes the closest mesh hit, returns
-            // (t < 1e30) = true when it is nearer than its early-exit distance, and otherwise keeps hit = true
-            // whatever the terrain does (:204-259), so existence is all that is read from the mesh here.
-            if (mesh_bvh<true>(P.mesh, o, tmin, d, tmax, t, n)) return true;
-        } else if (mesh_sweep(P.mesh, o, tmin, d, tmax, t, n)) {
-            if (t < 0.01f) return t < 1e30f;
-            if (t < best_t) {
-                best_t = t;
-                hit = true;
-            }
-        }
+        if (P.mesh.bvh_nodes ? mesh_bvh<true>(P.mesh, o, tmin, d, tmax, t, n) : mesh_sweep(P.mesh, o, tmin, d, tmax, t, n))
+            return t < 1e30f;
     }
+#endif
     // terrain_tmax: a certificate that no terrain lies beyond it on this ray (f3d_cone.h sun_clear_from): the march stops
     // after the node that contains it (sun rays only: the curved instantiation carries the stop rule)
-    RayCtx r = make_ray(P.terrain, o, tmin, d, best_t, apply_curvature);
+    RayCtx r = make_ray(P.terrain, o, tmin, d, tmax, apply_curvature);
 #if defined(F3D_TRAVERSAL_DESCENT)
     TraceHit th = trace_terrain(P.terrain, r, true, pend);  // the reference-shaped sorted descent
 #else
@@ -202,11 +226,17 @@ F3D_HD bool occluded(const FrameParams &P, V3 o, float tmin, V3 d, float tmax, b
     TraceHit th = apply_curvature ? march_terrain<true>(P.terrain, r, true, true, pend, terrain_tmax)
                                   : march_terrain<false>(P.terrain, r, true, true, pend, terrain_tmax);
 #endif
-    if (th.hit && th.t < best_t) {
-        best_t = th.t;
-        hit = true;
+    bool hit = th.hit && th.t < tmax && th.t < 1e30f;
+#if !defined(F3D_MESH_FIRST)
+    if (Pending::kMesh && P.mesh.traversal_mode == 0u) {
+        float t;
+        V3 n;
+        // (accepted triangles have t < tmax; `t < 1e30` is the reference's own last word on the mesh hit)
+        if (!hit && (P.mesh.bvh_nodes ? mesh_bvh<true>(P.mesh, o, tmin, d, tmax, t, n) : mesh_sweep(P.mesh, o, tmin, d, tmax, t, n)))
+            hit = t < 1e30f;
     }
-    return hit && best_t < 1e30f;
+#endif
+    return hit;
 }
 
 // terrain_env_radiance, hybrid_terrain_traversal.wgsl:392-405

@@ -30,6 +30,7 @@ struct RayLog {
     uint64_t leaf_mask;
 };
 struct ArrayPending {
+    static constexpr bool kMesh = true;  // (f3d_lds.h: only the device compiles terrain-only kernels)
     uint32_t w[kMaxLevels];
     std::vector<RayLog> *log = nullptr;
     void note(int kind) {
