@@ -168,6 +168,13 @@ HIPCC_FLAGS = [
     # that costs register pairs and moves: 5763 -> 6362 Msamples/s without it (profiles/README.md)
     "-fno-slp-vectorize",
 ]
+# only for f3d_kernels.hip (the frame kernels; compiled to an object first, then linked with the rest):
+KERNEL_FLAGS = [
+    # the "VGPR live-range optimisation for if-else structures" lengthens live ranges across the divergent regions of the
+    # march; without it the 80-VGPR frame kernel spills less inside them: 7 875-7 946 -> 8 023-8 034 Msamples/s in one call,
+    # same image (profiles/README.md, round 3).  The other translation units keep the default (the smoke marcher loses with it).
+    "-mllvm", "-amdgpu-opt-vgpr-liverange=false",
+]
 HIP_SOURCES = ["f3d_kernels.hip", "f3d_host.hip", "f3d_denoise.hip", "f3d_smoke.hip", "f3d_smoke_sim.hip", "f3d_composite.hip", "f3d_lbvh.hip", "f3d_wavefront.hip",
                "f3d_aether_bake.hip", "f3d_aether_ref.hip"]
 
@@ -180,7 +187,7 @@ def source_digest() -> str:
     csrc, inc = _PKG / "csrc", _PKG.parent / "include"
     if not csrc.is_dir() or not inc.is_dir():
         return None
-    h = hashlib.sha256(" ".join(HIPCC_FLAGS + HIP_SOURCES).encode())
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS + KERNEL_FLAGS + HIP_SOURCES).encode())
     for f in sorted(csrc.glob("*.h")) + sorted(csrc.glob("*.hip")) + sorted(inc.glob("*.h")):
         h.update(f.name.encode())
         h.update(f.read_bytes())
@@ -221,11 +228,20 @@ def build_library(force: bool = False) -> Path:
     if force or built_digest(LIB_PATH) != digest:
         csrc = _PKG / "csrc"
         tmp = LIB_PATH.with_name(f"{LIB_PATH.name}.{os.getpid()}.tmp")  # several ranks may find the library stale at once
-        cmd = [_hipcc(), *HIPCC_FLAGS, f'-DF3D_SOURCE_DIGEST="{digest}"', *(str(csrc / n) for n in HIP_SOURCES), "-o", str(tmp)]
-        proc = subprocess.run(cmd, capture_output=True, text=True)
-        if proc.returncode != 0:
-            tmp.unlink(missing_ok=True)
-            raise RuntimeError("hipcc failed:\n" + proc.stdout + proc.stderr)
+        obj = LIB_PATH.with_name(f"f3d_kernels.{os.getpid()}.o")
+        define = f'-DF3D_SOURCE_DIGEST="{digest}"'
+        compile_only = [f for f in HIPCC_FLAGS if f != "-shared"]
+        cmds = [[_hipcc(), *compile_only, *KERNEL_FLAGS, define, "-c", str(csrc / HIP_SOURCES[0]), "-o", str(obj)],
+                # (the object first: hipcc puts a sticky `-x hip` in front of every .hip it is given)
+                [_hipcc(), *HIPCC_FLAGS, define, str(obj), *(str(csrc / n) for n in HIP_SOURCES[1:]), "-o", str(tmp)]]
+        try:
+            for cmd in cmds:
+                proc = subprocess.run(cmd, capture_output=True, text=True)
+                if proc.returncode != 0:
+                    tmp.unlink(missing_ok=True)
+                    raise RuntimeError("hipcc failed:\n" + proc.stdout + proc.stderr)
+        finally:
+            obj.unlink(missing_ok=True)
         os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
