@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of library variants with their dynamic instruction mix: tools/gpu_r3_salu.sh name...
+# A/B of library variants with their dynamic instruction mix: tools/gpu_variant_pmc.sh name...
 # per variant: bench timing (3 windows), then one --pmc pass (SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY)
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
 STEPS=16 bash tools/gpu_variant_ab.sh "$@"
