@@ -78,7 +78,7 @@ def kernel_source_hash() -> str:
         h.update((csrc / name).read_bytes())
     import __graft_entry__ as entry
 
-    h.update(" ".join(entry.HIPCC_FLAGS).encode())
+    h.update(" ".join(entry.HIPCC_FLAGS + entry.KERNEL_FLAGS).encode())
     return h.hexdigest()[:16]
 
 
