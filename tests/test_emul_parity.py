@@ -235,3 +235,29 @@ def test_frames_in_flight_structure_matches_the_oracle(monkeypatch, size, spp, f
     assert np.array_equal(got["m2"], want["welford"][:, 1])
     if force:
         assert got["retraced_pixels"] > frames  # the re-trace pass ran in every frame
+
+
+def _mesh_scene_seeds(first, count):
+    seeds, seed = [], first
+    while len(seeds) < count:
+        if scenes.random_scene(seed)[3].get("mesh_vertices") is not None:
+            seeds.append(seed)
+        seed += 1
+    return seeds
+
+
+@pytest.mark.parametrize("seed", _mesh_scene_seeds(40000, 16))
+@pytest.mark.parametrize("lanes", [1, 4])
+def test_mesh_walk_on_random_scenes_matches_the_sweep(seed, lanes):
+    """The threaded-BVH walk of csrc/f3d_shade.h (terrain asked first by the occlusion rays, successor as a select, slab test
+    as one fma per plane) against the oracle's sweep over all triangles, on random terrain + mesh scenes of the fuzz
+    generator (tools/fuzz_emul_mesh.py runs thousands of them): every output the same bits."""
+    dem, size, cam, kw = scenes.random_scene(seed)
+    kw = dict(kw, max_frames=3, min_frames=3, variance_threshold=1e30)
+    try:
+        want = oracle.render(dem, size[0], size[1], cam, **kw)
+    except RuntimeError as exc:  # (a scene both sides reject: the generator makes a few)
+        with pytest.raises(RuntimeError):
+            emul.render(dem, size[0], size[1], cam, sample_lanes=lanes, **kw)
+        pytest.skip(str(exc)[:60])
+    _same(emul.render(dem, size[0], size[1], cam, sample_lanes=lanes, **kw), want)
