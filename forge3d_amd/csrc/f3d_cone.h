@@ -142,11 +142,8 @@ F3D_HD PrimaryStart primary_start(const FrameParams &P, uint32_t gx, uint32_t gy
 #ifndef F3D_SUN_SLACK
 #define F3D_SUN_SLACK 1.0f
 #endif
-F3D_HD float pixel_cone_delta(const CameraDev &C) {
-    const float px = C.half_w / (float)C.width, py = C.half_h / (float)C.height;
-    const float plane = f_sqrt(px * px + py * py);
-    return plane < 0.25f ? 1.01f * plane * (1.0f + plane * plane) : -1.0f;  // < 0: pixels too wide for certificates
-}
+// (a render constant: evaluated once by the host, f3d_setup.h fill_uniforms -> CameraDev::cone_delta)
+F3D_HD float pixel_cone_delta(const CameraDev &C) { return C.cone_delta; }
 // Samples whose primary hit lies within this distance (along the ray) of the centre ray's hit use the certificate.
 F3D_HD float sun_depth_slack(float centre_depth, float delta, float cell) { return F3D_SUN_SLACK * centre_depth * delta + 0.5f * cell; }
 
@@ -267,10 +264,11 @@ F3D_HD uint32_t horizon_block_level(uint32_t cell_w, uint32_t cell_h) {
 }
 // horizontal radius around a block's centre that holds every IBL-ray origin on the block: half its diagonal, the 1e-3
 // lift off the surface, and slack for a hit point rounded across the block's border
-F3D_HD float horizon_block_rho(const TerrainDev &T, uint32_t level) {
-    const float w = T.spacing_x * (float)(1u << level), d = T.spacing_z * (float)(1u << level);
-    return 0.5f * f_sqrt(w * w + d * d) + 0.02f * f_max(T.spacing_x, T.spacing_z) + 4e-3f;
+F3D_HD float horizon_block_rho(float spacing_x, float spacing_z, uint32_t level) {
+    const float w = spacing_x * (float)(1u << level), d = spacing_z * (float)(1u << level);
+    return 0.5f * f_sqrt(w * w + d * d) + 0.02f * f_max(spacing_x, spacing_z) + 4e-3f;
 }
+F3D_HD float horizon_block_rho(const TerrainDev &T, uint32_t level) { return horizon_block_rho(T.spacing_x, T.spacing_z, level); }
 // how far below the block's lowest corner an IBL-ray origin may lie (solver rounding + the lift along a normal)
 F3D_HD float horizon_y_margin(const TerrainDev &T) {
     const uint32_t top = T.mip_count - 1u;
@@ -356,18 +354,22 @@ F3D_HD void horizon_block_build(const TerrainDev &T, uint32_t level, uint32_t bx
 // does not clear the far horizon of its sector.
 F3D_HD float ibl_stop(const TerrainDev &T, V3 o, V3 d) {
     if (!T.horizon) return 3.0e38f;
+    uint32_t level = T.horizon_level;
+    float spacing_x = T.spacing_x, spacing_z = T.spacing_z;
+    F3D_OPAQUE_UNIFORM(level);  // (the block constants are formed in here, not hoisted in front of the sample loop: f3d_math.h)
+    F3D_OPAQUE_UNIFORM(spacing_x);
+    F3D_OPAQUE_UNIFORM(spacing_z);
     const float hlen = f_sqrt(d.x * d.x + d.z * d.z);
     if (!(hlen > 1e-6f)) return 3.0e38f;
     const float slope = d.y / hlen;
     if (!(slope >= 0.0f)) return 3.0e38f;  // (a descending ray is lowest at the FAR edge of a cell: not what the horizon bounds)
-    const uint32_t level = T.horizon_level;
     uint32_t cx = sat_u32(f_floor((o.x - T.origin_x) * T.inv_spacing_x)), cz = sat_u32(f_floor((o.z - T.origin_z) * T.inv_spacing_z));
     cx = cx < T.cell_w - 1u ? cx : T.cell_w - 1u;
     cz = cz < T.cell_h - 1u ? cz : T.cell_h - 1u;
     const uint32_t bx = cx >> level, bz = cz >> level;
     float mx, mz, y_lo;
     horizon_block_frame(T, level, bx, bz, mx, mz, y_lo);
-    const float rho = horizon_block_rho(T, level);
+    const float rho = horizon_block_rho(spacing_x, spacing_z, level);
     const float ex = o.x - mx, ez = o.z - mz;
     if (!(ex * ex + ez * ez <= rho * rho) || !(o.y >= y_lo)) return 3.0e38f;  // the certificate's preconditions
 #if defined(F3D_HORIZON_LAZY)  // host emulator: records are built when first read (NaN = not yet; racing threads write equal values)
@@ -383,7 +385,7 @@ F3D_HD float ibl_stop(const TerrainDev &T, V3 o, V3 d) {
     const float horizon = T.horizon[((size_t)bz * T.horizon_bx + bx) * kIblSectors + ibl_sector(d.x, d.z)];
     if (!(horizon < 1e30f)) return 3.0e38f;
     if (!(slope > horizon + 1e-4f * f_abs(horizon) + 1e-5f)) return 3.0e38f;
-    return ibl_stop_distance(rho, f_max(T.spacing_x, T.spacing_z)) / hlen;
+    return ibl_stop_distance(rho, f_max(spacing_x, spacing_z)) / hlen;
 }
 
 }  // namespace f3d

@@ -9,12 +9,20 @@ namespace f3d {
 
 constexpr int kWave = 64;
 
+// Lane id from the hardware, never from a register that has to stay alive: volatile, so it is neither hoisted nor merged.
+__device__ __forceinline__ uint32_t lane_now() {
+    uint32_t l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 // Per-wave LDS scratch of the traversal: a copy of the per-level layout tables, so that a lane
 // can look its (per-lane) level up with one ds_read_b64 instead of a vector load from the kernarg
 // segment, and -- only for the sorted descent kept for the test hook / A-B builds -- the
 // pending-sibling words as a [level][lane] column (bank = lane, conflict-free).
-// Rows kParkRow.. of the column hold the sample-lane frame's accumulators between rounds.
-constexpr int kParkRow = 3 * kLeafFifoRows, kParkWords = 7;
+// Rows kParkRow.. of the column hold the sample-lane frame's accumulators between rounds and its frame-head record.
+// (6 656 bytes a wave: 24 waves of a CU -- 6 per SIMD -- fit the 160 KB.)
+constexpr int kParkRow = 3 * kLeafFifoRows, kParkHead = 7, kParkWords = 9;  // 7 accumulator words + the frame head's record
 constexpr int kBoardRow = kParkRow + kParkWords;  // verdict board of the ray sharing (f3d_march.h): one word per lane
 constexpr int kLdsRows = kBoardRow + 1 > kMaxLevels ? kBoardRow + 1 : kMaxLevels;
 constexpr int kLdsWords = kLdsRows * kWave + 4 * kMaxLevels;
@@ -58,15 +66,20 @@ struct LdsPending {
     }
     __device__ __forceinline__ bool any(bool pred) const { return __ballot(pred) != 0ull; }
     // ---- ray sharing (f3d_march.h march_shared) ----
-    __device__ __forceinline__ uint32_t lane() const { return threadIdx.x & (kWave - 1u); }
+    // The lane id is REMATERIALISED where it is used (two v_mbcnt, no input): as a value derived from threadIdx.x it was
+    // hoisted out of every loop together with the masks built from it and lived in scratch across the whole kernel.
+    __device__ __forceinline__ uint32_t lane() const { return lane_now(); }
     __device__ __forceinline__ bool share_now(bool marching) const { return share_now(marching, share_below); }
     __device__ __forceinline__ bool share_now(bool marching, uint32_t below) const {
         const uint32_t n = (uint32_t)__popcll(__ballot(marching));
         return n != 0u && n <= below && (uint32_t)__popcll(__ballot(true)) >= kShareAvail * n;
     }
     // the verdict board lives in row kBoardRow of the WAVE's columns: board[l] = col[l - lane]
-    // (volatile: lanes talk to each other through it without a barrier -- one wave, LDS operations in order)
-    __device__ __forceinline__ volatile uint32_t *board() const { return col - lane() + kBoardRow * kWave; }
+    // (volatile: lanes talk to each other through it without a barrier -- one wave, LDS operations in order; the pointer
+    // is an LDS pointer by TYPE: address-space inference skips volatile accesses, and as generic ones they were flat_load /
+    // flat_store through a 64-bit address that sat in scratch)
+    using LdsWord = __attribute__((address_space(3))) volatile uint32_t;
+    __device__ __forceinline__ LdsWord *board() const { return (LdsWord *)(col - lane() + kBoardRow * kWave); }
     __device__ __forceinline__ void verdict_post(bool hit) const { board()[lane()] = hit ? 1u : 0u; }
     __device__ __forceinline__ void verdict_set(uint32_t owner) const { board()[owner & (kWave - 1u)] = 1u; }
     __device__ __forceinline__ bool verdict_get(uint32_t owner) const { return board()[owner & (kWave - 1u)] != 0u; }

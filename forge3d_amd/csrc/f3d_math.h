@@ -19,8 +19,15 @@
 // value instead of keeping the hot path's temporaries alive across a memory wait (f3d_march.h, corner ties).
 #if defined(__HIP_DEVICE_COMPILE__)
 #define F3D_OPAQUE(x) asm volatile("" : "+v"(x))
+// The same, said of a WAVE-UNIFORM value (a kernel parameter): whatever is computed from it stays where it is written.
+// Loop-invariant code motion otherwise hoists every expression of render constants out of the sample loop -- also from
+// branches that never run -- and, being float arithmetic, each lands in a VECTOR register that then lives in scratch for
+// the whole kernel (64 lanes x 4 bytes per constant; a third of the frame kernel's scratch before round 4).  (A vector
+// register on purpose: an "s" constraint is refused wherever the compiler has already moved the value to one.)
+#define F3D_OPAQUE_UNIFORM(x) asm volatile("" : "+v"(x))
 #else
 #define F3D_OPAQUE(x) (void)(x)
+#define F3D_OPAQUE_UNIFORM(x) (void)(x)
 #endif
 #else
 #include <cmath>
@@ -28,6 +35,7 @@
 #define F3D_HD inline
 #define F3D_LAMBDA __attribute__((always_inline))
 #define F3D_OPAQUE(x) (void)(x)
+#define F3D_OPAQUE_UNIFORM(x) (void)(x)
 // Host-only builds (tests/emul) have no HIP vector types.
 struct alignas(16) float4 {
     float x, y, z, w;

@@ -110,7 +110,16 @@ struct CameraDev {  // Uniforms, hybrid_kernel.wgsl:8-23 (+ derived constants)
     float exposure;
     uint32_t width, height;  // FULL image size
     uint32_t seed_hi, seed_lo;
+    float cone_delta;  // f3d_cone.h pixel_cone_delta(): half-width of a pixel's ray cone per unit depth (< 0: no certificates)
 };
+
+// Half-width of a pixel's ray cone per unit depth, with margin (the certificates of f3d_cone.h are built for it);
+// < 0: pixels too wide for certificates.
+F3D_HD float pixel_cone_delta_of(float half_w, float half_h, uint32_t width, uint32_t height) {
+    const float px = half_w / (float)width, py = half_h / (float)height;
+    const float plane = f_sqrt(px * px + py * py);
+    return plane < 0.25f ? 1.01f * plane * (1.0f + plane * plane) : -1.0f;
+}
 
 struct LightDev {  // LightingUniforms, hybrid_kernel.wgsl:27-38 (+ derived constants)
     V3 wi;         // normalize(light_dir): candidate sample direction

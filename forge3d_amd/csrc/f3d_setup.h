@@ -358,6 +358,7 @@ inline bool fill_uniforms(const f3d_terrain_ref_desc &d, FrameParams &P) {
     P.cam.height = d.height;
     P.cam.seed_hi = d.seed;
     P.cam.seed_lo = d.seed ^ 0x85EBCA6Bu;
+    P.cam.cone_delta = pixel_cone_delta_of(P.cam.half_w, P.cam.half_h, d.width, d.height);
     P.light.wi = normalize(light_dir);
     P.light.wi_reuse = normalize(P.light.wi);
     P.light.color = V3{sun_intensity * sun_color[0], sun_intensity * sun_color[1], sun_intensity * sun_color[2]};

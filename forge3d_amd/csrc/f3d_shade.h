@@ -242,13 +242,16 @@ F3D_HD bool occluded(const FrameParams &P, V3 o, float tmin, V3 d, float tmax, b
 // terrain_env_radiance, hybrid_terrain_traversal.wgsl:392-405
 F3D_HD V3 env_radiance(const EnvDev &E, V3 dir) {
     if (E.width == 0u || E.height == 0u) return V3{E.intensity, E.intensity, E.intensity};
+    uint32_t width = E.width, height = E.height;
+    F3D_OPAQUE_UNIFORM(width);  // (the map's constants are formed here, not in front of the sample loop: f3d_math.h)
+    F3D_OPAQUE_UNIFORM(height);
     V3 d = normalize(dir);
     float uu = atan2_det(d.z, d.x) / (2.0f * kPi) + 0.5f;
     float vv = acos_det(f_clamp(d.y, -1.0f, 1.0f)) / kPi;
-    uint32_t px = sat_u32(uu * (float)E.width), py = sat_u32(vv * (float)E.height);
-    px = px < E.width - 1u ? px : E.width - 1u;
-    py = py < E.height - 1u ? py : E.height - 1u;
-    float4 t = E.texels[(size_t)py * E.width + px];
+    uint32_t px = sat_u32(uu * (float)width), py = sat_u32(vv * (float)height);
+    px = px < width - 1u ? px : width - 1u;
+    py = py < height - 1u ? py : height - 1u;
+    float4 t = E.texels[(size_t)py * width + px];
     return V3{t.x * E.intensity, t.y * E.intensity, t.z * E.intensity};
 }
 
@@ -483,7 +486,9 @@ F3D_HD PrimaryHit sample_primary(const FrameParams &P, uint32_t gx, uint32_t gy,
     if (P.sun_clear && ph.hit.kind != 0u) {
         const uint32_t lp = (gy - P.row_begin) * P.cam.width + gx;
         const float2 c = P.sun_clear[lp];
-        const float cell = f_min(P.terrain.spacing_x, P.terrain.spacing_z);
+        float sx = P.terrain.spacing_x;
+        F3D_OPAQUE_UNIFORM(sx);
+        const float cell = f_min(sx, P.terrain.spacing_z);
         if (c.y > 0.0f && f_abs(ph.hit.t - c.y) <= sun_depth_slack(c.y, pixel_cone_delta(P.cam), cell)) {
             ph.cert = lp;  // the sample's hit point is within the radius the pixel's certificates allow for
             if (c.x < 1e30f) ph.sun_tmax = c.x;
@@ -520,7 +525,7 @@ struct ShadeSetup {
 
 // Everything of a sample's shading except the two occlusion rays; draws u1, u2 from `rng` on a hit; o.a = the miss
 // radiance on a miss, o.target_pdf = the candidate weight.
-F3D_HD ShadeSetup sample_shade_setup(const FrameParams &P, const FrameHead &h, const PrimaryHit &ph, uint32_t &rng, SampleOut &o) {
+F3D_HD ShadeSetup sample_shade_setup(const FrameParams &P, bool prev_valid, const PrimaryHit &ph, uint32_t &rng, SampleOut &o) {
     ShadeSetup su;
     IblRay &q = su.q;
     q.valid = false;
@@ -536,12 +541,20 @@ F3D_HD ShadeSetup sample_shade_setup(const FrameParams &P, const FrameHead &h, c
         return su;
     }
     const V3 n = ph.hit.n;
-    const V3 albedo = ph.hit.kind == 1u ? P.light.albedo : V3{0.7f, 0.7f, 0.8f};
+    V3 albedo = P.light.albedo;
+    F3D_OPAQUE_UNIFORM(albedo.x);  // (render constants: their products are formed per sample, not held across the kernel)
+    F3D_OPAQUE_UNIFORM(albedo.y);
+    F3D_OPAQUE_UNIFORM(albedo.z);
+    if (ph.hit.kind != 1u) albedo = V3{0.7f, 0.7f, 0.8f};
     const V3 so = along(ph.hit.p, 1e-3f, n);
     // candidate generation for this hit (:500-512)
     o.target_pdf = luminance((albedo * P.light.color) * f_max(dot(n, P.light.wi), 0.0f));
     // sun through the merged reservoir, :517-532
-    su.sun_dir = h.prev_valid ? P.light.wi_reuse : P.light.wi;
+    // (component selects: `cond ? P.light.wi_reuse : P.light.wi` became a select of two kernarg ADDRESSES and a vector load)
+    uint32_t from_reservoir = prev_valid ? 1u : 0u;
+    F3D_OPAQUE(from_reservoir);  // (per lane but the same in every round: selected here, not kept in three registers)
+    su.sun_dir = V3{from_reservoir ? P.light.wi_reuse.x : P.light.wi.x, from_reservoir ? P.light.wi_reuse.y : P.light.wi.y,
+                    from_reservoir ? P.light.wi_reuse.z : P.light.wi.z};
     const float nd = f_max(dot(n, su.sun_dir), 0.0f);
     if (nd > 0.0f) {
         su.need_sun = true;
@@ -564,10 +577,12 @@ F3D_HD ShadeSetup sample_shade_setup(const FrameParams &P, const FrameHead &h, c
 
 // First half of the shading of a sample whose primary hit is known (:486-536): candidate, sun term
 // (with its shadow ray), and the IBL ray to trace; draws u1, u2 from `rng` on a hit.
-template <class Pending>
-F3D_HD IblRay sample_shade_sun(const FrameParams &P, const FrameHead &h, const PrimaryHit &ph, uint32_t &rng,
+// reuse_w(): the reuse weight of the frame head, asked for AFTER the shadow ray (the sample-lane kernels keep it in the
+// lane's LDS column, f3d_frame.h, instead of in a register across the march).
+template <class Pending, class ReuseW>
+F3D_HD IblRay sample_shade_sun(const FrameParams &P, bool prev_valid, ReuseW reuse_w, const PrimaryHit &ph, uint32_t &rng,
                                SampleOut &o, Pending &pend) {
-    const ShadeSetup su = sample_shade_setup(P, h, ph, rng, o);
+    const ShadeSetup su = sample_shade_setup(P, prev_valid, ph, rng, o);
     if (su.need_sun) {
         float vis = 1.0f;
 #if defined(F3D_MODEL_HINT_SUN)  // scheduling-model builds of the emulator only
@@ -576,12 +591,18 @@ F3D_HD IblRay sample_shade_sun(const FrameParams &P, const FrameHead &h, const P
 #if !defined(F3D_TIMING_NO_SHADOW)  // timing experiment only (wrong image): tools/gpu_build_ab.sh
         if (P.light.shadows_enabled != 0u && occluded(P, su.q.o, 1e-3f, su.sun_dir, 1e30f, true, pend, ph.sun_tmax)) vis = 0.0f;
 #endif
-        o.a = (su.y * vis) * h.reuse_w;
+        o.a = (su.y * vis) * reuse_w();
     }
 #if defined(F3D_MODEL_HINT)  // scheduling-model builds of the emulator only (tools/march_model.py predictor)
     if (su.q.valid) pend.hint(F3D_MODEL_HINT);
 #endif
     return su.q;
+}
+template <class Pending>
+F3D_HD IblRay sample_shade_sun(const FrameParams &P, const FrameHead &h, const PrimaryHit &ph, uint32_t &rng,
+                               SampleOut &o, Pending &pend) {
+    const float w = h.reuse_w;
+    return sample_shade_sun(P, h.prev_valid, [w]() F3D_LAMBDA { return w; }, ph, rng, o, pend);
 }
 
 // The verdict of an IBL ray (intersect_ibl_occlusion_ray, hybrid_traversal.wgsl:250-259).
