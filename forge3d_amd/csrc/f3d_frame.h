@@ -187,7 +187,7 @@ __device__ __forceinline__ float frame_lanes(const FrameParams &P, uint32_t tile
     // in scratch, and 160 bytes of scratch per lane x 6 144 waves a CU did not fit the L2 (1.4 GB written per launch).
     // So nothing that can be formed again is kept: the pixel (lane_pixel), the lane's position in its group (lane_now),
     // every address; and what is the lane's own but only read between the marches is parked in its LDS column: the
-    // accumulators of the samples so far (7 words) and the frame head's record (2 words).
+    // accumulators of the samples so far (6 words) and the frame head's record (2 words).
     uint32_t *park = pend.col + kParkRow * kWave;
     uint32_t stream = 0u;  // state at the start of the current round
     {
@@ -247,9 +247,9 @@ __device__ __forceinline__ float frame_lanes(const FrameParams &P, uint32_t tile
         V3 radiance = V3{f_from_bits(park[0]), f_from_bits(park[kWave]), f_from_bits(park[2 * kWave])};
         Reservoir cand;
         cand.w_sum = f_from_bits(park[3 * kWave]);
-        cand.m = park[4 * kWave];
+        cand.m = park[4 * kWave] & ~kLightTypeBit;
         cand.target_pdf = f_from_bits(park[5 * kWave]);
-        cand.directional = park[6 * kWave] != 0u;
+        cand.directional = (park[4 * kWave] & kLightTypeBit) != 0u;
         cand.weight = 0.0f;
         const int base = (int)(lane_now() & ~(S - 1u));
 #pragma unroll
@@ -264,17 +264,16 @@ __device__ __forceinline__ float frame_lanes(const FrameParams &P, uint32_t tile
         park[kWave] = f_bits(radiance.y);
         park[2 * kWave] = f_bits(radiance.z);
         park[3 * kWave] = f_bits(cand.w_sum);
-        park[4 * kWave] = cand.m;
+        park[4 * kWave] = cand.m | (cand.directional ? kLightTypeBit : 0u);
         park[5 * kWave] = f_bits(cand.target_pdf);
-        park[6 * kWave] = cand.directional ? 1u : 0u;
         rng_skip(stream, 2u * n_act + 2u * (uint32_t)__popc(pred));
     }
     if (!valid || (lane_now() & (S - 1u)) != 0u) return 0.0f;
     Reservoir cand;
     cand.w_sum = f_from_bits(park[3 * kWave]);
-    cand.m = park[4 * kWave];
+    cand.m = park[4 * kWave] & ~kLightTypeBit;
     cand.target_pdf = f_from_bits(park[5 * kWave]);
-    cand.directional = park[6 * kWave] != 0u;
+    cand.directional = (park[4 * kWave] & kLightTypeBit) != 0u;
     cand.weight = 0.0f;
     uint32_t gx, gy;
     lane_pixel<S>(P, tile, gx, gy);

@@ -21,10 +21,14 @@ __device__ __forceinline__ uint32_t lane_now() {
 // segment, and -- only for the sorted descent kept for the test hook / A-B builds -- the
 // pending-sibling words as a [level][lane] column (bank = lane, conflict-free).
 // Rows kParkRow.. of the column hold the sample-lane frame's accumulators between rounds and its frame-head record.
-// (6 656 bytes a wave: 24 waves of a CU -- 6 per SIMD -- fit the 160 KB.)
-constexpr int kParkRow = 3 * kLeafFifoRows, kParkHead = 7, kParkWords = 9;  // 7 accumulator words + the frame head's record
-constexpr int kBoardRow = kParkRow + kParkWords;  // verdict board of the ray sharing (f3d_march.h): one word per lane
-constexpr int kLdsRows = kBoardRow + 1 > kMaxLevels ? kBoardRow + 1 : kMaxLevels;
+// 6 144 bytes a wave, and not a row more: LDS is handed out in 2 KiB pieces on gfx950 (tools/experiments/lds_granule.hip),
+// so 6 656 bytes cost 8 KiB and a CU held 20 waves instead of 24 -- measured 4 % of the frame.  Hence the verdict board
+// shares a word with the head's flags (its bit is set by other lanes: an LDS atomic) and the candidate's light-type flag
+// rides in bit 31 of its sample count, as in the packed reservoir.
+constexpr int kParkRow = 3 * kLeafFifoRows, kParkHead = 6, kParkWords = 8;  // 6 accumulator words + the frame head's record {reuse weight, flags}
+constexpr int kBoardRow = kParkRow + kParkHead + 1;  // verdict board of the ray sharing (f3d_march.h): bit 31 of the flags word
+constexpr uint32_t kBoardBit = 0x80000000u;
+constexpr int kLdsRows = kParkRow + kParkWords > kMaxLevels ? kParkRow + kParkWords : kMaxLevels;
 constexpr int kLdsWords = kLdsRows * kWave + 4 * kMaxLevels;
 struct LdsPending {
     // may the scene hold a mesh?  (closest_hit / occluded, f3d_shade.h: the terrain-only frame kernels are compiled without
@@ -80,9 +84,16 @@ struct LdsPending {
     // flat_store through a 64-bit address that sat in scratch)
     using LdsWord = __attribute__((address_space(3))) volatile uint32_t;
     __device__ __forceinline__ LdsWord *board() const { return (LdsWord *)(col - lane() + kBoardRow * kWave); }
-    __device__ __forceinline__ void verdict_post(bool hit) const { board()[lane()] = hit ? 1u : 0u; }
-    __device__ __forceinline__ void verdict_set(uint32_t owner) const { board()[owner & (kWave - 1u)] = 1u; }
-    __device__ __forceinline__ bool verdict_get(uint32_t owner) const { return board()[owner & (kWave - 1u)] != 0u; }
+    __device__ __forceinline__ void verdict_post(bool hit) const {  // every lane, before any verdict_set of the call
+        LdsWord *mine = (LdsWord *)(col + kBoardRow * kWave);
+        const uint32_t w = *mine;
+        *mine = hit ? w | kBoardBit : w & ~kBoardBit;
+    }
+    __device__ __forceinline__ void verdict_set(uint32_t owner) const {  // (several lanes may name one owner; its other bits stay)
+        __hip_atomic_fetch_or((__attribute__((address_space(3))) uint32_t *)(board() + (owner & (kWave - 1u))), kBoardBit, __ATOMIC_RELAXED,
+                              __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    __device__ __forceinline__ bool verdict_get(uint32_t owner) const { return (board()[owner & (kWave - 1u)] & kBoardBit) != 0u; }
     // wave primitives of march_deal (f3d_march.h)
     __device__ __forceinline__ unsigned long long ballot(bool pred) const { return __ballot(pred); }
     __device__ __forceinline__ float shfl(float v, int src) const { return __shfl(v, src, kWave); }
