@@ -559,7 +559,7 @@ struct WfSource {
 };
 template <bool SUN, int MIN_WAVES>
 __global__ __launch_bounds__(kWave, MIN_WAVES) void k_wf_occl(const WfOcclParams W) {
-    constexpr uint32_t kRows = 3u * kLeafFifoRows;  // the leaf FIFO; no park rows, no verdict board: 4 KiB a wave
+    constexpr uint32_t kRows = kFifoWords * kLeafFifoRows;  // the leaf FIFO; no park rows, no verdict board
     __shared__ __attribute__((aligned(16))) uint32_t lds[kRows * kWave + 4 * kMaxLevels];
     LdsPending pend = make_pending(lds, W.terrain, kRows);
     WfSource<SUN> src{W, 0u, (W.regions + kWfChunk - 1u) / kWfChunk, 0u, 0u, 0u, 0u, true};

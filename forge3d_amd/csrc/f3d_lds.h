@@ -25,7 +25,7 @@ __device__ __forceinline__ uint32_t lane_now() {
 // so 6 656 bytes cost 8 KiB and a CU held 20 waves instead of 24 -- measured 4 % of the frame.  Hence the verdict board
 // shares a word with the head's flags (its bit is set by other lanes: an LDS atomic) and the candidate's light-type flag
 // rides in bit 31 of its sample count, as in the packed reservoir.
-constexpr int kParkRow = 3 * kLeafFifoRows, kParkHead = 6, kParkWords = 8;  // 6 accumulator words + the frame head's record {reuse weight, flags}
+constexpr int kParkRow = kFifoWords * kLeafFifoRows, kParkHead = 6, kParkWords = 8;  // 6 accumulator words + the frame head's record {reuse weight, flags}
 constexpr int kBoardRow = kParkRow + kParkHead + 1;  // verdict board of the ray sharing (f3d_march.h): bit 31 of the flags word
 constexpr uint32_t kBoardBit = 0x80000000u;
 constexpr int kLdsRows = kParkRow + kParkWords > kMaxLevels ? kParkRow + kParkWords : kMaxLevels;
@@ -47,19 +47,24 @@ struct LdsPending {
         const unsigned long long leaf = __ballot(at_leaf), inner = __ballot(!at_leaf);
         return (uint32_t)__popcll(leaf) >= leaf_quorum || inner == 0ull;
     }
-    // ---- deferred leaf FIFO of the march (f3d_march.h): 3 words per entry in the lane's column ----
+    // ---- deferred leaf FIFO of the march (f3d_march.h): kFifoWords words per entry in the lane's column ----
     __device__ __forceinline__ void fifo_put(uint32_t k, uint32_t cell, float lo, float hi) {
-        uint32_t *e = col + mul24(k, 3u * kWave);
+        uint32_t *e = col + mul24(k, kFifoWords * kWave);
         e[0] = cell;
-        e[kWave] = f_bits(lo);
-        e[2 * kWave] = f_bits(hi);
+        if (kFifoWords == 3u) {
+            e[kWave] = f_bits(lo);
+            e[2 * kWave] = f_bits(hi);
+        }
     }
-    __device__ __forceinline__ void fifo_retag(uint32_t k, uint32_t cell) { col[mul24(k, 3u * kWave)] = cell; }
+    __device__ __forceinline__ void fifo_retag(uint32_t k, uint32_t cell) { col[mul24(k, kFifoWords * kWave)] = cell; }
     __device__ __forceinline__ void fifo_get(uint32_t k, uint32_t &cell, float &lo, float &hi) const {
-        const uint32_t *e = col + mul24(k, 3u * kWave);
+        const uint32_t *e = col + mul24(k, kFifoWords * kWave);
         cell = e[0];
-        lo = f_from_bits(e[kWave]);
-        hi = f_from_bits(e[2 * kWave]);
+        lo = hi = 0.0f;  // (one-word entries: the drain forms the interval again)
+        if (kFifoWords == 3u) {
+            lo = f_from_bits(e[kWave]);
+            hi = f_from_bits(e[2 * kWave]);
+        }
     }
     // drain now?  enough lanes have a leaf queued, or a FIFO is full, or nobody marches any more
     __device__ __forceinline__ bool flush_now(uint32_t queued, bool marching) const {

@@ -83,6 +83,18 @@ constexpr uint32_t kLeafFifo = F3D_LEAF_FIFO;  // entries per lane (A/B: 2, 3, 6
 // A step queues at most two entries (a leaf AND the corner it leaves through) and the wave drains as soon
 // as one lane holds kLeafFifo: storage for one more.
 constexpr uint32_t kLeafFifoRows = kLeafFifo + 1u;
+// An entry is {cell, lo, hi}.  -DF3D_FIFO_WORDS=1 (round 4, measured and NOT adopted) keeps the cell only -- or the corner
+// of a TIE -- and lets the drain form the interval again, by the expressions the step used on the same integers (a TIE's
+// parameter T is the plane parameter of its corner's x line: every site that queues one has just compared that very
+// value for equality with T).  Bit-identical (the emulator hands the drain NaNs for lo / hi in that build), 4 352 bytes of
+// LDS a wave instead of 6 144, i.e. room for 7 and 8 waves per SIMD (LDS is handed out in 1 280-byte pieces:
+// tools/experiments/lds_granule.hip) -- but the ~20 instructions per drained leaf cost more than the waves bring:
+// 8 680 (3 words, 6 waves) / 8 450 (1 word, 6) / 8 610 (1 word, 7) / 8 330 (1 word, 8) Msamples/s on one box.
+#ifndef F3D_FIFO_WORDS
+#define F3D_FIFO_WORDS 3
+#endif
+constexpr uint32_t kFifoWords = F3D_FIFO_WORDS;
+static_assert(kFifoWords == 1u || kFifoWords == 3u, "F3D_FIFO_WORDS: 1 (cell only) or 3 (cell, lo, hi)");
 // A lane takes up to kStepsPerVote march steps between two wave votes (the flush / share / done ballots and their
 // branches are about a seventh of an iteration's serial latency); it stops early when its ray ends or its FIFO could
 // overflow (a step queues at most two entries).  Results do not depend on it (3.1 of DESIGN.md: verdicts do not depend
@@ -328,6 +340,19 @@ F3D_HD void march_drain(const TerrainDev &T, const RayCtx &r, bool any_hit, Marc
             uint32_t cx = cell & 0xFFFFu, cz = cell >> 16;
             bool solve = true;
             const bool tie = any_hit && (cell & kTieFlag) != 0u;
+            if (kFifoWords == 1u) {  // the interval again, as march_step formed it (see kFifoWords)
+                if (tie) {
+                    lo = hi = (plane_at(T.origin_x, cell & 0x3FFFu, T.spacing_x) - r.o.x) * r.inv_x;
+                } else {
+                    const uint32_t cx1 = cx + 1u < T.cell_w ? cx + 1u : T.cell_w, cz1 = cz + 1u < T.cell_h ? cz + 1u : T.cell_h;
+                    const float tx0 = (plane_at(T.origin_x, cx, T.spacing_x) - r.o.x) * r.inv_x;
+                    const float tx1 = (plane_at(T.origin_x, cx1, T.spacing_x) - r.o.x) * r.inv_x;
+                    const float tz0 = (plane_at(T.origin_z, cz, T.spacing_z) - r.o.z) * r.inv_z;
+                    const float tz1 = (plane_at(T.origin_z, cz1, T.spacing_z) - r.o.z) * r.inv_z;
+                    lo = f_max(f_max(f_min(tx0, tx1), f_min(tz0, tz1)), r.tmin);
+                    hi = f_min(f_min(f_max(tx0, tx1), f_max(tz0, tz1)), r.tmax);
+                }
+            }
             if (tie) {
                 const uint32_t X = cell & 0x3FFFu, Z = (cell >> 14) & 0x3FFFu;
                 const bool xf = (cell & kTieXFwd) != 0u, zf = (cell & kTieZFwd) != 0u, second = (cell & kTieSecond) != 0u;

@@ -79,8 +79,9 @@ struct ArrayPending {
     }
     void fifo_get(uint32_t k, uint32_t &cell, float &lo, float &hi) const {
         cell = q_cell[k];
-        lo = q_lo[k];
-        hi = q_hi[k];
+        // one-word entries (f3d_march.h kFifoWords): the drain must form the interval itself -- poison what it is handed
+        lo = kFifoWords == 3u ? q_lo[k] : f_from_bits(0x7fc00000u);
+        hi = kFifoWords == 3u ? q_hi[k] : f_from_bits(0x7fc00000u);
     }
     bool flush_now(uint32_t queued, bool marching) const { return queued >= kLeafFifo || (!marching && queued != 0u); }
     bool any(bool pred) const { return pred; }
