@@ -12,10 +12,13 @@ state) are resident in HBM before the timed region.
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the image is split into N
-load-balanced row strips (measured before the timed region, forge3d_amd/distributed.py),
-the 3-row reservoir halos move over RCCL after every frame, the variance
-statistic is all-reduced per window and the RGBA8/AOV strips are gathered to rank 0 at the
-end (strong scaling: the 1080p frame is fixed).
+load-balanced row strips (measured before the timed region, forge3d_amd/distributed.py).
+After every frame each strip PULLS the 4 edge rows of packed reservoirs of its two
+neighbours itself, on the device, from their IPC-mapped memory over xGMI (peer halos: no
+Python and no collective per frame; if the devices cannot map each other every rank
+falls back to an RCCL send / recv pair per frame -- `config.peer_halos` says which ran).
+RCCL carries the all-reduce of the variance record per window and the gather of the
+RGBA8 / AOV strips to rank 0 at the end (strong scaling: the 1080p frame is fixed).
 """
 from __future__ import annotations
 
@@ -267,7 +270,7 @@ def main():
     kw = dict(kw, spp=args.spp, variance_threshold=1e30)
 
     windows = 1 + max(0, args.extra_windows)
-    total_frames = args.warmup + args.steps * windows
+    total_frames = args.warmup + args.steps * max(windows, 2)  # (one window more when the kernel-timing window is an extra one)
     kw = dict(kw, max_frames=max(total_frames, 2), min_frames=max(total_frames, 2))
     if world == 1:  # a throw-away session of another DEM first: module load and allocator start-up are not set-up of THIS render
         from forge3d_amd.session import TerrainSession
@@ -286,28 +289,41 @@ def main():
     setup_ms = (time.perf_counter() - t_setup) * 1e3
     # warmup (untimed) ---------------------------------------------------------------
     r.run_frames(0, args.warmup)
+    if r.peer_halos:
+        r.session.halo_stats(reset=True)  # the warm-up's waits (first launches, code loads) are not the loop's
     r.barrier()
     torch.cuda.synchronize()
-    r.session.kernel_timing(True)
     t0 = time.perf_counter()
     r.run_frames(args.warmup, args.steps)
     torch.cuda.synchronize()
     r.barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms, launches = r.session.kernel_timing(False)
+    halo = r.session.halo_stats() if r.peer_halos else None
     rank_ms = r._gather_floats(elapsed / args.steps * 1e3) if world > 1 else [elapsed / args.steps * 1e3]
+    halo_wait_ms = r._gather_floats(sum(halo["wait_ms"]) / args.steps) if (world > 1 and halo) else None
+    halo_longest_ms = r._gather_floats(halo["longest_wait_ms"]) if (world > 1 and halo) else None
     elapsed = r.max_over_ranks(elapsed)
-    kernel_ms = r.max_over_ranks(kernel_ms)
-    # further windows of the same K frames (the accumulation simply continues): the spread of the measurement
+    # further windows of the same K frames (the accumulation simply continues): the spread of the measurement.  The
+    # frame kernel is timed (two hip events around every launch) in the LAST of them, or -- with --extra-windows 0 --
+    # in a window of its own after the timed region: the headline window runs without the events.
     window_ms = [elapsed / args.steps * 1e3]
-    for wi in range(1, windows):
+    kernel_ms, launches = 0.0, 0
+    for wi in range(1, windows + (1 if windows == 1 else 0)):
+        timed_kernels = wi == max(1, windows - 1)
         r.barrier()
         torch.cuda.synchronize()
+        if timed_kernels:
+            r.session.kernel_timing(True)
         t1 = time.perf_counter()
         r.run_frames(args.warmup + wi * args.steps, args.steps)
         torch.cuda.synchronize()
         r.barrier()
-        window_ms.append(r.max_over_ranks(time.perf_counter() - t1) / args.steps * 1e3)
+        dt = r.max_over_ranks(time.perf_counter() - t1) / args.steps * 1e3
+        if timed_kernels:
+            kernel_ms, launches = r.session.kernel_timing(False)
+            kernel_ms = r.max_over_ranks(kernel_ms)
+        if wi < windows:
+            window_ms.append(dt)
     # final composition (untimed, but exercised): gather strips to rank 0
     image = r.gather_image(total_frames)
     halo_bytes = 0 if world == 1 else HALO_ROWS * args.width * 16 * ((1 if rank > 0 else 0) + (1 if rank < world - 1 else 0))
@@ -327,7 +343,11 @@ def main():
                 "workload": f"BASELINE.json configs[1]: rainier-proxy DEM {args.dem}x{args.dem}, "
                             f"{args.width}x{args.height}, {args.spp} spp/frame x {args.steps} frames "
                             f"= {args.spp * args.steps} spp, sun az302/el24, orbit phi28/theta49 fov42",
-                "parallelism": "1 GPU" if world == 1 else f"{world} row strips, RCCL halo exchange + gather",
+                "parallelism": "1 GPU" if world == 1 else (
+                    f"{world} load-balanced row strips; halos: " + ("pulled by the strips from IPC-mapped peer memory (device-side, no collective per frame)"
+                                                                   if r.peer_halos else "RCCL send / recv pair per frame")
+                    + "; RCCL all-reduce per window + gather of the strips"),
+                **({"peer_halos": bool(r.peer_halos)} if world > 1 else {}),
                 "kernel_variant": args.variant,
                 "frames_in_flight": r.session.frames_in_flight(),
                 "setup_ms_once_per_render": round(setup_ms, 3),
@@ -336,6 +356,10 @@ def main():
                               "the certificates pay back about 3 ms",
                 **({"strip_row_bounds": r.bounds, "strip_probe_ms": r.balance_log[-1]["ms"] if r.balance_log else None,
                     "rccl_ranks": world, "rank_ms_per_step": [round(x, 4) for x in rank_ms], "halo_bytes_per_frame_rank0": halo_bytes,
+                    # device time each rank's pulls stood waiting for its neighbours' frame counters, per frame (peer halos only),
+                    # and the longest single wait: what the first real multi-GPU run has to show
+                    "halo_wait_ms_per_frame": [round(x, 4) for x in halo_wait_ms] if halo_wait_ms else None,
+                    "halo_longest_wait_ms": [round(x, 4) for x in halo_longest_ms] if halo_longest_ms else None,
                     "dist_backend": os.environ.get("F3D_DIST_BACKEND") or "nccl"} if world > 1 else {}),
             },
         }

@@ -18,7 +18,7 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libf3dhip.so"
 
 STATUS_OK, STATUS_VALUE, STATUS_RENDER, STATUS_UPLOAD, STATUS_DEVICE = 0, 1, 2, 3, 4
-ABI_VERSION = 3  # F3D_ABI_VERSION of include/f3d_terrain_pt.h this mirror was written against
+ABI_VERSION = 4  # F3D_ABI_VERSION of include/f3d_terrain_pt.h this mirror was written against
 
 _EARTH = {"flat": 0, "sphere": 1, "ellipsoid": 2, "wgs84": 2}
 _REFRACTION = {"none": 0, "bennett": 1, "saemundsson": 2, "effective_radius": 3}
@@ -81,6 +81,12 @@ class HaloExport(C.Structure):
                 ("rows", C.c_uint32), ("width", C.c_uint32), ("device", C.c_int32), ("pid", C.c_uint32)]
 
 
+class HaloStats(C.Structure):
+    """f3d_halo_stats"""
+    _fields_ = [("reset", C.c_uint32), ("frames_published", C.c_uint32), ("timeouts", C.c_uint32), ("pulls", C.c_uint32),
+                ("wait_ms", C.c_double * 2), ("longest_wait_ms", C.c_double), ("timeout_ms", C.c_double)]
+
+
 class SessionOpts(C.Structure):
     """f3d_session_opts"""
     _fields_ = [
@@ -107,6 +113,7 @@ ABI = [
     ("f3d_session_halo_connect", C.c_int, [C.c_void_p, C.c_int32, _P(HaloExport), C.c_char_p, C.c_size_t]),
     ("f3d_session_halo_probe", C.c_int, [C.c_void_p, C.c_int32, C.c_uint32, _P(C.c_uint32), C.c_char_p, C.c_size_t]),
     ("f3d_session_halo_status", C.c_int, [C.c_void_p, _P(C.c_uint32), C.c_char_p, C.c_size_t]),
+    ("f3d_session_halo_stats", C.c_int, [C.c_void_p, _P(HaloStats), C.c_char_p, C.c_size_t]),
     ("f3d_session_enqueue_batch_strip", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_char_p, C.c_size_t]),
     ("f3d_session_frames_in_flight", C.c_uint32, [C.c_void_p]),
     ("f3d_session_retraced_pixels", C.c_int, [C.c_void_p, _P(C.c_uint64)]),

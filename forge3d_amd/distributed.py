@@ -33,9 +33,9 @@ RES_BYTES = 16
 WELFORD_WINDOW = 32
 
 
-def init_process_group(world: int, rank: int, backend: str | None = None):
-    """Join the default process group when world > 1 (env:// rendezvous on 127.0.0.1)."""
-    if world <= 1:
+def init_process_group(world: int, rank: int, backend: str | None = None, force: bool = False):
+    """Join the default process group when world > 1 (env:// rendezvous on 127.0.0.1); force: also for a world of one."""
+    if world <= 1 and not force:
         return
     import torch
     import torch.distributed as dist
@@ -150,11 +150,14 @@ class HipBackend:
 
 class StripRenderer:
     def __init__(self, dem, width, height, cam, *, rank=0, world=1, device=0, backend=None, row_bounds=None,
-                 balance_iters=5, peer_halos=None, **kw):
+                 balance_iters=5, peer_halos=None, force_collectives=False, **kw):
         import torch
 
         self.torch = torch
         self.rank, self.world = rank, world
+        # force_collectives: a world-1 job still goes through every collective and the peer-halo set-up (the GPU suite's
+        # RCCL smoke test: one rank is all a one-GPU box can give the nccl backend)
+        self.distributed = world > 1 or bool(force_collectives)
         self.width, self.height = int(width), int(height)
         self.backend = backend or HipBackend(device)
         self.balance_log = []
@@ -179,7 +182,7 @@ class StripRenderer:
             self.bounds = [strip_rows(self.height, world, r)[0] for r in range(world)] + [self.height]
             if world > 1 and self.height < world * HALO_ROWS:
                 raise ValueError(f"strips need at least {HALO_ROWS} rows each ({self.height} rows / {world} ranks)")
-            if world > 1 and balance_iters > 0 and hasattr(self.backend, "probe"):
+            if self.distributed and balance_iters > 0 and hasattr(self.backend, "probe"):
                 self.bounds = self._balance(dem, cam, kw, balance_iters)
         self.row_begin, self.row_end = self.bounds[rank], self.bounds[rank + 1]
         self.rows = self.row_end - self.row_begin
@@ -200,7 +203,7 @@ class StripRenderer:
             peer_halos = os.environ.get("F3D_PEER_HALOS", "1") != "0"
         self.peer_halos = False
         self.session = None
-        if world > 1 and peer_halos and isinstance(self.backend, HipBackend):
+        if self.distributed and peer_halos and isinstance(self.backend, HipBackend):
             self.session = self._connect_peers(dem, cam, kw)
             self.peer_halos = self.session is not None
         if self.session is None:
@@ -270,6 +273,20 @@ class StripRenderer:
             if not agreed(ok):
                 session.close()
                 return None
+        # ... and the same with a REAL block: every strip fills its edge rows with a pattern by a many-workgroup kernel (dirty
+        # lines in every XCD's L2, as the frame kernels leave them), publishes behind it, and its neighbours pull the block
+        # with the frame loop's own kernel and check its sum.  Twice, with different patterns in the same memory.
+        for salt in (0x0B10C000, 0x0C0DE000):
+            try:
+                session.halo_probe_fill(salt + self.rank + 1)
+                session.halo_probe_pull(salt + self.rank, salt + self.rank + 2)
+            except Exception:  # noqa: BLE001
+                ok = 0
+            dist.barrier()  # (a strip's edge rows are cleared again by its own pull: nobody refills before everybody has pulled)
+            if not agreed(ok):
+                session.close()
+                return None
+        session.halo_stats(reset=True)  # the probes' waits are not the render's
         dist.barrier()  # nobody starts rendering (and polling counters) before every neighbour is mapped
         return session
 
@@ -281,7 +298,7 @@ class StripRenderer:
         import torch.distributed as dist
 
         dev = self.backend.empty_i32(1).device
-        if dev.type != "cpu" and self.world > 1 and dist.get_backend() == "gloo":
+        if dev.type != "cpu" and self.distributed and dist.get_backend() == "gloo":
             return self.torch.device("cpu")
         return dev
 
@@ -335,7 +352,7 @@ class StripRenderer:
         (point-to-point over the direct xGMI link); returns what finish_halo_exchange needs.  With RCCL
         the transfers run on its own stream, ordered after the work already enqueued on the session's
         stream (the frame, or its edge bands when the session was cut into three or more bands)."""
-        if self.world == 1:
+        if not self.distributed:
             return None
         import torch.distributed as dist
 
@@ -375,13 +392,13 @@ class StripRenderer:
         self.finish_halo_exchange(self.start_halo_exchange(which))
 
     def barrier(self):
-        if self.world > 1:
+        if self.distributed:
             import torch.distributed as dist
 
             dist.barrier()
 
     def max_over_ranks(self, value: float) -> float:
-        if self.world == 1:
+        if not self.distributed:
             return float(value)
         import torch.distributed as dist
 
@@ -396,7 +413,7 @@ class StripRenderer:
         emulator's path): per frame a point-to-point exchange posted from here -- with frames in flight between the
         merges; with the fused kernel after the frame (a one-band session renders the whole strip in part 1 of
         enqueue_frame_part, so the transfer does NOT overlap the frame; bands >= 3 would split edge and interior)."""
-        if self.world == 1:
+        if not self.distributed:
             self.session.enqueue_frames(first, count, collect_last)
             return
         if self.peer_halos:
@@ -451,17 +468,23 @@ class StripRenderer:
         n_window = ((frames - 1) % WELFORD_WINDOW) + 1
         if n_window < 2:
             return None
-        if self.world == 1:
+        if not self.distributed:
             m2, bad = self.session.window_stats()
         else:
             import torch.distributed as dist
 
             self.backend.sync()
-            if self.peer_halos and self.session.halo_timeouts():
-                raise RuntimeError("[Render] Render error: a neighbouring strip stopped raising its frame counter (halo wait timed out)")
-            stats = self.stats.to(self._comm_device())
+            # A strip whose halo wait timed out must NOT leave the collective sequence (raising here would pair its next
+            # all-reduce -- _agree's 1 word -- with the others' 5): the count rides in the record every rank reduces, and every
+            # rank raises the same error after it.
+            timeouts = self.session.halo_timeouts() if self.peer_halos else 0
+            dev = self._comm_device()
+            stats = self.torch.cat([self.stats.to(dev), self.torch.tensor([min(int(timeouts), 0x7FFFFFFF)], dtype=self.stats.dtype, device=dev)])
             dist.all_reduce(stats, op=dist.ReduceOp.MAX)
             host = stats.cpu().numpy().astype(np.uint32)
+            if host[4] != 0:
+                raise RuntimeError("[Render] Render error: a neighbouring strip stopped raising its frame counter (halo wait timed out "
+                                   "on some rank): the window's halo rows are stale")
             m2 = float(host[:1].view(np.float32)[0])
             bad = bool(host[1])
         if bad:
@@ -471,7 +494,7 @@ class StripRenderer:
     def _agree(self, error: "Exception | None"):
         """All ranks learn whether ANY rank failed before the next collective, so that nobody is left waiting in
         it: rank-local failures (a probe, a resolve, a non-finite statistic) are re-raised everywhere."""
-        if self.world == 1:
+        if not self.distributed:
             if error is not None:
                 raise error
             return
@@ -524,7 +547,7 @@ class StripRenderer:
         are resolved straight into device tensors (f3d_session_resolve_device) and gathered device to device; the
         sun-lit-scene check of the reference (some reservoir must be valid, render_terrain.rs:1313-1337) is made
         over ALL strips."""
-        if self.world == 1:
+        if not self.distributed:
             return self.session.resolve(frames)
         import torch.distributed as dist
 

@@ -149,11 +149,32 @@ class TerrainSession:
         self._check(self._lib.f3d_session_halo_probe(self._handle, 1, 0, seen, self._err, len(self._err)))
         return int(seen[0]), int(seen[1])
 
+    def halo_probe_fill(self, nonce: int):
+        """Link check with a real block, step 1: fill this strip's two edge blocks of reservoir buffer 0 with the pattern of
+        `nonce` (a many-workgroup kernel, as the frame kernels leave their rows) and publish the nonce behind it."""
+        self._check(self._lib.f3d_session_halo_probe(self._handle, 2, int(nonce) & 0xFFFFFFFF, None, self._err, len(self._err)))
+
+    def halo_probe_pull(self, nonce_above: int, nonce_below: int):
+        """Step 2: wait (on the device) for the neighbours' nonces, pull their blocks with the frame loop's kernel and compare
+        the sums with the patterns'; raises if a block is not what its owner wrote.  Leaves reservoir buffer 0 cleared."""
+        seen = (C.c_uint32 * 2)(int(nonce_above) & 0xFFFFFFFF, int(nonce_below) & 0xFFFFFFFF)
+        self._check(self._lib.f3d_session_halo_probe(self._handle, 3, 0, seen, self._err, len(self._err)))
+        return int(seen[0]), int(seen[1])
+
     def halo_timeouts(self) -> int:
-        """Device-side halo waits that gave up (a neighbour that stopped); synchronises."""
+        """Device-side halo waits of the last enqueue_batch_strip that gave up (a neighbour that stopped); synchronises."""
         n = C.c_uint32(0)
         self._check(self._lib.f3d_session_halo_status(self._handle, C.byref(n), self._err, len(self._err)))
         return int(n.value)
+
+    def halo_stats(self, reset: bool = False) -> dict:
+        """How long this strip's pulls stood waiting for its neighbours (device time, ms) since the last reset; synchronises."""
+        rec = _native.HaloStats()
+        rec.reset = 1 if reset else 0
+        self._check(self._lib.f3d_session_halo_stats(self._handle, C.byref(rec), self._err, len(self._err)))
+        return {"frames_published": int(rec.frames_published), "timeouts": int(rec.timeouts), "pulls": int(rec.pulls),
+                "wait_ms": (float(rec.wait_ms[0]), float(rec.wait_ms[1])), "longest_wait_ms": float(rec.longest_wait_ms),
+                "timeout_ms": float(rec.timeout_ms)}
 
     def enqueue_batch_strip(self, first_frame: int, count: int, collect_stats: bool = False):
         """Frames [first_frame, first_frame + count) of a connected strip in ONE call: per frame its kernels, the frame

@@ -32,8 +32,10 @@ extern "C" {
  *   3  round 3: + struct_size first in f3d_terrain_ref_desc / f3d_session_opts / f3d_wf_scene (and in the new
  *               f3d_composite_desc, f3d_aether_ref_desc), f3d_abi_version(); f3d_wf_scene + terrain, hair, medium;
  *               new entry points: peer halos (f3d_session_halo_*, f3d_session_enqueue_batch_strip),
- *               f3d_session_set_accumulation, f3d_smoke_step, f3d_smoke_composite, f3d_aether_reference_render */
-#define F3D_ABI_VERSION 3u
+ *               f3d_session_set_accumulation, f3d_smoke_step, f3d_smoke_composite, f3d_aether_reference_render
+ *   4  round 4: + f3d_session_halo_stats / f3d_halo_stats, f3d_session_halo_probe modes 2 and 3 (no existing struct
+ *               changed: a caller built against version 3 keeps working) */
+#define F3D_ABI_VERSION 4u
 #define F3D_STATUS_OK 0
 #define F3D_STATUS_VALUE 1
 #define F3D_STATUS_RENDER 2
@@ -206,7 +208,7 @@ int f3d_session_enqueue_frame_part(f3d_session *session, uint32_t frame, uint32_
 int f3d_session_window_stats(f3d_session *session, float *max_m2, int32_t *nonfinite, char *err,
                              size_t errlen);
 /* Device pointer + byte size of the halo rows of reservoir buffer `which` (0/1):
- * side 0 = the 3 owned rows at the top (to send up), 1 = the 3 owned rows at the
+ * side 0 = the f3d_halo_rows() owned rows at the top (to send up), 1 = the owned rows at the
  * bottom (to send down), 2 = halo above the strip (to receive), 3 = halo below. */
 int f3d_session_halo(f3d_session *session, int32_t which, int32_t side, void **ptr, uint64_t *bytes);
 /* ---- peer halos: the strips of one node without the host or a collective in the frame chain --------------------
@@ -226,8 +228,29 @@ int f3d_session_halo(f3d_session *session, int32_t which, int32_t side, void **p
  *                             seen[1] = below; 0 where there is no neighbour) with the loads the pull uses.  With a barrier
  *                             of the caller's between the two, a neighbour whose word does not read back (no peer access
  *                             between the devices, a stale mapping) is found before a frame depends on it
- *   f3d_session_halo_status   device-side wait time-outs so far (a dead neighbour must not hang the GPU: a wait gives
- *                             up after ~4 s and counts here; the caller turns a non-zero count into an error) */
+ *                             Modes 2 / 3 do the same with a REAL block: mode 2 fills this strip's two edge blocks of
+ *                             reservoir buffer 0 with a pattern of `nonce` (a many-workgroup kernel, as the frame kernels
+ *                             leave their rows) and publishes the nonce behind it; mode 3 (seen[0] / seen[1] = the nonces the
+ *                             strips above / below published) waits for them on the device, pulls both blocks with the frame
+ *                             loop's own kernel and compares their sums with the pattern's: seen[side] = 1 / 0, status 4 if a
+ *                             block is not what its owner wrote.  Mode 3 leaves reservoir buffer 0 cleared; every strip must
+ *                             have finished mode 3 (a barrier of the caller's) before any strip renders
+ *   f3d_session_halo_status   device-side wait time-outs of the LAST f3d_session_enqueue_batch_strip (a dead neighbour must
+ *                             not hang the GPU: a wait gives up after F3D_HALO_TIMEOUT_MS, default 20 000, and counts here;
+ *                             a strip that has timed out stops pulling for the rest of that call -- its halo rows are stale --
+ *                             and the caller turns a non-zero count into an error on every rank)
+ *   f3d_session_halo_stats    how long this strip's pulls stood waiting for its neighbours since the last reset
+ * Frame numbers of a connected session only rise: f3d_session_enqueue_batch_strip refuses a frame it has enqueued before
+ * (the neighbours' counters are never cleared). */
+typedef struct f3d_halo_stats {
+    uint32_t reset;            /* in: 1 = clear the wait times and the pull count after reading them */
+    uint32_t frames_published; /* this strip's frame counter */
+    uint32_t timeouts, pulls;  /* waits that gave up (last call); neighbour blocks pulled */
+    double wait_ms[2];         /* total device time the pulls waited for the strip above / below */
+    double longest_wait_ms;    /* longest single wait */
+    double timeout_ms;         /* the limit in force */
+} f3d_halo_stats;
+int f3d_session_halo_stats(f3d_session *session, f3d_halo_stats *out, char *err, size_t errlen);
 typedef struct f3d_halo_export {
     uint8_t handle[3][64]; /* hipIpcMemHandle_t of reservoir buffer 0, 1 and of the counter block */
     uint64_t offset[3];    /* byte offset of the object inside the exported allocation */
