@@ -578,8 +578,13 @@ __global__ __launch_bounds__(kWave, MIN_WAVES) void k_trace(const FrameParams P)
         P.tile_cost[tile] = (uint32_t)(wall_clock64() - t_start);
 }
 
-// The ordered half of a frame (see above): one lane per pixel, 8x8 tiles.
+// The ordered half of a frame (see above): one lane per pixel, 8x8 tiles.  A pixel-frame whose sun direction was
+// mispredicted is traced again HERE, by its own lane (fix_pixel: head again -- idempotent --, the pixel's primary and sun
+// rays with the direction the real head reads, the IBL terms from the records, the tail).  Round 3 listed such pixels and
+// re-traced them 64 to a wave in a second kernel (k_fix): a launch per frame in the ordered chain (11 us of a 0.30 ms
+// strip-frame, profiles/r04_strip_rocprofv3_summary.txt) for a list that is empty in all but a handful of frames.
 __global__ __launch_bounds__(kWave) void k_merge(const FrameParams P) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kLdsWords];
     uint32_t gx = 0u, gy = 0u;
     const bool active = tile_pixel(P, gx, gy);
     float m2 = 0.0f;
@@ -594,35 +599,16 @@ __global__ __launch_bounds__(kWave) void k_merge(const FrameParams P) {
             // the prediction for the frames traced next (frame 0 says nothing: there every head is invalid by definition)
             if (P.frame_index > 0u) P.head[lp].y = h.prev_valid ? kHeadPrevValid : 0u;
         }
-        if (redo) P.fix_list[atomicAdd(&P.fix_count[P.frame_index & 1u], 1u)] = (uint32_t)lp;  // k_fix runs before the next merge
-        else m2 = merge_pixel(P, gx, gy, h, rec, pixels);
+        if (!redo) m2 = merge_pixel(P, gx, gy, h, rec, pixels);
     }
-    if (P.collect_stats != 0u) publish_window_stats(P, active && !redo, m2);
-}
-
-// The mispredicted pixel-frames of k_merge, 64 to a wave: head again (idempotent), the pixel's primary and sun rays
-// with the direction the real head reads -- the sample loop of frame_pixel, its IBL terms taken from the records --
-// and the tail.  A small fixed grid strides over the list.
-__global__ __launch_bounds__(kWave) void k_fix(const FrameParams P) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[kLdsWords];
-    LdsPending pend = make_pending(lds, P.terrain);
-    const uint32_t count = P.fix_count[P.frame_index & 1u];
-    if (blockIdx.x == 0u && threadIdx.x == 0u) {
-        P.fix_count[(P.frame_index & 1u) ^ 1u] = 0u;  // the next frame's list starts empty
-        atomicAdd(&P.fix_count[2], count);
-    }
-    const size_t pixels = (size_t)(P.row_end - P.row_begin) * P.cam.width;
-    for (uint32_t i0 = blockIdx.x * kWave; i0 < count; i0 += gridDim.x * kWave) {  // wave-uniform
-        const uint32_t i = i0 + threadIdx.x;
-        const bool active = i < count;
-        float m2 = 0.0f;
-        if (active) {
-            const uint32_t lp = P.fix_list[i];
-            const uint32_t gx = lp % P.cam.width, gy = P.row_begin + lp / P.cam.width;
-            m2 = fix_pixel(P, gx, gy, P.trace + 2u * ((size_t)(P.frame_index - P.trace_first) * P.spp * pixels + lp), pixels, pend);
+    if (__ballot(redo) != 0ull) {  // rare (3 pixel-frames in the first 18 frames of the headline scene, none later)
+        LdsPending pend = make_pending(lds, P.terrain);
+        if (redo) {
+            m2 = fix_pixel(P, gx, gy, rec, pixels, pend);
+            atomicAdd(&P.fix_count[2], 1u);  // diagnostics: f3d_session_retraced_pixels
         }
-        if (P.collect_stats != 0u) publish_window_stats(P, active, m2);
     }
+    if (P.collect_stats != 0u) publish_window_stats(P, active, m2);
 }
 
 // First prediction of "the merged reservoir is valid" for the frames traced before any merge: the centre ray hit a

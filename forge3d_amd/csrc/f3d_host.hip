@@ -1405,13 +1405,17 @@ int f3d_session_halo_probe(f3d_session *s, int32_t mode, uint32_t nonce, uint32_
                 if (got[1] != 0u || got[6 + side] != expect[side]) ok = false;
                 seen[side] = got[6 + side] == expect[side] ? 1u : 0u;
             }
-            // the probe wrote into reservoir buffer 0 (my edge rows in mode 2, my halo rows here): leave it as a new session has it
-            hip_check(hipMemsetAsync(s->res[0], 0, ((size_t)s->rows + 2u * kHaloRows) * row * sizeof(PackedReservoir), s->stream), "reservoir clear");
             hip_check(hipMemsetAsync(s->halo_flags + 1, 0, sizeof(uint32_t), s->stream), "halo time-out count");
+            hip_check(hipStreamSynchronize(s->stream), "halo probe pull");
+            if (!ok)
+                fail(F3D_STATUS_DEVICE, "peer halos: the block pulled from a neighbouring strip is not the block it wrote (sums above %08x / %08x, below %08x / %08x, %u time-outs)",
+                     got[6], expect[0], got[7], expect[1], got[1]);
+        } else if (mode == 4) {  // the probes wrote into reservoir buffer 0 (edge rows in mode 2, halo rows in mode 3): as a new session has it
+            const size_t row = (size_t)s->width;
+            hip_check(hipMemsetAsync(s->res[0], 0, ((size_t)s->rows + 2u * kHaloRows) * row * sizeof(PackedReservoir), s->stream), "reservoir clear");
             hip_check(hipStreamSynchronize(s->stream), "halo probe clear");
-            if (!ok) fail(F3D_STATUS_DEVICE, "peer halos: the block pulled from a neighbouring strip is not the block it wrote");
         } else {
-            fail(F3D_STATUS_VALUE, "halo probe: mode must be 0 (publish), 1 (read), 2 (fill + publish a block) or 3 (pull + check the blocks)");
+            fail(F3D_STATUS_VALUE, "halo probe: mode must be 0 (publish), 1 (read), 2 (fill + publish a block), 3 (pull + check the blocks) or 4 (clear)");
         }
     });
 }

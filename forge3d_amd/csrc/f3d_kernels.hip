@@ -194,8 +194,7 @@ hipError_t launch_trace_init(const FrameParams &p, hipStream_t stream) {
 }
 hipError_t launch_merge(const FrameParams &p, hipStream_t stream) {
     if (frame_grid(p) == 0u) return hipSuccess;
-    hipLaunchKernelGGL(k_merge, dim3(frame_grid(p)), dim3(kWave), 0, stream, p);
-    if (p.same_sun == 0u) hipLaunchKernelGGL(k_fix, dim3(512), dim3(kWave), 0, stream, p);  // the mispredicted pixel-frames
+    hipLaunchKernelGGL(k_merge, dim3(frame_grid(p)), dim3(kWave), 0, stream, p);  // (re-traces its mispredicted pixel-frames itself)
     return hipGetLastError();
 }
 hipError_t launch_tile_order(const FrameParams &p, const uint32_t *cost, uint32_t *order, hipStream_t stream) {

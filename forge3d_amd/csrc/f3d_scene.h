@@ -198,9 +198,9 @@ struct FrameParams {
     float4 *trace;
     uint32_t trace_first;
     uint32_t same_sun;  // the frame head's two sun directions (wi, normalize(wi)) are the same bits
-    // pixel-frames whose sun direction was mispredicted: k_merge lists them, k_fix re-traces them, 64 to a wave
-    uint32_t *fix_list;   // strip-local pixel indices
-    uint32_t *fix_count;  // [0], [1]: entries for frame parity 0 / 1; [2]: running total (diagnostics)
+    // pixel-frames whose sun direction was mispredicted: k_merge traces them again itself
+    uint32_t *fix_list;   // (unused since round 4: round 3 listed the pixels for a second kernel)
+    uint32_t *fix_count;  // [2]: running total (diagnostics)
     WfQueues wf;          // wavefront form of the trace batch (sun_o == null: k_trace traces the rays itself)
 };
 

@@ -223,11 +223,12 @@ class StripRenderer:
 
         torch = self.torch
         session, export, ok = None, b"", 1
+        self.peer_halo_failure = None  # why THIS rank could not (the other ranks only learn that somebody could not)
         try:
             session = self.backend.make_session(dem, self.width, self.height, cam, self.row_begin, self.row_end, None, self.stats, kw)
             export = session.halo_export()
-        except Exception:  # noqa: BLE001 -- the classic path reports what is wrong with the scene
-            ok = 0
+        except Exception as exc:  # noqa: BLE001 -- the classic path reports what is wrong with the scene
+            ok, self.peer_halo_failure = 0, f"export: {exc}"
         dev = self._comm_device()
         size = 512
         mine = torch.zeros(size, dtype=torch.uint8)
@@ -241,8 +242,9 @@ class StripRenderer:
                     session.halo_connect(0, bytes(parts[self.rank - 1].cpu().numpy()[:n].tobytes()))
                 if self.rank < self.world - 1:
                     session.halo_connect(1, bytes(parts[self.rank + 1].cpu().numpy()[:n].tobytes()))
-            except Exception:  # noqa: BLE001
-                ok = 0
+            except Exception as exc:  # noqa: BLE001
+                ok, self.peer_halo_failure = 0, f"connect: {exc}"
+
         def agreed(value):
             flag = torch.tensor([value], dtype=torch.int32, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -258,18 +260,18 @@ class StripRenderer:
         for salt in (0x5EED0000, 0x0BEEF000):
             try:
                 session.halo_probe_publish(salt + self.rank + 1)
-            except Exception:  # noqa: BLE001
-                ok = 0
+            except Exception as exc:  # noqa: BLE001
+                ok, self.peer_halo_failure = 0, f"probe store: {exc}"
             dist.barrier()
             if ok:
                 try:
                     above, below = session.halo_probe_read()
                     if self.rank > 0 and above != salt + self.rank:
-                        ok = 0
+                        ok, self.peer_halo_failure = 0, f"the word of the strip above reads {above:#x}, not {salt + self.rank:#x}"
                     if self.rank < self.world - 1 and below != salt + self.rank + 2:
-                        ok = 0
-                except Exception:  # noqa: BLE001
-                    ok = 0
+                        ok, self.peer_halo_failure = 0, f"the word of the strip below reads {below:#x}, not {salt + self.rank + 2:#x}"
+                except Exception as exc:  # noqa: BLE001
+                    ok, self.peer_halo_failure = 0, f"probe load: {exc}"
             if not agreed(ok):
                 session.close()
                 return None
@@ -280,12 +282,13 @@ class StripRenderer:
             try:
                 session.halo_probe_fill(salt + self.rank + 1)
                 session.halo_probe_pull(salt + self.rank, salt + self.rank + 2)
-            except Exception:  # noqa: BLE001
-                ok = 0
-            dist.barrier()  # (a strip's edge rows are cleared again by its own pull: nobody refills before everybody has pulled)
+            except Exception as exc:  # noqa: BLE001
+                ok, self.peer_halo_failure = 0, f"block probe: {exc}"
+            dist.barrier()  # nobody refills (or clears) its edge rows before every neighbour has pulled them
             if not agreed(ok):
                 session.close()
                 return None
+        session.halo_probe_clear()  # the patterns sit in reservoir buffer 0: as a new session has it
         session.halo_stats(reset=True)  # the probes' waits are not the render's
         dist.barrier()  # nobody starts rendering (and polling counters) before every neighbour is mapped
         return session

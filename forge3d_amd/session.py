@@ -156,10 +156,14 @@ class TerrainSession:
 
     def halo_probe_pull(self, nonce_above: int, nonce_below: int):
         """Step 2: wait (on the device) for the neighbours' nonces, pull their blocks with the frame loop's kernel and compare
-        the sums with the patterns'; raises if a block is not what its owner wrote.  Leaves reservoir buffer 0 cleared."""
+        the sums with the patterns'; raises if a block is not what its owner wrote."""
         seen = (C.c_uint32 * 2)(int(nonce_above) & 0xFFFFFFFF, int(nonce_below) & 0xFFFFFFFF)
         self._check(self._lib.f3d_session_halo_probe(self._handle, 3, 0, seen, self._err, len(self._err)))
         return int(seen[0]), int(seen[1])
+
+    def halo_probe_clear(self):
+        """Step 3, once EVERY strip has pulled (a barrier): reservoir buffer 0 as a new session has it."""
+        self._check(self._lib.f3d_session_halo_probe(self._handle, 4, 0, None, self._err, len(self._err)))
 
     def halo_timeouts(self) -> int:
         """Device-side halo waits of the last enqueue_batch_strip that gave up (a neighbour that stopped); synchronises."""

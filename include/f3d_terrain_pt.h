@@ -233,8 +233,9 @@ int f3d_session_halo(f3d_session *session, int32_t which, int32_t side, void **p
  *                             leave their rows) and publishes the nonce behind it; mode 3 (seen[0] / seen[1] = the nonces the
  *                             strips above / below published) waits for them on the device, pulls both blocks with the frame
  *                             loop's own kernel and compares their sums with the pattern's: seen[side] = 1 / 0, status 4 if a
- *                             block is not what its owner wrote.  Mode 3 leaves reservoir buffer 0 cleared; every strip must
- *                             have finished mode 3 (a barrier of the caller's) before any strip renders
+ *                             block is not what its owner wrote.  Mode 4 clears reservoir buffer 0 again -- only after EVERY
+ *                             strip has finished mode 3 (a barrier of the caller's: a neighbour may still be pulling this
+ *                             strip's rows), and before any strip renders (another barrier)
  *   f3d_session_halo_status   device-side wait time-outs of the LAST f3d_session_enqueue_batch_strip (a dead neighbour must
  *                             not hang the GPU: a wait gives up after F3D_HALO_TIMEOUT_MS, default 20 000, and counts here;
  *                             a strip that has timed out stops pulling for the rest of that call -- its halo rows are stale --

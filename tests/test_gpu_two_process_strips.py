@@ -43,7 +43,8 @@ def _worker(rank, world, port, out_path, in_flight=0, peer_halos=True, height=20
     image = r.gather_image(34)
     info = {"bounds": r.bounds, "balance_rounds": len(r.balance_log), "lanes": r.session.sample_lanes(),
             "in_flight": r.session.frames_in_flight(), "peer_halos": r.peer_halos,
-            "halo_timeouts": r.session.halo_timeouts() if r.peer_halos else 0, "halo": halo}
+            "halo_timeouts": r.session.halo_timeouts() if r.peer_halos else 0, "halo": halo,
+            "peer_halo_failure": getattr(r, "peer_halo_failure", None)}
     if r.peer_halos:  # frame numbers of a connected session only rise (f3d_terrain_pt.h)
         try:
             r.session.enqueue_batch_strip(0, 1)
@@ -78,7 +79,14 @@ def _run_strips(world, port, in_flight, peer_halos, height):
     import torch.multiprocessing as mp
 
     out = tempfile.mktemp(suffix=".pkl")
-    mp.spawn(_worker, args=(world, port, out, in_flight, peer_halos, height), nprocs=world, join=True)
+    try:
+        mp.spawn(_worker, args=(world, port, out, in_flight, peer_halos, height), nprocs=world, join=True)
+    except Exception:  # noqa: BLE001 -- a rendezvous port taken between probing and use (seen once in ~20 runs): once more, on a new port
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        mp.spawn(_worker, args=(world, port, out, in_flight, peer_halos, height), nprocs=world, join=True)
     with open(out, "rb") as f:
         multi = pickle.load(f)
     os.unlink(out)
@@ -98,7 +106,7 @@ def _check_against_one_strip(multi, world, in_flight, peer_halos, height):
         single = sess.resolve(34)
     assert not bad
     info = multi["info"]
-    assert info["peer_halos"] == peer_halos and info["halo_timeouts"] == 0
+    assert info["peer_halos"] == peer_halos and info["halo_timeouts"] == 0, info.get("peer_halo_failure")
     if in_flight is not None:
         assert info["in_flight"] == in_flight  # 6: batches traced in one launch, halos exchanged between the merges
     assert info["balance_rounds"] >= 2 and info["bounds"][0] == 0 and info["bounds"][-1] == height and len(info["bounds"]) == world + 1
