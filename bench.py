@@ -275,7 +275,8 @@ def main():
     if world == 1:  # a throw-away session of another DEM first: module load and allocator start-up are not set-up of THIS render
         from forge3d_amd.session import TerrainSession
 
-        warm = np.zeros((64, 64), np.float32)
+        # (large enough to go through the staged upload: the first asynchronous host-to-device copy of a process costs 7 ms)
+        warm = np.zeros((768, 768), np.float32)
         warm[::3, ::5] = 1.0
         with TerrainSession(warm, 64, 64, cam, device=local_rank, **dict(kw, max_frames=2, min_frames=2)) as ws:
             ws.enqueue_frames(0, 2)
@@ -287,6 +288,7 @@ def main():
     torch.cuda.synchronize()
     # once per render, outside the timed region: DEM upload, min-max tables, G-buffer pass, ray certificates
     setup_ms = (time.perf_counter() - t_setup) * 1e3
+    setup_phases = r.session.setup_ms() if hasattr(r.session, "setup_ms") else {}
     # warmup (untimed) ---------------------------------------------------------------
     r.run_frames(0, args.warmup)
     if r.peer_halos:
@@ -351,9 +353,15 @@ def main():
                 "kernel_variant": args.variant,
                 "frames_in_flight": r.session.frames_in_flight(),
                 "setup_ms_once_per_render": round(setup_ms, 3),
-                "setup_note": "session creation outside the timed region: DEM upload, min-max tables, G-buffer pass, ray certificates "
-                              "(primary start + sun cylinder, about 1.1 ms of kernels at 1080p), reservoir clears; at 256 spp = 32 frames "
-                              "the certificates pay back about 3 ms",
+                # f3d_session_setup_ms: host wall time of the session's creation by phase (validate = one pass over the DEM: finiteness
+                # + the scene cache's key; upload + tables are 0 for a cached DEM; alloc = per-pixel state + clears; passes = ENQUEUEING
+                # the G-buffer / certificate kernels); device_passes = until those kernels have run (G-buffer, primary-start and
+                # sun-cylinder certificates: about 1.1 ms at 1080p, paid back in about 3 frames); the rest of setup_ms_once_per_render is
+                # this script's Python around the session (balancing probes and peer-halo set-up when N > 1)
+                "setup_ms": {**{k: round(v, 3) for k, v in setup_phases.items()},
+                             "device_passes_and_python": round(setup_ms - setup_phases.get("total", 0.0), 3)},
+                "setup_note": "session creation outside the timed region, for a DEM this process has not seen: DEM fingerprint, staged upload, "
+                              "min-max tables, state allocation + clears, G-buffer pass, ray certificates",
                 **({"strip_row_bounds": r.bounds, "strip_probe_ms": r.balance_log[-1]["ms"] if r.balance_log else None,
                     "rccl_ranks": world, "rank_ms_per_step": [round(x, 4) for x in rank_ms], "halo_bytes_per_frame_rank0": halo_bytes,
                     # device time each rank's pulls stood waiting for its neighbours' frame counters, per frame (peer halos only),

@@ -136,6 +136,7 @@ ABI = [
                                       _P(C.c_int32), C.c_char_p, C.c_size_t]),
     ("f3d_session_resolve_device", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_char_p, C.c_size_t]),
+    ("f3d_session_setup_ms", C.c_int, [C.c_void_p, _P(C.c_double), C.c_uint32]),
     ("f3d_session_info", C.c_int, [C.c_void_p, _P(C.c_uint64), _P(C.c_uint64), _P(C.c_uint64), _P(C.c_uint32),
                                    _P(C.c_uint32)]),
     ("f3d_session_kernel_timing", C.c_int, [C.c_void_p, C.c_int32, _P(C.c_double), _P(C.c_uint32)]),

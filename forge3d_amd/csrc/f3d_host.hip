@@ -179,6 +179,21 @@ TerrainTables build_tables(Ledger &mem, const float *d_heights, uint32_t w, uint
 
 }  // namespace
 
+// Where session set-up spends its time (f3d_session_setup_ms; bench.py reports it beside the loop it prepares).
+enum SetupPhase { kSetupTotal = 0, kSetupValidate, kSetupHash, kSetupUpload, kSetupTables, kSetupScene, kSetupAlloc, kSetupPasses, kSetupPhases };
+struct SetupClock {
+    double *ms;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+    explicit SetupClock(double *out) : ms(out) {}
+    void lap(SetupPhase phase) {
+        const auto now = std::chrono::steady_clock::now();
+        ms[phase] += std::chrono::duration<double, std::milli>(now - last).count();
+        ms[kSetupTotal] = std::chrono::duration<double, std::milli>(now - t0).count();
+        last = now;
+    }
+};
+static thread_local double *g_setup_ms = nullptr;  // the session being created on this thread (acquire_tables laps into it)
+
 // ---------------------------------------------------------------------------------------
 // scene cache: acceleration tables of recently rendered DEMs stay on the device
 // ---------------------------------------------------------------------------------------
@@ -236,12 +251,46 @@ uint64_t hash_bytes(const void *data, size_t n, uint64_t seed) {  // 8 bytes at 
 }
 
 // Tables for this DEM on this device: from the cache, or built now (and cached when the limit allows).
+// Host -> device through the library's own pinned staging pair (two 4 MiB buffers a process, allocated on first use):
+// a pageable hipMemcpy of the 16.8 MB headline DEM took 7.3 ms the first time a process made one (the runtime sets up its
+// staging then) and the copy into pinned memory overlaps the DMA of the chunk before.
+void upload_staged(void *dst, const void *src, size_t bytes, hipStream_t stream) {
+    constexpr size_t kChunk = 4u << 20;
+    static std::mutex staging_mutex;
+    static void *staging[2] = {nullptr, nullptr};
+    static hipEvent_t drained[2] = {nullptr, nullptr};
+    std::lock_guard<std::mutex> lock(staging_mutex);
+    for (int i = 0; i < 2; i++)  // (also for a small first upload: the pair is part of a process's start-up, not of a later render)
+        if (!staging[i]) {
+            hip_check(hipHostMalloc(&staging[i], kChunk, hipHostMallocDefault), "pinned staging buffer");
+            hip_check(hipEventCreateWithFlags(&drained[i], hipEventDisableTiming), "staging event");
+        }
+    if (bytes < (256u << 10)) {  // small: one plain copy
+        hip_check(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), "upload");
+        return;
+    }
+    size_t done = 0;
+    for (int turn = 0; done < bytes; turn ^= 1) {
+        const size_t n = std::min(kChunk, bytes - done);
+        hip_check(hipEventSynchronize(drained[turn]), "staging buffer");  // (never recorded: returns at once)
+        memcpy(staging[turn], (const char *)src + done, n);
+        hip_check(hipMemcpyAsync((char *)dst + done, staging[turn], n, hipMemcpyHostToDevice, stream), "upload");
+        hip_check(hipEventRecord(drained[turn], stream), "staging event");
+        done += n;
+    }
+    hip_check(hipEventSynchronize(drained[0]), "upload");  // the staging pair is free again, the data is on its way in order
+    hip_check(hipEventSynchronize(drained[1]), "upload");
+}
+
 std::shared_ptr<CachedTables> acquire_tables(int device, const float *heights, uint32_t w, uint32_t h, float exaggeration,
-                                             hipStream_t stream, bool *was_cached) {
+                                             hipStream_t stream, bool *was_cached, const DemFingerprint *known = nullptr) {
     const uint64_t bytes = (uint64_t)w * h * sizeof(float);
-    uint64_t key = hash_bytes(heights, bytes, 0x6a09e667f3bcc908ull);
-    key = hash_bytes(&exaggeration, sizeof(float), key ^ ((uint64_t)w << 32 | h));
-    const uint64_t key2 = hash_bytes(heights, bytes, 0xbb67ae8584caa73bull) + 0x3c6ef372fe94f82bull * (uint64_t)w;
+    double none[kSetupPhases] = {};
+    SetupClock clock(g_setup_ms ? g_setup_ms : none);
+    const DemFingerprint fp = known ? *known : dem_fingerprint(heights, (size_t)w * h);
+    const uint64_t key = hash_bytes(&exaggeration, sizeof(float), fp.key ^ ((uint64_t)w << 32 | h));
+    const uint64_t key2 = fp.key2 + 0x3c6ef372fe94f82bull * (uint64_t)w;
+    clock.lap(kSetupHash);
     {
         std::lock_guard<std::mutex> lock(g_scene_mutex);
         for (auto &e : g_scene_cache)
@@ -262,11 +311,13 @@ std::shared_ptr<CachedTables> acquire_tables(int device, const float *heights, u
     e->h = h;
     e->exaggeration = exaggeration;
     float *d_heights = (float *)e->mem.alloc(bytes, "DEM upload");
-    hip_check(hipMemcpy(d_heights, heights, bytes, hipMemcpyHostToDevice), "DEM upload");
+    upload_staged(d_heights, heights, bytes, stream);  // (in stream order: the table build follows on the same stream)
+    clock.lap(kSetupUpload);
     e->tables = build_tables(e->mem, d_heights, w, h, exaggeration, stream, false);
     // the corner records hold every height (x exaggeration): the raw upload is build-time scratch
     hip_check(hipStreamSynchronize(stream), "table build");
     e->mem.free(d_heights, bytes);
+    clock.lap(kSetupTables);
     std::lock_guard<std::mutex> lock(g_scene_mutex);
     e->stamp = ++g_scene_stamp;
     if (g_scene_limit > 0) {
@@ -305,6 +356,7 @@ SharedTerrain acquire_shared_terrain(const float *heights, uint32_t w, uint32_t 
 // session
 // ---------------------------------------------------------------------------------------
 struct f3d_session {
+    double setup_ms[kSetupPhases] = {};
     Ledger mem;
     hipStream_t stream = nullptr;
     int device = 0;
@@ -478,9 +530,14 @@ void check_abi(const f3d_terrain_ref_desc *d, const f3d_session_opts *opts) {
 }
 
 void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_session_opts *opts) {
+    SetupClock clock(s.setup_ms);
     check_abi(&d, opts);
     validate_desc(d);
-    validate_scene(d);
+    // every DEM sample is looked at ONCE: finiteness (validate_scene) and the scene cache's key come out of one pass
+    DemFingerprint fp;
+    const bool fp_known = d.heights && d.dem_width >= 2 && d.dem_height >= 2 && d.dem_width <= 8193 && d.dem_height <= 8193;
+    if (fp_known) fp = dem_fingerprint(d.heights, (size_t)d.dem_width * d.dem_height);
+    validate_scene(d, fp_known ? (fp.finite ? 1 : 0) : -1);
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -501,10 +558,19 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
 
     FrameParams &P = s.params;
     s.require_valid_reservoirs = fill_uniforms(d, P);  // curvature, camera, lighting
+    clock.lap(kSetupValidate);
 
     // DEM upload + GPU table build (reference: CPU build + per-level write_texture), or the cached tables of this DEM
     bool was_cached = false;
-    s.scene = acquire_tables(s.device, d.heights, d.dem_width, d.dem_height, d.exaggeration, s.stream, &was_cached);
+    g_setup_ms = s.setup_ms;
+    try {
+        s.scene = acquire_tables(s.device, d.heights, d.dem_width, d.dem_height, d.exaggeration, s.stream, &was_cached, &fp);
+    } catch (...) {
+        g_setup_ms = nullptr;
+        throw;
+    }
+    g_setup_ms = nullptr;
+    clock.last = std::chrono::steady_clock::now();  // (acquire_tables lapped its own phases)
     s.tables = s.scene->tables;
     s.mem.device_bytes += s.scene->mem.device_bytes;  // shared, but part of this render's working set
     apply_layout(s.tables.layout, P.terrain);
@@ -601,6 +667,7 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
         }
     }
     if (d.atmosphere) upload_aether(s, *d.atmosphere, d);
+    clock.lap(kSetupScene);
     P.row_begin = s.row_begin;
     P.row_end = s.row_end;
     P.band_begin = s.row_begin;
@@ -760,6 +827,7 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
     s.mem.note_host_visible(4 * sizeof(uint32_t));
     P.gbuffer_n = s.gbuffer_n;
     P.stats = s.stats;
+    clock.lap(kSetupAlloc);
 
     // memory-budget gate, render_terrain.rs:875-888
     if (s.mem.device_bytes > s.budget)
@@ -791,6 +859,7 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
         P.band_end = s.row_end;
         hip_check(launch_trace_init(P, s.stream), "trace prediction init");
     }
+    clock.lap(kSetupPasses);
 }
 
 // One band of one frame: frame head (sample-lane form) + frame kernel over the band's rows, on the band's
@@ -1533,6 +1602,12 @@ int f3d_session_resolve(f3d_session *s, uint32_t frames, uint8_t *rgba, float *a
             fail(F3D_STATUS_RENDER, "terrain PT reservoir bookkeeping produced non-finite values");
         if (any_valid_reservoir) *any_valid_reservoir = s->host_stats[2] != 0u;
     });
+}
+
+int f3d_session_setup_ms(f3d_session *s, double *out, uint32_t count) {
+    if (!s || !out) return F3D_STATUS_VALUE;
+    for (uint32_t i = 0; i < count; i++) out[i] = i < (uint32_t)kSetupPhases ? s->setup_ms[i] : 0.0;
+    return F3D_STATUS_OK;
 }
 
 int f3d_session_info(f3d_session *s, uint64_t *gpu_resource_bytes, uint64_t *minmax_pyramid_bytes,

@@ -234,6 +234,13 @@ class TerrainSession:
         return {"gpu_resource_bytes": int(g.value), "minmax_pyramid_bytes": int(p.value),
                 "peak_host_visible_bytes": int(h.value), "rows": int(rows.value), "width": int(width.value)}
 
+    def setup_ms(self) -> dict:
+        """Host wall time of the session's creation by phase (ms): what a render pays once before its first frame."""
+        out = (C.c_double * 8)()
+        self._lib.f3d_session_setup_ms(self._handle, out, 8)
+        keys = ("total", "validate", "hash", "upload", "tables", "scene", "alloc", "passes")
+        return {k: float(out[i]) for i, k in enumerate(keys)}
+
     def sample_lanes(self) -> int:
         """Sample lanes per pixel of the frame kernel (1, 2, 4 or 8; chosen from the strip size and spp)."""
         return int(self._lib.f3d_session_sample_lanes(self._handle))

@@ -283,6 +283,12 @@ int f3d_session_set_accumulation(f3d_session *session, const float *sums_rgba, c
 /* Same, but leaves the results in caller-owned DEVICE buffers (for an RCCL gather). */
 int f3d_session_resolve_device(f3d_session *session, uint32_t frames, void *d_rgba, void *d_albedo,
                                void *d_normal, void *d_depth, char *err, size_t errlen);
+/* Host wall time of f3d_session_create by phase, ms: out[0] total, [1] validation + uniforms, [2] hashing the DEM (scene
+ * cache key), [3] DEM upload, [4] acceleration-table build (synchronised), [5] mesh / environment / atmosphere uploads and
+ * the mesh BVH, [6] allocation + clears of the per-pixel state, [7] enqueueing the G-buffer and certificate passes (their
+ * device time is NOT in it: the call returns with them in flight).  [3] and [4] are 0 for a DEM the scene cache holds. */
+#define F3D_SETUP_PHASES 8
+int f3d_session_setup_ms(f3d_session *session, double *out, uint32_t count);
 /* Memory / layout diagnostics of a session. */
 int f3d_session_info(f3d_session *session, uint64_t *gpu_resource_bytes, uint64_t *minmax_pyramid_bytes,
                      uint64_t *peak_host_visible_bytes, uint32_t *rows, uint32_t *width);

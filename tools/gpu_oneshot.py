@@ -12,7 +12,7 @@ from forge3d_amd import _native, datasets  # noqa: E402
 dem, cam, kw = datasets.rainier_proxy_scene(2048)
 k = dict(kw, spp=8, max_frames=32, min_frames=32, variance_threshold=1e30)
 orig = _native.lib().f3d_terrain_ref_render
-for attempt in range(2):
+for attempt in range(4):
     t0 = time.perf_counter()
     try:
         out = f3d.hybrid_render_terrain_reference(dem, 1920, 1080, cam, **k)
