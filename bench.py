@@ -57,6 +57,8 @@ def parse_args():
     ap.add_argument("--extra-windows", type=int, default=4, help="further timed windows of --steps frames (spread report)")
     ap.add_argument("--no-terrain-filling", action="store_true", help="skip the second, terrain-filling camera")
     ap.add_argument("--no-configs", action="store_true", help="skip the short timed windows of BASELINE.json's other configurations")
+    ap.add_argument("--dem-path", default=None, help="a real DEM (GeoTIFF / .npy) for an ADDITIONAL labelled run of the headline configuration; "
+                                                     "default: $FORGE3D_REPO_ROOT/assets/tif/dem_rainier.tif when that exists (BASELINE.md section 3)")
     return ap.parse_args()
 
 
@@ -444,6 +446,35 @@ def main():
             "shaded_msamples_per_s": rate2 * hit2, "grays_per_s": rate2 * 1e6 * (1.0 + 2.0 * hit2) / 1e9,
             "camera": {k: [float(x) for x in v] if isinstance(v, tuple) else v for k, v in cam2.items()},
         }
+    if rank == 0 and world == 1:
+        # "if a real dem_rainier.tif is supplied via FORGE3D_REPO_ROOT, S2 is run on it as well and
+        # labelled" (reference python/forge3d/datasets.py:53-61, :312 fetch_dem('rainier')).  The headline stays the proxy.
+        real_path = args.dem_path
+        if real_path is None:
+            try:
+                real_path = str(datasets.fetch_dem("rainier"))
+            except (FileNotFoundError, KeyError):
+                real_path = None
+        if real_path:
+            try:
+                rdem, rcam, rkw, what = datasets.real_dem_scene(real_path)
+                frames_r = args.warmup + args.steps
+                rr = StripRenderer(rdem, args.width, args.height, rcam, rank=0, world=1, device=local_rank, kernel_variant=args.variant, memory_budget_bytes=16 << 30,
+                                   **dict(rkw, spp=args.spp, variance_threshold=1e30, max_frames=frames_r, min_frames=frames_r))
+                rr.run_frames(0, args.warmup)
+                torch.cuda.synchronize()
+                t3 = time.perf_counter()
+                rr.run_frames(args.warmup, args.steps)
+                torch.cuda.synchronize()
+                dt3 = time.perf_counter() - t3
+                img3 = rr.gather_image(frames_r)
+                rr.close()
+                result["config_real_dem"] = {"value": args.width * args.height * args.spp * args.steps / dt3 / 1e6, "unit": "Msamples/s",
+                                             "ms_per_step": dt3 / args.steps * 1e3, "steps": args.steps, "data": "real: " + what,
+                                             "hit_fraction": float(np.isfinite(img3["depth"]).mean()),
+                                             "image_mean_rgb": [float(x) for x in img3["rgba"][..., :3].mean((0, 1))]}
+            except Exception as exc:  # noqa: BLE001 -- an unreadable file must not cost the headline
+                result["config_real_dem"] = {"error": str(exc)[:300], "data": f"real DEM {real_path}"}
     if rank == 0 and world == 1 and not args.no_configs:
         result["configs"] = other_configs(dem, cam, kw, args, local_rank)
     if rank == 0:

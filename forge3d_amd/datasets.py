@@ -118,3 +118,63 @@ def proxy_buildings(dem: np.ndarray, spacing: float, n_boxes: int = 50_000, seed
     local = np.array([t for a, b, c, d in quads for t in ((a, b, c), (a, c, d))], np.uint32)
     idx = (local[None, :, :] + (8 * np.arange(n_boxes, dtype=np.uint32))[:, None, None]).reshape(-1, 3)
     return verts.reshape(-1, 3).astype(np.float32), idx.astype(np.uint32)
+
+
+# ---- real DEMs, when somebody supplies them ---------------------------------------------------------------------------
+# The reference's sample DEMs are git-LFS / remote objects (python/forge3d/datasets.py:53-61: `rainier` ->
+# assets/tif/dem_rainier.tif, sha256 875b2434...); this package never downloads.  fetch_dem looks where the reference's
+# _local_dataset_path looks -- $FORGE3D_REPO_ROOT/assets/tif/ -- and says so when the file is not there.
+_LOCAL_DEMS = {"rainier": "assets/tif/dem_rainier.tif", "fuji": "assets/tif/Mount_Fuji_30m.tif"}
+
+
+def fetch_dem(name: str, cache_dir=None, base_url=None):
+    """Path of a sample DEM of the reference (python/forge3d/datasets.py:312 fetch_dem): only from a local checkout
+    ($FORGE3D_REPO_ROOT) -- there is no download here."""
+    import os
+    from pathlib import Path
+
+    if name not in _LOCAL_DEMS:
+        raise KeyError(f"Unknown dataset '{name}'. Available datasets: {', '.join(sorted(_LOCAL_DEMS))}")
+    roots = [os.environ.get("FORGE3D_REPO_ROOT"), cache_dir]
+    for root in roots:
+        if root and (Path(root) / _LOCAL_DEMS[name]).is_file():
+            return Path(root) / _LOCAL_DEMS[name]
+        if root and (Path(root) / Path(_LOCAL_DEMS[name]).name).is_file():
+            return Path(root) / Path(_LOCAL_DEMS[name]).name
+    raise FileNotFoundError(f"{_LOCAL_DEMS[name]} not found under $FORGE3D_REPO_ROOT (forge3d_amd does not download: the reference's "
+                            "sample DEMs are git-LFS objects; point FORGE3D_REPO_ROOT at a checkout that has them)")
+
+
+def real_dem_scene(path, max_side: int = 8193):
+    """BASELINE.json config 2 on a REAL DEM file (GeoTIFF or .npy, forge3d_amd.io.load_heightmap): the same orbit camera
+    (phi 28, theta 49, radius 1.25 x span, fov 42), sun and material as rainier_proxy_scene.  Heights are shifted to start
+    at 0; the cell spacing is the GeoTIFF's pixel scale when that is in metres (> 0.01 -- a geographic raster's degrees are
+    turned into metres at the raster's latitude), else 10 m.  Returns (dem, camera, kwargs, description)."""
+    from . import io
+
+    p = str(path)
+    dem = io.load_heightmap(p)
+    spacing_x = spacing_z = 10.0
+    if p.lower().endswith((".tif", ".tiff")):
+        _, info = io.read_geotiff(p)
+        scale, tie = info.get("pixel_scale"), info.get("tiepoint")
+        if scale and scale[0] > 0.0 and scale[1] > 0.0:
+            if scale[0] > 0.01:
+                spacing_x, spacing_z = float(scale[0]), float(scale[1])
+            else:  # degrees: metres per degree at the raster's latitude
+                lat = float(tie[4]) if tie else 0.0
+                spacing_x = float(scale[0]) * 111_320.0 * max(0.1, math.cos(math.radians(lat)))
+                spacing_z = float(scale[1]) * 110_574.0
+    step = 1
+    while max(dem.shape) // step > max_side:  # the reference's node packing holds 8192 cells a side
+        step += 1
+    if step > 1:
+        dem = np.ascontiguousarray(dem[::step, ::step])
+        spacing_x, spacing_z = spacing_x * step, spacing_z * step
+    dem = np.ascontiguousarray(dem - dem.min(), np.float32)
+    span = max((dem.shape[1] - 1) * spacing_x, (dem.shape[0] - 1) * spacing_z)
+    cam = orbit_camera((0.0, 0.5 * float(dem.max()), 0.0), 1.25 * span, 28.0, 49.0, 42.0)
+    kw = dict(spacing=(spacing_x, spacing_z), exaggeration=1.0, albedo=(0.6, 0.6, 0.6), sun_azimuth_deg=302.0,
+              sun_elevation_deg=24.0, sun_intensity=2.5, env_intensity=0.35, seed=7)
+    what = f"real DEM {p} ({dem.shape[1]}x{dem.shape[0]}, spacing {spacing_x:.2f} x {spacing_z:.2f} m, relief {float(dem.max()):.0f} m)"
+    return dem, cam, kw, what

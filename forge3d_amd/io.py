@@ -340,17 +340,25 @@ def read_hdr(path) -> np.ndarray:
     parts = resolution.split()
     if len(parts) != 4:
         raise HdrError(f"Invalid HDR resolution line: {resolution}")
-    try:
-        height = int(parts[1])
-    except ValueError:
-        raise HdrError(f"Invalid HDR height: {parts[1]}") from None
-    try:
-        width = int(parts[3])
-    except ValueError:
-        raise HdrError(f"Invalid HDR width: {parts[3]}") from None
+    # the reference parses both as u32 (str::parse: decimal digits only -- int() would also take "+5" and "1_0")
+    if not parts[1].isascii() or not parts[1].isdigit() or len(parts[1]) > 10 or int(parts[1]) > 0xFFFFFFFF:
+        raise HdrError(f"Invalid HDR height: {parts[1]}")
+    if not parts[3].isascii() or not parts[3].isdigit() or len(parts[3]) > 10 or int(parts[3]) > 0xFFFFFFFF:
+        raise HdrError(f"Invalid HDR width: {parts[3]}")
+    height, width = int(parts[1]), int(parts[3])
     if width <= 0 or height <= 0:
         raise HdrError("HDR image dimensions cannot be zero")
-    rgbe = _hdr_rows(memoryview(data), end, width, height)
+    # a scanline is at least 4 bytes in either form: a header that promises more rows than the file can hold is refused
+    # BEFORE (height, width, 4) bytes are allocated for it (a 30-byte file could ask for gigabytes)
+    remaining = len(data) - end
+    # (run-length rows hold at most 127 pixels per 2 bytes and component: < 16 pixels per byte)
+    # (only where the allocation would matter: small pictures fail row by row, in the reference's order and words)
+    if width * height * 4 > (64 << 20) and (height > remaining // 4 or width * height > 64 * max(remaining, 1)):
+        raise HdrError(f"Failed to read scanline header at row {min(height, remaining // 4)}: file ends")
+    try:
+        rgbe = _hdr_rows(memoryview(data), end, width, height)
+    except (MemoryError, OverflowError):
+        raise HdrError(f"HDR image of {width} x {height} pixels does not fit in memory") from None
     scale = np.ldexp(np.float32(1.0), rgbe[..., 3].astype(np.int32) - 136).astype(np.float32)
     scale[rgbe[..., 3] == 0] = 0.0
     return rgbe[..., :3].astype(np.float32) * scale[..., None]

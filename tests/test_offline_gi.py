@@ -87,3 +87,26 @@ def test_render_terrain_gi_equals_the_composition_of_the_oracles(turbidity, size
     for key in ("rgba", "albedo", "normal", "depth"):
         assert np.array_equal(got[key], want[key], equal_nan=True), key
     assert got["frames"] == spp and got["path_vertices"] > w * h * spp
+
+
+@pytest.mark.gpu
+def test_config3_gi_at_full_size_equals_the_composition_of_the_oracles():
+    """BASELINE.json configs[2] exactly as bench.py times it (`configs.C3_gi`) -- the 2048^2 rainier-proxy DEM as the
+    heightfield primitive of the PBR path tracer at 1920 x 1080, the AETHER post at turbidity 2 on its radiance -- 4 paths a
+    pixel against the composition of the two CPU oracles (seconds on the GPU box's host cores), every pixel of every output.
+    (Round 3 checked the GI leg at <= 160 x 96 only; the 1080p render existed as a bench number compared with nothing.)"""
+    from forge3d_amd import datasets, offline
+
+    dem, cam, kw = datasets.rainier_proxy_scene(2048)
+    geo = dict(spacing=kw["spacing"], exaggeration=kw["exaggeration"], albedo=kw.get("albedo", (0.6, 0.6, 0.6)),
+               sun_azimuth_deg=kw["sun_azimuth_deg"], sun_elevation_deg=kw["sun_elevation_deg"], sun_intensity=kw["sun_intensity"])
+    handle = atm.AtmosphereLutHandle.load_shipped(atm.AtmosphereConfig(turbidity=2.0), bank_dir=BANK)
+    w, h, spp = 1920, 1080, 4
+    got = offline.render_terrain_gi(dem, w, h, cam, spp=spp, atmosphere=handle, memory_budget_bytes=8 << 30, **geo)
+    gi, want = _oracle_composition(dem, w, h, cam, geo, handle, spp)
+    hit = np.isfinite(want["depth"])
+    assert 0.3 < hit.mean() < 0.5  # the benched camera: ~40 % terrain, the rest sky
+    assert got["path_vertices"] > w * h * spp * 1.2  # multi-bounce: more than one vertex a path on the terrain pixels
+    assert np.array_equal(got["hdr"], gi["hdr"])
+    for key in ("rgba", "albedo", "normal", "depth"):
+        assert np.array_equal(got[key], want[key], equal_nan=True), key
