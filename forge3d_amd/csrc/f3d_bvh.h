@@ -330,4 +330,92 @@ inline MeshBvh build_mesh_bvh(const float *verts, uint32_t vertex_count, const u
     return b.out;
 }
 
+// ---- the same tree, four children wide ------------------------------------------------------------------------------
+// The threaded binary walk visits a node per box test and every visit is a dependent, scattered 32-byte load: measured on
+// the 600 000-triangle stand-in of BASELINE.json configs[3], 45 loop iterations per walk at ~1 300 cycles each, ~150 of
+// them the wave's own instructions.  Collapsing the binary tree -- a node adopts its grandchildren,
+// largest box first, until it has four children -- puts four box tests behind ONE 128-byte load and cuts the chain of
+// dependent loads to the number of ENTERED nodes.  Leaves keep their triangles (the binary tree's leaf order).
+// Returns an empty vector when the tree is deeper than the walk's per-level stack (kBvh4MaxLevels).
+inline std::vector<Bvh4Node> collapse_bvh4(const MeshBvh &bvh) {
+    std::vector<Bvh4Node> out;
+    if (bvh.nodes.empty()) return out;
+    const auto area = [&](uint32_t n) {
+        const BvhNode &b = bvh.nodes[n];
+        const float dx = b.bmax[0] - b.bmin[0], dy = b.bmax[1] - b.bmin[1], dz = b.bmax[2] - b.bmin[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    struct Item {
+        uint32_t binary, wide, level;  // binary inner node -> record `wide` at `level`
+    };
+    std::vector<Item> todo;
+    out.emplace_back();
+    bool too_deep = false;
+    const auto fill = [&](Bvh4Node &n, uint32_t slot, uint32_t b) {
+        const BvhNode &s = bvh.nodes[b];
+        n.lo_x[slot] = s.bmin[0];
+        n.hi_x[slot] = s.bmax[0];
+        n.lo_y[slot] = s.bmin[1];
+        n.hi_y[slot] = s.bmax[1];
+        n.lo_z[slot] = s.bmin[2];
+        n.hi_z[slot] = s.bmax[2];
+        n.leaf[slot] = s.leaf;
+    };
+    const auto clear = [&](Bvh4Node &n) {
+        for (uint32_t s = 0; s < 4u; s++) {
+            n.lo_x[s] = n.lo_y[s] = n.lo_z[s] = INFINITY;
+            n.hi_x[s] = n.hi_y[s] = n.hi_z[s] = -INFINITY;
+            n.leaf[s] = 0u;
+        }
+        n.first_child = n.inner = n.pad0 = n.pad1 = 0u;
+    };
+    clear(out[0]);
+    if (bvh.nodes[0].leaf != 0u) {  // a mesh of one leaf: a root whose only child is that leaf
+        fill(out[0], 0u, 0u);
+        return out;
+    }
+    todo.push_back(Item{0u, 0u, 0u});
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        // the children of binary node i: i + 1 and the node after i + 1's subtree
+        uint32_t kids[4] = {it.binary + 1u, bvh.nodes[it.binary + 1u].skip, 0u, 0u};
+        uint32_t n = 2u;
+        while (n < 4u) {  // adopt the grandchildren of the inner child with the largest box
+            int pick = -1;
+            float best = -1.0f;
+            for (uint32_t k = 0; k < n; k++)
+                if (bvh.nodes[kids[k]].leaf == 0u && area(kids[k]) > best) {
+                    best = area(kids[k]);
+                    pick = (int)k;
+                }
+            if (pick < 0) break;
+            const uint32_t b = kids[pick];
+            kids[pick] = b + 1u;
+            kids[n++] = bvh.nodes[b + 1u].skip;
+        }
+        // inner children first: they become consecutive records
+        uint32_t order[4], inner = 0u, m = 0u;
+        for (uint32_t k = 0; k < n; k++)
+            if (bvh.nodes[kids[k]].leaf == 0u) order[m++] = kids[k];
+        inner = m;
+        for (uint32_t k = 0; k < n; k++)
+            if (bvh.nodes[kids[k]].leaf != 0u) order[m++] = kids[k];
+        const uint32_t first_child = (uint32_t)out.size();
+        if (inner != 0u && it.level > kBvh4MaxLevels - 1u) too_deep = true;  // (no row left to record the siblings it descends past)
+        for (uint32_t k = 0; k < inner; k++) {
+            out.emplace_back();
+            clear(out.back());
+        }
+        Bvh4Node &rec = out[it.wide];
+        for (uint32_t k = 0; k < n; k++) fill(rec, k, order[k]);
+        for (uint32_t k = 0; k < inner; k++) rec.leaf[k] = 0u;
+        rec.first_child = first_child;
+        rec.inner = inner;
+        for (uint32_t k = 0; k < inner; k++) todo.push_back(Item{order[k], first_child + k, it.level + 1u});
+    }
+    if (too_deep || out.size() >= (1u << 27)) out.clear();  // (the stack word holds first_child in 28 bits)
+    return out;
+}
+
 }  // namespace f3d

@@ -637,7 +637,7 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
         uint32_t builder = opts ? opts->mesh_builder : 0u;
         if (builder == 0u) {
             const char *env = getenv("F3D_MESH_BVH");
-            builder = (env && strcmp(env, "lbvh") == 0) ? 2u : 1u;
+            builder = (env && strcmp(env, "lbvh") == 0) ? 2u : ((env && strcmp(env, "binary") == 0) ? 3u : 1u);
         }
         if (builder == 2u) {
             LbvhResult lb;
@@ -649,21 +649,30 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
                 P.mesh.bvh_tris = lb.tris;
                 P.mesh.bvh_node_count = lb.node_count;
             }
-        } else if (builder == 1u) {
+        } else if (builder == 1u || builder == 3u) {
             const MeshBvh bvh = build_mesh_bvh(d.mesh_vertices, d.mesh_vertex_count, d.mesh_indices, d.mesh_index_count);
             if (!bvh.nodes.empty()) {
-                BvhNode *dn = (BvhNode *)s.mem.alloc(bvh.nodes.size() * sizeof(BvhNode), "mesh BVH nodes");
+                // the walk's form: four children wide (one 128-byte record per ENTERED node, f3d_shade.h mesh_bvh4) unless the
+                // tree is too deep for the walk's per-level words or the binary form is asked for (3: A/B, the round-3 walk)
+                std::vector<Bvh4Node> wide;
+                if (builder == 1u) wide = collapse_bvh4(bvh);
                 float4 *dt = (float4 *)s.mem.alloc(bvh.tris.size() * sizeof(float), "mesh BVH triangles");
-                hip_check(hipMemcpy(dn, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice),
-                          "BVH upload");
-                hip_check(hipMemcpy(dt, bvh.tris.data(), bvh.tris.size() * sizeof(float), hipMemcpyHostToDevice),
-                          "BVH upload");
-                P.mesh.bvh_nodes = dn;
+                hip_check(hipMemcpy(dt, bvh.tris.data(), bvh.tris.size() * sizeof(float), hipMemcpyHostToDevice), "BVH upload");
                 P.mesh.bvh_tris = dt;
-                P.mesh.bvh_node_count = (uint32_t)bvh.nodes.size();
+                if (!wide.empty()) {
+                    Bvh4Node *dw = (Bvh4Node *)s.mem.alloc(wide.size() * sizeof(Bvh4Node), "mesh BVH nodes (4-wide)");
+                    hip_check(hipMemcpy(dw, wide.data(), wide.size() * sizeof(Bvh4Node), hipMemcpyHostToDevice), "BVH upload");
+                    P.mesh.bvh4_nodes = dw;
+                    P.mesh.bvh4_node_count = (uint32_t)wide.size();
+                } else {
+                    BvhNode *dn = (BvhNode *)s.mem.alloc(bvh.nodes.size() * sizeof(BvhNode), "mesh BVH nodes");
+                    hip_check(hipMemcpy(dn, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice), "BVH upload");
+                    P.mesh.bvh_nodes = dn;
+                    P.mesh.bvh_node_count = (uint32_t)bvh.nodes.size();
+                }
             }
         } else {
-            fail(F3D_STATUS_VALUE, "mesh_builder must be 0 (automatic), 1 (host SAH) or 2 (GPU LBVH), got %u", builder);
+            fail(F3D_STATUS_VALUE, "mesh_builder must be 0 (automatic), 1 (host SAH, walked 4 wide), 2 (GPU LBVH) or 3 (host SAH, binary walk), got %u", builder);
         }
     }
     if (d.atmosphere) upload_aether(s, *d.atmosphere, d);
@@ -1688,7 +1697,8 @@ int f3d_session_fingerprint(f3d_session *s, uint64_t *out, uint32_t count) {
         out[6] = dev(P.terrain.bands, L.band_count * sizeof(NodeRec));
         out[7] = dev(P.mesh.vertices, (size_t)P.mesh.vertex_count * sizeof(float4));
         out[8] = dev(P.mesh.indices, (size_t)P.mesh.index_count * sizeof(uint32_t));
-        out[9] = dev(P.mesh.bvh_nodes, (size_t)P.mesh.bvh_node_count * sizeof(BvhNode));
+        out[9] = P.mesh.bvh4_nodes ? dev(P.mesh.bvh4_nodes, (size_t)P.mesh.bvh4_node_count * sizeof(Bvh4Node))
+                                   : dev(P.mesh.bvh_nodes, (size_t)P.mesh.bvh_node_count * sizeof(BvhNode));
         out[10] = dev(P.mesh.bvh_tris, (size_t)P.mesh.index_count * sizeof(float4));
         out[11] = dev(P.env.texels, (size_t)P.env.width * P.env.height * sizeof(float4));
         out[12] = dev(s->gbuffer_n, px * sizeof(float4));

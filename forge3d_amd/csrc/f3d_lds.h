@@ -39,6 +39,11 @@ struct LdsPending {
     uint32_t leaf_quorum, share_below;
     __device__ __forceinline__ void put(uint32_t level, uint32_t word) { col[level * kWave] = word; }
     __device__ __forceinline__ uint32_t get(uint32_t level) const { return col[level * kWave]; }
+    // per-level words of the 4-wide mesh walk (f3d_shade.h mesh_bvh4): the rows of the leaf FIFO, which is empty while a
+    // mesh is walked (closest_hit walks the mesh before the terrain; occluded() after the terrain march has drained)
+    static_assert(kFifoWords * kLeafFifoRows >= kBvh4MaxLevels || !kMesh, "the 4-wide mesh walk keeps a word per level in the leaf FIFO's rows");
+    __device__ __forceinline__ void stack_put(uint32_t level, uint32_t word) { col[level * kWave] = word; }
+    __device__ __forceinline__ uint32_t stack_get(uint32_t level) const { return col[level * kWave]; }
     __device__ __forceinline__ void note(int) const {}  // step-statistics hook (host emulator only)
     __device__ __forceinline__ void feature(float) const {}
     __device__ __forceinline__ void hint(float) const {}

@@ -87,6 +87,20 @@ struct BvhNode {
 };
 static_assert(sizeof(BvhNode) == 32, "BvhNode is two dwordx4 loads");
 
+// 4-wide BVH node (f3d_bvh.h collapse_bvh4, f3d_shade.h mesh_bvh4): the CHILDREN's boxes live in the parent, one 128-byte
+// record = one cache line per visited node.  Slots [0, inner) are inner children -- the records first_child + slot --,
+// slots [inner, 4) leaves ((first triangle << 3) | count in `leaf[slot]`) or empty (box (+inf, -inf), leaf 0).
+struct alignas(128) Bvh4Node {
+    float lo_x[4], hi_x[4], lo_y[4], hi_y[4], lo_z[4], hi_z[4];
+    uint32_t leaf[4];
+    uint32_t first_child, inner, pad0, pad1;
+};
+static_assert(sizeof(Bvh4Node) == 128, "Bvh4Node is eight dwordx4 loads, one cache line");
+// Levels of the 4-wide tree whose nodes may have unvisited siblings waiting: the walk keeps one word per level in the
+// lane's LDS column, in the rows of the terrain march's leaf FIFO (empty while a mesh is walked).  Deeper trees are walked
+// in the threaded binary form.
+constexpr uint32_t kBvh4MaxLevels = 15;
+
 struct MeshDev {  // HybridUniforms mesh part, hybrid_traversal.wgsl:9-17
     const float4 *vertices;  // xyz + pad (reference MeshVertex)
     const uint32_t *indices;
@@ -96,6 +110,8 @@ struct MeshDev {  // HybridUniforms mesh part, hybrid_traversal.wgsl:9-17
     const BvhNode *bvh_nodes;
     const float4 *bvh_tris;  // 3 float4 per triangle in leaf order; v0.w = original triangle index (bits)
     uint32_t bvh_node_count;
+    const Bvh4Node *bvh4_nodes;  // the same tree four children wide (null: walk the binary form); shares bvh_tris
+    uint32_t bvh4_node_count;
 };
 
 struct EnvDev {  // equirect environment, hybrid_terrain_traversal.wgsl:392-405

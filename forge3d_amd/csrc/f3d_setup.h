@@ -387,6 +387,8 @@ inline bool fill_uniforms(const f3d_terrain_ref_desc &d, FrameParams &P) {
     P.mesh.index_count = 0;
     P.mesh.bvh_nodes = nullptr;
     P.mesh.bvh_tris = nullptr;
+    P.mesh.bvh4_nodes = nullptr;
+    P.mesh.bvh4_node_count = 0u;
     P.mesh.bvh_node_count = 0;
 
     const float kDegF = 0.017453292519943295f;

@@ -153,9 +153,107 @@ F3D_HD bool mesh_bvh(const MeshDev &M, V3 o, float tmin, V3 d, float tmax, float
     return any;
 }
 
-F3D_HD bool mesh_closest(const MeshDev &M, V3 o, float tmin, V3 d, float tmax, float &t_best, V3 &n_best) {
+// The same answer through the 4-wide form of the tree (f3d_bvh.h collapse_bvh4, f3d_scene.h Bvh4Node): a visited node
+// tests its four CHILDREN's boxes from one 128-byte record, so the chain of dependent loads is as long as the number of
+// nodes a ray enters, not the number of boxes it tests (round 4; the binary walk above measured ~45 dependent loads a ray
+// on the 600 000-triangle stand-in, each ~1 300 cycles of a wave's time).  Children wait their turn in one word per LEVEL
+// -- (first_child << 4) | mask of the inner slots still to visit -- in the lane's column (Stack::stack_put / stack_get:
+// LDS rows on the device), and `open` says which levels hold one; no other stack.  The order of visits is fixed (slot
+// order) and immaterial: the answer is the sweep's "smallest t, lowest index among equal t", or existence (ANY).
+template <bool ANY, class Stack>
+F3D_HD bool mesh_bvh4(const MeshDev &M, V3 o, float tmin, V3 d, float tmax, float &t_best, V3 &n_best, Stack &stk) {
+    const float ix = (d.x < 0.0f ? -1.0f : 1.0f) / f_max(f_abs(d.x), 1e-12f);
+    const float iy = (d.y < 0.0f ? -1.0f : 1.0f) / f_max(f_abs(d.y), 1e-12f);
+    const float iz = (d.z < 0.0f ? -1.0f : 1.0f) / f_max(f_abs(d.z), 1e-12f);
+    const float oix = o.x * ix, oiy = o.y * iy, oiz = o.z * iz;  // plane * (1/d) - o * (1/d): see mesh_bvh
+    uint32_t best_tri = 0xFFFFFFFFu;
+    t_best = tmax;
+    const float4 *nodes = reinterpret_cast<const float4 *>(M.bvh4_nodes);
+    constexpr uint32_t kDone = 0xFFFFFFFFu;
+    uint32_t node = 0u, level = 0u, open = 0u;
+    while (node != kDone) {
+        const float4 *rec = nodes + 8u * node;
+        const float4 lox = rec[0], hix = rec[1], loy = rec[2], hiy = rec[3], loz = rec[4], hiz = rec[5];
+        const float4 leaf = rec[6], meta = rec[7];
+        F3D_MESH_STAT(0);
+        uint32_t hit = 0u;
+#define F3D_BVH4_SLOT(S, C)                                                                                       \
+        {                                                                                                         \
+            const float ax = f_fma(lox.C, ix, -oix), bx = f_fma(hix.C, ix, -oix);                                 \
+            const float ay = f_fma(loy.C, iy, -oiy), by = f_fma(hiy.C, iy, -oiy);                                 \
+            const float az = f_fma(loz.C, iz, -oiz), bz = f_fma(hiz.C, iz, -oiz);                                 \
+            const float enter = f_max(f_max(f_min(ax, bx), f_min(ay, by)), f_max(f_min(az, bz), tmin));           \
+            const float exit = f_min(f_min(f_max(ax, bx), f_max(ay, by)), f_min(f_max(az, bz), t_best));          \
+            hit |= (enter <= exit * 1.00001f) ? (1u << S) : 0u; /* conservative: boxes are padded, ties are kept; an empty slot's (+inf, -inf) never passes */ \
+        }
+        F3D_BVH4_SLOT(0, x)
+        F3D_BVH4_SLOT(1, y)
+        F3D_BVH4_SLOT(2, z)
+        F3D_BVH4_SLOT(3, w)
+#undef F3D_BVH4_SLOT
+        const uint32_t first_child = f_bits(meta.x), inner_slots = (1u << f_bits(meta.y)) - 1u;
+        uint32_t inner = hit & inner_slots, leaves = hit & ~inner_slots;
+        while (leaves != 0u) {  // the divergent region of the walk: the triangles of the leaf children the ray enters
+            const uint32_t s = (uint32_t)__builtin_ctz(leaves);
+            leaves &= leaves - 1u;
+            const uint32_t word = f_bits(s == 0u ? leaf.x : (s == 1u ? leaf.y : (s == 2u ? leaf.z : leaf.w)));
+            const uint32_t first = word >> 3, count = word & 7u;
+            F3D_MESH_STAT(2);
+            for (uint32_t k = 0u; k < count; k++) {
+                const float4 a = M.bvh_tris[3u * (first + k)], b = M.bvh_tris[3u * (first + k) + 1u], c = M.bvh_tris[3u * (first + k) + 2u];
+                float t;
+                V3 n;
+                if (ray_triangle(o, tmin, d, tmax, V3{a.x, a.y, a.z}, V3{b.x, b.y, b.z}, V3{c.x, c.y, c.z}, t, n)) {
+                    const uint32_t tri = f_bits(a.w);
+                    if (ANY ? best_tri == 0xFFFFFFFFu : (t < t_best || (t == t_best && tri < best_tri))) {
+                        t_best = t;
+                        n_best = n;
+                        best_tri = tri;
+                    }
+                }
+            }
+        }
+        if (ANY && best_tri != 0xFFFFFFFFu) {  // existence is all an occlusion ray asks for
+            inner = 0u;
+            open = 0u;
+        }
+        // the next node: the first inner child entered (its siblings wait in this level's word), or the next waiting sibling
+        // of the deepest level that holds one, or nothing
+        uint32_t next = kDone;
+        if (inner != 0u) {
+            const uint32_t rest = inner & (inner - 1u);
+            if (rest != 0u) {
+                stk.stack_put(level, (first_child << 4) | rest);
+                open |= 1u << level;
+            }
+            next = first_child + (uint32_t)__builtin_ctz(inner);
+            level = level + 1u;
+        } else if (open != 0u) {
+            const uint32_t at = 31u - (uint32_t)__builtin_clz(open);
+            const uint32_t word = stk.stack_get(at);
+            const uint32_t rest = (word & 15u) & ((word & 15u) - 1u);
+            if (rest != 0u) stk.stack_put(at, (word & ~15u) | rest);
+            else open &= ~(1u << at);
+            next = (word >> 4) + (uint32_t)__builtin_ctz(word & 15u);
+            level = at + 1u;
+        }
+        node = next;
+    }
+    return best_tri != 0xFFFFFFFFu;
+}
+
+template <class Stack>
+F3D_HD bool mesh_closest(const MeshDev &M, V3 o, float tmin, V3 d, float tmax, float &t_best, V3 &n_best, Stack &stk) {
+    if (M.bvh4_nodes) return mesh_bvh4<false>(M, o, tmin, d, tmax, t_best, n_best, stk);
     if (M.bvh_nodes) return mesh_bvh<false>(M, o, tmin, d, tmax, t_best, n_best);
     return mesh_sweep(M, o, tmin, d, tmax, t_best, n_best);
+}
+// Is any triangle of the mesh hit (occlusion rays)?
+template <class Stack>
+F3D_HD bool mesh_any(const MeshDev &M, V3 o, float tmin, V3 d, float tmax, float &t, V3 &n, Stack &stk) {
+    if (M.bvh4_nodes) return mesh_bvh4<true>(M, o, tmin, d, tmax, t, n, stk);
+    if (M.bvh_nodes) return mesh_bvh<true>(M, o, tmin, d, tmax, t, n);
+    return mesh_sweep(M, o, tmin, d, tmax, t, n);
 }
 
 // intersect_hybrid, hybrid_traversal.wgsl:175-201 (closest hit, curvature off)
@@ -171,7 +269,7 @@ F3D_HD SurfaceHit closest_hit(const FrameParams &P, V3 o, float tmin, V3 d, floa
     if (Pending::kMesh && P.mesh.traversal_mode == 0u) {
         float t;
         V3 n;
-        if (mesh_closest(P.mesh, o, tmin, d, tmax, t, n) && t < best.t) {
+        if (mesh_closest(P.mesh, o, tmin, d, tmax, t, n, pend) && t < best.t) {
             best.kind = 2u;
             best.t = t;
             best.n = n;
@@ -209,8 +307,7 @@ F3D_HD bool occluded(const FrameParams &P, V3 o, float tmin, V3 d, float tmax, b
     if (Pending::kMesh && P.mesh.traversal_mode == 0u) {
         float t;
         V3 n;
-        if (P.mesh.bvh_nodes ? mesh_bvh<true>(P.mesh, o, tmin, d, tmax, t, n) : mesh_sweep(P.mesh, o, tmin, d, tmax, t, n))
-            return t < 1e30f;
+        if (mesh_any(P.mesh, o, tmin, d, tmax, t, n, pend)) return t < 1e30f;
     }
 #endif
     // terrain_tmax: a certificate that no terrain lies beyond it on this ray (f3d_cone.h sun_clear_from): the march stops
@@ -232,8 +329,7 @@ F3D_HD bool occluded(const FrameParams &P, V3 o, float tmin, V3 d, float tmax, b
         float t;
         V3 n;
         // (accepted triangles have t < tmax; `t < 1e30` is the reference's own last word on the mesh hit)
-        if (!hit && (P.mesh.bvh_nodes ? mesh_bvh<true>(P.mesh, o, tmin, d, tmax, t, n) : mesh_sweep(P.mesh, o, tmin, d, tmax, t, n)))
-            hit = t < 1e30f;
+        if (!hit && mesh_any(P.mesh, o, tmin, d, tmax, t, n, pend)) hit = t < 1e30f;
     }
 #endif
     return hit;

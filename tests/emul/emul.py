@@ -390,3 +390,22 @@ def aether_reference(heightmap, width, height, cam, **kw) -> dict:
         raise RuntimeError(err.value.decode())
     return {"mean_xyz": mean_xyz, "linear_rgb": rgb, "variance": float(out.variance), "converged": bool(out.converged),
             "terrain_primary_hits": int(out.terrain_primary_hits)}
+
+
+def bvh4_nodes(vertices, indices):
+    """(records of the 4-wide form of the mesh BVH -- 0 when the tree is too deep for it --, nodes of the binary tree)."""
+    v = np.ascontiguousarray(vertices, np.float32)
+    i = np.ascontiguousarray(indices, np.uint32)
+    fn = lib().emul_bvh4_nodes
+    fn.restype = C.c_uint32
+    fn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+    n = C.c_uint32(0)
+    wide = fn(v.ctypes.data, v.shape[0], i.ctypes.data, i.size, C.addressof(n))
+    return int(wide), int(n.value)
+
+
+def set_mesh_walk(form: int):
+    """0: the reference's sweep, 1: the threaded binary walk, 2: four children wide (default)."""
+    fn = lib().emul_set_use_bvh
+    fn.argtypes = [C.c_int32]
+    fn(int(form))

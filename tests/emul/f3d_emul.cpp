@@ -59,6 +59,9 @@ struct ArrayPending {
     }
     bool leaf_gate(bool) const { return true; }  // one lane at a time: the gate is always open
     // ray sharing needs other lanes: never offered here
+    uint32_t bvh4_stack[kBvh4MaxLevels];  // per-level words of the 4-wide mesh walk (f3d_shade.h mesh_bvh4)
+    void stack_put(uint32_t level, uint32_t word) { bvh4_stack[level] = word; }
+    uint32_t stack_get(uint32_t level) const { return bvh4_stack[level]; }
     uint32_t lane() const { return 0u; }
     bool share_now(bool, uint32_t = 0u) const { return false; }
     template <bool CURVED>
@@ -282,7 +285,7 @@ HostTables build_tables_host(const float *heights, uint32_t w, uint32_t h, float
 // primaries re-traced until every sample started from the right stream state, contributions
 // replayed in sample order.  Same helpers (sample_primary / sample_shade / accumulate_sample) as
 // the device code, so the CPU parity tests pin the speculation scheme against the oracle.
-static bool g_use_bvh = true;  // false: the reference's sweep over all triangles (A/B of the BVH itself)
+static int g_use_bvh = 2;  // 0: the reference's sweep over all triangles (A/B of the BVH itself); 1: the threaded binary walk; 2: four children wide (the product's default)
 static uint32_t g_sample_lanes = 1u;
 static uint64_t g_retraces = 0;  // primaries traced a second time (statistics for the tests)
 
@@ -542,6 +545,7 @@ int emul_render(const f3d_terrain_ref_desc *d, uint32_t row_begin, uint32_t row_
         t.attach_horizon(P.terrain);
         std::vector<float> env4, mesh4;
         MeshBvh bvh;
+        std::vector<Bvh4Node> bvh4;
         if (d->env_map) {
             env4 = pad_rgb_to_rgba(d->env_map, (size_t)d->env_width * d->env_height, 1.0f);
             P.env.texels = (const float4 *)env4.data();
@@ -560,6 +564,11 @@ int emul_render(const f3d_terrain_ref_desc *d, uint32_t row_begin, uint32_t row_
                 P.mesh.bvh_nodes = bvh.nodes.data();
                 P.mesh.bvh_tris = (const float4 *)bvh.tris.data();
                 P.mesh.bvh_node_count = (uint32_t)bvh.nodes.size();
+                if (g_use_bvh == 2) bvh4 = collapse_bvh4(bvh);
+                if (!bvh4.empty()) {
+                    P.mesh.bvh4_nodes = bvh4.data();
+                    P.mesh.bvh4_node_count = (uint32_t)bvh4.size();
+                }
             }
         }
         if (row_end == 0) row_end = d->height;
@@ -763,6 +772,7 @@ struct EmulSession {
     std::vector<float> env4, mesh4;
     std::vector<uint32_t> mesh_idx;
     MeshBvh bvh;
+    std::vector<Bvh4Node> bvh4;
     std::vector<float4> accum, gbuf;
     std::vector<uint2> starts;
     std::vector<float2> sun_clear;
@@ -801,6 +811,11 @@ void *emul_session_create(const f3d_terrain_ref_desc *d, uint32_t row_begin, uin
                 s->P.mesh.bvh_nodes = s->bvh.nodes.data();
                 s->P.mesh.bvh_tris = (const float4 *)s->bvh.tris.data();
                 s->P.mesh.bvh_node_count = (uint32_t)s->bvh.nodes.size();
+                if (g_use_bvh == 2) s->bvh4 = collapse_bvh4(s->bvh);
+                if (!s->bvh4.empty()) {
+                    s->P.mesh.bvh4_nodes = s->bvh4.data();
+                    s->P.mesh.bvh4_node_count = (uint32_t)s->bvh4.size();
+                }
             }
         }
         if (row_end == 0) row_end = d->height;
@@ -964,7 +979,7 @@ int emul_primary_start(const f3d_terrain_ref_desc *d, uint32_t gx, uint32_t gy, 
     }
 }
 
-void emul_set_use_bvh(int32_t on) { g_use_bvh = on != 0; }
+void emul_set_use_bvh(int32_t form) { g_use_bvh = form < 0 ? 0 : (form > 2 ? 2 : form); }  // 0 sweep, 1 binary walk, 2 four wide
 // FNV-1a over the node and triangle arrays of the mesh BVH built with / without worker threads
 uint64_t emul_bvh_fingerprint(const float *verts, uint32_t nverts, const uint32_t *idx, uint32_t nidx, int32_t parallel,
                               uint32_t *node_count) {
@@ -978,6 +993,12 @@ uint64_t emul_bvh_fingerprint(const float *verts, uint32_t nverts, const uint32_
     mix(bvh.tris.data(), bvh.tris.size() * sizeof(float));
     if (node_count) *node_count = (uint32_t)bvh.nodes.size();
     return h;
+}
+// records of the 4-wide form of the mesh BVH (0: the tree is too deep for the walk's per-level words -> binary walk)
+uint32_t emul_bvh4_nodes(const float *verts, uint32_t nverts, const uint32_t *idx, uint32_t nidx, uint32_t *binary_nodes) {
+    const MeshBvh bvh = build_mesh_bvh(verts, nverts, idx, nidx);
+    if (binary_nodes) *binary_nodes = (uint32_t)bvh.nodes.size();
+    return (uint32_t)collapse_bvh4(bvh).size();
 }
 // sample lanes of the frame emulation (1 = frame_pixel; 2, 4, 8 = the frame_lanes mirror)
 void emul_set_frames_in_flight(uint32_t n) { g_frames_in_flight = n; }

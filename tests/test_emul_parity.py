@@ -261,3 +261,29 @@ def test_mesh_walk_on_random_scenes_matches_the_sweep(seed, lanes):
             emul.render(dem, size[0], size[1], cam, sample_lanes=lanes, **kw)
         pytest.skip(str(exc)[:60])
     _same(emul.render(dem, size[0], size[1], cam, sample_lanes=lanes, **kw), want)
+
+
+def test_four_wide_mesh_walk_is_what_runs_and_equals_the_other_forms():
+    """Round 4: the mesh BVH is walked four children wide (f3d_shade.h mesh_bvh4 over f3d_bvh.h collapse_bvh4).  The mesh
+    tests above run that form (the emulator's default, like the product's); here it is checked that the collapse really
+    yields a tree (a too-deep one would silently fall back to the binary walk) and that sweep, binary walk and 4-wide walk
+    give the same bits on a scene with coplanar pairs and slivers."""
+    from forge3d_amd import datasets
+
+    dem = scenes.golden_dem()
+    v, i = datasets.proxy_buildings(dem, 100.0 / (dem.shape[1] - 1), n_boxes=400, seed=3)
+    v = v * np.float32([1.0, 0.02, 1.0])  # the proxy's metre-sized boxes on the unit-height golden DEM
+    wide, binary = emul.bvh4_nodes(v, i)
+    assert 0 < wide < binary // 3  # four children a record: far fewer records than binary nodes
+    kw = scenes.fixed_frames(scenes.scene_kwargs(dem), 2, spp=2, mesh_vertices=v, mesh_indices=i)
+    images = []
+    try:
+        for form in (0, 1, 2):
+            emul.set_mesh_walk(form)
+            images.append(emul.render(dem, 96, 72, scenes.CAM, **kw))
+    finally:
+        emul.set_mesh_walk(2)
+    assert int((images[0]["albedo"][..., 2] > 0.7).sum()) > 100  # the mesh is in view
+    for other in images[1:]:
+        for key in ("rgba", "albedo", "normal", "depth"):
+            assert np.array_equal(images[0][key], other[key], equal_nan=True), key

@@ -29,8 +29,13 @@ t0 = time.perf_counter()
 if what == "C4":
     v, i = datasets.proxy_buildings(dem, kw["spacing"][0])
     with TerrainSession(dem, 4096, 4096, cam, memory_budget_bytes=16 << 30, mesh_vertices=v, mesh_indices=i, **dict(kw, max_frames=6, min_frames=6)) as s:
-        s.enqueue_frames(0, 6)
+        s.enqueue_frames(0, 2)
         torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        s.enqueue_frames(2, 4)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / 4
+        print("C4 ms per frame %.3f = %.0f Msamples/s (mesh walk: %s)" % (dt * 1e3, 4096 * 4096 * 8 / dt / 1e6, __import__("os").environ.get("F3D_MESH_BVH", "4-wide")))
 elif what == "C3_gi":
     from forge3d_amd import offline
 
