@@ -157,6 +157,7 @@ ABI = [
     ("f3d_device_name", C.c_char_p, [C.c_int32]),
     ("f3d_version", C.c_char_p, []),
     ("f3d_abi_version", C.c_uint32, []),
+    ("f3d_device_pool_trim", None, []),
     ("f3d_source_digest", C.c_char_p, []),
     ("f3d_debug_poison", None, [C.c_int32]),
 ]

@@ -20,10 +20,29 @@ int poison_pattern();  // -1: off (f3d_host.hip)
 void poison_register(void *user, void *base);
 void *poison_take(void *user);  // base pointer of a poisoned allocation (and forget it); nullptr: a plain allocation
 
+// Freed blocks are kept (per device, exact size, newest first; F3D_DEVICE_POOL_MB, default 2 048, 0 = off) and handed out
+// again: a camera path or a smoke sequence allocates the same dozen buffers for every frame, and hipFree waits for the
+// device.  Callers free only what no stream still uses (sessions synchronise their streams before they go).  Poisoned
+// allocations bypass the pool (their guard regions are part of the pattern test).  f3d_device_pool_trim() empties it.
+hipError_t pool_take(void **out, size_t bytes);   // hipErrorOutOfMemory: nothing of that size waiting (f3d_host.hip)
+bool pool_give(void *p);                           // false: not taken (pool off or full): the caller frees
+void pool_note(void *p, size_t bytes);             // a fresh hipMalloc the pool may take back later
+void pool_trim();
+
 inline hipError_t device_alloc(void **out, size_t bytes) {
     if (bytes == 0) bytes = 16;
     const int pattern = poison_pattern();
-    if (pattern < 0) return hipMalloc(out, bytes);
+    if (pattern < 0) {
+        if (pool_take(out, bytes) == hipSuccess) return hipSuccess;
+        hipError_t e = hipMalloc(out, bytes);
+        if (e == hipErrorOutOfMemory) {  // what the pool holds may be what is missing
+            (void)hipGetLastError();
+            pool_trim();
+            e = hipMalloc(out, bytes);
+        }
+        if (e == hipSuccess) pool_note(*out, bytes);
+        return e;
+    }
     const size_t padded = (bytes + 255u) & ~(size_t)255u;  // keeps the alignment hipMalloc gives
     void *base = nullptr;
     hipError_t e = hipMalloc(&base, padded + 2u * kPoisonGuardBytes);
@@ -40,6 +59,7 @@ inline hipError_t device_alloc(void **out, size_t bytes) {
 inline hipError_t device_free(void *p) {
     if (!p) return hipSuccess;
     void *base = poison_take(p);
+    if (!base && pool_give(p)) return hipSuccess;
     return hipFree(base ? base : p);
 }
 

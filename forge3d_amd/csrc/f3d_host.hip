@@ -84,6 +84,80 @@ std::mutex g_poison_mutex;
 std::unordered_map<void *, void *> g_poison_bases;
 }  // namespace
 int poison_pattern() { return g_poison_pattern.load(); }
+
+// ---- device memory pool (f3d_devmem.h) ----
+namespace {
+struct PoolBlock {
+    void *p;
+    size_t bytes;
+    int device;
+};
+std::mutex g_pool_mutex;
+std::vector<PoolBlock> &g_pool_free = *new std::vector<PoolBlock>();          // waiting to be handed out again
+std::unordered_map<void *, PoolBlock> &g_pool_live = *new std::unordered_map<void *, PoolBlock>();  // handed out: size and device by address
+size_t g_pool_bytes = 0;
+size_t pool_limit() {
+    static const size_t limit = [] {
+        const char *e = getenv("F3D_DEVICE_POOL_MB");
+        return (size_t)(e ? std::max(0.0, atof(e)) : 2048.0) << 20;
+    }();
+    return limit;
+}
+}  // namespace
+hipError_t pool_take(void **out, size_t bytes) {
+    if (pool_limit() == 0) return hipErrorOutOfMemory;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return hipErrorOutOfMemory;
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    for (size_t i = g_pool_free.size(); i-- > 0;)
+        if (g_pool_free[i].bytes == bytes && g_pool_free[i].device == device) {
+            *out = g_pool_free[i].p;
+            g_pool_live[*out] = g_pool_free[i];
+            g_pool_bytes -= bytes;
+            g_pool_free.erase(g_pool_free.begin() + (long)i);
+            return hipSuccess;
+        }
+    return hipErrorOutOfMemory;
+}
+void pool_note(void *p, size_t bytes) {
+    if (pool_limit() == 0) return;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return;
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    g_pool_live[p] = PoolBlock{p, bytes, device};
+}
+bool pool_give(void *p) {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    auto it = g_pool_live.find(p);
+    if (it == g_pool_live.end()) return false;
+    const PoolBlock b = it->second;
+    g_pool_live.erase(it);
+    if (b.bytes > pool_limit() || g_pool_free.size() >= 256u) return false;
+    while (g_pool_bytes + b.bytes > pool_limit() && !g_pool_free.empty()) {  // make room: the oldest go back to the driver
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        (void)hipSetDevice(g_pool_free.front().device);
+        (void)hipFree(g_pool_free.front().p);
+        if (prev >= 0) (void)hipSetDevice(prev);
+        g_pool_bytes -= g_pool_free.front().bytes;
+        g_pool_free.erase(g_pool_free.begin());
+    }
+    g_pool_free.push_back(b);
+    g_pool_bytes += b.bytes;
+    return true;
+}
+void pool_trim() {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    for (const PoolBlock &b : g_pool_free) {
+        (void)hipSetDevice(b.device);
+        (void)hipFree(b.p);
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
+    g_pool_free.clear();
+    g_pool_bytes = 0;
+}
 void poison_register(void *user, void *base) {
     std::lock_guard<std::mutex> lock(g_poison_mutex);
     g_poison_bases[user] = base;
@@ -1971,6 +2045,7 @@ const char *f3d_device_name(int32_t device) {
 
 const char *f3d_version(void) { return "forge3d_amd 0.3.0 (gfx950 terrain path tracer)"; }
 uint32_t f3d_abi_version(void) { return F3D_ABI_VERSION; }
+void f3d_device_pool_trim(void) { f3d::pool_trim(); }
 
 #ifndef F3D_SOURCE_DIGEST
 #define F3D_SOURCE_DIGEST "unknown"

@@ -339,10 +339,18 @@ extern "C" int f3d_smoke_render(const f3d_smoke_volume *vol, const f3d_smoke_vie
         };
         const uint64_t n = (uint64_t)P.nx * P.ny * P.nz;
         const float *host[6] = {vol->density, vol->temperature, vol->soot, vol->humidity, vol->emission, vol->age};
-        float *dev[6];
-        for (int i = 0; i < 6; i++) {
-            dev[i] = (float *)alloc(n * sizeof(float), "smoke field");
-            hip_ok(hipMemcpy(dev[i], host[i], n * sizeof(float), hipMemcpyHostToDevice), "smoke field upload");
+        const float *dev[6];
+        for (int i = 0; i < 6; i++) {  // a field that already is device memory (a resident smoke sequence) is read where it is
+            hipPointerAttribute_t attr{};
+            const bool resident = hipPointerGetAttributes(&attr, host[i]) == hipSuccess && attr.type == hipMemoryTypeDevice;
+            (void)hipGetLastError();
+            if (resident) {
+                dev[i] = host[i];
+                continue;
+            }
+            float *up = (float *)alloc(n * sizeof(float), "smoke field");
+            hip_ok(hipMemcpy(up, host[i], n * sizeof(float), hipMemcpyHostToDevice), "smoke field upload");
+            dev[i] = up;
         }
         float4 *rec_a = (float4 *)alloc(n * sizeof(float4), "smoke records");
         float2 *rec_b = (float2 *)alloc(n * sizeof(float2), "smoke records");
@@ -352,7 +360,10 @@ extern "C" int f3d_smoke_render(const f3d_smoke_volume *vol, const f3d_smoke_vie
         P.rec_a = rec_a;
         P.rec_b = rec_b;
         const size_t px = (size_t)P.width * P.height;
-        P.out = (uint8_t *)alloc(px * 4, "smoke rgba");
+        hipPointerAttribute_t out_attr{};
+        const bool out_on_device = hipPointerGetAttributes(&out_attr, rgba) == hipSuccess && out_attr.type == hipMemoryTypeDevice;
+        (void)hipGetLastError();
+        P.out = out_on_device ? rgba : (uint8_t *)alloc(px * 4, "smoke rgba");  // (a device image stays on the device: the composite reads it there)
         hipEvent_t e0, e1;
         hip_ok(hipEventCreate(&e0), "event");
         hip_ok(hipEventCreate(&e1), "event");
@@ -361,7 +372,8 @@ extern "C" int f3d_smoke_render(const f3d_smoke_volume *vol, const f3d_smoke_vie
         hipLaunchKernelGGL(k_smoke, dim3(tiles), dim3(64), 0, nullptr, P);
         hip_ok(hipGetLastError(), "smoke kernel");
         hip_ok(hipEventRecord(e1, nullptr), "event");
-        hip_ok(hipMemcpy(rgba, P.out, px * 4, hipMemcpyDeviceToHost), "smoke readback");
+        if (out_on_device) hip_ok(hipEventSynchronize(e1), "smoke kernel");
+        else hip_ok(hipMemcpy(rgba, P.out, px * 4, hipMemcpyDeviceToHost), "smoke readback");
         float ms = 0.0f;
         (void)hipEventElapsedTime(&ms, e0, e1);
         (void)hipEventDestroy(e0);

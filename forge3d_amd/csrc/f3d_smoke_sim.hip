@@ -232,8 +232,22 @@ extern "C" int f3d_smoke_step(f3d_smoke_state *st, const f3d_smoke_step_settings
         s.block = dim3(64);
         s.grid = dim3((s.G.nx + 63u) / 64u, s.G.ny, s.G.nz);
         float **dev[9] = {&s.F.density, &s.F.temperature, &s.F.fuel, &s.F.soot, &s.F.humidity, &s.F.emission_rate, &s.F.particle_age, &s.F.velocity, &s.F.pressure};
+        // The nine fields may be DEVICE arrays (all nine, or none): the solver then works on them in place and nothing crosses
+        // the bus -- a smoke sequence keeps its state on the GPU (forge3d_amd.smoke.SmokeSequence; BASELINE.json configs[4]).
+        int on_device = 0;
+        for (int f = 0; f < 9; f++) {
+            hipPointerAttribute_t attr{};
+            if (hipPointerGetAttributes(&attr, host[f]) == hipSuccess && attr.type == hipMemoryTypeDevice) on_device++;
+            (void)hipGetLastError();
+        }
+        if (on_device != 0 && on_device != 9) fail(F3D_STATUS_VALUE, "the nine smoke state fields must be all host or all device arrays");
+        const bool resident = on_device == 9;
         for (int f = 0; f < 9; f++) {
             const size_t bytes = s.n * sizeof(float) * (f == 7 ? 3u : 1u);
+            if (resident) {
+                *dev[f] = host[f];
+                continue;
+            }
             *dev[f] = (float *)s.alloc(bytes);
             ok(hipMemcpy(*dev[f], host[f], bytes, hipMemcpyHostToDevice), "smoke state upload");
         }
@@ -335,7 +349,8 @@ extern "C" int f3d_smoke_step(f3d_smoke_state *st, const f3d_smoke_step_settings
         float ms = 0.0f;
         ok(hipEventElapsedTime(&ms, e0, e1), "event");
         if (device_seconds) *device_seconds = ms * 1e-3;
-        for (int f = 0; f < 9; f++) ok(hipMemcpy(host[f], *dev[f], s.n * sizeof(float) * (f == 7 ? 3u : 1u), hipMemcpyDeviceToHost), "smoke state read-back");
+        if (!resident)
+            for (int f = 0; f < 9; f++) ok(hipMemcpy(host[f], *dev[f], s.n * sizeof(float) * (f == 7 ? 3u : 1u), hipMemcpyDeviceToHost), "smoke state read-back");
         st->time_seconds = s.G.time_seconds;
         st->frame_index = s.G.frame_index;
     } catch (const Failure &f) {

@@ -298,6 +298,10 @@ int f3d_session_info(f3d_session *session, uint64_t *gpu_resource_bytes, uint64_
 int f3d_session_kernel_timing(f3d_session *session, int32_t enable, double *avg_ms, uint32_t *launches);
 /* Sample lanes per pixel the frame kernel of this session runs with (1, 2, 4 or 8); 0 on a NULL session. */
 uint32_t f3d_session_sample_lanes(f3d_session *session);
+/* Device memory the library has freed is kept for its next allocation of the same size (F3D_DEVICE_POOL_MB, default
+ * 2048, 0 = off): a camera path or a smoke sequence allocates the same buffers frame after frame.  This hands everything
+ * that is waiting back to the driver. */
+void f3d_device_pool_trim(void);
 /* Rows of neighbour state a strip keeps above and below its own (4: the spatial pass reaches -3 .. +4 rows); the halo
  * blocks of f3d_session_halo and the extra rows of ext_reservoirs are this many rows. */
 uint32_t f3d_halo_rows(void);
@@ -369,7 +373,9 @@ typedef struct f3d_smoke_settings { /* SmokeRenderSettings, reference src/smoke/
 } f3d_smoke_settings;
 
 /* rgba: caller-owned height x width x 4 bytes (straight colour, alpha = 1 - transmittance).  kernel_seconds
- * (optional) receives the ray-march kernel's device time.  Errors carry the reference's message texts. */
+ * (optional) receives the ray-march kernel's device time.  Errors carry the reference's message texts.
+ * Each of the six fields, and rgba, may be a DEVICE pointer: such a field is read where it is and a device image is
+ * left on the device (a resident smoke sequence: f3d_smoke_step on device fields -> f3d_smoke_render -> f3d_smoke_composite). */
 int f3d_smoke_render(const f3d_smoke_volume *volume, const f3d_smoke_view *view, const f3d_smoke_settings *settings,
                      uint8_t *rgba, double *kernel_seconds, char *err, size_t errlen);
 
@@ -378,7 +384,8 @@ int f3d_smoke_render(const f3d_smoke_volume *volume, const f3d_smoke_view *view,
  * src/smoke/py.rs:459-480; single-threaded host code there): `steps` steps of the solver on the device -- emitters,
  * forces (wind, buoyancy, procedural turbulence), semi-Lagrangian / MacCormack advection, diffusion, vorticity
  * confinement, Jacobi pressure projection, boundary damping, sub-grid density eddies, decay and ageing.  All fields are
- * caller-owned HOST arrays, read and written in place ((nz, ny, nx) f32, velocity (nz, ny, nx, 3)). */
+ * caller-owned arrays, read and written in place ((nz, ny, nx) f32, velocity (nz, ny, nx, 3)): nine HOST arrays (uploaded and
+ * read back by the call) or nine DEVICE arrays (the solver works on them where they are: nothing crosses the bus). */
 typedef struct f3d_smoke_state {
     float *density, *temperature, *fuel, *soot, *humidity, *emission_rate, *particle_age, *velocity, *pressure;
     uint32_t dims[3];

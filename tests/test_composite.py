@@ -225,3 +225,45 @@ def test_config5_end_to_end_over_a_terrain_frame():
     mine = smoke.simulate_over_terrain(terrain, dom2, smoke.SmokeStepSettings(**settings), [smoke.SmokeEmitter(**e) for e in emitters], 3,
                                        steps_per_frame=2, rank=1, world=2, **cam)
     assert sorted(mine) == [1] and np.array_equal(mine[1], frames[1])
+
+
+@pytest.mark.gpu
+def test_resident_smoke_sequence_equals_the_host_array_path():
+    """Round 4: the sequence with its state, the smoke layer and the terrain frame resident on the GPU (SmokeSequence: only
+    the finished RGBA8 frames leave, through two pinned buffers) gives the frames AND the final solver state of the
+    host-array path, which crosses the bus with every field for every step and frame."""
+    from forge3d_amd import smoke
+
+    w, h = 200, 120
+    rng = np.random.default_rng(5)
+    terrain = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    terrain[..., 3] = 255
+    dims = (24, 16, 20)
+    emitters = [smoke.SmokeEmitter(center=(6.0, 3.0, 10.0), radius=2.5, density_rate=6.0, temperature_rate=3.0, soot_rate=0.3, emission_rate=2.0,
+                                   velocity=(3.0, 0.4, 0.0))]
+    settings = smoke.SmokeStepSettings(dt=0.1, turbulence_strength=0.5, turbulence_seed=7, wind=(1.5, 0.0, -0.2), pressure_iterations=8)
+    cam = dict(camera_pos=(12.0, 10.0, 46.0), target=(12.0, 6.0, 10.0))
+    host_dom, dev_dom = smoke.SmokeDomain(dims), smoke.SmokeDomain(dims)
+    want = smoke.simulate_over_terrain(terrain, host_dom, settings, emitters, 5, steps_per_frame=2, resident=False, **cam)
+    seq = smoke.SmokeSequence(dev_dom, terrain, **cam)
+    got = [frame.copy() for frame in seq.frames(5, settings, emitters, steps_per_frame=2)]
+    assert len(got) == 5
+    for f in range(5):
+        assert np.array_equal(got[f], want[f]), f
+    seq.download()
+    assert dev_dom.frame_index == host_dom.frame_index == 10 and dev_dom.time_seconds == host_dom.time_seconds
+    for name in ("density", "temperature", "fuel", "soot", "humidity", "emission_rate", "particle_age", "velocity", "pressure"):
+        assert np.array_equal(getattr(dev_dom, name), getattr(host_dom, name)), name
+    assert all(v > 0.0 for v in seq.kernel_seconds.values())
+    with pytest.raises(ValueError, match="all host or all device"):
+        st = smoke._State()
+        for name in smoke._STATE_FIELDS:
+            setattr(st, name, seq.state[name].data_ptr())
+        st.density = np.zeros(dims[::-1], np.float32).ctypes.data  # one host array among device arrays
+        st.dims = (smoke.C.c_uint32 * 3)(*dims)
+        st.voxel_size = (smoke.C.c_float * 3)(1.0, 1.0, 1.0)
+        st.origin = (smoke.C.c_float * 3)(0.0, 0.0, 0.0)
+        err = smoke.C.create_string_buffer(256)
+        rc = smoke._native.lib().f3d_smoke_step(smoke.C.byref(st), smoke.C.byref(settings._native()), None, 0, 1, None, err, len(err))
+        if rc != 0:
+            raise ValueError(err.value.decode())
