@@ -1761,6 +1761,7 @@ int f3d_session_fingerprint(f3d_session *s, uint64_t *out, uint32_t count) {
         m.indices = nullptr;
         m.bvh_nodes = nullptr;
         m.bvh_tris = nullptr;
+        m.bvh4_nodes = nullptr;
         const uint32_t scalars[8] = {P.spp, P.row_begin, P.row_end, P.tile_map, P.sample_lanes, P.same_sun, P.env.width, P.env.height};
         out[0] = hash_bytes(&P.cam, sizeof(P.cam), 1);
         out[1] = hash_bytes(&P.light, sizeof(P.light), 2);

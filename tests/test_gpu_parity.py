@@ -1028,7 +1028,7 @@ def test_results_do_not_depend_on_what_the_allocator_hands_out(f3d, oracle):
                 s.window_stats()
                 images.append(s.resolve(22)["rgba"])
         assert all(np.array_equal(images[0], im) for im in images[1:])
-        assert all(prints[0] == p for p in prints[1:])
+        assert all(prints[0] == p for p in prints[1:]), [k for p in prints[1:] for k in p if p[k] != prints[0][k]]
         mdem, msize, mcam, mkw = scenes.random_scene(101)  # a scene with a mesh: BVH upload, mesh buffers
         want = oracle.render(mdem, msize[0], msize[1], mcam, **mkw)
         for pattern in (0xFF, 0x00):
