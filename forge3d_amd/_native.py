@@ -179,10 +179,10 @@ HIPCC_FLAGS = [
 ]
 # only for f3d_kernels.hip (the frame kernels; compiled to an object first, then linked with the rest):
 KERNEL_FLAGS = [
-    # the "VGPR live-range optimisation for if-else structures" lengthens live ranges across the divergent regions of the
-    # march; without it the 80-VGPR frame kernel spills less inside them: 7 875-7 946 -> 8 023-8 034 Msamples/s in one call,
-    # same image (profiles/README.md, round 3).  The other translation units keep the default (the smoke marcher loses with it).
-    "-mllvm", "-amdgpu-opt-vgpr-liverange=false",
+    # (round 3 switched the "VGPR live-range optimisation for if-else structures" off for this translation unit,
+    # `-mllvm -amdgpu-opt-vgpr-liverange=false`: the frame kernel then spilled less inside the march's divergent regions, +1.5 %.
+    # Round 4 took the spills out at the source -- 160 -> 12 bytes of scratch per lane -- and with them the reason: the
+    # default is now 1.1 % FASTER, 8 690 -> 8 785 Msamples/s in one call, same image; profiles/r04_variant_ab.log)
 ]
 HIP_SOURCES = ["f3d_kernels.hip", "f3d_host.hip", "f3d_denoise.hip", "f3d_smoke.hip", "f3d_smoke_sim.hip", "f3d_composite.hip", "f3d_lbvh.hip", "f3d_wavefront.hip",
                "f3d_aether_bake.hip", "f3d_aether_ref.hip"]

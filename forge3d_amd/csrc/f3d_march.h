@@ -100,8 +100,9 @@ static_assert(kFifoWords == 1u || kFifoWords == 3u, "F3D_FIFO_WORDS: 1 (cell onl
 // overflow (a step queues at most two entries).  Results do not depend on it (3.1 of DESIGN.md: verdicts do not depend
 // on when leaves are evaluated).  Measured on the headline frame: 1 / 2 / 4 / 6 / 8 / 12 / 16 steps -> 6 989 / 7 270 /
 // 7 422 / 7 529 / 7 514 / 7 368 / 7 095 Msamples/s (profiles/r03_variant_ab.log); 4 inside the ray-sharing rounds.
+// Round 4, after the spills went: 5 / 6 / 8 / 10 -> 8 713 / 8 690 / 8 750 / lower (profiles/r04_variant_ab.log): 8.
 #ifndef F3D_STEPS_PER_VOTE
-#define F3D_STEPS_PER_VOTE 6
+#define F3D_STEPS_PER_VOTE 8
 #endif
 constexpr uint32_t kStepsPerVote = F3D_STEPS_PER_VOTE;
 #ifndef F3D_STEPS_PER_VOTE_SHARED
@@ -406,7 +407,7 @@ F3D_HD void march_drain(const TerrainDev &T, const RayCtx &r, bool any_hit, Marc
 // live in scalar registers as long as the ray is loop-invariant (and their tail is short: 17 % of the
 // shadow iterations run with <= 4 lanes).
 #ifndef F3D_SHARE_BELOW
-#define F3D_SHARE_BELOW 16
+#define F3D_SHARE_BELOW 16  // (with kShareAvail = 4 lanes per ray, a 64-lane wave never deals more than 16: larger values change nothing)
 #endif
 #ifndef F3D_SHARE_ROUNDS
 #define F3D_SHARE_ROUNDS 10

@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.."
 NAME=$1; shift
 mkdir -p build_ab
 COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize"
-KERNEL_FLAGS=${KERNEL_FLAGS--mllvm -amdgpu-opt-vgpr-liverange=false}
+KERNEL_FLAGS=${KERNEL_FLAGS-}
 /opt/rocm/bin/hipcc $COMMON $KERNEL_FLAGS "$@" -c forge3d_amd/csrc/f3d_kernels.hip -o build_ab/f3d_kernels_$NAME.o 2> build_ab/$NAME.err
 /opt/rocm/bin/hipcc $COMMON -shared "$@" build_ab/f3d_kernels_$NAME.o \
     forge3d_amd/csrc/f3d_host.hip forge3d_amd/csrc/f3d_denoise.hip forge3d_amd/csrc/f3d_smoke.hip forge3d_amd/csrc/f3d_smoke_sim.hip forge3d_amd/csrc/f3d_composite.hip \

@@ -4,7 +4,7 @@
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT=$(mktemp -d)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-opt-vgpr-liverange=false "$@" -c "$ROOT/forge3d_amd/csrc/f3d_kernels.hip" \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize "$@" -c "$ROOT/forge3d_amd/csrc/f3d_kernels.hip" \
     -o "$OUT/k.o" -Rpass-analysis=kernel-resource-usage 2>&1 |
   awk '/Function Name:/ {name=$NF} /remark:/ && /Name:/ {name=$(NF-1)}
        /VGPRs:/ && !/AGPRs/ && !/Spill/ {v=$(NF-1)} /AGPRs:/ {a=$(NF-1)} /TotalSGPRs:/ {sg=$(NF-1)}

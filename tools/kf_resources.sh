@@ -13,7 +13,7 @@ cat > "$OUT/one.hip" <<SRC
 #include "f3d_frame.h"
 namespace f3d { template __global__ void $KERNEL(const FrameParams); }
 SRC
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-opt-vgpr-liverange=false \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize \
     -I "$ROOT/forge3d_amd/csrc" -I "$ROOT/include" "$@" --cuda-device-only -S "$OUT/one.hip" -o "$OUT/one.s" -Rpass-analysis=kernel-resource-usage 2>&1 |
   awk '/Function Name:/ {name=$(NF-1)} /VGPRs:/ && !/AGPRs/ && !/Spill/ {v=$(NF-1)} /TotalSGPRs:/ {sg=$(NF-1)} /ScratchSize/ {sc=$(NF-1)} /Occupancy/ {oc=$(NF-1)}
        /LDS Size/ {if (name ~ /k_frame|k_trace|k_wf/) printf "%s: vgpr %s sgpr %s scratch %s B/lane occ %s lds %s\n", name, v, sg, sc, oc, $(NF-1)}'
