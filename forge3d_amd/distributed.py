@@ -126,10 +126,12 @@ class HipBackend:
     def sync(self):
         self.torch.cuda.synchronize(self.device)
 
-    def probe(self, dem, width, height, cam, row_begin, row_end, kw, frames=4):
+    def probe(self, dem, width, height, cam, row_begin, row_end, kw, frames=4, whole_loop=False):
         """Milliseconds per frame of the strip [row_begin, row_end): `frames` probe frames enqueued back to
         back (after one untimed frame) in a throw-away session, device time from start to drain -- the bands
-        of consecutive frames overlap exactly as in the render.  Halos stay empty."""
+        of consecutive frames overlap exactly as in the render.  Halos stay empty.  whole_loop: frames
+        0 .. frames - 1 of the fresh session, the first frame and (frames in flight) the short first batches
+        included -- what a strip of a render of that many frames costs, not its steady rate."""
         import time
 
         nbytes = (row_end - row_begin + 2 * HALO_ROWS) * width * RES_BYTES
@@ -137,10 +139,11 @@ class HipBackend:
         stats = self.empty_i32(4)
         session = self.make_session(dem, width, height, cam, row_begin, row_end, res, stats, kw)
         try:
-            session.enqueue_frames(0, 1)
+            if not whole_loop:
+                session.enqueue_frames(0, 1)
             self.sync()
             t0 = time.perf_counter()
-            session.enqueue_frames(1, frames)
+            session.enqueue_frames(0 if whole_loop else 1, frames)
             self.sync()
             ms = (time.perf_counter() - t0) * 1e3 / frames
         finally:
@@ -171,7 +174,12 @@ class StripRenderer:
             fd = 16 if (world >= 5 and isinstance(self.backend, HipBackend)) else 0
         if fd:
             kw = dict(kw, frames_in_flight=int(fd))
-        self.probe_frames = 16 if fd else 4  # batches need a few frames to reach their steady throughput
+        # Strips with frames in flight are balanced on what a 256-spp render (32 frames) costs them from its first frame on:
+        # their first batches are short (f3d_host.hip trace_batch) and a sky strip pays relatively more for them than its
+        # steady rate says -- balanced on the steady rate, the rehearsal's top strip took 10.2 ms of the loop against a mean
+        # of 9.5 (profiles/r04_strip_balance.log).
+        self.probe_frames = min(32, int(kw.get("max_frames", 32))) if fd else 4
+        self.probe_whole_loop = bool(fd)
         if row_bounds is not None:
             self.bounds = [int(b) for b in row_bounds]
             if (len(self.bounds) != world + 1 or self.bounds[0] != 0 or self.bounds[-1] != self.height
@@ -326,7 +334,7 @@ class StripRenderer:
             ms, error = float("nan"), None
             try:
                 ms = self.backend.probe(dem, self.width, self.height, cam, bounds[self.rank], bounds[self.rank + 1], kw,
-                                        frames=self.probe_frames)
+                                        frames=self.probe_frames, **({"whole_loop": True} if self.probe_whole_loop else {}))
             except Exception as exc:  # noqa: BLE001
                 error = exc
             self._agree(error)

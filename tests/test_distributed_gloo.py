@@ -51,7 +51,7 @@ def _worker(rank, world, port, out_path, mode):
     if mode == "balanced":
         # synthetic probe: rows of the top half ("sky") cost 1, the others 5 -> unequal strips
         class CostBackend(emul.EmulBackend):
-            def probe(self, dem, width, height, cam, row_begin, row_end, kw, frames=2):
+            def probe(self, dem, width, height, cam, row_begin, row_end, kw, frames=2, whole_loop=False):
                 return float(sum(1.0 if y < height // 2 else 5.0 for y in range(row_begin, row_end)))
 
         backend = CostBackend()

@@ -40,7 +40,8 @@ backend = HipBackend(0)
 
 
 def probe(b0, b1, **extra):
-    return min(backend.probe(dem, W, H, cam, b0, b1, dict(kw, **extra), frames=args.frames) for _ in range(2))
+    loop = bool(extra.get("frames_in_flight"))  # as StripRenderer._balance: strips with frames in flight are balanced on the 32-frame loop
+    return min(backend.probe(dem, W, H, cam, b0, b1, dict(kw, **extra), frames=32 if loop else args.frames, whole_loop=loop) for _ in range(2))
 
 
 full = probe(0, H)
@@ -71,3 +72,25 @@ for world in [int(x) for x in args.worlds.split(",")]:
         if new_bounds == bounds:
             break
         bounds = new_bounds
+    # the partition as a 256-spp render runs it: the WHOLE accumulation loop (frames 0..31 of a fresh session, first frame and
+    # short first batches included), per strip, against the same loop of the full frame
+    import time
+
+    import torch
+    from forge3d_amd.session import TerrainSession
+
+    def loop_ms(b0, b1, **extra):
+        best = 1e9
+        for _ in range(2):
+            with TerrainSession(dem, W, H, cam, row_begin=b0, row_end=b1, **dict(kw, **extra)) as s:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                s.enqueue_frames(0, 32)
+                torch.cuda.synchronize()
+                best = min(best, (time.perf_counter() - t0) * 1e3)
+        return best
+
+    full_loop = loop_ms(0, H)
+    loops = [loop_ms(bounds[r], bounds[r + 1], frames_in_flight=args.fd) for r in range(world)]
+    print(json.dumps({"world": world, "render_256spp_loop_ms": {"full_frame": round(full_loop, 3), "strips": [round(t, 3) for t in loops]},
+                      "ms_per_strip_frame": round(max(loops) / 32, 4), "compute_bound_speedup_256spp": full_loop / max(loops), "bounds": bounds}), flush=True)
