@@ -483,6 +483,22 @@ def main():
                 result["config_real_dem"] = {"error": str(exc)[:300], "data": f"real DEM {real_path}"}
     if rank == 0 and world == 1 and not args.no_configs:
         result["configs"] = other_configs(dem, cam, kw, args, local_rank)
+        # roofline rows of these configurations' dominant kernels (and of the multi-GPU strip form) from the rocprofv3 passes
+        # committed under profiles/ (tools/gpu_profile_config.sh -> tools/config_rooflines.py): quoted only for THESE kernel sources
+        try:
+            for path in sorted((ROOT / "profiles").glob("r*_config_rooflines.json"), reverse=True):
+                rows = json.loads(path.read_text())
+                if any(r.get("kernel_source_hash") != result["kernel_source_hash"] for r in rows.values()):
+                    continue
+                for key, dest in (("C4_standin", "C4_standin"), ("C3_gi", "C3_gi")):
+                    if key in rows and dest in result["configs"] and "error" not in result["configs"][dest]:
+                        result["configs"][dest]["profiled_kernel"] = rows[key]
+                if "C5" in result["configs"] and "error" not in result["configs"]["C5"]:
+                    result["configs"]["C5"]["profiled_kernels"] = {k[3:]: rows[k] for k in ("C5_march", "C5_solver_jacobi") if k in rows}
+                result["strip_form_profiled_kernels"] = {k: rows[k] for k in ("strip_trace", "strip_merge", "strip_fused") if k in rows}
+                break
+        except Exception:  # noqa: BLE001 -- a report, never a reason to lose the line
+            pass
     if rank == 0:
         print(json.dumps(result))
 

@@ -8,7 +8,7 @@ cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 LOG=gpurun_out/${TAG}_strip_balance.log
 : > $LOG
 echo "== fd 16 (the driver's default from 5 ranks on)" >> $LOG
-python tools/strip_balance.py --worlds 8 --fd 16 --rounds 3 2>/dev/null >> $LOG
+python tools/strip_balance.py --worlds 8 --fd 16 --rounds 4 2>/dev/null >> $LOG
 echo "== fd 0 (fused kernel: the default below 5 ranks)" >> $LOG
 python tools/strip_balance.py --worlds 2,4 --fd 0 --rounds 3 2>/dev/null >> $LOG
 cat $LOG
