@@ -255,5 +255,26 @@ class TerrainSession:
         return float(avg.value), int(n.value)
 
 
+def kernel_variant(*, sample_lanes: int = 0, waves_per_simd: int = 0, tile_map: int = 0, leaf_quorum: int = 0, share_below: int = 0) -> int:
+    """f3d_session_opts.kernel_variant from names (include/f3d_terrain_pt.h lists the decimal fields): every A/B switch of the
+    frame kernel that is not a build flag.  All zero = the shipped default."""
+    if sample_lanes not in (0, 1, 2, 4, 8):
+        raise ValueError("sample_lanes must be 0 (automatic), 1, 2, 4 or 8")
+    if waves_per_simd not in (0, 1, 4, 5, 6, 7, 8):
+        raise ValueError("waves_per_simd must be 0 / 6 (default), 4, 5, 7, 8 or 1 (unconstrained)")
+    if not (0 <= tile_map <= 4 and 0 <= leaf_quorum <= 64 and 0 <= share_below <= 64):
+        raise ValueError("tile_map in 0..4, leaf_quorum and share_below in 0..64")
+    budget = 0 if waves_per_simd in (0, 6) else 100 + waves_per_simd
+    return budget + 1000 * tile_map + 10000 * leaf_quorum + 1000000 * sample_lanes + 10000000 * share_below
+
+
+def describe_kernel_variant(v: int) -> dict:
+    """The fields of a kernel_variant, by name."""
+    v = int(v)
+    budget = v % 1000
+    return {"waves_per_simd": 6 if budget == 0 else (budget - 100), "tile_map": (v // 1000) % 10, "leaf_quorum": (v // 10000) % 100,
+            "sample_lanes": (v // 1000000) % 10, "share_below": (v // 10000000) % 100}
+
+
 def reservoir_buffer_bytes(rows: int, width: int) -> int:
     return (rows + 2 * HALO_ROWS) * width * RESERVOIR_BYTES

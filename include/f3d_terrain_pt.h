@@ -142,9 +142,18 @@ typedef struct f3d_session_opts {
     uint32_t row_begin;  /* first owned image row */
     uint32_t row_end;    /* one past the last owned row; 0 = height */
     uint64_t memory_budget_bytes; /* 0 = 512 MiB (reference MEMORY_BUDGET_LIMIT) */
-    int32_t kernel_variant;       /* 0 = default.  Tuning digits: v % 1000 register-budget A/B kernel,
-                                   * (v / 1000) % 10 tile-to-XCD map, (v / 10000) % 100 leaf-FIFO drain quorum,
-                                   * (v / 1000000) % 10 sample lanes per pixel (1, 2, 4, 8; 0 = automatic) */
+    int32_t kernel_variant;       /* 0 = default.  A/B switches as decimal fields (forge3d_amd.session.kernel_variant() builds one
+                                   * from names, describe_kernel_variant() reads one back):
+                                   *   v % 1000              register budget of the frame kernel: 0 = 6 waves per SIMD (80 VGPRs);
+                                   *                         104 / 105 / 107 / 108 = 4 / 5 / 7 / 8 waves; 101 = unconstrained
+                                   *   (v / 1000) % 10       tile -> XCD map: 0 / 2 rows dealt round-robin + longest-first dispatch
+                                   *                         (default), 1 consecutive tiles, 3 contiguous bands, 4 = 2 without longest-first
+                                   *   (v / 10000) % 100     lanes with a queued leaf that trigger a drain (0 = 64: only a full FIFO does)
+                                   *   (v / 1000000) % 10    sample lanes per pixel: 1, 2, 4, 8; 0 = automatic (a non-zero register
+                                   *                         budget with 0 here selects the 1-lane kernel)
+                                   *   (v / 10000000) % 100  ray sharing: deal the IBL rays when at most this many lanes still march
+                                   *                         (0 = 16; 64 = from the first step)
+                                   * e.g. 4000105 = 4 sample lanes at 5 waves per SIMD; 8001000 = 8 lanes, consecutive tiles */
     /* Optional caller-owned DEVICE buffers (NULL -> the library allocates).  The
      * strip driver allocates these as torch tensors so RCCL can move them.
      *   reservoirs[2]: ping-pong packed reservoirs, each (rows + 8) * width * 16 B,

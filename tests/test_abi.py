@@ -233,3 +233,16 @@ def test_python_and_library_agree_on_the_halo():
     assert _native.lib().f3d_halo_rows() == HALO_ROWS == session_rows == 4
     assert RES_BYTES == RESERVOIR_BYTES == 16
     assert reservoir_buffer_bytes(10, 7) == (10 + 2 * 4) * 7 * 16
+
+
+def test_kernel_variant_fields_have_names():
+    """f3d_session_opts.kernel_variant packs its A/B switches as decimal fields; the package builds and reads them by name."""
+    from forge3d_amd.session import describe_kernel_variant, kernel_variant
+
+    assert kernel_variant() == 0
+    assert kernel_variant(sample_lanes=4, waves_per_simd=5) == 4000105
+    assert kernel_variant(sample_lanes=8, tile_map=1) == 8001000
+    for v in (0, 4000105, 8001000, 160105, 640000000 + 4000000):
+        assert kernel_variant(**describe_kernel_variant(v)) == v
+    with pytest.raises(ValueError):
+        kernel_variant(sample_lanes=3)
