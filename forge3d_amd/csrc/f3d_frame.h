@@ -32,9 +32,11 @@ struct TileShape {
 
 // Pixel of this lane: the launch covers the image rows [band_begin, band_end) of the strip, tiled from band_begin.
 // `tile` returns the tile id of the wave (0xFFFFFFFF: the workgroup is padding).
+// wg: the workgroup's position in the dispatch order of ONE frame (blockIdx.x, except in k_trace's batches: batch_slot).
 template <uint32_t S = 1u>
 __device__ __forceinline__ bool tile_pixel(const FrameParams &P, uint32_t &gx, uint32_t &gy, uint32_t &tile,
-                                           const uint32_t *order = nullptr) {
+                                           const uint32_t *order = nullptr, uint32_t wg = 0xFFFFFFFFu) {
+    if (wg == 0xFFFFFFFFu) wg = blockIdx.x;
     using Shape = TileShape<S>;
     constexpr uint32_t TW = 1u << Shape::kLogW, TH = 1u << Shape::kLogH;
     const uint32_t rows = P.band_end - P.band_begin;
@@ -50,18 +52,18 @@ __device__ __forceinline__ bool tile_pixel(const FrameParams &P, uint32_t &gx, u
     // `order` (map 2 only): the same row -> XCD dealing, but each XCD starts its most expensive tiles first.
     uint32_t t;
     if (order) {
-        t = order[blockIdx.x];
+        t = order[wg];
     } else if (P.tile_map == 1u) {
-        t = blockIdx.x;
+        t = wg;
     } else if (P.tile_map == 2u) {
-        const uint32_t xcd = blockIdx.x % kNumXcd, i = blockIdx.x / kNumXcd;
+        const uint32_t xcd = wg % kNumXcd, i = wg / kNumXcd;
         const uint32_t rows_per_xcd = (tiles_y + kNumXcd - 1u) / kNumXcd;
         const uint32_t ty = (i / tiles_x) * kNumXcd + xcd;
         if (i >= rows_per_xcd * tiles_x || ty >= tiles_y) return false;
         t = ty * tiles_x + (i % tiles_x);
     } else {  // 3 (and anything else): contiguous bands
         const uint32_t per_xcd = (ntiles + kNumXcd - 1u) / kNumXcd;
-        t = (blockIdx.x % kNumXcd) * per_xcd + blockIdx.x / kNumXcd;
+        t = (wg % kNumXcd) * per_xcd + wg / kNumXcd;
     }
     if (t >= ntiles) return false;
     tile = t;
@@ -566,15 +568,27 @@ __global__ __launch_bounds__(kWave, MIN_WAVES) void k_wf_occl(const WfOcclParams
     march_stream<SUN>(W.terrain, src, pend, W.quorum ? W.quorum : (uint32_t)F3D_STREAM_QUORUM);
 }
 
+// A batch of frames is one launch (grid.y = frames).  The hardware starts workgroups with blockIdx.x running fastest, so
+// taken literally frame 0's tiles would all start before frame 1's -- longest first WITHIN a frame, but the long tiles of
+// the batch's last frame would start last and the launch would end in their tail (round 3).  The launch's linear order is
+// therefore re-read (round 4): groups of 8 consecutive workgroups (one per XCD, which keeps a tile's row on its XCD) cycle
+// through ALL frames of the batch before the next 8 slots of the per-frame order are touched -- longest first over the
+// whole batch.  Which workgroup traces a (frame, tile) never changes what it computes.
+__device__ __forceinline__ void batch_slot(uint32_t &frame_in_batch, uint32_t &slot) {
+    const uint32_t linear = blockIdx.y * gridDim.x + blockIdx.x, group = linear / kNumXcd, xcd = linear % kNumXcd;  // (gridDim.x is a multiple of 8: frame_grid)
+    frame_in_batch = group % gridDim.y;
+    slot = (group / gridDim.y) * kNumXcd + xcd;
+}
 template <int MIN_WAVES, uint32_t S, bool MESH = false>
 __global__ __launch_bounds__(kWave, MIN_WAVES) void k_trace(const FrameParams P) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[kLdsWords];
     const unsigned long long t_start = wall_clock64();
     typename PendingFor<MESH>::type pend{make_pending(lds, P.terrain)};
-    uint32_t gx = 0u, gy = 0u, tile;
-    const bool active = tile_pixel<S>(P, gx, gy, tile, P.tile_order);
-    trace_lanes<S>(P, P.frame_index + blockIdx.y, tile, active, pend);
-    if (lane_now() == 0u && blockIdx.y == 0u && P.tile_cost && tile != 0xFFFFFFFFu)
+    uint32_t gx = 0u, gy = 0u, tile, frame_in_batch, slot;
+    batch_slot(frame_in_batch, slot);
+    const bool active = tile_pixel<S>(P, gx, gy, tile, P.tile_order, slot);
+    trace_lanes<S>(P, P.frame_index + frame_in_batch, tile, active, pend);
+    if (lane_now() == 0u && frame_in_batch == 0u && P.tile_cost && tile != 0xFFFFFFFFu)
         P.tile_cost[tile] = (uint32_t)(wall_clock64() - t_start);
 }
 
@@ -594,12 +608,14 @@ __global__ __launch_bounds__(kWave) void k_merge(const FrameParams P) {
     bool redo = false;
     if (active) {
         const FrameHead h = frame_head<true>(P, gx, gy);
-        if (P.same_sun == 0u) {
-            redo = merge_mispredicted(P, h, rec, pixels);
-            // the prediction for the frames traced next (frame 0 says nothing: there every head is invalid by definition)
-            if (P.frame_index > 0u) P.head[lp].y = h.prev_valid ? kHeadPrevValid : 0u;
+        // the prediction for the frames traced next (frame 0 says nothing: there every head is invalid by definition)
+        if (P.same_sun == 0u && P.frame_index > 0u) P.head[lp].y = h.prev_valid ? kHeadPrevValid : 0u;
+        if (P.spp == 8u) {  // (wave-uniform) every record load of the pixel-frame in flight at once: merge_pixel_n
+            m2 = merge_pixel_n<8u>(P, gx, gy, h, rec, pixels, P.same_sun == 0u, redo);
+        } else {
+            if (P.same_sun == 0u) redo = merge_mispredicted(P, h, rec, pixels);
+            if (!redo) m2 = merge_pixel(P, gx, gy, h, rec, pixels);
         }
-        if (!redo) m2 = merge_pixel(P, gx, gy, h, rec, pixels);
     }
     if (__ballot(redo) != 0ull) {  // rare (3 pixel-frames in the first 18 frames of the headline scene, none later)
         LdsPending pend = make_pending(lds, P.terrain);

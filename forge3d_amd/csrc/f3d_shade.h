@@ -814,6 +814,36 @@ F3D_HD float merge_pixel(const FrameParams &P, uint32_t gx, uint32_t gy, const F
     return frame_tail(P, gx, gy, cand, radiance);
 }
 
+// Both for a sample count known at compile time (k_merge, spp = 8: the strip driver's case).  A merge wave is nothing but
+// memory latency -- the head's reservoirs, then 2 records per sample that k_trace left in HBM -- and with the count in a
+// register the loop waits for every sample's records in turn (8 round trips); unrolled, all of a pixel-frame's record loads
+// are in flight at once.  `redo` = the pixel-frame was mispredicted (nothing is merged then).  Same operations, same order.
+template <uint32_t N>
+F3D_HD float merge_pixel_n(const FrameParams &P, uint32_t gx, uint32_t gy, const FrameHead &h, const float4 *rec, size_t pixels, bool check, bool &redo) {
+    float4 r0[N], r1[N];
+#pragma unroll
+    for (uint32_t s = 0u; s < N; s++) {
+        r0[s] = rec[2u * (size_t)s * pixels];
+        r1[s] = rec[2u * (size_t)s * pixels + 1u];
+    }
+    redo = false;
+    if (check) {
+#pragma unroll
+        for (uint32_t s = 0u; s < N; s++)
+            if (trace_code_hit(r1[s].w) && (r1[s].w == 3.0f) != h.prev_valid) redo = true;
+    }
+    if (redo) return 0.0f;
+    V3 radiance = V3{0.0f, 0.0f, 0.0f};
+    Reservoir cand = empty_reservoir();
+#pragma unroll
+    for (uint32_t s = 0u; s < N; s++) {
+        V3 a = V3{r0[s].x, r0[s].y, r0[s].z};
+        if (trace_code_hit(r1[s].w)) a = a * h.reuse_w;
+        accumulate_sample(cand, radiance, a, V3{r1[s].x, r1[s].y, r1[s].z}, r0[s].w);
+    }
+    return frame_tail(P, gx, gy, cand, radiance);
+}
+
 // A mispredicted pixel-frame again: head (idempotent), the pixel's primary and sun rays with the direction the real
 // head reads -- frame_pixel's sample loop, the IBL terms taken from the records -- and the tail.
 template <class Pending>
