@@ -61,10 +61,18 @@ def _worker(rank, world, port, out_path, mode):
         kw = scenes.fixed_frames(kw, 6, spp=2)
     if mode == "noconv":  # the variance gate cannot be met: every rank must raise the reference's message
         kw = {**scenes.scene_kwargs(dem), "variance_threshold": 1e-12, "max_frames": 8, "min_frames": 2, "spp": 1}
-    if mode == "rankfail":  # one rank's session breaks in the middle of the render: nobody may be left in a collective
+    if mode in ("rankfail", "halotimeout"):  # one rank's session breaks in the middle of the render: nobody may be left in a collective
         kw = scenes.fixed_frames(kw, 40, spp=1)
     r = StripRenderer(dem, 72, 50, scenes.CAM, rank=rank, world=world, backend=backend, **extra, **kw)
-    if mode in ("noconv", "rankfail"):
+    if mode in ("noconv", "rankfail", "halotimeout"):
+        if mode == "halotimeout":
+            # ONE rank's device-side halo wait timed out.  The count must ride in the record every rank
+            # all-reduces -- a rank that raised before that all-reduce would pair its next, 1-word agreement all-reduce with
+            # the others' statistics all-reduce -- and every rank must raise the same error after the same collective.
+            r.peer_halos = True  # (the emulator exchanges halos over gloo; only the time-out bookkeeping of the peer path is played)
+            r.session.halo_timeouts = (lambda: 1) if rank == world - 1 else (lambda: 0)
+            r.session.enqueue_batch_strip = lambda first, count, collect=False: [
+                (r.session.enqueue_frame_part(f, 1, collect and f + 1 == first + count), r.exchange_halos(f & 1)) for f in range(first, first + count)]
         if mode == "rankfail" and rank == world - 1:
             real = r.session.enqueue_frame_part
 
@@ -211,6 +219,14 @@ def test_a_failing_rank_stops_every_rank_instead_of_hanging_them():
     assert len(msgs) == 2
     assert any("injected failure on the last rank" in m for m in msgs)
     assert any("another rank of the strip job failed" in m for m in msgs)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_a_halo_time_out_on_one_rank_is_raised_by_every_rank_after_the_same_collective(world):
+    msgs = _messages(world, "halotimeout")
+    assert len(msgs) == world
+    for m in msgs:
+        assert "halo wait timed out" in m, msgs
 
 
 def test_strip_rows_partition_the_image():
