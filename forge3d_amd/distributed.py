@@ -167,11 +167,13 @@ class StripRenderer:
         # Frames in flight (f3d_session_opts.frames_in_flight): thin strips trace batches of frames in one launch and run
         # the ordered half per frame, with the halo exchange between merges.  Measured per strip-frame of the 1080p headline
         # (tools/strip_balance.py, profiles/r03_strip_balance.log; fused / 16 in flight): 2 strips 1.13 / 1.23 ms, 4 strips
-        # 0.62 / 0.65, 6 strips 0.49 / 0.45, 8 strips 0.42 / 0.36 -- so from 5 ranks on.  Fatter strips keep the fused
-        # kernel.  The session lowers the number to what its memory budget holds.
+        # 0.62 / 0.65, 6 strips 0.49 / 0.45, 8 strips 0.42 / 0.36 -- so from 5 ranks on in round 3.  Round 4
+        # (profiles/r04_strip_balance.log): 2 strips 0.99 / 1.02, 3 strips 0.69 / 0.69, 4 strips 0.545 / 0.536 over the
+        # 32 frames of a 256-spp render -- and 0.538 / 0.489 in the steady state a longer render lives in -- so from 4 ranks on.
+        # Fatter strips keep the fused kernel.  The session lowers the number to what its memory budget holds.
         fd = kw.pop("frames_in_flight", None)
         if fd is None:
-            fd = 16 if (world >= 5 and isinstance(self.backend, HipBackend)) else 0
+            fd = 16 if (world >= 4 and isinstance(self.backend, HipBackend)) else 0
         if fd:
             kw = dict(kw, frames_in_flight=int(fd))
         # Strips with frames in flight are balanced on what a 256-spp render (32 frames) costs them from its first frame on:

@@ -120,11 +120,11 @@ def _check_against_one_strip(multi, world, in_flight, peer_halos, height):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,in_flight", [(4, 0), (8, None)])
+@pytest.mark.parametrize("world,in_flight", [(4, 0), (4, None), (8, None)])
 def test_four_and_eight_processes_on_one_gpu_with_peer_halos(world, in_flight):
     """The node-sized job on the one GPU of the test box: `world` OS processes, real IPC handles, INTERIOR ranks with a
     neighbour on both sides, `world`-way measured balancing.  in_flight None = the driver's default for that many ranks
-    (16 frames in flight from 5 ranks on): the path bench.py --gpus 8 takes.  Collectives over gloo (RCCL refuses several
+    (16 frames in flight from 4 ranks on): the path bench.py --gpus 8 takes.  Collectives over gloo (RCCL refuses several
     ranks per device; its own smoke test is test_gpu_nccl_smoke.py).  The stitched image must equal the one-strip image."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -59,7 +59,7 @@ elif what == "C5":
         smoke.render_over_terrain(terrain, dom, **view)
 elif what in ("strip", "strip_fused"):
     # rows of the heaviest strip of the balanced 8-strip partition (profiles/r04_strip_balance.log)
-    b0, b1 = 666, 755
+    b0, b1 = (int(x) for x in __import__("os").environ.get("F3D_STRIP_ROWS", "666,755").split(","))
     fd = 16 if what == "strip" else 0
     with TerrainSession(dem, 1920, 1080, cam, row_begin=b0, row_end=b1, memory_budget_bytes=8 << 30, frames_in_flight=fd,
                         **dict(kw, max_frames=64, min_frames=64)) as s:
