@@ -59,7 +59,12 @@ inline hipError_t device_alloc(void **out, size_t bytes) {
 inline hipError_t device_free(void *p) {
     if (!p) return hipSuccess;
     void *base = poison_take(p);
-    if (!base && pool_give(p)) return hipSuccess;
+    if (!base) {
+        // hipFree waits for the device; a block that goes back to the pool must not be handed out while a kernel of an
+        // abandoned call (an error path) still writes to it: keep that guarantee (on an idle device this costs microseconds)
+        (void)hipDeviceSynchronize();
+        if (pool_give(p)) return hipSuccess;
+    }
     return hipFree(base ? base : p);
 }
 
