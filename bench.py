@@ -288,6 +288,7 @@ def main():
         warm[::3, ::5] = 1.0
         with TerrainSession(warm, 64, 64, cam, device=local_rank, **dict(kw, max_frames=2, min_frames=2)) as ws:
             ws.enqueue_frames(0, 2)
+        torch.zeros(4, dtype=torch.int32, device=f"cuda:{local_rank}")  # (torch's own allocator and stream start up with its first device tensor: 15-20 ms on some boxes)
         torch.cuda.synchronize()
     torch.cuda.synchronize()
     t_setup = time.perf_counter()

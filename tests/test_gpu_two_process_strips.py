@@ -75,7 +75,7 @@ def test_two_processes_on_one_gpu_reproduce_the_single_process_image(in_flight, 
     _check_against_one_strip(multi, 2, in_flight, peer_halos, 200)
 
 
-def _run_strips(world, port, in_flight, peer_halos, height):
+def _run_strips(world, port, in_flight, peer_halos, height, _retried=False):
     import torch.multiprocessing as mp
 
     out = tempfile.mktemp(suffix=".pkl")
@@ -90,6 +90,15 @@ def _run_strips(world, port, in_flight, peer_halos, height):
     with open(out, "rb") as f:
         multi = pickle.load(f)
     os.unlink(out)
+    if peer_halos and not multi["info"]["peer_halos"] and not _retried:
+        # every rank fell back to the classic exchange: on this box all ranks share ONE GPU, and a link probe that waits on
+        # the device can time out when the processes' queues are starved (seen twice in ~30 runs).  Say why, try once more.
+        print("peer halos fell back:", multi["info"].get("peer_halo_failure"), file=sys.stderr)
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        return _run_strips(world, port, in_flight, peer_halos, height, _retried=True)
     return multi
 
 
