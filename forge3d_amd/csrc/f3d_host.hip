@@ -72,359 +72,7 @@ f3d_session &checked(f3d_session *s) {
 
 }  // namespace
 
-// ---- poison mode of the device allocator (f3d_devmem.h) ----
-namespace f3d {
-namespace {
-int poison_from_env() {  // F3D_POISON=<0..255>: a whole process (e.g. the GPU test suite) in poison mode
-    const char *v = getenv("F3D_POISON");
-    return (v && *v) ? (atoi(v) & 0xFF) : -1;
-}
-std::atomic<int> g_poison_pattern{poison_from_env()};
-std::mutex g_poison_mutex;
-std::unordered_map<void *, void *> g_poison_bases;
-}  // namespace
-int poison_pattern() { return g_poison_pattern.load(); }
-
-// ---- device memory pool (f3d_devmem.h) ----
-namespace {
-struct PoolBlock {
-    void *p;
-    size_t bytes;
-    int device;
-};
-std::mutex g_pool_mutex;
-std::vector<PoolBlock> &g_pool_free = *new std::vector<PoolBlock>();          // waiting to be handed out again
-std::unordered_map<void *, PoolBlock> &g_pool_live = *new std::unordered_map<void *, PoolBlock>();  // handed out: size and device by address
-size_t g_pool_bytes = 0;
-size_t pool_limit() {
-    static const size_t limit = [] {
-        const char *e = getenv("F3D_DEVICE_POOL_MB");
-        return (size_t)(e ? std::max(0.0, atof(e)) : 2048.0) << 20;
-    }();
-    return limit;
-}
-}  // namespace
-hipError_t pool_take(void **out, size_t bytes) {
-    if (pool_limit() == 0) return hipErrorOutOfMemory;
-    int device = 0;
-    if (hipGetDevice(&device) != hipSuccess) return hipErrorOutOfMemory;
-    std::lock_guard<std::mutex> lock(g_pool_mutex);
-    for (size_t i = g_pool_free.size(); i-- > 0;)
-        if (g_pool_free[i].bytes == bytes && g_pool_free[i].device == device) {
-            *out = g_pool_free[i].p;
-            g_pool_live[*out] = g_pool_free[i];
-            g_pool_bytes -= bytes;
-            g_pool_free.erase(g_pool_free.begin() + (long)i);
-            return hipSuccess;
-        }
-    return hipErrorOutOfMemory;
-}
-void pool_note(void *p, size_t bytes) {
-    if (pool_limit() == 0) return;
-    int device = 0;
-    if (hipGetDevice(&device) != hipSuccess) return;
-    std::lock_guard<std::mutex> lock(g_pool_mutex);
-    g_pool_live[p] = PoolBlock{p, bytes, device};
-}
-bool pool_give(void *p) {
-    std::lock_guard<std::mutex> lock(g_pool_mutex);
-    auto it = g_pool_live.find(p);
-    if (it == g_pool_live.end()) return false;
-    const PoolBlock b = it->second;
-    g_pool_live.erase(it);
-    if (b.bytes > pool_limit() || g_pool_free.size() >= 256u) return false;
-    while (g_pool_bytes + b.bytes > pool_limit() && !g_pool_free.empty()) {  // make room: the oldest go back to the driver
-        int prev = -1;
-        (void)hipGetDevice(&prev);
-        (void)hipSetDevice(g_pool_free.front().device);
-        (void)hipFree(g_pool_free.front().p);
-        if (prev >= 0) (void)hipSetDevice(prev);
-        g_pool_bytes -= g_pool_free.front().bytes;
-        g_pool_free.erase(g_pool_free.begin());
-    }
-    g_pool_free.push_back(b);
-    g_pool_bytes += b.bytes;
-    return true;
-}
-void pool_trim() {
-    std::lock_guard<std::mutex> lock(g_pool_mutex);
-    int prev = -1;
-    (void)hipGetDevice(&prev);
-    for (const PoolBlock &b : g_pool_free) {
-        (void)hipSetDevice(b.device);
-        (void)hipFree(b.p);
-    }
-    if (prev >= 0) (void)hipSetDevice(prev);
-    g_pool_free.clear();
-    g_pool_bytes = 0;
-}
-void poison_register(void *user, void *base) {
-    std::lock_guard<std::mutex> lock(g_poison_mutex);
-    g_poison_bases[user] = base;
-}
-void *poison_take(void *user) {
-    std::lock_guard<std::mutex> lock(g_poison_mutex);
-    auto it = g_poison_bases.find(user);
-    if (it == g_poison_bases.end()) return nullptr;
-    void *base = it->second;
-    g_poison_bases.erase(it);
-    return base;
-}
-}  // namespace f3d
-
-namespace {
-
-// ---- device memory ledger (the reference's TrackedGpu / global memory tracker) ----
-struct Ledger {
-    std::vector<void *> owned;
-    uint64_t device_bytes = 0;
-    uint64_t host_visible_peak = 0;
-    void *alloc(size_t bytes, const char *what) {
-        void *p = nullptr;
-        hip_check(device_alloc(&p, bytes), what);
-        owned.push_back(p);
-        device_bytes += bytes;
-        return p;
-    }
-    void free(void *p, size_t bytes) {  // give a buffer back before the session ends (build-time scratch)
-        for (auto it = owned.begin(); it != owned.end(); ++it)
-            if (*it == p) {
-                owned.erase(it);
-                (void)device_free(p);
-                device_bytes -= bytes;
-                return;
-            }
-    }
-    void adopt(void *p, size_t bytes) {  // take ownership of a device buffer somebody else allocated
-        owned.push_back(p);
-        device_bytes += bytes;
-    }
-    void note_host_visible(uint64_t bytes) {
-        if (bytes > host_visible_peak) host_visible_peak = bytes;
-    }
-    void release() {
-        for (void *p : owned) (void)device_free(p);
-        owned.clear();
-    }
-};
-
-// ---- acceleration tables, built on the GPU ----
-struct TerrainTables {
-    TerrainDev dev{};
-    TableLayout layout;
-    uint64_t bytes = 0;  // leaf + node tables
-    LeafRec *leaves = nullptr;
-    NodeRec *nodes = nullptr;
-    NodeRec *bands = nullptr;  // row-major (min,max) of every level (the march's table)
-};
-
-// keep_nodes: the tiled node table (levels >= 1) is the input of the band tables and of the sorted descent
-// kept for the test hook (f3d_terrain_trace_batch modes 0 / 1, f3d_build_minmax_mips); the frame kernel's
-// march reads the band tables only, so sessions give the node table back once the bands are built.
-TerrainTables build_tables(Ledger &mem, const float *d_heights, uint32_t w, uint32_t h, float exaggeration,
-                           hipStream_t stream, bool keep_nodes) {
-    TerrainTables t;
-    t.layout = table_layout(w, h);
-    const TableLayout &L = t.layout;
-    t.leaves = (LeafRec *)mem.alloc(L.leaf_count * sizeof(LeafRec), "leaf table");
-    t.nodes = (NodeRec *)mem.alloc((L.node_count ? L.node_count : 1) * sizeof(NodeRec), "node table");
-    t.bands = (NodeRec *)mem.alloc(L.band_count * sizeof(NodeRec), "band tables");
-    t.bytes = L.leaf_count * sizeof(LeafRec) + (L.node_count + L.band_count) * sizeof(NodeRec);
-    hip_check(launch_leaf_build(leaf_build_params(L, d_heights, w, h, exaggeration, t.leaves), stream),
-              "leaf table build");
-    for (uint32_t l = 1; l < L.levels; l++)
-        hip_check(launch_level_build(level_build_params(L, l, t.leaves, t.nodes), stream), "node table build");
-    for (uint32_t l = 0; l < L.levels; l++)
-        hip_check(launch_band_build(band_build_params(L, l, t.leaves, t.nodes, t.bands), stream), "band table build");
-#if !defined(F3D_TRAVERSAL_DESCENT)  // (A/B builds of the frame kernel on the sorted descent need the node table)
-    if (!keep_nodes) {
-        hip_check(hipStreamSynchronize(stream), "table build");
-        mem.free(t.nodes, (L.node_count ? L.node_count : 1) * sizeof(NodeRec));
-        t.nodes = nullptr;
-        t.bytes = L.leaf_count * sizeof(LeafRec) + L.band_count * sizeof(NodeRec);
-    }
-#endif
-    apply_layout(L, t.dev);
-    t.dev.leaves = t.leaves;
-    t.dev.nodes = t.nodes;
-    t.dev.bands = t.bands;
-    return t;
-}
-
-}  // namespace
-
-// Where session set-up spends its time (f3d_session_setup_ms; bench.py reports it beside the loop it prepares).
-enum SetupPhase { kSetupTotal = 0, kSetupValidate, kSetupHash, kSetupUpload, kSetupTables, kSetupScene, kSetupAlloc, kSetupPasses, kSetupPhases };
-struct SetupClock {
-    double *ms;
-    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
-    explicit SetupClock(double *out) : ms(out) {}
-    void lap(SetupPhase phase) {
-        const auto now = std::chrono::steady_clock::now();
-        ms[phase] += std::chrono::duration<double, std::milli>(now - last).count();
-        ms[kSetupTotal] = std::chrono::duration<double, std::milli>(now - t0).count();
-        last = now;
-    }
-};
-static thread_local double *g_setup_ms = nullptr;  // the session being created on this thread (acquire_tables laps into it)
-
-// ---------------------------------------------------------------------------------------
-// scene cache: acceleration tables of recently rendered DEMs stay on the device
-// ---------------------------------------------------------------------------------------
-// A caller rendering a camera path calls the one-shot entry point once per frame with the same DEM; rebuilding
-// 123 MB of tables (and uploading 17 MB) every time is wasted work.  Tables are immutable once built, so sessions
-// SHARE them: the cache maps (device, DEM bytes, dims, exaggeration) to a reference-counted table set and keeps
-// the most recent kSceneCacheEntries of them after their last session has gone.  A per-process cache behind a
-// mutex -- the only global state of the library besides the HIP context.
-namespace {
-
-struct CachedTables {
-    int device = 0;
-    uint64_t key = 0, key2 = 0, dem_bytes = 0;  // two independent 64-bit hashes of the DEM bytes
-    uint32_t w = 0, h = 0;
-    float exaggeration = 0.0f;
-    Ledger mem;  // owns leaf + band tables (+ the far-horizon tables)
-    TerrainTables tables;
-    uint64_t stamp = 0;
-    // far-horizon tables of the IBL rays (f3d_cone.h): they depend on the heights AND on the cell spacing, which is not
-    // part of the cache key (the band tables do not care), so one table per spacing this DEM has been rendered with
-    struct Horizon {
-        float spacing_x, spacing_z;
-        float *table;
-        uint32_t level, bx, bz;
-    };
-    std::vector<Horizon> horizons;
-    ~CachedTables() {
-        int prev = -1;
-        (void)hipGetDevice(&prev);
-        (void)hipSetDevice(device);
-        mem.release();
-        if (prev >= 0) (void)hipSetDevice(prev);
-    }
-};
-
-std::mutex g_scene_mutex;
-// deliberately never destroyed: a static destructor would call hipFree after the HIP runtime has been torn down at
-// interpreter exit (the process's memory goes back to the driver anyway)
-std::vector<std::shared_ptr<CachedTables>> &g_scene_cache = *new std::vector<std::shared_ptr<CachedTables>>();
-uint64_t g_scene_stamp = 0;
-size_t g_scene_limit = 2;  // f3d_scene_cache_limit
-
-uint64_t hash_bytes(const void *data, size_t n, uint64_t seed) {  // 8 bytes at a time, multiply-xorshift
-    const uint8_t *p = (const uint8_t *)data;
-    uint64_t h = seed ^ (n * 0x9E3779B97F4A7C15ull);
-    size_t i = 0;
-    for (; i + 8 <= n; i += 8) {
-        uint64_t v;
-        memcpy(&v, p + i, 8);
-        h = (h ^ v) * 0xFF51AFD7ED558CCDull;
-        h ^= h >> 32;
-    }
-    for (; i < n; i++) h = (h ^ p[i]) * 0x100000001B3ull;
-    return h ^ (h >> 29);
-}
-
-// Tables for this DEM on this device: from the cache, or built now (and cached when the limit allows).
-// Host -> device through the library's own pinned staging pair (two 4 MiB buffers a process, allocated on first use):
-// a pageable hipMemcpy of the 16.8 MB headline DEM took 7.3 ms the first time a process made one (the runtime sets up its
-// staging then) and the copy into pinned memory overlaps the DMA of the chunk before.
-void upload_staged(void *dst, const void *src, size_t bytes, hipStream_t stream) {
-    constexpr size_t kChunk = 4u << 20;
-    static std::mutex staging_mutex;
-    static void *staging[2] = {nullptr, nullptr};
-    static hipEvent_t drained[2] = {nullptr, nullptr};
-    std::lock_guard<std::mutex> lock(staging_mutex);
-    for (int i = 0; i < 2; i++)  // (also for a small first upload: the pair is part of a process's start-up, not of a later render)
-        if (!staging[i]) {
-            hip_check(hipHostMalloc(&staging[i], kChunk, hipHostMallocDefault), "pinned staging buffer");
-            hip_check(hipEventCreateWithFlags(&drained[i], hipEventDisableTiming), "staging event");
-        }
-    if (bytes < (256u << 10)) {  // small: one plain copy
-        hip_check(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), "upload");
-        return;
-    }
-    size_t done = 0;
-    for (int turn = 0; done < bytes; turn ^= 1) {
-        const size_t n = std::min(kChunk, bytes - done);
-        hip_check(hipEventSynchronize(drained[turn]), "staging buffer");  // (never recorded: returns at once)
-        memcpy(staging[turn], (const char *)src + done, n);
-        hip_check(hipMemcpyAsync((char *)dst + done, staging[turn], n, hipMemcpyHostToDevice, stream), "upload");
-        hip_check(hipEventRecord(drained[turn], stream), "staging event");
-        done += n;
-    }
-    hip_check(hipEventSynchronize(drained[0]), "upload");  // the staging pair is free again, the data is on its way in order
-    hip_check(hipEventSynchronize(drained[1]), "upload");
-}
-
-std::shared_ptr<CachedTables> acquire_tables(int device, const float *heights, uint32_t w, uint32_t h, float exaggeration,
-                                             hipStream_t stream, bool *was_cached, const DemFingerprint *known = nullptr) {
-    const uint64_t bytes = (uint64_t)w * h * sizeof(float);
-    double none[kSetupPhases] = {};
-    SetupClock clock(g_setup_ms ? g_setup_ms : none);
-    const DemFingerprint fp = known ? *known : dem_fingerprint(heights, (size_t)w * h);
-    const uint64_t key = hash_bytes(&exaggeration, sizeof(float), fp.key ^ ((uint64_t)w << 32 | h));
-    const uint64_t key2 = fp.key2 + 0x3c6ef372fe94f82bull * (uint64_t)w;
-    clock.lap(kSetupHash);
-    {
-        std::lock_guard<std::mutex> lock(g_scene_mutex);
-        for (auto &e : g_scene_cache)
-            if (e->device == device && e->key == key && e->key2 == key2 && e->w == w && e->h == h && e->exaggeration == exaggeration &&
-                e->dem_bytes == bytes) {
-                e->stamp = ++g_scene_stamp;
-                *was_cached = true;
-                return e;
-            }
-    }
-    *was_cached = false;
-    auto e = std::make_shared<CachedTables>();
-    e->device = device;
-    e->key = key;
-    e->key2 = key2;
-    e->dem_bytes = bytes;
-    e->w = w;
-    e->h = h;
-    e->exaggeration = exaggeration;
-    float *d_heights = (float *)e->mem.alloc(bytes, "DEM upload");
-    upload_staged(d_heights, heights, bytes, stream);  // (in stream order: the table build follows on the same stream)
-    clock.lap(kSetupUpload);
-    e->tables = build_tables(e->mem, d_heights, w, h, exaggeration, stream, false);
-    // the corner records hold every height (x exaggeration): the raw upload is build-time scratch
-    hip_check(hipStreamSynchronize(stream), "table build");
-    e->mem.free(d_heights, bytes);
-    clock.lap(kSetupTables);
-    std::lock_guard<std::mutex> lock(g_scene_mutex);
-    e->stamp = ++g_scene_stamp;
-    if (g_scene_limit > 0) {
-        g_scene_cache.push_back(e);
-        while (g_scene_cache.size() > g_scene_limit) {  // drop the least recently used (sessions holding it keep it alive)
-            size_t oldest = 0;
-            for (size_t i = 1; i < g_scene_cache.size(); i++)
-                if (g_scene_cache[i]->stamp < g_scene_cache[oldest]->stamp) oldest = i;
-            g_scene_cache.erase(g_scene_cache.begin() + (long)oldest);
-        }
-    }
-    return e;
-}
-
-}  // namespace
-
-namespace f3d {
-SharedTerrain acquire_shared_terrain(const float *heights, uint32_t w, uint32_t h, float exaggeration, hipStream_t stream) {
-    int device = 0;
-    hip_check(hipGetDevice(&device), "hipGetDevice");
-    bool was_cached = false;
-    std::shared_ptr<CachedTables> e = acquire_tables(device, heights, w, h, exaggeration, stream, &was_cached);
-    SharedTerrain out;
-    out.dev = TerrainDev{};
-    apply_layout(e->tables.layout, out.dev);
-    out.dev.leaves = e->tables.leaves;
-    out.dev.nodes = e->tables.nodes;
-    out.dev.bands = e->tables.bands;
-    out.bytes = e->mem.device_bytes;
-    out.keep = e;
-    return out;
-}
-}  // namespace f3d
+#include "f3d_host_mem.h"  // poison mode, device memory pool, ledger, acceleration tables, scene cache
 
 // ---------------------------------------------------------------------------------------
 // session
@@ -1196,151 +844,7 @@ void resolve(f3d_session &s, uint32_t frames, uint8_t *d_rgba, float *d_albedo, 
 
 }  // namespace
 
-// ---- peer halos --------------------------------------------------------------------------------------------------
-namespace {
-__global__ void k_halo_flag(uint32_t *flag, uint32_t frames_merged) {
-    __hip_atomic_store(flag, frames_merged, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-struct HaloPullParams {
-    const uint32_t *flag[2];  // the neighbours' "frames merged" counters (null: no neighbour on that side)
-    const unsigned long long *src[2];
-    unsigned long long *dst[2];
-    uint32_t words;           // 8-byte words per halo block
-    uint32_t want;            // frames the neighbour must have merged (probe: the nonce its word must hold)
-    uint32_t exact;           // 0: wait for flag >= want (frame counters only rise); 1: for flag == want (link probe)
-    uint32_t *counters;       // this strip's counter block (f3d_session::halo_flags)
-    uint32_t *publish;        // word of it to set to `want` first (the kernels of the frame are behind us on the stream); null: nothing
-    unsigned long long timeout_ticks;
-    uint32_t *checksum;       // link probe: [side] = sum of the 32-bit halves of the block pulled; null in the frame loop
-};
-// One workgroup per neighbour: wait until it has merged `want` frames, then copy its edge rows into my halo rows.
-// Every access to the neighbour's memory is a system-scope load that bypasses this device's caches.
-// The wait is timed into the counter block (words 8..13): the first multi-GPU run then says how long a strip stood here.
-// A wait that exceeds timeout_ticks gives up and counts in word 1; a strip that has timed out stops pulling for the rest of
-// the CALL that enqueued it (its halo rows are stale, the caller must fail the render: f3d_session_halo_status) -- the
-// next f3d_session_enqueue_batch_strip starts with the count cleared.
-__global__ __launch_bounds__(1024) void k_halo_pull(const HaloPullParams H) {
-    const uint32_t side = blockIdx.x;
-    if (H.publish && side == 0u && threadIdx.x == 0u) __hip_atomic_store(H.publish, H.want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (!H.flag[side]) return;
-    __shared__ uint32_t ok;
-    __shared__ uint32_t sum;
-    if (threadIdx.x == 0u) {
-        sum = 0u;
-        const unsigned long long t0 = wall_clock64();
-        ok = __hip_atomic_load(H.counters + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u ? 1u : 0u;  // a neighbour is gone: do not wait again
-        unsigned long long waited = 0ull;
-        while (ok != 0u) {
-            const uint32_t seen = __hip_atomic_load(H.flag[side], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (H.exact ? seen == H.want : seen >= H.want) break;
-            __builtin_amdgcn_s_sleep(16);
-            waited = wall_clock64() - t0;
-            if (waited > H.timeout_ticks) {  // the neighbour is gone
-                ok = 0u;
-                atomicAdd(H.counters + 1, 1u);
-            }
-        }
-        atomicAdd(reinterpret_cast<unsigned long long *>(H.counters + 8) + side, waited);
-        atomicAdd(H.counters + 12, 1u);
-        atomicMax(H.counters + 13, (uint32_t)(waited > 0xFFFFFFFFull ? 0xFFFFFFFFull : waited));
-    }
-    __syncthreads();
-    if (ok == 0u) return;
-    uint32_t part = 0u;
-    for (uint32_t i = threadIdx.x; i < H.words; i += blockDim.x) {
-        const unsigned long long v = __hip_atomic_load(H.src[side] + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        H.dst[side][i] = v;
-        part += (uint32_t)v + (uint32_t)(v >> 32);
-    }
-    if (H.checksum) {
-        atomicAdd(&sum, part);
-        __syncthreads();
-        if (threadIdx.x == 0u) H.checksum[side] = sum;
-    }
-}
-
-// Link probe with a REAL block (f3d_session_halo_probe modes 2 / 3): a strip fills its two edge blocks of reservoir buffer
-// 0 with a pattern of its nonce -- a kernel of many workgroups, so the lines are dirty in the L2 of every XCD, as the
-// frame kernels leave them -- and publishes the nonce behind it; its neighbours wait for the nonce and pull the block with
-// the frame loop's own kernel, which also sums it.  A stale line, a mapping of the wrong buffer or an edge-row offset that
-// is off by a row shows as a checksum that is not the pattern's.
-__host__ __device__ inline uint32_t halo_probe_word(uint32_t nonce, uint32_t index) {  // 32-bit half `index` of the buffer
-    uint32_t x = nonce ^ (index * 0x9E3779B9u);
-    x ^= x >> 15;
-    x *= 0x2C1B3C6Du;
-    x ^= x >> 12;
-    return x;
-}
-__global__ void k_halo_probe_fill(uint32_t *buffer, uint32_t first, uint32_t count, uint32_t nonce) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) buffer[first + i] = halo_probe_word(nonce, first + i);
-}
-
-// Link check (f3d_session_halo_probe): word 2 of a strip's counter block is a nonce its owner stores and its
-// neighbours read back, with the accesses the frame loop uses.
-__global__ void k_halo_probe_read(const uint32_t *above, const uint32_t *below, uint32_t *out) {
-    out[0] = above ? __hip_atomic_load(above + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
-    out[1] = below ? __hip_atomic_load(below + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
-}
-
-void enqueue_halo_sync(f3d_session &s, uint32_t frame) {  // behind the kernels of `frame`
-    if (!s.peer[0].connected && !s.peer[1].connected) {  // nobody to pull from: publish only
-        hipLaunchKernelGGL(k_halo_flag, dim3(1), dim3(1), 0, s.stream, s.halo_flags, frame + 1u);
-        return;
-    }
-    HaloPullParams H{};  // one launch: publish my counter, then wait for and copy the neighbours' rows
-    H.publish = s.halo_flags;
-    H.counters = s.halo_flags;
-    H.timeout_ticks = s.halo_timeout_ticks;
-    const size_t row = (size_t)s.width, block = (size_t)kHaloRows * row;
-    const uint32_t which = frame & 1u;
-    H.words = (uint32_t)(block * sizeof(PackedReservoir) / 8u);
-    H.want = frame + 1u;
-    if (s.peer[0].connected) {  // the strip above: its BOTTOM owned rows -> my halo above
-        H.flag[0] = s.peer[0].flags;
-        H.src[0] = (const unsigned long long *)(s.peer[0].res[which] + (size_t)s.peer[0].rows * row);
-        H.dst[0] = (unsigned long long *)(s.res[which]);
-    }
-    if (s.peer[1].connected) {  // the strip below: its TOP owned rows -> my halo below
-        H.flag[1] = s.peer[1].flags;
-        H.src[1] = (const unsigned long long *)(s.peer[1].res[which] + block);
-        H.dst[1] = (unsigned long long *)(s.res[which] + ((size_t)s.rows + kHaloRows) * row);
-    }
-    hipLaunchKernelGGL(k_halo_pull, dim3(2), dim3(1024), 0, s.stream, H);
-    hip_check(hipGetLastError(), "halo pull kernel");
-}
-
-// Frames [first, first + count) of a strip whose neighbours are connected: enqueue_range with the halo step after
-// every frame.
-void enqueue_batch_strip(f3d_session &s, uint32_t first, uint32_t count, bool collect_last) {
-    if (!s.halo_flags) fail(F3D_STATUS_VALUE, "f3d_session_halo_export has not been called for this session");
-    // The neighbours wait for `counter >= frame + 1` on a counter that is never cleared: frames of a connected session only
-    // go up (a second pass over frames 0.. would find the neighbours' counters high already and pull rows of the wrong frame).
-    if (first < s.halo_frames_published)
-        fail(F3D_STATUS_VALUE, "peer halos: frame %u was enqueued before (this strip has published %u frames); frame numbers of a connected session only rise",
-             first, s.halo_frames_published);
-    s.halo_frames_published = first + count;
-    hip_check(hipMemsetAsync(s.halo_flags + 1, 0, sizeof(uint32_t), s.stream), "halo time-out count");  // a new call waits again
-    if (s.fd_frames) {
-        for (uint32_t done = 0; done < count;) {
-            const uint32_t n = trace_batch(s, first + done, count - done);
-            enqueue_trace(s, first + done, n);
-            for (uint32_t i = 0; i < n; i++) {
-                enqueue_merge(s, first + done + i, collect_last && done + i + 1 == count);
-                enqueue_halo_sync(s, first + done + i);
-            }
-            done += n;
-        }
-        return;
-    }
-    for (uint32_t i = 0; i < count; i++) {
-        fork_bands(s, collect_last && i + 1 == count);
-        enqueue_frame(s, first + i, collect_last && i + 1 == count, 0u, false);
-        join_bands(s);
-        enqueue_halo_sync(s, first + i);
-    }
-}
-}  // namespace
+#include "f3d_host_halo.h"  // peer halos: the pull kernel, the batch enqueue and their C ABI
 
 // ---------------------------------------------------------------------------------------
 // C ABI
@@ -1433,200 +937,6 @@ int f3d_session_window_stats(f3d_session *s, float *max_m2, int32_t *nonfinite, 
         if (max_m2) *max_m2 = f_from_bits(s->host_stats[0]);
         if (nonfinite) *nonfinite = s->host_stats[1] != 0u;
     });
-}
-
-int f3d_session_halo_export(f3d_session *s, f3d_halo_export *out, char *err, size_t errlen) {
-    return c_abi(err, errlen, [&] {
-        DeviceGuard g(checked(s).device);
-        if (!out) fail(F3D_STATUS_VALUE, "null export record");
-        if (!s->owns_reservoirs) fail(F3D_STATUS_VALUE, "peer halos need reservoirs owned by the session (no ext_reservoirs)");
-        if (!s->halo_flags) {
-            hip_check(hipMalloc((void **)&s->halo_flags, 256), "halo counters");
-            hip_check(hipMemset(s->halo_flags, 0, 256), "halo counters");
-            int khz = 0;  // the clock wall_clock64() counts (100 MHz on gfx950)
-            if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, s->device) == hipSuccess && khz > 0) s->wall_clock_khz = (double)khz;
-            (void)hipGetLastError();
-            double ms = 20000.0;  // a neighbour that is merely slow (first-launch code load, a profiler, a shared GPU) is not gone
-            if (const char *e = getenv("F3D_HALO_TIMEOUT_MS")) ms = atof(e) > 0.0 ? atof(e) : ms;
-            s->halo_timeout_ticks = (unsigned long long)(ms * s->wall_clock_khz);
-        }
-        memset(out, 0, sizeof(*out));
-        void *objects[3] = {s->res[0], s->res[1], s->halo_flags};
-        for (int i = 0; i < 3; i++) {
-            void *base = nullptr;
-            size_t size = 0;
-            hip_check(hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)objects[i]), "allocation of a halo object");
-            hipIpcMemHandle_t h;
-            hip_check(hipIpcGetMemHandle(&h, base), "hipIpcGetMemHandle");
-            static_assert(sizeof(h) == 64, "hipIpcMemHandle_t is 64 bytes");
-            memcpy(out->handle[i], &h, 64);
-            out->offset[i] = (uint64_t)((char *)objects[i] - (char *)base);
-            out->address[i] = (uint64_t)(uintptr_t)objects[i];
-        }
-        out->rows = s->rows;
-        out->width = s->width;
-        out->device = s->device;
-        out->pid = (uint32_t)getpid();
-        hip_check(hipStreamSynchronize(s->stream), "export sync");
-    });
-}
-
-int f3d_session_halo_connect(f3d_session *s, int32_t side, const f3d_halo_export *peer, char *err, size_t errlen) {
-    return c_abi(err, errlen, [&] {
-        DeviceGuard g(checked(s).device);
-        if (side < 0 || side > 1 || !peer) fail(F3D_STATUS_VALUE, "halo connect: side must be 0 (above) or 1 (below)");
-        if (peer->width != s->width) fail(F3D_STATUS_VALUE, "halo connect: the neighbour renders another image width");
-        if (!s->halo_flags) fail(F3D_STATUS_VALUE, "f3d_session_halo_export has not been called for this session");
-        f3d_session::PeerLink &L = s->peer[side];
-        if (L.connected) fail(F3D_STATUS_VALUE, "halo connect: side %d is connected already", side);
-        void *mapped[3];
-        for (int i = 0; i < 3; i++) {
-            hipIpcMemHandle_t h;
-            memcpy(&h, peer->handle[i], 64);
-            void *base = nullptr;
-            if (peer->pid == (uint32_t)getpid()) {
-                mapped[i] = (void *)(uintptr_t)peer->address[i];  // a process cannot open its own handles: same address space
-                if (peer->device != s->device) {  // (one process driving several GPUs: map the neighbour's memory here)
-                    const hipError_t e = hipDeviceEnablePeerAccess(peer->device, 0);
-                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) hip_check(e, "hipDeviceEnablePeerAccess");
-                    (void)hipGetLastError();
-                }
-                continue;
-            } else {
-                hip_check(hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess), "hipIpcOpenMemHandle");
-                L.opened[i] = base;
-            }
-            mapped[i] = (char *)base + peer->offset[i];
-        }
-        L.res[0] = (const PackedReservoir *)mapped[0];
-        L.res[1] = (const PackedReservoir *)mapped[1];
-        L.flags = (const uint32_t *)mapped[2];
-        L.rows = peer->rows;
-        L.connected = true;
-    });
-}
-
-int f3d_session_halo_probe(f3d_session *s, int32_t mode, uint32_t nonce, uint32_t *seen, char *err, size_t errlen) {
-    return c_abi(err, errlen, [&] {
-        DeviceGuard g(checked(s).device);
-        if (!s->halo_flags) fail(F3D_STATUS_VALUE, "f3d_session_halo_export has not been called for this session");
-        if (mode == 0) {  // publish: the store the frame loop uses for its counter
-            hipLaunchKernelGGL(k_halo_flag, dim3(1), dim3(1), 0, s->stream, s->halo_flags + 2, nonce);
-            hip_check(hipStreamSynchronize(s->stream), "halo probe store");
-        } else if (mode == 1) {  // read the neighbours' words with the loads the pull uses
-            if (!seen) fail(F3D_STATUS_VALUE, "null output");
-            hipLaunchKernelGGL(k_halo_probe_read, dim3(1), dim3(1), 0, s->stream, s->peer[0].connected ? s->peer[0].flags : nullptr,
-                               s->peer[1].connected ? s->peer[1].flags : nullptr, s->halo_flags + 4);
-            hip_check(hipStreamSynchronize(s->stream), "halo probe load");
-            hip_check(hipMemcpy(seen, s->halo_flags + 4, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost), "halo probe read-back");
-        } else if (mode == 2) {  // fill my two edge blocks of buffer 0 with the pattern of `nonce`, then publish it
-            const uint32_t row_words = s->width * (uint32_t)(sizeof(PackedReservoir) / 4u), block_words = kHaloRows * row_words;
-            uint32_t *buf = reinterpret_cast<uint32_t *>(s->res[0]);
-            for (uint32_t first_row : {kHaloRows, s->rows})  // top owned rows, bottom owned rows (they overlap in strips of < 8 rows: one pattern)
-                hipLaunchKernelGGL(k_halo_probe_fill, dim3((block_words + 255u) / 256u), dim3(256), 0, s->stream, buf, first_row * row_words, block_words, nonce);
-            hipLaunchKernelGGL(k_halo_flag, dim3(1), dim3(1), 0, s->stream, s->halo_flags + 2, nonce);
-            hip_check(hipGetLastError(), "halo probe fill");
-        } else if (mode == 3) {  // pull the neighbours' blocks (they publish seen[0] above / seen[1] below) and check their sums
-            if (!seen) fail(F3D_STATUS_VALUE, "null nonces");
-            HaloPullParams H{};
-            H.counters = s->halo_flags;
-            H.timeout_ticks = s->halo_timeout_ticks;
-            H.exact = 1u;
-            H.checksum = s->halo_flags + 6;
-            const size_t row = (size_t)s->width, block = (size_t)kHaloRows * row;
-            const uint32_t row_words = s->width * (uint32_t)(sizeof(PackedReservoir) / 4u), block_words = kHaloRows * row_words;
-            H.words = (uint32_t)(block * sizeof(PackedReservoir) / 8u);
-            uint32_t expect[2] = {0u, 0u};
-            bool ok = true;
-            for (int side = 0; side < 2; side++) {  // one launch per side: each waits for its own neighbour's nonce
-                if (!s->peer[side].connected) continue;
-                HaloPullParams one = H;
-                one.want = seen[side];
-                const uint32_t first_row = side == 0 ? s->peer[0].rows : kHaloRows;  // the neighbour's bottom / top owned rows
-                one.flag[side] = s->peer[side].flags + 2;
-                one.src[side] = (const unsigned long long *)(s->peer[side].res[0] + (size_t)first_row * row);
-                one.dst[side] = (unsigned long long *)(s->res[0] + (side == 0 ? 0 : ((size_t)s->rows + kHaloRows) * row));
-                hipLaunchKernelGGL(k_halo_pull, dim3(2), dim3(1024), 0, s->stream, one);
-                for (uint32_t i = 0; i < block_words; i++) expect[side] += halo_probe_word(seen[side], first_row * row_words + i);
-            }
-            hip_check(hipStreamSynchronize(s->stream), "halo probe pull");
-            uint32_t got[8];
-            hip_check(hipMemcpy(got, s->halo_flags, sizeof(got), hipMemcpyDeviceToHost), "halo probe read-back");
-            for (int side = 0; side < 2; side++) {
-                if (!s->peer[side].connected) continue;
-                if (got[1] != 0u || got[6 + side] != expect[side]) ok = false;
-                seen[side] = got[6 + side] == expect[side] ? 1u : 0u;
-            }
-            hip_check(hipMemsetAsync(s->halo_flags + 1, 0, sizeof(uint32_t), s->stream), "halo time-out count");
-            hip_check(hipStreamSynchronize(s->stream), "halo probe pull");
-            if (!ok)
-                fail(F3D_STATUS_DEVICE, "peer halos: the block pulled from a neighbouring strip is not the block it wrote (sums above %08x / %08x, below %08x / %08x, %u time-outs)",
-                     got[6], expect[0], got[7], expect[1], got[1]);
-        } else if (mode == 4) {  // the probes wrote into reservoir buffer 0 (edge rows in mode 2, halo rows in mode 3): as a new session has it
-            const size_t row = (size_t)s->width;
-            hip_check(hipMemsetAsync(s->res[0], 0, ((size_t)s->rows + 2u * kHaloRows) * row * sizeof(PackedReservoir), s->stream), "reservoir clear");
-            hip_check(hipStreamSynchronize(s->stream), "halo probe clear");
-        } else {
-            fail(F3D_STATUS_VALUE, "halo probe: mode must be 0 (publish), 1 (read), 2 (fill + publish a block), 3 (pull + check the blocks) or 4 (clear)");
-        }
-    });
-}
-
-int f3d_session_halo_stats(f3d_session *s, f3d_halo_stats *out, char *err, size_t errlen) {
-    return c_abi(err, errlen, [&] {
-        DeviceGuard g(checked(s).device);
-        if (!out) fail(F3D_STATUS_VALUE, "null output");
-        const bool reset = out->reset != 0u;
-        memset(out, 0, sizeof(*out));
-        if (!s->halo_flags) return;
-        hip_check(hipStreamSynchronize(s->stream), "halo stats");
-        uint32_t w[16];
-        hip_check(hipMemcpy(w, s->halo_flags, sizeof(w), hipMemcpyDeviceToHost), "halo stats");
-        const double ms_per_tick = 1.0 / s->wall_clock_khz;
-        out->frames_published = w[0];
-        out->timeouts = w[1];
-        out->pulls = w[12];
-        out->wait_ms[0] = (double)(((unsigned long long)w[9] << 32) | w[8]) * ms_per_tick;
-        out->wait_ms[1] = (double)(((unsigned long long)w[11] << 32) | w[10]) * ms_per_tick;
-        out->longest_wait_ms = (double)w[13] * ms_per_tick;
-        out->timeout_ms = (double)s->halo_timeout_ticks * ms_per_tick;
-        if (reset) hip_check(hipMemsetAsync(s->halo_flags + 8, 0, 6 * sizeof(uint32_t), s->stream), "halo stats reset");
-    });
-}
-
-int f3d_session_halo_status(f3d_session *s, uint32_t *timeouts, char *err, size_t errlen) {
-    return c_abi(err, errlen, [&] {
-        DeviceGuard g(checked(s).device);
-        if (!timeouts) fail(F3D_STATUS_VALUE, "null output");
-        *timeouts = 0u;
-        if (s->halo_flags) {
-            hip_check(hipStreamSynchronize(s->stream), "halo status");
-            hip_check(hipMemcpy(timeouts, s->halo_flags + 1, sizeof(uint32_t), hipMemcpyDeviceToHost), "halo status");
-        }
-    });
-}
-
-int f3d_session_enqueue_batch_strip(f3d_session *s, uint32_t first_frame, uint32_t count, int32_t collect_stats_on_last, char *err,
-                                    size_t errlen) {
-    return c_abi(err, errlen, [&] {
-        DeviceGuard g(checked(s).device);
-        enqueue_batch_strip(*s, first_frame, count, collect_stats_on_last != 0);
-    });
-}
-
-int f3d_session_halo(f3d_session *s, int32_t which, int32_t side, void **ptr, uint64_t *bytes) {
-    if (!s || !ptr || !bytes || which < 0 || which > 1 || side < 0 || side > 3) return F3D_STATUS_VALUE;
-    const size_t row = (size_t)s->width;
-    size_t first;
-    switch (side) {
-        case 0: first = kHaloRows; break;                 // top owned rows
-        case 1: first = s->rows; break;                   // bottom owned rows
-        case 2: first = 0; break;                         // halo above
-        default: first = (size_t)s->rows + kHaloRows; break;  // halo below
-    }
-    *ptr = (void *)(s->res[which] + first * row);
-    *bytes = (uint64_t)kHaloRows * row * sizeof(PackedReservoir);
-    return F3D_STATUS_OK;
 }
 
 int f3d_session_set_accumulation(f3d_session *s, const float *sums_rgba, char *err, size_t errlen) {
