@@ -118,7 +118,9 @@ def _check_against_one_strip(multi, world, in_flight, peer_halos, height):
     assert info["peer_halos"] == peer_halos and info["halo_timeouts"] == 0, info.get("peer_halo_failure")
     if in_flight is not None:
         assert info["in_flight"] == in_flight  # 6: batches traced in one launch, halos exchanged between the merges
-    assert info["balance_rounds"] >= 2 and info["bounds"][0] == 0 and info["bounds"][-1] == height and len(info["bounds"]) == world + 1
+    # (>= 1: the measured loop stops as soon as a re-partition from the gathered times repeats the boundaries it timed --
+    # with noisy one-GPU timings that is sometimes the equal split itself, seen 2 in ~40 runs)
+    assert info["balance_rounds"] >= 1 and info["bounds"][0] == 0 and info["bounds"][-1] == height and len(info["bounds"]) == world + 1
     if peer_halos:  # rank 0 pulls from the strip below it only: one block per frame, and the waits were timed
         assert info["halo"]["pulls"] == 34 and info["halo"]["timeouts"] == 0 and info["halo"]["frames_published"] == 34
         assert info["halo"]["wait_ms"][0] == 0.0 and info["halo"]["longest_wait_ms"] < info["halo"]["timeout_ms"]
