@@ -414,7 +414,7 @@ inline std::vector<Bvh4Node> collapse_bvh4(const MeshBvh &bvh) {
         rec.inner = inner;
         for (uint32_t k = 0; k < inner; k++) todo.push_back(Item{order[k], first_child + k, it.level + 1u});
     }
-    if (too_deep || out.size() >= (1u << 27)) out.clear();  // (the stack word holds first_child in 28 bits)
+    if (too_deep || out.size() >= (1u << 23)) out.clear();  // (the stack word holds first_child in 24 bits: f3d_shade.h mesh_bvh4)
     return out;
 }
 

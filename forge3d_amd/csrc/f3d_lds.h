@@ -30,7 +30,8 @@ constexpr int kBoardRow = kParkRow + kParkHead + 1;  // verdict board of the ray
 constexpr uint32_t kBoardBit = 0x80000000u;
 constexpr int kLdsRows = kParkRow + kParkWords > kMaxLevels ? kParkRow + kParkWords : kMaxLevels;
 constexpr int kLdsWords = kLdsRows * kWave + 4 * kMaxLevels;
-struct LdsPending {
+template <int BOARD_ROW>
+struct LdsPendingAt {
     // may the scene hold a mesh?  (closest_hit / occluded, f3d_shade.h: the terrain-only frame kernels are compiled without
     // the mesh walk, so nothing the mesh path needs can move their register allocation -- and the other way round)
     static constexpr bool kMesh = true;
@@ -93,9 +94,9 @@ struct LdsPending {
     // is an LDS pointer by TYPE: address-space inference skips volatile accesses, and as generic ones they were flat_load /
     // flat_store through a 64-bit address that sat in scratch)
     using LdsWord = __attribute__((address_space(3))) volatile uint32_t;
-    __device__ __forceinline__ LdsWord *board() const { return (LdsWord *)(col - lane() + kBoardRow * kWave); }
+    __device__ __forceinline__ LdsWord *board() const { return (LdsWord *)(col - lane() + BOARD_ROW * kWave); }
     __device__ __forceinline__ void verdict_post(bool hit) const {  // every lane, before any verdict_set of the call
-        LdsWord *mine = (LdsWord *)(col + kBoardRow * kWave);
+        LdsWord *mine = (LdsWord *)(col + BOARD_ROW * kWave);
         const uint32_t w = *mine;
         *mine = hit ? w | kBoardBit : w & ~kBoardBit;
     }
@@ -127,6 +128,12 @@ struct LdsPending {
         tiles_x = e.y;
     }
 };
+using LdsPending = LdsPendingAt<kBoardRow>;
+// The PBR path tracer's terrain primitive parks nothing: leaf FIFO rows, then the board's row, then the level table --
+// 4 352 bytes a wave, four of the 1 280-byte pieces LDS is handed out in, so that eight waves fit a SIMD (f3d_wavefront.hip).
+constexpr int kCompactRows = kParkRow + 1;
+constexpr int kCompactLdsWords = kCompactRows * kWave + 4 * kMaxLevels;
+using LdsPendingCompact = LdsPendingAt<kParkRow>;
 // rows: lane-column rows in front of the level table (the occlusion-stream kernels need the leaf FIFO only)
 struct LdsPendingTerrainOnly : LdsPending {
     static constexpr bool kMesh = false;
@@ -140,7 +147,8 @@ struct PendingFor<false> {
     using type = LdsPendingTerrainOnly;
 };
 
-__device__ __forceinline__ LdsPending make_pending(uint32_t *lds, const TerrainDev &T, uint32_t rows = kLdsRows) {
+template <class Pending = LdsPending>
+__device__ __forceinline__ Pending make_pending(uint32_t *lds, const TerrainDev &T, uint32_t rows = kLdsRows) {
     const uint32_t lane = threadIdx.x & (kWave - 1u);  // `lds` is this WAVE's block (workgroups may hold several)
     if (lane < kMaxLevels) {
         uint32_t *e = lds + rows * kWave + 4 * lane;
@@ -150,9 +158,8 @@ __device__ __forceinline__ LdsPending make_pending(uint32_t *lds, const TerrainD
         e[3] = T.tiles_x[lane];
     }
     __syncthreads();
-    return LdsPending{lds + lane, lds + rows * kWave, T.leaf_quorum ? T.leaf_quorum : kDefaultLeafQuorum,
-                      T.share_below ? (T.share_below < 64u ? T.share_below : 64u) : kShareBelow};
+    return Pending{lds + lane, lds + rows * kWave, T.leaf_quorum ? T.leaf_quorum : kDefaultLeafQuorum,
+                   T.share_below ? (T.share_below < 64u ? T.share_below : 64u) : kShareBelow};
 }
-
 
 }  // namespace f3d

@@ -40,12 +40,19 @@ struct WfParams {
 #ifndef F3D_WF_WAVES
 #define F3D_WF_WAVES 4
 #endif
+// The instantiation with the heightfield primitive waits for scattered table records more than it computes: six waves a SIMD
+// at 80 registers and 284 bytes of spills beat four at 128 and 92 (C3 GI, 1080p x 32 paths: 4 / 5 / 6 / 7 / 8 waves ->
+// 23.6 / 22.9 / 22.1 / 21.8-22.7 / 22.2-22.4 ms; its LDS block is the compact one of f3d_lds.h so that the waves fit).  Without
+// the primitive the BLAS walk's spills decide: 4 / 5 / 6 -> 137.6 / 178.6 / 203.8 ms at the adjudication gate.
+#ifndef F3D_WF_WAVES_TERRAIN
+#define F3D_WF_WAVES_TERRAIN 6
+#endif
 template <bool TERRAIN>  // scenes with the heightfield primitive (f3d_wf_path.h) run their own instantiation
-__global__ __launch_bounds__(64, F3D_WF_WAVES) void k_wf_paths(const WfParams P) {
+__global__ __launch_bounds__(64, TERRAIN ? F3D_WF_WAVES_TERRAIN : F3D_WF_WAVES) void k_wf_paths(const WfParams P) {
     // traversal context of the terrain march (f3d_lds.h)
-    __shared__ __attribute__((aligned(16))) uint32_t lds[TERRAIN ? kLdsWords : 1];
-    LdsPending pend{};
-    if (TERRAIN) pend = make_pending(lds, P.S.terrain);
+    __shared__ __attribute__((aligned(16))) uint32_t lds[TERRAIN ? kCompactLdsWords : 1];
+    LdsPendingCompact pend{};
+    if (TERRAIN) pend = make_pending<LdsPendingCompact>(lds, P.S.terrain, kCompactRows);
     const uint32_t tiles_x = (P.S.width + 7u) / 8u, tiles = tiles_x * ((P.S.height + 7u) / 8u);
     const uint32_t tile = blockIdx.x % tiles, group = blockIdx.x / tiles;
     const uint32_t x = (tile % tiles_x) * 8u + (threadIdx.x & 7u), y = (tile / tiles_x) * 8u + (threadIdx.x >> 3);
@@ -56,7 +63,7 @@ __global__ __launch_bounds__(64, F3D_WF_WAVES) void k_wf_paths(const WfParams P)
         const uint32_t n = P.count - begin < P.frames_per_lane ? P.count - begin : P.frames_per_lane;
         float4 *out = P.totals + (size_t)begin * pixels + pixel;
         const uint32_t first = P.first + begin;
-        vertices = wf::trace_frames(P.S, pixel, first, n, wf::HipWave<LdsPending, TERRAIN>{&pend}, [&](uint32_t frame, V3 total) {
+        vertices = wf::trace_frames(P.S, pixel, first, n, wf::HipWave<LdsPendingCompact, TERRAIN>{&pend}, [&](uint32_t frame, V3 total) {
             out[(size_t)(frame - first) * pixels] = float4{total.x, total.y, total.z, 0.0f};
         });
     }

@@ -582,6 +582,15 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
         acc = acc + mix3(S.env_ground, S.env_sky, 0.5f * (back.y + 1.0f)) * (1.0f - mtrans);
     }
 
+    // Next-event estimation.  The three candidates are SAMPLED here, in the reference's order (the random numbers are drawn in
+    // that order), but their shadow rays are traced at the end of the vertex, after the continuation has been sampled:
+    // shadowed() draws no random numbers and the contributions are added in the same order as before, so every result is
+    // unchanged -- and the march of a shadow ray then runs with the vertex's BSDF state (material, frame, half of the hit
+    // record) dead instead of live across it, through ONE copy of the march code instead of three.
+    const V3 zero3{0.0f, 0.0f, 0.0f};
+    V3 env_wi = zero3, env_c = zero3, dir_wi = zero3, dir_c = zero3, area_wi = zero3, area_c = zero3;
+    uint32_t nee_on = 0u;
+    float area_tmax = 1e30f;
     {  // environment, mixture of a power-cosine lobe about +Y and the cosine hemisphere, balance heuristic
         const float u1 = rng_next(rng), u2 = rng_next(rng), u3 = rng_next(rng);
         V3 wi;
@@ -602,8 +611,9 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
             const Bsdf br = bsdf_eval(M, wo, wi, n);
             const float w_mis = pdf_light / f_max(pdf_light + br.pdf, 1e-8f);
             const float k = (((cos_surf / f_max(pdf_light, 1e-8f)) * w_mis) * M.imp) * mtrans;
-            const V3 contrib = ((P.thr * br.f) * L_env) * k;
-            if (!shadowed(S, so, wi, 1e-3f, 1e30f, wave)) acc = acc + contrib;
+            env_c = ((P.thr * br.f) * L_env) * k;
+            env_wi = wi;
+            nee_on |= 1u;
         }
     }
     if (S.dir_count > 0u) {  // delta lights: weight 1
@@ -614,8 +624,9 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
             const Bsdf br = bsdf_eval(M, wo, L.wi, n);
             const float p_sel = S.dir_sum_imp > 0.0f ? L.importance / f_max(S.dir_sum_imp, 1e-8f) : 1.0f / (float)S.dir_count;
             const float k = ((cos_surf / f_max(p_sel, 1e-8f)) * M.imp) * mtrans;
-            const V3 contrib = ((P.thr * br.f) * L.Li) * k;
-            if (!shadowed(S, so, L.wi, 1e-3f, 1e30f, wave)) acc = acc + contrib;
+            dir_c = ((P.thr * br.f) * L.Li) * k;
+            dir_wi = L.wi;
+            nee_on |= 2u;
         }
     }
     if (S.area_count > 0u) {  // discs, sampled uniformly by area, balance heuristic
@@ -639,13 +650,16 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
                     const float pdf_light = p_sel * pdf;
                     const float w_mis = pdf_light / f_max(pdf_light + br.pdf, 1e-8f);
                     const float k = (((cos_surf / f_max(pdf_light, 1e-8f)) * w_mis) * M.imp) * mtrans;
-                    const V3 contrib = ((P.thr * br.f) * L.Li) * k;
-                    if (!shadowed(S, so, wi, 1e-3f, dist - 1e-3f, wave)) acc = acc + contrib;
+                    area_c = ((P.thr * br.f) * L.Li) * k;
+                    area_wi = wi;
+                    area_tmax = dist - 1e-3f;
+                    nee_on |= 4u;
                 }
             }
         }
     }
 
+    const bool go_on = [&]() -> bool {
     V3 wi, thr;
     if (H.hair) {  // Kajiya-Kay, :708-729: cosine-hemisphere continuation weighted by a diffuse term and two lobes about the strand
         const V3 T = normalize(H.tangent);
@@ -730,6 +744,19 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
     P.depth = P.depth + 1u;
     P.rng_hi = rng;
     return true;
+    }();
+    // the deferred shadow rays (pt_shadow.wgsl main): every lane takes ITS next one, in the order their contributions were
+    // added before (environment, directional, area), until no lane of the wave has one left
+    while (wave.count(nee_on != 0u) != 0u) {
+        if (nee_on != 0u) {
+            const uint32_t k = (uint32_t)__builtin_ctz(nee_on);
+            nee_on &= nee_on - 1u;
+            const V3 wi = k == 0u ? env_wi : (k == 1u ? dir_wi : area_wi);
+            const V3 c = k == 0u ? env_c : (k == 1u ? dir_c : area_c);
+            if (!shadowed(S, so, wi, 1e-3f, k == 2u ? area_tmax : 1e30f, wave)) acc = acc + c;
+        }
+    }
+    return go_on;
 }
 
 // How many lanes of the wave could use another closest-hit attempt (the host "wave" is one lane wide), and the
@@ -757,13 +784,16 @@ struct HipWave {
 // same pass, so the lanes of a wave never wait for the longest path of a frame.  It is also TWO-PHASE: about half of
 // all closest-hit queries are misses (every path ends with one), and a miss costs a sixth of a surface vertex; so the
 // cheap phase (camera ray, closest hit, background) is repeated for the lanes without a pending surface hit for as
-// long as at least `kRefill` of them can still use it, and only then do the lanes with a hit run the expensive phase
-// together.  Measured at the adjudication gate: 146 ms without refills, 131 ms with kRefill 6...20, 141 ms at 48.  Each lane's own
+// long as at least F3D_WF_REFILL of them can still use it, and only then do the lanes with a hit run the expensive phase
+// together.  Measured at the adjudication gate: 146 ms without refills, 131 ms with a threshold of 6...20, 141 ms at 48.  Each lane's own
 // sequence of operations -- and therefore every result -- is the same for any wave width or refill threshold.
+// With the heightfield primitive (BASELINE configs[2], six waves a SIMD): 8 (20 / 12 / 8 / 4 -> 23.3 / 22.8 / 22.9 / 22.8 ms).
 #ifndef F3D_WF_REFILL
 #define F3D_WF_REFILL 20
 #endif
-constexpr uint32_t kRefill = F3D_WF_REFILL;
+#ifndef F3D_WF_REFILL_TERRAIN
+#define F3D_WF_REFILL_TERRAIN 8
+#endif
 
 template <class Wave, class Sink>
 F3D_HD uint32_t trace_frames(const SceneDev &S, uint32_t pixel, uint32_t first, uint32_t count, Wave wave, Sink &&sink) {
@@ -799,7 +829,7 @@ F3D_HD uint32_t trace_frames(const SceneDev &S, uint32_t pixel, uint32_t first, 
                     fresh = true;
                 }
             }
-            if (wave.count(!pending && frame < end) < kRefill) break;
+            if (wave.count(!pending && frame < end) < (Wave::kTerrain ? (uint32_t)F3D_WF_REFILL_TERRAIN : (uint32_t)F3D_WF_REFILL)) break;
         }
         if (wave.count(pending) == 0u) {
             if (wave.count(frame < end) == 0u) break;

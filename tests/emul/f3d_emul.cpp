@@ -285,6 +285,15 @@ HostTables build_tables_host(const float *heights, uint32_t w, uint32_t h, float
 // primaries re-traced until every sample started from the right stream state, contributions
 // replayed in sample order.  Same helpers (sample_primary / sample_shade / accumulate_sample) as
 // the device code, so the CPU parity tests pin the speculation scheme against the oracle.
+#if defined(F3D_MESH_STATS_HOST)  // statistics build (F3D_EMUL_CXXFLAGS=-DF3D_MESH_STATS_HOST): tools/experiments/bvh4_order.py
+namespace f3d { unsigned long long g_host_mesh_stats[8]; }
+extern "C" void emul_mesh_stats(unsigned long long *out, int32_t reset) {
+    for (int i = 0; i < 8; i++) {
+        out[i] = g_host_mesh_stats[i];
+        if (reset) g_host_mesh_stats[i] = 0ull;
+    }
+}
+#endif
 static int g_use_bvh = 2;  // 0: the reference's sweep over all triangles (A/B of the BVH itself); 1: the threaded binary walk; 2: four children wide (the product's default)
 static uint32_t g_sample_lanes = 1u;
 static uint64_t g_retraces = 0;  // primaries traced a second time (statistics for the tests)

@@ -3,6 +3,7 @@
 
     python tools/config_workload.py C4          4096 x 4096, proxy DEM + 600 000 triangles, 8 spp x 6 frames  (k_frame<0,6,4,true>)
     python tools/config_workload.py C3_gi       1080p, proxy DEM in the PBR path tracer, 32 paths a pixel       (k_wf_paths<true>)
+    python tools/config_workload.py gate        the adjudication scene of the PBR tracer, 512 x 512 x 4096 frames              (k_wf_paths<false>)
     python tools/config_workload.py C5          8 frames of the smoke sequence at 1080p: solver step + march + composite
     python tools/config_workload.py strip       the heaviest eighth of the 1080p headline frame, 16 frames in flight, 48 frames
     python tools/config_workload.py strip_fused the same strip with the fused kernel (k_frame<0,6,8,false>)
@@ -43,6 +44,11 @@ elif what == "C3_gi":
              sun_intensity=kw["sun_intensity"], memory_budget_bytes=8 << 30)
     gi = offline.render_terrain_gi(dem, 1920, 1080, cam, spp=32, **k)
     print("gi loop ms", gi["gi_seconds"] * 1e3)
+elif what == "gate":  # the adjudication gate's path-traced half (no terrain primitive: k_wf_paths<false>), 512^2 x 4096 frames
+    from forge3d_amd import wavefront as w
+
+    best = min((w.render_scene(w.adjudication_scene(), 512, 512, 4096) for _ in range(3)), key=lambda o: o["loop_seconds"])
+    print("gate gi loop ms", best["loop_seconds"] * 1e3)
 elif what == "C5":
     from forge3d_amd import smoke
 
