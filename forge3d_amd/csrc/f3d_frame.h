@@ -637,10 +637,51 @@ __global__ __launch_bounds__(kWave) void k_trace_init(const FrameParams P) {
     P.head[lp] = uint2{0u, (g.w != 0.0f && dot(V3{g.x, g.y, g.z}, P.light.wi) > 0.0f) ? kHeadPrevValid : 0u};
 }
 
+// Does no reservoir the spatial pass of this 8x8 tile could read hold a sample (m == 0)?  The pass draws its neighbours
+// from [gx - 3, gx + 3] x [gy - 3, gy + 3], clamped to the image: at most 14 x 14 pixels for the tile, read here as one
+// word each (the wave's lanes over a 16-wide raster of the box) and voted on.  Wave-uniform.
+__device__ __forceinline__ bool head_neighbourhood_empty(const FrameParams &P, uint32_t gx, uint32_t gy) {
+    const uint32_t lane = lane_now();
+    const uint32_t x0 = gx - (lane & 7u), y0 = gy - (lane >> 3);  // the tile's first pixel
+    const uint32_t x_last = (x0 + 7u < P.cam.width ? x0 + 7u : P.cam.width - 1u), y_last = (y0 + 7u < P.band_end ? y0 + 7u : P.band_end - 1u);
+    const uint32_t xa = x0 >= 3u ? x0 - 3u : 0u, ya = y0 >= 3u ? y0 - 3u : 0u;
+    const uint32_t xb = x_last + 3u < P.cam.width ? x_last + 3u : P.cam.width - 1u, yb = y_last + 3u < P.cam.height ? y_last + 3u : P.cam.height - 1u;
+    const uint32_t *words = reinterpret_cast<const uint32_t *>(P.res_in);
+    uint32_t some = 0u;
+#pragma unroll
+    for (uint32_t i = 0u; i < 4u; i++) {
+        const uint32_t k = lane + 64u * i, bx = xa + (k & 15u), by = ya + (k >> 4);
+        if (bx <= xb && by <= yb) some |= words[4u * reservoir_index(P, bx, by) + 1u] & ~kLightTypeBit;
+    }
+    return __ballot(some != 0u) == 0ull;
+}
+
 // Frame head of the sample-lane form: one lane per pixel (8x8 tiles).
+// A tile whose neighbourhood holds no sample -- the sky, 60 % of the headline frame -- skips the spatial pass: with m == 0
+// everywhere no candidate is considered and no number drawn, the pass returns the pixel's own light type and target pdf
+// around w_sum = 0, m = 0, weight = 0, and the head is "no usable history" (spatial_reuse / frame_head, f3d_shade.h, for
+// that input; k_head 53 -> see profiles/README.md).
 __global__ __launch_bounds__(kWave) void k_head(const FrameParams P) {
-    uint32_t gx, gy;
-    if (tile_pixel(P, gx, gy)) P.head[(size_t)(gy - P.row_begin) * P.cam.width + gx] = pack_head(frame_head<true>(P, gx, gy));
+    uint32_t gx, gy, tile;
+    const bool active = tile_pixel<1u>(P, gx, gy, tile);
+    if (tile == 0xFFFFFFFFu) return;
+#if !defined(F3D_NO_EMPTY_HEAD)  // A/B + test-of-the-tests switch
+    if (P.frame_index > 0u && head_neighbourhood_empty(P, gx, gy)) {
+        if (active) {
+            const size_t ri = reservoir_index(P, gx, gy), lp = (size_t)(gy - P.row_begin) * P.cam.width + gx;
+            const PackedReservoir self = P.res_in[ri];
+            P.res_out[ri] = PackedReservoir{0.0f, self.m_lt, 0.0f, self.target_pdf};
+            FrameHead h;
+            h.centre_hit = P.gbuffer_n[lp].w != 0.0f;
+            h.prev_valid = false;
+            h.reuse_w = 1.0f;
+            h.rng = 0u;  // (not part of the record)
+            P.head[lp] = pack_head(h);
+        }
+        return;
+    }
+#endif
+    if (active) P.head[(size_t)(gy - P.row_begin) * P.cam.width + gx] = pack_head(frame_head<true>(P, gx, gy));
 }
 
 // VARIANT is reserved for A/B builds (0 = the shipped kernel).
