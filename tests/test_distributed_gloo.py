@@ -136,7 +136,7 @@ def _run(world, mode):
     return image
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])  # 4: interior ranks with a neighbour on both sides, the driver's many-rank defaults
 def test_strips_over_gloo_reproduce_the_single_strip_image(world):
     single = _run(1, "fixed")
     multi = _run(world, "fixed")
