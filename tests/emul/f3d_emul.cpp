@@ -939,6 +939,56 @@ int emul_horizon_blocks(const f3d_terrain_ref_desc *d, uint32_t n, const uint32_
     }
 }
 
+// The claim behind k_head's shortcut for tiles whose neighbourhood holds no reservoir sample (csrc/f3d_frame.h
+// head_neighbourhood_empty): for a pixel whose 7 x 7 neighbourhood (clamped to the image) has m == 0 everywhere, frame_head
+// parks {0, the pixel's own light-type bit, 0, its own target pdf} and returns "no usable history" -- whatever else the
+// records hold.  res: (height + 2 * kHaloRows) rows of `width` packed reservoirs (rows of the halo included, strip = image);
+// gbuffer: per pixel {n, hit flag}.  Returns the number of pixels for which the claim applies and frame_head says
+// otherwise (0 = the claim holds); *applies = how many pixels it applied to.
+uint32_t emul_head_shortcut_mismatches(uint32_t width, uint32_t height, uint32_t frame, const void *res, const float *gbuffer,
+                                       const float *wi_reuse, uint32_t seed_hi, uint32_t seed_lo, uint32_t *applies) {
+    FrameParams P{};
+    P.cam.width = width;
+    P.cam.height = height;
+    P.cam.seed_hi = seed_hi;
+    P.cam.seed_lo = seed_lo;
+    P.row_begin = 0;
+    P.row_end = height;
+    P.frame_index = frame;
+    P.light.wi_reuse = V3{wi_reuse[0], wi_reuse[1], wi_reuse[2]};
+    P.gbuffer_n = reinterpret_cast<const float4 *>(gbuffer);
+    const PackedReservoir *in = reinterpret_cast<const PackedReservoir *>(res);
+    std::vector<PackedReservoir> out((size_t)(height + 2u * kHaloRows) * width);
+    P.res_in = in;
+    P.res_out = out.data();
+    uint32_t bad = 0u, n = 0u;
+    for (uint32_t gy = 0; gy < height; gy++)
+        for (uint32_t gx = 0; gx < width; gx++) {
+            bool empty = true;
+            for (int dy = -3; dy <= 3 && empty; dy++)
+                for (int dx = -3; dx <= 3; dx++) {
+                    const int qx = std::min(std::max((int)gx + dx, 0), (int)width - 1), qy = std::min(std::max((int)gy + dy, 0), (int)height - 1);
+                    if ((in[reservoir_index(P, (uint32_t)qx, (uint32_t)qy)].m_lt & ~kLightTypeBit) != 0u) {
+                        empty = false;
+                        break;
+                    }
+                }
+            if (!empty) continue;
+            n++;
+            const FrameHead h = frame_head(P, gx, gy);
+            const size_t ri = reservoir_index(P, gx, gy);
+            const PackedReservoir self = in[ri], parked = out[ri];
+            const uint2 rec = pack_head(h);
+            const bool centre_hit = gbuffer[4u * ((size_t)gy * width + gx) + 3u] != 0.0f;
+            const bool same = f_bits(parked.w_sum) == 0u && parked.m_lt == self.m_lt && f_bits(parked.weight) == 0u &&
+                              f_bits(parked.target_pdf) == f_bits(self.target_pdf) && rec.x == f_bits(1.0f) &&
+                              rec.y == (centre_hit ? kHeadCentreHit : 0u);
+            if (!same) bad++;
+        }
+    if (applies) *applies = n;
+    return bad;
+}
+
 // debugging aid: the sun-ray certificate of one pixel: {clear_from, centre depth, centre origin xyz}
 int emul_sun_clear(const f3d_terrain_ref_desc *d, uint32_t gx, uint32_t gy, float *out) {
     try {
