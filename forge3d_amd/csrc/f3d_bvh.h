@@ -363,8 +363,13 @@ inline std::vector<Bvh4Node> collapse_bvh4(const MeshBvh &bvh) {
     };
     const auto clear = [&](Bvh4Node &n) {
         for (uint32_t s = 0; s < 4u; s++) {
+            // an EMPTY slot: both planes at +inf on every axis.  The walk's slab test orders each axis's two plane
+            // parameters with min / max, so the "inverted" box (+inf, -inf) of round 4 passed for every ray (enter = tmin,
+            // exit = t_best) and only its leaf word of 0 triangles kept the answer right (round-4 advice).  With both planes
+            // at +inf an axis gives (+inf, +inf) for a positive direction component -- enter = +inf -- and (-inf, -inf) for
+            // a negative one -- exit = -inf; a ray's t_best is finite (1e30 at most), so enter <= exit fails either way.
             n.lo_x[s] = n.lo_y[s] = n.lo_z[s] = INFINITY;
-            n.hi_x[s] = n.hi_y[s] = n.hi_z[s] = -INFINITY;
+            n.hi_x[s] = n.hi_y[s] = n.hi_z[s] = INFINITY;
             n.leaf[s] = 0u;
         }
         n.first_child = n.inner = n.pad0 = n.pad1 = 0u;

@@ -20,10 +20,11 @@ int poison_pattern();  // -1: off (f3d_host.hip)
 void poison_register(void *user, void *base);
 void *poison_take(void *user);  // base pointer of a poisoned allocation (and forget it); nullptr: a plain allocation
 
-// Freed blocks are kept (per device, exact size, newest first; F3D_DEVICE_POOL_MB, default 2 048, 0 = off) and handed out
+// Freed blocks are kept (per device, exact size, newest first; F3D_DEVICE_POOL_MB, default 1 024, 0 = off) and handed out
 // again: a camera path or a smoke sequence allocates the same dozen buffers for every frame, and hipFree waits for the
 // device.  Callers free only what no stream still uses (sessions synchronise their streams before they go).  Poisoned
-// allocations bypass the pool (their guard regions are part of the pattern test).  f3d_device_pool_trim() empties it.
+// allocations bypass the pool (their guard regions are part of the pattern test).  f3d_device_pool_trim() empties it (the strip driver
+// does so before it sizes its torch / RCCL buffers: memory the pool holds is invisible to torch's allocator).
 hipError_t pool_take(void **out, size_t bytes);   // hipErrorOutOfMemory: nothing of that size waiting (f3d_host.hip)
 bool pool_give(void *p);                           // false: not taken (pool off or full): the caller frees
 void pool_note(void *p, size_t bytes);             // a fresh hipMalloc the pool may take back later
@@ -60,9 +61,8 @@ inline hipError_t device_free(void *p) {
     if (!p) return hipSuccess;
     void *base = poison_take(p);
     if (!base) {
-        // hipFree waits for the device; a block that goes back to the pool must not be handed out while a kernel of an
-        // abandoned call (an error path) still writes to it: keep that guarantee (on an idle device this costs microseconds)
-        (void)hipDeviceSynchronize();
+        // (pool_give waits for the block's own device before it keeps a block; a block it does not keep -- pool off, full,
+        // or a pointer it never saw -- goes to hipFree, which waits by itself)
         if (pool_give(p)) return hipSuccess;
     }
     return hipFree(base ? base : p);

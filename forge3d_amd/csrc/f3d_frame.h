@@ -638,14 +638,19 @@ __global__ __launch_bounds__(kWave) void k_trace_init(const FrameParams P) {
 }
 
 // Does no reservoir the spatial pass of this 8x8 tile could read hold a sample (m == 0)?  The pass draws its neighbours
-// from [gx - 3, gx + 3] x [gy - 3, gy + 3], clamped to the image: at most 14 x 14 pixels for the tile, read here as one
-// word each (the wave's lanes over a 16-wide raster of the box) and voted on.  Wave-uniform.
+// from [gx - 3, gx + 4] x [gy - 3, gy + 4], clamped to the image -- PLUS four, not three: the offset is floor(u * 7) - 3
+// and u is exactly 1.0 for the top 128 values of the generator (f3d_math.h rng_next; the same fact kHaloRows = 4 rests
+// on, tests/test_halo_reach.py; round 4 looked three pixels out here and was wrong for 2^-25 of the draws).  At most
+// 15 x 15 pixels for the tile, read here as one word each (the wave's lanes over a 16-wide raster of the box) and voted
+// on.  Wave-uniform.
 __device__ __forceinline__ bool head_neighbourhood_empty(const FrameParams &P, uint32_t gx, uint32_t gy) {
     const uint32_t lane = lane_now();
     const uint32_t x0 = gx - (lane & 7u), y0 = gy - (lane >> 3);  // the tile's first pixel
     const uint32_t x_last = (x0 + 7u < P.cam.width ? x0 + 7u : P.cam.width - 1u), y_last = (y0 + 7u < P.band_end ? y0 + 7u : P.band_end - 1u);
-    const uint32_t xa = x0 >= 3u ? x0 - 3u : 0u, ya = y0 >= 3u ? y0 - 3u : 0u;
-    const uint32_t xb = x_last + 3u < P.cam.width ? x_last + 3u : P.cam.width - 1u, yb = y_last + 3u < P.cam.height ? y_last + 3u : P.cam.height - 1u;
+    const uint32_t xa = x0 >= kSpatialReachLo ? x0 - kSpatialReachLo : 0u, ya = y0 >= kSpatialReachLo ? y0 - kSpatialReachLo : 0u;
+    static_assert(8u + kSpatialReachLo + kSpatialReachHi <= 16u, "the 16 x 16 raster below covers the tile's reach");
+    const uint32_t xb = x_last + kSpatialReachHi < P.cam.width ? x_last + kSpatialReachHi : P.cam.width - 1u;
+    const uint32_t yb = y_last + kSpatialReachHi < P.cam.height ? y_last + kSpatialReachHi : P.cam.height - 1u;
     const uint32_t *words = reinterpret_cast<const uint32_t *>(P.res_in);
     uint32_t some = 0u;
 #pragma unroll

@@ -14,6 +14,7 @@
 #include <atomic>
 #include <exception>
 #include <memory>
+#include <map>
 #include <mutex>
 #include <new>
 #include <unordered_map>

@@ -31,7 +31,7 @@ size_t g_pool_bytes = 0;
 size_t pool_limit() {
     static const size_t limit = [] {
         const char *e = getenv("F3D_DEVICE_POOL_MB");
-        return (size_t)(e ? std::max(0.0, atof(e)) : 2048.0) << 20;
+        return (size_t)(e ? std::max(0.0, atof(e)) : 1024.0) << 20;
     }();
     return limit;
 }
@@ -65,6 +65,15 @@ bool pool_give(void *p) {
     const PoolBlock b = it->second;
     g_pool_live.erase(it);
     if (b.bytes > pool_limit() || g_pool_free.size() >= 256u) return false;
+    {
+        // a block that goes back to the pool must not be handed out while a kernel of an abandoned call (an error path)
+        // still writes to it: wait for the BLOCK's device (hipFree, the other way out, waits by itself)
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        if (prev != b.device) (void)hipSetDevice(b.device);
+        (void)hipDeviceSynchronize();
+        if (prev >= 0 && prev != b.device) (void)hipSetDevice(prev);
+    }
     while (g_pool_bytes + b.bytes > pool_limit() && !g_pool_free.empty()) {  // make room: the oldest go back to the driver
         int prev = -1;
         (void)hipGetDevice(&prev);
@@ -257,19 +266,35 @@ uint64_t hash_bytes(const void *data, size_t n, uint64_t seed) {  // 8 bytes at 
 }
 
 // Tables for this DEM on this device: from the cache, or built now (and cached when the limit allows).
-// Host -> device through the library's own pinned staging pair (two 4 MiB buffers a process, allocated on first use):
+// Host -> device through the library's own pinned staging pair (two 4 MiB buffers a device, allocated on first use):
 // a pageable hipMemcpy of the 16.8 MB headline DEM took 7.3 ms the first time a process made one (the runtime sets up its
 // staging then) and the copy into pinned memory overlaps the DMA of the chunk before.
+// One pair PER DEVICE (round-4 advice: a process that drives several GPUs -- f3d_session_halo_connect supports it -- recorded
+// device A's events on device B's stream, which hipEventRecord refuses): events belong to the device that was current when
+// they were created, the buffers are pinned portably, and uploads to different devices do not wait for each other.
+struct StagingPair {
+    std::mutex mutex;
+    void *buffer[2] = {nullptr, nullptr};
+    hipEvent_t drained[2] = {nullptr, nullptr};
+};
+StagingPair &staging_for_current_device() {
+    static std::mutex map_mutex;
+    static std::map<int, std::unique_ptr<StagingPair>> &pairs = *new std::map<int, std::unique_ptr<StagingPair>>();  // (never destroyed: see g_scene_cache)
+    int device = 0;
+    hip_check(hipGetDevice(&device), "current device");
+    std::lock_guard<std::mutex> lock(map_mutex);
+    std::unique_ptr<StagingPair> &slot = pairs[device];
+    if (!slot) slot.reset(new StagingPair());
+    return *slot;
+}
 void upload_staged(void *dst, const void *src, size_t bytes, hipStream_t stream) {
     constexpr size_t kChunk = 4u << 20;
-    static std::mutex staging_mutex;
-    static void *staging[2] = {nullptr, nullptr};
-    static hipEvent_t drained[2] = {nullptr, nullptr};
-    std::lock_guard<std::mutex> lock(staging_mutex);
-    for (int i = 0; i < 2; i++)  // (also for a small first upload: the pair is part of a process's start-up, not of a later render)
-        if (!staging[i]) {
-            hip_check(hipHostMalloc(&staging[i], kChunk, hipHostMallocDefault), "pinned staging buffer");
-            hip_check(hipEventCreateWithFlags(&drained[i], hipEventDisableTiming), "staging event");
+    StagingPair &pair = staging_for_current_device();
+    std::lock_guard<std::mutex> lock(pair.mutex);
+    for (int i = 0; i < 2; i++)  // (also for a small first upload: the pair is part of a device's start-up, not of a later render)
+        if (!pair.buffer[i]) {
+            hip_check(hipHostMalloc(&pair.buffer[i], kChunk, hipHostMallocPortable), "pinned staging buffer");
+            hip_check(hipEventCreateWithFlags(&pair.drained[i], hipEventDisableTiming), "staging event");
         }
     if (bytes < (256u << 10)) {  // small: one plain copy
         hip_check(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), "upload");
@@ -278,14 +303,14 @@ void upload_staged(void *dst, const void *src, size_t bytes, hipStream_t stream)
     size_t done = 0;
     for (int turn = 0; done < bytes; turn ^= 1) {
         const size_t n = std::min(kChunk, bytes - done);
-        hip_check(hipEventSynchronize(drained[turn]), "staging buffer");  // (never recorded: returns at once)
-        memcpy(staging[turn], (const char *)src + done, n);
-        hip_check(hipMemcpyAsync((char *)dst + done, staging[turn], n, hipMemcpyHostToDevice, stream), "upload");
-        hip_check(hipEventRecord(drained[turn], stream), "staging event");
+        hip_check(hipEventSynchronize(pair.drained[turn]), "staging buffer");  // (never recorded: returns at once)
+        memcpy(pair.buffer[turn], (const char *)src + done, n);
+        hip_check(hipMemcpyAsync((char *)dst + done, pair.buffer[turn], n, hipMemcpyHostToDevice, stream), "upload");
+        hip_check(hipEventRecord(pair.drained[turn], stream), "staging event");
         done += n;
     }
-    hip_check(hipEventSynchronize(drained[0]), "upload");  // the staging pair is free again, the data is on its way in order
-    hip_check(hipEventSynchronize(drained[1]), "upload");
+    hip_check(hipEventSynchronize(pair.drained[0]), "upload");  // the staging pair is free again, the data is on its way in order
+    hip_check(hipEventSynchronize(pair.drained[1]), "upload");
 }
 
 std::shared_ptr<CachedTables> acquire_tables(int device, const float *heights, uint32_t w, uint32_t h, float exaggeration,

@@ -56,33 +56,13 @@ hipError_t launch_frame(const FrameParams &p, int variant, hipStream_t stream) {
                 if (mesh) hipLaunchKernelGGL((k_frame<0, 6, 4, true>), grid, block, 0, stream, p);
                 else hipLaunchKernelGGL((k_frame<0, 6, 4>), grid, block, 0, stream, p);
                 break;
-            case 4104:
-                if (mesh) hipLaunchKernelGGL((k_frame<0, 4, 4, true>), grid, block, 0, stream, p);
-                else hipLaunchKernelGGL((k_frame<0, 4, 4>), grid, block, 0, stream, p);
-                break;
             case 4105:
                 if (mesh) hipLaunchKernelGGL((k_frame<0, 5, 4, true>), grid, block, 0, stream, p);
                 else hipLaunchKernelGGL((k_frame<0, 5, 4>), grid, block, 0, stream, p);
                 break;
-            case 4107:
-                if (mesh) hipLaunchKernelGGL((k_frame<0, 7, 4, true>), grid, block, 0, stream, p);
-                else hipLaunchKernelGGL((k_frame<0, 7, 4>), grid, block, 0, stream, p);
-                break;
-            case 4108:
-                if (mesh) hipLaunchKernelGGL((k_frame<0, 8, 4, true>), grid, block, 0, stream, p);
-                else hipLaunchKernelGGL((k_frame<0, 8, 4>), grid, block, 0, stream, p);
-                break;
             case 8000:
                 if (mesh) hipLaunchKernelGGL((k_frame<0, 6, 8, true>), grid, block, 0, stream, p);
                 else hipLaunchKernelGGL((k_frame<0, 6, 8>), grid, block, 0, stream, p);
-                break;
-            case 8104:
-                if (mesh) hipLaunchKernelGGL((k_frame<0, 4, 8, true>), grid, block, 0, stream, p);
-                else hipLaunchKernelGGL((k_frame<0, 4, 8>), grid, block, 0, stream, p);
-                break;
-            case 8105:
-                if (mesh) hipLaunchKernelGGL((k_frame<0, 5, 8, true>), grid, block, 0, stream, p);
-                else hipLaunchKernelGGL((k_frame<0, 5, 8>), grid, block, 0, stream, p);
                 break;
             default: return hipErrorInvalidValue;
         }
@@ -93,21 +73,9 @@ hipError_t launch_frame(const FrameParams &p, int variant, hipStream_t stream) {
             if (mesh) hipLaunchKernelGGL((k_frame<0, 6, 1u, true>), grid, block, 0, stream, p);
             else hipLaunchKernelGGL((k_frame<0, 6>), grid, block, 0, stream, p);
             break;  // default: 80 VGPRs, 6 waves/SIMD
-        case 101:
-            if (mesh) hipLaunchKernelGGL((k_frame<0, 1, 1u, true>), grid, block, 0, stream, p);
-            else hipLaunchKernelGGL((k_frame<0, 1>), grid, block, 0, stream, p);
-            break;
         case 104:
             if (mesh) hipLaunchKernelGGL((k_frame<0, 4, 1u, true>), grid, block, 0, stream, p);
             else hipLaunchKernelGGL((k_frame<0, 4>), grid, block, 0, stream, p);
-            break;
-        case 105:
-            if (mesh) hipLaunchKernelGGL((k_frame<0, 5, 1u, true>), grid, block, 0, stream, p);
-            else hipLaunchKernelGGL((k_frame<0, 5>), grid, block, 0, stream, p);
-            break;
-        case 108:
-            if (mesh) hipLaunchKernelGGL((k_frame<0, 8, 1u, true>), grid, block, 0, stream, p);
-            else hipLaunchKernelGGL((k_frame<0, 8>), grid, block, 0, stream, p);
             break;
         default: return hipErrorInvalidValue;
     }

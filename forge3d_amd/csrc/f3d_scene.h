@@ -30,6 +30,11 @@ constexpr uint32_t kWelfordWindow = 32;   // WELFORD_WINDOW, render_terrain.rs:2
 // floor(u * 7) - 3 (pt_restir_spatial.wgsl:171-176) and u = f32(x) / 2^32 IS 1.0 for the top 128 values of x, so the
 // reach is [-3, +4], not the nominal radius 3: 2^-25 of the draws look four rows down.
 constexpr uint32_t kHaloRows = 4;
+#if !defined(F3D_SPATIAL_REACH_HI)  // (3 = round 4's window: test-of-the-tests build for tests/test_gpu_head_reach.py)
+#define F3D_SPATIAL_REACH_HI 4
+#endif
+constexpr uint32_t kSpatialReachLo = 3, kSpatialReachHi = F3D_SPATIAL_REACH_HI;  // the same reach per axis, for code that bounds the pass's reads
+static_assert(kHaloRows >= kSpatialReachHi && kHaloRows >= kSpatialReachLo, "a strip's halo covers the spatial pass");
 constexpr uint32_t kIblSectors = 8;      // azimuth sectors of the IBL rays' far-horizon certificate (f3d_cone.h)
 constexpr uint32_t kDefaultLeafQuorum = 64;  // lanes with a queued leaf that trigger a wave drain
                                              // (64 = only when a FIFO is full or nobody marches; measured best)

@@ -197,7 +197,7 @@ F3D_HD bool mesh_bvh4(const MeshDev &M, V3 o, float tmin, V3 d, float tmax, floa
             const float az = f_fma(loz.C, iz, -oiz), bz = f_fma(hiz.C, iz, -oiz);                                 \
             const float enter = f_max(f_max(f_min(ax, bx), f_min(ay, by)), f_max(f_min(az, bz), tmin));           \
             const float exit = f_min(f_min(f_max(ax, bx), f_max(ay, by)), f_min(f_max(az, bz), t_best));          \
-            hit |= (enter <= exit * 1.00001f) ? (1u << S) : 0u; /* conservative: boxes are padded, ties are kept; an empty slot's (+inf, -inf) never passes */ \
+            hit |= (enter <= exit * 1.00001f) ? (1u << S) : 0u; /* conservative: boxes are padded, ties are kept; an empty slot (both planes at +inf, f3d_bvh.h) never passes: enter = +inf or exit = -inf */ \
             F3D_BVH4_KEEP(S, enter)                                                                               \
         }
         F3D_BVH4_SLOT(0, x)

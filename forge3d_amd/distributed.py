@@ -107,9 +107,20 @@ class HipBackend:
 
         self.torch = torch
         self.device = torch.device("cuda", device)
+        # device memory libf3dhip.so has freed waits in its own pool (f3d_devmem.h), where torch's allocator and RCCL cannot see
+        # it: hand it back before this strip's reservoir / gather buffers are sized
+        from . import _native
+
+        _native.lib().f3d_device_pool_trim()
 
     def empty_bytes(self, n):
-        return self.torch.zeros(n, dtype=self.torch.uint8, device=self.device)
+        try:
+            return self.torch.zeros(n, dtype=self.torch.uint8, device=self.device)
+        except self.torch.cuda.OutOfMemoryError:
+            from . import _native
+
+            _native.lib().f3d_device_pool_trim()
+            return self.torch.zeros(n, dtype=self.torch.uint8, device=self.device)
 
     def empty_i32(self, n):
         return self.torch.zeros(n, dtype=self.torch.int32, device=self.device)

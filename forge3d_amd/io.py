@@ -273,7 +273,7 @@ def _hdr_rows(buf: memoryview, pos: int, width: int, height: int) -> np.ndarray:
     n = len(buf)
     for y in range(height):
         if pos + 4 > n:
-            raise HdrError(f"Failed to read scanline header at row {y}: file ends")
+            raise HdrError(f"Failed to read scanline header at row {y}: failed to fill whole buffer")
         head = bytes(buf[pos:pos + 4])
         if head[0] == 2 and head[1] == 2 and head[2] == ((width >> 8) & 0xFF) and head[3] == (width & 0xFF):
             pos += 4
@@ -282,7 +282,7 @@ def _hdr_rows(buf: memoryview, pos: int, width: int, height: int) -> np.ndarray:
                 row = out[y, :, c]
                 while x < width:
                     if pos >= n:
-                        raise HdrError("Failed to read RLE run info: file ends")
+                        raise HdrError("Failed to read RLE run info: failed to fill whole buffer")
                     count = buf[pos]
                     pos += 1
                     if count > 128:
@@ -290,20 +290,20 @@ def _hdr_rows(buf: memoryview, pos: int, width: int, height: int) -> np.ndarray:
                         if x + count > width:
                             raise HdrError("HDR RLE run exceeds scanline width")
                         if pos >= n:
-                            raise HdrError("Failed to read RLE repeat value: file ends")
+                            raise HdrError("Failed to read RLE repeat value: failed to fill whole buffer")
                         row[x:x + count] = buf[pos]
                         pos += 1
                     else:
                         if x + count > width:
                             raise HdrError("HDR literal run exceeds scanline width")
                         if pos + count > n:
-                            raise HdrError("Failed to read literal value: file ends")
+                            raise HdrError("Failed to read literal value: failed to fill whole buffer")
                         row[x:x + count] = np.frombuffer(buf[pos:pos + count], np.uint8)
                         pos += count
                     x += count
         else:
             if pos + 4 * width > n:
-                raise HdrError(f"Failed to read pixel data at row {y}: file ends")
+                raise HdrError(f"Failed to read pixel data at row {y}: failed to fill whole buffer")
             out[y] = np.frombuffer(buf[pos:pos + 4 * width], np.uint8).reshape(width, 4)
             pos += 4 * width
     return out
@@ -340,12 +340,21 @@ def read_hdr(path) -> np.ndarray:
     parts = resolution.split()
     if len(parts) != 4:
         raise HdrError(f"Invalid HDR resolution line: {resolution}")
-    # the reference parses both as u32 (str::parse: decimal digits only -- int() would also take "+5" and "1_0")
-    if not parts[1].isascii() or not parts[1].isdigit() or len(parts[1]) > 10 or int(parts[1]) > 0xFFFFFFFF:
+    # the reference parses both with str::parse::<u32> (src/formats/hdr.rs:137-143): an optional single leading '+', then
+    # ASCII decimal digits -- any number of them, leading zeros included -- with a value that fits 32 bits.  int() alone
+    # would also take "1_0", " 5" and "-0".
+    def parse_u32(text):
+        digits = text[1:] if text.startswith("+") else text
+        if not digits or not digits.isascii() or not digits.isdigit():
+            return None
+        value = int(digits.lstrip("0") or "0") if len(digits.lstrip("0")) <= 10 else 1 << 32
+        return value if value <= 0xFFFFFFFF else None
+
+    height, width = parse_u32(parts[1]), parse_u32(parts[3])
+    if height is None:
         raise HdrError(f"Invalid HDR height: {parts[1]}")
-    if not parts[3].isascii() or not parts[3].isdigit() or len(parts[3]) > 10 or int(parts[3]) > 0xFFFFFFFF:
+    if width is None:
         raise HdrError(f"Invalid HDR width: {parts[3]}")
-    height, width = int(parts[1]), int(parts[3])
     if width <= 0 or height <= 0:
         raise HdrError("HDR image dimensions cannot be zero")
     # a scanline is at least 4 bytes in either form: a header that promises more rows than the file can hold is refused
@@ -354,7 +363,7 @@ def read_hdr(path) -> np.ndarray:
     # (run-length rows hold at most 127 pixels per 2 bytes and component: < 16 pixels per byte)
     # (only where the allocation would matter: small pictures fail row by row, in the reference's order and words)
     if width * height * 4 > (64 << 20) and (height > remaining // 4 or width * height > 64 * max(remaining, 1)):
-        raise HdrError(f"Failed to read scanline header at row {min(height, remaining // 4)}: file ends")
+        raise HdrError(f"Failed to read scanline header at row {min(height, remaining // 4)}: failed to fill whole buffer")
     try:
         rgbe = _hdr_rows(memoryview(data), end, width, height)
     except (MemoryError, OverflowError):

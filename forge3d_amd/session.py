@@ -260,8 +260,8 @@ def kernel_variant(*, sample_lanes: int = 0, waves_per_simd: int = 0, tile_map: 
     frame kernel that is not a build flag.  All zero = the shipped default."""
     if sample_lanes not in (0, 1, 2, 4, 8):
         raise ValueError("sample_lanes must be 0 (automatic), 1, 2, 4 or 8")
-    if waves_per_simd not in (0, 1, 4, 5, 6, 7, 8):
-        raise ValueError("waves_per_simd must be 0 / 6 (default), 4, 5, 7, 8 or 1 (unconstrained)")
+    if waves_per_simd not in (0, 4, 5, 6):
+        raise ValueError("waves_per_simd must be 0 / 6 (default), 4 (1 sample lane) or 5 (4 sample lanes)")
     if not (0 <= tile_map <= 4 and 0 <= leaf_quorum <= 64 and 0 <= share_below <= 64):
         raise ValueError("tile_map in 0..4, leaf_quorum and share_below in 0..64")
     budget = 0 if waves_per_simd in (0, 6) else 100 + waves_per_simd

@@ -145,7 +145,8 @@ typedef struct f3d_session_opts {
     int32_t kernel_variant;       /* 0 = default.  A/B switches as decimal fields (forge3d_amd.session.kernel_variant() builds one
                                    * from names, describe_kernel_variant() reads one back):
                                    *   v % 1000              register budget of the frame kernel: 0 = 6 waves per SIMD (80 VGPRs);
-                                   *                         104 / 105 / 107 / 108 = 4 / 5 / 7 / 8 waves; 101 = unconstrained
+                                   *                         104 = 4 waves (1 sample lane), 105 = 5 waves (4 sample lanes): the two
+                                   *                         occupancy A/Bs profiles/README.md still cites; anything else is refused
                                    *   (v / 1000) % 10       tile -> XCD map: 0 / 2 rows dealt round-robin + longest-first dispatch
                                    *                         (default), 1 consecutive tiles, 3 contiguous bands, 4 = 2 without longest-first
                                    *   (v / 10000) % 100     lanes with a queued leaf that trigger a drain (0 = 64: only a full FIFO does)
@@ -308,8 +309,9 @@ int f3d_session_kernel_timing(f3d_session *session, int32_t enable, double *avg_
 /* Sample lanes per pixel the frame kernel of this session runs with (1, 2, 4 or 8); 0 on a NULL session. */
 uint32_t f3d_session_sample_lanes(f3d_session *session);
 /* Device memory the library has freed is kept for its next allocation of the same size (F3D_DEVICE_POOL_MB, default
- * 2048, 0 = off): a camera path or a smoke sequence allocates the same buffers frame after frame.  This hands everything
- * that is waiting back to the driver. */
+ * 1024, 0 = off): a camera path or a smoke sequence allocates the same buffers frame after frame.  This hands everything
+ * that is waiting back to the driver -- call it before another allocator (torch, RCCL) sizes large buffers on the device:
+ * what the pool holds is invisible to them. */
 void f3d_device_pool_trim(void);
 /* Rows of neighbour state a strip keeps above and below its own (4: the spatial pass reaches -3 .. +4 rows); the halo
  * blocks of f3d_session_halo and the extra rows of ext_reservoirs are this many rows. */

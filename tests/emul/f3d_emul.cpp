@@ -940,13 +940,14 @@ int emul_horizon_blocks(const f3d_terrain_ref_desc *d, uint32_t n, const uint32_
 }
 
 // The claim behind k_head's shortcut for tiles whose neighbourhood holds no reservoir sample (csrc/f3d_frame.h
-// head_neighbourhood_empty): for a pixel whose 7 x 7 neighbourhood (clamped to the image) has m == 0 everywhere, frame_head
+// head_neighbourhood_empty): for a pixel whose [-3, +reach_hi]^2 neighbourhood (clamped to the image) has m == 0 everywhere, frame_head
 // parks {0, the pixel's own light-type bit, 0, its own target pdf} and returns "no usable history" -- whatever else the
 // records hold.  res: (height + 2 * kHaloRows) rows of `width` packed reservoirs (rows of the halo included, strip = image);
 // gbuffer: per pixel {n, hit flag}.  Returns the number of pixels for which the claim applies and frame_head says
-// otherwise (0 = the claim holds); *applies = how many pixels it applied to.
+// otherwise (0 = the claim holds); *applies = how many pixels it applied to.  reach_hi = kSpatialReachHi (4) is the window
+// the kernel uses; 3 is round 4's window, kept callable so that the test can show the constructed u == 1.0 case break it.
 uint32_t emul_head_shortcut_mismatches(uint32_t width, uint32_t height, uint32_t frame, const void *res, const float *gbuffer,
-                                       const float *wi_reuse, uint32_t seed_hi, uint32_t seed_lo, uint32_t *applies) {
+                                       const float *wi_reuse, uint32_t seed_hi, uint32_t seed_lo, uint32_t *applies, uint32_t reach_hi) {
     FrameParams P{};
     P.cam.width = width;
     P.cam.height = height;
@@ -965,8 +966,8 @@ uint32_t emul_head_shortcut_mismatches(uint32_t width, uint32_t height, uint32_t
     for (uint32_t gy = 0; gy < height; gy++)
         for (uint32_t gx = 0; gx < width; gx++) {
             bool empty = true;
-            for (int dy = -3; dy <= 3 && empty; dy++)
-                for (int dx = -3; dx <= 3; dx++) {
+            for (int dy = -(int)kSpatialReachLo; dy <= (int)reach_hi && empty; dy++)
+                for (int dx = -(int)kSpatialReachLo; dx <= (int)reach_hi; dx++) {
                     const int qx = std::min(std::max((int)gx + dx, 0), (int)width - 1), qy = std::min(std::max((int)gy + dy, 0), (int)height - 1);
                     if ((in[reservoir_index(P, (uint32_t)qx, (uint32_t)qy)].m_lt & ~kLightTypeBit) != 0u) {
                         empty = false;

@@ -339,19 +339,24 @@ def test_viewer_set_ibl_reads_hdr_files(tmp_path):
 
 
 def test_hdr_header_cannot_ask_for_more_than_the_file_holds(tmp_path):
-    """dimensions are u32 decimal digits as in the reference's parse; a tiny file that promises a huge image is
-    refused before anything is allocated for it."""
+    """ADVICE r3 / r4: dimensions parse as Rust's str::parse::<u32> does (reference src/formats/hdr.rs:137-143: an optional
+    leading '+', decimal digits with any number of leading zeros, value < 2^32); a tiny file that promises a huge image is
+    refused before anything is allocated for it, in the words of the reference's read_exact failure."""
     from forge3d_amd import io
 
     head = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n"
-    for res in (b"-Y +5 +X 4\n", b"-Y 1_0 +X 4\n", b"-Y 4 +X 4294967296\n"):
+    for res in (b"-Y +2 +X 0000000000004\n", b"-Y 2 +X +4\n"):  # what u32::from_str accepts
+        p = tmp_path / "plus.hdr"
+        p.write_bytes(head + res + bytes([1, 2, 3, 128] * 8))
+        assert io.read_hdr(p).shape == (2, 4, 3)
+    for res in (b"-Y ++5 +X 4\n", b"-Y -0 +X 4\n", b"-Y + +X 4\n", b"-Y 1_0 +X 4\n", b"-Y 4 +X 4294967296\n", b"-Y 4 +X 00000000099999999999\n"):
         p = tmp_path / "bad.hdr"
         p.write_bytes(head + res + b"\0" * 64)
         with pytest.raises(io.HdrError, match="Invalid HDR"):
             io.read_hdr(p)
     p = tmp_path / "huge.hdr"
     p.write_bytes(head + b"-Y 60000 +X 60000\n" + b"\0" * 32)
-    with pytest.raises(io.HdrError, match="file ends"):
+    with pytest.raises(io.HdrError, match="failed to fill whole buffer"):
         io.read_hdr(p)
 
 
