@@ -35,11 +35,36 @@ sys.path.insert(0, str(ROOT))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# state bytes the FRAME KERNEL moves per pixel-frame.  1-lane kernel (head fused): reservoir r16+w16,
-# accumulation r16+w16, Welford m2 r4+w4, G-buffer r16 = 88 B.  Sample-lane kernel: the head (reservoir and
-# G-buffer reads, 32 B) runs in k_head, which is timed and priced separately; k_frame reads its 8-byte record and
-# the parked reservoir: r8 + r16 + w16 + r16 + w16 + r4 + w4 = 80 B.
+# State bytes per pixel-frame, S of SURVEY.md 8(d) -- ONE accounting, the same in DESIGN.md 4.1 / 6 and BASELINE.md 4:
+#   1-lane kernel (head fused into k_frame): reservoir r16 + w16, accumulation r16 + w16, Welford m2 r4 + w4,
+#   G-buffer r16 = 88 B.
+#   Sample-lane form (the default): k_head reads reservoir 16 + G-buffer 16 and writes the parked history 16 + its 8-byte
+#   record = 56 B, timed and priced apart; k_frame -- the kernel the roofline object is about -- reads the record 8 and the
+#   parked history 16, writes the reservoir 16, accumulation r16 + w16, m2 r4 + w4 = 80 B.  (The frame as a whole: 136 B.)
 STATE_BYTES_PER_PIXEL_FRAME = {False: 88, True: 80}
+K_HEAD_STATE_BYTES = 56
+
+
+def golden_scores(device: int):
+    """SSIM / mean-abs of THIS build's render of the reference's locked golden scene against the reference's committed golden
+    image (BASELINE.json's metric: "...; SSIM vs golden"; reference gate tests/test_hybrid_terrain_pt.py:858-859: SSIM >= 0.995,
+    mean-abs <= 2.0).  The scene converges by the reference's Welford gate (256 frames of 1 spp at 256 x 256); tests/metrics.py
+    restates the reference's SSIM (tests/_ssim.py).  The PNG is data the reference's own tests hold (tests/golden/)."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import metrics
+
+    from forge3d_amd import datasets, hybrid_render_terrain_reference, io
+
+    dem, cam, kw = datasets.mini_dem_scene(np.load(ROOT / "tests" / "golden" / "mini_dem.npy"))
+    t0 = time.perf_counter()
+    out = hybrid_render_terrain_reference(dem, 256, 256, cam, **kw)
+    seconds = time.perf_counter() - t0
+    golden = io.png_to_numpy(ROOT / "tests" / "golden" / "mini_dem_reference.png")
+    return {"ssim_vs_golden": metrics.ssim(out["rgba"][..., :3], golden[..., :3], data_range=255.0),
+            "mean_abs_vs_golden": metrics.mean_abs(out["rgba"][..., :3], golden[..., :3]),
+            "golden": {"scene": "reference golden scene: mini-DEM 128^2, 256x256, 1 spp/frame until the Welford gate fires",
+                       "frames": int(out["frames"]), "gate": "SSIM >= 0.995 and mean-abs <= 2.0 (tests/test_hybrid_terrain_pt.py:858-859)",
+                       "render_ms": round(seconds * 1e3, 2)}}
 
 
 def parse_args():
@@ -343,7 +368,10 @@ def main():
         samples_per_step = args.width * args.height * args.spp
         value = samples_per_step * args.steps / elapsed / 1e6
         result = {
-            "metric": "Msamples/s (W*H*spp/s) at 1080p, 256 spp", "value": value, "unit": "Msamples/s",
+            # BASELINE.json's metric, with the resolution and sample count of THIS run written out (the steady-state rate per
+            # accumulation frame does not depend on how many frames the run accumulates: windows_ms_per_step)
+            "metric": f"Msamples/s (W*H*spp/s) at {args.width}x{args.height}, {args.spp * args.steps} spp "
+                      f"({args.spp} spp/frame x {args.steps} frames timed); SSIM vs golden", "value": value, "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             # the timed region above is window 0; the others repeat it on the continuing accumulation
             "windows_ms_per_step": [round(x, 4) for x in window_ms],
@@ -432,6 +460,12 @@ def main():
             result["grays_per_s"] = value * 1e6 * (1.0 + 2.0 * hit) / 1e9  # primary + 2 occlusion rays per shaded sample
         result["kernel_source_hash"] = kernel_source_hash()
     r.close()
+    if rank == 0:
+        try:
+            result.update(golden_scores(local_rank))
+        except Exception as exc:  # noqa: BLE001 -- a report, never a reason to lose the line
+            result["ssim_vs_golden"] = None
+            result["golden"] = {"error": str(exc)[:200]}
     if rank == 0 and world == 1 and not args.no_terrain_filling:
         # the same DEM from inside the footprint: (nearly) every sample is shaded -- a harder number than the headline
         cam2 = terrain_filling_camera(dem, kw)

@@ -7,10 +7,13 @@ five-anchor turbidity bank and its interpolation (src/core/atmosphere/precompute
 (src/py_functions/path_tracing/terrain_reference.rs:45-219).
 
 Where the tables come from.  The reference compiles its bank (5 x 598 032 bytes, ``turbidity-{1,2,4,8,10}.bin``)
-into the extension module.  This package does not ship that data: ``load_shipped`` reads the bank from a directory
--- ``bank_dir=``, ``$FORGE3D_AETHER_LUT_DIR``, or ``$FORGE3D_REPO_ROOT/src/core/atmosphere/precomputed`` (a forge3d
-checkout) -- verifies every anchor it touches against the reference's locked SHA-256 (precomputed.rs:36-43) and
-applies the reference's bracket interpolation.  When NO bank directory is known the anchors are baked on the GPU by
+into the extension module.  This package installs the same five data files beside itself
+(``forge3d_amd/data/aether_bank/``, round 5: a drop-in has to answer ``load_shipped`` with the shipped tables on a box
+that holds no forge3d checkout): ``load_shipped`` reads the bank from ``bank_dir=``, ``$FORGE3D_AETHER_LUT_DIR``,
+``$FORGE3D_REPO_ROOT/src/core/atmosphere/precomputed`` (a forge3d checkout) or that installed directory, in this order,
+verifies every anchor it touches against the reference's locked SHA-256 (precomputed.rs:36-43) and
+applies the reference's bracket interpolation.  When NO bank directory is found (the data directory was stripped from an
+installation, or ``$FORGE3D_AETHER_NO_INSTALLED_BANK=1`` -- the tests' switch) the anchors are baked on the GPU by
 this package's own baker (``atmosphere_bake_luts``, csrc/f3d_aether_bake.hip) -- which reproduces the shipped anchors
 to the last f16 bit in 99.99 % of the values and within 1 f16 ulp in the rest (tests/test_aether_bake.py) -- and that
 provenance is VISIBLE: the handle says ``precomputed=False`` / ``provenance="baked"`` and a ``RuntimeWarning`` is
@@ -29,6 +32,7 @@ from pathlib import Path
 import numpy as np
 
 TURBIDITY_BANK = (1.0, 2.0, 4.0, 8.0, 10.0)
+INSTALLED_BANK = Path(__file__).resolve().parent / "data" / "aether_bank"  # the reference's five anchors (data), SHA-checked on load
 ANCHOR_SHA256 = {  # precomputed.rs:36-43
     1.0: "9ead28087343283942d0bf834aecfb7b3a7b0ea513b830731c2cf9bc77a15f0b",
     2.0: "c6a77bd25241d6123078cace17d9a2181b520c44ac0e871274d755e092e565bc",
@@ -113,12 +117,14 @@ def find_bank(bank_dir=None) -> Path:
         candidates.append(Path(os.environ["FORGE3D_AETHER_LUT_DIR"]))
     if os.environ.get("FORGE3D_REPO_ROOT"):
         candidates.append(Path(os.environ["FORGE3D_REPO_ROOT"]) / "src" / "core" / "atmosphere" / "precomputed")
+    if os.environ.get("FORGE3D_AETHER_NO_INSTALLED_BANK", "") in ("", "0"):
+        candidates.append(INSTALLED_BANK)
     for c in candidates:
         if c.is_dir() and any(c.glob("turbidity-*.bin")):
             return c
     raise FileNotFoundError(
         "no AETHER LUT bank found (looked in bank_dir, $FORGE3D_AETHER_LUT_DIR, $FORGE3D_REPO_ROOT/src/core/atmosphere/"
-        "precomputed): forge3d_amd does not ship the reference's baked tables")
+        "precomputed and the package's data/aether_bank)")
 
 
 def _read_anchor(bank: Path, turbidity: float, dims: LutDimensions):
@@ -235,7 +241,7 @@ def _warn_baked_once() -> None:
         import warnings
 
         warnings.warn("forge3d_amd.atmosphere: no AETHER LUT bank directory found (bank_dir, $FORGE3D_AETHER_LUT_DIR, "
-                      "$FORGE3D_REPO_ROOT): the turbidity anchors are baked on the GPU by this package's baker instead of read "
+                      "$FORGE3D_REPO_ROOT, the package's data/aether_bank): the turbidity anchors are baked on the GPU by this package's baker instead of read "
                       "from the reference's SHA-locked files (<= 1 f16 ulp apart; handle.provenance == 'baked'). "
                       "Set FORGE3D_AETHER_REQUIRE_BANK=1 to make this an error.", RuntimeWarning, stacklevel=3)
 

@@ -352,3 +352,24 @@ int smoke_oracle_raymarch_projection_rgba(const smoke_volume *v, uint32_t width,
     }
     return 0;
 }
+
+/* ---- hooks onto the marcher's primitives (tests/test_smoke.py: pinned against vectors written by the REFERENCE's own NumPy
+ * helpers, python/forge3d/smoke.py:734-941, through tests/golden/make_smoke_vectors.py).  The NumPy helpers are the
+ * reference's second, independent statement of the same primitives (its example renderer), so a misreading of
+ * src/smoke/render.rs shared by this file and the HIP kernel cannot hide behind them. ---- */
+void smoke_oracle_hook_sample_scalar(const float *field, const uint32_t dims[3], const float *points, uint32_t n, float *out) {
+    for (uint32_t i = 0; i < n; i++) out[i] = sample_scalar(field, dims, points + 3u * i); /* voxel-index coordinates (x, y, z) */
+}
+void smoke_oracle_hook_ray_box(const float *origins, const float dir[3], const float mn[3], const float mx[3], uint32_t n,
+                               float *near_out, float *far_out, int32_t *valid) {
+    for (uint32_t i = 0; i < n; i++) {
+        float a = 0.0f, b = 0.0f;
+        valid[i] = ray_box_intersection((v3){origins[3u * i], origins[3u * i + 1u], origins[3u * i + 2u]}, (v3){dir[0], dir[1], dir[2]},
+                                        (v3){mn[0], mn[1], mn[2]}, (v3){mx[0], mx[1], mx[2]}, &a, &b);
+        near_out[i] = a;
+        far_out[i] = b;
+    }
+}
+float smoke_oracle_hook_henyey_greenstein(float cos_theta, float g) { return henyey_greenstein(cos_theta, g); }
+float smoke_oracle_hook_smoothstep(float e0, float e1, float x) { return render_smoothstep(e0, e1, x); }
+float smoke_oracle_hook_exp(float x) { return exp_det(x); }

@@ -1,6 +1,6 @@
 """AETHER aerial-perspective post of the terrain path tracer (BASELINE.json configs[2]).
 
-Pins: the LUT anchors under tests/golden/atmosphere/ are the reference's shipped bank files (data), verified
+Pins: the LUT anchors under forge3d_amd/data/aether_bank/ are the reference's shipped bank files (data), verified
 against the SHA-256 values the reference locks in src/core/atmosphere/precomputed.rs:36-43; the post itself is
 pinned by the reference's own gates for this pass (tests/test_atmosphere_reference.py:869-963: AOVs untouched,
 > 50 % of hit and of sky pixels change, extreme radiometric inputs stay finite and non-black) evaluated on the
@@ -17,7 +17,7 @@ import scenes
 from forge3d_amd import atmosphere as atm
 from oracle import oracle
 
-BANK = scenes.GOLDEN_DIR / "atmosphere"
+from forge3d_amd.atmosphere import INSTALLED_BANK as BANK  # noqa: E402  (the reference's five anchors: data, byte-identical, SHA-locked)
 
 
 def aerial_scene(size=64, exposure=1.0, sun_intensity=2.5):
@@ -45,7 +45,7 @@ def handle(turbidity=10.0):
 def _independent_vectors():
     import json
 
-    return json.loads((BANK / "independent_oracle_vectors.json").read_text())
+    return json.loads((scenes.GOLDEN_DIR / "atmosphere" / "independent_oracle_vectors.json").read_text())
 
 
 def test_segment_transmittance_follows_the_independent_spectral_law():
@@ -169,6 +169,11 @@ def test_missing_bank_is_visible_or_an_error(monkeypatch):
     """round-2 advice: load_shipped must not silently substitute baked anchors for the shipped bank."""
     monkeypatch.delenv("FORGE3D_AETHER_LUT_DIR", raising=False)
     monkeypatch.delenv("FORGE3D_REPO_ROOT", raising=False)
+    # as installed, the package answers with the reference's own anchors (round-4 verdict 2d: the bench's C3 ran on "baked")
+    monkeypatch.delenv("FORGE3D_AETHER_NO_INSTALLED_BANK", raising=False)
+    installed = atm.AtmosphereLutHandle.load_shipped(atm.AtmosphereConfig(turbidity=9.0), require_bank=True)
+    assert installed.precomputed and installed.provenance == "shipped" and installed.precomputed_turbidity_bracket == (8.0, 10.0)
+    monkeypatch.setenv("FORGE3D_AETHER_NO_INSTALLED_BANK", "1")  # ... and an installation without its data directory:
     with pytest.raises(FileNotFoundError):
         atm.AtmosphereLutHandle.load_shipped(atm.AtmosphereConfig(turbidity=3.0), require_bank=True)
     monkeypatch.setenv("FORGE3D_AETHER_REQUIRE_BANK", "1")
@@ -180,7 +185,7 @@ def test_missing_bank_is_visible_or_an_error(monkeypatch):
 
 # ---- LUT bank ------------------------------------------------------------------------------------------
 def test_fixture_anchors_are_the_reference_anchors():
-    for t in (2.0, 4.0, 10.0):
+    for t in atm.TURBIDITY_BANK:
         raw = (BANK / f"turbidity-{int(t)}.bin").read_bytes()
         assert len(raw) == 598_032 and hashlib.sha256(raw).hexdigest() == atm.ANCHOR_SHA256[t]
 
@@ -200,7 +205,7 @@ def test_anchor_payloads_are_complete_and_physical():
     assert h.precomputed_turbidity_bracket == (1.0, 2.0)
 
 
-def test_bracket_interpolation_rounds_through_f16():
+def test_bracket_interpolation_rounds_through_f16(tmp_path):
     """precomputed.rs interpolate_f16 (:60-84): f16(a + (b - a) * factor) per component"""
     lo, hi, mid = handle(2.0), handle(4.0), handle(3.0)
     a = lo.accumulated_scattering.view(np.float16).astype(np.float32)
@@ -208,8 +213,11 @@ def test_bracket_interpolation_rounds_through_f16():
     want = (a + (b - a) * np.float32(0.5)).astype(np.float16).view(np.uint16)
     assert np.array_equal(mid.accumulated_scattering, want) and mid.precomputed_turbidity_bracket == (2.0, 4.0)
     assert np.allclose(mid.order_deltas, 0.5 * (lo.order_deltas + hi.order_deltas))
+    partial = tmp_path / "bank"
+    partial.mkdir()
+    (partial / "turbidity-10.bin").write_bytes((BANK / "turbidity-10.bin").read_bytes())
     with pytest.raises(FileNotFoundError):
-        atm.AtmosphereLutHandle.load_shipped(atm.AtmosphereConfig(turbidity=9.0), bank_dir=BANK)  # anchor 8 is not a fixture
+        atm.AtmosphereLutHandle.load_shipped(atm.AtmosphereConfig(turbidity=9.0), bank_dir=partial)  # anchor 8 is not in THAT directory
 
 
 def test_atmosphere_setting_is_parsed_like_the_reference(monkeypatch):
@@ -336,6 +344,7 @@ def test_missing_bank_bakes_visibly_on_the_gpu(monkeypatch):
     monkeypatch.delenv("FORGE3D_AETHER_LUT_DIR", raising=False)
     monkeypatch.delenv("FORGE3D_REPO_ROOT", raising=False)
     monkeypatch.delenv("FORGE3D_AETHER_REQUIRE_BANK", raising=False)
+    monkeypatch.setenv("FORGE3D_AETHER_NO_INSTALLED_BANK", "1")
     monkeypatch.setattr(atm, "_WARNED_BAKED", False)
     with pytest.warns(RuntimeWarning, match="baked on the GPU"):
         h = atm.AtmosphereLutHandle.load_shipped(atm.AtmosphereConfig(turbidity=2.0))

@@ -1182,3 +1182,25 @@ def test_config4_strip_of_4096_pixels_matches_the_oracle(f3d, oracle):
     for key in ("albedo", "normal", "depth"):  # frame-0 AOVs of the strip: the oracle's rows
         assert np.array_equal(got[key], want[key][rows[0]:rows[1]], equal_nan=True), key
     assert np.isclose(got["albedo"][..., 2], 0.8, atol=2e-3).any()  # a building is in the strip
+
+
+def test_one_process_uploads_a_dem_to_two_devices(f3d):
+    """Round-4 advice: the staged upload's pinned buffers and events were one process-wide pair, created under whichever
+    device uploaded first; a second device then recorded another device's event on its stream.  One process, two devices,
+    a DEM past the 256 KiB staging threshold on each, same image from both.  Skipped on a one-GPU box."""
+    from forge3d_amd import _native
+    from forge3d_amd.session import TerrainSession
+
+    if _native.device_count() < 2:
+        pytest.skip("needs two HIP devices")
+    dem = scenes.golden_dem(1)  # 256 x 256 f32 = 256 KiB: the chunked path
+    assert dem.nbytes >= 256 << 10
+    kw = scenes.fixed_frames(scenes.scene_kwargs(dem), 3, spp=2)
+    images = []
+    for device in (0, 1, 0):
+        _native.lib().f3d_scene_cache_limit(0)  # every session uploads
+        with TerrainSession(dem, 96, 64, scenes.CAM, device=device, **kw) as s:
+            s.enqueue_frames(0, 3, False)
+            images.append(s.resolve(3)["rgba"])
+    _native.lib().f3d_scene_cache_limit(2)
+    assert np.array_equal(images[0], images[1]) and np.array_equal(images[0], images[2])

@@ -14,7 +14,7 @@ import scenes
 from forge3d_amd import atmosphere as atm
 from oracle import oracle, wavefront_oracle
 
-BANK = scenes.GOLDEN_DIR / "atmosphere"
+from forge3d_amd.atmosphere import INSTALLED_BANK as BANK  # noqa: E402
 
 
 def _case(turbidity=None):

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import smoke_oracle
+import scenes
 
 
 def ball(dims, centre, radius, value):
@@ -274,3 +275,132 @@ def test_config5_sequence_of_120_frames_matches_the_oracle():
     assert len(seq) == 120
     for i, img in enumerate(seq):
         assert np.array_equal(img, smoke_oracle.render_rgba(_sequence_fields(i), 240, 135, frame_index=i, fovy_deg=40.0, **cam)), i
+
+
+# ---- the marcher's primitives against the REFERENCE'S OWN NumPy statements of them ---------------------------------------
+# tests/golden/smoke/marcher_vectors.npz: inputs and outputs of python/forge3d/smoke.py:734-941 (_smoke_sample_volume,
+# _smoke_ray_box_intersection, _smoke_henyey_greenstein, _smoke_smoothstep, _smoke_light_transmittance), written by
+# tests/golden/make_smoke_vectors.py in the build container.  Round-4 verdict (Weak 3): the marcher's oracle was pinned by
+# properties only -- "a shared misreading passes".  The NumPy helpers are the reference's second, independent statement of
+# the same primitives, so oracle/smoke_oracle.c's hooks are checked against them: exactly where the two statements perform
+# the same f32 operations, to a few ulps where they differ in form (mix vs lerp, 1/d vs division, f64 vs f32 powers).
+def _marcher_vectors():
+    return np.load(scenes.GOLDEN_DIR / "smoke" / "marcher_vectors.npz")
+
+
+def _hook_sample(field, xyz):
+    import ctypes as C
+
+    L = smoke_oracle.lib()
+    field = np.ascontiguousarray(field, np.float32)
+    d, h, w = field.shape
+    dims = (C.c_uint32 * 3)(w, h, d)
+    pts = np.ascontiguousarray(xyz, np.float32)
+    out = np.zeros(len(pts), np.float32)
+    L.smoke_oracle_hook_sample_scalar(field.ctypes.data_as(C.c_void_p), dims, pts.ctypes.data_as(C.c_void_p), C.c_uint32(len(pts)),
+                                      out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_trilinear_sampler_agrees_with_the_reference_numpy_sampler(tag):
+    v = _marcher_vectors()
+    field, xyz, want = v[f"sample_{tag}_field"], v[f"sample_{tag}_xyz"], v[f"sample_{tag}_out"]
+    got = _hook_sample(field, xyz)
+    # a*(1-t) + b*t against a + (b-a)*t, three levels deep: a few ulps of the largest corner value (fields are in [0, 3])
+    assert np.max(np.abs(got - want)) <= 3.0 * 8 * np.finfo(np.float32).eps
+    # on lattice points both forms return the stored voxel exactly
+    lattice = np.all(xyz == np.floor(xyz), axis=1)
+    assert lattice.sum() >= 5
+    assert np.array_equal(got[lattice], want[lattice])
+    # and the far faces are inside the domain for both (the Rust sampler clamps, the NumPy one keeps x <= width - 1 valid)
+    d, h, w = field.shape
+    far = (xyz[:, 0] == w - 1) | (xyz[:, 1] == h - 1) | (xyz[:, 2] == d - 1)
+    assert far.sum() >= 30 and np.all(want[far] > 0.0) and np.max(np.abs(got[far] - want[far])) <= 3.0 * 8 * np.finfo(np.float32).eps
+
+
+def test_ray_box_agrees_with_the_reference_numpy_intersection():
+    import ctypes as C
+
+    v = _marcher_vectors()
+    L = smoke_oracle.lib()
+    upper = v["box_upper"]
+    mn = (C.c_float * 3)(0.0, 0.0, 0.0)
+    mx = (C.c_float * 3)(*[float(x) for x in upper])
+    checked = 0
+    for k in range(8):
+        o, dvec = np.ascontiguousarray(v[f"box_{k}_origins"], np.float32), v[f"box_{k}_dir"]
+        n = len(o)
+        near, far, valid = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.int32)
+        L.smoke_oracle_hook_ray_box(o.ctypes.data_as(C.c_void_p), (C.c_float * 3)(*[float(x) for x in dvec]), mn, mx, C.c_uint32(n),
+                                    near.ctypes.data_as(C.c_void_p), far.ctypes.data_as(C.c_void_p), valid.ctypes.data_as(C.c_void_p))
+        want_valid, want_enter, want_exit = v[f"box_{k}_valid"], v[f"box_{k}_enter"], v[f"box_{k}_exit"]
+        # (lo - o) * (1 / d) against (lo - o) / d: one rounding apart, so a verdict may only differ where the interval is
+        # within a few ulps of empty; everywhere else it is the same verdict and the same interval to a few ulps
+        scale = np.maximum(1.0, np.maximum(np.abs(want_enter), np.abs(want_exit)))
+        scale = np.where(np.isfinite(scale), scale, 1.0)
+        margin = want_exit - np.maximum(want_enter, 0.0)
+        knife = np.abs(margin) <= 8 * np.finfo(np.float32).eps * scale
+        # One place where the reference's two statements differ by construction: an origin EXACTLY on a face plane with the
+        # ray parallel to that face.  The NumPy helper calls it inside (origin >= 0 and origin <= upper -> (-inf, +inf)); the
+        # Rust marcher forms (plane - origin) * (1 / 0 -> inf) = 0 * inf = NaN there, glam's min / max drop the NaN and keep
+        # the other plane's infinity, and the ray misses (src/smoke/render.rs:348-377, restated as written).  Measure zero
+        # for a camera; the vectors hold such rows on purpose and they are set aside here.
+        for axis in range(3):
+            if dvec[axis] == 0.0:
+                knife |= (o[:, axis] == 0.0) | (o[:, axis] == upper[axis])
+        assert np.array_equal(valid.astype(bool)[~knife], want_valid[~knife])
+        assert knife.mean() < 0.06
+        both = valid.astype(bool) & want_valid
+        # an axis the ray is parallel to contributes (-inf, +inf) in both statements: compare the finite bounds
+        fin = both & np.isfinite(want_enter) & np.isfinite(want_exit)
+        assert np.max(np.abs(near[fin] - want_enter[fin]) / scale[fin]) <= 4 * np.finfo(np.float32).eps
+        assert np.max(np.abs(far[fin] - want_exit[fin]) / scale[fin]) <= 4 * np.finfo(np.float32).eps
+        checked += int(fin.sum())
+    assert checked > 1000
+
+
+def test_phase_function_and_smoothstep_agree_with_the_reference_numpy_helpers():
+    v = _marcher_vectors()
+    L = smoke_oracle.lib()
+    import ctypes as C
+
+    L.smoke_oracle_hook_henyey_greenstein.restype = C.c_float
+    L.smoke_oracle_hook_smoothstep.restype = C.c_float
+    got = np.asarray([L.smoke_oracle_hook_henyey_greenstein(C.c_float(float(c)), C.c_float(float(g))) for c, g in v["hg_in"]], np.float64)
+    # f32 (denominator * sqrt) against f64 denom ** 1.5; the Rust marcher does not clamp g (its settings validation bounds it)
+    assert np.max(np.abs(got - v["hg_out"]) / v["hg_out"]) <= 4e-6
+    for (e0, e1), want in zip(v["smoothstep_edges"], v["smoothstep_out"]):
+        got = np.asarray([L.smoke_oracle_hook_smoothstep(C.c_float(float(e0)), C.c_float(float(e1)), C.c_float(float(x))) for x in v["smoothstep_x"]])
+        assert np.max(np.abs(got - want)) <= 4 * np.finfo(np.float32).eps
+
+
+def test_numpy_sun_march_rebuilt_from_the_oracle_primitives():
+    """_smoke_light_transmittance (python/forge3d/smoke.py:847-876) is a composite of the sampler and exp(): the same loop built
+    from the oracle's sample_scalar and exp_det reproduces the reference's output (inside the grid; where the NumPy sampler
+    returns 0 outside it the rebuilt loop does the same)."""
+    import ctypes as C
+
+    v = _marcher_vectors()
+    L = smoke_oracle.lib()
+    L.smoke_oracle_hook_exp.restype = C.c_float
+    density, soot, sun = v["light_density"], v["light_soot"], v["light_sun"]
+    depth, height, width = density.shape
+    zg, xg = np.mgrid[0:depth, 0:width].astype(np.float32)
+    for k in range(2):
+        layer, steps, step_size, density_scale, extinction, soot_absorption = [float(x) for x in v[f"light_{k}_params"]]
+        if step_size <= 0.0:
+            step_size = 1.0
+        od = np.zeros((depth, width), np.float32)
+        for i in range(1, int(steps) + 1):
+            dist = float(i) * step_size
+            sx, sy, sz = xg + float(sun[0]) * dist, np.full_like(xg, layer) + float(sun[1]) * dist, zg + float(sun[2]) * dist
+            inside = (sx >= 0) & (sx <= width - 1) & (sy >= 0) & (sy <= height - 1) & (sz >= 0) & (sz <= depth - 1)
+            pts = np.stack([sx, sy, sz], axis=-1).reshape(-1, 3)
+            sd = np.where(inside, _hook_sample(density, pts).reshape(depth, width), 0.0)
+            ss = np.where(inside, _hook_sample(soot, pts).reshape(depth, width), 0.0)
+            od += (sd * density_scale * extinction * (1.0 + ss * soot_absorption * 0.85) * step_size).astype(np.float32)
+        got = np.asarray([L.smoke_oracle_hook_exp(C.c_float(-float(x))) for x in np.clip(od, 0.0, 9.0).reshape(-1)], np.float32).reshape(depth, width)
+        want = v[f"light_{k}_out"]
+        assert want.min() < 0.5 < want.max()  # the case exercises real attenuation
+        assert np.max(np.abs(got - want)) <= 2e-5
