@@ -11,6 +11,9 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <map>
+#include <mutex>
+#include <string>
 
 namespace f3d {
 
@@ -66,6 +69,61 @@ inline hipError_t device_free(void *p) {
         if (pool_give(p)) return hipSuccess;
     }
     return hipFree(base ? base : p);
+}
+
+// ---- stream-ordered scratch that outlives a call (round 5) -----------------------------------------------------------------
+// The smoke entry points (f3d_smoke_step / _render / _composite) run on the null stream and used to allocate their scratch
+// per call and free it at the end -- which forced every call to wait for its own kernels and, through the pool's wait,
+// for the device: 0.55 ms of host time around 1.9 ms of kernels per frame of a resident sequence (BASELINE.json configs[4]).
+// A workspace buffer is identified by a tag, grows when a call needs more, and stays: the next call's kernels are behind
+// this call's in the stream, so reuse needs no wait, and a call whose results stay on the device can return as soon as its
+// launches are enqueued.  One caller at a time per device (workspace_lock: held while a call enqueues).
+// f3d_device_pool_trim() frees the workspace too.
+struct WorkspaceEntry {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+inline std::mutex &workspace_lock() {
+    static std::mutex &m = *new std::mutex();
+    return m;
+}
+inline std::map<std::pair<int, std::string>, WorkspaceEntry> &workspace_map() {
+    static auto &m = *new std::map<std::pair<int, std::string>, WorkspaceEntry>();  // (never destroyed: static destructors run after the HIP runtime has gone)
+    return m;
+}
+// (call with workspace_lock() held) a buffer of at least `bytes` for `tag` on the current device; hipErrorOutOfMemory etc. on failure
+inline hipError_t workspace(void **out, const char *tag, size_t bytes) {
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    WorkspaceEntry &w = workspace_map()[{device, std::string(tag)}];
+    if (w.bytes < bytes || !w.p) {
+        if (w.p) {
+            (void)hipDeviceSynchronize();  // (rare: a larger domain than before) whatever still reads the old buffer
+            (void)device_free(w.p);
+            w = WorkspaceEntry{};
+        }
+        e = device_alloc(&w.p, bytes);
+        if (e != hipSuccess) {
+            w = WorkspaceEntry{};
+            return e;
+        }
+        w.bytes = bytes;
+    }
+    *out = w.p;
+    return hipSuccess;
+}
+inline void workspace_trim() {
+    std::lock_guard<std::mutex> lock(workspace_lock());
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    for (auto &kv : workspace_map()) {
+        (void)hipSetDevice(kv.first.first);
+        (void)hipDeviceSynchronize();
+        if (kv.second.p) (void)device_free(kv.second.p);
+    }
+    workspace_map().clear();
+    if (prev >= 0) (void)hipSetDevice(prev);
 }
 
 }  // namespace f3d

@@ -1357,7 +1357,10 @@ const char *f3d_device_name(int32_t device) {
 
 const char *f3d_version(void) { return "forge3d_amd 0.3.0 (gfx950 terrain path tracer)"; }
 uint32_t f3d_abi_version(void) { return F3D_ABI_VERSION; }
-void f3d_device_pool_trim(void) { f3d::pool_trim(); }
+void f3d_device_pool_trim(void) {
+    f3d::workspace_trim();  // (first: its buffers go to the pool, which is emptied next)
+    f3d::pool_trim();
+}
 
 #ifndef F3D_SOURCE_DIGEST
 #define F3D_SOURCE_DIGEST "unknown"

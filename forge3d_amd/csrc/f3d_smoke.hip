@@ -10,8 +10,13 @@
 // Results are bit-identical to oracle/smoke_oracle.c (same operation order, no contraction, exp_det).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <exception>
+#include <mutex>
+#include <vector>
 
 #include "f3d_setup.h"
 #include "f3d_devmem.h"
@@ -32,6 +37,8 @@ struct SmokeParams {
     const float2 *rec_b;  // humidity, emission
     uint32_t nx, ny, nz;
     V3 origin, voxel, bmin, bmax;
+    const uint8_t *occupied;  // per 4 x 4 x 4 block of low corners: does a tap whose low corner lies in it touch any density != 0?
+    uint32_t ocx, ocy;        // blocks along x, y
     uint32_t frame_index, width, height, mode;  // mode 0 perspective, 1 projection
     V3 eye, forward, right, camera_up, sun, view;
     float tan_half_fov, aspect, diagonal, step, shadow_step;
@@ -39,18 +46,39 @@ struct SmokeParams {
     uint8_t *out;
 };
 
+// Empty-space map (round 5).  Most of a ray's steps, and most of a self-shadow march, cross voxels that hold NO smoke at all:
+// density exactly 0 at all eight corners of the tap.  Such a step changes nothing -- the interpolated density is 0, the
+// reference's own `density > 1e-5` test skips it (render.rs:226-228), and a self-shadow step adds +0 to the optical depth
+// (render.rs:308-322) -- but it still cost eight 16-byte gathers from L2, which is what this kernel is bound by (VALU issue
+// 0.33, lane use 0.93: profiles/r04_config_rooflines.json).  k_smoke_pack therefore also marks, per 4 x 4 x 4 block of tap
+// LOW corners, whether any tap with its low corner there touches a voxel whose density is not +-0; a step whose block is
+// unmarked is taken without its loads.  Exact, not a threshold: only taps that are zero at every corner are skipped, so
+// images stay bit-identical to the oracle's (tests/test_smoke.py).
+constexpr uint32_t kOccShift = 2u;
 struct PackParams {
     const float *density, *temperature, *soot, *humidity, *emission, *age;
     float4 *rec_a;
     float2 *rec_b;
     uint64_t n;
+    uint8_t *occupied;
+    uint32_t nx, ny, nz, ocx, ocy;
 };
 
 __global__ void k_smoke_pack(const PackParams P) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.n) return;
-    P.rec_a[i] = float4{P.density[i], P.soot[i], P.age[i], P.temperature[i]};
+    const float d = P.density[i];
+    P.rec_a[i] = float4{d, P.soot[i], P.age[i], P.temperature[i]};
     P.rec_b[i] = float2{P.humidity[i], P.emission[i]};
+    if (d != 0.0f) {  // (also true for a NaN: never skipped)
+        // voxel (x, y, z) is a corner of the taps whose low corner is (x - 1 .. x, y - 1 .. y, z - 1 .. z)
+        const uint32_t x = (uint32_t)(i % P.nx), y = (uint32_t)((i / P.nx) % P.ny), z = (uint32_t)(i / ((uint64_t)P.nx * P.ny));
+        const uint32_t bx1 = x >> kOccShift, by1 = y >> kOccShift, bz1 = z >> kOccShift;
+        const uint32_t bx0 = (x ? x - 1u : 0u) >> kOccShift, by0 = (y ? y - 1u : 0u) >> kOccShift, bz0 = (z ? z - 1u : 0u) >> kOccShift;
+        for (uint32_t bz = bz0; bz <= bz1; bz++)
+            for (uint32_t by = by0; by <= by1; by++)
+                for (uint32_t bx = bx0; bx <= bx1; bx++) P.occupied[(bz * P.ocy + by) * P.ocx + bx] = 1u;  // (every writer stores the same byte)
+    }
 }
 
 __device__ __forceinline__ float lerp_ref(float a, float b, float t) { return a + (b - a) * t; }  // sampling.rs:88-90
@@ -61,6 +89,7 @@ __device__ __forceinline__ float vdot(V3 a, V3 b) { return (a.x * b.x) + (a.y * 
 // trilinear tap set of grid_coord_from_world + sample_scalar (types.rs:375-381, sampling.rs:1-34)
 struct Tap {
     uint32_t i000, dx, dy, dz;  // linear index of the low corner, strides to the high ones (0 at the border)
+    uint32_t block;             // of the empty-space map (see k_smoke_pack)
     float fx, fy, fz;
 };
 __device__ __forceinline__ Tap make_tap(const SmokeParams &P, V3 pos) {
@@ -71,6 +100,7 @@ __device__ __forceinline__ Tap make_tap(const SmokeParams &P, V3 pos) {
     const uint32_t x0 = (uint32_t)f_floor(x), y0 = (uint32_t)f_floor(y), z0 = (uint32_t)f_floor(z);
     Tap t;
     t.i000 = (z0 * P.ny + y0) * P.nx + x0;
+    t.block = ((z0 >> kOccShift) * P.ocy + (y0 >> kOccShift)) * P.ocx + (x0 >> kOccShift);
     t.dx = x0 + 1u < P.nx ? 1u : 0u;
     t.dy = y0 + 1u < P.ny ? P.nx : 0u;
     t.dz = z0 + 1u < P.nz ? P.nx * P.ny : 0u;
@@ -117,6 +147,9 @@ __device__ float sun_transmittance(const SmokeParams &P, V3 start) {
         const float tt = t0 + ((float)i + 0.5f) * P.shadow_step;
         if (tt > t1) break;
         const Tap t = make_tap(P, vadd(start, vscale(P.sun, P.shadow_step + tt)));
+#if !defined(F3D_SMOKE_NO_SKIP)  // A/B + test-of-the-tests switch
+        if (P.occupied[t.block] == 0u) continue;  // density +-0 at all eight corners: the step adds +-0 to od (and od > 8 was tested when it last grew)
+#endif
         const float density = F3D_TRI(P.rec_a, x), soot = F3D_TRI(P.rec_a, y), age = f_max(F3D_TRI(P.rec_a, z), 0.0f);
         const float age_t = smoothstep_ref(1.6f, 17.0f, age);
         const float gate = 0.50f + 0.50f * smoothstep_ref(0.045f, 0.34f, density);
@@ -132,39 +165,9 @@ __device__ __forceinline__ V3 mix3(V3 a, V3 b, float t) {
 }
 __device__ __forceinline__ uint8_t to_u8(float v) { return (uint8_t)(f_clamp(v, 0.0f, 1.0f) * 255.0f + 0.5f); }
 
-// march_ray_rgba, render.rs:192-288
-__device__ uchar4 march_ray(const SmokeParams &P, V3 origin, V3 dir, float t0, float t1, uint32_t seed) {
-    uint32_t v = seed;  // hash01, sampling.rs:96-103
-    v ^= v >> 16;
-    v *= 0x7FEB352Du;
-    v ^= v >> 15;
-    v *= 0x846CA68Bu;
-    v ^= v >> 16;
-    const float jitter = ((float)v / 4294967296.0f - 0.5f) * P.st.jitter_strength * P.step;
-    float t = f_max(t0 + jitter, 0.0f), transmittance = 1.0f;
-    V3 rgb = V3{0.0f, 0.0f, 0.0f};
-    const float cos_theta = f_clamp(vdot(dir, P.sun), -1.0f, 1.0f);
-    const float g2 = P.st.phase_g * P.st.phase_g;  // henyey_greenstein, render.rs:394-398 (powf(d, 1.5) = d sqrt(d))
-    const float denom = f_max(1.0f + g2 - 2.0f * P.st.phase_g * cos_theta, 1.0e-4f);
-    const float phase = (1.0f - g2) / (4.0f * kPi * (denom * f_sqrt(denom)));
-    for (uint32_t steps = 0u; t < t1 && steps < P.st.max_steps && transmittance > 0.01f; steps++, t += P.step) {
-        const V3 p = vadd(origin, vscale(dir, t));
-        const Tap tp = make_tap(P, p);
-        const Tap &t_ = tp;
-#define t t_
-        const float s_density = F3D_TRI(P.rec_a, x), s_soot = F3D_TRI(P.rec_a, y), s_age = f_max(F3D_TRI(P.rec_a, z), 0.0f);
-#undef t
-        const float age_t = smoothstep_ref(1.6f, 17.0f, s_age);
-        const float gate = 0.50f + 0.50f * smoothstep_ref(0.045f, 0.34f, s_density);
-        const float density = f_max(s_density * P.st.density_scale * (1.0f - 0.58f * age_t) * gate, 0.0f);
-        if (!(density > 1.0e-5f)) continue;
-#define t t_
-        const float s_temperature = F3D_TRI(P.rec_a, w), s_humidity = F3D_TRI(P.rec_b, x), s_emission = F3D_TRI(P.rec_b, y);
-#undef t
-        const float sigma_t = density * P.st.extinction * (1.0f + s_soot * P.st.soot_absorption * 0.85f);
-        const float seg_tr = f_clamp(exp_det(-sigma_t * P.step), 0.0f, 1.0f);
-        const float seg_w = sigma_t > 1.0e-6f ? (1.0f - seg_tr) / sigma_t : P.step;
-        const float light = P.st.self_shadow ? sun_transmittance(P, p) : 1.0f;
+// The in-scattered + emitted radiance of a step (march_ray, render.rs:237-283; smoke_color :343-361)
+__device__ __forceinline__ V3 smoke_source(const SmokeParams &P, V3 p, float s_density, float s_soot, float s_age, float s_temperature, float s_humidity,
+                                           float s_emission, float sigma_t, float light, float phase) {
         // smoke_color, render.rs:343-361
         const float body = f_clamp(s_density * 1.45f + s_soot * 1.35f, 0.0f, 1.0f);
         V3 col = mix3(P.st.thin, P.st.dense, body);
@@ -187,22 +190,62 @@ __device__ uchar4 march_ray(const SmokeParams &P, V3 origin, V3 dir, float t0, f
         const V3 direct = vscale(vscale(cs * sun_rad, phase), light);
         const float fresh_heat = s_temperature * freshness * freshness;
         const V3 emission = vscale(V3{1.0f, 0.30f, 0.055f}, f_clamp((fresh_heat * 0.10f + s_emission * 1.18f) * P.st.fire_glow, 0.0f, 5.0f));
-        const V3 source = vadd(vadd(direct, multiple), emission);
-        rgb = vadd(rgb, vscale(vscale(source, seg_w), transmittance));
-        transmittance *= seg_tr;
-    }
+        return vadd(vadd(direct, multiple), emission);
+}
+// ... and the pixel a finished ray leaves (render.rs:284-288)
+__device__ __forceinline__ uchar4 smoke_pixel(const SmokeParams &P, V3 rgb, float transmittance) {
     const float alpha = f_clamp(1.0f - transmittance, 0.0f, 1.0f);
     const V3 straight = alpha > 1.0e-5f ? V3{rgb.x / alpha, rgb.y / alpha, rgb.z / alpha} : rgb;
     const V3 e = vscale(straight, P.st.exposure);
     return uchar4{to_u8(e.x / (1.0f + e.x)), to_u8(e.y / (1.0f + e.y)), to_u8(e.z / (1.0f + e.z)), to_u8(alpha)};
 }
 
-__global__ __launch_bounds__(64) void k_smoke(const SmokeParams P) {
-    const uint32_t tiles_x = (P.width + 7u) / 8u;
-    const uint32_t x = (blockIdx.x % tiles_x) * 8u + (threadIdx.x & 7u), y = (blockIdx.x / tiles_x) * 8u + (threadIdx.x >> 3);
-    if (x >= P.width || y >= P.height) return;
-    V3 origin, dir;
-    uint32_t seed = x * 73856093u + y * 19349663u + P.frame_index;
+// march_ray_rgba, render.rs:192-288
+__device__ uchar4 march_ray(const SmokeParams &P, V3 origin, V3 dir, float t0, float t1, uint32_t seed) {
+    uint32_t v = seed;  // hash01, sampling.rs:96-103
+    v ^= v >> 16;
+    v *= 0x7FEB352Du;
+    v ^= v >> 15;
+    v *= 0x846CA68Bu;
+    v ^= v >> 16;
+    const float jitter = ((float)v / 4294967296.0f - 0.5f) * P.st.jitter_strength * P.step;
+    float t = f_max(t0 + jitter, 0.0f), transmittance = 1.0f;
+    V3 rgb = V3{0.0f, 0.0f, 0.0f};
+    const float cos_theta = f_clamp(vdot(dir, P.sun), -1.0f, 1.0f);
+    const float g2 = P.st.phase_g * P.st.phase_g;  // henyey_greenstein, render.rs:394-398 (powf(d, 1.5) = d sqrt(d))
+    const float denom = f_max(1.0f + g2 - 2.0f * P.st.phase_g * cos_theta, 1.0e-4f);
+    const float phase = (1.0f - g2) / (4.0f * kPi * (denom * f_sqrt(denom)));
+    for (uint32_t steps = 0u; t < t1 && steps < P.st.max_steps && transmittance > 0.01f; steps++, t += P.step) {
+        const V3 p = vadd(origin, vscale(dir, t));
+        const Tap tp = make_tap(P, p);
+#if !defined(F3D_SMOKE_NO_SKIP)
+        if (P.occupied[tp.block] == 0u) continue;  // density +-0 at all eight corners: the reference's `density > 1e-5` test skips the step
+#endif
+        const Tap &t_ = tp;
+#define t t_
+        const float s_density = F3D_TRI(P.rec_a, x), s_soot = F3D_TRI(P.rec_a, y), s_age = f_max(F3D_TRI(P.rec_a, z), 0.0f);
+#undef t
+        const float age_t = smoothstep_ref(1.6f, 17.0f, s_age);
+        const float gate = 0.50f + 0.50f * smoothstep_ref(0.045f, 0.34f, s_density);
+        const float density = f_max(s_density * P.st.density_scale * (1.0f - 0.58f * age_t) * gate, 0.0f);
+        if (!(density > 1.0e-5f)) continue;
+#define t t_
+        const float s_temperature = F3D_TRI(P.rec_a, w), s_humidity = F3D_TRI(P.rec_b, x), s_emission = F3D_TRI(P.rec_b, y);
+#undef t
+        const float sigma_t = density * P.st.extinction * (1.0f + s_soot * P.st.soot_absorption * 0.85f);
+        const float seg_tr = f_clamp(exp_det(-sigma_t * P.step), 0.0f, 1.0f);
+        const float seg_w = sigma_t > 1.0e-6f ? (1.0f - seg_tr) / sigma_t : P.step;
+        const float light = P.st.self_shadow ? sun_transmittance(P, p) : 1.0f;
+        const V3 source = smoke_source(P, p, s_density, s_soot, s_age, s_temperature, s_humidity, s_emission, sigma_t, light, phase);
+        rgb = vadd(rgb, vscale(vscale(source, seg_w), transmittance));
+        transmittance *= seg_tr;
+    }
+    return smoke_pixel(P, rgb, transmittance);
+}
+
+// the ray of pixel (x, y) and the seed of its jitter
+__device__ __forceinline__ void pixel_ray(const SmokeParams &P, uint32_t x, uint32_t y, V3 &origin, V3 &dir, uint32_t &seed) {
+    seed = x * 73856093u + y * 19349663u + P.frame_index;
     if (P.mode == 0u) {  // raymarch_rgba, render.rs:69-75
         const float px = (((float)x + 0.5f) / (float)P.width * 2.0f - 1.0f) * P.aspect * P.tan_half_fov;
         const float py = (1.0f - ((float)y + 0.5f) / (float)P.height * 2.0f) * P.tan_half_fov;
@@ -216,10 +259,198 @@ __global__ __launch_bounds__(64) void k_smoke(const SmokeParams P) {
         origin = V3{plane.x - dir.x * P.diagonal, plane.y - dir.y * P.diagonal, plane.z - dir.z * P.diagonal};
         seed += 0x9e3779b9u;
     }
+}
+
+// One lane per pixel, the whole ray: the form that runs (see the measurement under "sift + cooperative march" below).
+__global__ __launch_bounds__(64) void k_smoke(const SmokeParams P) {
+    const uint32_t tiles_x = (P.width + 7u) / 8u;
+    const uint32_t x = (blockIdx.x % tiles_x) * 8u + (threadIdx.x & 7u), y = (blockIdx.x / tiles_x) * 8u + (threadIdx.x >> 3);
+    if (x >= P.width || y >= P.height) return;
+    V3 origin, dir;
+    uint32_t seed;
+    pixel_ray(P, x, y, origin, dir, seed);
     uchar4 px4 = uchar4{0, 0, 0, 0};
     float t0, t1;
     if (ray_box(origin, dir, P.bmin, P.bmax, t0, t1)) px4 = march_ray(P, origin, dir, f_max(t0, 0.0f), t1, seed);
     reinterpret_cast<uchar4 *>(P.out)[(size_t)y * P.width + x] = px4;
+}
+
+// ---- sift + cooperative march (round 5) ------------------------------------------------------------------------------------
+// The frame of BASELINE.json configs[4] has 68 000 pixels with smoke in 2 million; their rays -- a self-shadow march of 20
+// steps at every one of ~40 steps inside the plume, each step eight dependent 16-byte gathers -- are 1 100 waves' worth of
+// one-lane-per-pixel work on a chip with 1 024 SIMDs: one wave a SIMD, each waiting for its own loads (lane use 0.93, VALU issue
+// 0.31, 1.4 ms: profiles/r04_config_rooflines.json).  So the frame is taken in two launches:
+//   k_smoke_sift   one lane per pixel: the ray's steps up to the first one that touches smoke at all (the empty-space map,
+//                  k_smoke_pack) -- no loads but the map's byte; rays that never get there are finished (no smoke: 0), the
+//                  others are appended, ballot-compacted, to a list with the state the march resumes from (steps taken, t).
+//   k_smoke_heavy  EIGHT lanes per listed pixel, eight pixels a wave, waves fetching work from a cursor: the lanes of a
+//                  pixel walk its ray together (every value of the reference's loop is replicated in all eight) and share
+//                  what is parallel in it: the self-shadow march, whose steps are independent of each other.  Lane j
+//                  evaluates steps j, j + 8, j + 16 ... and the group then adds the eight terms of a round in step order,
+//                  with the reference's two exits (the ray leaves the box; optical depth > 8) tested where the reference
+//                  tests them -- so the sum is the sequential sum, bit for bit.  Eight times the waves, a third of the
+//                  dependent gathers per step.
+// Results are those of k_smoke (and the oracle) bit for bit: tests/test_smoke.py.
+// MEASURED, NOT ADOPTED (F3D_SMOKE_MARCH=sift runs it; profiles/README.md round 5): 1.65 ms against k_smoke's 1.46 ms on
+// the configs[4] frame, and worse with more waves a SIMD (1.91 / 2.70 ms at 6 / 8: spills).  The premise was wrong: the
+// marcher is not waiting for too few waves' loads, it is bound by what the texture addressers can gather -- TA busy 61 %
+// of the launch, 95 % of the gathers hit L1, 22 addresser cycles per 16-byte x 64-lane gather -- and eight lanes that
+// replicate a pixel's primary taps and spread its shadow taps along the sun direction touch MORE cache lines per gather
+// than 64 neighbouring pixels do.  What did pay is the empty-space map alone (1.60 -> 1.46 ms).
+struct HeavyItem {
+    uint32_t pixel, steps;
+    float t;
+};
+struct SiftParams {
+    SmokeParams P;
+    HeavyItem *items;
+    uint32_t *counters;  // [0] listed pixels, [1] work cursor of k_smoke_heavy
+};
+constexpr uint32_t kGroup = 8u;  // lanes per pixel in k_smoke_heavy
+
+__global__ __launch_bounds__(64) void k_smoke_sift(const SiftParams S) {
+    const SmokeParams &P = S.P;
+    const uint32_t tiles_x = (P.width + 7u) / 8u;
+    const uint32_t x = (blockIdx.x % tiles_x) * 8u + (threadIdx.x & 7u), y = (blockIdx.x / tiles_x) * 8u + (threadIdx.x >> 3);
+    const bool inside = x < P.width && y < P.height;
+    bool heavy = false;
+    HeavyItem item{0u, 0u, 0.0f};
+    if (inside) {
+        V3 origin, dir;
+        uint32_t seed;
+        pixel_ray(P, x, y, origin, dir, seed);
+        float t0, t1;
+        if (ray_box(origin, dir, P.bmin, P.bmax, t0, t1)) {
+            uint32_t v = seed;  // hash01, sampling.rs:96-103 (as march_ray)
+            v ^= v >> 16;
+            v *= 0x7FEB352Du;
+            v ^= v >> 15;
+            v *= 0x846CA68Bu;
+            v ^= v >> 16;
+            const float jitter = ((float)v / 4294967296.0f - 0.5f) * P.st.jitter_strength * P.step;
+            float t = f_max(f_max(t0, 0.0f) + jitter, 0.0f);
+            uint32_t steps = 0u;
+            // the steps that touch no smoke: march_ray's loop with its body skipped (transmittance stays 1)
+            for (; t < t1 && steps < P.st.max_steps; steps++, t += P.step) {
+#if !defined(F3D_SMOKE_NO_SKIP)
+                if (P.occupied[make_tap(P, vadd(origin, vscale(dir, t))).block] != 0u) break;
+#else
+                break;
+#endif
+            }
+            heavy = t < t1 && steps < P.st.max_steps;
+            item = HeavyItem{y * P.width + x, steps, t};
+        }
+        if (!heavy) reinterpret_cast<uchar4 *>(P.out)[(size_t)y * P.width + x] = uchar4{0, 0, 0, 0};
+    }
+    const unsigned long long mask = __ballot(heavy);
+    if (mask != 0ull) {
+        uint32_t base = 0u;
+        const uint32_t lane = threadIdx.x & 63u;
+        if (lane == (uint32_t)__builtin_ctzll(mask)) base = atomicAdd(&S.counters[0], (uint32_t)__popcll(mask));
+        base = (uint32_t)__shfl((int)base, __builtin_ctzll(mask), 64);
+        if (heavy) S.items[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = item;
+    }
+}
+
+// sun_transmittance (render.rs:290-330) by the kGroup lanes of a pixel: see above.  `sub` = the lane's number in its group.
+__device__ float sun_transmittance_group(const SmokeParams &P, V3 start, uint32_t sub, uint32_t group_shift) {
+    float t0, t1;
+    if (!ray_box(vadd(start, vscale(P.sun, P.shadow_step)), P.sun, P.bmin, P.bmax, t0, t1)) return 1.0f;
+    t0 = f_max(t0, 0.0f);
+    float od = 0.0f;
+    bool done = false;
+    for (uint32_t i0 = 0u; i0 < P.st.shadow_steps && !done; i0 += kGroup) {
+        const uint32_t i = i0 + sub;
+        const float tt = t0 + ((float)i + 0.5f) * P.shadow_step;
+        const bool ends = !(i < P.st.shadow_steps) || tt > t1;  // the loop ends in front of this step
+        bool adds = false;
+        float term = 0.0f;
+        if (!ends) {
+            const Tap t = make_tap(P, vadd(start, vscale(P.sun, P.shadow_step + tt)));
+#if !defined(F3D_SMOKE_NO_SKIP)
+            if (P.occupied[t.block] != 0u)
+#endif
+            {
+                const float density = F3D_TRI(P.rec_a, x), soot = F3D_TRI(P.rec_a, y), age = f_max(F3D_TRI(P.rec_a, z), 0.0f);
+                const float age_t = smoothstep_ref(1.6f, 17.0f, age);
+                const float gate = 0.50f + 0.50f * smoothstep_ref(0.045f, 0.34f, density);
+                term = density * P.st.density_scale * (1.0f - 0.58f * age_t) * gate * P.st.extinction * (1.0f + soot * P.st.soot_absorption) * P.shadow_step;
+                adds = true;
+            }
+        }
+        const uint32_t ends_mask = (uint32_t)(__ballot(ends) >> group_shift) & 0xFFu, adds_mask = (uint32_t)(__ballot(adds) >> group_shift) & 0xFFu;
+#pragma unroll
+        for (uint32_t k = 0u; k < kGroup; k++) {
+            const float term_k = __shfl(term, (int)k, (int)kGroup);
+            if (!done) {
+                if ((ends_mask >> k) & 1u) {
+                    done = true;
+                } else if ((adds_mask >> k) & 1u) {
+                    od += term_k;
+                    if (od > 8.0f) done = true;
+                }
+            }
+        }
+    }
+    return f_clamp(exp_det(-od), 0.0f, 1.0f);
+}
+
+#ifndef F3D_SMOKE_HEAVY_WAVES
+#define F3D_SMOKE_HEAVY_WAVES 4
+#endif
+__global__ __launch_bounds__(64, F3D_SMOKE_HEAVY_WAVES) void k_smoke_heavy(const SiftParams S) {
+    const SmokeParams &P = S.P;
+    const uint32_t lane = threadIdx.x & 63u, sub = lane & (kGroup - 1u), group_shift = lane & ~(kGroup - 1u);
+    const uint32_t count = S.counters[0];
+    for (;;) {
+        uint32_t base = 0u;
+        if (lane == 0u) base = atomicAdd(&S.counters[1], 64u / kGroup);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= count) return;
+        const uint32_t index = base + (lane >> 3);
+        if (index < count) {  // (the last fetch's spare groups idle until the wave fetches again)
+        const HeavyItem item = S.items[index];
+        const uint32_t x = item.pixel % P.width, y = item.pixel / P.width;
+        V3 origin, dir;
+        uint32_t seed;
+        pixel_ray(P, x, y, origin, dir, seed);
+        float t0, t1;
+        (void)ray_box(origin, dir, P.bmin, P.bmax, t0, t1);  // (k_smoke_sift found the box: t1 as it computed it)
+        // march_ray from the listed step on
+        float t = item.t, transmittance = 1.0f;
+        V3 rgb = V3{0.0f, 0.0f, 0.0f};
+        const float cos_theta = f_clamp(vdot(dir, P.sun), -1.0f, 1.0f);
+        const float g2 = P.st.phase_g * P.st.phase_g;
+        const float denom = f_max(1.0f + g2 - 2.0f * P.st.phase_g * cos_theta, 1.0e-4f);
+        const float phase = (1.0f - g2) / (4.0f * kPi * (denom * f_sqrt(denom)));
+        for (uint32_t steps = item.steps; t < t1 && steps < P.st.max_steps && transmittance > 0.01f; steps++, t += P.step) {
+            const V3 p = vadd(origin, vscale(dir, t));
+            const Tap tp = make_tap(P, p);
+#if !defined(F3D_SMOKE_NO_SKIP)
+            if (P.occupied[tp.block] == 0u) continue;
+#endif
+            const Tap &t_ = tp;
+#define t t_
+            const float s_density = F3D_TRI(P.rec_a, x), s_soot = F3D_TRI(P.rec_a, y), s_age = f_max(F3D_TRI(P.rec_a, z), 0.0f);
+#undef t
+            const float age_t = smoothstep_ref(1.6f, 17.0f, s_age);
+            const float gate = 0.50f + 0.50f * smoothstep_ref(0.045f, 0.34f, s_density);
+            const float density = f_max(s_density * P.st.density_scale * (1.0f - 0.58f * age_t) * gate, 0.0f);
+            if (!(density > 1.0e-5f)) continue;
+#define t t_
+            const float s_temperature = F3D_TRI(P.rec_a, w), s_humidity = F3D_TRI(P.rec_b, x), s_emission = F3D_TRI(P.rec_b, y);
+#undef t
+            const float sigma_t = density * P.st.extinction * (1.0f + s_soot * P.st.soot_absorption * 0.85f);
+            const float seg_tr = f_clamp(exp_det(-sigma_t * P.step), 0.0f, 1.0f);
+            const float seg_w = sigma_t > 1.0e-6f ? (1.0f - seg_tr) / sigma_t : P.step;
+            const float light = P.st.self_shadow ? sun_transmittance_group(P, p, sub, group_shift) : 1.0f;
+            rgb = vadd(rgb, vscale(vscale(smoke_source(P, p, s_density, s_soot, s_age, s_temperature, s_humidity, s_emission, sigma_t, light, phase), seg_w), transmittance));
+            transmittance *= seg_tr;
+        }
+        if (sub == 0u) reinterpret_cast<uchar4 *>(P.out)[item.pixel] = smoke_pixel(P, rgb, transmittance);
+        }
+    }
 }
 
 void hip_ok(hipError_t e, const char *what) {
@@ -277,7 +508,6 @@ void validate_volume(const f3d_smoke_volume &v) {  // SmokeDomainConfig::validat
 extern "C" int f3d_smoke_render(const f3d_smoke_volume *vol, const f3d_smoke_view *view, const f3d_smoke_settings *settings,
                                 uint8_t *rgba, double *kernel_seconds, char *err, size_t errlen) {
     if (err && errlen) err[0] = 0;
-    std::vector<void *> owned;
     int rc = F3D_STATUS_OK;
     try {
         if (!vol || !view || !settings || !rgba) fail(F3D_STATUS_VALUE, "null argument");
@@ -331,10 +561,13 @@ extern "C" int f3d_smoke_render(const f3d_smoke_volume *vol, const f3d_smoke_vie
                                 V3{settings->thin_color[0], settings->thin_color[1], settings->thin_color[2]},
                                 V3{settings->dense_color[0], settings->dense_color[1], settings->dense_color[2]}};
 
-        auto alloc = [&](size_t bytes, const char *what) {
+        std::lock_guard<std::mutex> workspace_guard(workspace_lock());  // one smoke call at a time enqueues (f3d_devmem.h)
+        uint32_t n_scratch = 0;
+        auto alloc = [&](size_t bytes, const char *what) {  // stream-ordered scratch that stays for the next call
+            char tag[48];
+            snprintf(tag, sizeof(tag), "smoke.render.%u", n_scratch++);  // (the same sequence of requests in every call)
             void *p = nullptr;
-            hip_ok(device_alloc(&p, bytes), what);
-            owned.push_back(p);
+            hip_ok(workspace(&p, tag, bytes), what);
             return p;
         };
         const uint64_t n = (uint64_t)P.nx * P.ny * P.nz;
@@ -346,6 +579,7 @@ extern "C" int f3d_smoke_render(const f3d_smoke_volume *vol, const f3d_smoke_vie
             (void)hipGetLastError();
             if (resident) {
                 dev[i] = host[i];
+                n_scratch++;  // (keeps the numbering of the requests after it)
                 continue;
             }
             float *up = (float *)alloc(n * sizeof(float), "smoke field");
@@ -354,7 +588,13 @@ extern "C" int f3d_smoke_render(const f3d_smoke_volume *vol, const f3d_smoke_vie
         }
         float4 *rec_a = (float4 *)alloc(n * sizeof(float4), "smoke records");
         float2 *rec_b = (float2 *)alloc(n * sizeof(float2), "smoke records");
-        const PackParams pack{dev[0], dev[1], dev[2], dev[3], dev[4], dev[5], rec_a, rec_b, n};
+        P.ocx = ((P.nx - 1u) >> kOccShift) + 1u;
+        P.ocy = ((P.ny - 1u) >> kOccShift) + 1u;
+        const size_t occ_bytes = (size_t)P.ocx * P.ocy * (((P.nz - 1u) >> kOccShift) + 1u);
+        uint8_t *occupied = (uint8_t *)alloc(occ_bytes, "smoke empty-space map");
+        hip_ok(hipMemsetAsync(occupied, 0, occ_bytes, nullptr), "smoke empty-space map");
+        P.occupied = occupied;
+        const PackParams pack{dev[0], dev[1], dev[2], dev[3], dev[4], dev[5], rec_a, rec_b, n, occupied, P.nx, P.ny, P.nz, P.ocx, P.ocy};
         hipLaunchKernelGGL(k_smoke_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, pack);
         hip_ok(hipGetLastError(), "smoke pack kernel");
         P.rec_a = rec_a;
@@ -364,21 +604,42 @@ extern "C" int f3d_smoke_render(const f3d_smoke_volume *vol, const f3d_smoke_vie
         const bool out_on_device = hipPointerGetAttributes(&out_attr, rgba) == hipSuccess && out_attr.type == hipMemoryTypeDevice;
         (void)hipGetLastError();
         P.out = out_on_device ? rgba : (uint8_t *)alloc(px * 4, "smoke rgba");  // (a device image stays on the device: the composite reads it there)
-        hipEvent_t e0, e1;
-        hip_ok(hipEventCreate(&e0), "event");
-        hip_ok(hipEventCreate(&e1), "event");
-        hip_ok(hipEventRecord(e0, nullptr), "event");
+        if (out_on_device) n_scratch++;
+        HeavyItem *items = (HeavyItem *)alloc(px * sizeof(HeavyItem), "smoke work list");
+        uint32_t *counters = (uint32_t *)alloc(2 * sizeof(uint32_t), "smoke work list");
+        // a device image whose caller does not ask for the kernel time: the call returns with its launches enqueued
+        const bool timed = kernel_seconds != nullptr || !out_on_device;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (timed) {
+            hip_ok(hipEventCreate(&e0), "event");
+            hip_ok(hipEventCreate(&e1), "event");
+            hip_ok(hipEventRecord(e0, nullptr), "event");
+        }
         const uint32_t tiles = ((P.width + 7u) / 8u) * ((P.height + 7u) / 8u);
-        hipLaunchKernelGGL(k_smoke, dim3(tiles), dim3(64), 0, nullptr, P);
+        const char *form = getenv("F3D_SMOKE_MARCH");
+        if (!(form && strcmp(form, "sift") == 0)) {  // the default: one lane per pixel, the whole ray
+            hipLaunchKernelGGL(k_smoke, dim3(tiles), dim3(64), 0, nullptr, P);
+        } else {
+            SiftParams S{};
+            S.P = P;
+            S.items = (HeavyItem *)alloc(px * sizeof(HeavyItem), "smoke work list");
+            S.counters = (uint32_t *)alloc(2 * sizeof(uint32_t), "smoke work list");
+            hip_ok(hipMemsetAsync(S.counters, 0, 2 * sizeof(uint32_t), nullptr), "smoke work list");
+            hipLaunchKernelGGL(k_smoke_sift, dim3(tiles), dim3(64), 0, nullptr, S);
+            const uint32_t waves = (uint32_t)std::min<size_t>((px + 7u) / 8u, 16384u);  // (work is fetched from a cursor: any number >= what the chip holds will do)
+            hipLaunchKernelGGL(k_smoke_heavy, dim3(waves), dim3(64), 0, nullptr, S);
+        }
         hip_ok(hipGetLastError(), "smoke kernel");
-        hip_ok(hipEventRecord(e1, nullptr), "event");
-        if (out_on_device) hip_ok(hipEventSynchronize(e1), "smoke kernel");
-        else hip_ok(hipMemcpy(rgba, P.out, px * 4, hipMemcpyDeviceToHost), "smoke readback");
-        float ms = 0.0f;
-        (void)hipEventElapsedTime(&ms, e0, e1);
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        if (kernel_seconds) *kernel_seconds = ms * 1e-3;
+        if (timed) {
+            hip_ok(hipEventRecord(e1, nullptr), "event");
+            if (out_on_device) hip_ok(hipEventSynchronize(e1), "smoke kernel");
+            else hip_ok(hipMemcpy(rgba, P.out, px * 4, hipMemcpyDeviceToHost), "smoke readback");
+            float ms = 0.0f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            if (kernel_seconds) *kernel_seconds = ms * 1e-3;
+        }
     } catch (const Failure &f) {
         rc = report(f, err, errlen);
     } catch (const std::exception &e) {
@@ -387,6 +648,5 @@ extern "C" int f3d_smoke_render(const f3d_smoke_volume *vol, const f3d_smoke_vie
     } catch (...) {
         rc = F3D_STATUS_DEVICE;
     }
-    for (void *p : owned) (void)device_free(p);
     return rc;
 }

@@ -4,7 +4,10 @@
 // configs[4] (a 120-frame sequence) advances it frame by frame and renders each state with f3d_smoke_render.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <exception>
 #include <vector>
 
@@ -83,6 +86,286 @@ __global__ void k_sum_total(const SumArgs A) {
     if (threadIdx.x < A.n_kinds) A.out[A.out_slot[threadIdx.x]] = sim_sum_seq(A.slabs + (size_t)threadIdx.x * A.G.nz, A.G.nz);
 }
 
+// ---- the step as PHASES (round 5) -------------------------------------------------------------------------------------
+// A step of the launch-per-pass form above is ~85 launches and copies of 8-11 us each over a grid whose every pass is 1-2 us
+// of memory traffic (786 432 voxels in BASELINE.json configs[4]): 0.82 ms of launch ramps.  Per voxel the arithmetic of a
+// pass is a function of the previous passes' fields (f3d_smoke_sim.h), so passes can share a launch whenever no voxel reads
+// what ANOTHER voxel writes in it.  The phases below are that grouping -- 17 + the Jacobi sweeps instead of ~55 + the sweeps:
+//   * pointwise passes ride with their neighbours in the step (emission clear + emitters + forces; gradient + boundary
+//     conditions; mass scaling + sub-grid eddies; diffusion + decay);
+//   * the three velocity components are diffused in one phase, the five scalar fields advected in one phase from ONE
+//     back-trace (the reference re-derives the identical back-traced position per field) and diffused in one phase;
+//   * no device-to-device copies and no clears: passes alternate between a field and its twin buffer, and the one pass
+//     that would leave a result in the wrong place writes it home in the phase that follows;
+//   * the four grid sums in front of the density advection (mass, centroid) are one row pass with four accumulators.
+// Per voxel every phase calls the launch-per-pass form's functions with the same arguments, so all forms and the oracle
+// agree bit for bit (tests/test_smoke_sim.py).  Two drivers run the phases:
+//   fused       (default) one launch per phase, (x, y) flattened so that a 96-wide row does not leave a third of a wave idle;
+//   persistent  ONE cooperative launch for all steps, a grid barrier between phases -- built to get rid of the launches
+//               altogether and measured (tools/experiments/sim_phases.py): on this chip a grid barrier costs MORE than a
+//               launch, 10 us of same-address atomics and polling + 13 us of cache maintenance (an agent-scope release
+//               writes the XCD's L2 back, an acquire invalidates it: the eight L2s are not coherent with each other) against
+//               ~3.5 us of work per phase; 1.49 ms a step.  Kept as a tested form (F3D_SMOKE_SOLVER=persistent).
+enum Phase : uint32_t { kPhEmitForces, kPhAdvectVec, kPhDiffuseVec, kPhCurl, kPhConfine, kPhDivergence, kPhJacobi, kPhGradientBoundary,
+                        kPhLaneShear, kPhAdvectScalars, kPhCorrectScalars, kPhScaleSubgrid, kPhDiffuseDecay };
+constexpr uint32_t kInlineEmitters = 4u;  // emitters that travel in the kernel arguments (a host-to-device copy of pageable memory waits for the stream)
+struct StepArgs {
+    SimGrid G;
+    SimFields F;
+    SimSettings S;
+    const SimEmitter *emitters;  // more than kInlineEmitters: a device copy
+    SimEmitter inline_emitters[kInlineEmitters];
+    uint32_t emitter_count, steps;
+    float *vel_b, *curl, *mag, *div, *pres_b;
+    float *adv[5], *adv2[5];  // advected scalars (predictor; MacCormack-corrected)
+    float *rows, *slabs, *sums;
+    unsigned int *barrier;  // persistent form: [0] arrivals, [1] generation, [2] abort
+};
+struct PhaseCtx {
+    float *cur, *next;   // Jacobi: pressure in, pressure out; gradient: the final pressure
+    uint32_t corrected;  // the advected scalars are in adv2 (MacCormack) instead of adv
+};
+template <uint32_t PH>
+__device__ __forceinline__ void phase_voxel(const StepArgs &A, const SimGrid &G, const PhaseCtx &C, uint32_t v, uint32_t x, uint32_t y, uint32_t z) {
+    const SimFields &F = A.F;
+    const SimSettings &S = A.S;
+    if (PH == kPhEmitForces) {
+        F.emission_rate[v] = 0.0f;
+        for (uint32_t e = 0u; e < A.emitter_count; e++) {
+            const SimEmitter E = A.emitter_count <= kInlineEmitters ? A.inline_emitters[e] : A.emitters[e];
+            if (G.time_seconds >= E.start_time && G.time_seconds <= E.end_time) sim_emit(G, F, E, S.dt, x, y, z);
+        }
+        sim_forces(G, F, S, x, y, z);
+    } else if (PH == kPhAdvectVec) {
+        sim_advect_vector(G, F.velocity, A.vel_b, S.dt, x, y, z);
+    } else if (PH == kPhDiffuseVec) {  // diffuse_vector (sim.rs:739-754), or the advected velocity as it is: home either way
+        if (S.diffusion > 0.0f) {
+            for (uint32_t c = 0u; c < 3u; c++) sim_diffuse(G, A.vel_b, F.velocity, S.diffusion * S.dt, 3u, c, x, y, z);
+        } else {
+            for (uint32_t c = 0u; c < 3u; c++) F.velocity[3u * (size_t)v + c] = A.vel_b[3u * (size_t)v + c];
+        }
+    } else if (PH == kPhCurl) {
+        sim_curl(G, F.velocity, A.curl, A.mag, x, y, z);
+    } else if (PH == kPhConfine) {
+        sim_confine(G, A.curl, A.mag, F.velocity, S.vorticity, S.dt, x, y, z);
+    } else if (PH == kPhDivergence) {
+        sim_divergence(G, F.velocity, A.div, x, y, z);
+        F.pressure[v] = 0.0f;
+    } else if (PH == kPhJacobi) {
+        sim_jacobi(G, C.cur, A.div, C.next, x, y, z);
+    } else if (PH == kPhGradientBoundary) {
+        sim_subtract_gradient(G, C.cur, F.velocity, x, y, z);
+        if (C.cur != F.pressure) F.pressure[v] = C.cur[v];  // (an odd number of sweeps: the field goes home here)
+        sim_boundary(G, F, S, x, y, z);
+    } else if (PH == kPhLaneShear) {
+        sim_lane_shear(G, F, S, A.sums, x, y, z);
+    } else if (PH == kPhAdvectScalars) {  // advect_scalar x 5, first pass (sim.rs:603-613): one back-trace serves all five
+        const float *old[5] = {F.density, F.temperature, F.fuel, F.soot, F.humidity};
+        float bx, by, bz;
+        sim_back(G, F.velocity, S.dt, x, y, z, bx, by, bz);
+#pragma unroll
+        for (uint32_t f = 0u; f < 5u; f++) A.adv[f][v] = f_max(sim_sample(G, old[f], bx, by, bz, 1u, 0u), 0.0f);
+    } else if (PH == kPhCorrectScalars) {
+        const float *old[5] = {F.density, F.temperature, F.fuel, F.soot, F.humidity};
+#pragma unroll
+        for (uint32_t f = 0u; f < 5u; f++) sim_advect_correct(G, old[f], F.velocity, A.adv[f], A.adv2[f], S.dt, x, y, z);
+    } else if (PH == kPhScaleSubgrid) {
+        float *const *adv = C.corrected ? A.adv2 : A.adv;
+        SimFields T = F;  // the advected fields, where they are: scale_to_mass (sim.rs:699-711) and the sub-grid eddies act on them
+        T.density = adv[0];
+        T.temperature = adv[1];
+        T.fuel = adv[2];
+        T.soot = adv[3];
+        T.humidity = adv[4];
+        if (S.mass_conservation != 0) {
+            const float target = A.sums[3], mass = A.sums[0];
+            if (target > 0.0f && mass > 1.0e-12f) T.density[v] *= target / mass;
+        }
+        sim_subgrid(G, T, S, x, y, z);
+    } else if (PH == kPhDiffuseDecay) {  // apply_scalar_diffusion (sim.rs:236-245) home, then decay and ageing of the voxel
+        float *const *adv = C.corrected ? A.adv2 : A.adv;
+        float *home[5] = {F.density, F.temperature, F.fuel, F.soot, F.humidity};
+#pragma unroll
+        for (uint32_t f = 0u; f < 5u; f++) {
+            if (S.diffusion > 0.0f) sim_diffuse(G, adv[f], home[f], S.diffusion * S.dt, 1u, 0u, x, y, z);
+            else home[f][v] = adv[f][v];
+        }
+        sim_decay(G, F, S, v);
+    }
+}
+// grid sums of `density`: one lane a row, every kind in one sweep over x (the adds of a kind in sim_sum_row's order)
+struct SumKinds {
+    uint32_t n, kind[4], slot[4];
+};
+__device__ __forceinline__ void sums_row(const StepArgs &A, const SimGrid &G, const float *density, const SumKinds &K, uint32_t r) {
+    const uint32_t n_rows = G.ny * G.nz, y = r % G.ny, z = r / G.ny;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    auto term = [&](uint32_t kind, float d, float m, uint32_t x) {
+        return kind == 0u ? d : (kind == 1u ? m : (kind == 2u ? (float)x * m : (float)z * m));
+    };
+    for (uint32_t x = 0u; x < G.nx; x++) {
+        const float d = density[sim_index(G, x, y, z)], m = f_max(d, 0.0f);
+        a0 += term(K.kind[0], d, m, x);
+        if (K.n > 1u) a1 += term(K.kind[1], d, m, x);
+        if (K.n > 2u) a2 += term(K.kind[2], d, m, x);
+        if (K.n > 3u) a3 += term(K.kind[3], d, m, x);
+    }
+    A.rows[r] = a0;
+    if (K.n > 1u) A.rows[(size_t)n_rows + r] = a1;
+    if (K.n > 2u) A.rows[2u * (size_t)n_rows + r] = a2;
+    if (K.n > 3u) A.rows[3u * (size_t)n_rows + r] = a3;
+}
+// ... then the rows of a slab and the slabs by ONE workgroup, in the order of sim_sum_seq
+__device__ __forceinline__ void sums_finish(const StepArgs &A, const SimGrid &G, const SumKinds &K) {
+    const uint32_t n_rows = G.ny * G.nz;
+    for (uint32_t j = threadIdx.x; j < K.n * G.nz; j += blockDim.x) {
+        const uint32_t k = j / G.nz, z = j - k * G.nz;
+        A.slabs[(size_t)k * G.nz + z] = sim_sum_seq(A.rows + (size_t)k * n_rows + (size_t)z * G.ny, G.ny);
+    }
+    __syncthreads();
+    if (threadIdx.x < K.n) A.sums[K.slot[threadIdx.x]] = sim_sum_seq(A.slabs + (size_t)threadIdx.x * G.nz, G.nz);
+}
+__device__ __forceinline__ SumKinds sums_before_advection(const SimSettings &S) {
+    // mass and centroid for the lane shear, mass before the density advection (the shear moves velocity only, so the
+    // density these are taken from is the same: one pass)
+    SumKinds K{};
+    if (S.turbulence_strength > 0.0f) {
+        K.kind[K.n] = 1u, K.slot[K.n++] = 0u;
+        K.kind[K.n] = 2u, K.slot[K.n++] = 1u;
+        K.kind[K.n] = 3u, K.slot[K.n++] = 2u;
+    }
+    if (S.mass_conservation != 0) K.kind[K.n] = 0u, K.slot[K.n++] = 3u;
+    return K;
+}
+
+// fused driver: one launch per phase, a lane per voxel
+constexpr uint32_t kPhaseBlock = 256u;
+template <uint32_t PH>
+__global__ __launch_bounds__(kPhaseBlock) void k_phase(const StepArgs A, const PhaseCtx C) {
+    const uint32_t n = A.G.nx * A.G.ny * A.G.nz, v = blockIdx.x * kPhaseBlock + threadIdx.x;
+    if (v >= n) return;
+    const uint32_t plane = A.G.nx * A.G.ny, z = v / plane, y = (v - z * plane) / A.G.nx, x = v - z * plane - y * A.G.nx;
+    phase_voxel<PH>(A, A.G, C, v, x, y, z);
+}
+__global__ __launch_bounds__(64) void k_phase_sum_rows(const StepArgs A, const SumKinds K, const float *density) {
+    const uint32_t r = blockIdx.x * 64u + threadIdx.x;
+    if (r < A.G.ny * A.G.nz) sums_row(A, A.G, density, K, r);
+}
+__global__ __launch_bounds__(256) void k_phase_sum_finish(const StepArgs A, const SumKinds K) { sums_finish(A, A.G, K); }
+
+// persistent driver: the grid barrier.  Cache maintenance is most of its cost (see above), so the fences are executed by
+// ONE wave of the workgroup -- with all sixteen executing them a barrier took 37 us and a Jacobi sweep of three voxels a lane
+// 32 us.  The other waves are ordered behind that wave by the workgroup barriers on either side (they share its CU's L1,
+// which its buffer_inv has emptied, and its XCD's L2).  A barrier that is not released within about a second (a workgroup
+// that never arrived: cannot happen under a cooperative launch) sets the abort word and lets every lane run to the end, so
+// a broken launch ends in an error, not in a hung GPU.
+constexpr uint32_t kStepBlock = 1024u, kWave = 64u;
+__device__ __forceinline__ void grid_barrier(unsigned int *bar) {
+#if defined(F3D_SIM_PHASE_TIMES)  // diagnostics build (tools/experiments/sim_phases.py): when did workgroup 0 reach each barrier, when did it leave? (100 MHz)
+    if (blockIdx.x == 0u && threadIdx.x == 0u) {
+        const unsigned int k = bar[3];
+        if (k < 2000u) reinterpret_cast<unsigned long long *>(bar + 4)[2u * k] = wall_clock64();
+    }
+#endif
+    __syncthreads();  // every wave's stores of the phase have left it
+    if (threadIdx.x < kWave) {  // (wave 0, all lanes: a fence is a wave's instruction)
+#if !defined(F3D_SIM_BARRIER_NOFENCE)  // (timing experiment, wrong results)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
+        if (threadIdx.x == 0u) {
+            const unsigned int gen = __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int arrived = __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (arrived == gridDim.x - 1u) {
+                __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                uint32_t polls = 0u;
+                while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+                    if (++polls > (1u << 22)) {
+                        __hip_atomic_store(&bar[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+        }
+#if !defined(F3D_SIM_BARRIER_NOFENCE)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+    }
+    __syncthreads();
+#if defined(F3D_SIM_PHASE_TIMES)
+    if (blockIdx.x == 0u && threadIdx.x == 0u) {
+        const unsigned int k = bar[3];
+        if (k < 2000u) reinterpret_cast<unsigned long long *>(bar + 4)[2u * k + 1u] = wall_clock64();
+        bar[3] = k + 1u;
+    }
+#endif
+}
+__global__ __launch_bounds__(kStepBlock) void k_sim_step(const StepArgs A) {
+    SimGrid G = A.G;
+    const SimSettings &S = A.S;
+    const uint32_t n = G.nx * G.ny * G.nz, lanes = gridDim.x * kStepBlock, lane = blockIdx.x * kStepBlock + threadIdx.x;
+    const uint32_t plane = G.nx * G.ny;
+    PhaseCtx C{};
+#define F3D_SIM_PHASE(PH)                                                                                                     \
+    {                                                                                                                         \
+        for (uint32_t v = lane; v < n; v += lanes) {                                                                          \
+            const uint32_t z = v / plane, y = (v - z * plane) / G.nx, x = v - z * plane - y * G.nx;                           \
+            phase_voxel<PH>(A, G, C, v, x, y, z);                                                                             \
+        }                                                                                                                     \
+        grid_barrier(A.barrier);                                                                                              \
+    }
+    auto grid_sums = [&](const float *density, const SumKinds &K) {
+        for (uint32_t r = lane; r < G.ny * G.nz; r += lanes) sums_row(A, G, density, K, r);
+        grid_barrier(A.barrier);
+        if (blockIdx.x == 0u) sums_finish(A, G, K);
+        grid_barrier(A.barrier);
+    };
+    auto project = [&](uint32_t iterations) {  // sim.rs:270-317; ends with the boundary conditions that follow it in the step
+        F3D_SIM_PHASE(kPhDivergence)
+        C.cur = A.F.pressure;
+        C.next = A.pres_b;
+        for (uint32_t it = 0u; it < iterations; it++) {
+            F3D_SIM_PHASE(kPhJacobi)
+            float *t = C.cur;
+            C.cur = C.next;
+            C.next = t;
+        }
+        F3D_SIM_PHASE(kPhGradientBoundary)
+    };
+    for (uint32_t step = 0u; step < A.steps; step++) {  // SmokeVolume::step, sim.rs:47-139
+        F3D_SIM_PHASE(kPhEmitForces)
+        F3D_SIM_PHASE(kPhAdvectVec)
+        F3D_SIM_PHASE(kPhDiffuseVec)
+        if (S.vorticity > 0.0f) {
+            F3D_SIM_PHASE(kPhCurl)
+            F3D_SIM_PHASE(kPhConfine)
+        }
+        project(S.pressure_iterations > 1u ? S.pressure_iterations : 1u);
+        const SumKinds before = sums_before_advection(S);
+        if (before.n != 0u) grid_sums(A.F.density, before);
+        if (S.turbulence_strength > 0.0f) F3D_SIM_PHASE(kPhLaneShear)
+        F3D_SIM_PHASE(kPhAdvectScalars)
+        C.corrected = 0u;
+        if (S.mac_cormack != 0) {
+            F3D_SIM_PHASE(kPhCorrectScalars)
+            C.corrected = 1u;
+        }
+        if (S.mass_conservation != 0) {
+            SumKinds after{};
+            after.n = 1u;  // kind 0 -> slot 0
+            grid_sums(C.corrected ? A.adv2[0] : A.adv[0], after);
+        }
+        F3D_SIM_PHASE(kPhScaleSubgrid)
+        F3D_SIM_PHASE(kPhDiffuseDecay)
+        project((S.pressure_iterations / 2u) > 1u ? S.pressure_iterations / 2u : 1u);
+        G.time_seconds += S.dt;
+        G.frame_index += 1u;
+    }
+#undef F3D_SIM_PHASE
+}
+
 void ok(hipError_t e, const char *what) {
     if (e != hipSuccess) fail(F3D_STATUS_DEVICE, "HIP failure in %s: %s", what, hipGetErrorString(e));
 }
@@ -91,17 +374,15 @@ struct Sim {
     SimGrid G;
     SimFields F{};
     float *tmp_a = nullptr, *tmp_b = nullptr, *vec_a = nullptr, *curl = nullptr, *div = nullptr, *rows = nullptr, *slabs = nullptr, *sums = nullptr;
-    std::vector<void *> owned;
     size_t n = 0;
     dim3 grid, block;
-    void *alloc(size_t bytes) {
+    uint32_t n_scratch = 0;
+    void *alloc(size_t bytes, const char *tag = nullptr) {  // stream-ordered scratch that stays for the next call (f3d_devmem.h workspace)
+        char name[48];
+        if (!tag) snprintf(name, sizeof(name), "smoke.sim.%u", n_scratch++);
         void *p = nullptr;
-        ok(device_alloc(&p, bytes), "smoke solver allocation");
-        owned.push_back(p);
+        ok(workspace(&p, tag ? tag : name, bytes), "smoke solver allocation");
         return p;
-    }
-    ~Sim() {
-        for (void *p : owned) (void)device_free(p);
     }
     template <uint32_t PASS>
     void run(SimKernelArgs A) {
@@ -225,6 +506,7 @@ extern "C" int f3d_smoke_step(f3d_smoke_state *st, const f3d_smoke_step_settings
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) fail(F3D_STATUS_DEVICE, "no HIP device available: libf3dhip has no CPU fallback");
 
+        std::lock_guard<std::mutex> workspace_guard(workspace_lock());  // one smoke call at a time enqueues (f3d_devmem.h)
         Sim s;
         s.n = (size_t)n64;
         s.G = SimGrid{st->dims[0], st->dims[1], st->dims[2], st->voxel_size[0], st->voxel_size[1], st->voxel_size[2], st->origin[0], st->origin[1],
@@ -248,17 +530,18 @@ extern "C" int f3d_smoke_step(f3d_smoke_state *st, const f3d_smoke_step_settings
                 *dev[f] = host[f];
                 continue;
             }
-            *dev[f] = (float *)s.alloc(bytes);
+            static const char *const kFieldTags[9] = {"smoke.sim.f0", "smoke.sim.f1", "smoke.sim.f2", "smoke.sim.f3", "smoke.sim.f4", "smoke.sim.f5", "smoke.sim.f6", "smoke.sim.f7", "smoke.sim.f8"};
+            *dev[f] = (float *)s.alloc(bytes, kFieldTags[f]);
             ok(hipMemcpy(*dev[f], host[f], bytes, hipMemcpyHostToDevice), "smoke state upload");
         }
-        s.tmp_a = (float *)s.alloc(s.n * sizeof(float));
-        s.tmp_b = (float *)s.alloc(s.n * sizeof(float));
-        s.vec_a = (float *)s.alloc(3 * s.n * sizeof(float));
-        s.curl = (float *)s.alloc(3 * s.n * sizeof(float));
-        s.div = (float *)s.alloc(s.n * sizeof(float));
-        s.rows = (float *)s.alloc(4 * (size_t)s.G.ny * s.G.nz * sizeof(float));
-        s.slabs = (float *)s.alloc(4 * (size_t)s.G.nz * sizeof(float));
-        s.sums = (float *)s.alloc(4 * sizeof(float));
+        s.tmp_a = (float *)s.alloc(s.n * sizeof(float), "smoke.sim.tmp_a");
+        s.tmp_b = (float *)s.alloc(s.n * sizeof(float), "smoke.sim.tmp_b");
+        s.vec_a = (float *)s.alloc(3 * s.n * sizeof(float), "smoke.sim.vec_a");
+        s.curl = (float *)s.alloc(3 * s.n * sizeof(float), "smoke.sim.curl");
+        s.div = (float *)s.alloc(s.n * sizeof(float), "smoke.sim.div");
+        s.rows = (float *)s.alloc(4 * (size_t)s.G.ny * s.G.nz * sizeof(float), "smoke.sim.rows");
+        s.slabs = (float *)s.alloc(4 * (size_t)s.G.nz * sizeof(float), "smoke.sim.slabs");
+        s.sums = (float *)s.alloc(4 * sizeof(float), "smoke.sim.sums");
         SimSettings S{};
         S.dt = settings->dt; S.density_decay = settings->density_decay; S.temperature_decay = settings->temperature_decay;
         S.velocity_damping = settings->velocity_damping; S.diffusion = settings->diffusion; S.buoyancy = settings->buoyancy;
@@ -267,8 +550,147 @@ extern "C" int f3d_smoke_step(f3d_smoke_state *st, const f3d_smoke_step_settings
         S.terrain_collision = settings->terrain_collision; S.boundary_damping = settings->boundary_damping;
         for (int a = 0; a < 3; a++) S.wind[a] = settings->wind[a];
 
+        // A call whose state stays on the device and whose caller does not ask for the device time returns as soon as its
+        // launches are enqueued (a resident sequence: the next call's work is behind this call's in the stream).
+        const bool timed = device_seconds != nullptr || !resident;
         ok(hipEventCreate(&e0), "event");
         ok(hipEventCreate(&e1), "event");
+        // Which driver (see "the step as PHASES" above): fused launches by default; F3D_SMOKE_SOLVER=persistent / launches
+        // select the one cooperative launch and the round-3 launch-per-pass form (both kept as tested A/Bs).
+        const char *form = getenv("F3D_SMOKE_SOLVER");
+        bool persistent = form && strcmp(form, "persistent") == 0;
+        const bool per_pass = form && strcmp(form, "launches") == 0;
+        int device = 0, cus = 0, cooperative = 0, per_cu = 0;
+        ok(hipGetDevice(&device), "device");
+        if (persistent) {
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+            (void)hipDeviceGetAttribute(&cooperative, hipDeviceAttributeCooperativeLaunch, device);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sim_step, (int)kStepBlock, 0) != hipSuccess) per_cu = 0;
+            (void)hipGetLastError();
+            if (!cooperative || cus <= 0 || per_cu <= 0) fail(F3D_STATUS_DEVICE, "F3D_SMOKE_SOLVER=persistent: this device cannot co-schedule the step kernel");
+        }
+        if (!per_pass) {
+            StepArgs K{};
+            K.G = s.G;
+            K.F = s.F;
+            K.S = S;
+            K.emitter_count = emitter_count;
+            K.steps = steps;
+            static_assert(sizeof(SimEmitter) == sizeof(f3d_smoke_emitter), "emitter layouts differ");
+            if (emitter_count <= kInlineEmitters) {
+                if (emitter_count) memcpy(K.inline_emitters, emitters, emitter_count * sizeof(SimEmitter));
+            } else {
+                SimEmitter *d_em = (SimEmitter *)s.alloc(emitter_count * sizeof(SimEmitter), "smoke.sim.emitters");
+                ok(hipMemcpyAsync(d_em, emitters, emitter_count * sizeof(SimEmitter), hipMemcpyHostToDevice, nullptr), "emitters");
+                K.emitters = d_em;
+            }
+            K.vel_b = s.vec_a;
+            K.curl = s.curl;
+            K.mag = s.tmp_a;
+            K.div = s.div;
+            K.pres_b = s.tmp_b;
+            static const char *const kAdvTags[10] = {"smoke.sim.adv0", "smoke.sim.adv1", "smoke.sim.adv2", "smoke.sim.adv3", "smoke.sim.adv4", "smoke.sim.cor0", "smoke.sim.cor1", "smoke.sim.cor2", "smoke.sim.cor3", "smoke.sim.cor4"};
+            for (int f = 0; f < 5; f++) K.adv[f] = (float *)s.alloc(s.n * sizeof(float), kAdvTags[f]);
+            if (S.mac_cormack)
+                for (int f = 0; f < 5; f++) K.adv2[f] = (float *)s.alloc(s.n * sizeof(float), kAdvTags[5 + f]);
+            K.rows = s.rows;
+            K.slabs = s.slabs;
+            K.sums = s.sums;
+            if (persistent) {
+#if defined(F3D_SIM_PHASE_TIMES)
+                constexpr size_t kBarrierBytes = 4 * sizeof(unsigned int) + 2 * 2000 * sizeof(unsigned long long);
+#else
+                constexpr size_t kBarrierBytes = 4 * sizeof(unsigned int);
+#endif
+                K.barrier = (unsigned int *)s.alloc(kBarrierBytes, "smoke.sim.barrier");
+                ok(hipMemsetAsync(K.barrier, 0, kBarrierBytes, nullptr), "barrier clear");
+                const uint32_t wanted = (uint32_t)((s.n + kStepBlock - 1u) / kStepBlock);
+                const uint32_t blocks = std::min<uint32_t>((uint32_t)cus, std::max<uint32_t>(wanted, 1u));  // one workgroup a CU: co-resident by construction
+                void *params[1] = {&K};
+                ok(hipEventRecord(e0, nullptr), "event");
+                ok(hipLaunchCooperativeKernel((const void *)k_sim_step, dim3(blocks), dim3(kStepBlock), params, 0u, nullptr), "cooperative launch of the smoke solver");
+                ok(hipEventRecord(e1, nullptr), "event");
+                ok(hipEventSynchronize(e1), "smoke solver");
+                unsigned int bar[4] = {};
+                ok(hipMemcpy(bar, K.barrier, sizeof(bar), hipMemcpyDeviceToHost), "barrier read-back");
+#if defined(F3D_SIM_PHASE_TIMES)
+                if (const char *path = getenv("F3D_SIM_PHASE_FILE")) {
+                    std::vector<unsigned long long> t(2 * 2000);
+                    ok(hipMemcpy(t.data(), K.barrier + 4, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost), "phase times");
+                    if (FILE *f = fopen(path, "w")) {
+                        for (unsigned int k = 0; k < bar[3] && k < 2000u; k++) fprintf(f, "%u %llu %llu\n", k, t[2 * k], t[2 * k + 1]);
+                        fclose(f);
+                    }
+                }
+#endif
+                if (bar[2] != 0u) fail(F3D_STATUS_DEVICE, "smoke solver: a grid barrier of the persistent step kernel was not released (%u workgroups)", blocks);
+                for (uint32_t step = 0; step < steps; step++) {
+                    s.G.time_seconds += S.dt;
+                    s.G.frame_index += 1u;
+                }
+            } else {
+                // fused: one launch per phase, in stream order (k_phase); the step's time and frame advance on the host
+                const dim3 grid((unsigned)((s.n + kPhaseBlock - 1u) / kPhaseBlock)), block(kPhaseBlock);
+                const dim3 row_grid((s.G.ny * s.G.nz + 63u) / 64u);
+                PhaseCtx C{};
+                auto sums = [&](const float *density, const SumKinds &kinds) {
+                    hipLaunchKernelGGL(k_phase_sum_rows, row_grid, dim3(64), 0, nullptr, K, kinds, density);
+                    hipLaunchKernelGGL(k_phase_sum_finish, dim3(1), dim3(256), 0, nullptr, K, kinds);
+                };
+                auto project_fused = [&](uint32_t iterations) {
+                    hipLaunchKernelGGL(k_phase<kPhDivergence>, grid, block, 0, nullptr, K, C);
+                    C.cur = K.F.pressure;
+                    C.next = K.pres_b;
+                    for (uint32_t it = 0; it < iterations; it++) {
+                        hipLaunchKernelGGL(k_phase<kPhJacobi>, grid, block, 0, nullptr, K, C);
+                        std::swap(C.cur, C.next);
+                    }
+                    hipLaunchKernelGGL(k_phase<kPhGradientBoundary>, grid, block, 0, nullptr, K, C);
+                };
+                if (timed) ok(hipEventRecord(e0, nullptr), "event");
+                for (uint32_t step = 0; step < steps; step++) {  // SmokeVolume::step, sim.rs:47-139
+                    hipLaunchKernelGGL(k_phase<kPhEmitForces>, grid, block, 0, nullptr, K, C);
+                    hipLaunchKernelGGL(k_phase<kPhAdvectVec>, grid, block, 0, nullptr, K, C);
+                    hipLaunchKernelGGL(k_phase<kPhDiffuseVec>, grid, block, 0, nullptr, K, C);
+                    if (S.vorticity > 0.0f) {
+                        hipLaunchKernelGGL(k_phase<kPhCurl>, grid, block, 0, nullptr, K, C);
+                        hipLaunchKernelGGL(k_phase<kPhConfine>, grid, block, 0, nullptr, K, C);
+                    }
+                    project_fused(std::max(1u, S.pressure_iterations));
+                    SumKinds before{};
+                    if (S.turbulence_strength > 0.0f) {
+                        before.kind[before.n] = 1u, before.slot[before.n++] = 0u;
+                        before.kind[before.n] = 2u, before.slot[before.n++] = 1u;
+                        before.kind[before.n] = 3u, before.slot[before.n++] = 2u;
+                    }
+                    if (S.mass_conservation) before.kind[before.n] = 0u, before.slot[before.n++] = 3u;
+                    if (before.n != 0u) sums(K.F.density, before);
+                    if (S.turbulence_strength > 0.0f) hipLaunchKernelGGL(k_phase<kPhLaneShear>, grid, block, 0, nullptr, K, C);
+                    hipLaunchKernelGGL(k_phase<kPhAdvectScalars>, grid, block, 0, nullptr, K, C);
+                    C.corrected = 0u;
+                    if (S.mac_cormack) {
+                        hipLaunchKernelGGL(k_phase<kPhCorrectScalars>, grid, block, 0, nullptr, K, C);
+                        C.corrected = 1u;
+                    }
+                    if (S.mass_conservation) {
+                        SumKinds after{};
+                        after.n = 1u;  // kind 0 -> slot 0
+                        sums(C.corrected ? K.adv2[0] : K.adv[0], after);
+                    }
+                    hipLaunchKernelGGL(k_phase<kPhScaleSubgrid>, grid, block, 0, nullptr, K, C);
+                    hipLaunchKernelGGL(k_phase<kPhDiffuseDecay>, grid, block, 0, nullptr, K, C);
+                    project_fused(std::max(1u, S.pressure_iterations / 2u));
+                    s.G.time_seconds += S.dt;
+                    s.G.frame_index += 1u;
+                    K.G = s.G;
+                }
+                ok(hipGetLastError(), "smoke solver kernels");
+                if (timed) {
+                    ok(hipEventRecord(e1, nullptr), "event");
+                    ok(hipEventSynchronize(e1), "smoke solver");
+                }
+            }
+        } else {
         ok(hipEventRecord(e0, nullptr), "event");
         for (uint32_t step = 0; step < steps; step++) {  // SmokeVolume::step, sim.rs:47-139
             ok(hipMemsetAsync(s.F.emission_rate, 0, s.n * sizeof(float), nullptr), "emission clear");
@@ -345,9 +767,10 @@ extern "C" int f3d_smoke_step(f3d_smoke_state *st, const f3d_smoke_step_settings
         }
         ok(hipEventRecord(e1, nullptr), "event");
         ok(hipEventSynchronize(e1), "smoke solver");
+        }
         ok(hipGetLastError(), "smoke solver kernels");
         float ms = 0.0f;
-        ok(hipEventElapsedTime(&ms, e0, e1), "event");
+        if (timed || persistent || per_pass) ok(hipEventElapsedTime(&ms, e0, e1), "event");
         if (device_seconds) *device_seconds = ms * 1e-3;
         if (!resident)
             for (int f = 0; f < 9; f++) ok(hipMemcpy(host[f], *dev[f], s.n * sizeof(float) * (f == 7 ? 3u : 1u), hipMemcpyDeviceToHost), "smoke state read-back");

@@ -609,6 +609,10 @@ class SmokeSequence:
         self.copied = [torch.cuda.Event() for _ in range(2)]
         self.copy_stream = torch.cuda.Stream(self.device)  # the read-back of frame f beside the kernels of frame f + 1
         self.kernel_seconds = {"solver_step": 0.0, "march": 0.0, "composite": 0.0}
+        # timing=True makes every library call record and wait for its device time (kernel_seconds); without it a call on
+        # resident state returns with its launches enqueued and the host runs ahead of the device (round 5)
+        self.timing = False
+        self.rendered = [torch.cuda.Event() for _ in range(2)]
         self._turn = 0
         self._err = C.create_string_buffer(512)
 
@@ -645,7 +649,7 @@ class SmokeSequence:
                 setattr(dst, name, (C.c_float * 3)(*v) if name in ("center", "velocity") else float(v))
         seconds = C.c_double(0.0)
         self._check(_native.lib().f3d_smoke_step(C.byref(st), C.byref(settings._native()), em, C.c_uint32(len(emitters)), C.c_uint32(int(steps)),
-                                                 C.byref(seconds), self._err, len(self._err)))
+                                                 C.byref(seconds) if self.timing else None, self._err, len(self._err)))
         self.time_seconds, self.frame_index = float(st.time_seconds), int(st.frame_index)
         self.kernel_seconds["solver_step"] = float(seconds.value) / int(steps)
 
@@ -664,30 +668,38 @@ class SmokeSequence:
         seconds = C.c_double(0.0)
         native = self.settings._native()
         self._check(_native.lib().f3d_smoke_render(C.byref(vol), C.byref(self.view), C.byref(native), C.c_void_p(self.layer.data_ptr()),
-                                                   C.byref(seconds), self._err, len(self._err)))
+                                                   C.byref(seconds) if self.timing else None, self._err, len(self._err)))
         self.kernel_seconds["march"] = float(seconds.value)
         out = self.out[self._turn]
+        # (this image's last read-back -- two frames ago, on the copy stream -- before the composite overwrites it)
+        self.torch.cuda.default_stream(self.device).wait_event(self.copied[self._turn])
         desc = _CompositeDesc()
         desc.struct_size = C.sizeof(_CompositeDesc)
         desc.mode, desc.width, desc.height = COMPOSITE_ATMOSPHERIC, self.width, self.height
         desc.layer_width, desc.layer_height = self.width, self.height
         desc.base, desc.layer = self.base.data_ptr(), self.layer.data_ptr()
         desc.max_alpha = HYBRID_SMOKE_MAX_ALPHA
-        self._check(_native.lib().f3d_smoke_composite(C.byref(desc), C.c_void_p(out.data_ptr()), C.byref(seconds), self._err, len(self._err)))
+        seconds = C.c_double(0.0)
+        self._check(_native.lib().f3d_smoke_composite(C.byref(desc), C.c_void_p(out.data_ptr()), C.byref(seconds) if self.timing else None,
+                                                      self._err, len(self._err)))
         self.kernel_seconds["composite"] = float(seconds.value)
+        self.rendered[self._turn].record(self.torch.cuda.default_stream(self.device))  # (the library launches on the null stream)
         return out
 
-    def frames(self, count: int, settings=None, emitters=None, steps_per_frame: int = 1):
+    def frames(self, count: int, settings=None, emitters=None, steps_per_frame: int = 1, timing: bool = False):
         """`count` frames of emitters -> solver -> ray-marcher -> composite; yields (H, W, 4) uint8 host images (each a view of
         a pinned buffer that the frame after next reuses: copy what is to be kept).  The device-to-host copy of a frame
-        runs while the next frame's kernels do."""
+        runs while the next frame's kernels do, and -- unless timing=True asks for kernel_seconds -- the host enqueues a
+        frame's launches without waiting for the device."""
         torch = self.torch
         pending = None
+        self.timing = bool(timing)
         for _ in range(int(count)):
             self.step(settings, emitters, steps=steps_per_frame)
             image = self.render_to_device()
             turn = self._turn
-            with torch.cuda.stream(self.copy_stream):  # (the library's calls return with their kernels done: the image is complete)
+            with torch.cuda.stream(self.copy_stream):
+                self.copy_stream.wait_event(self.rendered[turn])  # the image is complete when the null stream gets there
                 self.pinned[turn].copy_(image, non_blocking=True)
                 self.copied[turn].record()
             self._turn ^= 1

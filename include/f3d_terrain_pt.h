@@ -386,7 +386,11 @@ typedef struct f3d_smoke_settings { /* SmokeRenderSettings, reference src/smoke/
 /* rgba: caller-owned height x width x 4 bytes (straight colour, alpha = 1 - transmittance).  kernel_seconds
  * (optional) receives the ray-march kernel's device time.  Errors carry the reference's message texts.
  * Each of the six fields, and rgba, may be a DEVICE pointer: such a field is read where it is and a device image is
- * left on the device (a resident smoke sequence: f3d_smoke_step on device fields -> f3d_smoke_render -> f3d_smoke_composite). */
+ * left on the device (a resident smoke sequence: f3d_smoke_step on device fields -> f3d_smoke_render -> f3d_smoke_composite).
+ * The three smoke entry points launch on the NULL stream and keep their scratch between calls (freed by
+ * f3d_device_pool_trim).  A call whose results stay on the device and whose time pointer (kernel_seconds /
+ * device_seconds) is NULL returns as soon as its launches are enqueued: order other streams behind the null stream
+ * (an event) before reading its outputs; errors of the kernels themselves then surface in a later call. */
 int f3d_smoke_render(const f3d_smoke_volume *volume, const f3d_smoke_view *view, const f3d_smoke_settings *settings,
                      uint8_t *rgba, double *kernel_seconds, char *err, size_t errlen);
 

@@ -254,6 +254,9 @@ def test_resident_smoke_sequence_equals_the_host_array_path():
     assert dev_dom.frame_index == host_dom.frame_index == 10 and dev_dom.time_seconds == host_dom.time_seconds
     for name in ("density", "temperature", "fuel", "soot", "humidity", "emission_rate", "particle_age", "velocity", "pressure"):
         assert np.array_equal(getattr(dev_dom, name), getattr(host_dom, name)), name
+    assert all(v == 0.0 for v in seq.kernel_seconds.values())  # untimed calls: the host did not wait for any of them
+    for _ in seq.frames(1, settings, emitters, timing=True):
+        pass
     assert all(v > 0.0 for v in seq.kernel_seconds.values())
     with pytest.raises(ValueError, match="all host or all device"):
         st = smoke._State()

@@ -140,14 +140,19 @@ def _domain(fields, voxel_size=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), frame_in
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", ["sift", "single"])
 @pytest.mark.parametrize("size,settings,geom", [
     ((96, 64), {}, {}),
     ((160, 90), dict(self_shadow=False, exposure=1.4, phase_g=-0.5), dict(voxel_size=(2.0, 1.5, 2.5), origin=(-10.0, 3.0, 7.0))),
     ((61, 47), dict(step_size=0.4, shadow_step_size=1.1, shadow_steps=33, max_steps=900, jitter_strength=1.0), dict(frame_index=77)),
     ((128, 128), dict(density_scale=2.5, extinction=4.0, soot_absorption=0.9, fire_glow=1.5, thin_color=(0.2, 0.3, 0.4)), {}),
 ])
-def test_hip_smoke_matches_the_oracle_bit_for_bit(size, settings, geom):
+def test_hip_smoke_matches_the_oracle_bit_for_bit(size, settings, geom, form, monkeypatch):
+    """Both forms of the device marcher (csrc/f3d_smoke.hip): sift + eight cooperating lanes per smoke pixel (the default) and
+    one lane per pixel for the whole ray (F3D_SMOKE_MARCH=single)."""
     from forge3d_amd import smoke
+
+    monkeypatch.setenv("F3D_SMOKE_MARCH", form)
 
     fields = plume()
     vs, og = geom.get("voxel_size", (1.0, 1.0, 1.0)), geom.get("origin", (0.0, 0.0, 0.0))

@@ -69,6 +69,10 @@ def _cases():
         "turbulent_wind": (dict(dims=(24, 16, 20), voxel_size=(1.5, 1.0, 2.0), origin=(-3.0, 0.0, 2.0)), plume,
                            dict(dt=0.1, turbulence_strength=0.8, turbulence_seed=31, wind=(1.2, 0.05, -0.7), velocity_damping=0.05, boundary_damping=0.2), 6),
         "maccormack": (dict(dims=(18, 18, 18)), plume, dict(dt=0.2, mac_cormack=True, diffusion=0.01, vorticity=0.4, pressure_iterations=9), 5),
+        # more emitters than travel in the kernel arguments (csrc/f3d_smoke_sim.hip kInlineEmitters = 4): the device-copy path
+        "six_emitters": (dict(dims=(22, 12, 16)), [dict(center=(4.0 + 2.5 * k, 3.0 + 0.5 * k, 5.0 + 1.5 * k), radius=1.5 + 0.2 * k, density_rate=2.0 + k,
+                                                      temperature_rate=1.0 + 0.5 * k, velocity=(0.1 * k, 1.0, -0.05 * k)) for k in range(6)],
+                         dict(dt=0.15, pressure_iterations=6), 3),
         "bare": (dict(dims=(12, 10, 14)), plume[:1], dict(dt=0.3, diffusion=0.0, vorticity=0.0, velocity_damping=0.0, mass_conservation=False,
                                                           terrain_collision=False, pressure_iterations=1, turbulence_strength=0.3, wind=(0.0, 0.0, 0.0)), 4),
     }
@@ -109,10 +113,14 @@ def test_python_surface_of_the_solver():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", ["fused", "persistent", "launches"])
 @pytest.mark.parametrize("case", sorted(_cases()))
-def test_hip_solver_equals_the_oracle(case):
+def test_hip_solver_equals_the_oracle(case, form, monkeypatch):
+    """All three drivers of the device solver (csrc/f3d_smoke_sim.hip): the step's phases as one launch each (the default),
+    as one persistent cooperative launch with grid barriers between them, and the round-3 form of one launch per pass."""
     from forge3d_amd import smoke
 
+    monkeypatch.setenv("F3D_SMOKE_SOLVER", form)
     geo, emitters, settings, steps = _cases()[case]
     want = _run(so.step, case)
     dom = smoke.SmokeDomain(geo["dims"], geo.get("voxel_size", (1.0, 1.0, 1.0)), geo.get("origin", (0.0, 0.0, 0.0)))
