@@ -21,8 +21,8 @@ __device__ __forceinline__ uint32_t lane_now() {
 // segment, and -- only for the sorted descent kept for the test hook / A-B builds -- the
 // pending-sibling words as a [level][lane] column (bank = lane, conflict-free).
 // Rows kParkRow.. of the column hold the sample-lane frame's accumulators between rounds and its frame-head record.
-// 6 144 bytes a wave, and not a row more: LDS is handed out in 2 KiB pieces on gfx950 (tools/experiments/lds_granule.hip),
-// so 6 656 bytes cost 8 KiB and a CU held 20 waves instead of 24 -- measured 4 % of the frame.  Hence the verdict board
+// 6 144 bytes a wave, and not a row more: LDS is handed out in 1 280-byte pieces on gfx950 (tools/experiments/lds_granule.hip),
+// so 6 656 bytes cost 7 680 and a CU held 21 one-wave workgroups instead of 24 -- measured 4 % of the frame.  Hence the verdict board
 // shares a word with the head's flags (its bit is set by other lanes: an LDS atomic) and the candidate's light-type flag
 // rides in bit 31 of its sample count, as in the packed reservoir.
 constexpr int kParkRow = kFifoWords * kLeafFifoRows, kParkHead = 6, kParkWords = 8;  // 6 accumulator words + the frame head's record {reuse weight, flags}
@@ -129,9 +129,16 @@ struct LdsPendingAt {
     }
 };
 using LdsPending = LdsPendingAt<kBoardRow>;
-// The PBR path tracer's terrain primitive parks nothing: leaf FIFO rows, then the board's row, then the level table --
-// 4 352 bytes a wave, four of the 1 280-byte pieces LDS is handed out in, so that eight waves fit a SIMD (f3d_wavefront.hip).
-constexpr int kCompactRows = kParkRow + 1;
+// The PBR path tracer's terrain primitive: leaf FIFO rows, then the board's row, then kPathParkRows rows in which a lane
+// parks its path's loop-carried state across the marches (f3d_wf_path.h, round 5), then the level table.  With 8 park
+// rows the block is 6 400 bytes -- five of the 1 280-byte pieces LDS is handed out in: 25 one-wave workgroups a CU, room
+// for six waves a SIMD; 13 rows (7 680 bytes, 21 workgroups) go with five waves.
+#ifndef F3D_WF_PARK
+#define F3D_WF_PARK 8
+#endif
+constexpr int kPathParkRows = F3D_WF_PARK;
+constexpr int kPathParkRow0 = kParkRow + 1;
+constexpr int kCompactRows = kParkRow + 1 + kPathParkRows;
 constexpr int kCompactLdsWords = kCompactRows * kWave + 4 * kMaxLevels;
 using LdsPendingCompact = LdsPendingAt<kParkRow>;
 // rows: lane-column rows in front of the level table (the occlusion-stream kernels need the leaf FIFO only)

@@ -47,7 +47,10 @@ struct WfParams {
 #ifndef F3D_WF_WAVES_TERRAIN
 #define F3D_WF_WAVES_TERRAIN 6
 #endif
-template <bool TERRAIN>  // scenes with the heightfield primitive (f3d_wf_path.h) run their own instantiation
+// LITE (round 5): a scene of spheres + heightfield + environment + directional lights only -- what render_terrain_gi builds
+// (BASELINE.json configs[2]) -- runs an instantiation without the BLAS walk, the hair segments, the area lights and the fog:
+// their live ranges were part of why the per-vertex state of the full kernel lives in scratch (284 B a lane).
+template <bool TERRAIN, bool LITE = false>  // scenes with the heightfield primitive (f3d_wf_path.h) run their own instantiation
 __global__ __launch_bounds__(64, TERRAIN ? F3D_WF_WAVES_TERRAIN : F3D_WF_WAVES) void k_wf_paths(const WfParams P) {
     // traversal context of the terrain march (f3d_lds.h)
     __shared__ __attribute__((aligned(16))) uint32_t lds[TERRAIN ? kCompactLdsWords : 1];
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(64, TERRAIN ? F3D_WF_WAVES_TERRAIN : F3D_WF_WAVES) 
         const uint32_t n = P.count - begin < P.frames_per_lane ? P.count - begin : P.frames_per_lane;
         float4 *out = P.totals + (size_t)begin * pixels + pixel;
         const uint32_t first = P.first + begin;
-        vertices = wf::trace_frames(P.S, pixel, first, n, wf::HipWave<LdsPendingCompact, TERRAIN>{&pend}, [&](uint32_t frame, V3 total) {
+        vertices = wf::trace_frames(P.S, pixel, first, n, wf::HipWave<LdsPendingCompact, TERRAIN, LITE>{&pend}, [&](uint32_t frame, V3 total) {
             out[(size_t)(frame - first) * pixels] = float4{total.x, total.y, total.z, 0.0f};
         });
     }
@@ -251,7 +254,10 @@ extern "C" int f3d_wavefront_render(const f3d_wf_scene *scene, uint32_t width, u
             P.first = first_frame + done;
             P.count = std::min(round_frames, frame_count - done);
             const uint32_t groups = (P.count + fpl - 1u) / fpl;
-            if (S.has_terrain) hipLaunchKernelGGL(k_wf_paths<true>, dim3(tiles * groups), dim3(64), 0, nullptr, P);
+            const bool lite = S.has_terrain && S.blas_count == 0u && S.inst_count == 0u && S.hair_count == 0u && S.area_count == 0u && S.medium_on == 0u &&
+                              getenv("F3D_WF_FULL_KERNEL") == nullptr;  // (A/B + test switch: the full instantiation for a lite scene -- same results)
+            if (lite) hipLaunchKernelGGL((k_wf_paths<true, true>), dim3(tiles * groups), dim3(64), 0, nullptr, P);
+            else if (S.has_terrain) hipLaunchKernelGGL(k_wf_paths<true>, dim3(tiles * groups), dim3(64), 0, nullptr, P);
             else hipLaunchKernelGGL(k_wf_paths<false>, dim3(tiles * groups), dim3(64), 0, nullptr, P);
             ok(hipGetLastError(), "path tracing kernel");
             const FoldParams F{P.totals, d_accum, (uint32_t)pixels, P.count};

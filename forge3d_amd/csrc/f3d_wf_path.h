@@ -360,7 +360,9 @@ F3D_HD bool closest(const SceneDev &S, V3 o, V3 d, float tmin, SurfaceHitWf &H, 
             mat = i;
         }
     }
-    if (S.inst_count == 0u) {
+    if (Wave::kLite) {
+        // (a scene without meshes, hair, area lights and fog -- render_terrain_gi's -- runs an instantiation without their code)
+    } else if (S.inst_count == 0u) {
         float t;
         V3 nn;
         if (S.blas_count > 0u && walk_blas<false>(S.blas[0], o, d, tmin, tmax, t, nn) && t < t_best) {
@@ -384,7 +386,7 @@ F3D_HD bool closest(const SceneDev &S, V3 o, V3 d, float tmin, SurfaceHitWf &H, 
     }
     bool hair = false;
     V3 tangent{0.0f, 0.0f, 0.0f};
-    for (uint32_t i = 0u; i < S.hair_count; i++) {  // hair strands, :499-521 (after spheres and meshes, like the reference)
+    for (uint32_t i = 0u; !Wave::kLite && i < S.hair_count; i++) {  // hair strands, :499-521 (after spheres and meshes, like the reference)
         const HairDev seg = S.hair[i];
         float t;
         V3 nn;
@@ -434,6 +436,7 @@ F3D_HD bool shadowed(const SceneDev &S, V3 ro, V3 rd, float tmin, float tmax, Wa
         const float t0 = -b - q, t1 = -b + q;
         if ((t0 > tmin && t0 < tmax) || (t1 > tmin && t1 < tmax)) return true;
     }
+    if (Wave::kLite) return false;
     float t;
     V3 nn;
     if (S.inst_count == 0u) return S.blas_count > 0u && walk_blas<true>(S.blas[0], ro, rd, tmin, tmax, t, nn);
@@ -550,6 +553,39 @@ F3D_HD uint32_t pick(uint32_t count, float sum_imp, uint32_t &rng, Imp imp) {
     return idx < count - 1u ? idx : count - 1u;
 }
 
+// ---- parked path state (round 5) ---------------------------------------------------------------------------------------------
+// A march of the heightfield primitive needs ~70 of the 80 registers six waves a SIMD leave a lane; what the flat loop carries
+// ACROSS a march -- the frame's running total, the path throughput, the continuation the vertex has already sampled, the
+// next-event contributions whose shadow rays are still to be traced -- lived in scratch: 284 bytes a lane, 15 GB written per
+// 1080p x 32-path launch (profiles/r04_C3_gi_rocprofv3_summary.txt).  Those values are needed before and after a march,
+// never during it, so a lane writes them to rows of its own LDS column in front of the march and reads them back behind it
+// (Wave::kPark rows: 8 with six waves a SIMD, 13 with five; 0 = a kernel without the LDS block: everything stays in registers).
+// Same values, same operations in the same order: results are unchanged (tests/test_wavefront.py, test_offline_gi.py).
+// Row map.  The frame's total and the throughput LIVE in rows 0..5 (kOn): every use reads them, every update writes them,
+// so no lane of a wave holds them in a register while any other lane marches (a value that is only parked on the marching
+// lanes' path stays allocated for the waiting ones).  With 13 rows (kHit) a hit waits in rows 6..12 between closest() and
+// the vertex's shading -- position, normal, material; across the vertex's shadow rays the same rows hold the two next-event
+// contributions and the path depth.  With 8 rows the depth and the RNG word use rows 6 and 7 there.
+template <class Wave>
+struct ParkRows {
+    static constexpr uint32_t kAcc = 0u, kThr = 3u;
+    static constexpr bool kOn = Wave::kPark >= 8u;
+    static constexpr bool kHit = Wave::kPark >= 13u;
+    static constexpr uint32_t kHitP = 6u, kHitN = 9u, kHitMat = 12u;             // kHit, between closest() and the vertex
+    static constexpr uint32_t kEnvC = 6u, kDirC = 9u, kDepth = kHit ? 12u : 6u;  // across the vertex's shadow rays
+    static constexpr uint32_t kRng = 7u;                                         // (8-row form only)
+};
+template <class Wave>
+F3D_HD void park3(const Wave &w, uint32_t row, V3 v) {
+    w.park(row, v.x);
+    w.park(row + 1u, v.y);
+    w.park(row + 2u, v.z);
+}
+template <class Wave>
+F3D_HD V3 unpark3(const Wave &w, uint32_t row) {
+    return V3{w.unpark(row), w.unpark(row + 1u), w.unpark(row + 2u)};
+}
+
 // One surface vertex: emission, NEE (environment / directional / area) with its shadow rays, continuation sample,
 // roulette (pt_shade.wgsl main :460-862 + pt_shadow.wgsl main).  Returns true when the path continues in P.
 template <class Wave>
@@ -567,7 +603,13 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
     M.imp = md.importance;
     const float sm = f_saturate(md.metallic);
     M.F0 = V3{mix(0.04f, md.albedo.x, sm), mix(0.04f, md.albedo.y, sm), mix(0.04f, md.albedo.z, sm)};
-    if (md.emissive.x > 0.0f || md.emissive.y > 0.0f || md.emissive.z > 0.0f) acc = acc + P.thr * md.emissive;
+    using Rows = ParkRows<Wave>;
+    auto acc_add = [&](V3 c) F3D_LAMBDA {
+        if (Rows::kOn) park3(wave, Rows::kAcc, unpark3(wave, Rows::kAcc) + c);
+        else acc = acc + c;
+    };
+    const V3 thr_in = Rows::kOn ? unpark3(wave, Rows::kThr) : P.thr;  // the throughput the path arrives with
+    if (md.emissive.x > 0.0f || md.emissive.y > 0.0f || md.emissive.z > 0.0f) acc_add(thr_in * md.emissive);
 
     uint32_t rng = P.rng_hi ^ (pixel * 26699u) ^ (frame * 30977u);
     const V3 n = normalize(H.n), wo = normalize(normalize(neg(P.d)));
@@ -576,10 +618,10 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
     const V3 so = H.p + n * 1e-3f;
     // homogeneous fog, :328-338 / :500-520: next-event contributions of this vertex are attenuated over the segment that
     // reached it; a PRIMARY hit also adds the environment seen through the fog it looks through
-    const float mtrans = S.medium_on != 0u ? exp_det(-f_max(H.t, 0.0f) * S.medium_mu) : 1.0f;
-    if (S.medium_on != 0u && P.depth == 0u) {
+    const float mtrans = (!Wave::kLite && S.medium_on != 0u) ? exp_det(-f_max(H.t, 0.0f) * S.medium_mu) : 1.0f;
+    if (!Wave::kLite && S.medium_on != 0u && P.depth == 0u) {
         const V3 back = neg(wo);
-        acc = acc + mix3(S.env_ground, S.env_sky, 0.5f * (back.y + 1.0f)) * (1.0f - mtrans);
+        acc_add(mix3(S.env_ground, S.env_sky, 0.5f * (back.y + 1.0f)) * (1.0f - mtrans));
     }
 
     // Next-event estimation.  The three candidates are SAMPLED here, in the reference's order (the random numbers are drawn in
@@ -611,7 +653,7 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
             const Bsdf br = bsdf_eval(M, wo, wi, n);
             const float w_mis = pdf_light / f_max(pdf_light + br.pdf, 1e-8f);
             const float k = (((cos_surf / f_max(pdf_light, 1e-8f)) * w_mis) * M.imp) * mtrans;
-            env_c = ((P.thr * br.f) * L_env) * k;
+            env_c = ((thr_in * br.f) * L_env) * k;
             env_wi = wi;
             nee_on |= 1u;
         }
@@ -624,12 +666,12 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
             const Bsdf br = bsdf_eval(M, wo, L.wi, n);
             const float p_sel = S.dir_sum_imp > 0.0f ? L.importance / f_max(S.dir_sum_imp, 1e-8f) : 1.0f / (float)S.dir_count;
             const float k = ((cos_surf / f_max(p_sel, 1e-8f)) * M.imp) * mtrans;
-            dir_c = ((P.thr * br.f) * L.Li) * k;
+            dir_c = ((thr_in * br.f) * L.Li) * k;
             dir_wi = L.wi;
             nee_on |= 2u;
         }
     }
-    if (S.area_count > 0u) {  // discs, sampled uniformly by area, balance heuristic
+    if (!Wave::kLite && S.area_count > 0u) {  // discs, sampled uniformly by area, balance heuristic
         const uint32_t idx = pick(S.area_count, S.area_sum_imp, rng, [&](uint32_t i) { return S.area[i].importance; });
         const AreaLightDev L = S.area[idx];
         const float u1 = rng_next(rng), u2 = rng_next(rng);
@@ -650,7 +692,7 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
                     const float pdf_light = p_sel * pdf;
                     const float w_mis = pdf_light / f_max(pdf_light + br.pdf, 1e-8f);
                     const float k = (((cos_surf / f_max(pdf_light, 1e-8f)) * w_mis) * M.imp) * mtrans;
-                    area_c = ((P.thr * br.f) * L.Li) * k;
+                    area_c = ((thr_in * br.f) * L.Li) * k;
                     area_wi = wi;
                     area_tmax = dist - 1e-3f;
                     nee_on |= 4u;
@@ -661,7 +703,7 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
 
     const bool go_on = [&]() -> bool {
     V3 wi, thr;
-    if (H.hair) {  // Kajiya-Kay, :708-729: cosine-hemisphere continuation weighted by a diffuse term and two lobes about the strand
+    if (!Wave::kLite && H.hair) {  // Kajiya-Kay, :708-729: cosine-hemisphere continuation weighted by a diffuse term and two lobes about the strand
         const V3 T = normalize(H.tangent);
         const float u1 = rng_next(rng), u2 = rng_next(rng);
         wi = normalize(to_world(basis, cosine_hemisphere(u1, u2)));
@@ -672,7 +714,7 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
         const V3 f{kd * (md.albedo.x / kPi) + M.F0.x * spec, kd * (md.albedo.y / kPi) + M.F0.y * spec, kd * (md.albedo.z / kPi) + M.F0.z * spec};
         const float cos_theta = f_max(0.0f, dot(n, wi));
         const float pdf = cos_theta / kPi + 1e-8f;
-        thr = (P.thr * f) * (cos_theta / pdf);
+        thr = (thr_in * f) * (cos_theta / pdf);
     } else if (md.metallic > 0.5f) {  // GGX half-vector sampling
         const float u1 = rng_next(rng), u2 = rng_next(rng);
         const float a = f_max(0.02f, md.roughness * md.roughness);
@@ -706,7 +748,7 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
                                 : smith_g1(n_dot_l, a) * smith_g1(n_dot_v, a);
         const V3 spec = schlick(v_dot_h, M.F0) * ((D * G) / f_max((4.0f * n_dot_l) * n_dot_v, 1e-6f));
         const float pdf = (D * n_dot_h) / f_max(4.0f * v_dot_h, 1e-6f);
-        thr = (P.thr * spec) * (n_dot_l / f_max(pdf, 1e-6f));
+        thr = (thr_in * spec) * (n_dot_l / f_max(pdf, 1e-6f));
     } else if (md.ior > 1.01f) {  // smooth dielectric, Schlick-weighted reflect / refract
         const float cosi = f_saturate(dot(n, wo));
         const float r0 = (md.ior - 1.0f) / (md.ior + 1.0f);
@@ -722,13 +764,13 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
             const float kk = 1.0f - (eta * eta) * (1.0f - ni * ni);
             wi = kk < 0.0f ? normalize(reflect3(neg(wo), n)) : normalize(I * eta - N * (eta * ni + f_sqrt(kk)));
         }
-        thr = P.thr * V3{f_max(md.albedo.x, 0.0f), f_max(md.albedo.y, 0.0f), f_max(md.albedo.z, 0.0f)};
+        thr = thr_in * V3{f_max(md.albedo.x, 0.0f), f_max(md.albedo.y, 0.0f), f_max(md.albedo.z, 0.0f)};
     } else {  // Lambert
         const float u1 = rng_next(rng), u2 = rng_next(rng);
         wi = normalize(to_world(basis, cosine_hemisphere(u1, u2)));
         const float cos_theta = f_max(0.0f, dot(n, wi));
         const float pdf = cos_theta / kPi + 1e-8f;
-        thr = (P.thr * V3{md.albedo.x / kPi, md.albedo.y / kPi, md.albedo.z / kPi}) * (cos_theta / pdf);
+        thr = (thr_in * V3{md.albedo.x / kPi, md.albedo.y / kPi, md.albedo.z / kPi}) * (cos_theta / pdf);
     }
     float rr = 1.0f;
     if (P.depth >= 4u) {
@@ -740,21 +782,36 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
     P.o = H.p + normalize(H.n) * 1e-3f;
     P.tmin = 1e-3f;
     P.d = wi;
-    P.thr = thr * rr;
+    if (Rows::kOn) park3(wave, Rows::kThr, thr * rr);
+    else P.thr = thr * rr;
     P.depth = P.depth + 1u;
     P.rng_hi = rng;
     return true;
     }();
     // the deferred shadow rays (pt_shadow.wgsl main): every lane takes ITS next one, in the order their contributions were
-    // added before (environment, directional, area), until no lane of the wave has one left
+    // added before (environment, directional, area), until no lane of the wave has one left.  What the vertex has decided
+    // already waits in the lane's park rows meanwhile (see "parked path state").
+    if (Rows::kOn) {
+        wave.park(Rows::kDepth, f_from_bits(P.depth));
+        if (Rows::kHit) {
+            park3(wave, Rows::kEnvC, env_c);
+            park3(wave, Rows::kDirC, dir_c);
+        } else {
+            wave.park(Rows::kRng, f_from_bits(P.rng_hi));
+        }
+    }
     while (wave.count(nee_on != 0u) != 0u) {
         if (nee_on != 0u) {
             const uint32_t k = (uint32_t)__builtin_ctz(nee_on);
             nee_on &= nee_on - 1u;
             const V3 wi = k == 0u ? env_wi : (k == 1u ? dir_wi : area_wi);
-            const V3 c = k == 0u ? env_c : (k == 1u ? dir_c : area_c);
-            if (!shadowed(S, so, wi, 1e-3f, k == 2u ? area_tmax : 1e30f, wave)) acc = acc + c;
+            if (!shadowed(S, so, wi, 1e-3f, k == 2u ? area_tmax : 1e30f, wave))
+                acc_add((Rows::kHit && k < 2u) ? unpark3(wave, Rows::kEnvC + 3u * k) : (k == 0u ? env_c : (k == 1u ? dir_c : area_c)));
         }
+    }
+    if (Rows::kOn) {
+        P.depth = f_bits(wave.unpark(Rows::kDepth));
+        if (!Rows::kHit) P.rng_hi = f_bits(wave.unpark(Rows::kRng));
     }
     return go_on;
 }
@@ -765,15 +822,25 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
 template <class Pend>
 struct SoloWave {
     static constexpr bool kTerrain = true;
+    static constexpr bool kLite = false;
+    static constexpr uint32_t kPark = 13u;  // (the host runs the parked form of the code, the park being an array)
     Pend *pend;
+    mutable uint32_t parked[13];
     F3D_HD uint32_t count(bool flag) const { return flag ? 64u : 0u; }
+    F3D_HD void park(uint32_t row, float v) const { parked[row] = f_bits(v); }
+    F3D_HD float unpark(uint32_t row) const { return f_from_bits(parked[row]); }
 };
 #if defined(__HIPCC__)
-template <class Pend, bool TERRAIN>
+template <class Pend, bool TERRAIN, bool LITE = false>
 struct HipWave {
     static constexpr bool kTerrain = TERRAIN;
+    static constexpr bool kLite = LITE;  // no meshes, hair, area lights, fog in the scene: their code is not in the kernel
+    // rows of the lane's LDS column in which the path's loop-carried state waits out a march (0: no LDS block, nothing parked)
+    static constexpr uint32_t kPark = TERRAIN ? (uint32_t)kPathParkRows : 0u;
     Pend *pend;
     __device__ uint32_t count(bool flag) const { return (uint32_t)__popcll(__ballot(flag)); }
+    __device__ void park(uint32_t row, float v) const { pend->col[(kPathParkRow0 + row) * kWave] = f_bits(v); }
+    __device__ float unpark(uint32_t row) const { return f_from_bits(pend->col[(kPathParkRow0 + row) * kWave]); }
 };
 #endif
 
@@ -804,11 +871,21 @@ F3D_HD uint32_t trace_frames(const SceneDev &S, uint32_t pixel, uint32_t first, 
     P.o = P.d = P.thr = V3{0.0f, 0.0f, 0.0f};
     P.tmin = 0.0f;
     P.depth = P.rng_hi = 0u;
-    V3 total{0.0f, 0.0f, 0.0f};
+    using Rows = ParkRows<Wave>;
+    V3 total{0.0f, 0.0f, 0.0f};  // (kOn: rows kAcc.. instead)
+    if (Rows::kOn) park3(wave, Rows::kAcc, total);
     SurfaceHitWf H;
-    H.p = H.n = V3{0.0f, 0.0f, 0.0f};
+    H.p = H.n = H.tangent = V3{0.0f, 0.0f, 0.0f};
     H.t = 0.0f;
     H.mat = 0u;
+    H.hair = false;
+    auto finish_frame = [&]() F3D_LAMBDA {  // the frame's total goes out, the next frame starts from zero
+        sink(frame, Rows::kOn ? unpark3(wave, Rows::kAcc) : total);
+        total = V3{0.0f, 0.0f, 0.0f};
+        if (Rows::kOn) park3(wave, Rows::kAcc, total);
+        frame++;
+        fresh = true;
+    };
     for (;;) {
         for (;;) {  // cheap phase
             if (!pending && frame < end) {
@@ -816,17 +893,22 @@ F3D_HD uint32_t trace_frames(const SceneDev &S, uint32_t pixel, uint32_t first, 
                     const uint32_t seed_hi = splitmix32(S.seed_hi ^ frame);
                     seed_lo = splitmix32(S.seed_lo ^ (frame * 0x00009E3Du));
                     camera_ray(S, pixel, frame, seed_hi, seed_lo, P);
+                    if (Rows::kOn) park3(wave, Rows::kThr, P.thr);
                     fresh = false;
                 }
                 vertices++;
                 if (closest(S, P.o, P.d, P.tmin, H, wave)) {
                     pending = true;
+                    if (Rows::kHit) {  // the hit waits for the expensive phase in the park rows, not in registers
+                        park3(wave, Rows::kHitP, H.p);
+                        park3(wave, Rows::kHitN, H.n);
+                        wave.park(Rows::kHitMat, f_from_bits(H.mat));
+                    }
                 } else {  // pt_scatter.wgsl:113-131
-                    total = total + P.thr * mix3(S.miss_ground, S.miss_sky, 0.5f * (P.d.y + 1.0f));
-                    sink(frame, total);
-                    total = V3{0.0f, 0.0f, 0.0f};
-                    frame++;
-                    fresh = true;
+                    const V3 miss = (Rows::kOn ? unpark3(wave, Rows::kThr) : P.thr) * mix3(S.miss_ground, S.miss_sky, 0.5f * (P.d.y + 1.0f));
+                    if (Rows::kOn) park3(wave, Rows::kAcc, unpark3(wave, Rows::kAcc) + miss);
+                    else total = total + miss;
+                    finish_frame();
                 }
             }
             if (wave.count(!pending && frame < end) < (Wave::kTerrain ? (uint32_t)F3D_WF_REFILL_TERRAIN : (uint32_t)F3D_WF_REFILL)) break;
@@ -837,12 +919,12 @@ F3D_HD uint32_t trace_frames(const SceneDev &S, uint32_t pixel, uint32_t first, 
         }
         if (pending) {  // expensive phase
             pending = false;
-            if (!surface_vertex(S, pixel, frame, seed_lo, H, P, total, wave)) {
-                sink(frame, total);
-                total = V3{0.0f, 0.0f, 0.0f};
-                frame++;
-                fresh = true;
+            if (Rows::kHit) {
+                H.p = unpark3(wave, Rows::kHitP);
+                H.n = unpark3(wave, Rows::kHitN);
+                H.mat = f_bits(wave.unpark(Rows::kHitMat));
             }
+            if (!surface_vertex(S, pixel, frame, seed_lo, H, P, total, wave)) finish_frame();
         }
     }
     return vertices;
