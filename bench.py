@@ -310,7 +310,7 @@ def main():
     windows = 1 + max(0, args.extra_windows)
     total_frames = args.warmup + args.steps * max(windows, 2)  # (one window more when the kernel-timing window is an extra one)
     kw = dict(kw, max_frames=max(total_frames, 2), min_frames=max(total_frames, 2))
-    if world == 1:  # a throw-away session of another DEM first: module load and allocator start-up are not set-up of THIS render
+    if True:  # (every rank) a throw-away session of another DEM first: module load and allocator start-up are not set-up of THIS render
         from forge3d_amd.session import TerrainSession
 
         # (large enough to go through the staged upload: the first asynchronous host-to-device copy of a process costs 7 ms)
@@ -320,6 +320,15 @@ def main():
             ws.enqueue_frames(0, 2)
         torch.zeros(4, dtype=torch.int32, device=f"cuda:{local_rank}")  # (torch's own allocator and stream start up with its first device tensor: 15-20 ms on some boxes)
         torch.cuda.synchronize()
+    if world > 1:  # every rank has started up, and the process group has made its connections (once per process, not per render)
+        import torch.distributed as dist
+
+        comm = "cpu" if dist.get_backend() == "gloo" else f"cuda:{local_rank}"
+        warm_box = torch.zeros(8, dtype=torch.float64, device=comm)
+        dist.all_reduce(warm_box)  # (each kind of collective the set-up uses, once: their first use builds the backend's channels)
+        dist.broadcast(warm_box, src=0)
+        dist.all_gather([torch.empty_like(warm_box) for _ in range(world)], warm_box)
+        dist.barrier()
     torch.cuda.synchronize()
     t_setup = time.perf_counter()
     r = StripRenderer(dem, args.width, args.height, cam, rank=rank, world=world, device=local_rank,
@@ -404,7 +413,7 @@ def main():
                              "device_passes_and_python": round(setup_ms - setup_phases.get("total", 0.0), 3)},
                 "setup_note": "session creation outside the timed region, for a DEM this process has not seen: DEM fingerprint, staged upload, "
                               "min-max tables, state allocation + clears, G-buffer pass, ray certificates",
-                **({"strip_row_bounds": r.bounds, "strip_probe_ms": r.balance_log[-1]["ms"] if r.balance_log else None,
+                **({"setup_trace_ms_rank0": {k: round(v, 2) for k, v in getattr(r, "setup_trace", {}).items()}, "strip_row_bounds": r.bounds, "strip_probe_ms": r.balance_log[-1]["ms"] if r.balance_log else None,
                     "rccl_ranks": world, "rank_ms_per_step": [round(x, 4) for x in rank_ms], "halo_bytes_per_frame_rank0": halo_bytes,
                     # device time each rank's pulls stood waiting for its neighbours' frame counters, per frame (peer halos only),
                     # and the longest single wait: what the first real multi-GPU run has to show

@@ -18,7 +18,7 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libf3dhip.so"
 
 STATUS_OK, STATUS_VALUE, STATUS_RENDER, STATUS_UPLOAD, STATUS_DEVICE = 0, 1, 2, 3, 4
-ABI_VERSION = 4  # F3D_ABI_VERSION of include/f3d_terrain_pt.h this mirror was written against
+ABI_VERSION = 5  # F3D_ABI_VERSION of include/f3d_terrain_pt.h this mirror was written against
 
 _EARTH = {"flat": 0, "sphere": 1, "ellipsoid": 2, "wgs84": 2}
 _REFRACTION = {"none": 0, "bennett": 1, "saemundsson": 2, "effective_radius": 3}
@@ -141,6 +141,7 @@ ABI = [
                                    _P(C.c_uint32)]),
     ("f3d_session_kernel_timing", C.c_int, [C.c_void_p, C.c_int32, _P(C.c_double), _P(C.c_uint32)]),
     ("f3d_session_sample_lanes", C.c_uint32, [C.c_void_p]),
+    ("f3d_session_row_costs", C.c_int, [C.c_void_p, _P(C.c_float), C.c_uint32, C.c_char_p, C.c_size_t]),
     ("f3d_halo_rows", C.c_uint32, []),
     ("f3d_session_enqueue_frame_part", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_char_p, C.c_size_t]),
     ("f3d_atrous_denoise", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32,

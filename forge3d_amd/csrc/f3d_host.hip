@@ -1043,6 +1043,37 @@ int f3d_session_kernel_timing(f3d_session *s, int32_t enable, double *avg_ms, ui
 }
 
 uint32_t f3d_session_sample_lanes(f3d_session *s) { return s ? s->params.sample_lanes : 0u; }
+
+// What the last fused frame cost, row by row: every wave of the frame kernel leaves its duration in tile_cost (the input of
+// the longest-first dispatch); a tile's time is spread over its rows.  The strip driver cuts the image where these sums are
+// equal (forge3d_amd/distributed.py) -- one probe frame instead of rounds of whole-loop probe renders.
+int f3d_session_row_costs(f3d_session *s, float *out, uint32_t rows, char *err, size_t errlen) {
+    try {
+        if (!s || !out) fail(F3D_STATUS_VALUE, "null argument");
+        if (rows != s->rows) fail(F3D_STATUS_VALUE, "the session owns %u rows, %u asked for", s->rows, rows);
+        if (!s->tile_cost || s->cost_frame < 0) fail(F3D_STATUS_VALUE, "no frame has left its tile costs yet (a one-band session with the default tile map does, from its first fused frame on)");
+        DeviceGuard guard(s->device);
+        hip_check(hipStreamSynchronize(s->stream), "row costs");
+        FrameParams P = s->params;
+        P.band_begin = s->row_begin;
+        P.band_end = s->row_end;
+        const uint32_t tiles = frame_tile_count(P, nullptr);
+        std::vector<uint32_t> cost(tiles);
+        hip_check(hipMemcpy(cost.data(), s->tile_cost, (size_t)tiles * sizeof(uint32_t), hipMemcpyDeviceToHost), "tile costs");
+        const uint32_t lanes = P.sample_lanes ? P.sample_lanes : 1u;
+        const uint32_t log_s = lanes == 1u ? 0u : (lanes == 2u ? 1u : (lanes == 4u ? 2u : 3u)), log_w = lanes <= 2u ? 3u : 2u, log_h = 6u - log_s - log_w;  // TileShape<S>
+        const uint32_t tiles_x = (s->width + (1u << log_w) - 1u) >> log_w, th = 1u << log_h;
+        std::vector<double> sum(rows, 0.0);
+        for (uint32_t t = 0; t < tiles; t++) {
+            const uint32_t r0 = (t / tiles_x) * th, r1 = std::min(rows, r0 + th);
+            for (uint32_t r = r0; r < r1; r++) sum[r] += (double)cost[t] / (double)(r1 - r0);
+        }
+        for (uint32_t r = 0; r < rows; r++) out[r] = (float)sum[r];
+        return F3D_STATUS_OK;
+    } catch (const Failure &f) {
+        return report(f, err, errlen);
+    }
+}
 uint32_t f3d_halo_rows(void) { return kHaloRows; }
 
 // Diagnostics: FNV-style hashes of everything a frame launch reads -- the by-value uniforms (camera, light, terrain and

@@ -17,10 +17,15 @@ CPU with the kernel emulator under tests/emul.
 
 Strips are LOAD-BALANCED, not equal: a sky row costs a fraction of a terrain row and the sky
 sits at the top of the frame, so equal strips would leave the top ranks idle (strong scaling
-is bounded by the slowest strip).  Before the render every rank times a few probe frames of
-its strip, the times are all-gathered, a per-row cost density is updated multiplicatively and
-the rows are re-partitioned (`balance_iters` rounds; the best measured partition wins).  Any
-partition gives the same image -- state is keyed by full-image coordinates.
+is bounded by the slowest strip).  Round 5: the cut comes from ONE measurement -- rank 0 renders
+a few frames of the whole image in a throw-away session, the frame kernel's own per-tile wave
+times (what its longest-first dispatch sorts by) are summed by row (f3d_session_row_costs),
+broadcast, and every rank cuts the rows into strips of equal cost: ~10 ms once instead of up to
+six rounds of whole-loop probe renders of every strip (2 s of set-up for a 60 ms render at 8
+ranks rehearsed on one GPU, round-4 verdict).  `balance_iters` > 0 adds that many rounds of the
+measured refinement of rounds 1-4 on top (every rank times probe frames of its strip, the times
+are all-gathered, the density is updated multiplicatively; the best measured partition wins).
+Any partition gives the same image -- state is keyed by full-image coordinates.
 """
 from __future__ import annotations
 
@@ -31,6 +36,11 @@ import numpy as np
 from .session import HALO_ROWS  # noqa: E402  (4: f3d_scene.h kHaloRows)
 RES_BYTES = 16
 WELFORD_WINDOW = 32
+# What a row costs beyond the wave time the frame kernel logs for it, as a fraction of the mean row: the per-pixel passes
+# (frame head, merge, state traffic) and the launches of a strip-frame do not shrink with a row's ray work.  Calibrated on
+# the 8-, 4- and 2-strip rehearsals of the headline frame (profiles/r05_strip_balance.log: with 0.02 the sky strip of 400
+# rows took 10.3 ms of the 32-frame loop against 8.9 for the others; 0.005-0.0065 ms per row and loop in all three).
+ROW_COST_FLOOR = 0.08
 
 
 def init_process_group(world: int, rank: int, backend: str | None = None, force: bool = False):
@@ -137,6 +147,18 @@ class HipBackend:
     def sync(self):
         self.torch.cuda.synchronize(self.device)
 
+    def row_costs(self, dem, width, height, cam, kw, frames=3):
+        """Cost by image row of the whole frame (float64[height]): `frames` fused frames in a throw-away full-height
+        session, the last one's per-tile wave times summed by row (TerrainSession.row_costs)."""
+        from .session import TerrainSession
+
+        k = {key: v for key, v in kw.items() if key not in ("frames_in_flight", "bands", "band_streams")}
+        k.update(max_frames=max(int(frames), 2), min_frames=max(int(frames), 2), variance_threshold=1e30)
+        stream = self.torch.cuda.current_stream(self.device).cuda_stream
+        with TerrainSession(dem, width, height, cam, device=self.device.index, stream=stream, **k) as s:
+            s.enqueue_frames(0, int(frames))
+            return s.row_costs().astype(np.float64)
+
     def probe(self, dem, width, height, cam, row_begin, row_end, kw, frames=4, whole_loop=False):
         """Milliseconds per frame of the strip [row_begin, row_end): `frames` probe frames enqueued back to
         back (after one untimed frame) in a throw-away session, device time from start to drain -- the bands
@@ -164,7 +186,7 @@ class HipBackend:
 
 class StripRenderer:
     def __init__(self, dem, width, height, cam, *, rank=0, world=1, device=0, backend=None, row_bounds=None,
-                 balance_iters=5, peer_halos=None, force_collectives=False, **kw):
+                 balance_iters=0, peer_halos=None, force_collectives=False, **kw):
         import torch
 
         self.torch = torch
@@ -175,6 +197,17 @@ class StripRenderer:
         self.width, self.height = int(width), int(height)
         self.backend = backend or HipBackend(device)
         self.balance_log = []
+        import time as _time
+
+        self.setup_trace = {}  # this rank's wall time of the set-up by step (ms): what a render pays once
+        self._lap_t = _time.perf_counter()
+
+        def lap(name):
+            now = _time.perf_counter()
+            self.setup_trace[name] = self.setup_trace.get(name, 0.0) + (now - self._lap_t) * 1e3
+            self._lap_t = now
+
+        self._lap = lap
         # Frames in flight (f3d_session_opts.frames_in_flight): thin strips trace batches of frames in one launch and run
         # the ordered half per frame, with the halo exchange between merges.  Measured per strip-frame of the 1080p headline
         # (tools/strip_balance.py, profiles/r03_strip_balance.log; fused / 16 in flight): 2 strips 1.13 / 1.23 ms, 4 strips
@@ -203,8 +236,13 @@ class StripRenderer:
             self.bounds = [strip_rows(self.height, world, r)[0] for r in range(world)] + [self.height]
             if world > 1 and self.height < world * HALO_ROWS:
                 raise ValueError(f"strips need at least {HALO_ROWS} rows each ({self.height} rows / {world} ranks)")
+            self._lap("before balancing")
+            if self.distributed and hasattr(self.backend, "row_costs"):
+                self.bounds = self._balance_from_cost_map(dem, cam, kw)
+                self._lap("cost map + broadcast")
             if self.distributed and balance_iters > 0 and hasattr(self.backend, "probe"):
                 self.bounds = self._balance(dem, cam, kw, balance_iters)
+                self._lap("measured balance rounds")
         self.row_begin, self.row_end = self.bounds[rank], self.bounds[rank + 1]
         self.rows = self.row_end - self.row_begin
         nbytes = (self.rows + 2 * HALO_ROWS) * self.width * RES_BYTES
@@ -246,7 +284,9 @@ class StripRenderer:
         session, export, ok = None, b"", 1
         self.peer_halo_failure = None  # why THIS rank could not (the other ranks only learn that somebody could not)
         try:
+            self._lap("buffers")
             session = self.backend.make_session(dem, self.width, self.height, cam, self.row_begin, self.row_end, None, self.stats, kw)
+            self._lap("strip session")
             export = session.halo_export()
         except Exception as exc:  # noqa: BLE001 -- the classic path reports what is wrong with the scene
             ok, self.peer_halo_failure = 0, f"export: {exc}"
@@ -256,6 +296,7 @@ class StripRenderer:
         mine[: len(export)] = torch.frombuffer(bytearray(export), dtype=torch.uint8) if export else mine[:0]
         parts = [torch.empty(size, dtype=torch.uint8, device=dev) for _ in range(self.world)]
         dist.all_gather(parts, mine.to(dev))
+        self._lap("halo export + all-gather")
         if ok:
             try:
                 n = len(export)
@@ -271,6 +312,7 @@ class StripRenderer:
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             return int(flag.item()) == 1
 
+        self._lap("halo connect (IPC map)")
         if not agreed(ok):
             if session is not None:
                 session.close()
@@ -305,13 +347,14 @@ class StripRenderer:
                 session.halo_probe_pull(salt + self.rank, salt + self.rank + 2)
             except Exception as exc:  # noqa: BLE001
                 ok, self.peer_halo_failure = 0, f"block probe: {exc}"
-            dist.barrier()  # nobody refills (or clears) its edge rows before every neighbour has pulled them
+            # (the all-reduce is also the barrier this needs: nobody refills -- or clears -- its edge rows before every
+            # neighbour has pulled them, and nobody starts rendering before every neighbour is mapped and checked)
             if not agreed(ok):
                 session.close()
                 return None
-        session.halo_probe_clear()  # the patterns sit in reservoir buffer 0: as a new session has it
+        session.halo_probe_clear()  # the patterns sit in reservoir buffer 0: as a new session has it (in stream order before frame 0)
         session.halo_stats(reset=True)  # the probes' waits are not the render's
-        dist.barrier()  # nobody starts rendering (and polling counters) before every neighbour is mapped
+        self._lap("link checks (4 rounds)")
         return session
 
     # -- communication device ---------------------------------------------------------
@@ -335,11 +378,34 @@ class StripRenderer:
         dist.all_gather(parts, mine)
         return [float(p.item()) for p in parts]
 
+    def _balance_from_cost_map(self, dem, cam, kw):
+        """Strips of equal cost from rank 0's row-cost map of the whole frame (module docstring).  One broadcast; every rank
+        cuts the same map, so every rank derives the same boundaries."""
+        import torch.distributed as dist
+
+        density, error = np.ones(self.height), None
+        if self.rank == 0:
+            try:
+                density = np.asarray(self.backend.row_costs(dem, self.width, self.height, cam, kw), np.float64)
+                if density.shape != (self.height,) or not np.all(np.isfinite(density)) or density.sum() <= 0.0:
+                    density = np.ones(self.height)
+            except Exception as exc:  # noqa: BLE001 -- agreed on below, before the broadcast
+                error = exc
+        self._agree(error)
+        box = self.torch.from_numpy(density).to(self._comm_device())
+        dist.broadcast(box, src=0)
+        self.cost_density = box.cpu().numpy()
+        # a floor under the measured cost: the fixed part of a row (ROW_COST_FLOOR)
+        floor = ROW_COST_FLOOR * float(self.cost_density.mean())
+        bounds = partition_rows(self.cost_density + floor, self.world, HALO_ROWS)
+        self.balance_log.append({"bounds": list(bounds), "ms": None, "from": "row cost map of one full frame (rank 0)"})
+        return bounds
+
     def _balance(self, dem, cam, kw, iters):
         """Measure-and-repartition loop (module docstring).  Every rank sees the same gathered
         times, so every rank derives the same boundaries; the best MEASURED partition is kept."""
         bounds = list(self.bounds)
-        density = np.ones(self.height)
+        density = np.asarray(getattr(self, "cost_density", np.ones(self.height)), np.float64).copy()
         best = None
         for it in range(iters + 1):
             # a probe that fails on one rank (a fat strip over the memory budget, a stale library) must not leave the

@@ -245,6 +245,12 @@ class TerrainSession:
         """Sample lanes per pixel of the frame kernel (1, 2, 4 or 8; chosen from the strip size and spp)."""
         return int(self._lib.f3d_session_sample_lanes(self._handle))
 
+    def row_costs(self) -> np.ndarray:
+        """Cost of the last fused frame by image row of this strip (float32[rows], wave time in 100 MHz ticks); synchronises."""
+        out = np.zeros(self.rows, np.float32)
+        self._check(self._lib.f3d_session_row_costs(self._handle, out.ctypes.data_as(C.POINTER(C.c_float)), self.rows, self._err, len(self._err)))
+        return out
+
     def kernel_timing(self, enable: bool):
         """enable=True starts recording a hipEvent pair around every frame launch;
         enable=False stops and returns (average ms per launch, launches)."""

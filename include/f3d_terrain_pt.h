@@ -34,8 +34,10 @@ extern "C" {
  *               new entry points: peer halos (f3d_session_halo_*, f3d_session_enqueue_batch_strip),
  *               f3d_session_set_accumulation, f3d_smoke_step, f3d_smoke_composite, f3d_aether_reference_render
  *   4  round 4: + f3d_session_halo_stats / f3d_halo_stats, f3d_session_halo_probe modes 2 and 3 (no existing struct
- *               changed: a caller built against version 3 keeps working) */
-#define F3D_ABI_VERSION 4u
+ *               changed: a caller built against version 3 keeps working)
+ *   5  round 5: + f3d_session_row_costs; the smoke entry points return without waiting when their results stay on the
+ *               device and no time is asked for (no existing struct or signature changed) */
+#define F3D_ABI_VERSION 5u
 #define F3D_STATUS_OK 0
 #define F3D_STATUS_VALUE 1
 #define F3D_STATUS_RENDER 2
@@ -308,6 +310,9 @@ int f3d_session_info(f3d_session *session, uint64_t *gpu_resource_bytes, uint64_
 int f3d_session_kernel_timing(f3d_session *session, int32_t enable, double *avg_ms, uint32_t *launches);
 /* Sample lanes per pixel the frame kernel of this session runs with (1, 2, 4 or 8); 0 on a NULL session. */
 uint32_t f3d_session_sample_lanes(f3d_session *session);
+/* (ABI 5) Cost of the session's last fused frame by image row (out[rows], rows = the session's; 100 MHz ticks of wave time,
+ * a tile's duration spread over its rows): what the strip driver balances row strips on.  Synchronises the stream. */
+int f3d_session_row_costs(f3d_session *session, float *out, uint32_t rows, char *err, size_t errlen);
 /* Device memory the library has freed is kept for its next allocation of the same size (F3D_DEVICE_POOL_MB, default
  * 1024, 0 = off): a camera path or a smoke sequence allocates the same buffers frame after frame.  This hands everything
  * that is waiting back to the driver -- call it before another allocator (torch, RCCL) sizes large buffers on the device:

@@ -48,13 +48,23 @@ def _worker(rank, world, port, out_path, mode):
     else:  # converge through two Welford windows
         kw = {**kw, "variance_threshold": 5e-3, "max_frames": 256, "spp": 1}
     backend, extra = emul.EmulBackend(), {}
-    if mode == "balanced":
-        # synthetic probe: rows of the top half ("sky") cost 1, the others 5 -> unequal strips
+    if mode in ("balanced", "refined"):
+        # synthetic costs: rows of the top half ("sky") cost 1, the others 5 -> unequal strips.  "balanced": the cut comes
+        # from rank 0's row-cost map alone (round 5, one broadcast); "refined": three measured rounds on top of a FLAT map
         class CostBackend(emul.EmulBackend):
+            def row_costs(self, dem, width, height, cam, kw, frames=3):
+                import numpy as np
+
+                if mode == "refined":
+                    return np.ones(height)
+                return np.asarray([1.0 if y < height // 2 else 5.0 for y in range(height)])
+
             def probe(self, dem, width, height, cam, row_begin, row_end, kw, frames=2, whole_loop=False):
                 return float(sum(1.0 if y < height // 2 else 5.0 for y in range(row_begin, row_end)))
 
         backend = CostBackend()
+        if mode == "refined":
+            extra["balance_iters"] = 4
         kw = scenes.fixed_frames(kw, 6, spp=2)
     if mode == "bounds":
         extra["row_bounds"] = [0, 7, 50] if world == 2 else [0, 4, 41, 50]
@@ -96,13 +106,13 @@ def _worker(rank, world, port, out_path, mode):
         dist.barrier()
         dist.destroy_process_group()
         return
-    if mode == "balanced":
+    if mode in ("balanced", "refined"):
         sizes = [b1 - b0 for b0, b1 in zip(r.bounds, r.bounds[1:])]
         costs = [sum(1.0 if y < 25 else 5.0 for y in range(b0, b1)) for b0, b1 in zip(r.bounds, r.bounds[1:])]
         assert sizes[0] > sizes[-1] and max(costs) / (sum(costs) / world) < 1.1, (r.bounds, costs)
-        assert len(r.balance_log) >= 2
+        assert len(r.balance_log) == 1 if mode == "balanced" else len(r.balance_log) >= 3, r.balance_log
     image = r.render() if mode == "converge" else None
-    if mode in ("fixed", "balanced", "bounds"):
+    if mode in ("fixed", "balanced", "refined", "bounds"):
         r.run_frames(0, 6, collect_last=True)
         var = r.window_variance(6)
         image = r.gather_image(6)
@@ -145,7 +155,7 @@ def test_strips_over_gloo_reproduce_the_single_strip_image(world):
     assert single["variance"] == multi["variance"]
 
 
-@pytest.mark.parametrize("world,mode", [(2, "balanced"), (3, "balanced"), (2, "bounds"), (3, "bounds")])
+@pytest.mark.parametrize("world,mode", [(2, "balanced"), (3, "balanced"), (3, "refined"), (2, "bounds"), (3, "bounds")])
 def test_unequal_strips_reproduce_the_single_strip_image(world, mode):
     """Load-balanced (measured, here with a synthetic cost probe) and hand-picked boundaries:
     every rank derives the same partition and the stitched image is still bit-identical."""

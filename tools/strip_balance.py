@@ -19,7 +19,7 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from forge3d_amd import datasets  # noqa: E402
-from forge3d_amd.distributed import HALO_ROWS, HipBackend, partition_rows, rebalance, strip_rows  # noqa: E402
+from forge3d_amd.distributed import HALO_ROWS, ROW_COST_FLOOR, HipBackend, partition_rows, rebalance, strip_rows  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--worlds", default="2,4,8")
@@ -30,18 +30,26 @@ ap.add_argument("--frames", type=int, default=16)
 ap.add_argument("--sweep", action="store_true")
 ap.add_argument("--rounds", type=int, default=4)
 ap.add_argument("--fd", type=int, default=0, help="frames in flight of the strip sessions (f3d_session_opts.frames_in_flight)")
+ap.add_argument("--config", default="c2", help="c2: the 1080p headline frame; c4: BASELINE.json configs[3] stand-in, 4096^2 with the 600 000-triangle mesh")
+ap.add_argument("--costmap", action="store_true", help="cut the strips from ONE row-cost map of the full frame (round 5: StripRenderer's default) "
+                                                       "instead of iterating measured probes; --rounds N then adds N measured refinement rounds")
 args = ap.parse_args()
 
 W, H, SPP = 1920, 1080, 8
+LOOP_FRAMES = 32
 dem, cam, kw = datasets.rainier_proxy_scene(2048)
 kw = dict(kw, spp=SPP, max_frames=64, min_frames=64, variance_threshold=1e30, memory_budget_bytes=8 << 30,
           kernel_variant=args.variant)
+if args.config == "c4":
+    W, H, LOOP_FRAMES = 4096, 4096, 16  # 128 spp
+    v, i = datasets.proxy_buildings(dem, kw["spacing"][0])
+    kw.update(mesh_vertices=v, mesh_indices=i, memory_budget_bytes=24 << 30)
 backend = HipBackend(0)
 
 
 def probe(b0, b1, **extra):
     loop = bool(extra.get("frames_in_flight"))  # as StripRenderer._balance: strips with frames in flight are balanced on the 32-frame loop
-    return min(backend.probe(dem, W, H, cam, b0, b1, dict(kw, **extra), frames=32 if loop else args.frames, whole_loop=loop) for _ in range(2))
+    return min(backend.probe(dem, W, H, cam, b0, b1, dict(kw, **extra), frames=LOOP_FRAMES if loop else args.frames, whole_loop=loop) for _ in range(2))
 
 
 full = probe(0, H)
@@ -62,7 +70,14 @@ if args.sweep:
 for world in [int(x) for x in args.worlds.split(",")]:
     bounds = [strip_rows(H, world, r)[0] for r in range(world)] + [H]
     density = np.ones(H)
-    for it in range(args.rounds):
+    if args.costmap:
+        import time as _time
+
+        t0 = _time.perf_counter()
+        density = np.asarray(backend.row_costs(dem, W, H, cam, kw), np.float64)
+        bounds = partition_rows(density + ROW_COST_FLOOR * density.mean(), world, HALO_ROWS)
+        print(json.dumps({"world": world, "cost_map_ms": round((_time.perf_counter() - t0) * 1e3, 2), "bounds": bounds}), flush=True)
+    for it in range(0 if (args.costmap and args.rounds == 4) else args.rounds):
         times = [probe(bounds[r], bounds[r + 1], bands=args.bands, band_streams=args.streams, frames_in_flight=args.fd) for r in range(world)]
         print(json.dumps({"world": world, "round": it, "bounds": bounds, "ms": [round(t, 3) for t in times],
                           "imbalance": max(times) / (sum(times) / world),
@@ -85,12 +100,12 @@ for world in [int(x) for x in args.worlds.split(",")]:
             with TerrainSession(dem, W, H, cam, row_begin=b0, row_end=b1, **dict(kw, **extra)) as s:
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                s.enqueue_frames(0, 32)
+                s.enqueue_frames(0, LOOP_FRAMES)
                 torch.cuda.synchronize()
                 best = min(best, (time.perf_counter() - t0) * 1e3)
         return best
 
     full_loop = loop_ms(0, H)
     loops = [loop_ms(bounds[r], bounds[r + 1], frames_in_flight=args.fd) for r in range(world)]
-    print(json.dumps({"world": world, "render_256spp_loop_ms": {"full_frame": round(full_loop, 3), "strips": [round(t, 3) for t in loops]},
-                      "ms_per_strip_frame": round(max(loops) / 32, 4), "compute_bound_speedup_256spp": full_loop / max(loops), "bounds": bounds}), flush=True)
+    print(json.dumps({"config": args.config, "cut": "cost map" if args.costmap else "measured rounds", "world": world, "render_256spp_loop_ms": {"full_frame": round(full_loop, 3), "strips": [round(t, 3) for t in loops]},
+                      "ms_per_strip_frame": round(max(loops) / LOOP_FRAMES, 4), "compute_bound_speedup_256spp": full_loop / max(loops), "bounds": bounds}), flush=True)
