@@ -442,7 +442,8 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
         const uint64_t planned = s.mem.device_bytes + 2 * (uint64_t)res_n * sizeof(PackedReservoir) +
                                  (uint64_t)px * (sizeof(float4) + sizeof(float) + sizeof(float4) + sizeof(float) + 4 +
                                                  3 * sizeof(float) + 3 * sizeof(float) +
-                                                 (P.sample_lanes > 1u ? sizeof(uint2) : 0)) + 16;
+                                                 (P.sample_lanes > 1u ? sizeof(uint2) : 0) +
+                                                 sizeof(uint2) + sizeof(float2) /* ray certificates (f3d_cone.h) */ + 1 /* tile costs and order */) + 16;
         if (planned > s.budget)
             fail(F3D_STATUS_RENDER,
                  "terrain PT exceeds the memory budget before rendering: tracked total %llu (host-visible %llu) > "

@@ -11,6 +11,11 @@ tile's 8 samples per pixel could buy (round-4 verdict item 3).  Cost unit = one 
                they fill, then the IBL rays likewise
   stream       phase-major, and inside an occlusion phase a lane that finishes takes the next waiting ray (refill when
                REFILL_Q lanes wait, REFILL_COST iterations a refill)
+  pair         per round ONE march loop for both occlusion rays of a sample: a lane runs its sun ray, then its IBL ray
+               ("pair ideal": switching at once and for free; "pair q<N>": the lanes that are through with their sun ray
+               wait until N of them wait -- or nobody else will -- and switch together at REFILL_COST, the tail shared)
+
+    python tools/phase_model.py 400:656 [log] [--pair]     (--pair: every 5th tile, the pair schedules are slow to simulate)
 """
 import os
 import struct
@@ -112,12 +117,87 @@ def stream(steps, shared_tail=True):
     return t
 
 
+def pair_stream(sun, ibl, quorum, refill_cost, share=True):
+    """One loop for both occlusion rays of every lane (see the module docstring)."""
+    q = [[x for x in (s, i) if x > 0] for s, i in zip(sun, ibl)]
+    lanes = np.zeros(len(q))
+    pending = np.array([len(x) for x in q])
+    for li in range(len(q)):
+        if q[li]:
+            lanes[li] = q[li].pop(0)
+            pending[li] -= 1
+    t = refill_cost
+    for _ in range(10000):
+        marching = lanes > 0
+        waiting = (~marching) & (pending > 0)
+        if not marching.any() and not waiting.any():
+            break
+        if pending.sum() == 0:
+            live = lanes[marching]
+            t += lockstep_shared(live) if share else live.max()
+            break
+        if waiting.sum() >= quorum or not marching.any() or (waiting.any() and not (marching & (pending > 0)).any()):
+            t += refill_cost
+            for li in np.nonzero(waiting)[0]:
+                lanes[li] = q[li].pop(0)
+                pending[li] -= 1
+            continue
+        cand = np.sort(lanes[marching & (pending > 0)])
+        need = quorum - waiting.sum()
+        step = cand[need - 1] if len(cand) >= need else (cand[-1] if len(cand) else lanes[marching].max())
+        t += step
+        lanes[marching] -= step
+        lanes = np.clip(lanes, 0, None)
+    return t
+
+
+def pair_table(W, R, spp, pixels):
+    names = ("shipped", "pair ideal", "pair q16", "pair q32", "pair q16, switch cost 1", "pair q16, tail not shared")
+    tot = dict.fromkeys(names, 0.0)
+    prim = 0.0
+    tiles = [(ty, tx) for ty in range(0, R, 4) for tx in range(0, W, 4)][::5]
+    for ty, tx in tiles:
+        px = [pixels[y * W + x] for y in range(ty, min(ty + 4, R)) for x in range(tx, min(tx + 4, W))]
+        P = np.zeros((len(px), spp, 3))
+        for li, rays in enumerate(px):
+            s = -1
+            for kind, steps, mask in rays:
+                kind = int(kind) & 0xFF
+                if kind == 2:
+                    s += 1
+                    P[li, s, 0] = max(steps, 1)
+                elif kind == 7:
+                    P[li, s, 1] = max(steps, 1)
+                else:
+                    P[li, s, 2] = max(steps, 1)
+        for r0 in range(0, spp, 4):
+            blk = P[:, r0:r0 + 4, :].reshape(-1, 3)
+            prim += blk[:, 0].max()
+            sun, ibl = blk[:, 1], blk[:, 2]
+            if not ((sun > 0) | (ibl > 0)).any():
+                continue
+            s_, i_ = sun[sun > 0], ibl[ibl > 0]
+            tot["shipped"] += (s_.max() if s_.size else 0.0) + (lockstep_shared(i_) if i_.size else 0.0)
+            both = sun + ibl
+            tot["pair ideal"] += lockstep_shared(both[both > 0])
+            tot["pair q16"] += pair_stream(sun, ibl, 16, REFILL_COST)
+            tot["pair q32"] += pair_stream(sun, ibl, 32, REFILL_COST)
+            tot["pair q16, switch cost 1"] += pair_stream(sun, ibl, 16, 1.0)
+            tot["pair q16, tail not shared"] += pair_stream(sun, ibl, 16, REFILL_COST, False)
+    print(f"pair schedules on {len(tiles)} tiles: primary iterations {prim:.0f}")
+    for k, v in tot.items():
+        print(f"  {k:28s} occlusion iterations {v:9.0f}   whole frame {(prim + tot['shipped']) / (prim + v):.3f}x")
+
+
 def main():
     rows = tuple(int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "400:656").split(":"))
-    path = sys.argv[2] if len(sys.argv) > 2 else "/tmp/model/band_%d_%d.raylog" % rows
+    path = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else "/tmp/model/band_%d_%d.raylog" % rows
     if not os.path.exists(path):
         make_log(rows, path)
     W, R, spp, pixels = load_log(path)
+    if "--pair" in sys.argv:
+        pair_table(W, R, spp, pixels)
+        return
     S, TW, TH = 4, 4, 4
     tot = {k: 0.0 for k in ("shipped", "phase-major", "pm+stream-ibl", "pm+stream-both", "stream-in-round")}
     phase = {k: [0.0, 0.0] for k in ("primary", "sun", "ibl")}  # [lane-steps, 64 x wave iterations] in the shipped schedule

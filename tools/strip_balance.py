@@ -78,7 +78,7 @@ for world in [int(x) for x in args.worlds.split(",")]:
         bounds = partition_rows(density + ROW_COST_FLOOR * density.mean(), world, HALO_ROWS)
         print(json.dumps({"world": world, "cost_map_ms": round((_time.perf_counter() - t0) * 1e3, 2), "bounds": bounds}), flush=True)
     for it in range(0 if (args.costmap and args.rounds == 4) else args.rounds):
-        times = [probe(bounds[r], bounds[r + 1], bands=args.bands, band_streams=args.streams, frames_in_flight=args.fd) for r in range(world)]
+        times = [probe(bounds[r], bounds[r + 1], bands=args.bands, band_streams=args.streams, frames_in_flight=args.fd if world >= 4 else 0) for r in range(world)]
         print(json.dumps({"world": world, "round": it, "bounds": bounds, "ms": [round(t, 3) for t in times],
                           "imbalance": max(times) / (sum(times) / world),
                           "compute_bound_speedup": full / max(times)}), flush=True)
@@ -106,6 +106,7 @@ for world in [int(x) for x in args.worlds.split(",")]:
         return best
 
     full_loop = loop_ms(0, H)
-    loops = [loop_ms(bounds[r], bounds[r + 1], frames_in_flight=args.fd) for r in range(world)]
+    fd = args.fd if world >= 4 else 0  # (as the strip driver: fat strips keep the fused kernel)
+    loops = [loop_ms(bounds[r], bounds[r + 1], frames_in_flight=fd) for r in range(world)]
     print(json.dumps({"config": args.config, "cut": "cost map" if args.costmap else "measured rounds", "world": world, "render_256spp_loop_ms": {"full_frame": round(full_loop, 3), "strips": [round(t, 3) for t in loops]},
                       "ms_per_strip_frame": round(max(loops) / LOOP_FRAMES, 4), "compute_bound_speedup_256spp": full_loop / max(loops), "bounds": bounds}), flush=True)
