@@ -16,9 +16,9 @@ ROOT = Path(__file__).resolve().parent.parent
 tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 WHAT = {  # config -> (summary file, kernel name prefix in the summary, launches of it that make one "unit", unit)
     "C4_standin": ("C4", "void f3d::k_frame<0, 6, 4u, true>", "frame of 4096 x 4096 x 8 spp"),
-    "C3_gi": ("C3_gi", "void (anonymous namespace)::k_wf_paths<true>", "launch of 1920 x 1080 x 32 paths"),
+    "C3_gi": ("C3_gi", "void (anonymous namespace)::k_wf_paths<true>" if tag < "r05" else "void (anonymous namespace)::k_wf_paths<true, true>", "launch of 1920 x 1080 x 32 paths"),
     "C5_march": ("C5", "(anonymous namespace)::k_smoke(", "1080p frame of the smoke marcher"),
-    "C5_solver_jacobi": ("C5", "void (anonymous namespace)::k_sim<7u>", "Jacobi sweep of the 96 x 64 x 128 domain"),
+    "C5_solver_jacobi": ("C5", "void (anonymous namespace)::k_sim<7u>" if tag < "r05" else "void (anonymous namespace)::k_phase<6u>", "Jacobi sweep of the 96 x 64 x 128 domain"),
     "strip_trace": ("strip", "void f3d::k_trace<6, 8u, false>", "batch of <= 16 frames of an eighth of the 1080p frame"),
     "strip_merge": ("strip", "f3d::k_merge(", "strip-frame"),
     "strip_fused": ("strip_fused", "void f3d::k_frame<0, 6, 8u, false>", "strip-frame (fused kernel, 8 lanes)"),

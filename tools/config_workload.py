@@ -4,7 +4,7 @@
     python tools/config_workload.py C4          4096 x 4096, proxy DEM + 600 000 triangles, 8 spp x 6 frames  (k_frame<0,6,4,true>)
     python tools/config_workload.py C3_gi       1080p, proxy DEM in the PBR path tracer, 32 paths a pixel       (k_wf_paths<true>)
     python tools/config_workload.py gate        the adjudication scene of the PBR tracer, 512 x 512 x 4096 frames              (k_wf_paths<false>)
-    python tools/config_workload.py C5          8 frames of the smoke sequence at 1080p: solver step + march + composite
+    python tools/config_workload.py C5          16 frames of the resident smoke sequence at 1080p: solver phases + march + composite
     python tools/config_workload.py strip       the heaviest eighth of the 1080p headline frame, 16 frames in flight, 48 frames
     python tools/config_workload.py strip_fused the same strip with the fused kernel (k_frame<0,6,8,false>)
 """
@@ -60,9 +60,9 @@ elif what == "C5":
     view = dict(camera_pos=(48.0, 70.0, -120.0), target=(48.0, 28.0, 64.0), up=(0.0, 1.0, 0.0), fovy_deg=40.0)
     yy, xx = np.mgrid[0:1080, 0:1920]
     terrain = np.stack([(xx * 255 // 1919), (yy * 255 // 1079), np.full_like(xx, 96), np.full_like(xx, 255)], axis=-1).astype(np.uint8)
-    for _ in range(8):
-        dom.step(settings, emitters, steps=1)
-        smoke.render_over_terrain(terrain, dom, **view)
+    seq = smoke.SmokeSequence(dom, terrain, **view)  # the resident sequence bench.py times: solver phases, pack, march, composite per frame
+    for _ in seq.frames(16, settings, emitters):
+        pass
 elif what in ("strip", "strip_fused"):
     # rows of the heaviest strip of the balanced 8-strip partition (profiles/r04_strip_balance.log)
     b0, b1 = (int(x) for x in __import__("os").environ.get("F3D_STRIP_ROWS", "666,755").split(","))
