@@ -239,7 +239,7 @@ class StripRenderer:
             self._lap("before balancing")
             if self.distributed and hasattr(self.backend, "row_costs"):
                 self.bounds = self._balance_from_cost_map(dem, cam, kw)
-                self._lap("cost map + broadcast")
+                self._lap("cost map: cut")
             if self.distributed and balance_iters > 0 and hasattr(self.backend, "probe"):
                 self.bounds = self._balance(dem, cam, kw, balance_iters)
                 self._lap("measured balance rounds")
@@ -391,9 +391,12 @@ class StripRenderer:
                     density = np.ones(self.height)
             except Exception as exc:  # noqa: BLE001 -- agreed on below, before the broadcast
                 error = exc
+        self._lap("cost map: rank 0's probe frames")
         self._agree(error)
+        self._lap("cost map: agreement")
         box = self.torch.from_numpy(density).to(self._comm_device())
         dist.broadcast(box, src=0)
+        self._lap("cost map: broadcast")
         self.cost_density = box.cpu().numpy()
         # a floor under the measured cost: the fixed part of a row (ROW_COST_FLOOR)
         floor = ROW_COST_FLOOR * float(self.cost_density.mean())
