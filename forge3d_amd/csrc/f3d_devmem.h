@@ -55,6 +55,13 @@ inline hipError_t device_alloc(void **out, size_t bytes) {
         (void)hipFree(base);
         return e;
     }
+    // the fill runs on the null stream and need not have finished when hipMemset returns; a session on a NON-BLOCKING stream
+    // (torch's: the strip drivers') is not ordered behind it, and its first kernels raced the pattern -- whole strips of
+    // garbage in poison mode only (round 5: the 4096^2 peer-halo case of the device suite under F3D_POISON).  Debug mode: wait.
+    if ((e = hipDeviceSynchronize()) != hipSuccess) {
+        (void)hipFree(base);
+        return e;
+    }
     *out = (char *)base + kPoisonGuardBytes;
     poison_register(*out, base);
     return hipSuccess;
