@@ -37,7 +37,7 @@ struct SmokeParams {
     const float2 *rec_b;  // humidity, emission
     uint32_t nx, ny, nz;
     V3 origin, voxel, bmin, bmax;
-    const uint8_t *occupied;  // per 4 x 4 x 4 block of low corners: does a tap whose low corner lies in it touch any density != 0?
+    const uint8_t *occupied;  // per low corner (or block of low corners, kOccShift): does a tap there touch any density != 0?
     uint32_t ocx, ocy;        // blocks along x, y
     uint32_t frame_index, width, height, mode;  // mode 0 perspective, 1 projection
     V3 eye, forward, right, camera_up, sun, view;
@@ -50,11 +50,15 @@ struct SmokeParams {
 // density exactly 0 at all eight corners of the tap.  Such a step changes nothing -- the interpolated density is 0, the
 // reference's own `density > 1e-5` test skips it (render.rs:226-228), and a self-shadow step adds +0 to the optical depth
 // (render.rs:308-322) -- but it still cost eight 16-byte gathers from L2, which is what this kernel is bound by (VALU issue
-// 0.33, lane use 0.93: profiles/r04_config_rooflines.json).  k_smoke_pack therefore also marks, per 4 x 4 x 4 block of tap
-// LOW corners, whether any tap with its low corner there touches a voxel whose density is not +-0; a step whose block is
-// unmarked is taken without its loads.  Exact, not a threshold: only taps that are zero at every corner are skipped, so
-// images stay bit-identical to the oracle's (tests/test_smoke.py).
-constexpr uint32_t kOccShift = 2u;
+// 0.33, lane use 0.93: profiles/r04_config_rooflines.json).  k_smoke_pack therefore also marks, per tap LOW corner (a byte
+// a voxel: 786 KB for the 96 x 64 x 128 domain, L2-resident; -DF3D_SMOKE_OCC_SHIFT=2 is the first form, a byte per 4 x 4 x 4
+// block of low corners, which also skipped nothing in the 2-3 voxel shell around the plume), whether a tap with its low
+// corner there touches a voxel whose density is not +-0; a step whose mark is clear is taken without its loads.  Exact, not a
+// threshold: only taps that are zero at every corner are skipped, so images stay bit-identical to the oracle's (tests/test_smoke.py).
+#ifndef F3D_SMOKE_OCC_SHIFT
+#define F3D_SMOKE_OCC_SHIFT 0
+#endif
+constexpr uint32_t kOccShift = F3D_SMOKE_OCC_SHIFT;
 struct PackParams {
     const float *density, *temperature, *soot, *humidity, *emission, *age;
     float4 *rec_a;

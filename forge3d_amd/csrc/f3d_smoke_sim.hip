@@ -107,7 +107,7 @@ __global__ void k_sum_total(const SumArgs A) {
 //               writes the XCD's L2 back, an acquire invalidates it: the eight L2s are not coherent with each other) against
 //               ~3.5 us of work per phase; 1.49 ms a step.  Kept as a tested form (F3D_SMOKE_SOLVER=persistent).
 enum Phase : uint32_t { kPhEmitForces, kPhAdvectVec, kPhDiffuseVec, kPhCurl, kPhConfine, kPhDivergence, kPhJacobi, kPhGradientBoundary,
-                        kPhLaneShear, kPhAdvectScalars, kPhCorrectScalars, kPhScaleSubgrid, kPhDiffuseDecay };
+                        kPhLaneShear, kPhAdvectScalars, kPhCorrectScalars, kPhScaleSubgrid, kPhDiffuseDecay, kPhJacobiTwice };
 constexpr uint32_t kInlineEmitters = 4u;  // emitters that travel in the kernel arguments (a host-to-device copy of pageable memory waits for the stream)
 struct StepArgs {
     SimGrid G;
@@ -153,6 +153,8 @@ __device__ __forceinline__ void phase_voxel(const StepArgs &A, const SimGrid &G,
         F.pressure[v] = 0.0f;
     } else if (PH == kPhJacobi) {
         sim_jacobi(G, C.cur, A.div, C.next, x, y, z);
+    } else if (PH == kPhJacobiTwice) {
+        sim_jacobi_twice(G, C.cur, A.div, C.next, x, y, z);
     } else if (PH == kPhGradientBoundary) {
         sim_subtract_gradient(G, C.cur, F.velocity, x, y, z);
         if (C.cur != F.pressure) F.pressure[v] = C.cur[v];  // (an odd number of sweeps: the field goes home here)
@@ -633,6 +635,10 @@ extern "C" int f3d_smoke_step(f3d_smoke_state *st, const f3d_smoke_step_settings
                 const dim3 grid((unsigned)((s.n + kPhaseBlock - 1u) / kPhaseBlock)), block(kPhaseBlock);
                 const dim3 row_grid((s.G.ny * s.G.nz + 63u) / 64u);
                 PhaseCtx C{};
+                // MEASURED, NOT ADOPTED: two Jacobi sweeps a launch (sim_jacobi_twice: the intermediate field formed in registers, 32
+                // cached loads a voxel instead of 2 x 8) -- bit-identical, 15 launches fewer a step, and SLOWER: 0.411-0.416 ms
+                // against 0.386-0.397 (the doubled sweep costs more than the 5-us launch it saves).  F3D_SMOKE_DOUBLE_SWEEPS=1 runs it.
+                const bool single_sweeps = getenv("F3D_SMOKE_DOUBLE_SWEEPS") == nullptr;
                 auto sums = [&](const float *density, const SumKinds &kinds) {
                     hipLaunchKernelGGL(k_phase_sum_rows, row_grid, dim3(64), 0, nullptr, K, kinds, density);
                     hipLaunchKernelGGL(k_phase_sum_finish, dim3(1), dim3(256), 0, nullptr, K, kinds);
@@ -641,7 +647,12 @@ extern "C" int f3d_smoke_step(f3d_smoke_state *st, const f3d_smoke_step_settings
                     hipLaunchKernelGGL(k_phase<kPhDivergence>, grid, block, 0, nullptr, K, C);
                     C.cur = K.F.pressure;
                     C.next = K.pres_b;
-                    for (uint32_t it = 0; it < iterations; it++) {
+                    uint32_t it = 0;
+                    for (; it + 2u <= iterations && !single_sweeps; it += 2u) {  // two sweeps a launch (sim_jacobi_twice)
+                        hipLaunchKernelGGL(k_phase<kPhJacobiTwice>, grid, block, 0, nullptr, K, C);
+                        std::swap(C.cur, C.next);
+                    }
+                    for (; it < iterations; it++) {
                         hipLaunchKernelGGL(k_phase<kPhJacobi>, grid, block, 0, nullptr, K, C);
                         std::swap(C.cur, C.next);
                     }
