@@ -172,6 +172,7 @@ inline PreparedScene prepare_scene(const f3d_wf_scene &s, uint32_t width, uint32
     S.medium_on = s.medium.enabled > 0.5f ? 1u : 0u;  // pt_shade.wgsl:500-502
     S.medium_mu = f_max(s.medium.sigma_t * s.medium.density, 0.0f);
     S.has_terrain = 0u;
+    S.primary_start = s.terrain ? reinterpret_cast<const uint2 *>(s.primary_start) : nullptr;  // (a device pointer: f3d_wavefront.h)
     if (s.terrain) {  // placement and scalars as fill_uniforms (f3d_setup.h); tables are the caller's to attach
         const f3d_wf_terrain &t = *s.terrain;
         S.has_terrain = 1u;

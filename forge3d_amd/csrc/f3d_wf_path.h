@@ -97,6 +97,7 @@ struct SceneDev {
     // optional heightfield primitive (see the header): tables as the terrain tracer builds them, material slot of its hits
     TerrainDev terrain;
     uint32_t has_terrain, terrain_mat;
+    const uint2 *primary_start;  // per pixel {t_clear bits, level}: the terrain tracer's primary-ray certificates (f3d_cone.h); nullptr: none
     // hair strands (closest hits only) and the homogeneous fog (pt_shade.wgsl:328-338, :500-520)
     const HairDev *hair;
     uint32_t hair_count;
@@ -335,8 +336,10 @@ F3D_HD bool hair_segment(V3 o, V3 d, float tmin, float tmax, V3 p0, V3 p1, float
 }
 
 // pt_intersect.wgsl main, :431-558 (+ the terrain primitive)
+// camera_pixel: the pixel whose CAMERA ray this is (its march may start where the pixel's certificate ends); kNoPixel: any other ray
+constexpr uint32_t kNoPixel = 0xFFFFFFFFu;
 template <class Wave>
-F3D_HD bool closest(const SceneDev &S, V3 o, V3 d, float tmin, SurfaceHitWf &H, Wave &wave) {
+F3D_HD bool closest(const SceneDev &S, V3 o, V3 d, float tmin, SurfaceHitWf &H, Wave &wave, uint32_t camera_pixel = kNoPixel) {
     const float tmax = 1e30f;
     float t_best = 1e30f;
     V3 n = V3{0.0f, 1.0f, 0.0f};
@@ -400,7 +403,15 @@ F3D_HD bool closest(const SceneDev &S, V3 o, V3 d, float tmin, SurfaceHitWf &H, 
     }
     if (Wave::kTerrain && S.has_terrain != 0u) {  // terrain_trace(ray with tmax = the closest hit so far), curvature off
         const RayCtx r = make_ray(S.terrain, o, tmin, d, t_best, false);
-        const TraceHit th = march_terrain<false>(S.terrain, r, false, true, *wave.pend);
+        // A camera ray of a pixel with a certificate (round 5: the terrain tracer's, for the same camera -- f3d_cone.h
+        // primary_start) starts where the certificate ends: every node before that is one the march would step over without
+        // solving a leaf, so the hit is the same; 27 -> 14.5 steps per camera ray on the headline frame.
+        MarchState m = march_begin(S.terrain, r, true);
+        if (camera_pixel != kNoPixel && S.primary_start != nullptr) {
+            const uint2 st = S.primary_start[camera_pixel];
+            if (f_from_bits(st.x) > 0.0f) m = march_begin_at(S.terrain, r, f_from_bits(st.x), st.y);
+        }
+        const TraceHit th = march_terrain_from<false, true>(S.terrain, r, false, m, *wave.pend);
         if (th.hit && th.t < t_best) {
             t_best = th.t;
             n = th.n;
@@ -897,7 +908,7 @@ F3D_HD uint32_t trace_frames(const SceneDev &S, uint32_t pixel, uint32_t first, 
                     fresh = false;
                 }
                 vertices++;
-                if (closest(S, P.o, P.d, P.tmin, H, wave)) {
+                if (closest(S, P.o, P.d, P.tmin, H, wave, P.depth == 0u ? pixel : kNoPixel)) {
                     pending = true;
                     if (Rows::kHit) {  // the hit waits for the expensive phase in the park rows, not in registers
                         park3(wave, Rows::kHitP, H.p);

@@ -116,13 +116,20 @@ def render_terrain_gi(heightmap, width: int, height: int, camera=None, *, spacin
         object_importance=[1.0] * len(spheres), env_ground=tuple(ambient_color), env_sky=tuple(ambient_color), miss_ground=tuple(sky_color),
         miss_sky=tuple(sky_color), cam_origin=tuple(origin), cam_look_at=tuple(look_at), cam_up=tuple(up), fov_y_deg=fov, exposure=exposure,
         seed_hi=(0x9E3779B9 ^ int(seed)) & 0xFFFFFFFF, seed_lo=0x85EBCA6B)
-    gi = render_scene(scene, int(width), int(height), int(spp))
-    # the terrain tracer's session for the same camera: depth / hit mask / AOVs of the centre rays, its resolve and post
+    # the terrain tracer's session for the same camera: depth / hit mask / AOVs of the centre rays, its resolve and post -- and
+    # (round 5) its primary-ray certificates, which the PBR tracer's camera rays start from (same camera, same jitter range:
+    # f3d_cone.h; F3D_GI_NO_PRIMARY_START=1 switches the hand-over off -- same image)
+    import os
+
     kw = dict(spacing=tuple(spacing), exaggeration=float(exaggeration), albedo=tuple(albedo), sun_azimuth_deg=float(sun_azimuth_deg),
               sun_elevation_deg=float(sun_elevation_deg), sun_intensity=float(sun_intensity), sun_color=tuple(sun_color), spp=1,
               max_frames=2, min_frames=2, variance_threshold=1e30, seed=int(seed), atmosphere=atmosphere)
     with TerrainSession(dem, int(width), int(height), {"origin": origin, "look_at": look_at, "up": up, "fov_y": fov, "exposure": exposure},
                         memory_budget_bytes=int(memory_budget_bytes), **kw) as s:
+        scene_dict = scene.as_dict()
+        if not os.environ.get("F3D_GI_NO_PRIMARY_START"):
+            scene_dict["primary_start"] = s.primary_start_ptr()
+        gi = render_scene(scene_dict, int(width), int(height), int(spp))
         s.enqueue_frames(0, 2)  # (reservoirs for the resolve's validity pass; their radiance is replaced below)
         s.set_accumulation(gi["accum"])
         out = s.resolve(int(spp))

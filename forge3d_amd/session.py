@@ -251,6 +251,11 @@ class TerrainSession:
         self._check(self._lib.f3d_session_row_costs(self._handle, out.ctypes.data_as(C.POINTER(C.c_float)), self.rows, self._err, len(self._err)))
         return out
 
+    def primary_start_ptr(self) -> int:
+        """Device pointer to the session's primary-ray certificates (rows x width records, f3d_cone.h), 0 if it has none; valid
+        while the session lives.  The PBR path tracer takes it (WavefrontScene / f3d_wf_scene.primary_start)."""
+        return int(self._lib.f3d_session_primary_start(self._handle) or 0)
+
     def kernel_timing(self, enable: bool):
         """enable=True starts recording a hipEvent pair around every frame launch;
         enable=False stops and returns (average ms per launch, launches)."""

@@ -288,7 +288,8 @@ class _Scene(C.Structure):
                 ("env_ground", C.c_float * 4), ("env_sky", C.c_float * 4), ("miss_ground", C.c_float * 4), ("miss_sky", C.c_float * 4),
                 ("cam_origin", C.c_float * 3), ("cam_right", C.c_float * 3), ("cam_up", C.c_float * 3), ("cam_forward", C.c_float * 3),
                 ("cam_fov_y", C.c_float), ("cam_exposure", C.c_float), ("seed_hi", C.c_uint32), ("seed_lo", C.c_uint32),
-                ("terrain", C.POINTER(_Terrain)), ("hair", C.POINTER(_Hair)), ("hair_count", C.c_uint32), ("medium", _Medium)]
+                ("terrain", C.POINTER(_Terrain)), ("hair", C.POINTER(_Hair)), ("hair_count", C.c_uint32), ("medium", _Medium),
+                ("primary_start", C.c_void_p)]
 
 
 class _Out(C.Structure):
@@ -358,6 +359,7 @@ def _marshal(scene: Dict[str, Any]):
     if scene.get("medium") is not None:
         m = scene["medium"]
         s.medium = _Medium(float(m["g"]), float(m["sigma_t"]), float(m["density"]), float(m["enabled"]))
+    s.primary_start = C.c_void_p(int(scene.get("primary_start") or 0) or None)  # device pointer (TerrainSession.primary_start_ptr)
     return s, keep
 
 

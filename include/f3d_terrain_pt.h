@@ -313,6 +313,10 @@ uint32_t f3d_session_sample_lanes(f3d_session *session);
 /* (ABI 5) Cost of the session's last fused frame by image row (out[rows], rows = the session's; 100 MHz ticks of wave time,
  * a tile's duration spread over its rows): what the strip driver balances row strips on.  Synchronises the stream. */
 int f3d_session_row_costs(f3d_session *session, float *out, uint32_t rows, char *err, size_t errlen);
+/* (ABI 5) The session's primary-ray certificates (f3d_cone.h): a DEVICE pointer to rows x width records {f32 bits of t_clear,
+ * u32 level}, written by the G-buffer pass the session's creation enqueued on its stream; NULL when the camera's pixels are too
+ * wide for certificates.  Valid while the session lives.  The PBR path tracer takes it as f3d_wf_scene.primary_start. */
+const void *f3d_session_primary_start(f3d_session *session);
 /* Device memory the library has freed is kept for its next allocation of the same size (F3D_DEVICE_POOL_MB, default
  * 1024, 0 = off): a camera path or a smoke sequence allocates the same buffers frame after frame.  This hands everything
  * that is waiting back to the driver -- call it before another allocator (torch, RCCL) sizes large buffers on the device:

@@ -95,6 +95,11 @@ typedef struct f3d_wf_scene {
     const f3d_wf_hair_segment *hair; /* hair strands as cylinder segments (Kajiya-Kay continuation, pt_shade.wgsl:708-729); they */
     uint32_t hair_count;             /* are visible to closest-hit rays only: the reference's shadow stage does not test them */
     f3d_wf_medium medium;            /* all zero: no fog */
+    /* (ABI 5) optional DEVICE pointer, width x height records {f32 bits of t_clear, u32 level}: the terrain tracer's
+     * primary-ray certificates for the SAME camera, image size and heightfield (f3d_session_primary_start of a full-frame
+     * session; f3d_cone.h): every camera ray of a pixel is above every cell it passes before t_clear, so its march may
+     * start there.  The paths are the same with and without it (tests/test_offline_gi.py); NULL: none. */
+    const void *primary_start;
 } f3d_wf_scene;
 
 typedef struct f3d_wf_out {

@@ -88,6 +88,21 @@ def test_render_terrain_gi_equals_the_composition_of_the_oracles(turbidity, size
         assert np.array_equal(got[key], want[key], equal_nan=True), key
     assert got["frames"] == spp and got["path_vertices"] > w * h * spp
 
+@pytest.mark.gpu
+def test_camera_rays_starting_at_the_terrain_certificates_change_nothing(monkeypatch):
+    """`render_terrain_gi` hands the terrain tracer's primary-ray certificates (`f3d_session_primary_start`) to the PBR
+    tracer, whose camera rays then begin their march where the certificate proved free space ends.  With the hand-over
+    switched off the march starts at the box entry: both must produce the same hits, so the same bytes."""
+    from forge3d_amd import offline
+
+    dem, cam, geo, handle = _case(2.0)
+    on = offline.render_terrain_gi(dem, 200, 120, cam, spp=5, atmosphere=handle, **geo)
+    monkeypatch.setenv("F3D_GI_NO_PRIMARY_START", "1")
+    off = offline.render_terrain_gi(dem, 200, 120, cam, spp=5, atmosphere=handle, **geo)
+    for key in ("hdr", "rgba", "albedo", "normal", "depth"):
+        assert np.array_equal(on[key], off[key], equal_nan=True), key
+    assert on["path_vertices"] == off["path_vertices"]
+
 
 @pytest.mark.gpu
 def test_config3_gi_at_full_size_equals_the_composition_of_the_oracles():
