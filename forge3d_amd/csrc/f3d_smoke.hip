@@ -39,6 +39,8 @@ struct SmokeParams {
     V3 origin, voxel, bmin, bmax;
     const uint8_t *occupied;  // per low corner (or block of low corners, kOccShift): does a tap there touch any density != 0?
     uint32_t ocx, ocy;        // blocks along x, y
+    const uint32_t *bounds;   // of the marked entries of `occupied`: lowest x, y, z, then ~highest x, y, z (k_smoke_bounds)
+    uint32_t clip;            // 0: the box is not used (a voxel size that is not a positive finite number)
     uint32_t frame_index, width, height, mode;  // mode 0 perspective, 1 projection
     V3 eye, forward, right, camera_up, sun, view;
     float tan_half_fov, aspect, diagonal, step, shadow_step;
@@ -82,6 +84,37 @@ __global__ void k_smoke_pack(const PackParams P) {
         for (uint32_t bz = bz0; bz <= bz1; bz++)
             for (uint32_t by = by0; by <= by1; by++)
                 for (uint32_t bx = bx0; bx <= bx1; bx++) P.occupied[(bz * P.ocy + by) * P.ocx + bx] = 1u;  // (every writer stores the same byte)
+    }
+}
+
+// The box of the marked entries of the empty-space map, for smoke_box(): a workgroup per z slice of the map, the six bounds
+// folded into `bounds` (all 0xFF before the launch) with atomicMin -- the upper ones as their complements.
+__global__ __launch_bounds__(256) void k_smoke_bounds(const uint8_t *occupied, uint32_t ocx, uint32_t ocy, uint32_t *bounds) {
+    const uint32_t z = blockIdx.x, per_slice = ocx * ocy;
+    uint32_t lx = 0xFFFFFFFFu, ly = 0xFFFFFFFFu, hx = 0u, hy = 0u;
+    for (uint32_t i = threadIdx.x; i < per_slice; i += 256u)
+        if (occupied[(size_t)z * per_slice + i] != 0u) {
+            const uint32_t x = i % ocx, y = i / ocx;
+            lx = x < lx ? x : lx;
+            ly = y < ly ? y : ly;
+            hx = x > hx ? x : hx;
+            hy = y > hy ? y : hy;
+        }
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t a = (uint32_t)__shfl_xor((int)lx, o, 64), b = (uint32_t)__shfl_xor((int)ly, o, 64);
+        const uint32_t c = (uint32_t)__shfl_xor((int)hx, o, 64), d = (uint32_t)__shfl_xor((int)hy, o, 64);
+        lx = a < lx ? a : lx;
+        ly = b < ly ? b : ly;
+        hx = c > hx ? c : hx;
+        hy = d > hy ? d : hy;
+    }
+    if ((threadIdx.x & 63u) == 0u && lx != 0xFFFFFFFFu) {
+        atomicMin(&bounds[0], lx);
+        atomicMin(&bounds[1], ly);
+        atomicMin(&bounds[2], z);
+        atomicMin(&bounds[3], ~hx);
+        atomicMin(&bounds[4], ~hy);
+        atomicMin(&bounds[5], ~z);
     }
 }
 
@@ -141,13 +174,84 @@ __device__ __forceinline__ bool ray_box(V3 o, V3 d, V3 mn, V3 mx, float &near_t,
     return far_t >= f_max(near_t, 0.0f);
 }
 
+// The smoke's bounding box (round 5).  Most of the steps the empty-space map answers are nowhere near the plume: a camera ray
+// crosses the whole domain, the plume fills a part of it, and even a skipped step costs the tap's three IEEE divisions, its
+// clamps and the map's byte -- 60 vector instructions, on ~150 steps of each of two million rays: the larger part of the
+// 336 M vector instructions of a launch (profiles/r05_C5_rocprofv3_summary.txt).  k_smoke_bounds reduces the map to the
+// box of its marked low corners; a ray (and a self-shadow march) is clipped against that box, widened by a voxel and by a
+// bound on what float rounding can move a position or a slab parameter, and the steps outside the clipped interval are
+// taken without looking anything up: they are steps the map would have answered "empty" -- same image, bit for bit.
+struct SmokeBox {
+    V3 lo, hi;     // world space; -inf / +inf where the box touches a clamped end of the grid (or is not used)
+    V3 inv_sun;    // 1 / P.sun, to a few ulp (the margins below are thousands of ulp)
+    uint32_t any;  // 0: no voxel holds smoke
+};
+__device__ __forceinline__ V3 inv3(V3 d) { return V3{__frcp_rn(d.x), __frcp_rn(d.y), __frcp_rn(d.z)}; }
+__device__ __forceinline__ SmokeBox smoke_box(const SmokeParams &P) {
+    SmokeBox b;
+    const uint32_t l[3] = {P.bounds[0], P.bounds[1], P.bounds[2]}, h[3] = {~P.bounds[3], ~P.bounds[4], ~P.bounds[5]};
+    const uint32_t n[3] = {P.nx, P.ny, P.nz};
+    const float o[3] = {P.origin.x, P.origin.y, P.origin.z}, v[3] = {P.voxel.x, P.voxel.y, P.voxel.z};
+    float lo[3], hi[3];
+    b.any = l[0] != 0xFFFFFFFFu ? 1u : 0u;
+    for (int a = 0; a < 3; a++) {
+        // low corners c0 .. c1 (map blocks -> corners); a tap has low corner c for positions in [c + 0.5, c + 1.5) voxels from
+        // the origin, the first and the last corner also for everything the clamp folds onto them
+        const uint32_t c0 = l[a] << kOccShift, c1 = ((h[a] + 1u) << kOccShift) - 1u;
+        lo[a] = (c0 == 0u || P.clip == 0u) ? -__builtin_inff() : o[a] + ((float)c0 - 0.5f) * v[a];
+        hi[a] = (c1 + 1u >= n[a] || P.clip == 0u) ? __builtin_inff() : o[a] + ((float)c1 + 2.5f) * v[a];
+    }
+    b.lo = V3{lo[0], lo[1], lo[2]};
+    b.hi = V3{hi[0], hi[1], hi[2]};
+    b.inv_sun = inv3(P.sun);
+    return b;
+}
+// [ta, tb]: outside it no point o + d t (as the march evaluates it in float) has a tap with a marked low corner.  Any NaN
+// leaves a bound that no comparison trips.
+__device__ __forceinline__ void smoke_clip(const SmokeBox &b, V3 o, V3 d, V3 inv_d, float t_max, float &ta, float &tb) {
+    const float err = 1.0e-5f * ((f_abs(o.x) + f_abs(o.y) + f_abs(o.z)) + f_abs(t_max) * (f_abs(d.x) + f_abs(d.y) + f_abs(d.z)));
+    const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, ii[3] = {inv_d.x, inv_d.y, inv_d.z};
+    const float lo[3] = {b.lo.x, b.lo.y, b.lo.z}, hi[3] = {b.hi.x, b.hi.y, b.hi.z};
+    ta = -__builtin_inff();
+    tb = __builtin_inff();
+    for (int a = 0; a < 3; a++) {
+        const float l = lo[a] - err, h = hi[a] + err;
+        if (f_abs(dd[a]) > 1.0e-12f) {
+            const float p = (l - oo[a]) * ii[a], q = (h - oo[a]) * ii[a];
+            ta = f_max(ta, f_min(p, q));
+            tb = f_min(tb, f_max(p, q));
+        } else if (oo[a] < l || oo[a] > h) {
+            ta = __builtin_inff();
+            tb = -__builtin_inff();
+        }
+    }
+    ta -= 1.0e-5f * f_abs(ta);
+    tb += 1.0e-5f * f_abs(tb);
+    if (b.any == 0u) {
+        ta = __builtin_inff();
+        tb = -__builtin_inff();
+    }
+}
+
 // sun_transmittance, render.rs:290-330
-__device__ float sun_transmittance(const SmokeParams &P, V3 start) {
+__device__ float sun_transmittance(const SmokeParams &P, const SmokeBox &box, V3 start) {
     float t0, t1;
     if (!ray_box(vadd(start, vscale(P.sun, P.shadow_step)), P.sun, P.bmin, P.bmax, t0, t1)) return 1.0f;
     t0 = f_max(t0, 0.0f);
     float od = 0.0f;
-    for (uint32_t i = 0u; i < P.st.shadow_steps; i++) {
+    uint32_t i = 0u, i_end = P.st.shadow_steps;
+#if !defined(F3D_SMOKE_NO_SKIP) && !defined(F3D_SMOKE_NO_CLIP)
+    {   // steps whose position start + sun (shadow_step + tt) is outside the smoke's box add +-0: the loop starts and ends at the box
+        float ua, ub;
+        smoke_clip(box, start, P.sun, box.inv_sun, P.shadow_step * (float)(P.st.shadow_steps + 2u) + t0, ua, ub);
+        const float base = P.shadow_step + t0;  // position parameter of step i: base + (i + 0.5) shadow_step
+        const float per = __frcp_rn(P.shadow_step);
+        const float first = f_floor((ua - base) * per - 0.5f) - 2.0f, last = __builtin_ceilf((ub - base) * per - 0.5f) + 2.0f;
+        i = (uint32_t)f_min(f_max(first, 0.0f), (float)i_end);
+        i_end = (uint32_t)f_min(f_max(last, 0.0f), (float)i_end);
+    }
+#endif
+    for (; i < i_end; i++) {
         const float tt = t0 + ((float)i + 0.5f) * P.shadow_step;
         if (tt > t1) break;
         const Tap t = make_tap(P, vadd(start, vscale(P.sun, P.shadow_step + tt)));
@@ -204,8 +308,65 @@ __device__ __forceinline__ uchar4 smoke_pixel(const SmokeParams &P, V3 rgb, floa
     return uchar4{to_u8(e.x / (1.0f + e.x)), to_u8(e.y / (1.0f + e.y)), to_u8(e.z / (1.0f + e.z)), to_u8(alpha)};
 }
 
+// ---- the self-shadow marches taken out of the rays' loops (round 5) ---------------------------------------------------------
+// Per wave clocks of the one-kernel form on the configs[4] frame (tools/experiments/smoke_tile_clock.py): the launch takes
+// 1.21 ms and ONE wave of it runs for 1.17 ms -- the 8 x 8 tile through the thickest part of the plume, ~100 steps in smoke,
+// each with a self-shadow march of 20 steps, every step ~200 vector instructions issued by a wave that is alone on its SIMD
+// once the light tiles have drained -- while the waves of the whole launch add up to 0.76 ms per SIMD at one wave a SIMD.
+// The launch is as long as its longest ray.  But the reference's loop only needs the self-shadow march's result for the
+// radiance it adds (render.rs:237-283): the ray's own course -- which steps meet smoke, the transmittance, where it ends --
+// does not depend on it.  So the marches are independent of each other and of their rays, and the frame is taken in three
+// launches:
+//   k_smoke_rays<kCollect>  a lane per pixel walks its ray without the self-shadow marches and without the radiance, and
+//                   writes every step that meets smoke -- its position, the six interpolated fields, its extinction and its
+//                   transmittance -- to a slot of a chunked list: the lane's k-th such step of tile T goes to chunk
+//                   chunk_of[T][k / 16], row k % 16, column = lane (chunks handed out from a cursor as the tile's wave needs
+//                   them; the 64 lanes of a row are the tile's pixels at the same ordinal: neighbouring voxels, as in the
+//                   one-kernel form);
+//   k_smoke_light   a lane per slot, 64 slots a wave, waves striding over the chunks handed out: the self-shadow march from
+//                   that position (sun_transmittance, unchanged) -- 20 steps deep instead of 100 x 20, and as many waves as
+//                   the chip can hold;
+//   k_smoke_shade   a lane per pixel adds up the radiance of its listed steps in their order (smoke_source, unchanged): no
+//                   ray to walk any more, and loads whose addresses do not depend on what was loaded before.
+// Each value is computed by the same instructions from the same operands as in the one-kernel form, so the image is the
+// oracle's bit for bit (tests/test_smoke.py runs all forms).  When the list's space runs out, the tile is flagged and
+// k_smoke_shade walks its rays in the one-kernel form.
+enum : uint32_t { kWhole = 0u, kCollect = 1u };
+constexpr uint32_t kChunkRows = 16u, kChunkSlots = kChunkRows * 64u, kNoChunk = 0xFFFFFFFFu, kUnset = 0xFFFFFFFEu;
+struct Deferred {
+    float4 *where;       // per slot: the step's position, and its extinction sigma_t
+    float4 *fields;      // per slot: density, soot, age, temperature as interpolated there
+    float4 *more;        // per slot: humidity, emission, the step's transmittance, -
+    float *light;        // per slot: the self-shadow march's result (k_smoke_light)
+    uint32_t *spilled;   // [tile]: != 0 when the list had no room for all of the tile's steps
+    uint32_t *chunk_of;  // [tile][chunks_per_tile]
+    uint2 *owner;        // [chunk]: (tile, which 16 ordinals of it)
+    uint32_t *count;     // [pixel]: steps of the pixel's ray that met smoke
+    uint32_t *cursor;    // chunks handed out
+    uint32_t chunks_per_tile, capacity;  // capacity in chunks
+};
+
+// The slot of the lane's k-th smoke step, reserving the chunk if the tile has none for it yet (kNoChunk: no room left).
+__device__ __forceinline__ uint32_t deferred_slot(const Deferred &D, volatile uint32_t *wave_chunks, uint32_t tile, uint32_t k) {
+    const uint32_t c = k / kChunkRows, lane = threadIdx.x & 63u;
+    uint32_t id = wave_chunks[c];
+    while (id == kUnset) {  // one pass per chunk that lanes of the wave wait for
+        if (lane == (uint32_t)__builtin_ctzll(__ballot(1))) {
+            uint32_t fresh = atomicAdd(D.cursor, 1u);
+            if (fresh >= D.capacity) fresh = kNoChunk;
+            else D.owner[fresh] = uint2{tile, c};
+            D.chunk_of[(size_t)tile * D.chunks_per_tile + c] = fresh;
+            wave_chunks[c] = fresh;
+        }
+        id = wave_chunks[c];
+    }
+    return id == kNoChunk ? kNoChunk : id * kChunkSlots + (k % kChunkRows) * 64u + lane;
+}
+
 // march_ray_rgba, render.rs:192-288
-__device__ uchar4 march_ray(const SmokeParams &P, V3 origin, V3 dir, float t0, float t1, uint32_t seed) {
+template <uint32_t MODE>
+__device__ uchar4 march_ray(const SmokeParams &P, const SmokeBox &box, V3 origin, V3 dir, float t0, float t1, uint32_t seed,
+                            const Deferred &D, volatile uint32_t *wave_chunks, uint32_t tile, uint32_t &smoke_steps) {
     uint32_t v = seed;  // hash01, sampling.rs:96-103
     v ^= v >> 16;
     v *= 0x7FEB352Du;
@@ -219,7 +380,16 @@ __device__ uchar4 march_ray(const SmokeParams &P, V3 origin, V3 dir, float t0, f
     const float g2 = P.st.phase_g * P.st.phase_g;  // henyey_greenstein, render.rs:394-398 (powf(d, 1.5) = d sqrt(d))
     const float denom = f_max(1.0f + g2 - 2.0f * P.st.phase_g * cos_theta, 1.0e-4f);
     const float phase = (1.0f - g2) / (4.0f * kPi * (denom * f_sqrt(denom)));
-    for (uint32_t steps = 0u; t < t1 && steps < P.st.max_steps && transmittance > 0.01f; steps++, t += P.step) {
+    uint32_t steps = 0u, k = 0u;
+#if !defined(F3D_SMOKE_NO_SKIP) && !defined(F3D_SMOKE_NO_CLIP)
+    float ta, tb;
+    smoke_clip(box, origin, dir, inv3(dir), t1, ta, tb);
+    for (; t < t1 && steps < P.st.max_steps && t < ta; steps++, t += P.step) {}  // in front of the smoke's box: the reference's loop, nothing to look up
+#endif
+    for (; t < t1 && steps < P.st.max_steps && transmittance > 0.01f; steps++, t += P.step) {
+#if !defined(F3D_SMOKE_NO_SKIP) && !defined(F3D_SMOKE_NO_CLIP)
+        if (t > tb) break;  // behind it (P.step > 0): every step still to come would be skipped
+#endif
         const V3 p = vadd(origin, vscale(dir, t));
         const Tap tp = make_tap(P, p);
 #if !defined(F3D_SMOKE_NO_SKIP)
@@ -233,17 +403,30 @@ __device__ uchar4 march_ray(const SmokeParams &P, V3 origin, V3 dir, float t0, f
         const float gate = 0.50f + 0.50f * smoothstep_ref(0.045f, 0.34f, s_density);
         const float density = f_max(s_density * P.st.density_scale * (1.0f - 0.58f * age_t) * gate, 0.0f);
         if (!(density > 1.0e-5f)) continue;
+        const float sigma_t = density * P.st.extinction * (1.0f + s_soot * P.st.soot_absorption * 0.85f);
+        const float seg_tr = f_clamp(exp_det(-sigma_t * P.step), 0.0f, 1.0f);
 #define t t_
         const float s_temperature = F3D_TRI(P.rec_a, w), s_humidity = F3D_TRI(P.rec_b, x), s_emission = F3D_TRI(P.rec_b, y);
 #undef t
-        const float sigma_t = density * P.st.extinction * (1.0f + s_soot * P.st.soot_absorption * 0.85f);
-        const float seg_tr = f_clamp(exp_det(-sigma_t * P.step), 0.0f, 1.0f);
-        const float seg_w = sigma_t > 1.0e-6f ? (1.0f - seg_tr) / sigma_t : P.step;
-        const float light = P.st.self_shadow ? sun_transmittance(P, p) : 1.0f;
-        const V3 source = smoke_source(P, p, s_density, s_soot, s_age, s_temperature, s_humidity, s_emission, sigma_t, light, phase);
-        rgb = vadd(rgb, vscale(vscale(source, seg_w), transmittance));
+        if (MODE == kCollect) {
+            const uint32_t slot = deferred_slot(D, wave_chunks, tile, k);
+            if (slot != kNoChunk) {
+                D.where[slot] = float4{p.x, p.y, p.z, sigma_t};
+                D.fields[slot] = float4{s_density, s_soot, s_age, s_temperature};
+                D.more[slot] = float4{s_humidity, s_emission, seg_tr, 0.0f};
+            } else {
+                wave_chunks[D.chunks_per_tile] = 1u;  // the tile's "spilled" flag
+            }
+        } else {
+            const float seg_w = sigma_t > 1.0e-6f ? (1.0f - seg_tr) / sigma_t : P.step;
+            const float light = P.st.self_shadow ? sun_transmittance(P, box, p) : 1.0f;
+            const V3 source = smoke_source(P, p, s_density, s_soot, s_age, s_temperature, s_humidity, s_emission, sigma_t, light, phase);
+            rgb = vadd(rgb, vscale(vscale(source, seg_w), transmittance));
+        }
+        k++;
         transmittance *= seg_tr;
     }
+    smoke_steps = k;
     return smoke_pixel(P, rgb, transmittance);
 }
 
@@ -265,18 +448,110 @@ __device__ __forceinline__ void pixel_ray(const SmokeParams &P, uint32_t x, uint
     }
 }
 
-// One lane per pixel, the whole ray: the form that runs (see the measurement under "sift + cooperative march" below).
-__global__ __launch_bounds__(64) void k_smoke(const SmokeParams P) {
+// One lane per pixel, 8 x 8 pixels a wave.  MODE kWhole: the whole ray with its self-shadow marches (the form of rounds 3-4: runs
+// when a render has no self-shadowing, and as F3D_SMOKE_MARCH=single); kCollect: see "taken out of the rays' loops".
+__device__ __forceinline__ bool tile_pixel(const SmokeParams &P, uint32_t tile, uint32_t lane, uint32_t &x, uint32_t &y) {
     const uint32_t tiles_x = (P.width + 7u) / 8u;
-    const uint32_t x = (blockIdx.x % tiles_x) * 8u + (threadIdx.x & 7u), y = (blockIdx.x / tiles_x) * 8u + (threadIdx.x >> 3);
-    if (x >= P.width || y >= P.height) return;
+    x = (tile % tiles_x) * 8u + (lane & 7u);
+    y = (tile / tiles_x) * 8u + (lane >> 3);
+    return x < P.width && y < P.height;
+}
+template <uint32_t MODE>
+__device__ __forceinline__ void walk_pixel(const SmokeParams &P, const Deferred &D, volatile uint32_t *wave_chunks, uint32_t x, uint32_t y) {
     V3 origin, dir;
     uint32_t seed;
     pixel_ray(P, x, y, origin, dir, seed);
     uchar4 px4 = uchar4{0, 0, 0, 0};
     float t0, t1;
-    if (ray_box(origin, dir, P.bmin, P.bmax, t0, t1)) px4 = march_ray(P, origin, dir, f_max(t0, 0.0f), t1, seed);
-    reinterpret_cast<uchar4 *>(P.out)[(size_t)y * P.width + x] = px4;
+    const SmokeBox box = smoke_box(P);
+#if defined(F3D_SMOKE_TILE_CLOCK)  // diagnostic build (tools/experiments/smoke_tile_clock.py): when each wave ran, in the first pixels of its tile
+    const uint64_t clock0 = wall_clock64();
+#endif
+    uint32_t smoke_steps = 0u;
+    if (ray_box(origin, dir, P.bmin, P.bmax, t0, t1))
+        px4 = march_ray<MODE>(P, box, origin, dir, f_max(t0, 0.0f), t1, seed, D, wave_chunks, blockIdx.x, smoke_steps);
+    if (MODE == kCollect) D.count[(size_t)y * P.width + x] = smoke_steps;
+    else reinterpret_cast<uchar4 *>(P.out)[(size_t)y * P.width + x] = px4;
+#if defined(F3D_SMOKE_TILE_CLOCK)
+    const uint64_t clock1 = wall_clock64();  // 100 MHz
+    uint32_t *words = reinterpret_cast<uint32_t *>(P.out);
+    if (MODE != kCollect && threadIdx.x == 0u) words[(size_t)y * P.width + x] = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)clock0);
+    if (MODE != kCollect && threadIdx.x == 1u) words[(size_t)y * P.width + x] = (uint32_t)(clock1 - clock0);
+#endif
+}
+template <uint32_t MODE>
+__global__ __launch_bounds__(64) void k_smoke_rays(const SmokeParams P, const Deferred D) {
+    extern __shared__ uint32_t wave_chunks_lds[];
+    volatile uint32_t *wave_chunks = wave_chunks_lds;
+    if (MODE == kCollect) {
+        for (uint32_t i = threadIdx.x; i < D.chunks_per_tile; i += 64u) wave_chunks[i] = kUnset;
+        if (threadIdx.x == 0u) wave_chunks[D.chunks_per_tile] = 0u;
+    }
+    uint32_t x, y;
+    if (tile_pixel(P, blockIdx.x, threadIdx.x, x, y)) walk_pixel<MODE>(P, D, wave_chunks, x, y);
+    if (MODE == kCollect && threadIdx.x == 0u) D.spilled[blockIdx.x] = wave_chunks[D.chunks_per_tile];
+}
+
+// The self-shadow marches of the listed steps: a lane per slot, a wave per row of a chunk, the waves of the launch striding
+// over the rows of the chunks that k_smoke_rays<kCollect> handed out (their number is on the device: no host round trip).
+__global__ __launch_bounds__(64) void k_smoke_light(const SmokeParams P, const Deferred D) {
+    const uint32_t rows = min(*D.cursor, D.capacity) * kChunkRows, lane = threadIdx.x & 63u;
+    const SmokeBox box = smoke_box(P);
+    for (uint32_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const uint2 own = D.owner[row / kChunkRows];
+        uint32_t x, y;
+        if (!tile_pixel(P, own.x, lane, x, y)) continue;
+        if (own.y * kChunkRows + row % kChunkRows >= D.count[(size_t)y * P.width + x]) continue;  // the pixel's ray has fewer smoke steps
+        const uint32_t slot = row * 64u + lane;
+        const float4 p = D.where[slot];
+        D.light[slot] = sun_transmittance(P, box, V3{p.x, p.y, p.z});
+    }
+}
+
+// The radiance of a pixel's listed steps, in their order (march_ray's accumulation, render.rs:237-288).
+__global__ __launch_bounds__(64) void k_smoke_shade(const SmokeParams P, const Deferred D) {
+    extern __shared__ uint32_t wave_chunks_lds[];
+    volatile uint32_t *wave_chunks = wave_chunks_lds;
+    for (uint32_t i = threadIdx.x; i < D.chunks_per_tile; i += 64u) wave_chunks[i] = D.chunk_of[(size_t)blockIdx.x * D.chunks_per_tile + i];
+    uint32_t x, y;
+    if (!tile_pixel(P, blockIdx.x, threadIdx.x, x, y)) return;
+    if (D.spilled[blockIdx.x] != 0u) {  // the list ran out under this tile: its rays walked here, with their self-shadow marches
+        walk_pixel<kWhole>(P, D, wave_chunks, x, y);
+        return;
+    }
+    const uint32_t count = D.count[(size_t)y * P.width + x], lane = threadIdx.x & 63u;
+    float transmittance = 1.0f;
+    V3 rgb = V3{0.0f, 0.0f, 0.0f};
+    if (count != 0u) {
+        V3 origin, dir;
+        uint32_t seed;
+        pixel_ray(P, x, y, origin, dir, seed);
+        const float cos_theta = f_clamp(vdot(dir, P.sun), -1.0f, 1.0f);
+        const float g2 = P.st.phase_g * P.st.phase_g;  // henyey_greenstein, as in march_ray
+        const float denom = f_max(1.0f + g2 - 2.0f * P.st.phase_g * cos_theta, 1.0e-4f);
+        const float phase = (1.0f - g2) / (4.0f * kPi * (denom * f_sqrt(denom)));
+        auto slot_of = [&](uint32_t k) { return wave_chunks[k / kChunkRows] * kChunkSlots + (k % kChunkRows) * 64u + lane; };
+        uint32_t slot = slot_of(0u);
+        float4 where = D.where[slot], fields = D.fields[slot], more = D.more[slot];
+        float light = D.light[slot];
+        for (uint32_t k = 0u; k < count; k++) {
+            const float4 w = where, f = fields, m = more;  // this step; the next one's loads go out before it is evaluated
+            const float l = light;
+            if (k + 1u < count) {
+                slot = slot_of(k + 1u);
+                where = D.where[slot];
+                fields = D.fields[slot];
+                more = D.more[slot];
+                light = D.light[slot];
+            }
+            const float sigma_t = w.w, seg_tr = m.z;
+            const float seg_w = sigma_t > 1.0e-6f ? (1.0f - seg_tr) / sigma_t : P.step;
+            const V3 source = smoke_source(P, V3{w.x, w.y, w.z}, f.x, f.y, f.z, f.w, m.x, m.y, sigma_t, l, phase);
+            rgb = vadd(rgb, vscale(vscale(source, seg_w), transmittance));
+            transmittance *= seg_tr;
+        }
+    }
+    reinterpret_cast<uchar4 *>(P.out)[(size_t)y * P.width + x] = smoke_pixel(P, rgb, transmittance);
 }
 
 // ---- sift + cooperative march (round 5) ------------------------------------------------------------------------------------
@@ -601,6 +876,14 @@ extern "C" int f3d_smoke_render(const f3d_smoke_volume *vol, const f3d_smoke_vie
         const PackParams pack{dev[0], dev[1], dev[2], dev[3], dev[4], dev[5], rec_a, rec_b, n, occupied, P.nx, P.ny, P.nz, P.ocx, P.ocy};
         hipLaunchKernelGGL(k_smoke_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, pack);
         hip_ok(hipGetLastError(), "smoke pack kernel");
+        uint32_t *bounds = (uint32_t *)alloc(6 * sizeof(uint32_t), "smoke bounds");
+        hip_ok(hipMemsetAsync(bounds, 0xFF, 6 * sizeof(uint32_t), nullptr), "smoke bounds");
+        hipLaunchKernelGGL(k_smoke_bounds, dim3(((P.nz - 1u) >> kOccShift) + 1u), dim3(256), 0, nullptr, occupied, P.ocx, P.ocy, bounds);
+        hip_ok(hipGetLastError(), "smoke bounds kernel");
+        P.bounds = bounds;
+        P.clip = 1u;
+        for (int a = 0; a < 3; a++)
+            if (!(vol->voxel_size[a] > 0.0f) || !std::isfinite(vol->voxel_size[a]) || !std::isfinite(vol->origin[a])) P.clip = 0u;
         P.rec_a = rec_a;
         P.rec_b = rec_b;
         const size_t px = (size_t)P.width * P.height;
@@ -609,8 +892,6 @@ extern "C" int f3d_smoke_render(const f3d_smoke_volume *vol, const f3d_smoke_vie
         (void)hipGetLastError();
         P.out = out_on_device ? rgba : (uint8_t *)alloc(px * 4, "smoke rgba");  // (a device image stays on the device: the composite reads it there)
         if (out_on_device) n_scratch++;
-        HeavyItem *items = (HeavyItem *)alloc(px * sizeof(HeavyItem), "smoke work list");
-        uint32_t *counters = (uint32_t *)alloc(2 * sizeof(uint32_t), "smoke work list");
         // a device image whose caller does not ask for the kernel time: the call returns with its launches enqueued
         const bool timed = kernel_seconds != nullptr || !out_on_device;
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -621,8 +902,35 @@ extern "C" int f3d_smoke_render(const f3d_smoke_volume *vol, const f3d_smoke_vie
         }
         const uint32_t tiles = ((P.width + 7u) / 8u) * ((P.height + 7u) / 8u);
         const char *form = getenv("F3D_SMOKE_MARCH");
-        if (!(form && strcmp(form, "sift") == 0)) {  // the default: one lane per pixel, the whole ray
-            hipLaunchKernelGGL(k_smoke, dim3(tiles), dim3(64), 0, nullptr, P);
+        Deferred D{};
+        D.chunks_per_tile = (P.st.max_steps + kChunkRows - 1u) / kChunkRows;
+        const bool deferred = P.st.self_shadow != 0u && !form && D.chunks_per_tile <= 4096u;
+        if (deferred) {  // the default: the self-shadow marches as a launch of their own between two walks of the rays
+            size_t slots = std::max<size_t>((size_t)4 << 20, px * 16u);  // (a tile whose steps do not fit is walked by k_smoke_shade in the one-kernel form)
+            if (const char *e = getenv("F3D_SMOKE_SHADOW_SLOTS")) slots = (size_t)strtoull(e, nullptr, 10);  // test hook: a list that runs out
+            D.capacity = (uint32_t)std::min<size_t>(std::max<size_t>(slots / kChunkSlots, 1u), 1u << 21);
+            auto named = [&](const char *tag, size_t bytes) {  // (requests of this form only: their own tags)
+                void *q = nullptr;
+                hip_ok(workspace(&q, tag, bytes), "smoke shadow list");
+                return q;
+            };
+            const size_t list = (size_t)D.capacity * kChunkSlots;
+            D.where = (float4 *)named("smoke.render.shadow.where", list * sizeof(float4));
+            D.fields = (float4 *)named("smoke.render.shadow.fields", list * sizeof(float4));
+            D.more = (float4 *)named("smoke.render.shadow.more", list * sizeof(float4));
+            D.light = (float *)named("smoke.render.shadow.light", list * sizeof(float));
+            D.spilled = (uint32_t *)named("smoke.render.shadow.spilled", (size_t)tiles * sizeof(uint32_t));
+            D.chunk_of = (uint32_t *)named("smoke.render.shadow.chunk_of", (size_t)tiles * D.chunks_per_tile * sizeof(uint32_t));
+            D.owner = (uint2 *)named("smoke.render.shadow.owner", (size_t)D.capacity * sizeof(uint2));
+            D.count = (uint32_t *)named("smoke.render.shadow.count", px * sizeof(uint32_t));
+            D.cursor = (uint32_t *)named("smoke.render.shadow.cursor", sizeof(uint32_t));
+            hip_ok(hipMemsetAsync(D.cursor, 0, sizeof(uint32_t), nullptr), "smoke shadow list");
+            const size_t lds = ((size_t)D.chunks_per_tile + 1u) * sizeof(uint32_t);
+            hipLaunchKernelGGL(k_smoke_rays<kCollect>, dim3(tiles), dim3(64), lds, nullptr, P, D);
+            hipLaunchKernelGGL(k_smoke_light, dim3(16384), dim3(64), 0, nullptr, P, D);
+            hipLaunchKernelGGL(k_smoke_shade, dim3(tiles), dim3(64), lds, nullptr, P, D);
+        } else if (!(form && strcmp(form, "sift") == 0)) {  // one lane per pixel, the whole ray (F3D_SMOKE_MARCH=single, or no self-shadowing)
+            hipLaunchKernelGGL(k_smoke_rays<kWhole>, dim3(tiles), dim3(64), 0, nullptr, P, D);
         } else {
             SiftParams S{};
             S.P = P;

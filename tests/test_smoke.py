@@ -140,7 +140,7 @@ def _domain(fields, voxel_size=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), frame_in
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["sift", "single"])
+@pytest.mark.parametrize("form", ["deferred", "deferred-short-list", "sift", "single"])
 @pytest.mark.parametrize("size,settings,geom", [
     ((96, 64), {}, {}),
     ((160, 90), dict(self_shadow=False, exposure=1.4, phase_g=-0.5), dict(voxel_size=(2.0, 1.5, 2.5), origin=(-10.0, 3.0, 7.0))),
@@ -148,11 +148,16 @@ def _domain(fields, voxel_size=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), frame_in
     ((128, 128), dict(density_scale=2.5, extinction=4.0, soot_absorption=0.9, fire_glow=1.5, thin_color=(0.2, 0.3, 0.4)), {}),
 ])
 def test_hip_smoke_matches_the_oracle_bit_for_bit(size, settings, geom, form, monkeypatch):
-    """Both forms of the device marcher (csrc/f3d_smoke.hip): sift + eight cooperating lanes per smoke pixel (the default) and
-    one lane per pixel for the whole ray (F3D_SMOKE_MARCH=single)."""
+    """The forms of the device marcher (csrc/f3d_smoke.hip): the self-shadow marches as a launch of their own between two walks
+    of the rays (the default; "short list": with room for three chunks only, so that most tiles' steps fall back to marching
+    their shadows in the second walk), sift + eight cooperating lanes per smoke pixel (F3D_SMOKE_MARCH=sift) and one lane per
+    pixel for the whole ray (F3D_SMOKE_MARCH=single)."""
     from forge3d_amd import smoke
 
-    monkeypatch.setenv("F3D_SMOKE_MARCH", form)
+    if form in ("sift", "single"):
+        monkeypatch.setenv("F3D_SMOKE_MARCH", form)
+    elif form == "deferred-short-list":
+        monkeypatch.setenv("F3D_SMOKE_SHADOW_SLOTS", "3072")
 
     fields = plume()
     vs, og = geom.get("voxel_size", (1.0, 1.0, 1.0)), geom.get("origin", (0.0, 0.0, 0.0))
@@ -169,6 +174,58 @@ def test_hip_smoke_matches_the_oracle_bit_for_bit(size, settings, geom, form, mo
     want_p = smoke_oracle.render_projection_rgba(fields, size[0], size[1], (0.2, -1.0, 0.1), (0.4, 0.8, -0.2), voxel_size=vs,
                                                  origin=og, frame_index=geom.get("frame_index", 0), **settings)
     assert np.array_equal(got_p, want_p)
+
+
+def _box_cases():
+    """Volumes that exercise the clipping against the smoke's bounding box (csrc/f3d_smoke.hip, smoke_box / smoke_clip): smoke
+    at the clamped ends of the grid, a lone voxel, no smoke at all, a small voxel far from the world's origin (where float
+    rounding of a position is a visible fraction of a voxel), axis-parallel view and sun directions."""
+    dims = (20, 14, 24)
+    corners = np.zeros(dims, np.float32)
+    for c in ((0.5, 0.5, 0.5), (23.5, 13.5, 19.5), (0.5, 13.5, 19.5), (23.5, 0.5, 0.5)):
+        corners += ball(dims, c, 4.0, 1.5)
+    lone = np.zeros(dims, np.float32)
+    lone[11, 6, 9] = 3.0
+    edge = np.zeros(dims, np.float32)
+    edge[0, :, :] = 0.4
+    edge[:, :, -1] = 0.7
+    slab = np.zeros(dims, np.float32)
+    slab[6:9, 2:12, 3:20] = 0.9
+    cam_out = dict(camera_pos=(12.0, 16.0, -24.0), target=(12.0, 6.0, 10.0), up=(0.0, 1.0, 0.0), fovy_deg=50.0)
+    cam_in = dict(camera_pos=(12.3, 7.1, 9.6), target=(2.0, 3.0, 1.0), up=(0.0, 1.0, 0.0), fovy_deg=80.0)
+    cam_axis = dict(camera_pos=(12.0, 7.0, -30.0), target=(12.0, 7.0, 10.0), up=(0.0, 1.0, 0.0), fovy_deg=30.0)
+    return [
+        ("corners", corners, {}, cam_out, (0.4, 0.8, -0.2)),
+        ("corners-from-inside", corners, {}, cam_in, (-0.3, 0.5, 0.7)),
+        ("lone-voxel", lone, {}, cam_out, (0.4, 0.8, -0.2)),
+        ("lone-voxel-axis-sun", lone, {}, cam_axis, (1.0, 0.0, 0.0)),
+        ("faces", edge, {}, cam_in, (0.0, 1.0, 0.0)),
+        ("nothing", np.zeros(dims, np.float32), {}, cam_out, (0.4, 0.8, -0.2)),
+        ("small-voxels-far-away", slab, dict(voxel_size=(0.01, 0.02, 0.015), origin=(4000.0, -900.0, 2500.0)), cam_out, (0.4, 0.8, -0.2)),
+        ("slab-axis", slab, dict(voxel_size=(1.0, 0.5, 2.0)), cam_axis, (0.0, 0.0, -1.0)),
+    ]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", _box_cases(), ids=lambda c: c[0])
+def test_clipping_against_the_smoke_box_changes_nothing(case):
+    _, density, geom, cam, sun = case
+    fields = {"density": density, "soot": (0.3 * density).astype(np.float32), "particle_age": np.where(density > 0, 5.0, -1.0).astype(np.float32)}
+    vs, og = geom.get("voxel_size", (1.0, 1.0, 1.0)), geom.get("origin", (0.0, 0.0, 0.0))
+    cam = {k: (tuple(np.array(v) * np.array(vs) + np.array(og)) if k in ("camera_pos", "target") else v) for k, v in cam.items()}
+    dom = _domain(fields, vs, og, frame_index=3)
+    st = dict(shadow_steps=24, max_steps=400, step_size=0.5 * min(vs), shadow_step_size=1.3 * min(vs))
+    from forge3d_amd import smoke
+
+    got = dom.render_rgba(80, 60, settings=smoke.SmokeRenderSettings(**st), sun_direction=sun, **cam)
+    want = smoke_oracle.render_rgba(fields, 80, 60, sun_direction=sun, voxel_size=vs, origin=og, frame_index=3, **cam, **st)
+    assert np.array_equal(got, want), f"{(got != want).any(-1).sum()} pixels differ"
+    for view in ((0.0, -1.0, 0.0), (0.3, -0.8, 0.2)):
+        got_p = dom.render_projection_rgba(64, 48, view, sun, settings=smoke.SmokeRenderSettings(**st))
+        want_p = smoke_oracle.render_projection_rgba(fields, 64, 48, view, sun, voxel_size=vs, origin=og, frame_index=3, **st)
+        assert np.array_equal(got_p, want_p)
+    if density.any():
+        assert int(want[..., 3].max()) > 0
 
 
 @pytest.mark.gpu
