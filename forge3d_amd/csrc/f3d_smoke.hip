@@ -20,6 +20,7 @@
 
 #include "f3d_setup.h"
 #include "f3d_devmem.h"
+#include "f3d_div_known.h"
 
 using namespace f3d;
 
@@ -37,6 +38,8 @@ struct SmokeParams {
     const float2 *rec_b;  // humidity, emission
     uint32_t nx, ny, nz;
     V3 origin, voxel, bmin, bmax;
+    V3 voxel_rcp;        // RN(1 / voxel) per axis, for div_known()
+    uint32_t known_div;  // != 0: every voxel size is a divisor div_known() is exact for (the host checks; see there)
     const uint8_t *occupied;  // per low corner (or block of low corners, kOccShift): does a tap there touch any density != 0?
     uint32_t ocx, ocy;        // blocks along x, y
     const uint32_t *bounds;   // of the marked entries of `occupied`: lowest x, y, z, then ~highest x, y, z (k_smoke_bounds)
@@ -87,35 +90,51 @@ __global__ void k_smoke_pack(const PackParams P) {
     }
 }
 
-// The box of the marked entries of the empty-space map, for smoke_box(): a workgroup per z slice of the map, the six bounds
-// folded into `bounds` (all 0xFF before the launch) with atomicMin -- the upper ones as their complements.
-__global__ __launch_bounds__(256) void k_smoke_bounds(const uint8_t *occupied, uint32_t ocx, uint32_t ocy, uint32_t *bounds) {
+// The box of the marked entries of the empty-space map, for smoke_box(): a workgroup per z slice of the map leaves the slice's
+// bounds (x, y; the upper ones as their complements, so that "nothing marked" is all ones), a single wave folds the slices.
+// (A first form folded with atomicMin from every wave: 28 us of same-address atomics for a 7 us pack kernel.)
+__global__ __launch_bounds__(256) void k_smoke_bounds(const uint8_t *occupied, uint32_t ocx, uint32_t ocy, uint4 *slices) {
+    __shared__ uint4 part[4];
     const uint32_t z = blockIdx.x, per_slice = ocx * ocy;
-    uint32_t lx = 0xFFFFFFFFu, ly = 0xFFFFFFFFu, hx = 0u, hy = 0u;
+    uint32_t lx = 0xFFFFFFFFu, ly = 0xFFFFFFFFu, hx = 0xFFFFFFFFu, hy = 0xFFFFFFFFu;  // minima; hx, hy of the complements
     for (uint32_t i = threadIdx.x; i < per_slice; i += 256u)
         if (occupied[(size_t)z * per_slice + i] != 0u) {
             const uint32_t x = i % ocx, y = i / ocx;
-            lx = x < lx ? x : lx;
-            ly = y < ly ? y : ly;
-            hx = x > hx ? x : hx;
-            hy = y > hy ? y : hy;
+            lx = min(lx, x);
+            ly = min(ly, y);
+            hx = min(hx, ~x);
+            hy = min(hy, ~y);
         }
     for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t a = (uint32_t)__shfl_xor((int)lx, o, 64), b = (uint32_t)__shfl_xor((int)ly, o, 64);
-        const uint32_t c = (uint32_t)__shfl_xor((int)hx, o, 64), d = (uint32_t)__shfl_xor((int)hy, o, 64);
-        lx = a < lx ? a : lx;
-        ly = b < ly ? b : ly;
-        hx = c > hx ? c : hx;
-        hy = d > hy ? d : hy;
+        lx = min(lx, (uint32_t)__shfl_xor((int)lx, o, 64));
+        ly = min(ly, (uint32_t)__shfl_xor((int)ly, o, 64));
+        hx = min(hx, (uint32_t)__shfl_xor((int)hx, o, 64));
+        hy = min(hy, (uint32_t)__shfl_xor((int)hy, o, 64));
     }
-    if ((threadIdx.x & 63u) == 0u && lx != 0xFFFFFFFFu) {
-        atomicMin(&bounds[0], lx);
-        atomicMin(&bounds[1], ly);
-        atomicMin(&bounds[2], z);
-        atomicMin(&bounds[3], ~hx);
-        atomicMin(&bounds[4], ~hy);
-        atomicMin(&bounds[5], ~z);
+    if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = uint4{lx, ly, hx, hy};
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        uint4 r = part[0];
+        for (int w = 1; w < 4; w++) r = uint4{min(r.x, part[w].x), min(r.y, part[w].y), min(r.z, part[w].z), min(r.w, part[w].w)};
+        slices[z] = r;
     }
+}
+__global__ __launch_bounds__(64) void k_smoke_bounds_fold(const uint4 *slices, uint32_t n_slices, uint32_t *bounds) {
+    uint32_t v[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};  // lx ly lz ~hx ~hy ~hz
+    for (uint32_t z = threadIdx.x; z < n_slices; z += 64u) {
+        const uint4 s = slices[z];
+        if (s.x == 0xFFFFFFFFu) continue;
+        v[0] = min(v[0], s.x);
+        v[1] = min(v[1], s.y);
+        v[2] = min(v[2], z);
+        v[3] = min(v[3], s.z);
+        v[4] = min(v[4], s.w);
+        v[5] = min(v[5], ~z);
+    }
+    for (int o = 32; o > 0; o >>= 1)
+        for (int k = 0; k < 6; k++) v[k] = min(v[k], (uint32_t)__shfl_xor((int)v[k], o, 64));
+    if (threadIdx.x == 0u)
+        for (int k = 0; k < 6; k++) bounds[k] = v[k];
 }
 
 __device__ __forceinline__ float lerp_ref(float a, float b, float t) { return a + (b - a) * t; }  // sampling.rs:88-90
@@ -130,8 +149,20 @@ struct Tap {
     float fx, fy, fz;
 };
 __device__ __forceinline__ Tap make_tap(const SmokeParams &P, V3 pos) {
-    const float gx = (pos.x - P.origin.x) / P.voxel.x - 0.5f, gy = (pos.y - P.origin.y) / P.voxel.y - 0.5f,
-                gz = (pos.z - P.origin.z) / P.voxel.z - 0.5f;
+    const float ax = pos.x - P.origin.x, ay = pos.y - P.origin.y, az = pos.z - P.origin.z;
+    float gx, gy, gz;
+#if !defined(F3D_SMOKE_PLAIN_DIV)
+    if (P.known_div != 0u && f_max(f_max(f_abs(ax), f_abs(ay)), f_abs(az)) < kDivKnownMax) {
+        gx = div_known(ax, P.voxel.x, P.voxel_rcp.x) - 0.5f;
+        gy = div_known(ay, P.voxel.y, P.voxel_rcp.y) - 0.5f;
+        gz = div_known(az, P.voxel.z, P.voxel_rcp.z) - 0.5f;
+    } else
+#endif
+    {
+        gx = ax / P.voxel.x - 0.5f;
+        gy = ay / P.voxel.y - 0.5f;
+        gz = az / P.voxel.z - 0.5f;
+    }
     const float x = f_clamp(gx, 0.0f, (float)(P.nx - 1u)), y = f_clamp(gy, 0.0f, (float)(P.ny - 1u)),
                 z = f_clamp(gz, 0.0f, (float)(P.nz - 1u));
     const uint32_t x0 = (uint32_t)f_floor(x), y0 = (uint32_t)f_floor(y), z0 = (uint32_t)f_floor(z);
@@ -159,6 +190,32 @@ __device__ __forceinline__ float tri(const Tap &t, float c000, float c100, float
 
 __device__ __forceinline__ float smoothstep_ref(float e0, float e1, float x) {  // render_smoothstep, render.rs:405-408
     const float t = f_clamp((x - e0) / f_max(e1 - e0, 1.0e-6f), 0.0f, 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+// ... with edges that are literals at every call: the width and its reciprocal fold to constants (f3d_div_known.h; the static
+// assertions of `SmoothEdges` keep the two pairs of edges in use inside what it is exact for)
+template <int WHICH>
+struct SmoothEdges;
+template <>
+struct SmoothEdges<0> {  // the age ramp, render.rs:227 / :312
+    static constexpr float e0 = 1.6f, e1 = 17.0f;
+};
+template <>
+struct SmoothEdges<1> {  // the density gate, render.rs:228 / :313
+    static constexpr float e0 = 0.045f, e1 = 0.34f;
+};
+template <int WHICH>
+__device__ __forceinline__ float smoothstep_known(float x) {
+    constexpr float e0 = SmoothEdges<WHICH>::e0, e1 = SmoothEdges<WHICH>::e1;
+    constexpr float d = (e1 - e0) > 1.0e-6f ? (e1 - e0) : 1.0e-6f, r = 1.0f / d;
+    static_assert((__builtin_bit_cast(uint32_t, d) & 0x7FFFFFu) != 0x7FFFFFu && d > 0x1p-40f && d < 0x1p40f, "div_known needs another divisor");
+    const float a = x - e0;
+#if !defined(F3D_SMOKE_PLAIN_DIV)
+    const float q = f_abs(a) < kDivKnownMax ? div_known(a, d, r) : a / d;
+#else
+    const float q = a / d;
+#endif
+    const float t = f_clamp(q, 0.0f, 1.0f);
     return t * t * (3.0f - 2.0f * t);
 }
 
@@ -259,8 +316,8 @@ __device__ float sun_transmittance(const SmokeParams &P, const SmokeBox &box, V3
         if (P.occupied[t.block] == 0u) continue;  // density +-0 at all eight corners: the step adds +-0 to od (and od > 8 was tested when it last grew)
 #endif
         const float density = F3D_TRI(P.rec_a, x), soot = F3D_TRI(P.rec_a, y), age = f_max(F3D_TRI(P.rec_a, z), 0.0f);
-        const float age_t = smoothstep_ref(1.6f, 17.0f, age);
-        const float gate = 0.50f + 0.50f * smoothstep_ref(0.045f, 0.34f, density);
+        const float age_t = smoothstep_known<0>(age);
+        const float gate = 0.50f + 0.50f * smoothstep_known<1>(density);
         od += density * P.st.density_scale * (1.0f - 0.58f * age_t) * gate * P.st.extinction *
               (1.0f + soot * P.st.soot_absorption) * P.shadow_step;
         if (od > 8.0f) break;
@@ -399,8 +456,8 @@ __device__ uchar4 march_ray(const SmokeParams &P, const SmokeBox &box, V3 origin
 #define t t_
         const float s_density = F3D_TRI(P.rec_a, x), s_soot = F3D_TRI(P.rec_a, y), s_age = f_max(F3D_TRI(P.rec_a, z), 0.0f);
 #undef t
-        const float age_t = smoothstep_ref(1.6f, 17.0f, s_age);
-        const float gate = 0.50f + 0.50f * smoothstep_ref(0.045f, 0.34f, s_density);
+        const float age_t = smoothstep_known<0>(s_age);
+        const float gate = 0.50f + 0.50f * smoothstep_known<1>(s_density);
         const float density = f_max(s_density * P.st.density_scale * (1.0f - 0.58f * age_t) * gate, 0.0f);
         if (!(density > 1.0e-5f)) continue;
         const float sigma_t = density * P.st.extinction * (1.0f + s_soot * P.st.soot_absorption * 0.85f);
@@ -877,13 +934,20 @@ extern "C" int f3d_smoke_render(const f3d_smoke_volume *vol, const f3d_smoke_vie
         hipLaunchKernelGGL(k_smoke_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, pack);
         hip_ok(hipGetLastError(), "smoke pack kernel");
         uint32_t *bounds = (uint32_t *)alloc(6 * sizeof(uint32_t), "smoke bounds");
-        hip_ok(hipMemsetAsync(bounds, 0xFF, 6 * sizeof(uint32_t), nullptr), "smoke bounds");
-        hipLaunchKernelGGL(k_smoke_bounds, dim3(((P.nz - 1u) >> kOccShift) + 1u), dim3(256), 0, nullptr, occupied, P.ocx, P.ocy, bounds);
+        const uint32_t n_slices = ((P.nz - 1u) >> kOccShift) + 1u;
+        uint4 *slices = (uint4 *)alloc((size_t)n_slices * sizeof(uint4), "smoke bounds");
+        hipLaunchKernelGGL(k_smoke_bounds, dim3(n_slices), dim3(256), 0, nullptr, occupied, P.ocx, P.ocy, slices);
+        hipLaunchKernelGGL(k_smoke_bounds_fold, dim3(1), dim3(64), 0, nullptr, slices, n_slices, bounds);
         hip_ok(hipGetLastError(), "smoke bounds kernel");
         P.bounds = bounds;
         P.clip = 1u;
-        for (int a = 0; a < 3; a++)
-            if (!(vol->voxel_size[a] > 0.0f) || !std::isfinite(vol->voxel_size[a]) || !std::isfinite(vol->origin[a])) P.clip = 0u;
+        P.known_div = 1u;
+        for (int a = 0; a < 3; a++) {
+            const float d = vol->voxel_size[a];
+            if (!(d > 0.0f) || !std::isfinite(d) || !std::isfinite(vol->origin[a])) P.clip = 0u;
+            if (!div_known_divisor(d)) P.known_div = 0u;
+        }
+        P.voxel_rcp = V3{1.0f / P.voxel.x, 1.0f / P.voxel.y, 1.0f / P.voxel.z};  // IEEE divisions: correctly rounded
         P.rec_a = rec_a;
         P.rec_b = rec_b;
         const size_t px = (size_t)P.width * P.height;

@@ -254,6 +254,39 @@ __global__ __launch_bounds__(64) void k_phase_sum_rows(const StepArgs A, const S
     if (r < A.G.ny * A.G.nz) sums_row(A, A.G, density, K, r);
 }
 __global__ __launch_bounds__(256) void k_phase_sum_finish(const StepArgs A, const SumKinds K) { sums_finish(A, A.G, K); }
+// The same sums in the same order with the slab staged in LDS (round 5: a lane a row reading global memory touched 64 cache
+// lines per load and the single finishing workgroup walked rows and slabs from L2 -- 24 + 19 us, twice a step, a fifth of
+// the step).  A workgroup per z slab: coalesced copy into LDS (rows padded by one float: a lane a row would otherwise
+// hit one bank), a wave per kind adds its rows along x, one lane per kind adds the slab's rows; a second, one-wave launch
+// adds the slabs.
+__global__ __launch_bounds__(256) void k_phase_sum_slabs(const StepArgs A, const SumKinds K, const float *density) {
+    extern __shared__ float slab_lds[];
+    const SimGrid &G = A.G;
+    const uint32_t z = blockIdx.x, stride = G.nx + 1u;
+    float *tile = slab_lds, *row_sum = slab_lds + (size_t)G.ny * stride;
+    for (uint32_t i = threadIdx.x; i < G.nx * G.ny; i += 256u) {
+        const uint32_t y = i / G.nx, x = i - y * G.nx;
+        tile[y * stride + x] = density[sim_index(G, x, y, z)];
+    }
+    __syncthreads();
+    const uint32_t k = threadIdx.x >> 6;
+    if (k < K.n) {
+        const uint32_t kind = K.kind[k];
+        for (uint32_t r = threadIdx.x & 63u; r < G.ny; r += 64u) {
+            float a = 0.0f;
+            for (uint32_t x = 0u; x < G.nx; x++) {  // (sums_row's terms and order)
+                const float d = tile[r * stride + x], m = f_max(d, 0.0f);
+                a += kind == 0u ? d : (kind == 1u ? m : (kind == 2u ? (float)x * m : (float)z * m));
+            }
+            row_sum[k * G.ny + r] = a;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < K.n) A.slabs[(size_t)threadIdx.x * G.nz + z] = sim_sum_seq(row_sum + threadIdx.x * G.ny, G.ny);
+}
+__global__ __launch_bounds__(64) void k_phase_sum_total(const StepArgs A, const SumKinds K) {
+    if (threadIdx.x < K.n) A.sums[K.slot[threadIdx.x]] = sim_sum_seq(A.slabs + (size_t)threadIdx.x * A.G.nz, A.G.nz);
+}
 
 // persistent driver: the grid barrier.  Cache maintenance is most of its cost (see above), so the fences are executed by
 // ONE wave of the workgroup -- with all sixteen executing them a barrier took 37 us and a Jacobi sweep of three voxels a lane
@@ -639,9 +672,16 @@ extern "C" int f3d_smoke_step(f3d_smoke_state *st, const f3d_smoke_step_settings
                 // cached loads a voxel instead of 2 x 8) -- bit-identical, 15 launches fewer a step, and SLOWER: 0.411-0.416 ms
                 // against 0.386-0.397 (the doubled sweep costs more than the 5-us launch it saves).  F3D_SMOKE_DOUBLE_SWEEPS=1 runs it.
                 const bool single_sweeps = getenv("F3D_SMOKE_DOUBLE_SWEEPS") == nullptr;
+                const size_t slab_lds = ((size_t)s.G.ny * (s.G.nx + 1u) + 4u * (size_t)s.G.ny) * sizeof(float);
+                const bool slab_sums = slab_lds <= 60u * 1024u && getenv("F3D_SMOKE_ROW_SUMS") == nullptr;  // (else: a lane a row from global memory)
                 auto sums = [&](const float *density, const SumKinds &kinds) {
-                    hipLaunchKernelGGL(k_phase_sum_rows, row_grid, dim3(64), 0, nullptr, K, kinds, density);
-                    hipLaunchKernelGGL(k_phase_sum_finish, dim3(1), dim3(256), 0, nullptr, K, kinds);
+                    if (slab_sums) {
+                        hipLaunchKernelGGL(k_phase_sum_slabs, dim3(s.G.nz), dim3(256), slab_lds, nullptr, K, kinds, density);
+                        hipLaunchKernelGGL(k_phase_sum_total, dim3(1), dim3(64), 0, nullptr, K, kinds);
+                    } else {
+                        hipLaunchKernelGGL(k_phase_sum_rows, row_grid, dim3(64), 0, nullptr, K, kinds, density);
+                        hipLaunchKernelGGL(k_phase_sum_finish, dim3(1), dim3(256), 0, nullptr, K, kinds);
+                    }
                 };
                 auto project_fused = [&](uint32_t iterations) {
                     hipLaunchKernelGGL(k_phase<kPhDivergence>, grid, block, 0, nullptr, K, C);

@@ -19,6 +19,7 @@
 #include "../../forge3d_amd/csrc/f3d_shade.h"
 #include "../../forge3d_amd/csrc/f3d_wf_host.h"
 #include "../../forge3d_amd/csrc/f3d_aether_ref_host.h"
+#include "../../forge3d_amd/csrc/f3d_div_known.h"
 
 using namespace f3d;
 
@@ -1291,5 +1292,30 @@ int emul_aether_reference(const f3d_aether_ref_desc *d, f3d_aether_ref_out *out,
         return report(f, err, errlen);
     }
 }
+
+// div_known (csrc/f3d_div_known.h) against the division, for EVERY significand of the dividend at the given binary exponents
+// (the identity is invariant under scaling by powers of two as long as nothing leaves the normal range), both signs:
+// returns the number of dividends whose quotients differ in any bit.
+uint64_t emul_div_known_mismatches(float d, const int32_t *exponents, uint32_t n_exponents) {
+    const float r = 1.0f / d;
+    uint64_t bad = 0;
+    for (uint32_t e = 0; e < n_exponents; e++) {
+#pragma omp parallel for reduction(+ : bad)
+        for (int64_t m = 0; m < (int64_t)1 << 23; m++) {
+            const uint32_t bits = ((uint32_t)(exponents[e] + 127) << 23) | (uint32_t)m;
+            float a;
+            memcpy(&a, &bits, sizeof(a));
+            for (int sign = 0; sign < 2; sign++) {
+                const float x = sign ? -a : a;
+                const volatile float want = x / d;
+                const float got = f3d::div_known(x, d, r);
+                float w = want;
+                if (memcmp(&w, &got, sizeof(float)) != 0) bad++;
+            }
+        }
+    }
+    return bad;
+}
+int32_t emul_div_known_divisor(float d) { return f3d::div_known_divisor(d) ? 1 : 0; }
 
 }  // extern "C"

@@ -122,6 +122,30 @@ def test_python_surface_without_a_gpu():
     assert np.allclose(e.density, ball((16, 16, 16), (8, 8, 8), 4.0, 4.0), atol=1e-5)
 
 
+def test_three_instruction_quotients_are_the_ieee_quotients():
+    """csrc/f3d_div_known.h: the marcher's taps and smoothsteps divide by numbers known before the launch (the voxel size, the
+    width between two literal edges) with a multiply and two fmas.  Checked here against `/` for every significand of the
+    dividend, both signs, at three binary exponents, for the voxel sizes of this suite, the two smoothstep widths, and a
+    handful of divisors chosen to be awkward (thirds, tenths, one ulp below a power of two -- which the host must refuse)."""
+    import ctypes as C
+
+    from emul import emul
+
+    lib = emul.lib()
+    lib.emul_div_known_mismatches.restype = C.c_uint64
+    lib.emul_div_known_mismatches.argtypes = [C.c_float, C.POINTER(C.c_int32), C.c_uint32]
+    lib.emul_div_known_divisor.argtypes = [C.c_float]
+    exps = (C.c_int32 * 3)(-7, 0, 9)
+    f32 = np.float32
+    widths = [f32(17.0) - f32(1.6), f32(0.34) - f32(0.045)]
+    for d in [1.0, 2.0, 1.5, 2.5, 0.01, 0.02, 0.015, 0.5, 3.0, 1.0 / 3.0, 0.1, 0.7, 1.1, 7.0, 1e-3, 123.456, 0.75, *widths]:
+        d = float(f32(d))
+        assert lib.emul_div_known_divisor(d) == 1
+        assert lib.emul_div_known_mismatches(d, exps, 3) == 0, d
+    all_ones = float(np.nextafter(f32(2.0), f32(0.0)))
+    assert lib.emul_div_known_divisor(all_ones) == 0 and lib.emul_div_known_divisor(1e-20) == 0 and lib.emul_div_known_divisor(-1.0) == 0
+
+
 # ---- the HIP kernel against the oracle ---------------------------------------------------------------------
 def _domain(fields, voxel_size=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), frame_index=0):
     from forge3d_amd import smoke
