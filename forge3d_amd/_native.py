@@ -143,6 +143,8 @@ ABI = [
     ("f3d_session_sample_lanes", C.c_uint32, [C.c_void_p]),
     ("f3d_session_row_costs", C.c_int, [C.c_void_p, _P(C.c_float), C.c_uint32, C.c_char_p, C.c_size_t]),
     ("f3d_session_primary_start", C.c_void_p, [C.c_void_p]),
+    ("f3d_smoke_set_stream", None, [C.c_void_p]),
+    ("f3d_smoke_wait_fields_read", C.c_int, [C.c_void_p]),
     ("f3d_halo_rows", C.c_uint32, []),
     ("f3d_session_enqueue_frame_part", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_char_p, C.c_size_t]),
     ("f3d_atrous_denoise", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32,

@@ -53,7 +53,7 @@ struct Buffers {
         void *d = nullptr;
         ok(device_alloc(&d, bytes), "composite input");
         owned.push_back(d);
-        ok(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice), "composite upload");
+        ok(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice), "composite upload");  // (a fresh allocation: nothing in flight reads it)
         return static_cast<const uint32_t *>(d);
     }
 };
@@ -123,18 +123,21 @@ extern "C" int f3d_smoke_composite(const f3d_composite_desc *desc, uint8_t *out_
         if (timed) {
             ok(hipEventCreate(&e0), "event");
             ok(hipEventCreate(&e1), "event");
-            ok(hipEventRecord(e0, nullptr), "event");
+            ok(hipEventRecord(e0, call_stream()), "event");
         }
-        hipLaunchKernelGGL(k_composite, grid, block, 0, nullptr, P, base, layer, out);
+        hipLaunchKernelGGL(k_composite, grid, block, 0, call_stream(), P, base, layer, out);
         ok(hipGetLastError(), "composite kernel");
         if (timed) {
-            ok(hipEventRecord(e1, nullptr), "event");
+            ok(hipEventRecord(e1, call_stream()), "event");
             ok(hipEventSynchronize(e1), "composite");
             float ms = 0.0f;
             ok(hipEventElapsedTime(&ms, e0, e1), "event");
             if (kernel_seconds) *kernel_seconds = ms * 1e-3;
         }
-        if (!out_on_device) ok(hipMemcpy(out_rgba, out, bytes, hipMemcpyDeviceToHost), "composite read-back");
+        if (!out_on_device) {
+            ok(hipStreamSynchronize(call_stream()), "composite");
+            ok(hipMemcpy(out_rgba, out, bytes, hipMemcpyDeviceToHost), "composite read-back");
+        }
     } catch (const Failure &f) {
         rc = f.status;
         if (err && errlen) snprintf(err, errlen, "%s", f.message.c_str());

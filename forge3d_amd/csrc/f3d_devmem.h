@@ -99,6 +99,20 @@ inline std::map<std::pair<int, std::string>, WorkspaceEntry> &workspace_map() {
     return m;
 }
 // (call with workspace_lock() held) a buffer of at least `bytes` for `tag` on the current device; hipErrorOutOfMemory etc. on failure
+// The stream the smoke entry points (solver step, marcher, composite) enqueue on: the calling thread's choice
+// (f3d_smoke_set_stream), the null stream unless it made one.  A resident sequence puts the solver and the marcher on two
+// streams so that step f + 1 runs beside the march of frame f (forge3d_amd/smoke.py, SmokeSequence).
+inline hipStream_t &call_stream() {
+    static thread_local hipStream_t stream = nullptr;
+    return stream;
+}
+// ... and the moment the marcher has finished READING the volume's fields (its pack kernel): what a solver step on another
+// stream has to wait for before it overwrites them (f3d_smoke_wait_fields_read).
+inline hipEvent_t &fields_read_event() {
+    static thread_local hipEvent_t event = nullptr;
+    return event;
+}
+
 inline hipError_t workspace(void **out, const char *tag, size_t bytes) {
     int device = 0;
     hipError_t e = hipGetDevice(&device);

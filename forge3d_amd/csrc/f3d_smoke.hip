@@ -841,6 +841,12 @@ void validate_volume(const f3d_smoke_volume &v) {  // SmokeDomainConfig::validat
 
 }  // namespace
 
+extern "C" void f3d_smoke_set_stream(void *stream) { call_stream() = static_cast<hipStream_t>(stream); }
+extern "C" int f3d_smoke_wait_fields_read(void *stream) {
+    if (!fields_read_event()) return F3D_STATUS_OK;
+    return hipStreamWaitEvent(static_cast<hipStream_t>(stream), fields_read_event(), 0) == hipSuccess ? F3D_STATUS_OK : F3D_STATUS_DEVICE;
+}
+
 extern "C" int f3d_smoke_render(const f3d_smoke_volume *vol, const f3d_smoke_view *view, const f3d_smoke_settings *settings,
                                 uint8_t *rgba, double *kernel_seconds, char *err, size_t errlen) {
     if (err && errlen) err[0] = 0;
@@ -919,6 +925,7 @@ extern "C" int f3d_smoke_render(const f3d_smoke_volume *vol, const f3d_smoke_vie
                 continue;
             }
             float *up = (float *)alloc(n * sizeof(float), "smoke field");
+            hip_ok(hipStreamSynchronize(call_stream()), "smoke field upload");  // (whatever the stream still reads from the buffer)
             hip_ok(hipMemcpy(up, host[i], n * sizeof(float), hipMemcpyHostToDevice), "smoke field upload");
             dev[i] = up;
         }
@@ -928,17 +935,19 @@ extern "C" int f3d_smoke_render(const f3d_smoke_volume *vol, const f3d_smoke_vie
         P.ocy = ((P.ny - 1u) >> kOccShift) + 1u;
         const size_t occ_bytes = (size_t)P.ocx * P.ocy * (((P.nz - 1u) >> kOccShift) + 1u);
         uint8_t *occupied = (uint8_t *)alloc(occ_bytes, "smoke empty-space map");
-        hip_ok(hipMemsetAsync(occupied, 0, occ_bytes, nullptr), "smoke empty-space map");
+        hip_ok(hipMemsetAsync(occupied, 0, occ_bytes, call_stream()), "smoke empty-space map");
         P.occupied = occupied;
         const PackParams pack{dev[0], dev[1], dev[2], dev[3], dev[4], dev[5], rec_a, rec_b, n, occupied, P.nx, P.ny, P.nz, P.ocx, P.ocy};
-        hipLaunchKernelGGL(k_smoke_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, pack);
+        hipLaunchKernelGGL(k_smoke_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, call_stream(), pack);
         hip_ok(hipGetLastError(), "smoke pack kernel");
         uint32_t *bounds = (uint32_t *)alloc(6 * sizeof(uint32_t), "smoke bounds");
         const uint32_t n_slices = ((P.nz - 1u) >> kOccShift) + 1u;
         uint4 *slices = (uint4 *)alloc((size_t)n_slices * sizeof(uint4), "smoke bounds");
-        hipLaunchKernelGGL(k_smoke_bounds, dim3(n_slices), dim3(256), 0, nullptr, occupied, P.ocx, P.ocy, slices);
-        hipLaunchKernelGGL(k_smoke_bounds_fold, dim3(1), dim3(64), 0, nullptr, slices, n_slices, bounds);
+        hipLaunchKernelGGL(k_smoke_bounds, dim3(n_slices), dim3(256), 0, call_stream(), occupied, P.ocx, P.ocy, slices);
+        hipLaunchKernelGGL(k_smoke_bounds_fold, dim3(1), dim3(64), 0, call_stream(), slices, n_slices, bounds);
         hip_ok(hipGetLastError(), "smoke bounds kernel");
+        if (!fields_read_event()) hip_ok(hipEventCreateWithFlags(&fields_read_event(), hipEventDisableTiming), "event");
+        hip_ok(hipEventRecord(fields_read_event(), call_stream()), "event");  // the volume's fields are not read after this point
         P.bounds = bounds;
         P.clip = 1u;
         P.known_div = 1u;
@@ -962,7 +971,7 @@ extern "C" int f3d_smoke_render(const f3d_smoke_volume *vol, const f3d_smoke_vie
         if (timed) {
             hip_ok(hipEventCreate(&e0), "event");
             hip_ok(hipEventCreate(&e1), "event");
-            hip_ok(hipEventRecord(e0, nullptr), "event");
+            hip_ok(hipEventRecord(e0, call_stream()), "event");
         }
         const uint32_t tiles = ((P.width + 7u) / 8u) * ((P.height + 7u) / 8u);
         const char *form = getenv("F3D_SMOKE_MARCH");
@@ -988,28 +997,31 @@ extern "C" int f3d_smoke_render(const f3d_smoke_volume *vol, const f3d_smoke_vie
             D.owner = (uint2 *)named("smoke.render.shadow.owner", (size_t)D.capacity * sizeof(uint2));
             D.count = (uint32_t *)named("smoke.render.shadow.count", px * sizeof(uint32_t));
             D.cursor = (uint32_t *)named("smoke.render.shadow.cursor", sizeof(uint32_t));
-            hip_ok(hipMemsetAsync(D.cursor, 0, sizeof(uint32_t), nullptr), "smoke shadow list");
+            hip_ok(hipMemsetAsync(D.cursor, 0, sizeof(uint32_t), call_stream()), "smoke shadow list");
             const size_t lds = ((size_t)D.chunks_per_tile + 1u) * sizeof(uint32_t);
-            hipLaunchKernelGGL(k_smoke_rays<kCollect>, dim3(tiles), dim3(64), lds, nullptr, P, D);
-            hipLaunchKernelGGL(k_smoke_light, dim3(16384), dim3(64), 0, nullptr, P, D);
-            hipLaunchKernelGGL(k_smoke_shade, dim3(tiles), dim3(64), lds, nullptr, P, D);
+            hipLaunchKernelGGL(k_smoke_rays<kCollect>, dim3(tiles), dim3(64), lds, call_stream(), P, D);
+            hipLaunchKernelGGL(k_smoke_light, dim3(16384), dim3(64), 0, call_stream(), P, D);
+            hipLaunchKernelGGL(k_smoke_shade, dim3(tiles), dim3(64), lds, call_stream(), P, D);
         } else if (!(form && strcmp(form, "sift") == 0)) {  // one lane per pixel, the whole ray (F3D_SMOKE_MARCH=single, or no self-shadowing)
-            hipLaunchKernelGGL(k_smoke_rays<kWhole>, dim3(tiles), dim3(64), 0, nullptr, P, D);
+            hipLaunchKernelGGL(k_smoke_rays<kWhole>, dim3(tiles), dim3(64), 0, call_stream(), P, D);
         } else {
             SiftParams S{};
             S.P = P;
             S.items = (HeavyItem *)alloc(px * sizeof(HeavyItem), "smoke work list");
             S.counters = (uint32_t *)alloc(2 * sizeof(uint32_t), "smoke work list");
-            hip_ok(hipMemsetAsync(S.counters, 0, 2 * sizeof(uint32_t), nullptr), "smoke work list");
-            hipLaunchKernelGGL(k_smoke_sift, dim3(tiles), dim3(64), 0, nullptr, S);
+            hip_ok(hipMemsetAsync(S.counters, 0, 2 * sizeof(uint32_t), call_stream()), "smoke work list");
+            hipLaunchKernelGGL(k_smoke_sift, dim3(tiles), dim3(64), 0, call_stream(), S);
             const uint32_t waves = (uint32_t)std::min<size_t>((px + 7u) / 8u, 16384u);  // (work is fetched from a cursor: any number >= what the chip holds will do)
-            hipLaunchKernelGGL(k_smoke_heavy, dim3(waves), dim3(64), 0, nullptr, S);
+            hipLaunchKernelGGL(k_smoke_heavy, dim3(waves), dim3(64), 0, call_stream(), S);
         }
         hip_ok(hipGetLastError(), "smoke kernel");
         if (timed) {
-            hip_ok(hipEventRecord(e1, nullptr), "event");
+            hip_ok(hipEventRecord(e1, call_stream()), "event");
             if (out_on_device) hip_ok(hipEventSynchronize(e1), "smoke kernel");
-            else hip_ok(hipMemcpy(rgba, P.out, px * 4, hipMemcpyDeviceToHost), "smoke readback");
+            else {
+                hip_ok(hipEventSynchronize(e1), "smoke kernel");  // (the copy below is not ordered behind a stream of the caller's)
+                hip_ok(hipMemcpy(rgba, P.out, px * 4, hipMemcpyDeviceToHost), "smoke readback");
+            }
             float ms = 0.0f;
             (void)hipEventElapsedTime(&ms, e0, e1);
             (void)hipEventDestroy(e0);

@@ -424,7 +424,7 @@ struct Sim {
         A.G = G;
         A.F = F;
         A.sums = sums;
-        hipLaunchKernelGGL(k_sim<PASS>, grid, block, 0, nullptr, A);
+        hipLaunchKernelGGL(k_sim<PASS>, grid, block, 0, call_stream(), A);
     }
     void sum(std::initializer_list<std::pair<uint32_t, uint32_t>> kinds_slots) {  // (kind, slot of `sums`)
         SumArgs A{};
@@ -438,9 +438,9 @@ struct Sim {
             A.out_slot[A.n_kinds++] = ks.second;
         }
         const uint32_t r = G.ny * G.nz;
-        hipLaunchKernelGGL(k_sum_rows, dim3((r + 63u) / 64u), dim3(64), 0, nullptr, A);
-        hipLaunchKernelGGL(k_sum_slabs, dim3((G.nz + 63u) / 64u), dim3(64), 0, nullptr, A);
-        hipLaunchKernelGGL(k_sum_total, dim3(1), dim3(64), 0, nullptr, A);
+        hipLaunchKernelGGL(k_sum_rows, dim3((r + 63u) / 64u), dim3(64), 0, call_stream(), A);
+        hipLaunchKernelGGL(k_sum_slabs, dim3((G.nz + 63u) / 64u), dim3(64), 0, call_stream(), A);
+        hipLaunchKernelGGL(k_sum_total, dim3(1), dim3(64), 0, call_stream(), A);
     }
 };
 
@@ -477,7 +477,7 @@ void project(Sim &s, uint32_t iterations) {
     SimKernelArgs A{};
     A.a = s.div;
     s.run<kDivergence>(A);
-    ok(hipMemsetAsync(s.F.pressure, 0, s.n * sizeof(float), nullptr), "pressure clear");
+    ok(hipMemsetAsync(s.F.pressure, 0, s.n * sizeof(float), call_stream()), "pressure clear");
     float *cur = s.F.pressure, *next = s.tmp_a;
     for (uint32_t it = 0; it < iterations; it++) {
         A = SimKernelArgs{};
@@ -487,7 +487,7 @@ void project(Sim &s, uint32_t iterations) {
         s.run<kJacobi>(A);
         std::swap(cur, next);
     }
-    if (cur != s.F.pressure) ok(hipMemcpyAsync(s.F.pressure, cur, s.n * sizeof(float), hipMemcpyDeviceToDevice, nullptr), "pressure copy");
+    if (cur != s.F.pressure) ok(hipMemcpyAsync(s.F.pressure, cur, s.n * sizeof(float), hipMemcpyDeviceToDevice, call_stream()), "pressure copy");
     A = SimKernelArgs{};
     A.a = s.F.pressure;
     s.run<kGradient>(A);
@@ -502,9 +502,9 @@ void advect(Sim &s, float *field, const SimSettings &S) {
     if (S.mac_cormack) {
         A.c = s.tmp_b;  // a = old, b = predicted, c = corrected
         s.run<kCorrect>(A);
-        ok(hipMemcpyAsync(field, s.tmp_b, s.n * sizeof(float), hipMemcpyDeviceToDevice, nullptr), "advected field");
+        ok(hipMemcpyAsync(field, s.tmp_b, s.n * sizeof(float), hipMemcpyDeviceToDevice, call_stream()), "advected field");
     } else {
-        ok(hipMemcpyAsync(field, s.tmp_a, s.n * sizeof(float), hipMemcpyDeviceToDevice, nullptr), "advected field");
+        ok(hipMemcpyAsync(field, s.tmp_a, s.n * sizeof(float), hipMemcpyDeviceToDevice, call_stream()), "advected field");
     }
 }
 void diffuse(Sim &s, float *field, float alpha, uint32_t stride, uint32_t comp, float *scratch) {
@@ -567,6 +567,7 @@ extern "C" int f3d_smoke_step(f3d_smoke_state *st, const f3d_smoke_step_settings
             }
             static const char *const kFieldTags[9] = {"smoke.sim.f0", "smoke.sim.f1", "smoke.sim.f2", "smoke.sim.f3", "smoke.sim.f4", "smoke.sim.f5", "smoke.sim.f6", "smoke.sim.f7", "smoke.sim.f8"};
             *dev[f] = (float *)s.alloc(bytes, kFieldTags[f]);
+            ok(hipStreamSynchronize(call_stream()), "smoke state upload");
             ok(hipMemcpy(*dev[f], host[f], bytes, hipMemcpyHostToDevice), "smoke state upload");
         }
         s.tmp_a = (float *)s.alloc(s.n * sizeof(float), "smoke.sim.tmp_a");
@@ -616,7 +617,7 @@ extern "C" int f3d_smoke_step(f3d_smoke_state *st, const f3d_smoke_step_settings
                 if (emitter_count) memcpy(K.inline_emitters, emitters, emitter_count * sizeof(SimEmitter));
             } else {
                 SimEmitter *d_em = (SimEmitter *)s.alloc(emitter_count * sizeof(SimEmitter), "smoke.sim.emitters");
-                ok(hipMemcpyAsync(d_em, emitters, emitter_count * sizeof(SimEmitter), hipMemcpyHostToDevice, nullptr), "emitters");
+                ok(hipMemcpyAsync(d_em, emitters, emitter_count * sizeof(SimEmitter), hipMemcpyHostToDevice, call_stream()), "emitters");
                 K.emitters = d_em;
             }
             K.vel_b = s.vec_a;
@@ -638,13 +639,13 @@ extern "C" int f3d_smoke_step(f3d_smoke_state *st, const f3d_smoke_step_settings
                 constexpr size_t kBarrierBytes = 4 * sizeof(unsigned int);
 #endif
                 K.barrier = (unsigned int *)s.alloc(kBarrierBytes, "smoke.sim.barrier");
-                ok(hipMemsetAsync(K.barrier, 0, kBarrierBytes, nullptr), "barrier clear");
+                ok(hipMemsetAsync(K.barrier, 0, kBarrierBytes, call_stream()), "barrier clear");
                 const uint32_t wanted = (uint32_t)((s.n + kStepBlock - 1u) / kStepBlock);
                 const uint32_t blocks = std::min<uint32_t>((uint32_t)cus, std::max<uint32_t>(wanted, 1u));  // one workgroup a CU: co-resident by construction
                 void *params[1] = {&K};
-                ok(hipEventRecord(e0, nullptr), "event");
-                ok(hipLaunchCooperativeKernel((const void *)k_sim_step, dim3(blocks), dim3(kStepBlock), params, 0u, nullptr), "cooperative launch of the smoke solver");
-                ok(hipEventRecord(e1, nullptr), "event");
+                ok(hipEventRecord(e0, call_stream()), "event");
+                ok(hipLaunchCooperativeKernel((const void *)k_sim_step, dim3(blocks), dim3(kStepBlock), params, 0u, call_stream()), "cooperative launch of the smoke solver");
+                ok(hipEventRecord(e1, call_stream()), "event");
                 ok(hipEventSynchronize(e1), "smoke solver");
                 unsigned int bar[4] = {};
                 ok(hipMemcpy(bar, K.barrier, sizeof(bar), hipMemcpyDeviceToHost), "barrier read-back");
@@ -676,36 +677,36 @@ extern "C" int f3d_smoke_step(f3d_smoke_state *st, const f3d_smoke_step_settings
                 const bool slab_sums = slab_lds <= 60u * 1024u && getenv("F3D_SMOKE_ROW_SUMS") == nullptr;  // (else: a lane a row from global memory)
                 auto sums = [&](const float *density, const SumKinds &kinds) {
                     if (slab_sums) {
-                        hipLaunchKernelGGL(k_phase_sum_slabs, dim3(s.G.nz), dim3(256), slab_lds, nullptr, K, kinds, density);
-                        hipLaunchKernelGGL(k_phase_sum_total, dim3(1), dim3(64), 0, nullptr, K, kinds);
+                        hipLaunchKernelGGL(k_phase_sum_slabs, dim3(s.G.nz), dim3(256), slab_lds, call_stream(), K, kinds, density);
+                        hipLaunchKernelGGL(k_phase_sum_total, dim3(1), dim3(64), 0, call_stream(), K, kinds);
                     } else {
-                        hipLaunchKernelGGL(k_phase_sum_rows, row_grid, dim3(64), 0, nullptr, K, kinds, density);
-                        hipLaunchKernelGGL(k_phase_sum_finish, dim3(1), dim3(256), 0, nullptr, K, kinds);
+                        hipLaunchKernelGGL(k_phase_sum_rows, row_grid, dim3(64), 0, call_stream(), K, kinds, density);
+                        hipLaunchKernelGGL(k_phase_sum_finish, dim3(1), dim3(256), 0, call_stream(), K, kinds);
                     }
                 };
                 auto project_fused = [&](uint32_t iterations) {
-                    hipLaunchKernelGGL(k_phase<kPhDivergence>, grid, block, 0, nullptr, K, C);
+                    hipLaunchKernelGGL(k_phase<kPhDivergence>, grid, block, 0, call_stream(), K, C);
                     C.cur = K.F.pressure;
                     C.next = K.pres_b;
                     uint32_t it = 0;
                     for (; it + 2u <= iterations && !single_sweeps; it += 2u) {  // two sweeps a launch (sim_jacobi_twice)
-                        hipLaunchKernelGGL(k_phase<kPhJacobiTwice>, grid, block, 0, nullptr, K, C);
+                        hipLaunchKernelGGL(k_phase<kPhJacobiTwice>, grid, block, 0, call_stream(), K, C);
                         std::swap(C.cur, C.next);
                     }
                     for (; it < iterations; it++) {
-                        hipLaunchKernelGGL(k_phase<kPhJacobi>, grid, block, 0, nullptr, K, C);
+                        hipLaunchKernelGGL(k_phase<kPhJacobi>, grid, block, 0, call_stream(), K, C);
                         std::swap(C.cur, C.next);
                     }
-                    hipLaunchKernelGGL(k_phase<kPhGradientBoundary>, grid, block, 0, nullptr, K, C);
+                    hipLaunchKernelGGL(k_phase<kPhGradientBoundary>, grid, block, 0, call_stream(), K, C);
                 };
-                if (timed) ok(hipEventRecord(e0, nullptr), "event");
+                if (timed) ok(hipEventRecord(e0, call_stream()), "event");
                 for (uint32_t step = 0; step < steps; step++) {  // SmokeVolume::step, sim.rs:47-139
-                    hipLaunchKernelGGL(k_phase<kPhEmitForces>, grid, block, 0, nullptr, K, C);
-                    hipLaunchKernelGGL(k_phase<kPhAdvectVec>, grid, block, 0, nullptr, K, C);
-                    hipLaunchKernelGGL(k_phase<kPhDiffuseVec>, grid, block, 0, nullptr, K, C);
+                    hipLaunchKernelGGL(k_phase<kPhEmitForces>, grid, block, 0, call_stream(), K, C);
+                    hipLaunchKernelGGL(k_phase<kPhAdvectVec>, grid, block, 0, call_stream(), K, C);
+                    hipLaunchKernelGGL(k_phase<kPhDiffuseVec>, grid, block, 0, call_stream(), K, C);
                     if (S.vorticity > 0.0f) {
-                        hipLaunchKernelGGL(k_phase<kPhCurl>, grid, block, 0, nullptr, K, C);
-                        hipLaunchKernelGGL(k_phase<kPhConfine>, grid, block, 0, nullptr, K, C);
+                        hipLaunchKernelGGL(k_phase<kPhCurl>, grid, block, 0, call_stream(), K, C);
+                        hipLaunchKernelGGL(k_phase<kPhConfine>, grid, block, 0, call_stream(), K, C);
                     }
                     project_fused(std::max(1u, S.pressure_iterations));
                     SumKinds before{};
@@ -716,11 +717,11 @@ extern "C" int f3d_smoke_step(f3d_smoke_state *st, const f3d_smoke_step_settings
                     }
                     if (S.mass_conservation) before.kind[before.n] = 0u, before.slot[before.n++] = 3u;
                     if (before.n != 0u) sums(K.F.density, before);
-                    if (S.turbulence_strength > 0.0f) hipLaunchKernelGGL(k_phase<kPhLaneShear>, grid, block, 0, nullptr, K, C);
-                    hipLaunchKernelGGL(k_phase<kPhAdvectScalars>, grid, block, 0, nullptr, K, C);
+                    if (S.turbulence_strength > 0.0f) hipLaunchKernelGGL(k_phase<kPhLaneShear>, grid, block, 0, call_stream(), K, C);
+                    hipLaunchKernelGGL(k_phase<kPhAdvectScalars>, grid, block, 0, call_stream(), K, C);
                     C.corrected = 0u;
                     if (S.mac_cormack) {
-                        hipLaunchKernelGGL(k_phase<kPhCorrectScalars>, grid, block, 0, nullptr, K, C);
+                        hipLaunchKernelGGL(k_phase<kPhCorrectScalars>, grid, block, 0, call_stream(), K, C);
                         C.corrected = 1u;
                     }
                     if (S.mass_conservation) {
@@ -728,8 +729,8 @@ extern "C" int f3d_smoke_step(f3d_smoke_state *st, const f3d_smoke_step_settings
                         after.n = 1u;  // kind 0 -> slot 0
                         sums(C.corrected ? K.adv2[0] : K.adv[0], after);
                     }
-                    hipLaunchKernelGGL(k_phase<kPhScaleSubgrid>, grid, block, 0, nullptr, K, C);
-                    hipLaunchKernelGGL(k_phase<kPhDiffuseDecay>, grid, block, 0, nullptr, K, C);
+                    hipLaunchKernelGGL(k_phase<kPhScaleSubgrid>, grid, block, 0, call_stream(), K, C);
+                    hipLaunchKernelGGL(k_phase<kPhDiffuseDecay>, grid, block, 0, call_stream(), K, C);
                     project_fused(std::max(1u, S.pressure_iterations / 2u));
                     s.G.time_seconds += S.dt;
                     s.G.frame_index += 1u;
@@ -737,14 +738,14 @@ extern "C" int f3d_smoke_step(f3d_smoke_state *st, const f3d_smoke_step_settings
                 }
                 ok(hipGetLastError(), "smoke solver kernels");
                 if (timed) {
-                    ok(hipEventRecord(e1, nullptr), "event");
+                    ok(hipEventRecord(e1, call_stream()), "event");
                     ok(hipEventSynchronize(e1), "smoke solver");
                 }
             }
         } else {
-        ok(hipEventRecord(e0, nullptr), "event");
+        ok(hipEventRecord(e0, call_stream()), "event");
         for (uint32_t step = 0; step < steps; step++) {  // SmokeVolume::step, sim.rs:47-139
-            ok(hipMemsetAsync(s.F.emission_rate, 0, s.n * sizeof(float), nullptr), "emission clear");
+            ok(hipMemsetAsync(s.F.emission_rate, 0, s.n * sizeof(float), call_stream()), "emission clear");
             for (uint32_t e = 0; e < emitter_count; e++)
                 if (s.G.time_seconds >= emitters[e].start_time && s.G.time_seconds <= emitters[e].end_time) {
                     SimKernelArgs A{};
@@ -758,14 +759,14 @@ extern "C" int f3d_smoke_step(f3d_smoke_state *st, const f3d_smoke_step_settings
             A.S = S;
             s.run<kForces>(A);
             // velocity = advect_vector(velocity_before, velocity_before)
-            ok(hipMemcpyAsync(s.vec_a, s.F.velocity, 3 * s.n * sizeof(float), hipMemcpyDeviceToDevice, nullptr), "velocity copy");
+            ok(hipMemcpyAsync(s.vec_a, s.F.velocity, 3 * s.n * sizeof(float), hipMemcpyDeviceToDevice, call_stream()), "velocity copy");
             A = SimKernelArgs{};
             A.a = s.vec_a;
             A.b = s.F.velocity;
             A.dt = S.dt;
             s.run<kAdvectVec>(A);
             if (S.diffusion > 0.0f) {  // diffuse_vector, sim.rs:739-754: component by component over a copy
-                ok(hipMemcpyAsync(s.vec_a, s.F.velocity, 3 * s.n * sizeof(float), hipMemcpyDeviceToDevice, nullptr), "velocity copy");
+                ok(hipMemcpyAsync(s.vec_a, s.F.velocity, 3 * s.n * sizeof(float), hipMemcpyDeviceToDevice, call_stream()), "velocity copy");
                 for (uint32_t c = 0; c < 3u; c++) {
                     A = SimKernelArgs{};
                     A.a = s.vec_a;
@@ -807,7 +808,7 @@ extern "C" int f3d_smoke_step(f3d_smoke_state *st, const f3d_smoke_step_settings
                 float *fields[5] = {s.F.density, s.F.temperature, s.F.fuel, s.F.soot, s.F.humidity};
                 for (float *f : fields) {
                     diffuse(s, f, S.diffusion * S.dt, 1u, 0u, s.tmp_a);
-                    ok(hipMemcpyAsync(f, s.tmp_a, s.n * sizeof(float), hipMemcpyDeviceToDevice, nullptr), "diffused field");
+                    ok(hipMemcpyAsync(f, s.tmp_a, s.n * sizeof(float), hipMemcpyDeviceToDevice, call_stream()), "diffused field");
                 }
             }
             s.run<kDecay>(A);
@@ -816,7 +817,7 @@ extern "C" int f3d_smoke_step(f3d_smoke_state *st, const f3d_smoke_step_settings
             s.G.time_seconds += S.dt;
             s.G.frame_index += 1u;
         }
-        ok(hipEventRecord(e1, nullptr), "event");
+        ok(hipEventRecord(e1, call_stream()), "event");
         ok(hipEventSynchronize(e1), "smoke solver");
         }
         ok(hipGetLastError(), "smoke solver kernels");

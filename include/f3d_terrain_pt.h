@@ -35,8 +35,9 @@ extern "C" {
  *               f3d_session_set_accumulation, f3d_smoke_step, f3d_smoke_composite, f3d_aether_reference_render
  *   4  round 4: + f3d_session_halo_stats / f3d_halo_stats, f3d_session_halo_probe modes 2 and 3 (no existing struct
  *               changed: a caller built against version 3 keeps working)
- *   5  round 5: + f3d_session_row_costs; the smoke entry points return without waiting when their results stay on the
- *               device and no time is asked for (no existing struct or signature changed) */
+ *   5  round 5: + f3d_session_row_costs, f3d_session_primary_start, f3d_smoke_set_stream, f3d_smoke_wait_fields_read; the
+ *               smoke entry points return without waiting when their results stay on the device and no time is asked for;
+ *               f3d_wf_scene + primary_start at its end (no existing signature changed) */
 #define F3D_ABI_VERSION 5u
 #define F3D_STATUS_OK 0
 #define F3D_STATUS_VALUE 1
@@ -396,12 +397,21 @@ typedef struct f3d_smoke_settings { /* SmokeRenderSettings, reference src/smoke/
  * (optional) receives the ray-march kernel's device time.  Errors carry the reference's message texts.
  * Each of the six fields, and rgba, may be a DEVICE pointer: such a field is read where it is and a device image is
  * left on the device (a resident smoke sequence: f3d_smoke_step on device fields -> f3d_smoke_render -> f3d_smoke_composite).
- * The three smoke entry points launch on the NULL stream and keep their scratch between calls (freed by
- * f3d_device_pool_trim).  A call whose results stay on the device and whose time pointer (kernel_seconds /
- * device_seconds) is NULL returns as soon as its launches are enqueued: order other streams behind the null stream
- * (an event) before reading its outputs; errors of the kernels themselves then surface in a later call. */
+ * The three smoke entry points launch on the calling thread's smoke stream -- the NULL stream until f3d_smoke_set_stream
+ * names another -- and keep their scratch between calls (freed by f3d_device_pool_trim).  A call whose results stay on
+ * the device and whose time pointer (kernel_seconds / device_seconds) is NULL returns as soon as its launches are enqueued:
+ * order other streams behind that stream (an event) before reading its outputs; errors of the kernels themselves then
+ * surface in a later call. */
 int f3d_smoke_render(const f3d_smoke_volume *volume, const f3d_smoke_view *view, const f3d_smoke_settings *settings,
                      uint8_t *rgba, double *kernel_seconds, char *err, size_t errlen);
+/* The stream (a hipStream_t; NULL = the null stream) on which the calling thread's next f3d_smoke_step / f3d_smoke_render /
+ * f3d_smoke_composite calls enqueue.  With the solver on one stream and the marcher on another, step f + 1 runs beside
+ * the march of frame f: the marcher reads the volume's fields only in its first kernels (it re-packs them), and
+ * f3d_smoke_wait_fields_read makes `stream` wait for exactly that point of the calling thread's LAST f3d_smoke_render
+ * (a no-op before the first).  Scratch is per entry point, not per stream: keep each entry point on one stream.
+ * (No counterpart in the reference, whose solver and marcher are host loops.) */
+void f3d_smoke_set_stream(void *stream);
+int f3d_smoke_wait_fields_read(void *stream);
 
 /* ---- smoke transport solver (the 120-frame sequence of BASELINE.json configs[4] needs its fields from somewhere) -----------
  * Replaces SmokeVolume::step / add_emitter (reference src/smoke/sim.rs:7-139, bound to Python as SmokeDomain.step,

@@ -5,6 +5,7 @@ F3D_SMOKE_SOLVER=launches.
 
     python tools/c5_time.py [frames=120]
 """
+import os
 import sys
 import time
 from pathlib import Path
@@ -27,11 +28,12 @@ view = dict(camera_pos=(48.0, 70.0, -120.0), target=(48.0, 28.0, 64.0), up=(0.0,
 yy, xx = np.mgrid[0:H, 0:W]
 terrain = np.stack([(xx * 255 // (W - 1)), (yy * 255 // (H - 1)), np.full_like(xx, 96), np.full_like(xx, 255)], axis=-1).astype(np.uint8)
 seq = smoke.SmokeSequence(dom, terrain, **view)
-for _ in seq.frames(40, settings, emitters):
+overlap = not os.environ.get("F3D_C5_NO_OVERLAP")  # A/B: everything on the null stream
+for _ in seq.frames(40, settings, emitters, overlap=overlap):
     pass
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-for frame in seq.frames(frames, settings, emitters):
+for frame in seq.frames(frames, settings, emitters, overlap=overlap):
     last = frame
 wall = (time.perf_counter() - t0) * 1e3 / frames
 import hashlib  # noqa: E402
