@@ -308,14 +308,21 @@ __device__ float sun_transmittance(const SmokeParams &P, const SmokeBox &box, V3
         i_end = (uint32_t)f_min(f_max(last, 0.0f), (float)i_end);
     }
 #endif
+    bool in_smoke = false;  // the step before this one had smoke under it: this one is not asked about, its gathers go out at once
     for (; i < i_end; i++) {
         const float tt = t0 + ((float)i + 0.5f) * P.shadow_step;
         if (tt > t1) break;
         const Tap t = make_tap(P, vadd(start, vscale(P.sun, P.shadow_step + tt)));
 #if !defined(F3D_SMOKE_NO_SKIP)  // A/B + test-of-the-tests switch
-        if (P.occupied[t.block] == 0u) continue;  // density +-0 at all eight corners: the step adds +-0 to od (and od > 8 was tested when it last grew)
+        // density +-0 at all eight corners: the step adds +-0 to od (and od > 8 was tested when it last grew).  The map only
+        // ever saves work -- a step that is evaluated although its corners are all zero adds the same +-0 -- so inside the
+        // plume, where the answer is almost always "occupied", the byte's round trip is left out
+        if (!in_smoke && P.occupied[t.block] == 0u) continue;
 #endif
         const float density = F3D_TRI(P.rec_a, x), soot = F3D_TRI(P.rec_a, y), age = f_max(F3D_TRI(P.rec_a, z), 0.0f);
+#if !defined(F3D_SMOKE_ALWAYS_ASK)
+        in_smoke = density != 0.0f;
+#endif
         const float age_t = smoothstep_known<0>(age);
         const float gate = 0.50f + 0.50f * smoothstep_known<1>(density);
         od += density * P.st.density_scale * (1.0f - 0.58f * age_t) * gate * P.st.extinction *
@@ -438,6 +445,7 @@ __device__ uchar4 march_ray(const SmokeParams &P, const SmokeBox &box, V3 origin
     const float denom = f_max(1.0f + g2 - 2.0f * P.st.phase_g * cos_theta, 1.0e-4f);
     const float phase = (1.0f - g2) / (4.0f * kPi * (denom * f_sqrt(denom)));
     uint32_t steps = 0u, k = 0u;
+    bool in_smoke = false;
 #if !defined(F3D_SMOKE_NO_SKIP) && !defined(F3D_SMOKE_NO_CLIP)
     float ta, tb;
     smoke_clip(box, origin, dir, inv3(dir), t1, ta, tb);
@@ -450,12 +458,17 @@ __device__ uchar4 march_ray(const SmokeParams &P, const SmokeBox &box, V3 origin
         const V3 p = vadd(origin, vscale(dir, t));
         const Tap tp = make_tap(P, p);
 #if !defined(F3D_SMOKE_NO_SKIP)
-        if (P.occupied[tp.block] == 0u) continue;  // density +-0 at all eight corners: the reference's `density > 1e-5` test skips the step
+        // density +-0 at all eight corners: the reference's `density > 1e-5` test skips the step (asked only when the step
+        // before had no smoke: see sun_transmittance)
+        if (!in_smoke && P.occupied[tp.block] == 0u) continue;
 #endif
         const Tap &t_ = tp;
 #define t t_
         const float s_density = F3D_TRI(P.rec_a, x), s_soot = F3D_TRI(P.rec_a, y), s_age = f_max(F3D_TRI(P.rec_a, z), 0.0f);
 #undef t
+#if !defined(F3D_SMOKE_ALWAYS_ASK)
+        in_smoke = s_density != 0.0f;
+#endif
         const float age_t = smoothstep_known<0>(s_age);
         const float gate = 0.50f + 0.50f * smoothstep_known<1>(s_density);
         const float density = f_max(s_density * P.st.density_scale * (1.0f - 0.58f * age_t) * gate, 0.0f);

@@ -17,17 +17,21 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 WHAT = {  # config -> (summary file, kernel name prefix in the summary, launches of it that make one "unit", unit)
     "C4_standin": ("C4", "void f3d::k_frame<0, 6, 4u, true>", "frame of 4096 x 4096 x 8 spp"),
     "C3_gi": ("C3_gi", "void (anonymous namespace)::k_wf_paths<true>" if tag < "r05" else "void (anonymous namespace)::k_wf_paths<true, true>", "launch of 1920 x 1080 x 32 paths"),
-    "C5_march": ("C5", "(anonymous namespace)::k_smoke(", "1080p frame of the smoke marcher"),
+    "C5_march": ("C5", "(anonymous namespace)::k_smoke(" if tag < "r05" else "(anonymous namespace)::k_smoke_light(", "1080p frame of the smoke marcher" if tag < "r05" else "self-shadow marches of a 1080p smoke frame"),
     "C5_solver_jacobi": ("C5", "void (anonymous namespace)::k_sim<7u>" if tag < "r05" else "void (anonymous namespace)::k_phase<6u>", "Jacobi sweep of the 96 x 64 x 128 domain"),
     "strip_trace": ("strip", "void f3d::k_trace<6, 8u, false>", "batch of <= 16 frames of an eighth of the 1080p frame"),
     "strip_merge": ("strip", "f3d::k_merge(", "strip-frame"),
     "strip_fused": ("strip_fused", "void f3d::k_frame<0, 6, 8u, false>", "strip-frame (fused kernel, 8 lanes)"),
 }
+if tag >= "r05":  # the marcher is three launches from round 5 on (csrc/f3d_smoke.hip)
+    WHAT["C5_march_collect"] = ("C5", "void (anonymous namespace)::k_smoke_rays<1u>", "ray walk that lists the smoke steps of a 1080p frame")
+    WHAT["C5_march_shade"] = ("C5", "(anonymous namespace)::k_smoke_shade(", "shading of the listed steps of a 1080p frame")
 out = {}
 for key, (cfg, kernel, unit) in WHAT.items():
     path = ROOT / "profiles" / f"{tag}_{cfg}_rocprofv3_summary.txt"
     text = path.read_text().splitlines()
     src = re.search(r"kernel sources: (\w+)", text[0])
+    lib_src = re.search(r"library sources: (\w+)", text[0])
     counters, avg_ns, calls = {}, None, None
     for line in text:
         if not line.startswith(kernel[:44]) and not line.startswith(kernel):
@@ -45,7 +49,8 @@ for key, (cfg, kernel, unit) in WHAT.items():
         continue
     c = counters
     row = {"kernel": kernel.replace("void ", "").rstrip("("), "per": unit, "kernel_ms": avg_ns / 1e6, "calls_profiled": calls,
-           "kernel_source_hash": src.group(1) if src else None, "profile": f"profiles/{path.name}"}
+           "kernel_source_hash": src.group(1) if src else None, "library_source_digest": lib_src.group(1) if lib_src else None,
+           "profile": f"profiles/{path.name}"}
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
         row.update(hbm_bytes_per_launch=int(traffic), roofline={"bound": "hbm", "achieved": traffic / (avg_ns * 1e-9) / 1e9, "peak": 8000.0, "unit": "GB/s",

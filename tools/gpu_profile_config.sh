@@ -13,7 +13,7 @@ timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIV
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE TCC_HIT_sum -d $OUT/pmc3 -o w -- $CMD > $OUT/pmc3.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum -d $OUT/pmc4 -o w -- $CMD > $OUT/pmc4.log 2>&1
 cd $R
-{ echo "# workload: python tools/config_workload.py $CFG   kernel sources: $(python -c 'import bench; print(bench.kernel_source_hash())')"; tail -3 $OUT/trace.log; python tools/rocpd_summary.py $OUT; } > $OUT/summary.txt 2>&1
+{ echo "# workload: python tools/config_workload.py $CFG   kernel sources: $(python -c 'import bench; print(bench.kernel_source_hash())')   library sources: $(python -c 'from forge3d_amd import _native; print(_native.source_digest()[:16])')"; tail -3 $OUT/trace.log; python tools/rocpd_summary.py $OUT; } > $OUT/summary.txt 2>&1
 python tools/trace_gaps.py $OUT/trace >> $OUT/summary.txt 2>&1
 rm -rf $OUT/pmc*/*.db   # (keep the trace db for the timeline, drop the counter dbs: the summary has their averages)
 grep -A14 "==== trace" $OUT/summary.txt | head -24
