@@ -61,7 +61,7 @@ elif what == "C5":
     yy, xx = np.mgrid[0:1080, 0:1920]
     terrain = np.stack([(xx * 255 // 1919), (yy * 255 // 1079), np.full_like(xx, 96), np.full_like(xx, 255)], axis=-1).astype(np.uint8)
     seq = smoke.SmokeSequence(dom, terrain, **view)  # the resident sequence bench.py times: solver phases, pack, march, composite per frame
-    for _ in seq.frames(16, settings, emitters):
+    for _ in seq.frames(16, settings, emitters, overlap=False):  # (one kernel after the other: clean durations; bench.py's sequence runs the solver beside the march)
         pass
 elif what in ("strip", "strip_fused"):
     # rows of the heaviest strip of the balanced 8-strip partition (profiles/r04_strip_balance.log)
