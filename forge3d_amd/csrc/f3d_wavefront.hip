@@ -166,7 +166,7 @@ struct DeviceScope {  // the caller's current device is restored on every exit p
 
 }  // namespace
 
-extern "C" int f3d_wavefront_render(const f3d_wf_scene *scene, uint32_t width, uint32_t height, uint32_t first_frame,
+extern "C" int f3d_wavefront_render(const f3d_wf_scene *scene_in, uint32_t width, uint32_t height, uint32_t first_frame,
                                     uint32_t frame_count, uint32_t frames_per_launch, int32_t device, f3d_wf_out *out, char *err,
                                     size_t errlen) {
     if (err && errlen) err[0] = 0;
@@ -174,7 +174,9 @@ extern "C" int f3d_wavefront_render(const f3d_wf_scene *scene, uint32_t width, u
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = F3D_STATUS_OK;
     try {
-        if (!scene || !out) fail(F3D_STATUS_VALUE, "null argument");
+        if (!scene_in || !out) fail(F3D_STATUS_VALUE, "null argument");
+        const f3d_wf_scene scene_now = wf::scene_of_caller(scene_in);
+        const f3d_wf_scene *scene = &scene_now;
         wf::validate_scene(*scene, width, height, frame_count);
         if ((uint64_t)first_frame + frame_count > 0xFFFFFFFFull) fail(F3D_STATUS_VALUE, "frame range overflows u32");
         DeviceScope scope(device);

@@ -5,6 +5,8 @@
 // importances and their sums, the camera's half extents -- is computed here once, with the same f32 helpers the
 // device uses, so the per-hit arithmetic of the reference (pt_shade.wgsl:118-152, 598-697) keeps its results.
 #pragma once
+#include <cstddef>
+#include <cstring>
 
 #include <cmath>
 #include <vector>
@@ -20,6 +22,20 @@ inline bool finite_n(const float *v, int n) {
     for (int i = 0; i < n; i++)
         if (!std::isfinite(v[i])) return false;
     return true;
+}
+
+// The caller's f3d_wf_scene as this revision of the header lays it out: the struct has only ever grown at its end, so a
+// caller built against an earlier revision (no `primary_start`) is read up to its own size and the rest is zero.
+inline f3d_wf_scene scene_of_caller(const f3d_wf_scene *s) {
+    uint32_t size = 0;
+    memcpy(&size, s, sizeof(size));  // (struct_size is the first member in every revision)
+    if (size != sizeof(f3d_wf_scene) && size != offsetof(f3d_wf_scene, primary_start))
+        fail(F3D_STATUS_VALUE, "f3d_wf_scene.struct_size is %u, this library expects %zu: the caller was built against another revision of f3d_wavefront.h",
+             size, sizeof(f3d_wf_scene));
+    f3d_wf_scene full{};
+    memcpy(&full, s, size);
+    full.struct_size = (uint32_t)sizeof(f3d_wf_scene);
+    return full;
 }
 
 inline void validate_scene(const f3d_wf_scene &s, uint32_t width, uint32_t height, uint32_t frame_count) {

@@ -152,6 +152,29 @@ def test_abi_version_and_struct_size_are_enforced(native):
     assert b"f3d_session_opts.struct_size" in err.value and not handle.value
 
 
+def test_a_wavefront_scene_of_the_previous_header_revision_is_still_read(native):
+    """f3d_wf_scene has only grown at its end (round 5: + primary_start): a caller whose struct ends in front of the new member
+    gets past the size check (and then fails for want of a device here, status 4), any other size is refused (status 1)."""
+    from forge3d_amd import wavefront as w
+
+    s, keep = w._marshal(w.adjudication_scene().wavefront_scene().as_dict())
+    hdr, rgba, acc = np.zeros((8, 8, 4), np.float32), np.zeros((8, 8, 4), np.uint8), np.zeros((8, 8, 4), np.float32)
+    out = w._Out(hdr.ctypes.data, rgba.ctypes.data, acc.ctypes.data, 0.0, 0, 0)
+    err = C.create_string_buffer(512)
+
+    def call(size):
+        s.struct_size = size
+        return native.lib().f3d_wavefront_render(C.byref(s), 8, 8, 0, 1, 1, 0, C.byref(out), err, 512)
+
+    full, previous = C.sizeof(w._Scene), w._Scene.primary_start.offset
+    assert previous == full - 8
+    for size in (full, previous):
+        rc = call(size)
+        assert rc != native.STATUS_VALUE or b"struct_size" not in err.value
+    for size in (0, previous - 8, full + 8):
+        assert call(size) == native.STATUS_VALUE and b"struct_size" in err.value
+
+
 def test_version_and_device_probe(native):
     L = native.lib()
     assert b"gfx950" in L.f3d_version()
