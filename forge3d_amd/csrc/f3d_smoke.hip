@@ -624,183 +624,11 @@ __global__ __launch_bounds__(64) void k_smoke_shade(const SmokeParams P, const D
     reinterpret_cast<uchar4 *>(P.out)[(size_t)y * P.width + x] = smoke_pixel(P, rgb, transmittance);
 }
 
-// ---- sift + cooperative march (round 5) ------------------------------------------------------------------------------------
-// The frame of BASELINE.json configs[4] has 68 000 pixels with smoke in 2 million; their rays -- a self-shadow march of 20
-// steps at every one of ~40 steps inside the plume, each step eight dependent 16-byte gathers -- are 1 100 waves' worth of
-// one-lane-per-pixel work on a chip with 1 024 SIMDs: one wave a SIMD, each waiting for its own loads (lane use 0.93, VALU issue
-// 0.31, 1.4 ms: profiles/r04_config_rooflines.json).  So the frame is taken in two launches:
-//   k_smoke_sift   one lane per pixel: the ray's steps up to the first one that touches smoke at all (the empty-space map,
-//                  k_smoke_pack) -- no loads but the map's byte; rays that never get there are finished (no smoke: 0), the
-//                  others are appended, ballot-compacted, to a list with the state the march resumes from (steps taken, t).
-//   k_smoke_heavy  EIGHT lanes per listed pixel, eight pixels a wave, waves fetching work from a cursor: the lanes of a
-//                  pixel walk its ray together (every value of the reference's loop is replicated in all eight) and share
-//                  what is parallel in it: the self-shadow march, whose steps are independent of each other.  Lane j
-//                  evaluates steps j, j + 8, j + 16 ... and the group then adds the eight terms of a round in step order,
-//                  with the reference's two exits (the ray leaves the box; optical depth > 8) tested where the reference
-//                  tests them -- so the sum is the sequential sum, bit for bit.  Eight times the waves, a third of the
-//                  dependent gathers per step.
-// Results are those of k_smoke (and the oracle) bit for bit: tests/test_smoke.py.
-// MEASURED, NOT ADOPTED (F3D_SMOKE_MARCH=sift runs it; profiles/README.md round 5): 1.65 ms against k_smoke's 1.46 ms on
-// the configs[4] frame, and worse with more waves a SIMD (1.91 / 2.70 ms at 6 / 8: spills).  The premise was wrong: the
-// marcher is not waiting for too few waves' loads, it is bound by what the texture addressers can gather -- TA busy 61 %
-// of the launch, 95 % of the gathers hit L1, 22 addresser cycles per 16-byte x 64-lane gather -- and eight lanes that
-// replicate a pixel's primary taps and spread its shadow taps along the sun direction touch MORE cache lines per gather
-// than 64 neighbouring pixels do.  What did pay is the empty-space map alone (1.60 -> 1.46 ms).
-struct HeavyItem {
-    uint32_t pixel, steps;
-    float t;
-};
-struct SiftParams {
-    SmokeParams P;
-    HeavyItem *items;
-    uint32_t *counters;  // [0] listed pixels, [1] work cursor of k_smoke_heavy
-};
-constexpr uint32_t kGroup = 8u;  // lanes per pixel in k_smoke_heavy
-
-__global__ __launch_bounds__(64) void k_smoke_sift(const SiftParams S) {
-    const SmokeParams &P = S.P;
-    const uint32_t tiles_x = (P.width + 7u) / 8u;
-    const uint32_t x = (blockIdx.x % tiles_x) * 8u + (threadIdx.x & 7u), y = (blockIdx.x / tiles_x) * 8u + (threadIdx.x >> 3);
-    const bool inside = x < P.width && y < P.height;
-    bool heavy = false;
-    HeavyItem item{0u, 0u, 0.0f};
-    if (inside) {
-        V3 origin, dir;
-        uint32_t seed;
-        pixel_ray(P, x, y, origin, dir, seed);
-        float t0, t1;
-        if (ray_box(origin, dir, P.bmin, P.bmax, t0, t1)) {
-            uint32_t v = seed;  // hash01, sampling.rs:96-103 (as march_ray)
-            v ^= v >> 16;
-            v *= 0x7FEB352Du;
-            v ^= v >> 15;
-            v *= 0x846CA68Bu;
-            v ^= v >> 16;
-            const float jitter = ((float)v / 4294967296.0f - 0.5f) * P.st.jitter_strength * P.step;
-            float t = f_max(f_max(t0, 0.0f) + jitter, 0.0f);
-            uint32_t steps = 0u;
-            // the steps that touch no smoke: march_ray's loop with its body skipped (transmittance stays 1)
-            for (; t < t1 && steps < P.st.max_steps; steps++, t += P.step) {
-#if !defined(F3D_SMOKE_NO_SKIP)
-                if (P.occupied[make_tap(P, vadd(origin, vscale(dir, t))).block] != 0u) break;
-#else
-                break;
-#endif
-            }
-            heavy = t < t1 && steps < P.st.max_steps;
-            item = HeavyItem{y * P.width + x, steps, t};
-        }
-        if (!heavy) reinterpret_cast<uchar4 *>(P.out)[(size_t)y * P.width + x] = uchar4{0, 0, 0, 0};
-    }
-    const unsigned long long mask = __ballot(heavy);
-    if (mask != 0ull) {
-        uint32_t base = 0u;
-        const uint32_t lane = threadIdx.x & 63u;
-        if (lane == (uint32_t)__builtin_ctzll(mask)) base = atomicAdd(&S.counters[0], (uint32_t)__popcll(mask));
-        base = (uint32_t)__shfl((int)base, __builtin_ctzll(mask), 64);
-        if (heavy) S.items[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = item;
-    }
-}
-
-// sun_transmittance (render.rs:290-330) by the kGroup lanes of a pixel: see above.  `sub` = the lane's number in its group.
-__device__ float sun_transmittance_group(const SmokeParams &P, V3 start, uint32_t sub, uint32_t group_shift) {
-    float t0, t1;
-    if (!ray_box(vadd(start, vscale(P.sun, P.shadow_step)), P.sun, P.bmin, P.bmax, t0, t1)) return 1.0f;
-    t0 = f_max(t0, 0.0f);
-    float od = 0.0f;
-    bool done = false;
-    for (uint32_t i0 = 0u; i0 < P.st.shadow_steps && !done; i0 += kGroup) {
-        const uint32_t i = i0 + sub;
-        const float tt = t0 + ((float)i + 0.5f) * P.shadow_step;
-        const bool ends = !(i < P.st.shadow_steps) || tt > t1;  // the loop ends in front of this step
-        bool adds = false;
-        float term = 0.0f;
-        if (!ends) {
-            const Tap t = make_tap(P, vadd(start, vscale(P.sun, P.shadow_step + tt)));
-#if !defined(F3D_SMOKE_NO_SKIP)
-            if (P.occupied[t.block] != 0u)
-#endif
-            {
-                const float density = F3D_TRI(P.rec_a, x), soot = F3D_TRI(P.rec_a, y), age = f_max(F3D_TRI(P.rec_a, z), 0.0f);
-                const float age_t = smoothstep_ref(1.6f, 17.0f, age);
-                const float gate = 0.50f + 0.50f * smoothstep_ref(0.045f, 0.34f, density);
-                term = density * P.st.density_scale * (1.0f - 0.58f * age_t) * gate * P.st.extinction * (1.0f + soot * P.st.soot_absorption) * P.shadow_step;
-                adds = true;
-            }
-        }
-        const uint32_t ends_mask = (uint32_t)(__ballot(ends) >> group_shift) & 0xFFu, adds_mask = (uint32_t)(__ballot(adds) >> group_shift) & 0xFFu;
-#pragma unroll
-        for (uint32_t k = 0u; k < kGroup; k++) {
-            const float term_k = __shfl(term, (int)k, (int)kGroup);
-            if (!done) {
-                if ((ends_mask >> k) & 1u) {
-                    done = true;
-                } else if ((adds_mask >> k) & 1u) {
-                    od += term_k;
-                    if (od > 8.0f) done = true;
-                }
-            }
-        }
-    }
-    return f_clamp(exp_det(-od), 0.0f, 1.0f);
-}
-
-#ifndef F3D_SMOKE_HEAVY_WAVES
-#define F3D_SMOKE_HEAVY_WAVES 4
-#endif
-__global__ __launch_bounds__(64, F3D_SMOKE_HEAVY_WAVES) void k_smoke_heavy(const SiftParams S) {
-    const SmokeParams &P = S.P;
-    const uint32_t lane = threadIdx.x & 63u, sub = lane & (kGroup - 1u), group_shift = lane & ~(kGroup - 1u);
-    const uint32_t count = S.counters[0];
-    for (;;) {
-        uint32_t base = 0u;
-        if (lane == 0u) base = atomicAdd(&S.counters[1], 64u / kGroup);
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        if (base >= count) return;
-        const uint32_t index = base + (lane >> 3);
-        if (index < count) {  // (the last fetch's spare groups idle until the wave fetches again)
-        const HeavyItem item = S.items[index];
-        const uint32_t x = item.pixel % P.width, y = item.pixel / P.width;
-        V3 origin, dir;
-        uint32_t seed;
-        pixel_ray(P, x, y, origin, dir, seed);
-        float t0, t1;
-        (void)ray_box(origin, dir, P.bmin, P.bmax, t0, t1);  // (k_smoke_sift found the box: t1 as it computed it)
-        // march_ray from the listed step on
-        float t = item.t, transmittance = 1.0f;
-        V3 rgb = V3{0.0f, 0.0f, 0.0f};
-        const float cos_theta = f_clamp(vdot(dir, P.sun), -1.0f, 1.0f);
-        const float g2 = P.st.phase_g * P.st.phase_g;
-        const float denom = f_max(1.0f + g2 - 2.0f * P.st.phase_g * cos_theta, 1.0e-4f);
-        const float phase = (1.0f - g2) / (4.0f * kPi * (denom * f_sqrt(denom)));
-        for (uint32_t steps = item.steps; t < t1 && steps < P.st.max_steps && transmittance > 0.01f; steps++, t += P.step) {
-            const V3 p = vadd(origin, vscale(dir, t));
-            const Tap tp = make_tap(P, p);
-#if !defined(F3D_SMOKE_NO_SKIP)
-            if (P.occupied[tp.block] == 0u) continue;
-#endif
-            const Tap &t_ = tp;
-#define t t_
-            const float s_density = F3D_TRI(P.rec_a, x), s_soot = F3D_TRI(P.rec_a, y), s_age = f_max(F3D_TRI(P.rec_a, z), 0.0f);
-#undef t
-            const float age_t = smoothstep_ref(1.6f, 17.0f, s_age);
-            const float gate = 0.50f + 0.50f * smoothstep_ref(0.045f, 0.34f, s_density);
-            const float density = f_max(s_density * P.st.density_scale * (1.0f - 0.58f * age_t) * gate, 0.0f);
-            if (!(density > 1.0e-5f)) continue;
-#define t t_
-            const float s_temperature = F3D_TRI(P.rec_a, w), s_humidity = F3D_TRI(P.rec_b, x), s_emission = F3D_TRI(P.rec_b, y);
-#undef t
-            const float sigma_t = density * P.st.extinction * (1.0f + s_soot * P.st.soot_absorption * 0.85f);
-            const float seg_tr = f_clamp(exp_det(-sigma_t * P.step), 0.0f, 1.0f);
-            const float seg_w = sigma_t > 1.0e-6f ? (1.0f - seg_tr) / sigma_t : P.step;
-            const float light = P.st.self_shadow ? sun_transmittance_group(P, p, sub, group_shift) : 1.0f;
-            rgb = vadd(rgb, vscale(vscale(smoke_source(P, p, s_density, s_soot, s_age, s_temperature, s_humidity, s_emission, sigma_t, light, phase), seg_w), transmittance));
-            transmittance *= seg_tr;
-        }
-        if (sub == 0u) reinterpret_cast<uchar4 *>(P.out)[item.pixel] = smoke_pixel(P, rgb, transmittance);
-        }
-    }
-}
+// (Round 5 first built the verdict's prescription -- the pixels that meet smoke sifted into a list, then eight cooperating
+// lanes per listed pixel sharing each self-shadow march -- and measured it: bit-identical, 1.65 ms against the one-kernel
+// form's 1.46, because it repeats a pixel's primary taps eightfold and spreads a wave's gathers over more cache lines.
+// Taking the marches OUT of the ray, above, gives the parallelism without either; the sift form is in the history
+// (commit a4420a0 and before), its numbers in profiles/README.md.)
 
 void hip_ok(hipError_t e, const char *what) {
     if (e != hipSuccess) fail(F3D_STATUS_DEVICE, "HIP failure in %s: %s", what, hipGetErrorString(e));
@@ -1013,19 +841,11 @@ extern "C" int f3d_smoke_render(const f3d_smoke_volume *vol, const f3d_smoke_vie
             hip_ok(hipMemsetAsync(D.cursor, 0, sizeof(uint32_t), call_stream()), "smoke shadow list");
             const size_t lds = ((size_t)D.chunks_per_tile + 1u) * sizeof(uint32_t);
             hipLaunchKernelGGL(k_smoke_rays<kCollect>, dim3(tiles), dim3(64), lds, call_stream(), P, D);
-            hipLaunchKernelGGL(k_smoke_light, dim3(16384), dim3(64), 0, call_stream(), P, D);
+            static const unsigned light_waves = getenv("F3D_SMOKE_LIGHT_WAVES") ? (unsigned)atoi(getenv("F3D_SMOKE_LIGHT_WAVES")) : 16384u;  // (experiment switch)
+            hipLaunchKernelGGL(k_smoke_light, dim3(light_waves), dim3(64), 0, call_stream(), P, D);
             hipLaunchKernelGGL(k_smoke_shade, dim3(tiles), dim3(64), lds, call_stream(), P, D);
-        } else if (!(form && strcmp(form, "sift") == 0)) {  // one lane per pixel, the whole ray (F3D_SMOKE_MARCH=single, or no self-shadowing)
+        } else {  // one lane per pixel, the whole ray (F3D_SMOKE_MARCH=single, or no self-shadowing)
             hipLaunchKernelGGL(k_smoke_rays<kWhole>, dim3(tiles), dim3(64), 0, call_stream(), P, D);
-        } else {
-            SiftParams S{};
-            S.P = P;
-            S.items = (HeavyItem *)alloc(px * sizeof(HeavyItem), "smoke work list");
-            S.counters = (uint32_t *)alloc(2 * sizeof(uint32_t), "smoke work list");
-            hip_ok(hipMemsetAsync(S.counters, 0, 2 * sizeof(uint32_t), call_stream()), "smoke work list");
-            hipLaunchKernelGGL(k_smoke_sift, dim3(tiles), dim3(64), 0, call_stream(), S);
-            const uint32_t waves = (uint32_t)std::min<size_t>((px + 7u) / 8u, 16384u);  // (work is fetched from a cursor: any number >= what the chip holds will do)
-            hipLaunchKernelGGL(k_smoke_heavy, dim3(waves), dim3(64), 0, call_stream(), S);
         }
         hip_ok(hipGetLastError(), "smoke kernel");
         if (timed) {

@@ -164,7 +164,7 @@ def _domain(fields, voxel_size=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), frame_in
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["deferred", "deferred-short-list", "sift", "single"])
+@pytest.mark.parametrize("form", ["deferred", "deferred-short-list", "single"])
 @pytest.mark.parametrize("size,settings,geom", [
     ((96, 64), {}, {}),
     ((160, 90), dict(self_shadow=False, exposure=1.4, phase_g=-0.5), dict(voxel_size=(2.0, 1.5, 2.5), origin=(-10.0, 3.0, 7.0))),
@@ -172,13 +172,13 @@ def _domain(fields, voxel_size=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), frame_in
     ((128, 128), dict(density_scale=2.5, extinction=4.0, soot_absorption=0.9, fire_glow=1.5, thin_color=(0.2, 0.3, 0.4)), {}),
 ])
 def test_hip_smoke_matches_the_oracle_bit_for_bit(size, settings, geom, form, monkeypatch):
-    """The forms of the device marcher (csrc/f3d_smoke.hip): the self-shadow marches as a launch of their own between two walks
-    of the rays (the default; "short list": with room for three chunks only, so that most tiles' steps fall back to marching
-    their shadows in the second walk), sift + eight cooperating lanes per smoke pixel (F3D_SMOKE_MARCH=sift) and one lane per
-    pixel for the whole ray (F3D_SMOKE_MARCH=single)."""
+    """The forms of the device marcher (csrc/f3d_smoke.hip): the self-shadow marches as a launch of their own between a ray walk
+    that lists the smoke steps and a shading pass over the list (the default; "short list": with room for three chunks only, so
+    that most tiles fall back to walking their rays in the shading pass), and one lane per pixel for the whole ray
+    (F3D_SMOKE_MARCH=single)."""
     from forge3d_amd import smoke
 
-    if form in ("sift", "single"):
+    if form == "single":
         monkeypatch.setenv("F3D_SMOKE_MARCH", form)
     elif form == "deferred-short-list":
         monkeypatch.setenv("F3D_SMOKE_SHADOW_SLOTS", "3072")

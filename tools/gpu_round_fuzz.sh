@@ -10,4 +10,5 @@ run tools/gpu_fuzz.py 640000 $((45 * K))
 run tools/gpu_fuzz_fd.py 92000 $((600 * K2))
 run tools/gpu_fuzz_strips.py 72000 $((300 * K2))
 run tools/gpu_fuzz_wavefront.py 34000 $((40 * K))
+run tools/gpu_fuzz_smoke.py 5000 $((50 * K))
 cat $L
