@@ -262,11 +262,11 @@ __global__ __launch_bounds__(256) void k_phase_sum_finish(const StepArgs A, cons
 __global__ __launch_bounds__(256) void k_phase_sum_slabs(const StepArgs A, const SumKinds K, const float *density) {
     extern __shared__ float slab_lds[];
     const SimGrid &G = A.G;
-    const uint32_t z = blockIdx.x, stride = G.nx + 1u;
-    float *tile = slab_lds, *row_sum = slab_lds + (size_t)G.ny * stride;
+    const uint32_t z = blockIdx.x, pitch = G.ny + 1u;  // x-major with an odd pitch: the copy's writes and the rows' reads both spread over the banks
+    float *tile = slab_lds, *row_sum = slab_lds + (size_t)G.nx * pitch;
     for (uint32_t i = threadIdx.x; i < G.nx * G.ny; i += 256u) {
         const uint32_t y = i / G.nx, x = i - y * G.nx;
-        tile[y * stride + x] = density[sim_index(G, x, y, z)];
+        tile[x * pitch + y] = density[sim_index(G, x, y, z)];
     }
     __syncthreads();
     const uint32_t k = threadIdx.x >> 6;
@@ -274,18 +274,35 @@ __global__ __launch_bounds__(256) void k_phase_sum_slabs(const StepArgs A, const
         const uint32_t kind = K.kind[k];
         for (uint32_t r = threadIdx.x & 63u; r < G.ny; r += 64u) {
             float a = 0.0f;
-            for (uint32_t x = 0u; x < G.nx; x++) {  // (sums_row's terms and order)
-                const float d = tile[r * stride + x], m = f_max(d, 0.0f);
+#pragma unroll 8
+            for (uint32_t x = 0u; x < G.nx; x++) {  // (sums_row's terms and order; the loads of eight steps go out together)
+                const float d = tile[x * pitch + r], m = f_max(d, 0.0f);
                 a += kind == 0u ? d : (kind == 1u ? m : (kind == 2u ? (float)x * m : (float)z * m));
             }
             row_sum[k * G.ny + r] = a;
         }
     }
     __syncthreads();
-    if (threadIdx.x < K.n) A.slabs[(size_t)threadIdx.x * G.nz + z] = sim_sum_seq(row_sum + threadIdx.x * G.ny, G.ny);
+    if (threadIdx.x < K.n) {
+        const float *v = row_sum + threadIdx.x * G.ny;
+        float sum = 0.0f;
+#pragma unroll 8
+        for (uint32_t r = 0u; r < G.ny; r++) sum += v[r];  // (sim_sum_seq)
+        A.slabs[(size_t)threadIdx.x * G.nz + z] = sum;
+    }
 }
-__global__ __launch_bounds__(64) void k_phase_sum_total(const StepArgs A, const SumKinds K) {
-    if (threadIdx.x < K.n) A.sums[K.slot[threadIdx.x]] = sim_sum_seq(A.slabs + (size_t)threadIdx.x * A.G.nz, A.G.nz);
+__global__ __launch_bounds__(256) void k_phase_sum_total(const StepArgs A, const SumKinds K) {
+    extern __shared__ float slab_lds[];
+    const uint32_t n = K.n * A.G.nz;
+    for (uint32_t i = threadIdx.x; i < n; i += 256u) slab_lds[i] = A.slabs[i];  // (one round trip for all of them instead of one per addend)
+    __syncthreads();
+    if (threadIdx.x < K.n) {
+        const float *v = slab_lds + threadIdx.x * A.G.nz;
+        float sum = 0.0f;
+#pragma unroll 8
+        for (uint32_t zz = 0u; zz < A.G.nz; zz++) sum += v[zz];  // (sim_sum_seq)
+        A.sums[K.slot[threadIdx.x]] = sum;
+    }
 }
 
 // persistent driver: the grid barrier.  Cache maintenance is most of its cost (see above), so the fences are executed by
@@ -673,12 +690,13 @@ extern "C" int f3d_smoke_step(f3d_smoke_state *st, const f3d_smoke_step_settings
                 // cached loads a voxel instead of 2 x 8) -- bit-identical, 15 launches fewer a step, and SLOWER: 0.411-0.416 ms
                 // against 0.386-0.397 (the doubled sweep costs more than the 5-us launch it saves).  F3D_SMOKE_DOUBLE_SWEEPS=1 runs it.
                 const bool single_sweeps = getenv("F3D_SMOKE_DOUBLE_SWEEPS") == nullptr;
-                const size_t slab_lds = ((size_t)s.G.ny * (s.G.nx + 1u) + 4u * (size_t)s.G.ny) * sizeof(float);
-                const bool slab_sums = slab_lds <= 60u * 1024u && getenv("F3D_SMOKE_ROW_SUMS") == nullptr;  // (else: a lane a row from global memory)
+                const size_t slab_lds = ((size_t)s.G.nx * (s.G.ny + 1u) + 4u * (size_t)s.G.ny) * sizeof(float);
+                const bool slab_sums = slab_lds <= 60u * 1024u && 4u * (size_t)s.G.nz * sizeof(float) <= 60u * 1024u &&
+                                       getenv("F3D_SMOKE_ROW_SUMS") == nullptr;  // (else: a lane a row from global memory)
                 auto sums = [&](const float *density, const SumKinds &kinds) {
                     if (slab_sums) {
                         hipLaunchKernelGGL(k_phase_sum_slabs, dim3(s.G.nz), dim3(256), slab_lds, call_stream(), K, kinds, density);
-                        hipLaunchKernelGGL(k_phase_sum_total, dim3(1), dim3(64), 0, call_stream(), K, kinds);
+                        hipLaunchKernelGGL(k_phase_sum_total, dim3(1), dim3(256), 4u * (size_t)s.G.nz * sizeof(float), call_stream(), K, kinds);
                     } else {
                         hipLaunchKernelGGL(k_phase_sum_rows, row_grid, dim3(64), 0, call_stream(), K, kinds, density);
                         hipLaunchKernelGGL(k_phase_sum_finish, dim3(1), dim3(256), 0, call_stream(), K, kinds);
