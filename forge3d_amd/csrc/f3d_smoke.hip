@@ -820,7 +820,7 @@ extern "C" int f3d_smoke_render(const f3d_smoke_volume *vol, const f3d_smoke_vie
         D.chunks_per_tile = (P.st.max_steps + kChunkRows - 1u) / kChunkRows;
         const bool deferred = P.st.self_shadow != 0u && !form && D.chunks_per_tile <= 4096u;
         if (deferred) {  // the default: the self-shadow marches as a launch of their own between two walks of the rays
-            size_t slots = std::max<size_t>((size_t)4 << 20, px * 16u);  // (a tile whose steps do not fit is walked by k_smoke_shade in the one-kernel form)
+            size_t slots = std::max<size_t>((size_t)1 << 20, px * 16u);  // 52 B a slot: 1.7 GB for a 1080p frame, 54 MB at least (a tile whose steps do not fit is walked by k_smoke_shade in the one-kernel form)
             if (const char *e = getenv("F3D_SMOKE_SHADOW_SLOTS")) slots = (size_t)strtoull(e, nullptr, 10);  // test hook: a list that runs out
             D.capacity = (uint32_t)std::min<size_t>(std::max<size_t>(slots / kChunkSlots, 1u), 1u << 21);
             auto named = [&](const char *tag, size_t bytes) {  // (requests of this form only: their own tags)
