@@ -655,6 +655,7 @@ class SmokeSequence:
                 v = getattr(e, name)
                 setattr(dst, name, (C.c_float * 3)(*v) if name in ("center", "velocity") else float(v))
         seconds = C.c_double(0.0)
+        self._enqueue_on(self._stream)
         self._check(_native.lib().f3d_smoke_step(C.byref(st), C.byref(settings._native()), em, C.c_uint32(len(emitters)), C.c_uint32(int(steps)),
                                                  C.byref(seconds) if self.timing else None, self._err, len(self._err)))
         self.time_seconds, self.frame_index = float(st.time_seconds), int(st.frame_index)
@@ -674,8 +675,14 @@ class SmokeSequence:
         vol.frame_index = int(self.frame_index) & 0xFFFFFFFF
         seconds = C.c_double(0.0)
         native = self.settings._native()
+        self._enqueue_on(self._stream)  # (per call: another sequence of this thread may have named its own stream in between)
         self._check(_native.lib().f3d_smoke_render(C.byref(vol), C.byref(self.view), C.byref(native), C.c_void_p(self.layer.data_ptr()),
                                                    C.byref(seconds) if self.timing else None, self._err, len(self._err)))
+        if self._stream is self.render_stream:
+            # the next step, on the solver's stream, overwrites the state: it waits for THIS march's re-pack of it -- asked for
+            # here, right behind the call, because the library remembers the last render of the THREAD, whoever made it
+            if _native.lib().f3d_smoke_wait_fields_read(C.c_void_p(self.solver_stream.cuda_stream)) != 0:
+                raise RuntimeError("f3d_smoke_wait_fields_read failed")
         self.kernel_seconds["march"] = float(seconds.value)
         out = self.out[self._turn]
         # (this image's last read-back -- two frames ago, on the copy stream -- before the composite overwrites it)
@@ -709,20 +716,17 @@ class SmokeSequence:
         pending = None
         self.timing = bool(timing)
         overlap = bool(overlap) and not self.timing
-        lib = _native.lib()
         torch.cuda.synchronize(self.device)  # (the state's upload and whatever the caller did to it on other streams)
         try:
             for _ in range(int(count)):
                 if overlap:
-                    self._enqueue_on(self.solver_stream)
-                    # the last march's re-pack of the state, before this step overwrites it
-                    self._check_plain(lib.f3d_smoke_wait_fields_read(C.c_void_p(self.solver_stream.cuda_stream)))
+                    self._stream = self.solver_stream
                 self.step(settings, emitters, steps=steps_per_frame)
                 if overlap:
                     self.stepped.record(self.solver_stream)
-                    self._enqueue_on(self.render_stream)
+                    self._stream = self.render_stream
                     self.render_stream.wait_event(self.stepped)
-                image = self.render_to_device()
+                image = self.render_to_device()  # (with the marcher on its own stream: also makes the solver's stream wait for the re-pack)
                 turn = self._turn
                 with torch.cuda.stream(self.copy_stream):
                     self.copy_stream.wait_event(self.rendered[turn])  # the image is complete when the marcher's stream gets there
@@ -739,11 +743,6 @@ class SmokeSequence:
         finally:
             torch.cuda.synchronize(self.device)
             self._enqueue_on(None)
-
-    @staticmethod
-    def _check_plain(rc):
-        if rc != 0:
-            raise RuntimeError("f3d_smoke_wait_fields_read failed")
 
     def download(self) -> "SmokeDomain":
         """Bring the domain's host arrays (and its clock) up to date with the resident state."""

@@ -228,6 +228,39 @@ def test_config5_end_to_end_over_a_terrain_frame():
 
 
 @pytest.mark.gpu
+def test_two_resident_sequences_driven_in_turns_stay_themselves():
+    """Round 5 put the solver and the marcher of a sequence on a stream each, with the library remembering the calling THREAD's
+    stream and last march: two sequences advanced alternately by one thread (zip over their frames) must each give the frames
+    they give alone -- with and without the overlap."""
+    from forge3d_amd import smoke
+
+    w, h = 160, 96
+    rng = np.random.default_rng(11)
+    terrain = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    terrain[..., 3] = 255
+    cam = dict(camera_pos=(12.0, 10.0, 46.0), target=(12.0, 6.0, 10.0))
+
+    def sequence(kind):
+        dom = smoke.SmokeDomain((24, 16, 20))
+        emitters = [smoke.SmokeEmitter(center=(6.0 + 8.0 * kind, 3.0, 10.0), radius=2.5, density_rate=6.0 - 2.0 * kind, temperature_rate=3.0, soot_rate=0.3,
+                                       emission_rate=2.0, velocity=(3.0 - 5.0 * kind, 0.4, 0.0))]
+        settings = smoke.SmokeStepSettings(dt=0.1, turbulence_strength=0.5, turbulence_seed=7 + kind, wind=(1.5, 0.0, -0.2), pressure_iterations=8)
+        return smoke.SmokeSequence(dom, terrain, **cam), settings, emitters
+
+    alone = []
+    for kind in (0, 1):
+        seq, settings, emitters = sequence(kind)
+        alone.append([f.copy() for f in seq.frames(7, settings, emitters, steps_per_frame=2, overlap=False)])
+    assert not np.array_equal(alone[0][-1], alone[1][-1])
+    for overlap in (True, False):
+        (a, sa, ea), (b, sb, eb) = sequence(0), sequence(1)
+        got = [(fa.copy(), fb.copy()) for fa, fb in zip(a.frames(7, sa, ea, steps_per_frame=2, overlap=overlap),
+                                                        b.frames(7, sb, eb, steps_per_frame=2, overlap=overlap))]
+        for f, (fa, fb) in enumerate(got):
+            assert np.array_equal(fa, alone[0][f]) and np.array_equal(fb, alone[1][f]), (overlap, f)
+
+
+@pytest.mark.gpu
 def test_resident_smoke_sequence_equals_the_host_array_path():
     """Round 4: the sequence with its state, the smoke layer and the terrain frame resident on the GPU (SmokeSequence: only
     the finished RGBA8 frames leave, through two pinned buffers) gives the frames AND the final solver state of the
