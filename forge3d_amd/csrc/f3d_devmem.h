@@ -6,6 +6,7 @@
 // put next door and the image depends on the process's history; DESIGN.md 8, the 4-row reach of the spatial pass).
 // tools/gpu_fuzz*.py render every configuration under different patterns and compare.
 #pragma once
+#include <cstdio>
 
 #include <hip/hip_runtime.h>
 
@@ -84,7 +85,8 @@ inline hipError_t device_free(void *p) {
 // for the device: 0.55 ms of host time around 1.9 ms of kernels per frame of a resident sequence (BASELINE.json configs[4]).
 // A workspace buffer is identified by a tag, grows when a call needs more, and stays: the next call's kernels are behind
 // this call's in the stream, so reuse needs no wait, and a call whose results stay on the device can return as soon as its
-// launches are enqueued.  One caller at a time per device (workspace_lock: held while a call enqueues).
+// launches are enqueued.  One caller at a time per device (workspace_lock: held while a call enqueues); buffers are per stream
+// (call_stream() below), since only one stream's launches are ordered behind each other.
 // f3d_device_pool_trim() frees the workspace too.
 struct WorkspaceEntry {
     void *p = nullptr;
@@ -117,7 +119,11 @@ inline hipError_t workspace(void **out, const char *tag, size_t bytes) {
     int device = 0;
     hipError_t e = hipGetDevice(&device);
     if (e != hipSuccess) return e;
-    WorkspaceEntry &w = workspace_map()[{device, std::string(tag)}];
+    // (a buffer belongs to the tag AND the stream its users are ordered on: two sequences of a process on two streams -- two
+    // threads, or two objects driven in turns by one -- must not march through each other's records)
+    char where[32];
+    snprintf(where, sizeof(where), "@%p", (void *)call_stream());
+    WorkspaceEntry &w = workspace_map()[{device, std::string(tag) + where}];
     if (w.bytes < bytes || !w.p) {
         if (w.p) {
             (void)hipDeviceSynchronize();  // (rare: a larger domain than before) whatever still reads the old buffer
