@@ -2,7 +2,10 @@
 """When did each wave of k_smoke run?  Needs a library built with -DF3D_SMOKE_TILE_CLOCK (tools/build_variant.sh tileclock
 -DF3D_SMOKE_TILE_CLOCK), which leaves each wave's start time and duration (100 MHz ticks) in the first pixels of its tile.
 
-    F3D_HIP_LIBRARY=build_ab/libf3dhip_tileclock.so python tools/experiments/smoke_tile_clock.py [steps=140]
+    F3D_SMOKE_MARCH=single F3D_HIP_LIBRARY=build_ab/libf3dhip_tileclock.so python tools/experiments/smoke_tile_clock.py [steps=140]
+
+(F3D_SMOKE_MARCH=single: the one-kernel form, whose waves are what this was written to look at -- the result is in
+profiles/README.md, round 5, and is why the marcher became three launches.)
 """
 import sys
 from pathlib import Path
