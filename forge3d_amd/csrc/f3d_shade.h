@@ -451,6 +451,12 @@ F3D_HD PackedReservoir pack(const Reservoir &r) {
 }
 F3D_HD Reservoir empty_reservoir() { return Reservoir{0.0f, 0u, 0.0f, 0.0f, false}; }
 
+// Every division of the reservoir arithmetic is a * (1 / b), the reciprocal rounded once.  Which of two
+// weights that are both exactly 1 in real arithmetic wins the temporal pass of frame 1 depends on it, and with it the start of a
+// 513-frame relaxation of the reuse weight: this form reproduces the reference's golden (12.6 % of those ties go to `prev`, the
+// golden implies 13 %), IEEE division (0 %) is 4 % too bright on every sun-lit pixel.  The oracle spells the same (restir_div).
+F3D_HD float restir_div(float a, float b) { return a * (1.0f / b); }
+
 // Address of image pixel (x, y) in a strip-local reservoir buffer (halo rows included).
 F3D_HD size_t reservoir_index(const FrameParams &P, uint32_t x, uint32_t y) {
     return (size_t)(y + kHaloRows - P.row_begin) * P.cam.width + x;
@@ -484,11 +490,11 @@ F3D_HD Reservoir spatial_reuse(const FrameParams &P, const PackedReservoir *res,
         if (!facing) return false;
         const float p_curr = 1.0f;
         if (r.target_pdf <= 0.0f) return false;
-        const float w = r.w_sum * (p_curr / f_max(r.target_pdf, 1e-6f));
+        const float w = r.w_sum * restir_div(p_curr, f_max(r.target_pdf, 1e-6f));
         if (w <= 0.0f) return false;
         wsum = wsum + w;
         const float u = rng_next(seed);
-        if (u < w / wsum) {
+        if (u < restir_div(w, wsum)) {
             chosen_directional = true;
             chosen_pdf = p_curr;
         }
@@ -534,7 +540,7 @@ F3D_HD Reservoir spatial_reuse(const FrameParams &P, const PackedReservoir *res,
     out.target_pdf = chosen_pdf;
     out.w_sum = wsum;
     out.m = m_total;
-    out.weight = (out.w_sum > 0.0f && out.target_pdf > 0.0f) ? out.w_sum / ((float)out.m * out.target_pdf) : 0.0f;
+    out.weight = (out.w_sum > 0.0f && out.target_pdf > 0.0f) ? restir_div(out.w_sum, (float)out.m * out.target_pdf) : 0.0f;
     return out;
 }
 
@@ -547,7 +553,7 @@ F3D_HD Reservoir temporal_merge(const Reservoir &rp, const Reservoir &rc) {
     Reservoir ro = (rp.weight > rc.weight) ? rp : rc;
     ro.m = rp.m + rc.m;
     ro.w_sum = rp.w_sum + rc.w_sum;
-    ro.weight = (ro.w_sum > 0.0f && ro.target_pdf > 0.0f) ? ro.w_sum / ((float)ro.m * ro.target_pdf) : 0.0f;
+    ro.weight = (ro.w_sum > 0.0f && ro.target_pdf > 0.0f) ? restir_div(ro.w_sum, (float)ro.m * ro.target_pdf) : 0.0f;
     return ro;
 }
 
@@ -572,10 +578,10 @@ F3D_HD FrameHead frame_head(const FrameParams &P, uint32_t gx, uint32_t gy) {
     if (P.frame_index > 0u) prev = spatial_reuse<PREFETCH>(P, P.res_in, gx, gy, P.frame_index - 1u, V3{g.x, g.y, g.z});
     // M-clamp, hybrid_terrain_traversal.wgsl:452-462
     if (prev.m > kRestirMCap) {
-        const float scale = (float)kRestirMCap / (float)prev.m;
+        const float scale = restir_div((float)kRestirMCap, (float)prev.m);
         prev.w_sum = prev.w_sum * scale;
         prev.m = kRestirMCap;
-        if (prev.target_pdf > 0.0f) prev.weight = prev.w_sum / ((float)prev.m * prev.target_pdf);
+        if (prev.target_pdf > 0.0f) prev.weight = restir_div(prev.w_sum, (float)prev.m * prev.target_pdf);
     }
     P.res_out[reservoir_index(P, gx, gy)] = pack(prev);
     FrameHead h;
@@ -792,7 +798,7 @@ F3D_HD float frame_tail(const FrameParams &P, uint32_t gx, uint32_t gy, Reservoi
     const float fspp = (float)P.spp;
     radiance = V3{radiance.x / fspp, radiance.y / fspp, radiance.z / fspp};
     if (cand.m > 0u && cand.w_sum > 0.0f && cand.target_pdf > 0.0f)
-        cand.weight = cand.w_sum / ((float)cand.m * cand.target_pdf);
+        cand.weight = restir_div(cand.w_sum, (float)cand.m * cand.target_pdf);
     const size_t ri = reservoir_index(P, gx, gy);
     const Reservoir prev = unpack(P.res_out[ri]);  // parked by frame_head
     P.res_out[ri] = pack(temporal_merge(prev, cand));
