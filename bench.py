@@ -80,6 +80,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--extra-windows", type=int, default=4, help="further timed windows of --steps frames (spread report)")
+    ap.add_argument("--no-recut", action="store_true", help="N > 1: keep the first cut of the strips whatever the warm-up frames cost each rank")
     ap.add_argument("--no-terrain-filling", action="store_true", help="skip the second, terrain-filling camera")
     ap.add_argument("--no-configs", action="store_true", help="skip the short timed windows of BASELINE.json's other configurations")
     ap.add_argument("--dem-path", default=None, help="a real DEM (GeoTIFF / .npy) for an ADDITIONAL labelled run of the headline configuration; "
@@ -287,6 +288,45 @@ def cpu_baseline(dem, cam, kw, args, world=1):
     }, counts
 
 
+def device_identity(torch, index: int) -> dict:
+    """What tells two devices apart in the line: index, name and whichever of uuid / PCI ids this torch build exposes."""
+    props = torch.cuda.get_device_properties(index)
+    ident = {"index": int(index), "name": str(props.name)}
+    for key in ("uuid", "pci_bus_id", "pci_device_id", "pci_domain_id", "gcnArchName"):
+        value = getattr(props, key, None)
+        if value is not None:
+            ident[key] = str(value)
+    return ident
+
+
+def recut_after_warmup(r, busy_ms, make_renderer, threshold=1.05):
+    """ONE re-cut of the strips from what the warm-up frames cost each rank on the strips it will be timed on (VERDICT r5
+    next 3b: ROW_COST_FLOOR was calibrated on one GPU and one scene).  busy_ms: every rank's time for the warm-up minus the
+    time its halo pulls stood waiting for a neighbour (the same list on every rank, so every rank decides the same).
+    Returns (renderer, report); the old renderer stays when the strips are balanced, the new cut equals the old one, or
+    the new renderer cannot be built (then every rank raises inside its constructor's agreement and keeps the old one)."""
+    from forge3d_amd.distributed import HALO_ROWS, partition_rows, rebalance
+
+    mean = float(np.mean(busy_ms))
+    report = {"busy_ms_per_rank": [round(x, 4) for x in busy_ms], "max_over_mean": round(max(busy_ms) / mean, 4) if mean > 0 else None,
+              "threshold": threshold, "recut": False}
+    if not (mean > 0.0 and all(np.isfinite(busy_ms)) and min(busy_ms) > 0.0) or max(busy_ms) / mean <= threshold:
+        return r, report
+    density = np.asarray(getattr(r, "cost_density", np.ones(r.height)), np.float64)
+    bounds = partition_rows(rebalance(density, r.bounds, busy_ms), r.world, HALO_ROWS)
+    report["bounds_before"], report["bounds_after"] = list(r.bounds), list(bounds)
+    if bounds == list(r.bounds):
+        return r, report
+    try:
+        new = make_renderer(bounds)
+    except Exception as exc:  # noqa: BLE001 -- raised on every rank (StripRenderer._agree): everybody keeps the old strips
+        report["failed"] = str(exc)[:200]
+        return r, report
+    r.close()
+    report["recut"] = True
+    return new, report
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -340,16 +380,50 @@ def main():
         dist.broadcast(warm_box, src=0)
         dist.all_gather([torch.empty_like(warm_box) for _ in range(world)], warm_box)
         dist.barrier()
+        # what the process group IS, from the group itself (not from the environment that asked for it), and which device
+        # every rank really renders on: N distinct devices must be visible in the line
+        identities = [None] * world
+        dist.all_gather_object(identities, {"rank": rank, "host": os.uname().nodename, "pid": os.getpid(), **device_identity(torch, local_rank)})
+        group = {"rccl_ranks": int(dist.get_world_size()), "dist_backend": str(dist.get_backend()), "rank_devices": identities,
+                 "distinct_devices": len({(d.get("host"), d.get("uuid") or d.get("pci_bus_id") or d.get("index")) for d in identities})}
+    else:
+        group = {"rank_devices": [{"rank": 0, **device_identity(torch, local_rank)}]}
     torch.cuda.synchronize()
     t_setup = time.perf_counter()
-    r = StripRenderer(dem, args.width, args.height, cam, rank=rank, world=world, device=local_rank,
-                      kernel_variant=args.variant, memory_budget_bytes=8 << 30, **kw)
+    def make_renderer(row_bounds=None):
+        return StripRenderer(dem, args.width, args.height, cam, rank=rank, world=world, device=local_rank, row_bounds=row_bounds,
+                             kernel_variant=args.variant, memory_budget_bytes=8 << 30, **kw)
+
+    r = make_renderer()
     torch.cuda.synchronize()
     # once per render, outside the timed region: DEM upload, min-max tables, G-buffer pass, ray certificates
     setup_ms = (time.perf_counter() - t_setup) * 1e3
     setup_phases = r.session.setup_ms() if hasattr(r.session, "setup_ms") else {}
+    setup_trace, first_balance = dict(getattr(r, "setup_trace", {})), list(r.balance_log)
     # warmup (untimed) ---------------------------------------------------------------
-    r.run_frames(0, args.warmup)
+    recut = None
+    if world > 1 and args.warmup > 0 and not args.no_recut:
+        # the warm-up runs on the strips that will be timed: what it cost each rank decides whether they are cut once more
+        if r.peer_halos:
+            r.session.halo_stats(reset=True)
+        r.barrier()
+        torch.cuda.synchronize()
+        t_warm = time.perf_counter()
+        r.run_frames(0, args.warmup)
+        torch.cuda.synchronize()
+        warm_ms = (time.perf_counter() - t_warm) * 1e3
+        if r.peer_halos:  # a strip that waits for its neighbours is not a slow strip
+            warm_ms = max(warm_ms - sum(r.session.halo_stats()["wait_ms"]), 1e-3)
+            busy = r._gather_floats(warm_ms)
+            t_recut = time.perf_counter()
+            r, recut = recut_after_warmup(r, busy, make_renderer)
+            recut["ms"] = round((time.perf_counter() - t_recut) * 1e3, 2)
+            if recut["recut"]:
+                r.run_frames(0, args.warmup)  # the new strips' own warm-up (the accumulation starts again at frame 0)
+        else:
+            recut = {"recut": False, "why": "classic halo exchange: a rank's waits are inside the collectives and cannot be told from its work"}
+    else:
+        r.run_frames(0, args.warmup)
     if r.peer_halos:
         r.session.halo_stats(reset=True)  # the warm-up's waits (first launches, code loads) are not the loop's
     r.barrier()
@@ -388,6 +462,25 @@ def main():
     # final composition (untimed, but exercised): gather strips to rank 0
     image = r.gather_image(total_frames)
     halo_bytes = 0 if world == 1 else HALO_ROWS * args.width * 16 * ((1 if rank > 0 else 0) + (1 if rank < world - 1 else 0))
+    warnings = []
+    if world > 1:
+        import torch.distributed as dist
+
+        reasons = [None] * world
+        dist.all_gather_object(reasons, getattr(r, "peer_halo_failure", None))
+        if not r.peer_halos:  # LOUD: the line is then a measurement of the fall-back, not of the design
+            warnings.append("PEER HALOS OFF: the strips exchanged their halo rows through an RCCL send / recv pair per frame "
+                            "(Python and a collective per frame) instead of pulling them on the device; reasons by rank: "
+                            + json.dumps(reasons))
+        if group.get("distinct_devices") != world:
+            warnings.append(f"{world} ranks on {group.get('distinct_devices')} distinct device(s): "
+                            + ("a one-GPU rehearsal (F3D_DIST_BACKEND=gloo), NOT a scaling measurement" if os.environ.get("F3D_DIST_BACKEND") == "gloo"
+                               else "ranks share devices"))
+        if getattr(r, "cost_probe_failed_ranks", None):
+            warnings.append(f"cost-map probe failed on ranks {r.cost_probe_failed_ranks}: their rows were cut at the mean cost")
+        for w in warnings:
+            if rank == 0:
+                print("bench.py WARNING:", w, file=sys.stderr, flush=True)
 
     if rank == 0:
         samples_per_step = args.width * args.height * args.spp
@@ -402,6 +495,7 @@ def main():
             "windows_ms_per_step": [round(x, 4) for x in window_ms],
             "median_window_ms_per_step": float(np.median(window_ms)),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            **({"warnings": warnings} if warnings else {}),
             "data": "synthetic (rainier-proxy 2048^2 DEM, seed 20260926; real Rainier DEM is git-LFS)",
             "config": {
                 "workload": f"BASELINE.json configs[1]: rainier-proxy DEM {args.dem}x{args.dem}, "
@@ -424,13 +518,17 @@ def main():
                              "device_passes_and_python": round(setup_ms - setup_phases.get("total", 0.0), 3)},
                 "setup_note": "session creation outside the timed region, for a DEM this process has not seen: DEM fingerprint, staged upload, "
                               "min-max tables, state allocation + clears, G-buffer pass, ray certificates",
-                **({"setup_trace_ms_rank0": {k: round(v, 2) for k, v in getattr(r, "setup_trace", {}).items()}, "strip_row_bounds": r.bounds, "strip_probe_ms": r.balance_log[-1]["ms"] if r.balance_log else None,
-                    "rccl_ranks": world, "rank_ms_per_step": [round(x, 4) for x in rank_ms], "halo_bytes_per_frame_rank0": halo_bytes,
+                **({"setup_trace_ms_rank0": {k: round(v, 2) for k, v in setup_trace.items()}, "strip_row_bounds": r.bounds, "strip_probe_ms": r.balance_log[-1]["ms"] if r.balance_log else None,
+                    "strip_cut": (first_balance[-1].get("from") if first_balance else "equal rows"),
+                    "cost_probe_failed_ranks": list(getattr(r, "cost_probe_failed_ranks", [])),
+                    # one re-cut from what the warm-up frames cost each rank on the strips of the first cut (busy = wall - halo waits)
+                    "recut_after_warmup": recut,
+                    **group, "rank_ms_per_step": [round(x, 4) for x in rank_ms], "halo_bytes_per_frame_rank0": halo_bytes,
                     # device time each rank's pulls stood waiting for its neighbours' frame counters, per frame (peer halos only),
                     # and the longest single wait: what the first real multi-GPU run has to show
                     "halo_wait_ms_per_frame": [round(x, 4) for x in halo_wait_ms] if halo_wait_ms else None,
                     "halo_longest_wait_ms": [round(x, 4) for x in halo_longest_ms] if halo_longest_ms else None,
-                    "dist_backend": os.environ.get("F3D_DIST_BACKEND") or "nccl"} if world > 1 else {}),
+                    } if world > 1 else {"rank_devices": group["rank_devices"]}),
             },
         }
         counts = None

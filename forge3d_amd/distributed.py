@@ -17,12 +17,14 @@ CPU with the kernel emulator under tests/emul.
 
 Strips are LOAD-BALANCED, not equal: a sky row costs a fraction of a terrain row and the sky
 sits at the top of the frame, so equal strips would leave the top ranks idle (strong scaling
-is bounded by the slowest strip).  Round 5: the cut comes from ONE measurement -- rank 0 renders
-a few frames of the whole image in a throw-away session, the frame kernel's own per-tile wave
-times (what its longest-first dispatch sorts by) are summed by row (f3d_session_row_costs),
-broadcast, and every rank cuts the rows into strips of equal cost: ~10 ms once instead of up to
-six rounds of whole-loop probe renders of every strip (2 s of set-up for a 60 ms render at 8
-ranks rehearsed on one GPU, round-4 verdict).  `balance_iters` > 0 adds that many rounds of the
+is bounded by the slowest strip).  The cut comes from ONE measurement: every rank renders a few
+frames of its EQUAL share of the rows in a throw-away session (round 5: rank 0 rendered the whole
+frame while the others waited -- 204 ms of a 4096^2 set-up, and a whole-frame session that a strip
+job's memory budget need not hold), the frame kernel's own per-tile wave times (what its
+longest-first dispatch sorts by, 100 MHz ticks: comparable between devices) are summed by row
+(f3d_session_row_costs), all-gathered, and every rank cuts the rows into strips of equal cost.
+A rank whose probe fails contributes "unknown" and its rows get the mean cost of the known ones:
+a failed probe costs balance, never the render.  `balance_iters` > 0 adds that many rounds of the
 measured refinement of rounds 1-4 on top (every rank times probe frames of its strip, the times
 are all-gathered, the density is updated multiplicatively; the best measured partition wins).
 Any partition gives the same image -- state is keyed by full-image coordinates.
@@ -147,15 +149,17 @@ class HipBackend:
     def sync(self):
         self.torch.cuda.synchronize(self.device)
 
-    def row_costs(self, dem, width, height, cam, kw, frames=3):
-        """Cost by image row of the whole frame (float64[height]): `frames` fused frames in a throw-away full-height
-        session, the last one's per-tile wave times summed by row (TerrainSession.row_costs)."""
+    def row_costs(self, dem, width, height, cam, kw, frames=3, row_begin=0, row_end=None):
+        """Cost by image row of the rows [row_begin, row_end) of the frame (float64[rows]; default: the whole frame):
+        `frames` fused frames in a throw-away session of that strip (halos empty), the last one's per-tile wave times
+        summed by row (TerrainSession.row_costs)."""
         from .session import TerrainSession
 
+        row_end = int(height) if row_end is None else int(row_end)
         k = {key: v for key, v in kw.items() if key not in ("frames_in_flight", "bands", "band_streams")}
         k.update(max_frames=max(int(frames), 2), min_frames=max(int(frames), 2), variance_threshold=1e30)
         stream = self.torch.cuda.current_stream(self.device).cuda_stream
-        with TerrainSession(dem, width, height, cam, device=self.device.index, stream=stream, **k) as s:
+        with TerrainSession(dem, width, height, cam, device=self.device.index, stream=stream, row_begin=int(row_begin), row_end=row_end, **k) as s:
             s.enqueue_frames(0, int(frames))
             return s.row_costs().astype(np.float64)
 
@@ -379,29 +383,47 @@ class StripRenderer:
         return [float(p.item()) for p in parts]
 
     def _balance_from_cost_map(self, dem, cam, kw):
-        """Strips of equal cost from rank 0's row-cost map of the whole frame (module docstring).  One broadcast; every rank
-        cuts the same map, so every rank derives the same boundaries."""
+        """Strips of equal cost from a row-cost map of the frame that the ranks measure TOGETHER: each its equal share of the
+        rows (module docstring).  One all-gather; every rank cuts the same map, so every rank derives the same boundaries.
+        A probe that fails (memory budget, a kernel variant that logs no tile costs) marks its rows unknown -- they get
+        the mean of the known rows, all ones when nobody knows anything: equal strips -- and is kept in
+        `cost_probe_failure`; it never aborts the job (round-5 advice: only agreement failures may)."""
         import torch.distributed as dist
 
-        density, error = np.ones(self.height), None
-        if self.rank == 0:
+        b0, b1 = strip_rows(self.height, self.world, self.rank)
+        share = max(strip_rows(self.height, self.world, r)[1] - strip_rows(self.height, self.world, r)[0] for r in range(self.world))
+        mine = np.full(share, np.nan)
+        self.cost_probe_failure = None
+        try:
             try:
-                density = np.asarray(self.backend.row_costs(dem, self.width, self.height, cam, kw), np.float64)
-                if density.shape != (self.height,) or not np.all(np.isfinite(density)) or density.sum() <= 0.0:
-                    density = np.ones(self.height)
-            except Exception as exc:  # noqa: BLE001 -- agreed on below, before the broadcast
-                error = exc
-        self._lap("cost map: rank 0's probe frames")
-        self._agree(error)
-        self._lap("cost map: agreement")
-        box = self.torch.from_numpy(density).to(self._comm_device())
-        dist.broadcast(box, src=0)
-        self._lap("cost map: broadcast")
-        self.cost_density = box.cpu().numpy()
+                cost = self.backend.row_costs(dem, self.width, self.height, cam, kw, row_begin=b0, row_end=b1)
+            except TypeError:  # a backend that can only probe the whole frame (tests): rank 0's map, cut here
+                cost = np.asarray(self.backend.row_costs(dem, self.width, self.height, cam, kw), np.float64)[b0:b1]
+            cost = np.asarray(cost, np.float64)
+            if cost.shape != (b1 - b0,) or not np.all(np.isfinite(cost)) or cost.min() < 0.0:
+                raise ValueError(f"row costs of rows {b0}..{b1}: shape {cost.shape}, not finite or negative")
+            mine[: b1 - b0] = cost
+        except Exception as exc:  # noqa: BLE001 -- "unknown", see above
+            self.cost_probe_failure = f"{type(exc).__name__}: {exc}"
+        self._lap("cost map: this rank's probe frames")
+        box = self.torch.from_numpy(mine).to(self._comm_device())
+        parts = [self.torch.empty_like(box) for _ in range(self.world)]
+        dist.all_gather(parts, box)
+        self._lap("cost map: all-gather")
+        density = np.concatenate([parts[r].cpu().numpy()[: strip_rows(self.height, self.world, r)[1] - strip_rows(self.height, self.world, r)[0]]
+                                  for r in range(self.world)])
+        known = np.isfinite(density)
+        self.cost_probe_failed_ranks = [r for r in range(self.world) if not np.isfinite(parts[r].cpu().numpy()[0])]
+        if known.any() and float(density[known].sum()) > 0.0:
+            density[~known] = float(density[known].mean())
+        else:
+            density = np.ones(self.height)
+        self.cost_density = density
         # a floor under the measured cost: the fixed part of a row (ROW_COST_FLOOR)
         floor = ROW_COST_FLOOR * float(self.cost_density.mean())
         bounds = partition_rows(self.cost_density + floor, self.world, HALO_ROWS)
-        self.balance_log.append({"bounds": list(bounds), "ms": None, "from": "row cost map of one full frame (rank 0)"})
+        self.balance_log.append({"bounds": list(bounds), "ms": None, "from": "row cost map, every rank its equal share of the rows",
+                                 "failed_ranks": list(self.cost_probe_failed_ranks)})
         return bounds
 
     def _balance(self, dem, cam, kw, iters):

@@ -87,7 +87,13 @@ static inline float poly_cos(float x) { /* |x| <= pi/4 */
     return fmaf(p, z * z, fmaf(-0.5f, z, 1.0f));
 }
 /* sin and cos of phi = 2*pi*u, u in [0,1]: quadrant from 4u, remainder * pi/2. */
+#ifdef F3DO_EXPERIMENT
+extern int f3do_experiment_libm; /* 1: libm sinf / cosf of 2*pi*u instead of the fixed polynomials */
+#endif
 void f3do_sincos_2pi(float u, float *s_out, float *c_out) {
+#ifdef F3DO_EXPERIMENT
+    if (f3do_experiment_libm) { float phi = 6.283185307179586f * u; *s_out = sinf(phi); *c_out = cosf(phi); return; }
+#endif
     float a = 4.0f * u;
     float k = rintf(a);
     float r = a - k;
@@ -1754,6 +1760,7 @@ void f3do_set_num_threads(int n) {
  * f3do_experiment_tie_prob >= 0: a pixel whose two weights agree to 4e-7 relative takes `prev` with this probability
  * (hash of the pixel), whatever the arithmetic said.  The counters see every such near-tie. */
 int f3do_experiment_div_model = 0;
+int f3do_experiment_libm = 0;
 double f3do_experiment_tie_prob = -1.0;
 unsigned f3do_experiment_ties = 0, f3do_experiment_ties_prev = 0;
 

@@ -44,6 +44,37 @@ def golden_png() -> np.ndarray:
     return np.array(Image.open(GOLDEN_DIR / "mini_dem_reference.png"))
 
 
+def normal_angles_vs_analytic(dem, depth, normal):
+    """Tier 1 of the reference's test_aov_parity_with_rasterizer (tests/test_hybrid_terrain_pt.py:331-381): angle in degrees
+    between a render's normal AOV and the central-difference normal of the heightfield at the point its depth AOV names,
+    over the hit pixels away from the DEM's border."""
+    hits = np.isfinite(depth)
+    spacing = SPAN / (dem.shape[1] - 1)
+    hz = dem * RELIEF
+    n_ref = np.stack([-np.gradient(hz, spacing, axis=1), np.ones_like(hz), -np.gradient(hz, spacing, axis=0)], -1)
+    n_ref /= np.linalg.norm(n_ref, axis=-1, keepdims=True)
+    origin = np.array(CAM["origin"], np.float64)
+    fwd = np.array(CAM["look_at"], np.float64) - origin
+    fwd /= np.linalg.norm(fwd)
+    right = np.cross(fwd, [0.0, 1.0, 0.0])
+    right /= np.linalg.norm(right)
+    up = np.cross(right, fwd)
+    half_h = np.tan(np.radians(CAM["fov_y"]) / 2.0)
+    ox = -0.5 * (dem.shape[1] - 1) * spacing
+    oz = -0.5 * (dem.shape[0] - 1) * spacing
+    ys, xs = np.nonzero(hits)
+    size = depth.shape[0]
+    ndc_x = (xs + 0.5) / size * 2 - 1
+    ndc_y = 1 - (ys + 0.5) / size * 2
+    dirs = ndc_x[:, None] * half_h * right + ndc_y[:, None] * half_h * up + fwd
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    pts = origin[None, :] + depth[ys, xs][:, None] * dirs
+    gx = np.clip((pts[:, 0] - ox) / spacing, 0, dem.shape[1] - 1.001).astype(int)
+    gz = np.clip((pts[:, 2] - oz) / spacing, 0, dem.shape[0] - 1.001).astype(int)
+    inner = (gx > 1) & (gx < dem.shape[1] - 2) & (gz > 1) & (gz < dem.shape[0] - 2)
+    return np.degrees(np.arccos(np.clip((n_ref[gz[inner], gx[inner]] * normal[ys[inner], xs[inner]]).sum(-1), -1, 1)))
+
+
 def curvature_fixture() -> np.ndarray:
     """256x256 proof DEM of the reference's traversal KATs
     (src/path_tracing/hybrid_compute/terrain_heightfield.rs:618-629), evaluated in f32."""

@@ -48,19 +48,32 @@ def _worker(rank, world, port, out_path, mode):
     else:  # converge through two Welford windows
         kw = {**kw, "variance_threshold": 5e-3, "max_frames": 256, "spp": 1}
     backend, extra = emul.EmulBackend(), {}
-    if mode in ("balanced", "refined"):
+    if mode in ("balanced", "refined", "probefail", "wholemap"):
         # synthetic costs: rows of the top half ("sky") cost 1, the others 5 -> unequal strips.  "balanced": the cut comes
-        # from rank 0's row-cost map alone (round 5, one broadcast); "refined": three measured rounds on top of a FLAT map
+        # from the row-cost map the ranks measure together, each its equal share of the rows (round 6, one all-gather);
+        # "refined": three measured rounds on top of a FLAT map; "probefail": the last rank's probe raises -- its rows count as
+        # the mean of the others', nobody aborts (round-5 advice); "wholemap": a backend that can only probe the whole frame
         class CostBackend(emul.EmulBackend):
-            def row_costs(self, dem, width, height, cam, kw, frames=3):
+            def row_costs(self, dem, width, height, cam, kw, frames=3, row_begin=0, row_end=None):
                 import numpy as np
 
+                row_end = height if row_end is None else row_end
+                assert (row_begin, row_end) == (height * rank // world, height * (rank + 1) // world), "every rank probes its equal share"
+                if mode == "probefail" and rank == world - 1:
+                    raise RuntimeError("[Memory] injected: the probe session exceeds the memory budget")
                 if mode == "refined":
-                    return np.ones(height)
-                return np.asarray([1.0 if y < height // 2 else 5.0 for y in range(height)])
+                    return np.ones(row_end - row_begin)
+                return np.asarray([1.0 if y < height // 2 else 5.0 for y in range(row_begin, row_end)])
 
             def probe(self, dem, width, height, cam, row_begin, row_end, kw, frames=2, whole_loop=False):
                 return float(sum(1.0 if y < height // 2 else 5.0 for y in range(row_begin, row_end)))
+
+        if mode == "wholemap":
+            class CostBackend(emul.EmulBackend):  # noqa: F811
+                def row_costs(self, dem, width, height, cam, kw, frames=3):
+                    import numpy as np
+
+                    return np.asarray([1.0 if y < height // 2 else 5.0 for y in range(height)])
 
         backend = CostBackend()
         if mode == "refined":
@@ -106,13 +119,18 @@ def _worker(rank, world, port, out_path, mode):
         dist.barrier()
         dist.destroy_process_group()
         return
-    if mode in ("balanced", "refined"):
+    if mode == "probefail":
+        assert r.cost_probe_failed_ranks == [world - 1] and (r.cost_probe_failure is not None) == (rank == world - 1)
+        assert r.balance_log[0]["failed_ranks"] == [world - 1]
+        sizes = [b1 - b0 for b0, b1 in zip(r.bounds, r.bounds[1:])]
+        assert sum(sizes) == 50 and min(sizes) >= 4 and sizes[0] > sizes[-1], r.bounds  # the known rows still shape the cut
+    if mode in ("balanced", "refined", "wholemap"):
         sizes = [b1 - b0 for b0, b1 in zip(r.bounds, r.bounds[1:])]
         costs = [sum(1.0 if y < 25 else 5.0 for y in range(b0, b1)) for b0, b1 in zip(r.bounds, r.bounds[1:])]
         assert sizes[0] > sizes[-1] and max(costs) / (sum(costs) / world) < 1.15, (r.bounds, costs)  # (ROW_COST_FLOOR weighs every row a little: 50 rows cut three ways cannot do better)
-        assert len(r.balance_log) == 1 if mode == "balanced" else len(r.balance_log) >= 3, r.balance_log
+        assert len(r.balance_log) == 1 if mode in ("balanced", "wholemap") else len(r.balance_log) >= 3, r.balance_log
     image = r.render() if mode == "converge" else None
-    if mode in ("fixed", "balanced", "refined", "bounds"):
+    if mode in ("fixed", "balanced", "refined", "bounds", "probefail", "wholemap"):
         r.run_frames(0, 6, collect_last=True)
         var = r.window_variance(6)
         image = r.gather_image(6)
@@ -155,7 +173,7 @@ def test_strips_over_gloo_reproduce_the_single_strip_image(world):
     assert single["variance"] == multi["variance"]
 
 
-@pytest.mark.parametrize("world,mode", [(2, "balanced"), (3, "balanced"), (3, "refined"), (2, "bounds"), (3, "bounds")])
+@pytest.mark.parametrize("world,mode", [(2, "balanced"), (3, "balanced"), (3, "refined"), (2, "bounds"), (3, "bounds"), (3, "probefail"), (2, "wholemap")])
 def test_unequal_strips_reproduce_the_single_strip_image(world, mode):
     """Load-balanced (measured, here with a synthetic cost probe) and hand-picked boundaries:
     every rank derives the same partition and the stitched image is still bit-identical."""

@@ -261,6 +261,7 @@ def test_terrain_reference_golden(reference, oracle):
     print(f"\nHIP terrain PT vs reference golden: SSIM {score:.6f}, mean abs {drift:.4f}, frames {out['frames']}")
     assert score >= 0.995
     assert drift <= 2.0
+    assert drift <= 0.5  # tighter than the reference's gate: the one-sided +2.4 / 255 of rounds 1-5 is gone
     want = oracle.render(dem, scenes.SIZE, scenes.SIZE, scenes.CAM, **scenes.scene_kwargs(dem))
     _same(out, want)
 
@@ -301,31 +302,7 @@ def test_terrain_hits_and_aov_consistency(reference):
 def test_normals_match_analytic_gradient(reference):
     """tier 1 of reference test_aov_parity_with_rasterizer (:313-381)."""
     dem, out = reference
-    depth, normal = out["depth"], out["normal"]
-    hits = np.isfinite(depth)
-    spacing = scenes.SPAN / (dem.shape[1] - 1)
-    hz = dem * scenes.RELIEF
-    n_ref = np.stack([-np.gradient(hz, spacing, axis=1), np.ones_like(hz), -np.gradient(hz, spacing, axis=0)], -1)
-    n_ref /= np.linalg.norm(n_ref, axis=-1, keepdims=True)
-    origin = np.array(scenes.CAM["origin"], np.float64)
-    fwd = np.array(scenes.CAM["look_at"], np.float64) - origin
-    fwd /= np.linalg.norm(fwd)
-    right = np.cross(fwd, [0.0, 1.0, 0.0])
-    right /= np.linalg.norm(right)
-    up = np.cross(right, fwd)
-    half_h = np.tan(np.radians(scenes.CAM["fov_y"]) / 2.0)
-    ox = -0.5 * (dem.shape[1] - 1) * spacing
-    oz = -0.5 * (dem.shape[0] - 1) * spacing
-    ys, xs = np.nonzero(hits)
-    ndc_x = (xs + 0.5) / scenes.SIZE * 2 - 1
-    ndc_y = 1 - (ys + 0.5) / scenes.SIZE * 2
-    dirs = ndc_x[:, None] * half_h * right + ndc_y[:, None] * half_h * up + fwd
-    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
-    pts = origin[None, :] + depth[ys, xs][:, None] * dirs
-    gx = np.clip((pts[:, 0] - ox) / spacing, 0, dem.shape[1] - 1.001).astype(int)
-    gz = np.clip((pts[:, 2] - oz) / spacing, 0, dem.shape[0] - 1.001).astype(int)
-    inner = (gx > 1) & (gx < dem.shape[1] - 2) & (gz > 1) & (gz < dem.shape[0] - 2)
-    ang = np.degrees(np.arccos(np.clip((n_ref[gz[inner], gx[inner]] * normal[ys[inner], xs[inner]]).sum(-1), -1, 1)))
+    ang = scenes.normal_angles_vs_analytic(dem, out["depth"], out["normal"])
     assert ang.mean() < 5.0
     assert np.percentile(ang, 95) < 15.0
 

@@ -37,6 +37,63 @@ def test_oracle_passes_the_reference_golden_gate(golden_render):
     assert out["converged"] and out["variance"] < 1e-3 and out["frames"] % 32 == 0
 
 
+def test_oracle_offset_to_the_golden_is_two_sided_noise(golden_render):
+    """Rounds 1-5: every sun-lit pixel sat +2.4 / 255 above the golden (mean-abs 1.364, 0 of 37 557 terrain pixels darker) --
+    the tie of frame 1's temporal pass resolved by IEEE division (tools/golden_offset.py).  With the reservoir
+    divisions as a * (1/b) what is left is noise around zero; this pins it well inside the reference's own gate."""
+    _, out = golden_render
+    golden = scenes.golden_png()
+    hits = np.isfinite(out["depth"])
+    d = out["rgba"][..., :3].astype(np.float64) - golden[..., :3].astype(np.float64)
+    assert mean_abs(out["rgba"][..., :3], golden[..., :3]) <= 0.5
+    assert abs(d[hits].mean()) < 0.5 and d[hits].std() < 1.2
+    assert 0.05 < (d[hits].mean(-1) < 0).mean() < 0.6  # darker and brighter pixels both exist
+    assert np.abs(d[~hits]).mean() < 0.01  # the sky never differed
+
+
+def test_oracle_normals_match_analytic_gradient(golden_render):
+    """Tier 1 of the reference's test_aov_parity_with_rasterizer (tests/test_hybrid_terrain_pt.py:313-381) on the ORACLE:
+    its normal AOV against central differences of the same heightfield, looked up through its own depth AOV."""
+    dem, out = golden_render
+    ang = scenes.normal_angles_vs_analytic(dem, out["depth"], out["normal"])
+    assert ang.mean() < 5.0
+    assert np.percentile(ang, 95) < 15.0
+
+
+def test_oracle_sun_color_is_a_live_control(golden_render):
+    """reference test_sun_color_live_control_changes_output (:697-709) and
+    test_zero_sun_color_render_succeeds_and_removes_direct_sun (:712-733) on the oracle."""
+    dem, out_default = golden_render
+    blue = oracle.render(dem, scenes.SIZE, scenes.SIZE, scenes.CAM, **{**scenes.scene_kwargs(dem), "sun_color": (0.2, 0.3, 1.5)})
+    a = out_default["rgba"][..., :3].astype(np.float64)
+    assert np.abs(a - blue["rgba"][..., :3].astype(np.float64)).mean() > 1.0
+    lit = np.isfinite(out_default["depth"])
+    assert blue["rgba"][lit][:, 2].mean() > blue["rgba"][lit][:, 0].mean()
+    kw = {**scenes.scene_kwargs(dem), "max_frames": 32, "min_frames": 2, "variance_threshold": 1e30}
+    default = oracle.render(dem, 128, 128, scenes.CAM, **kw)
+    zero = oracle.render(dem, 128, 128, scenes.CAM, **{**kw, "sun_color": (0.0, 0.0, 0.0)})
+    assert zero["rgba"].shape == (128, 128, 4) and zero["rgba"].dtype == np.uint8 and np.isfinite(zero["depth"]).any()
+    d, z = default["rgba"][..., :3].astype(np.float64), zero["rgba"][..., :3].astype(np.float64)
+    assert np.abs(d - z).mean() > 0.5 and z.mean() < d.mean()
+
+
+def test_oracle_mixed_scene_mesh_and_terrain():
+    """reference test_mixed_scene_mesh_and_terrain (:735-769) on the oracle."""
+    dem = scenes.golden_dem()
+    kw = {**scenes.scene_kwargs(dem), "max_frames": 64, "min_frames": 2, "variance_threshold": 1e30}
+    quad_v = np.array([[-18.0, 22.0, -6.0], [18.0, 22.0, -6.0], [18.0, 40.0, -6.0], [-18.0, 40.0, -6.0]], np.float32)
+    quad_i = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+    base = oracle.render(dem, 128, 128, scenes.CAM, **kw)
+    mixed = oracle.render(dem, 128, 128, scenes.CAM, mesh_vertices=quad_v, mesh_indices=quad_i, **kw)
+    d0, d1 = base["depth"], mixed["depth"]
+    closer = np.isfinite(d1) & (~np.isfinite(d0) | (d1 < d0 - 1.0))
+    assert closer.mean() > 0.01
+    assert np.allclose(mixed["albedo"][closer], [0.7, 0.7, 0.8], atol=2e-2)
+    terr = np.isfinite(d1) & ~closer
+    assert terr.mean() > 0.3
+    assert np.allclose(mixed["albedo"][terr], np.array(scenes.ALBEDO), atol=2e-2)
+
+
 def test_oracle_sky_value_and_coverage_match_the_golden(golden_render):
     """env 0.35 -> Reinhard 0.35/1.35 -> f16 -> u8 = 66, on the same 42.3 % of pixels."""
     _, out = golden_render

@@ -73,10 +73,16 @@ for world in [int(x) for x in args.worlds.split(",")]:
     if args.costmap:
         import time as _time
 
-        t0 = _time.perf_counter()
-        density = np.asarray(backend.row_costs(dem, W, H, cam, kw), np.float64)
+        # round 6: every rank probes its EQUAL share of the rows (here one after the other; in a job at the same time, so the
+        # set-up pays the longest share, not the sum)
+        parts, share_ms = [], []
+        for r in range(world):
+            t0 = _time.perf_counter()
+            parts.append(np.asarray(backend.row_costs(dem, W, H, cam, kw, row_begin=strip_rows(H, world, r)[0], row_end=strip_rows(H, world, r)[1]), np.float64))
+            share_ms.append((_time.perf_counter() - t0) * 1e3)
+        density = np.concatenate(parts)
         bounds = partition_rows(density + ROW_COST_FLOOR * density.mean(), world, HALO_ROWS)
-        print(json.dumps({"world": world, "cost_map_ms": round((_time.perf_counter() - t0) * 1e3, 2), "bounds": bounds}), flush=True)
+        print(json.dumps({"world": world, "cost_map_ms_longest_share": round(max(share_ms), 2), "cost_map_ms_all_shares_in_turn": round(sum(share_ms), 2), "bounds": bounds}), flush=True)
     for it in range(0 if (args.costmap and args.rounds == 4) else args.rounds):
         times = [probe(bounds[r], bounds[r + 1], bands=args.bands, band_streams=args.streams, frames_in_flight=args.fd if world >= 4 else 0) for r in range(world)]
         print(json.dumps({"world": world, "round": it, "bounds": bounds, "ms": [round(t, 3) for t in times],
@@ -108,5 +114,13 @@ for world in [int(x) for x in args.worlds.split(",")]:
     full_loop = loop_ms(0, H)
     fd = args.fd if world >= 4 else 0  # (as the strip driver: fat strips keep the fused kernel)
     loops = [loop_ms(bounds[r], bounds[r + 1], frames_in_flight=fd) for r in range(world)]
+    if args.costmap and max(loops) / (sum(loops) / world) > 1.05:
+        # bench.py's one re-cut from what the first frames cost each rank on these strips (recut_after_warmup)
+        recut = partition_rows(rebalance(density, bounds, loops), world, HALO_ROWS)
+        if recut != bounds:
+            print(json.dumps({"world": world, "recut": "max / mean of the strips' loops %.3f > 1.05" % (max(loops) / (sum(loops) / world)),
+                              "before": {"bounds": bounds, "strips_ms": [round(t, 3) for t in loops], "compute_bound_speedup_256spp": full_loop / max(loops)}}), flush=True)
+            bounds = recut
+            loops = [loop_ms(bounds[r], bounds[r + 1], frames_in_flight=fd) for r in range(world)]
     print(json.dumps({"config": args.config, "cut": "cost map" if args.costmap else "measured rounds", "world": world, "render_256spp_loop_ms": {"full_frame": round(full_loop, 3), "strips": [round(t, 3) for t in loops]},
                       "ms_per_strip_frame": round(max(loops) / LOOP_FRAMES, 4), "compute_bound_speedup_256spp": full_loop / max(loops), "bounds": bounds}), flush=True)
