@@ -18,7 +18,7 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libf3dhip.so"
 
 STATUS_OK, STATUS_VALUE, STATUS_RENDER, STATUS_UPLOAD, STATUS_DEVICE = 0, 1, 2, 3, 4
-ABI_VERSION = 5  # F3D_ABI_VERSION of include/f3d_terrain_pt.h this mirror was written against
+ABI_VERSION = 6  # F3D_ABI_VERSION of include/f3d_terrain_pt.h this mirror was written against
 
 _EARTH = {"flat": 0, "sphere": 1, "ellipsoid": 2, "wgs84": 2}
 _REFRACTION = {"none": 0, "bennett": 1, "saemundsson": 2, "effective_radius": 3}
@@ -145,6 +145,14 @@ ABI = [
     ("f3d_session_primary_start", C.c_void_p, [C.c_void_p]),
     ("f3d_smoke_set_stream", None, [C.c_void_p]),
     ("f3d_smoke_wait_fields_read", C.c_int, [C.c_void_p]),
+    # a resident smoke sequence behind a handle (ABI 6)
+    ("f3d_smoke_seq_create", C.c_int, [C.c_void_p, C.c_void_p, _P(C.c_void_p), C.c_char_p, C.c_size_t]),
+    ("f3d_smoke_seq_destroy", None, [C.c_void_p]),
+    ("f3d_smoke_seq_streams", C.c_int, [C.c_void_p, _P(C.c_void_p), _P(C.c_void_p)]),
+    ("f3d_smoke_seq_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, _P(C.c_double), C.c_char_p, C.c_size_t]),
+    ("f3d_smoke_seq_render", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_double), C.c_char_p, C.c_size_t]),
+    ("f3d_smoke_seq_composite", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_double), C.c_char_p, C.c_size_t]),
+    ("f3d_smoke_seq_stats", C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]),
     ("f3d_halo_rows", C.c_uint32, []),
     ("f3d_session_enqueue_frame_part", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_char_p, C.c_size_t]),
     ("f3d_atrous_denoise", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32,

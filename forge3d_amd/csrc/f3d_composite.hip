@@ -118,7 +118,7 @@ extern "C" int f3d_smoke_composite(const f3d_composite_desc *desc, uint8_t *out_
         // device images on both sides and nobody asking for the kernel time: the call returns with its launch enqueued (the
         // inputs it read where they are must not change until the stream gets there -- a resident sequence's next call is
         // behind this one in the same stream)
-        const bool timed = kernel_seconds != nullptr || !out_on_device || !buf.owned.empty();
+        const bool timed = kernel_seconds != nullptr || !out_on_device || !buf.owned.empty() || !current_smoke_context()->async_ok;
         const dim3 block(256), grid((d.width + 256u * kPixelsPerLane - 1u) / (256u * kPixelsPerLane), d.height);
         if (timed) {
             ok(hipEventCreate(&e0), "event");

@@ -100,29 +100,51 @@ inline std::map<std::pair<int, std::string>, WorkspaceEntry> &workspace_map() {
     static auto &m = *new std::map<std::pair<int, std::string>, WorkspaceEntry>();  // (never destroyed: static destructors run after the HIP runtime has gone)
     return m;
 }
-// (call with workspace_lock() held) a buffer of at least `bytes` for `tag` on the current device; hipErrorOutOfMemory etc. on failure
-// The stream the smoke entry points (solver step, marcher, composite) enqueue on: the calling thread's choice
-// (f3d_smoke_set_stream), the null stream unless it made one.  A resident sequence puts the solver and the marcher on two
-// streams so that step f + 1 runs beside the march of frame f (forge3d_amd/smoke.py, SmokeSequence).
-inline hipStream_t &call_stream() {
-    static thread_local hipStream_t stream = nullptr;
-    return stream;
+// What the smoke entry points (solver step, marcher, composite) of ONE call run in: the stream they enqueue on, the event that
+// marks the moment the marcher has finished READING the volume's fields (its pack kernel: what a solver step on another stream
+// waits for before it overwrites them), and the name space of their scratch.
+//   * a sequence handle (f3d_smoke_seq_*, ABI 6) owns a context: explicit state, two sequences never share anything;
+//   * the handle-less entry points (f3d_smoke_step / _render / _composite) use the calling thread's default context -- the null
+//     stream, synchronous calls as in ABI 4, until f3d_smoke_set_stream (the ABI-5 shim) names a stream for the thread.
+// The "current" pointer is set for the duration of a handle call and restored behind it (ScopedSmokeContext): it is how the
+// shared implementation finds its context, not state that outlives a call.
+struct SmokeContext {
+    hipStream_t stream = nullptr;
+    hipEvent_t fields_read = nullptr;
+    unsigned long long id = 0;  // 0: the thread's default context (scratch named by stream, as in ABI 5); else "#id"
+    bool async_ok = false;      // may a call whose results stay on the device return with its launches enqueued?
+    // the marcher's deferred self-shadow list of the last render: capacity, and where its fill count lives (read on request)
+    uint32_t shadow_capacity = 0;
+    const uint32_t *shadow_cursor = nullptr;
+};
+inline SmokeContext &thread_default_smoke_context() {
+    static thread_local SmokeContext context;
+    return context;
 }
-// ... and the moment the marcher has finished READING the volume's fields (its pack kernel): what a solver step on another
-// stream has to wait for before it overwrites them (f3d_smoke_wait_fields_read).
-inline hipEvent_t &fields_read_event() {
-    static thread_local hipEvent_t event = nullptr;
-    return event;
+inline SmokeContext *&current_smoke_context() {
+    static thread_local SmokeContext *current = nullptr;
+    if (!current) current = &thread_default_smoke_context();
+    return current;
 }
+struct ScopedSmokeContext {
+    SmokeContext *saved;
+    explicit ScopedSmokeContext(SmokeContext *c) : saved(current_smoke_context()) { current_smoke_context() = c; }
+    ~ScopedSmokeContext() { current_smoke_context() = saved; }
+};
+inline hipStream_t &call_stream() { return current_smoke_context()->stream; }
+inline hipEvent_t &fields_read_event() { return current_smoke_context()->fields_read; }
 
+// (call with workspace_lock() held) a buffer of at least `bytes` for `tag` on the current device; hipErrorOutOfMemory etc. on failure
 inline hipError_t workspace(void **out, const char *tag, size_t bytes) {
     int device = 0;
     hipError_t e = hipGetDevice(&device);
     if (e != hipSuccess) return e;
-    // (a buffer belongs to the tag AND the stream its users are ordered on: two sequences of a process on two streams -- two
-    // threads, or two objects driven in turns by one -- must not march through each other's records)
-    char where[32];
-    snprintf(where, sizeof(where), "@%p", (void *)call_stream());
+    // (a buffer belongs to the tag AND to whoever's launches are ordered behind each other on it: a sequence handle, or --
+    // handle-less calls -- the stream: two sequences of a process must not march through each other's records)
+    char where[40];
+    const SmokeContext &ctx = *current_smoke_context();
+    if (ctx.id != 0ull) snprintf(where, sizeof(where), "#%llu", ctx.id);
+    else snprintf(where, sizeof(where), "@%p", (void *)ctx.stream);
     WorkspaceEntry &w = workspace_map()[{device, std::string(tag) + where}];
     if (w.bytes < bytes || !w.p) {
         if (w.p) {
@@ -139,6 +161,26 @@ inline hipError_t workspace(void **out, const char *tag, size_t bytes) {
     }
     *out = w.p;
     return hipSuccess;
+}
+// Bytes of scratch held for one name space ("#id" / "@stream"), and their release (a sequence handle that goes away).
+inline size_t workspace_bytes(const std::string &suffix) {
+    std::lock_guard<std::mutex> lock(workspace_lock());
+    size_t total = 0;
+    for (auto &kv : workspace_map())
+        if (kv.first.second.size() >= suffix.size() && kv.first.second.compare(kv.first.second.size() - suffix.size(), suffix.size(), suffix) == 0) total += kv.second.bytes;
+    return total;
+}
+inline void workspace_release(const std::string &suffix) {  // the caller has drained the streams that used it
+    std::lock_guard<std::mutex> lock(workspace_lock());
+    for (auto it = workspace_map().begin(); it != workspace_map().end();) {
+        const std::string &name = it->first.second;
+        if (name.size() >= suffix.size() && name.compare(name.size() - suffix.size(), suffix.size(), suffix) == 0) {
+            if (it->second.p) (void)device_free(it->second.p);
+            it = workspace_map().erase(it);
+        } else {
+            ++it;
+        }
+    }
 }
 inline void workspace_trim() {
     std::lock_guard<std::mutex> lock(workspace_lock());

@@ -85,6 +85,7 @@ struct f3d_session {
     int device = 0;
     FrameParams params{};
     std::shared_ptr<CachedTables> scene;  // shared, immutable acceleration tables (scene cache)
+    std::shared_ptr<CachedMesh> mesh;     // shared, immutable device copy of the mesh and its BVH (mesh cache)
     TerrainTables tables;
     uint32_t width = 0, height = 0, row_begin = 0, row_end = 0, rows = 0;
     PackedReservoir *res[2] = {nullptr, nullptr};
@@ -340,21 +341,12 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
         P.env.width = d.env_width;
         P.env.height = d.env_height;
     }
-    // mesh (HybridScene::mesh_only + upload, src/sdf/hybrid.rs:285-366: vec4-padded vertices)
+    // mesh (HybridScene::mesh_only + upload, src/sdf/hybrid.rs:285-366: vec4-padded vertices) with its acceleration structure
+    // (reference: accel::build_bvh on the CPU, render_terrain.rs:597-627 -- which its kernel then never reads; here the rays
+    // actually walk it, f3d_bvh.h).  Immutable once built, so -- like the DEM tables -- shared through a small per-process
+    // cache (acquire_mesh, f3d_host_mem.h): the second session of a mesh (a strip job's probe and then its strip, a camera
+    // path) pays neither the 80 ms host build of 600 000 triangles nor the upload.
     if (d.mesh_vertices) {
-        const std::vector<float> v4 = pad_rgb_to_rgba(d.mesh_vertices, d.mesh_vertex_count, 0.0f);
-        float4 *dv = (float4 *)s.mem.alloc(v4.size() * sizeof(float), "mesh vertices");
-        uint32_t *di = (uint32_t *)s.mem.alloc((size_t)d.mesh_index_count * sizeof(uint32_t), "mesh indices");
-        hip_check(hipMemcpy(dv, v4.data(), v4.size() * sizeof(float), hipMemcpyHostToDevice), "mesh upload");
-        hip_check(hipMemcpy(di, d.mesh_indices, (size_t)d.mesh_index_count * sizeof(uint32_t), hipMemcpyHostToDevice),
-                  "mesh upload");
-        P.mesh.vertices = dv;
-        P.mesh.indices = di;
-        P.mesh.vertex_count = d.mesh_vertex_count;
-        P.mesh.index_count = d.mesh_index_count;
-        P.mesh.traversal_mode = 0u;
-        // acceleration structure (reference: accel::build_bvh on the CPU, render_terrain.rs:597-627 -- which its
-        // kernel then never reads; here the rays actually walk it, f3d_bvh.h)
         // builder: 0 / 1 the binned-SAH host build (better trees, the default); 2 the GPU linear BVH (f3d_lbvh.hip:
         // ~1 ms for 600 000 triangles instead of 80 ms -- meshes that change every frame)
         uint32_t builder = opts ? opts->mesh_builder : 0u;
@@ -362,41 +354,11 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
             const char *env = getenv("F3D_MESH_BVH");
             builder = (env && strcmp(env, "lbvh") == 0) ? 2u : ((env && strcmp(env, "binary") == 0) ? 3u : 1u);
         }
-        if (builder == 2u) {
-            LbvhResult lb;
-            hip_check(build_mesh_lbvh(dv, d.mesh_vertex_count, di, d.mesh_index_count, s.stream, &lb), "GPU LBVH build");
-            if (lb.nodes) {
-                s.mem.adopt(lb.nodes, lb.node_bytes);
-                s.mem.adopt(lb.tris, lb.tri_bytes);
-                P.mesh.bvh_nodes = lb.nodes;
-                P.mesh.bvh_tris = lb.tris;
-                P.mesh.bvh_node_count = lb.node_count;
-            }
-        } else if (builder == 1u || builder == 3u) {
-            const MeshBvh bvh = build_mesh_bvh(d.mesh_vertices, d.mesh_vertex_count, d.mesh_indices, d.mesh_index_count);
-            if (!bvh.nodes.empty()) {
-                // the walk's form: four children wide (one 128-byte record per ENTERED node, f3d_shade.h mesh_bvh4) unless the
-                // tree is too deep for the walk's per-level words or the binary form is asked for (3: A/B, the round-3 walk)
-                std::vector<Bvh4Node> wide;
-                if (builder == 1u) wide = collapse_bvh4(bvh);
-                float4 *dt = (float4 *)s.mem.alloc(bvh.tris.size() * sizeof(float), "mesh BVH triangles");
-                hip_check(hipMemcpy(dt, bvh.tris.data(), bvh.tris.size() * sizeof(float), hipMemcpyHostToDevice), "BVH upload");
-                P.mesh.bvh_tris = dt;
-                if (!wide.empty()) {
-                    Bvh4Node *dw = (Bvh4Node *)s.mem.alloc(wide.size() * sizeof(Bvh4Node), "mesh BVH nodes (4-wide)");
-                    hip_check(hipMemcpy(dw, wide.data(), wide.size() * sizeof(Bvh4Node), hipMemcpyHostToDevice), "BVH upload");
-                    P.mesh.bvh4_nodes = dw;
-                    P.mesh.bvh4_node_count = (uint32_t)wide.size();
-                } else {
-                    BvhNode *dn = (BvhNode *)s.mem.alloc(bvh.nodes.size() * sizeof(BvhNode), "mesh BVH nodes");
-                    hip_check(hipMemcpy(dn, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice), "BVH upload");
-                    P.mesh.bvh_nodes = dn;
-                    P.mesh.bvh_node_count = (uint32_t)bvh.nodes.size();
-                }
-            }
-        } else {
+        if (builder < 1u || builder > 3u)
             fail(F3D_STATUS_VALUE, "mesh_builder must be 0 (automatic), 1 (host SAH, walked 4 wide), 2 (GPU LBVH) or 3 (host SAH, binary walk), got %u", builder);
-        }
+        s.mesh = acquire_mesh(s.device, d.mesh_vertices, d.mesh_vertex_count, d.mesh_indices, d.mesh_index_count, builder, s.stream);
+        s.mem.device_bytes += s.mesh->mem.device_bytes;  // shared, but part of this render's working set
+        P.mesh = s.mesh->dev;
     }
     if (d.atmosphere) upload_aether(s, *d.atmosphere, d);
     clock.lap(kSetupScene);
@@ -1366,6 +1328,12 @@ void f3d_scene_cache_limit(uint32_t entries) {
         for (size_t i = 1; i < g_scene_cache.size(); i++)
             if (g_scene_cache[i]->stamp < g_scene_cache[oldest]->stamp) oldest = i;
         g_scene_cache.erase(g_scene_cache.begin() + (long)oldest);
+    }
+    while (g_mesh_cache.size() > g_scene_limit) {  // (the mesh cache follows the same limit)
+        size_t oldest = 0;
+        for (size_t i = 1; i < g_mesh_cache.size(); i++)
+            if (g_mesh_cache[i]->stamp < g_mesh_cache[oldest]->stamp) oldest = i;
+        g_mesh_cache.erase(g_mesh_cache.begin() + (long)oldest);
     }
 }
 

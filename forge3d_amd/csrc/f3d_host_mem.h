@@ -363,6 +363,103 @@ std::shared_ptr<CachedTables> acquire_tables(int device, const float *heights, u
     return e;
 }
 
+// ---- mesh cache: a mesh's device copy and its BVH, shared like the DEM tables (round 6) -------------------------------------
+struct CachedMesh {
+    int device = 0;
+    uint64_t key_v = 0, key_i = 0;
+    uint32_t vertex_count = 0, index_count = 0, builder = 0;
+    Ledger mem;
+    MeshDev dev{};
+    uint64_t stamp = 0;
+    ~CachedMesh() {
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        (void)hipSetDevice(device);
+        mem.release();
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+std::vector<std::shared_ptr<CachedMesh>> &g_mesh_cache = *new std::vector<std::shared_ptr<CachedMesh>>();  // (never destroyed: see g_scene_cache)
+
+std::shared_ptr<CachedMesh> acquire_mesh(int device, const float *vertices, uint32_t vertex_count, const uint32_t *indices, uint32_t index_count,
+                                         uint32_t builder, hipStream_t stream) {
+    const uint64_t key_v = hash_bytes(vertices, (size_t)vertex_count * 3u * sizeof(float), 0x6D657368ull);
+    const uint64_t key_i = hash_bytes(indices, (size_t)index_count * sizeof(uint32_t), 0x696E6478ull);
+    {
+        std::lock_guard<std::mutex> lock(g_scene_mutex);
+        for (auto &e : g_mesh_cache)
+            if (e->device == device && e->key_v == key_v && e->key_i == key_i && e->vertex_count == vertex_count && e->index_count == index_count &&
+                e->builder == builder) {
+                e->stamp = ++g_scene_stamp;
+                return e;
+            }
+    }
+    auto e = std::make_shared<CachedMesh>();
+    e->device = device;
+    e->key_v = key_v;
+    e->key_i = key_i;
+    e->vertex_count = vertex_count;
+    e->index_count = index_count;
+    e->builder = builder;
+    const std::vector<float> v4 = pad_rgb_to_rgba(vertices, vertex_count, 0.0f);
+    float4 *dv = (float4 *)e->mem.alloc(v4.size() * sizeof(float), "mesh vertices");
+    uint32_t *di = (uint32_t *)e->mem.alloc((size_t)index_count * sizeof(uint32_t), "mesh indices");
+    hip_check(hipMemcpy(dv, v4.data(), v4.size() * sizeof(float), hipMemcpyHostToDevice), "mesh upload");
+    hip_check(hipMemcpy(di, indices, (size_t)index_count * sizeof(uint32_t), hipMemcpyHostToDevice), "mesh upload");
+    MeshDev &M = e->dev;
+    M.vertices = dv;
+    M.indices = di;
+    M.vertex_count = vertex_count;
+    M.index_count = index_count;
+    M.traversal_mode = 0u;
+    if (builder == 2u) {
+        LbvhResult lb;
+        hip_check(build_mesh_lbvh(dv, vertex_count, di, index_count, stream, &lb), "GPU LBVH build");
+        hip_check(hipStreamSynchronize(stream), "GPU LBVH build");  // other sessions may walk it from their streams
+        if (lb.nodes) {
+            e->mem.adopt(lb.nodes, lb.node_bytes);
+            e->mem.adopt(lb.tris, lb.tri_bytes);
+            M.bvh_nodes = lb.nodes;
+            M.bvh_tris = lb.tris;
+            M.bvh_node_count = lb.node_count;
+        }
+    } else {
+        const MeshBvh bvh = build_mesh_bvh(vertices, vertex_count, indices, index_count);
+        if (!bvh.nodes.empty()) {
+            // the walk's form: four children wide (one 128-byte record per ENTERED node, f3d_shade.h mesh_bvh4) unless the
+            // tree is too deep for the walk's per-level words or the binary form is asked for (3: A/B, the round-3 walk)
+            std::vector<Bvh4Node> wide;
+            if (builder == 1u) wide = collapse_bvh4(bvh);
+            float4 *dt = (float4 *)e->mem.alloc(bvh.tris.size() * sizeof(float), "mesh BVH triangles");
+            hip_check(hipMemcpy(dt, bvh.tris.data(), bvh.tris.size() * sizeof(float), hipMemcpyHostToDevice), "BVH upload");
+            M.bvh_tris = dt;
+            if (!wide.empty()) {
+                Bvh4Node *dw = (Bvh4Node *)e->mem.alloc(wide.size() * sizeof(Bvh4Node), "mesh BVH nodes (4-wide)");
+                hip_check(hipMemcpy(dw, wide.data(), wide.size() * sizeof(Bvh4Node), hipMemcpyHostToDevice), "BVH upload");
+                M.bvh4_nodes = dw;
+                M.bvh4_node_count = (uint32_t)wide.size();
+            } else {
+                BvhNode *dn = (BvhNode *)e->mem.alloc(bvh.nodes.size() * sizeof(BvhNode), "mesh BVH nodes");
+                hip_check(hipMemcpy(dn, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice), "BVH upload");
+                M.bvh_nodes = dn;
+                M.bvh_node_count = (uint32_t)bvh.nodes.size();
+            }
+        }
+    }
+    std::lock_guard<std::mutex> lock(g_scene_mutex);
+    e->stamp = ++g_scene_stamp;
+    if (g_scene_limit > 0) {
+        g_mesh_cache.push_back(e);
+        while (g_mesh_cache.size() > g_scene_limit) {  // least recently used out (sessions holding it keep it alive)
+            size_t oldest = 0;
+            for (size_t i = 1; i < g_mesh_cache.size(); i++)
+                if (g_mesh_cache[i]->stamp < g_mesh_cache[oldest]->stamp) oldest = i;
+            g_mesh_cache.erase(g_mesh_cache.begin() + (long)oldest);
+        }
+    }
+    return e;
+}
+
 }  // namespace
 
 namespace f3d {

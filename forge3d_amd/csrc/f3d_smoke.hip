@@ -11,11 +11,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <mutex>
+#include <new>
 #include <vector>
 
 #include "f3d_setup.h"
@@ -397,6 +399,7 @@ __device__ __forceinline__ uchar4 smoke_pixel(const SmokeParams &P, V3 rgb, floa
 // k_smoke_shade walks its rays in the one-kernel form.
 enum : uint32_t { kWhole = 0u, kCollect = 1u };
 constexpr uint32_t kChunkRows = 16u, kChunkSlots = kChunkRows * 64u, kNoChunk = 0xFFFFFFFFu, kUnset = 0xFFFFFFFEu;
+constexpr size_t kListStepsPerPixel = 16u, kListCapMb = 2048u;  // sizing of the deferred list (f3d_smoke_render)
 struct Deferred {
     float4 *where;       // per slot: the step's position, and its extinction sigma_t
     float4 *fields;      // per slot: density, soot, age, temperature as interpolated there
@@ -682,16 +685,24 @@ void validate_volume(const f3d_smoke_volume &v) {  // SmokeDomainConfig::validat
 
 }  // namespace
 
-extern "C" void f3d_smoke_set_stream(void *stream) { call_stream() = static_cast<hipStream_t>(stream); }
+// ABI-5 shim (one revision): names the stream of the calling thread's DEFAULT context and, with it, opts the thread's
+// handle-less calls into returning before their kernels have finished.  New callers hold a sequence handle (below).
+extern "C" void f3d_smoke_set_stream(void *stream) {
+    SmokeContext &ctx = thread_default_smoke_context();
+    ctx.stream = static_cast<hipStream_t>(stream);
+    ctx.async_ok = true;
+}
 extern "C" int f3d_smoke_wait_fields_read(void *stream) {
-    if (!fields_read_event()) return F3D_STATUS_OK;
-    return hipStreamWaitEvent(static_cast<hipStream_t>(stream), fields_read_event(), 0) == hipSuccess ? F3D_STATUS_OK : F3D_STATUS_DEVICE;
+    SmokeContext &ctx = thread_default_smoke_context();
+    if (!ctx.fields_read) return F3D_STATUS_OK;
+    return hipStreamWaitEvent(static_cast<hipStream_t>(stream), ctx.fields_read, 0) == hipSuccess ? F3D_STATUS_OK : F3D_STATUS_DEVICE;
 }
 
 extern "C" int f3d_smoke_render(const f3d_smoke_volume *vol, const f3d_smoke_view *view, const f3d_smoke_settings *settings,
                                 uint8_t *rgba, double *kernel_seconds, char *err, size_t errlen) {
     if (err && errlen) err[0] = 0;
     int rc = F3D_STATUS_OK;
+    hipEvent_t e0 = nullptr, e1 = nullptr;  // (destroyed behind the catch blocks: a failure in between must not leak them)
     try {
         if (!vol || !view || !settings || !rgba) fail(F3D_STATUS_VALUE, "null argument");
         validate_settings(*settings);
@@ -807,8 +818,7 @@ extern "C" int f3d_smoke_render(const f3d_smoke_volume *vol, const f3d_smoke_vie
         P.out = out_on_device ? rgba : (uint8_t *)alloc(px * 4, "smoke rgba");  // (a device image stays on the device: the composite reads it there)
         if (out_on_device) n_scratch++;
         // a device image whose caller does not ask for the kernel time: the call returns with its launches enqueued
-        const bool timed = kernel_seconds != nullptr || !out_on_device;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
+        const bool timed = kernel_seconds != nullptr || !out_on_device || !current_smoke_context()->async_ok;
         if (timed) {
             hip_ok(hipEventCreate(&e0), "event");
             hip_ok(hipEventCreate(&e1), "event");
@@ -818,14 +828,28 @@ extern "C" int f3d_smoke_render(const f3d_smoke_volume *vol, const f3d_smoke_vie
         const char *form = getenv("F3D_SMOKE_MARCH");
         Deferred D{};
         D.chunks_per_tile = (P.st.max_steps + kChunkRows - 1u) / kChunkRows;
-        const bool deferred = P.st.self_shadow != 0u && !form && D.chunks_per_tile <= 4096u;
+        bool deferred = P.st.self_shadow != 0u && !form && D.chunks_per_tile <= 4096u;
         if (deferred) {  // the default: the self-shadow marches as a launch of their own between two walks of the rays
-            size_t slots = std::max<size_t>((size_t)1 << 20, px * 16u);  // 52 B a slot: 1.7 GB for a 1080p frame, 54 MB at least (a tile whose steps do not fit is walked by k_smoke_shade in the one-kernel form)
+            // The list of deferred steps, 52 B a slot: kListStepsPerPixel in-volume steps of every pixel (a tile takes them in
+            // chunks of 16 steps x 64 lanes), capped at F3D_SMOKE_SHADOW_MB.  A tile whose steps do not fit is walked by
+            // k_smoke_shade in the one-kernel form (same result), and a list that cannot be allocated at all sends the whole
+            // frame there.  f3d_smoke_seq_stats reports how much of it a render used.
+            size_t slots = std::max<size_t>((size_t)1 << 20, px * kListStepsPerPixel);
+            const size_t cap_mb = getenv("F3D_SMOKE_SHADOW_MB") ? (size_t)strtoull(getenv("F3D_SMOKE_SHADOW_MB"), nullptr, 10) : kListCapMb;
+            slots = std::min<size_t>(slots, std::max<size_t>((cap_mb << 20) / 52u, kChunkSlots));
             if (const char *e = getenv("F3D_SMOKE_SHADOW_SLOTS")) slots = (size_t)strtoull(e, nullptr, 10);  // test hook: a list that runs out
             D.capacity = (uint32_t)std::min<size_t>(std::max<size_t>(slots / kChunkSlots, 1u), 1u << 21);
-            auto named = [&](const char *tag, size_t bytes) {  // (requests of this form only: their own tags)
+            bool out_of_memory = false;
+            auto named = [&](const char *tag, size_t bytes) -> void * {  // (requests of this form only: their own tags)
                 void *q = nullptr;
-                hip_ok(workspace(&q, tag, bytes), "smoke shadow list");
+                if (out_of_memory) return q;
+                const hipError_t e = getenv("F3D_SMOKE_SHADOW_OOM") ? hipErrorOutOfMemory : workspace(&q, tag, bytes);  // (test hook)
+                if (e == hipErrorOutOfMemory) {
+                    (void)hipGetLastError();
+                    out_of_memory = true;
+                    return nullptr;
+                }
+                hip_ok(e, "smoke shadow list");
                 return q;
             };
             const size_t list = (size_t)D.capacity * kChunkSlots;
@@ -838,6 +862,11 @@ extern "C" int f3d_smoke_render(const f3d_smoke_volume *vol, const f3d_smoke_vie
             D.owner = (uint2 *)named("smoke.render.shadow.owner", (size_t)D.capacity * sizeof(uint2));
             D.count = (uint32_t *)named("smoke.render.shadow.count", px * sizeof(uint32_t));
             D.cursor = (uint32_t *)named("smoke.render.shadow.cursor", sizeof(uint32_t));
+            if (out_of_memory) deferred = false;  // the one-kernel form needs no list
+        }
+        current_smoke_context()->shadow_capacity = deferred ? D.capacity : 0u;
+        current_smoke_context()->shadow_cursor = deferred ? D.cursor : nullptr;
+        if (deferred) {
             hip_ok(hipMemsetAsync(D.cursor, 0, sizeof(uint32_t), call_stream()), "smoke shadow list");
             const size_t lds = ((size_t)D.chunks_per_tile + 1u) * sizeof(uint32_t);
             hipLaunchKernelGGL(k_smoke_rays<kCollect>, dim3(tiles), dim3(64), lds, call_stream(), P, D);
@@ -857,8 +886,6 @@ extern "C" int f3d_smoke_render(const f3d_smoke_volume *vol, const f3d_smoke_vie
             }
             float ms = 0.0f;
             (void)hipEventElapsedTime(&ms, e0, e1);
-            (void)hipEventDestroy(e0);
-            (void)hipEventDestroy(e1);
             if (kernel_seconds) *kernel_seconds = ms * 1e-3;
         }
     } catch (const Failure &f) {
@@ -869,5 +896,147 @@ extern "C" int f3d_smoke_render(const f3d_smoke_volume *vol, const f3d_smoke_vie
     } catch (...) {
         rc = F3D_STATUS_DEVICE;
     }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
     return rc;
+}
+
+// ---- sequence handle (ABI 6) ----------------------------------------------------------------------------------------------
+// A resident smoke sequence as an object: its two streams (solver, marcher), the ordering between them, its scratch and the
+// event that marks "the marcher has read the fields" all belong to the handle.  Round 5 kept the stream and the event in
+// thread-local variables behind f3d_smoke_set_stream / f3d_smoke_wait_fields_read: the library "remembered the last render of
+// the thread", and a caller driving two sequences had to re-name its stream before every call.  (No counterpart in the
+// reference, whose solver and marcher are host loops: src/smoke/sim.rs, src/smoke/render.rs.)
+struct f3d_smoke_seq {
+    int device = 0;
+    hipStream_t solver = nullptr, march = nullptr;  // the caller's streams (NULL: the null stream); they outlive the handle
+    hipEvent_t stepped = nullptr;  // the last step's launches, on the solver's stream
+    bool has_stepped = false;
+    SmokeContext ctx;
+};
+
+namespace {
+std::atomic<unsigned long long> g_smoke_seq_ids{1ull};
+
+struct SeqDevice {  // the handle's device for the duration of a call
+    int prev = -1;
+    explicit SeqDevice(int device) {
+        (void)hipGetDevice(&prev);
+        if (prev != device) (void)hipSetDevice(device);
+        else prev = -1;
+    }
+    ~SeqDevice() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+int seq_fail(char *err, size_t errlen, int status, const char *what) {
+    if (err && errlen) snprintf(err, errlen, "%s", what);
+    return status;
+}
+}  // namespace
+
+extern "C" int f3d_smoke_seq_create(void *stream_solver, void *stream_march, f3d_smoke_seq **out, char *err, size_t errlen) {
+    if (err && errlen) err[0] = 0;
+    if (!out) return seq_fail(err, errlen, F3D_STATUS_VALUE, "null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return seq_fail(err, errlen, F3D_STATUS_DEVICE, "no HIP device available: libf3dhip has no CPU fallback");
+    f3d_smoke_seq *q = new (std::nothrow) f3d_smoke_seq();
+    if (!q) return seq_fail(err, errlen, F3D_STATUS_DEVICE, "out of host memory");
+    bool ok = hipGetDevice(&q->device) == hipSuccess;
+    q->solver = static_cast<hipStream_t>(stream_solver);
+    q->march = static_cast<hipStream_t>(stream_march);
+    ok = ok && hipEventCreateWithFlags(&q->stepped, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&q->ctx.fields_read, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        if (q->stepped) (void)hipEventDestroy(q->stepped);
+        if (q->ctx.fields_read) (void)hipEventDestroy(q->ctx.fields_read);
+        delete q;
+        return seq_fail(err, errlen, F3D_STATUS_DEVICE, "could not create the sequence's events");
+    }
+    q->ctx.id = g_smoke_seq_ids.fetch_add(1ull);
+    q->ctx.async_ok = true;
+    // (a fresh fields_read event has never been recorded: waiting for it returns at once, as it should before the first render)
+    *out = q;
+    return F3D_STATUS_OK;
+}
+
+extern "C" void f3d_smoke_seq_destroy(f3d_smoke_seq *q) {
+    if (!q) return;
+    SeqDevice guard(q->device);
+    (void)hipStreamSynchronize(q->solver);
+    (void)hipStreamSynchronize(q->march);
+    char suffix[40];
+    snprintf(suffix, sizeof(suffix), "#%llu", q->ctx.id);
+    workspace_release(suffix);  // the scratch of this sequence goes back (to the library's pool; f3d_device_pool_trim empties that)
+    (void)hipEventDestroy(q->stepped);
+    (void)hipEventDestroy(q->ctx.fields_read);
+    delete q;
+}
+
+extern "C" int f3d_smoke_seq_streams(f3d_smoke_seq *q, void **stream_solver, void **stream_march) {
+    if (!q) return F3D_STATUS_VALUE;
+    if (stream_solver) *stream_solver = q->solver;
+    if (stream_march) *stream_march = q->march;
+    return F3D_STATUS_OK;
+}
+
+extern "C" int f3d_smoke_step(f3d_smoke_state *, const f3d_smoke_step_settings *, const f3d_smoke_emitter *, uint32_t, uint32_t, double *, char *, size_t);
+extern "C" int f3d_smoke_composite(const f3d_composite_desc *, uint8_t *, double *, char *, size_t);
+
+// `steps` solver steps on the solver's stream, behind the last render's reads of the fields.
+extern "C" int f3d_smoke_seq_step(f3d_smoke_seq *q, f3d_smoke_state *state, const f3d_smoke_step_settings *settings, const f3d_smoke_emitter *emitters,
+                                  uint32_t emitter_count, uint32_t steps, double *device_seconds, char *err, size_t errlen) {
+    if (!q) return seq_fail(err, errlen, F3D_STATUS_VALUE, "null sequence handle");
+    SeqDevice guard(q->device);
+    q->ctx.stream = q->solver;
+    if (hipStreamWaitEvent(q->solver, q->ctx.fields_read, 0) != hipSuccess) return seq_fail(err, errlen, F3D_STATUS_DEVICE, "could not order the step behind the last render");
+    ScopedSmokeContext scope(&q->ctx);
+    const int rc = f3d_smoke_step(state, settings, emitters, emitter_count, steps, device_seconds, err, errlen);
+    if (rc == F3D_STATUS_OK) {
+        if (hipEventRecord(q->stepped, q->solver) != hipSuccess) return seq_fail(err, errlen, F3D_STATUS_DEVICE, "could not record the step");
+        q->has_stepped = true;
+    }
+    return rc;
+}
+
+// The march of the volume into `rgba` on the marcher's stream, behind the last step.
+extern "C" int f3d_smoke_seq_render(f3d_smoke_seq *q, const f3d_smoke_volume *volume, const f3d_smoke_view *view, const f3d_smoke_settings *settings,
+                                    uint8_t *rgba, double *kernel_seconds, char *err, size_t errlen) {
+    if (!q) return seq_fail(err, errlen, F3D_STATUS_VALUE, "null sequence handle");
+    SeqDevice guard(q->device);
+    q->ctx.stream = q->march;
+    if (q->has_stepped && hipStreamWaitEvent(q->march, q->stepped, 0) != hipSuccess)
+        return seq_fail(err, errlen, F3D_STATUS_DEVICE, "could not order the render behind the last step");
+    ScopedSmokeContext scope(&q->ctx);
+    return f3d_smoke_render(volume, view, settings, rgba, kernel_seconds, err, errlen);  // (records ctx.fields_read behind its pack kernels)
+}
+
+// The composite on the marcher's stream (behind the render whose layer it reads).
+extern "C" int f3d_smoke_seq_composite(f3d_smoke_seq *q, const f3d_composite_desc *desc, uint8_t *out_rgba, double *kernel_seconds, char *err, size_t errlen) {
+    if (!q) return seq_fail(err, errlen, F3D_STATUS_VALUE, "null sequence handle");
+    SeqDevice guard(q->device);
+    q->ctx.stream = q->march;
+    ScopedSmokeContext scope(&q->ctx);
+    return f3d_smoke_composite(desc, out_rgba, kernel_seconds, err, errlen);
+}
+
+// What the sequence holds and how much of the deferred self-shadow list its last render used (waits for that render).
+extern "C" int f3d_smoke_seq_stats(f3d_smoke_seq *q, f3d_smoke_seq_stats_t *out, char *err, size_t errlen) {
+    if (!q || !out) return seq_fail(err, errlen, F3D_STATUS_VALUE, "null argument");
+    SeqDevice guard(q->device);
+    char suffix[40];
+    snprintf(suffix, sizeof(suffix), "#%llu", q->ctx.id);
+    out->scratch_bytes = workspace_bytes(suffix);
+    out->shadow_list_chunks = q->ctx.shadow_capacity;
+    out->shadow_list_chunks_used = 0u;
+    out->shadow_list_slots_per_chunk = kChunkSlots;
+    if (q->ctx.shadow_cursor) {
+        if (hipStreamSynchronize(q->march) != hipSuccess) return seq_fail(err, errlen, F3D_STATUS_DEVICE, "the marcher's stream failed");
+        uint32_t used = 0u;
+        if (hipMemcpy(&used, q->ctx.shadow_cursor, sizeof(used), hipMemcpyDeviceToHost) != hipSuccess) return seq_fail(err, errlen, F3D_STATUS_DEVICE, "could not read the list's fill count");
+        out->shadow_list_chunks_used = used;  // (may exceed the capacity: that many were asked for; the excess was walked in the one-kernel form)
+    }
+    return F3D_STATUS_OK;
 }

@@ -605,7 +605,7 @@ extern "C" int f3d_smoke_step(f3d_smoke_state *st, const f3d_smoke_step_settings
 
         // A call whose state stays on the device and whose caller does not ask for the device time returns as soon as its
         // launches are enqueued (a resident sequence: the next call's work is behind this call's in the stream).
-        const bool timed = device_seconds != nullptr || !resident;
+        const bool timed = device_seconds != nullptr || !resident || !current_smoke_context()->async_ok;  // (handle-less calls on the null stream wait, as in ABI 4)
         ok(hipEventCreate(&e0), "event");
         ok(hipEventCreate(&e1), "event");
         // Which driver (see "the step as PHASES" above): fused launches by default; F3D_SMOKE_SOLVER=persistent / launches

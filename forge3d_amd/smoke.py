@@ -614,14 +614,53 @@ class SmokeSequence:
         # resident state returns with its launches enqueued and the host runs ahead of the device (round 5)
         self.timing = False
         self.rendered = [torch.cuda.Event() for _ in range(2)]
-        # frames(): the solver and the marcher on a stream each (f3d_smoke_set_stream), so that step f + 1 runs beside the
-        # march of frame f -- the marcher reads the state only in its first kernels (f3d_smoke_wait_fields_read)
+        # frames(): the solver and the marcher on a stream each, so that step f + 1 runs beside the march of frame f -- the
+        # marcher reads the state only in its first kernels.  The library's sequence HANDLE (f3d_smoke_seq_*, ABI 6) holds the
+        # two streams, orders a step behind the last render's reads and a render behind the last step, and owns the scratch.
         self.solver_stream = torch.cuda.Stream(self.device)  # (a high-priority stream measured no different: 0.80-0.81 ms a frame either way)
         self.render_stream = torch.cuda.Stream(self.device)
-        self.stepped = torch.cuda.Event()
-        self._stream = None  # the stream the library calls of this object enqueue on (None: the null stream)
-        self._turn = 0
         self._err = C.create_string_buffer(512)
+        # one handle per schedule: "overlap" = (solver stream, marcher stream); "serial" = both on the null stream, which is what
+        # step() / render_to_device() called directly use (torch's default stream: the caller's tensor code is ordered with it)
+        self._handles = {}
+        self._mode = "serial"
+        self._turn = 0
+
+    def _handle(self, mode=None):
+        mode = mode or self._mode
+        if mode not in self._handles:
+            streams = (self.solver_stream.cuda_stream, self.render_stream.cuda_stream) if mode == "overlap" else (None, None)
+            h = C.c_void_p(None)
+            with self.torch.cuda.device(self.device):
+                self._check(_native.lib().f3d_smoke_seq_create(C.c_void_p(streams[0]), C.c_void_p(streams[1]), C.byref(h), self._err, len(self._err)))
+            self._handles[mode] = h
+        return self._handles[mode]
+
+    def _march_stream(self):
+        return self.render_stream if self._mode == "overlap" else self.torch.cuda.default_stream(self.device)
+
+    def close(self):
+        """Give the sequence's device scratch back (the library keeps it per handle; about 1.8 GB at 1080p with self-shadowing)."""
+        for h in self._handles.values():
+            _native.lib().f3d_smoke_seq_destroy(h)
+        self._handles = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
+
+    def stats(self) -> dict:
+        """f3d_smoke_seq_stats of the current schedule's handle: bytes of scratch held, and the fill of the marcher's deferred
+        self-shadow list in the last render (waits for it)."""
+        class _Stats(C.Structure):
+            _fields_ = [("scratch_bytes", C.c_uint64), ("shadow_list_chunks", C.c_uint32), ("shadow_list_chunks_used", C.c_uint32),
+                        ("shadow_list_slots_per_chunk", C.c_uint32), ("reserved", C.c_uint32)]
+
+        st = _Stats()
+        self._check(_native.lib().f3d_smoke_seq_stats(self._handle(), C.byref(st), self._err, len(self._err)))
+        return {name: int(getattr(st, name)) for name, _ in _Stats._fields_ if name != "reserved"}
 
     def set_terrain(self, terrain_rgba):
         """Another terrain frame under the same smoke (a moving sun, a camera path rendered frame by frame)."""
@@ -655,9 +694,8 @@ class SmokeSequence:
                 v = getattr(e, name)
                 setattr(dst, name, (C.c_float * 3)(*v) if name in ("center", "velocity") else float(v))
         seconds = C.c_double(0.0)
-        self._enqueue_on(self._stream)
-        self._check(_native.lib().f3d_smoke_step(C.byref(st), C.byref(settings._native()), em, C.c_uint32(len(emitters)), C.c_uint32(int(steps)),
-                                                 C.byref(seconds) if self.timing else None, self._err, len(self._err)))
+        self._check(_native.lib().f3d_smoke_seq_step(self._handle(), C.byref(st), C.byref(settings._native()), em, C.c_uint32(len(emitters)), C.c_uint32(int(steps)),
+                                                     C.byref(seconds) if self.timing else None, self._err, len(self._err)))
         self.time_seconds, self.frame_index = float(st.time_seconds), int(st.frame_index)
         self.kernel_seconds["solver_step"] = float(seconds.value) / int(steps)
 
@@ -675,18 +713,13 @@ class SmokeSequence:
         vol.frame_index = int(self.frame_index) & 0xFFFFFFFF
         seconds = C.c_double(0.0)
         native = self.settings._native()
-        self._enqueue_on(self._stream)  # (per call: another sequence of this thread may have named its own stream in between)
-        self._check(_native.lib().f3d_smoke_render(C.byref(vol), C.byref(self.view), C.byref(native), C.c_void_p(self.layer.data_ptr()),
-                                                   C.byref(seconds) if self.timing else None, self._err, len(self._err)))
-        if self._stream is self.render_stream:
-            # the next step, on the solver's stream, overwrites the state: it waits for THIS march's re-pack of it -- asked for
-            # here, right behind the call, because the library remembers the last render of the THREAD, whoever made it
-            if _native.lib().f3d_smoke_wait_fields_read(C.c_void_p(self.solver_stream.cuda_stream)) != 0:
-                raise RuntimeError("f3d_smoke_wait_fields_read failed")
+        # (the handle orders this march behind the last step, and the next step behind this march's re-pack of the state)
+        self._check(_native.lib().f3d_smoke_seq_render(self._handle(), C.byref(vol), C.byref(self.view), C.byref(native), C.c_void_p(self.layer.data_ptr()),
+                                                       C.byref(seconds) if self.timing else None, self._err, len(self._err)))
         self.kernel_seconds["march"] = float(seconds.value)
         out = self.out[self._turn]
         # (this image's last read-back -- two frames ago, on the copy stream -- before the composite overwrites it)
-        stream = self._stream if self._stream is not None else self.torch.cuda.default_stream(self.device)
+        stream = self._march_stream()
         stream.wait_event(self.copied[self._turn])
         desc = _CompositeDesc()
         desc.struct_size = C.sizeof(_CompositeDesc)
@@ -695,38 +728,35 @@ class SmokeSequence:
         desc.base, desc.layer = self.base.data_ptr(), self.layer.data_ptr()
         desc.max_alpha = HYBRID_SMOKE_MAX_ALPHA
         seconds = C.c_double(0.0)
-        self._check(_native.lib().f3d_smoke_composite(C.byref(desc), C.c_void_p(out.data_ptr()), C.byref(seconds) if self.timing else None,
-                                                      self._err, len(self._err)))
+        self._check(_native.lib().f3d_smoke_seq_composite(self._handle(), C.byref(desc), C.c_void_p(out.data_ptr()), C.byref(seconds) if self.timing else None,
+                                                          self._err, len(self._err)))
         self.kernel_seconds["composite"] = float(seconds.value)
         self.rendered[self._turn].record(stream)
         return out
 
-    def _enqueue_on(self, stream):
-        self._stream = stream
-        _native.lib().f3d_smoke_set_stream(C.c_void_p(stream.cuda_stream if stream is not None else None))
-
-    def frames(self, count: int, settings=None, emitters=None, steps_per_frame: int = 1, timing: bool = False, overlap: bool = True):
+    def frames(self, count: int, settings=None, emitters=None, steps_per_frame: int = 1, timing: bool = False, overlap: bool = True,
+               base_provider=None):
         """`count` frames of emitters -> solver -> ray-marcher -> composite; yields (H, W, 4) uint8 host images (each a view of
         a pinned buffer that the frame after next reuses: copy what is to be kept).  The device-to-host copy of a frame
         runs while the next frame's kernels do, and -- unless timing=True asks for kernel_seconds -- the host enqueues a
         frame's launches without waiting for the device.  overlap: the solver on a stream of its own, one step ahead of the
         marcher (neither fills the chip: the solver's phases are 3 000 short workgroups, the marcher's first walk is as long
-        as its longest ray); False = everything on the null stream, one kernel after the other."""
+        as its longest ray); False = everything on the null stream, one kernel after the other.
+        base_provider(i, base, stream): called before frame i's march; it enqueues, ON `stream` (the torch stream the frame's
+        composite runs on), whatever writes this frame's terrain image into `base` ((H, W, 4) uint8 on the device) -- a terrain
+        render under a moving sun, resolved straight into it (TerrainSession(stream=stream.cuda_stream).resolve_device)."""
         torch = self.torch
         pending = None
         self.timing = bool(timing)
         overlap = bool(overlap) and not self.timing
         torch.cuda.synchronize(self.device)  # (the state's upload and whatever the caller did to it on other streams)
+        self._mode = "overlap" if overlap else "serial"
         try:
-            for _ in range(int(count)):
-                if overlap:
-                    self._stream = self.solver_stream
-                self.step(settings, emitters, steps=steps_per_frame)
-                if overlap:
-                    self.stepped.record(self.solver_stream)
-                    self._stream = self.render_stream
-                    self.render_stream.wait_event(self.stepped)
-                image = self.render_to_device()  # (with the marcher on its own stream: also makes the solver's stream wait for the re-pack)
+            for index in range(int(count)):
+                self.step(settings, emitters, steps=steps_per_frame)  # (on the solver's stream, behind the last march's reads of the state)
+                if base_provider is not None:  # (in stream order behind the previous frame's composite, which read the old image)
+                    base_provider(index, self.base, self._march_stream())
+                image = self.render_to_device()  # (on the marcher's stream, behind the step)
                 turn = self._turn
                 with torch.cuda.stream(self.copy_stream):
                     self.copy_stream.wait_event(self.rendered[turn])  # the image is complete when the marcher's stream gets there
@@ -742,7 +772,7 @@ class SmokeSequence:
                 yield self.pinned[pending].numpy()
         finally:
             torch.cuda.synchronize(self.device)
-            self._enqueue_on(None)
+            self._mode = "serial"
 
     def download(self) -> "SmokeDomain":
         """Bring the domain's host arrays (and its clock) up to date with the resident state."""

@@ -37,8 +37,12 @@ extern "C" {
  *               changed: a caller built against version 3 keeps working)
  *   5  round 5: + f3d_session_row_costs, f3d_session_primary_start, f3d_smoke_set_stream, f3d_smoke_wait_fields_read; the
  *               smoke entry points return without waiting when their results stay on the device and no time is asked for;
- *               f3d_wf_scene + primary_start at its end (no existing signature changed) */
-#define F3D_ABI_VERSION 5u
+ *               f3d_wf_scene + primary_start at its end (no existing signature changed)
+ *   6  round 6: + f3d_smoke_seq_* (a smoke sequence behind a handle: its streams, its ordering, its scratch).  The handle-less
+ *               smoke entry points are synchronous again, as in ABI 4, unless the thread has called f3d_smoke_set_stream --
+ *               which, with f3d_smoke_wait_fields_read, stays for this one revision as a shim over the thread's default
+ *               context.  No struct changed: a caller built against version 3, 4 or 5 keeps working. */
+#define F3D_ABI_VERSION 6u
 #define F3D_STATUS_OK 0
 #define F3D_STATUS_VALUE 1
 #define F3D_STATUS_RENDER 2
@@ -397,14 +401,15 @@ typedef struct f3d_smoke_settings { /* SmokeRenderSettings, reference src/smoke/
  * (optional) receives the ray-march kernel's device time.  Errors carry the reference's message texts.
  * Each of the six fields, and rgba, may be a DEVICE pointer: such a field is read where it is and a device image is
  * left on the device (a resident smoke sequence: f3d_smoke_step on device fields -> f3d_smoke_render -> f3d_smoke_composite).
- * The three smoke entry points launch on the calling thread's smoke stream -- the NULL stream until f3d_smoke_set_stream
- * names another -- and keep their scratch between calls (freed by f3d_device_pool_trim).  A call whose results stay on
- * the device and whose time pointer (kernel_seconds / device_seconds) is NULL returns as soon as its launches are enqueued:
- * order other streams behind that stream (an event) before reading its outputs; errors of the kernels themselves then
- * surface in a later call. */
+ * The three handle-less smoke entry points launch on the NULL stream, return when their kernels have finished (as in ABI 4)
+ * and keep their scratch between calls (freed by f3d_device_pool_trim).  A resident sequence uses the handle below
+ * (f3d_smoke_seq_*: own streams, asynchronous calls, scratch freed with the handle).  ABI-5 shim, for one revision: a
+ * thread that has called f3d_smoke_set_stream gets round 5's behaviour for its handle-less calls -- they launch on the
+ * stream it named and, when their results stay on the device and no time is asked for, return with their launches enqueued. */
 int f3d_smoke_render(const f3d_smoke_volume *volume, const f3d_smoke_view *view, const f3d_smoke_settings *settings,
                      uint8_t *rgba, double *kernel_seconds, char *err, size_t errlen);
-/* The stream (a hipStream_t; NULL = the null stream) on which the calling thread's next f3d_smoke_step / f3d_smoke_render /
+/* ABI-5 SHIM (superseded by f3d_smoke_seq_*; kept for one revision).
+ * The stream (a hipStream_t; NULL = the null stream) on which the calling thread's next f3d_smoke_step / f3d_smoke_render /
  * f3d_smoke_composite calls enqueue.  With the solver on one stream and the marcher on another, step f + 1 runs beside
  * the march of frame f: the marcher reads the volume's fields only in its first kernels (it re-packs them), and
  * f3d_smoke_wait_fields_read makes `stream` wait for exactly that point of the calling thread's LAST f3d_smoke_render
@@ -471,6 +476,39 @@ typedef struct f3d_composite_desc {
     uint32_t max_alpha;            /* F3D_COMPOSITE_SMOKE_MAPS: HYBRID_SMOKE_MAX_ALPHA (168) */
 } f3d_composite_desc;
 int f3d_smoke_composite(const f3d_composite_desc *desc, uint8_t *out_rgba, double *kernel_seconds, char *err, size_t errlen);
+
+/* ---- a resident smoke sequence behind a handle (ABI 6) ----
+ * BASELINE.json configs[4] is a 120-frame sequence: per frame a solver step, a march, a composite, all on state that stays
+ * on the device.  The handle holds what such a sequence needs between calls -- which stream the solver runs on and which the
+ * marcher (the caller's hipStream_t values, which must outlive the handle; NULL = the null stream; the same stream twice =
+ * no overlap), the order between them, and the scratch of the three entry points:
+ *   f3d_smoke_seq_step       runs on the solver's stream, behind the last render's READS of the fields (the marcher re-packs
+ *                            the fields in its first kernels; the rest of the march runs beside the next step);
+ *   f3d_smoke_seq_render     runs on the marcher's stream, behind the last step;
+ *   f3d_smoke_seq_composite  runs on the marcher's stream (behind the render whose layer it reads).
+ * Arguments are those of f3d_smoke_step / f3d_smoke_render / f3d_smoke_composite.  A call whose results stay on the device
+ * and whose time pointer is NULL returns with its launches enqueued: order other streams behind the handle's streams
+ * (f3d_smoke_seq_streams + an event) before reading its outputs; kernel errors then surface in a later call.
+ * f3d_smoke_seq_destroy waits for both streams and gives the sequence's scratch back.  Two handles share nothing; one
+ * handle is for one thread at a time.  The reference has no counterpart (its solver and marcher are single-threaded host
+ * loops, src/smoke/sim.rs:270-317, src/smoke/render.rs:7-96). */
+typedef struct f3d_smoke_seq f3d_smoke_seq;
+typedef struct f3d_smoke_seq_stats_t {
+    uint64_t scratch_bytes;               /* device memory the sequence holds between calls */
+    uint32_t shadow_list_chunks;          /* capacity of the marcher's deferred self-shadow list in the last render, in chunks */
+    uint32_t shadow_list_chunks_used;     /* chunks that render asked for (above the capacity: the excess was walked in the one-kernel form) */
+    uint32_t shadow_list_slots_per_chunk; /* 52 bytes a slot */
+    uint32_t reserved;
+} f3d_smoke_seq_stats_t;
+int f3d_smoke_seq_create(void *stream_solver, void *stream_march, f3d_smoke_seq **out, char *err, size_t errlen);
+void f3d_smoke_seq_destroy(f3d_smoke_seq *seq);
+int f3d_smoke_seq_streams(f3d_smoke_seq *seq, void **stream_solver, void **stream_march);
+int f3d_smoke_seq_step(f3d_smoke_seq *seq, f3d_smoke_state *state, const f3d_smoke_step_settings *settings, const f3d_smoke_emitter *emitters,
+                       uint32_t emitter_count, uint32_t steps, double *device_seconds, char *err, size_t errlen);
+int f3d_smoke_seq_render(f3d_smoke_seq *seq, const f3d_smoke_volume *volume, const f3d_smoke_view *view, const f3d_smoke_settings *settings,
+                         uint8_t *rgba, double *kernel_seconds, char *err, size_t errlen);
+int f3d_smoke_seq_composite(f3d_smoke_seq *seq, const f3d_composite_desc *desc, uint8_t *out_rgba, double *kernel_seconds, char *err, size_t errlen);
+int f3d_smoke_seq_stats(f3d_smoke_seq *seq, f3d_smoke_seq_stats_t *out, char *err, size_t errlen);
 
 /* ---- AETHER acceptance reference: stochastic spectral transport (no LUT, black environment) ----
  * Replaces _forge3d.hybrid_render_aether_spectral_reference (reference src/py_functions/path_tracing/

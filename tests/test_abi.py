@@ -125,16 +125,16 @@ def test_integration_md_rust_structs_match_the_header():
         run = subprocess.run([str(exe)], capture_output=True, text=True)
     assert run.returncode == 0, run.stdout
     text = (ROOT / "INTEGRATION.md").read_text()
-    assert "f3d_abi_version" in text and "F3D_ABI_VERSION: u32 = 5" in text
+    assert "f3d_abi_version" in text and "F3D_ABI_VERSION: u32 = 6" in text
 
 
 def test_abi_version_and_struct_size_are_enforced(native):
     """A caller built against another revision of the header (round 1 -> 2 grew the descriptor by a pointer) is refused
     with a value error before the library reads a member."""
     L = native.lib()
-    assert L.f3d_abi_version() == native.ABI_VERSION == 5
+    assert L.f3d_abi_version() == native.ABI_VERSION == 6
     header = (ROOT / "include" / "f3d_terrain_pt.h").read_text()
-    assert "#define F3D_ABI_VERSION 5u" in header
+    assert "#define F3D_ABI_VERSION 6u" in header
     dem = np.zeros((4, 4), np.float32)
     desc, keep = native.make_desc(dem, 8, 8, {}, (1.0, 1.0), 1.0, (0.6, 0.6, 0.6), 315.0, 45.0, 2.5, None, 0.35, None, None, 1, 2, 2,
                                   1e30, 7, (1.0, 1.0, 1.0), 0.0, 0.0, "ellipsoid", 6371008.8, "bennett", 0.13, 1013.25, 15.0)

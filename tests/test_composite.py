@@ -261,6 +261,63 @@ def test_two_resident_sequences_driven_in_turns_stay_themselves():
 
 
 @pytest.mark.gpu
+def test_sequence_handle_owns_its_scratch_and_reports_the_shadow_list():
+    """ABI 6: the sequence's scratch belongs to its handle (f3d_smoke_seq_*): stats() sees it, close() gives it back, and a closed
+    sequence renders the same frames again through a fresh handle.  The marcher's deferred self-shadow list reports its fill."""
+    from forge3d_amd import smoke
+
+    w, h = 160, 96
+    rng = np.random.default_rng(3)
+    terrain = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    terrain[..., 3] = 255
+    cam = dict(camera_pos=(12.0, 10.0, 46.0), target=(12.0, 6.0, 10.0))
+    emitters = [smoke.SmokeEmitter(center=(6.0, 3.0, 10.0), radius=2.5, density_rate=6.0, temperature_rate=3.0, soot_rate=0.3, emission_rate=2.0, velocity=(3.0, 0.4, 0.0))]
+    settings = smoke.SmokeStepSettings(dt=0.1, turbulence_strength=0.5, turbulence_seed=7, wind=(1.5, 0.0, -0.2), pressure_iterations=8)
+
+    def run(seq, overlap):
+        return [f.copy() for f in seq.frames(4, settings, emitters, steps_per_frame=2, overlap=overlap)]
+
+    seq = smoke.SmokeSequence(smoke.SmokeDomain((24, 16, 20)), terrain, **cam)
+    first = run(seq, True)
+    seq._mode = "overlap"
+    st = seq.stats()
+    seq._mode = "serial"
+    assert st["scratch_bytes"] > 0 and st["shadow_list_slots_per_chunk"] == 1024
+    assert 0 < st["shadow_list_chunks_used"] <= st["shadow_list_chunks"]  # smoke was marched and the list held it
+    assert set(seq._handles) == {"overlap"}
+    seq.close()
+    assert seq._handles == {}
+    other = smoke.SmokeSequence(smoke.SmokeDomain((24, 16, 20)), terrain, **cam)
+    again = run(other, False)  # the serial schedule (null stream) through its own handle
+    for a, b in zip(first, again):
+        assert np.array_equal(a, b)
+    other.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("knob", ["F3D_SMOKE_SHADOW_OOM", "F3D_SMOKE_SHADOW_MB"])
+def test_a_shadow_list_that_cannot_be_had_changes_nothing(knob, monkeypatch):
+    """Round-5 advice: the deferred self-shadow list is bounded (F3D_SMOKE_SHADOW_MB) and a list that cannot be allocated sends the
+    frame through the one-kernel form instead of failing the call -- same frames either way."""
+    from forge3d_amd import smoke
+
+    w, h = 160, 96
+    terrain = np.full((h, w, 4), 255, np.uint8)
+    cam = dict(camera_pos=(12.0, 10.0, 46.0), target=(12.0, 6.0, 10.0))
+    emitters = [smoke.SmokeEmitter(center=(6.0, 3.0, 10.0), radius=2.5, density_rate=6.0, temperature_rate=3.0, soot_rate=0.3, emission_rate=2.0, velocity=(3.0, 0.4, 0.0))]
+    settings = smoke.SmokeStepSettings(dt=0.1, turbulence_strength=0.5, turbulence_seed=7, wind=(1.5, 0.0, -0.2), pressure_iterations=8)
+    want = [f.copy() for f in smoke.SmokeSequence(smoke.SmokeDomain((24, 16, 20)), terrain, **cam).frames(4, settings, emitters, steps_per_frame=2)]
+    monkeypatch.setenv(knob, "1" if knob.endswith("OOM") else "0")  # 0 MB: one chunk, nearly every tile spills
+    seq = smoke.SmokeSequence(smoke.SmokeDomain((24, 16, 20)), terrain, **cam)
+    got = [f.copy() for f in seq.frames(4, settings, emitters, steps_per_frame=2)]
+    for a, b in zip(want, got):
+        assert np.array_equal(a, b)
+    seq._mode = "overlap"
+    st = seq.stats()
+    assert st["shadow_list_chunks"] == (0 if knob.endswith("OOM") else 1)
+
+
+@pytest.mark.gpu
 def test_resident_smoke_sequence_equals_the_host_array_path():
     """Round 4: the sequence with its state, the smoke layer and the terrain frame resident on the GPU (SmokeSequence: only
     the finished RGBA8 frames leave, through two pinned buffers) gives the frames AND the final solver state of the
