@@ -343,6 +343,12 @@ def cpu_baseline(dem, cam, kw, args, world=1):
     }, counts
 
 
+def pmc_kernel_ms(issue: dict):
+    """Average duration of the profiled launches behind an `issue` block (tools/gpu_profile.sh stores it), or None."""
+    v = issue.get("kernel_ms_profiled")
+    return float(v) if v else None
+
+
 def device_identity(torch, index: int) -> dict:
     """What tells two devices apart in the line: index, name and whichever of uuid / PCI ids this torch build exposes."""
     props = torch.cuda.get_device_properties(index)
@@ -608,6 +614,7 @@ def main():
             # under profiles/; bench.py cannot run the profiler itself): only quoted when the
             # run matches the profiled configuration.
             traffic, traffic_note = None, "no PMC profile of these kernel sources under profiles/"
+            issue = None
             try:
                 # the newest profile of THESE kernel sources wins (rNN_pmc_traffic.json, written by tools/gpu_profile.sh)
                 for path in sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"), reverse=True):
@@ -619,6 +626,7 @@ def main():
                             and pmc.get("sample_lanes", 1) == lanes):
                         traffic = pmc["hbm_bytes_per_launch"]
                         traffic_note = f"rocprofv3 PMC passes of this command on these kernel sources (profiles/{path.name})"
+                        issue = dict(pmc.get("issue") or {}, profile=f"profiles/{path.name}") if pmc.get("issue") else None
                     break
             except Exception:
                 pass
@@ -629,6 +637,26 @@ def main():
                 "kernel_ms": frame_kernel_ms, "launches": launches, "bytes_per_sample": b_alg, "sample_lanes": lanes,
                 "per_sample_counts": counts,
             }
+            if issue:
+                # The roof this kernel is actually under (HBM traffic is 0.38x the algorithmic bytes and a fraction
+                # of the peak; the march is instruction-bound): vector instructions issued per second against what 1 024 SIMDs
+                # can issue -- one wave instruction every 2 cycles (MI355X_MICROARCH.md; this kernel's own calibration run,
+                # profiles/r03_valu_calib.log, measured 2.4) at the clock the profiled launches ran at.  achieved is the profile's
+                # instruction count over THIS run's kernel time.
+                instr = float(issue["valu_wave_instructions_per_launch"])
+                cycles = float(issue["gpu_cycles_per_launch"])
+                clock_hz = cycles / (float(pmc_kernel_ms(issue)) * 1e-3) if pmc_kernel_ms(issue) else None
+                peak = 1024.0 * (clock_hz or 2.4e9) / 2.0
+                achieved_issue = instr / (frame_kernel_ms * 1e-3)
+                result["roofline_issue"] = {
+                    "bound": "valu_issue", "achieved": achieved_issue / 1e12, "peak": peak / 1e12, "unit": "T wave-instructions/s",
+                    "frac": achieved_issue / peak, "frac_counters_only": instr * 2.0 / (1024.0 * cycles),
+                    "lane_utilisation": issue["lane_utilisation"], "useful_frac": achieved_issue / peak * issue["lane_utilisation"],
+                    "wait_fraction_of_wave_cycles": issue["wait_fraction_of_wave_cycles"], "salu_per_valu": issue["salu_per_valu"],
+                    "cycles_per_issue": 2.0, "clock_ghz": (clock_hz or 2.4e9) / 1e9, "simds": 1024,
+                    "valu_wave_instructions_per_launch": instr, "kernel": "k_frame", "profile": issue["profile"],
+                    "note": "useful_frac = frac x lane_utilisation: the share of the chip's lane-cycles that do this kernel's arithmetic",
+                }
         if image is not None:
             result["config"]["image_mean_rgb"] = [float(x) for x in image["rgba"][..., :3].mean((0, 1))]
             # what the samples were: the headline camera looks past the mountain (mostly sky)

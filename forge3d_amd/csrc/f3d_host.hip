@@ -1006,7 +1006,14 @@ int f3d_session_kernel_timing(f3d_session *s, int32_t enable, double *avg_ms, ui
 }
 
 uint32_t f3d_session_sample_lanes(f3d_session *s) { return s ? s->params.sample_lanes : 0u; }
-const void *f3d_session_primary_start(f3d_session *s) { return (s && s->params.cam.cone_delta >= 0.0f) ? s->params.primary_start : nullptr; }
+// (waits for the session's stream: the certificate pass wrote the buffer there, and whoever takes the pointer -- the PBR tracer
+// launches on the null stream -- is not ordered behind a non-blocking stream; a start read too early would skip terrain)
+const void *f3d_session_primary_start(f3d_session *s) {
+    if (!s || !(s->params.cam.cone_delta >= 0.0f) || !s->params.primary_start) return nullptr;
+    DeviceGuard guard(s->device);
+    if (hipStreamSynchronize(s->stream) != hipSuccess) return nullptr;
+    return s->params.primary_start;
+}
 
 // What the last fused frame cost, row by row: every wave of the frame kernel leaves its duration in tile_cost (the input of
 // the longest-first dispatch); a tile's time is spread over its rows.  The strip driver cuts the image where these sums are

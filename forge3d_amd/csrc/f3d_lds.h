@@ -30,11 +30,13 @@ constexpr int kBoardRow = kParkRow + kParkHead + 1;  // verdict board of the ray
 constexpr uint32_t kBoardBit = 0x80000000u;
 constexpr int kLdsRows = kParkRow + kParkWords > kMaxLevels ? kParkRow + kParkWords : kMaxLevels;
 constexpr int kLdsWords = kLdsRows * kWave + 4 * kMaxLevels;
-template <int BOARD_ROW>
+template <int BOARD_ROW, bool MESH_STACK = true>
 struct LdsPendingAt {
     // may the scene hold a mesh?  (closest_hit / occluded, f3d_shade.h: the terrain-only frame kernels are compiled without
     // the mesh walk, so nothing the mesh path needs can move their register allocation -- and the other way round)
-    static constexpr bool kMesh = true;
+    // MESH_STACK = false: the user never walks a mesh 4 wide through stack_put / stack_get (the PBR tracer walks its instanced
+    // meshes through the threaded BVH), so the leaf FIFO's rows need not hold kBvh4MaxLevels words.
+    static constexpr bool kMesh = MESH_STACK;
     uint32_t *col;          // lds + lane
     const uint32_t *table;  // lds + kLdsRows * kWave: {band_offset, band_shift, node_offset, tiles_x} per level
     uint32_t leaf_quorum, share_below;
@@ -42,8 +44,13 @@ struct LdsPendingAt {
     __device__ __forceinline__ uint32_t get(uint32_t level) const { return col[level * kWave]; }
     // per-level words of the 4-wide mesh walk (f3d_shade.h mesh_bvh4): the rows of the leaf FIFO, which is empty while a
     // mesh is walked (closest_hit walks the mesh before the terrain; occluded() after the terrain march has drained)
-    static_assert(kFifoWords * kLeafFifoRows >= kBvh4MaxLevels || !kMesh, "the 4-wide mesh walk keeps a word per level in the leaf FIFO's rows");
-    __device__ __forceinline__ void stack_put(uint32_t level, uint32_t word) { col[level * kWave] = word; }
+    // (asserted where the walk would use the rows: a translation unit with one-word FIFO entries and no 4-wide walk -- the PBR
+    // tracer's -- may still name these types)
+    template <bool M = MESH_STACK>
+    __device__ __forceinline__ void stack_put(uint32_t level, uint32_t word) {
+        static_assert(kFifoWords * kLeafFifoRows >= kBvh4MaxLevels || !M, "the 4-wide mesh walk keeps a word per level in the leaf FIFO's rows");
+        col[level * kWave] = word;
+    }
     __device__ __forceinline__ uint32_t stack_get(uint32_t level) const { return col[level * kWave]; }
     __device__ __forceinline__ void note(int) const {}  // step-statistics hook (host emulator only)
     __device__ __forceinline__ void feature(float) const {}
@@ -140,7 +147,7 @@ constexpr int kPathParkRows = F3D_WF_PARK;
 constexpr int kPathParkRow0 = kParkRow + 1;
 constexpr int kCompactRows = kParkRow + 1 + kPathParkRows;
 constexpr int kCompactLdsWords = kCompactRows * kWave + 4 * kMaxLevels;
-using LdsPendingCompact = LdsPendingAt<kParkRow>;
+using LdsPendingCompact = LdsPendingAt<kParkRow, false>;
 // rows: lane-column rows in front of the level table (the occlusion-stream kernels need the leaf FIFO only)
 struct LdsPendingTerrainOnly : LdsPending {
     static constexpr bool kMesh = false;

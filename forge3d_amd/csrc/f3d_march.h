@@ -228,6 +228,66 @@ F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint
 #endif
         const bool pass = !(lo > hi) & !march_band_rejects<CURVED>(r, lo, hi, band.mn, band.mx);  // :297-304 (bitwise: no branch)
         if (pass) ctx.note(-1);  // statistics hook (host emulator only): the last step whose band test passed
+#if defined(F3D_BRANCHLESS_STEP)
+        // A/B (round 6, DESIGN.md 6 "plateau"): the step with NO data-dependent branch but the rare corner ties -- DOWN and ACROSS
+        // are both formed and selected, the leaf goes into the FIFO's next free slot whether it is one or not (the slot counter
+        // moves only for a leaf; the loops call a step only with two slots free).  Same values by the same expressions as the
+        // branching form below.
+        {
+            const bool down = pass & (level > 0u), leaf = pass & (level == 0u);
+            const uint32_t cl = level > 0u ? level - 1u : 0u;
+            const uint32_t xm = (2u * nx + 1u) << cl, zm = (2u * nz + 1u) << cl;
+            const float txm = (plane_at(T.origin_x, xm, T.spacing_x) - r.o.x) * r.inv_x;
+            const float tzm = (plane_at(T.origin_z, zm, T.spacing_z) - r.o.z) * r.inv_z;
+            uint32_t ix = (x_forward != (txm <= m.t_cur)) ? 0u : 1u;
+            uint32_t iz = (z_forward != (tzm <= m.t_cur)) ? 0u : 1u;
+            ix = xm < T.cell_w ? ix : 0u;
+            iz = zm < T.cell_h ? iz : 0u;
+#if !defined(F3D_NO_CORNER_TIES)
+            if (any_hit && down && (txm == m.t_cur || tzm == m.t_cur)) {  // (rare) on a child boundary: see the branching form
+                uint32_t lv = level;
+                F3D_OPAQUE(lv);
+                const uint32_t ex1 = (nx + 1u) << lv, ez1 = (nz + 1u) << lv;
+                const uint32_t xin = x_forward ? nx << lv : (ex1 < T.cell_w ? ex1 : T.cell_w);
+                const uint32_t zin = z_forward ? nz << lv : (ez1 < T.cell_h ? ez1 : T.cell_h);
+                const float txin = (plane_at(T.origin_x, xin, T.spacing_x) - r.o.x) * r.inv_x;
+                const float tzin = (plane_at(T.origin_z, zin, T.spacing_z) - r.o.z) * r.inv_z;
+                if (txm == m.t_cur && tzin == m.t_cur && xm < T.cell_w) {
+                    ctx.fifo_put(queued, tie_entry(xm, zin, x_forward, z_forward), m.t_cur, m.t_cur);
+                    queued++;
+                } else if (tzm == m.t_cur && txin == m.t_cur && zm < T.cell_h) {
+                    ctx.fifo_put(queued, tie_entry(xin, zm, x_forward, z_forward), m.t_cur, m.t_cur);
+                    queued++;
+                }
+            }
+#endif
+            if (leaf) ctx.note(1);
+            ctx.fifo_put(queued, nx | (nz << 16), lo, hi);  // (a free slot: harmless when this is no leaf)
+            queued += leaf ? 1u : 0u;
+            const bool cross_x = x_out <= z_out, cross_z = z_out <= x_out;
+#if !defined(F3D_NO_CORNER_TIES)
+            if (any_hit && !down && cross_x && cross_z && exit < r.tmax) {  // out through the node's own corner (rare)
+                uint32_t lv = level;
+                F3D_OPAQUE(lv);
+                const uint32_t ex1 = (nx + 1u) << lv, ez1 = (nz + 1u) << lv;
+                const uint32_t X = x_forward ? (ex1 < T.cell_w ? ex1 : T.cell_w) : nx << lv;
+                const uint32_t Z = z_forward ? (ez1 < T.cell_h ? ez1 : T.cell_h) : nz << lv;
+                ctx.fifo_put(queued, tie_entry(X, Z, x_forward, z_forward), exit, exit);
+                queued++;
+            }
+#endif
+            const uint32_t qx = nx + ((cross_x && x_forward) ? 1u : 0u) - ((cross_x && !x_forward) ? 1u : 0u);
+            const uint32_t qz = nz + ((cross_z && z_forward) ? 1u : 0u) - ((cross_z && !z_forward) ? 1u : 0u);
+            const bool left = !(exit < r.tmax) | (SLICED & !(exit < t_stop)) | ((qx << level) >= T.cell_w) |
+                              ((qz << level) >= T.cell_h) | (march_height<CURVED>(r, exit) > r.y_exit);
+            const bool up = level < top && (((qx ^ nx) | (qz ^ nz)) > 1u);
+            m.nx = down ? 2u * nx + ix : (up ? qx >> 1 : qx);
+            m.nz = down ? 2u * nz + iz : (up ? qz >> 1 : qz);
+            m.level = down ? cl : (up ? level + 1u : level);
+            m.t_cur = down ? m.t_cur : f_max(m.t_cur, exit);
+            m.marching = down | !left;
+        }
+#else
         if (pass && level > 0u) {
             // DOWN into the child the ray is in at t_cur: it has passed the child boundary plane
             // iff that plane's parameter is <= t_cur
@@ -306,6 +366,7 @@ F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint
             m.t_cur = f_max(m.t_cur, exit);
             m.marching = !left;  // out of the footprint, or past tmax
         }
+#endif
     }
     if (VERIFY) m.unverified_start = false;
     if (m.marching) march_fetch(T, m, ctx);

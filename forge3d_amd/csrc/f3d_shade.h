@@ -743,8 +743,13 @@ F3D_HD IblRay sample_shade_sun(const FrameParams &P, bool prev_valid, ReuseW reu
 #if defined(F3D_MODEL_HINT_SUN)  // scheduling-model builds of the emulator only
         pend.hint(F3D_MODEL_HINT_SUN);
 #endif
+        float sun_stop = ph.sun_tmax;
+#if defined(F3D_SUN_HORIZON)  // A/B (round 6): the DEM-block far horizons (f3d_cone.h ibl_stop, built with F3D_IBL_HORIZON=1) for the
+        // sun rays too -- a curved sun ray lies above the straight ray the horizon bounds, so the stop stays conservative
+        if (ph.hit.kind == 1u) sun_stop = f_min(sun_stop, ibl_stop(P.terrain, su.q.o, su.sun_dir));
+#endif
 #if !defined(F3D_TIMING_NO_SHADOW)  // timing experiment only (wrong image): tools/gpu_build_ab.sh
-        if (P.light.shadows_enabled != 0u && occluded(P, su.q.o, 1e-3f, su.sun_dir, 1e30f, true, pend, ph.sun_tmax)) vis = 0.0f;
+        if (P.light.shadows_enabled != 0u && occluded(P, su.q.o, 1e-3f, su.sun_dir, 1e30f, true, pend, sun_stop)) vis = 0.0f;
 #endif
         o.a = (su.y * vis) * reuse_w();
     }

@@ -399,7 +399,11 @@ __device__ __forceinline__ uchar4 smoke_pixel(const SmokeParams &P, V3 rgb, floa
 // k_smoke_shade walks its rays in the one-kernel form.
 enum : uint32_t { kWhole = 0u, kCollect = 1u };
 constexpr uint32_t kChunkRows = 16u, kChunkSlots = kChunkRows * 64u, kNoChunk = 0xFFFFFFFFu, kUnset = 0xFFFFFFFEu;
-constexpr size_t kListStepsPerPixel = 16u, kListCapMb = 2048u;  // sizing of the deferred list (f3d_smoke_render)
+// Sizing of the deferred list (f3d_smoke_render): 4 in-volume steps per pixel, at most 1 GiB.  Round 5 took 16 a pixel and a cap
+// of 5.6 GB -- 1.7 GB at 1080p, held per stream for the life of the process (round-5 advice).  Measured on BASELINE configs[4]
+// (1080p, 96 x 64 x 128 plume, frame 160): 3 373 chunks used of the 8 100 this gives (f3d_smoke_seq_stats; 432 MB).  A tile whose
+// steps do not fit is walked in the one-kernel form by k_smoke_shade: slower, same pixels.
+constexpr size_t kListStepsPerPixel = 4u, kListCapMb = 1024u;
 struct Deferred {
     float4 *where;       // per slot: the step's position, and its extinction sigma_t
     float4 *fields;      // per slot: density, soot, age, temperature as interpolated there

@@ -320,7 +320,8 @@ uint32_t f3d_session_sample_lanes(f3d_session *session);
 int f3d_session_row_costs(f3d_session *session, float *out, uint32_t rows, char *err, size_t errlen);
 /* (ABI 5) The session's primary-ray certificates (f3d_cone.h): a DEVICE pointer to rows x width records {f32 bits of t_clear,
  * u32 level}, written by the G-buffer pass the session's creation enqueued on its stream; NULL when the camera's pixels are too
- * wide for certificates.  Valid while the session lives.  The PBR path tracer takes it as f3d_wf_scene.primary_start. */
+ * wide for certificates.  Valid while the session lives; the call waits for the session's stream, so the records are written
+ * when it returns.  The PBR path tracer takes it as f3d_wf_scene.primary_start (same camera, image size and heightfield). */
 const void *f3d_session_primary_start(f3d_session *session);
 /* Device memory the library has freed is kept for its next allocation of the same size (F3D_DEVICE_POOL_MB, default
  * 1024, 0 = off): a camera path or a smoke sequence allocates the same buffers frame after frame.  This hands everything

@@ -35,6 +35,26 @@ try:
                note="MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE count KB; gfx950 FETCH_SIZE under-reports wide reads, doubled (upper bound)")
 except Exception as exc:
     out["error"] = str(exc)
+try:  # the roof the kernel is actually under: vector-instruction issue (bench.py roofline_issue)
+    K = "%k_frame<0, 6, 4u, false>%"
+    p1, p2 = glob.glob("$OUT/pmc1/*.db")[0], glob.glob("$OUT/pmc2/*.db")[0]
+    c = {name: avg(db, name, K)[0] for db, names in ((p1, ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVES")),
+                                                      (p2, ("SQ_THREAD_CYCLES_VALU", "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE"))) for name in names}
+    cycles = c["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
+    # average duration of the same kernel in the kernel-trace pass (the clock the counters' cycles were counted at)
+    kms = None
+    try:
+        kms = sqlite3.connect(glob.glob("$OUT/trace/*.db")[0]).cursor().execute("select avg(end - start) from kernels where name like ?", (K,)).fetchone()[0] / 1e6
+    except Exception:
+        kms = None
+    out["issue"] = {"kernel_ms_profiled": kms, "counters_per_launch": c, "gpu_cycles_per_launch": cycles, "simds": 1024,
+                    "valu_wave_instructions_per_launch": c["SQ_INSTS_VALU"],
+                    "lane_utilisation": c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]),
+                    "wait_fraction_of_wave_cycles": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
+                    "salu_per_valu": c["SQ_INSTS_SALU"] / c["SQ_INSTS_VALU"],
+                    "source": "rocprofv3 --pmc passes 1 and 2 of tools/gpu_profile.sh, averages over the launches of k_frame<0, 6, 4u, false>"}
+except Exception as exc:
+    out["issue_error"] = str(exc)
 json.dump(out, open("$OUT/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out))
 PY
