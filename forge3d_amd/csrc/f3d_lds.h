@@ -141,7 +141,7 @@ using LdsPending = LdsPendingAt<kBoardRow>;
 // rows the block is 6 400 bytes -- five of the 1 280-byte pieces LDS is handed out in: 25 one-wave workgroups a CU, room
 // for six waves a SIMD; 13 rows (7 680 bytes, 21 workgroups) go with five waves.
 #ifndef F3D_WF_PARK
-#define F3D_WF_PARK 8
+#define F3D_WF_PARK 8  // (f3d_wavefront.hip asks for 18 together with one-word FIFO entries; other translation units never use the compact block)
 #endif
 constexpr int kPathParkRows = F3D_WF_PARK;
 constexpr int kPathParkRow0 = kParkRow + 1;

@@ -15,6 +15,15 @@
 #include <exception>
 #include <vector>
 
+// This translation unit's march keeps one-word leaf-FIFO entries (f3d_march.h: the drain forms a leaf's interval again, ~20
+// instructions a drained leaf): 5 rows of the wave's LDS block instead of 15, which is what lets the path's whole loop-carried
+// state live in LDS rows instead of scratch (f3d_wf_path.h LaneState) at the same 6 400 bytes a wave.
+#ifndef F3D_FIFO_WORDS
+#define F3D_FIFO_WORDS 1
+#endif
+#ifndef F3D_WF_PARK
+#define F3D_WF_PARK 18
+#endif
 #include "../../include/f3d_wavefront.h"
 #include "f3d_devmem.h"
 #include "f3d_lds.h"
@@ -60,16 +69,19 @@ __global__ __launch_bounds__(64, TERRAIN ? F3D_WF_WAVES_TERRAIN : F3D_WF_WAVES) 
     // (all frame groups of a tile together and image rows from the bottom up -- heavy tiles first -- measured 21.3-21.4 against
     // 21.4-21.6 ms on C3 GI: the tail is not what the round waits for; not taken)
     const uint32_t tile = blockIdx.x % tiles, group = blockIdx.x / tiles;
-    const uint32_t x = (tile % tiles_x) * 8u + (threadIdx.x & 7u), y = (tile / tiles_x) * 8u + (threadIdx.x >> 3);
+    const uint32_t x0 = (tile % tiles_x) * 8u, y0 = (tile / tiles_x) * 8u;
+    const uint32_t x = x0 + (threadIdx.x & 7u), y = y0 + (threadIdx.x >> 3);
     const uint32_t begin = group * P.frames_per_lane;
     uint32_t vertices = 0u;
     if (x < P.S.width && y < P.S.height && begin < P.count) {
-        const uint32_t pixel = y * P.S.width + x, pixels = P.S.width * P.S.height;
         const uint32_t n = P.count - begin < P.frames_per_lane ? P.count - begin : P.frames_per_lane;
-        float4 *out = P.totals + (size_t)begin * pixels + pixel;
         const uint32_t first = P.first + begin;
-        vertices = wf::trace_frames(P.S, pixel, first, n, wf::HipWave<LdsPendingCompact, TERRAIN, LITE>{&pend}, [&](uint32_t frame, V3 total) {
-            out[(size_t)(frame - first) * pixels] = float4{total.x, total.y, total.z, 0.0f};
+        const wf::HipWave<LdsPendingCompact, TERRAIN, LITE> wave{&pend, x0, y0, P.S.width};
+        // (the output address is formed from the lane's pixel where a frame ends, like everything else that depends on it:
+        // nothing per-lane but the march's own state is alive across a march)
+        vertices = wf::trace_frames(P.S, first, n, wave, [&](uint32_t frame, V3 total) {
+            const size_t pixels = (size_t)P.S.width * P.S.height;
+            P.totals[(size_t)(begin + (frame - first)) * pixels + wave.pixel()] = float4{total.x, total.y, total.z, 0.0f};
         });
     }
     unsigned long long total = vertices;
@@ -246,7 +258,7 @@ extern "C" int f3d_wavefront_render(const f3d_wf_scene *scene_in, uint32_t width
         const uint64_t want_waves = S.has_terrain ? 100000ull : 32768ull;
         while (fpl > 8u && (uint64_t)tiles * ((round_frames + fpl - 1u) / fpl) < want_waves) fpl >>= 1;
         if (const char *e = getenv("F3D_WF_FRAMES_PER_LANE")) fpl = (uint32_t)std::max(1, atoi(e));
-        fpl = std::min(fpl, round_frames);
+        fpl = std::min(std::min(fpl, round_frames), wf::kMaxFramesPerCall);  // (a lane's frame counter has 11 bits: f3d_wf_path.h LaneState)
         P.frames_per_lane = fpl;
         P.totals = (float4 *)alloc((size_t)round_frames * pixels * sizeof(float4), "frame totals");
         ok(hipEventCreate(&e0), "event");

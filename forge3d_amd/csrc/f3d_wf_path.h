@@ -564,28 +564,26 @@ F3D_HD uint32_t pick(uint32_t count, float sum_imp, uint32_t &rng, Imp imp) {
     return idx < count - 1u ? idx : count - 1u;
 }
 
-// ---- parked path state (round 5) ---------------------------------------------------------------------------------------------
-// A march of the heightfield primitive needs ~70 of the 80 registers six waves a SIMD leave a lane; what the flat loop carries
-// ACROSS a march -- the frame's running total, the path throughput, the continuation the vertex has already sampled, the
-// next-event contributions whose shadow rays are still to be traced -- lived in scratch: 284 bytes a lane, 15 GB written per
-// 1080p x 32-path launch (profiles/r04_C3_gi_rocprofv3_summary.txt).  Those values are needed before and after a march,
-// never during it, so a lane writes them to rows of its own LDS column in front of the march and reads them back behind it
-// (Wave::kPark rows: 8 with six waves a SIMD, 13 with five; 0 = a kernel without the LDS block: everything stays in registers).
-// Same values, same operations in the same order: results are unchanged (tests/test_wavefront.py, test_offline_gi.py).
-// Row map.  The frame's total and the throughput LIVE in rows 0..5 (kOn): every use reads them, every update writes them,
-// so no lane of a wave holds them in a register while any other lane marches (a value that is only parked on the marching
-// lanes' path stays allocated for the waiting ones).  With 13 rows (kHit) a hit waits in rows 6..12 between closest() and
-// the vertex's shading -- position, normal, material; across the vertex's shadow rays the same rows hold the two next-event
-// contributions and the path depth.  With 8 rows the depth and the RNG word use rows 6 and 7 there.
-template <class Wave>
-struct ParkRows {
-    static constexpr uint32_t kAcc = 0u, kThr = 3u;
-    static constexpr bool kOn = Wave::kPark >= 8u;
-    static constexpr bool kHit = Wave::kPark >= 13u;
-    static constexpr uint32_t kHitP = 6u, kHitN = 9u, kHitMat = 12u;             // kHit, between closest() and the vertex
-    static constexpr uint32_t kEnvC = 6u, kDirC = 9u, kDepth = kHit ? 12u : 6u;  // across the vertex's shadow rays
-    static constexpr uint32_t kRng = 7u;                                         // (8-row form only)
-};
+// ---- a lane's loop-carried path state (round 6: resident in the lane's LDS column) -------------------------------------------
+// A march of the heightfield primitive needs ~70 of the 80 registers six waves a SIMD leave a lane.  Whatever the flat loop
+// carries ACROSS a march therefore lived in scratch: 284 bytes a lane in round 4 (15 GB written per 1080p x 32-path launch),
+// 168 in round 5, which parked the frame's total and the throughput in eight rows of the lane's LDS column.  Round 6 gives the
+// PBR tracer's translation unit one-word leaf-FIFO entries (f3d_march.h F3D_FIFO_WORDS: the drain forms the interval again) --
+// 5 FIFO rows instead of 15 in the same 6 400-byte block -- and keeps ALL the loop-carried state in the 18 rows that frees:
+// every use reads its row, every change writes it, so no lane of a wave holds path state in a register while any other lane
+// marches (a value that is only parked on the marching lanes' path stays allocated for the lanes that wait).
+//   rows 0-2   the frame's running total              rows 3-5   the path throughput
+//   row  6     one word: depth (bits 0-4), "the next vertex starts a new frame" (5), "a hit waits for its shading" (6),
+//              frame - first (7-17: at most 1 023 frames a call), closest-hit queries made (18-31)
+//   row  7     the path's RNG word
+//   rows 8-10  the ray's direction: the camera ray or the continuation the last vertex sampled
+//   rows 11-13 A: the origin of a continuing ray until closest() has taken it | the waiting hit's position | across a vertex's
+//              shadow rays the environment sample's contribution
+//   rows 14-16 B: the waiting hit's normal | across the shadow rays the directional light's contribution
+//   row  17    the waiting hit's material
+// Same values, same operations in the same order as the register form (Wave::kPark == 0: the kernel without the heightfield
+// primitive, which has no LDS block and 128 registers): results are unchanged (tests/test_wavefront.py, test_offline_gi.py; the
+// host emulator runs the row form with an array for the rows).
 template <class Wave>
 F3D_HD void park3(const Wave &w, uint32_t row, V3 v) {
     w.park(row, v.x);
@@ -596,13 +594,61 @@ template <class Wave>
 F3D_HD V3 unpark3(const Wave &w, uint32_t row) {
     return V3{w.unpark(row), w.unpark(row + 1u), w.unpark(row + 2u)};
 }
+constexpr uint32_t kLaneRows = 18u;
+constexpr uint32_t kMaxFramesPerCall = 1023u;  // (frame - first) has 11 bits and the query count 14: 16 queries a frame at most
+template <class Wave>
+struct LaneState {
+    static constexpr bool kRows = Wave::kPark >= kLaneRows;
+    static constexpr uint32_t kAcc = 0u, kThr = 3u, kWord = 6u, kRng = 7u, kDir = 8u, kA = 11u, kB = 14u, kMat = 17u;
+    static constexpr uint32_t kDepthMask = 31u, kFresh = 32u, kPending = 64u, kFrameShift = 7u, kFrameMask = 2047u, kQueryShift = 18u;
+    const Wave &w;
+    V3 acc_{0.0f, 0.0f, 0.0f}, thr_{0.0f, 0.0f, 0.0f}, dir_{0.0f, 0.0f, 0.0f}, a_{0.0f, 0.0f, 0.0f}, b_{0.0f, 0.0f, 0.0f};
+    uint32_t word_ = 0u, rng_ = 0u, mat_ = 0u;
+    F3D_HD explicit LaneState(const Wave &wave) : w(wave) {}
+    F3D_HD V3 get3(uint32_t row, const V3 &reg) const { return kRows ? unpark3(w, row) : reg; }
+    F3D_HD void set3(uint32_t row, V3 &reg, V3 v) {
+        if (kRows) park3(w, row, v);
+        else reg = v;
+    }
+    F3D_HD V3 acc() const { return get3(kAcc, acc_); }
+    F3D_HD void set_acc(V3 v) { set3(kAcc, acc_, v); }
+    F3D_HD void add(V3 c) { set_acc(acc() + c); }
+    F3D_HD V3 thr() const { return get3(kThr, thr_); }
+    F3D_HD void set_thr(V3 v) { set3(kThr, thr_, v); }
+    F3D_HD V3 dir() const { return get3(kDir, dir_); }
+    F3D_HD void set_dir(V3 v) { set3(kDir, dir_, v); }
+    F3D_HD V3 a() const { return get3(kA, a_); }
+    F3D_HD void set_a(V3 v) { set3(kA, a_, v); }
+    F3D_HD V3 b() const { return get3(kB, b_); }
+    F3D_HD void set_b(V3 v) { set3(kB, b_, v); }
+    F3D_HD uint32_t word() const { return kRows ? f_bits(w.unpark(kWord)) : word_; }
+    F3D_HD void set_word(uint32_t v) {
+        if (kRows) w.park(kWord, f_from_bits(v));
+        else word_ = v;
+    }
+    F3D_HD uint32_t rng() const { return kRows ? f_bits(w.unpark(kRng)) : rng_; }
+    F3D_HD void set_rng(uint32_t v) {
+        if (kRows) w.park(kRng, f_from_bits(v));
+        else rng_ = v;
+    }
+    F3D_HD uint32_t mat() const { return kRows ? f_bits(w.unpark(kMat)) : mat_; }
+    F3D_HD void set_mat(uint32_t v) {
+        if (kRows) w.park(kMat, f_from_bits(v));
+        else mat_ = v;
+    }
+};
 
 // One surface vertex: emission, NEE (environment / directional / area) with its shadow rays, continuation sample,
 // roulette (pt_shade.wgsl main :460-862 + pt_shadow.wgsl main).  Returns true when the path continues in P.
+// H: the hit (position, normal, material -- and, scenes with hair or fog, its distance, hair flag and strand axis);
+// d_in: the direction the path arrived with.  Everything else the vertex reads and leaves is the lane's state L: it adds to
+// the frame's total, and when the path continues it leaves the new throughput, direction, RNG word and depth there and the
+// new ray's origin in rows A.  (`lane`, not L: the light records of the next-event blocks are called L.)
 template <class Wave>
-F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, uint32_t seed_lo, const SurfaceHitWf &H, PathState &P,
-                           V3 &acc, Wave &wave) {
-    (void)seed_lo;
+F3D_HD bool surface_vertex(const SceneDev &S, uint32_t frame, const SurfaceHitWf &H, V3 d_in, LaneState<Wave> &lane, Wave &wave) {
+    using Lane = LaneState<Wave>;
+    const uint32_t pixel = wave.pixel();
+    const uint32_t depth_in = lane.word() & Lane::kDepthMask;
     const MaterialDev md = S.mats[H.mat];
     MatCtx M;
     M.albedo = md.albedo;
@@ -614,23 +660,19 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
     M.imp = md.importance;
     const float sm = f_saturate(md.metallic);
     M.F0 = V3{mix(0.04f, md.albedo.x, sm), mix(0.04f, md.albedo.y, sm), mix(0.04f, md.albedo.z, sm)};
-    using Rows = ParkRows<Wave>;
-    auto acc_add = [&](V3 c) F3D_LAMBDA {
-        if (Rows::kOn) park3(wave, Rows::kAcc, unpark3(wave, Rows::kAcc) + c);
-        else acc = acc + c;
-    };
-    const V3 thr_in = Rows::kOn ? unpark3(wave, Rows::kThr) : P.thr;  // the throughput the path arrives with
+    auto acc_add = [&](V3 c) F3D_LAMBDA { lane.add(c); };
+    const V3 thr_in = lane.thr();  // the throughput the path arrives with
     if (md.emissive.x > 0.0f || md.emissive.y > 0.0f || md.emissive.z > 0.0f) acc_add(thr_in * md.emissive);
 
-    uint32_t rng = P.rng_hi ^ (pixel * 26699u) ^ (frame * 30977u);
-    const V3 n = normalize(H.n), wo = normalize(normalize(neg(P.d)));
+    uint32_t rng = lane.rng() ^ (pixel * 26699u) ^ (frame * 30977u);
+    const V3 n = normalize(H.n), wo = normalize(normalize(neg(d_in)));
     const float n_dot_v = f_max(dot(n, wo), 0.0f);
     const Frame3 basis = tangent_frame(n);
     const V3 so = H.p + n * 1e-3f;
     // homogeneous fog, :328-338 / :500-520: next-event contributions of this vertex are attenuated over the segment that
     // reached it; a PRIMARY hit also adds the environment seen through the fog it looks through
     const float mtrans = (!Wave::kLite && S.medium_on != 0u) ? exp_det(-f_max(H.t, 0.0f) * S.medium_mu) : 1.0f;
-    if (!Wave::kLite && S.medium_on != 0u && P.depth == 0u) {
+    if (!Wave::kLite && S.medium_on != 0u && depth_in == 0u) {
         const V3 back = neg(wo);
         acc_add(mix3(S.env_ground, S.env_sky, 0.5f * (back.y + 1.0f)) * (1.0f - mtrans));
     }
@@ -641,8 +683,10 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
     // unchanged -- and the march of a shadow ray then runs with the vertex's BSDF state (material, frame, half of the hit
     // record) dead instead of live across it, through ONE copy of the march code instead of three.
     const V3 zero3{0.0f, 0.0f, 0.0f};
-    V3 env_wi = zero3, env_c = zero3, dir_wi = zero3, dir_c = zero3, area_wi = zero3, area_c = zero3;
-    uint32_t nee_on = 0u;
+    // The two contributions every scene has go to rows A and B as soon as they are formed (the hit's position and normal, which
+    // those rows held, were read when the vertex began) and wait there for their shadow rays.
+    V3 env_wi = zero3, area_wi = zero3, area_c = zero3;
+    uint32_t nee_on = 0u, dir_light = 0u;  // (the directional light's direction is read from the light table again when its ray is traced)
     float area_tmax = 1e30f;
     {  // environment, mixture of a power-cosine lobe about +Y and the cosine hemisphere, balance heuristic
         const float u1 = rng_next(rng), u2 = rng_next(rng), u3 = rng_next(rng);
@@ -664,7 +708,7 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
             const Bsdf br = bsdf_eval(M, wo, wi, n);
             const float w_mis = pdf_light / f_max(pdf_light + br.pdf, 1e-8f);
             const float k = (((cos_surf / f_max(pdf_light, 1e-8f)) * w_mis) * M.imp) * mtrans;
-            env_c = ((thr_in * br.f) * L_env) * k;
+            lane.set_a(((thr_in * br.f) * L_env) * k);
             env_wi = wi;
             nee_on |= 1u;
         }
@@ -677,8 +721,8 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
             const Bsdf br = bsdf_eval(M, wo, L.wi, n);
             const float p_sel = S.dir_sum_imp > 0.0f ? L.importance / f_max(S.dir_sum_imp, 1e-8f) : 1.0f / (float)S.dir_count;
             const float k = ((cos_surf / f_max(p_sel, 1e-8f)) * M.imp) * mtrans;
-            dir_c = ((thr_in * br.f) * L.Li) * k;
-            dir_wi = L.wi;
+            lane.set_b(((thr_in * br.f) * L.Li) * k);
+            dir_light = idx;
             nee_on |= 2u;
         }
     }
@@ -784,60 +828,48 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t pixel, uint32_t frame, ui
         thr = (thr_in * V3{md.albedo.x / kPi, md.albedo.y / kPi, md.albedo.z / kPi}) * (cos_theta / pdf);
     }
     float rr = 1.0f;
-    if (P.depth >= 4u) {
+    if (depth_in >= 4u) {
         const float q = f_clamp(1.0f - f_max(thr.x, f_max(thr.y, thr.z)), 0.0f, 0.95f);
         if (rng_next(rng) < q) return false;
         rr = 1.0f / (1.0f - q);
     }
-    if (!((P.depth + 1u) < 16u)) return false;
-    P.o = H.p + normalize(H.n) * 1e-3f;
-    P.tmin = 1e-3f;
-    P.d = wi;
-    if (Rows::kOn) park3(wave, Rows::kThr, thr * rr);
-    else P.thr = thr * rr;
-    P.depth = P.depth + 1u;
-    P.rng_hi = rng;
+    if (!((depth_in + 1u) < 16u)) return false;
+    // (the new ray starts at `so` = H.p + normalize(H.n) * 1e-3 with tmin 1e-3: trace_frames takes both from rows A and the depth)
+    lane.set_dir(wi);
+    lane.set_thr(thr * rr);
+    lane.set_word(lane.word() + 1u);  // depth + 1 (the depth sits in the word's low bits and stays below 16)
+    lane.set_rng(rng);
     return true;
     }();
     // the deferred shadow rays (pt_shadow.wgsl main): every lane takes ITS next one, in the order their contributions were
-    // added before (environment, directional, area), until no lane of the wave has one left.  What the vertex has decided
-    // already waits in the lane's park rows meanwhile (see "parked path state").
-    if (Rows::kOn) {
-        wave.park(Rows::kDepth, f_from_bits(P.depth));
-        if (Rows::kHit) {
-            park3(wave, Rows::kEnvC, env_c);
-            park3(wave, Rows::kDirC, dir_c);
-        } else {
-            wave.park(Rows::kRng, f_from_bits(P.rng_hi));
-        }
-    }
+    // added before (environment, directional, area), until no lane of the wave has one left.  The two contributions every
+    // scene has wait in rows A and B meanwhile; the directional light's direction is read again from the light table.
     while (wave.count(nee_on != 0u) != 0u) {
         if (nee_on != 0u) {
             const uint32_t k = (uint32_t)__builtin_ctz(nee_on);
             nee_on &= nee_on - 1u;
-            const V3 wi = k == 0u ? env_wi : (k == 1u ? dir_wi : area_wi);
+            const V3 wi = k == 0u ? env_wi : (k == 1u ? S.dir[dir_light].wi : area_wi);
             if (!shadowed(S, so, wi, 1e-3f, k == 2u ? area_tmax : 1e30f, wave))
-                acc_add((Rows::kHit && k < 2u) ? unpark3(wave, Rows::kEnvC + 3u * k) : (k == 0u ? env_c : (k == 1u ? dir_c : area_c)));
+                acc_add(k == 0u ? lane.a() : (k == 1u ? lane.b() : area_c));
         }
     }
-    if (Rows::kOn) {
-        P.depth = f_bits(wave.unpark(Rows::kDepth));
-        if (!Rows::kHit) P.rng_hi = f_bits(wave.unpark(Rows::kRng));
-    }
+    if (go_on) lane.set_a(so);
     return go_on;
 }
 
-// How many lanes of the wave could use another closest-hit attempt (the host "wave" is one lane wide), and the
-// traversal context of the terrain primitive (f3d_march.h Ctx: the device's LDS block, the emulator's arrays).
-// kTerrain: the kernel was compiled with the heightfield primitive (scenes without one run a build without it).
+// How many lanes of the wave could use another closest-hit attempt (the host "wave" is one lane wide), the rows of the lane's
+// state (LaneState), which pixel the lane is, and the traversal context of the terrain primitive (f3d_march.h Ctx: the device's
+// LDS block, the emulator's arrays).  kTerrain: the kernel was compiled with the heightfield primitive.
 template <class Pend>
 struct SoloWave {
     static constexpr bool kTerrain = true;
     static constexpr bool kLite = false;
-    static constexpr uint32_t kPark = 13u;  // (the host runs the parked form of the code, the park being an array)
+    static constexpr uint32_t kPark = kLaneRows;  // (the host runs the row form of the code, the rows being an array)
     Pend *pend;
-    mutable uint32_t parked[13];
+    uint32_t pixel_;
+    mutable uint32_t parked[kLaneRows];
     F3D_HD uint32_t count(bool flag) const { return flag ? 64u : 0u; }
+    F3D_HD uint32_t pixel() const { return pixel_; }
     F3D_HD void park(uint32_t row, float v) const { parked[row] = f_bits(v); }
     F3D_HD float unpark(uint32_t row) const { return f_from_bits(parked[row]); }
 };
@@ -846,17 +878,23 @@ template <class Pend, bool TERRAIN, bool LITE = false>
 struct HipWave {
     static constexpr bool kTerrain = TERRAIN;
     static constexpr bool kLite = LITE;  // no meshes, hair, area lights, fog in the scene: their code is not in the kernel
-    // rows of the lane's LDS column in which the path's loop-carried state waits out a march (0: no LDS block, nothing parked)
+    // rows of the lane's LDS column that hold the path's loop-carried state (0: no LDS block, the state lives in registers)
     static constexpr uint32_t kPark = TERRAIN ? (uint32_t)kPathParkRows : 0u;
     Pend *pend;
+    uint32_t x0, y0, width;  // the wave's 8 x 8 tile (wave-uniform)
     __device__ uint32_t count(bool flag) const { return (uint32_t)__popcll(__ballot(flag)); }
+    // the lane's pixel, formed where it is used from the hardware's lane id (f3d_lds.h lane_now: never hoisted, never kept)
+    __device__ uint32_t pixel() const {
+        const uint32_t lane = lane_now();
+        return (y0 + (lane >> 3)) * width + x0 + (lane & 7u);
+    }
     __device__ void park(uint32_t row, float v) const { pend->col[(kPathParkRow0 + row) * kWave] = f_bits(v); }
     __device__ float unpark(uint32_t row) const { return f_from_bits(pend->col[(kPathParkRow0 + row) * kWave]); }
 };
 #endif
 
-// A pixel's frames [first, first + count): `sink(frame, total)` receives every frame's contributions, summed from zero
-// in stage order; returns the number of path vertices (closest-hit queries) traced.
+// A pixel's frames [first, first + count), count <= kMaxFramesPerCall: `sink(frame, total)` receives every frame's
+// contributions, summed from zero in stage order; returns the number of path vertices (closest-hit queries) traced.
 //
 // The loop is FLAT: its body is one path vertex, and a lane whose path ended starts its next frame's camera ray in the
 // same pass, so the lanes of a wave never wait for the longest path of a frame.  It is also TWO-PHASE: about half of
@@ -874,71 +912,84 @@ struct HipWave {
 #endif
 
 template <class Wave, class Sink>
-F3D_HD uint32_t trace_frames(const SceneDev &S, uint32_t pixel, uint32_t first, uint32_t count, Wave wave, Sink &&sink) {
-    uint32_t frame = first, vertices = 0u, seed_lo = 0u;
-    const uint32_t end = first + count;
-    bool fresh = true, pending = false;
-    PathState P;
-    P.o = P.d = P.thr = V3{0.0f, 0.0f, 0.0f};
-    P.tmin = 0.0f;
-    P.depth = P.rng_hi = 0u;
-    using Rows = ParkRows<Wave>;
-    V3 total{0.0f, 0.0f, 0.0f};  // (kOn: rows kAcc.. instead)
-    if (Rows::kOn) park3(wave, Rows::kAcc, total);
-    SurfaceHitWf H;
-    H.p = H.n = H.tangent = V3{0.0f, 0.0f, 0.0f};
-    H.t = 0.0f;
-    H.mat = 0u;
-    H.hair = false;
+F3D_HD uint32_t trace_frames(const SceneDev &S, uint32_t first, uint32_t count, Wave wave, Sink &&sink) {
+    using Lane = LaneState<Wave>;
+    Lane lane(wave);
+    lane.set_acc(V3{0.0f, 0.0f, 0.0f});
+    lane.set_word(Lane::kFresh);  // depth 0, frame `first`, no query yet
+    // what of a hit does not fit the rows (scenes with fog or hair only: the LITE kernel carries none of it)
+    float hit_t = 0.0f;
+    bool hit_hair = false;
+    V3 hit_tangent{0.0f, 0.0f, 0.0f};
+    auto frame_of = [&](uint32_t word) F3D_LAMBDA { return first + ((word >> Lane::kFrameShift) & Lane::kFrameMask); };
+    auto active = [&](uint32_t word) F3D_LAMBDA { return (word & Lane::kPending) == 0u && ((word >> Lane::kFrameShift) & Lane::kFrameMask) < count; };
     auto finish_frame = [&]() F3D_LAMBDA {  // the frame's total goes out, the next frame starts from zero
-        sink(frame, Rows::kOn ? unpark3(wave, Rows::kAcc) : total);
-        total = V3{0.0f, 0.0f, 0.0f};
-        if (Rows::kOn) park3(wave, Rows::kAcc, total);
-        frame++;
-        fresh = true;
+        const uint32_t word = lane.word();
+        sink(frame_of(word), lane.acc());
+        lane.set_acc(V3{0.0f, 0.0f, 0.0f});
+        lane.set_word(((word & ~Lane::kDepthMask) + (1u << Lane::kFrameShift)) | Lane::kFresh);
     };
     for (;;) {
         for (;;) {  // cheap phase
-            if (!pending && frame < end) {
-                if (fresh) {
-                    const uint32_t seed_hi = splitmix32(S.seed_hi ^ frame);
-                    seed_lo = splitmix32(S.seed_lo ^ (frame * 0x00009E3Du));
-                    camera_ray(S, pixel, frame, seed_hi, seed_lo, P);
-                    if (Rows::kOn) park3(wave, Rows::kThr, P.thr);
-                    fresh = false;
+            uint32_t word = lane.word();
+            if (active(word)) {
+                V3 o, d;
+                if (word & Lane::kFresh) {
+                    const uint32_t frame = frame_of(word);
+                    const uint32_t seed_hi = splitmix32(S.seed_hi ^ frame), seed_lo = splitmix32(S.seed_lo ^ (frame * 0x00009E3Du));
+                    PathState P;
+                    camera_ray(S, wave.pixel(), frame, seed_hi, seed_lo, P);
+                    o = P.o;
+                    d = P.d;
+                    lane.set_dir(d);
+                    lane.set_thr(P.thr);
+                    lane.set_rng(P.rng_hi);
+                    word = word & ~(Lane::kFresh | Lane::kDepthMask);
+                } else {  // the ray the last vertex left: origin in rows A, direction in its rows
+                    o = lane.a();
+                    d = lane.dir();
                 }
-                vertices++;
-                if (closest(S, P.o, P.d, P.tmin, H, wave, P.depth == 0u ? pixel : kNoPixel)) {
-                    pending = true;
-                    if (Rows::kHit) {  // the hit waits for the expensive phase in the park rows, not in registers
-                        park3(wave, Rows::kHitP, H.p);
-                        park3(wave, Rows::kHitN, H.n);
-                        wave.park(Rows::kHitMat, f_from_bits(H.mat));
+                const uint32_t depth = word & Lane::kDepthMask;
+                word += 1u << Lane::kQueryShift;
+                SurfaceHitWf H;
+                if (closest(S, o, d, depth == 0u ? 1e-4f : 1e-3f, H, wave, depth == 0u ? wave.pixel() : kNoPixel)) {
+                    // the hit waits for the expensive phase in the rows, not in registers
+                    lane.set_a(H.p);
+                    lane.set_b(H.n);
+                    lane.set_mat(H.mat);
+                    if (!Wave::kLite) {
+                        hit_t = H.t;
+                        hit_hair = H.hair;
+                        hit_tangent = H.tangent;
                     }
+                    lane.set_word(word | Lane::kPending);
                 } else {  // pt_scatter.wgsl:113-131
-                    const V3 miss = (Rows::kOn ? unpark3(wave, Rows::kThr) : P.thr) * mix3(S.miss_ground, S.miss_sky, 0.5f * (P.d.y + 1.0f));
-                    if (Rows::kOn) park3(wave, Rows::kAcc, unpark3(wave, Rows::kAcc) + miss);
-                    else total = total + miss;
+                    lane.set_word(word);
+                    lane.add(lane.thr() * mix3(S.miss_ground, S.miss_sky, 0.5f * (lane.dir().y + 1.0f)));
                     finish_frame();
                 }
             }
-            if (wave.count(!pending && frame < end) < (Wave::kTerrain ? (uint32_t)F3D_WF_REFILL_TERRAIN : (uint32_t)F3D_WF_REFILL)) break;
+            if (wave.count(active(lane.word())) < (Wave::kTerrain ? (uint32_t)F3D_WF_REFILL_TERRAIN : (uint32_t)F3D_WF_REFILL)) break;
         }
+        const bool pending = (lane.word() & Lane::kPending) != 0u;
         if (wave.count(pending) == 0u) {
-            if (wave.count(frame < end) == 0u) break;
+            if (wave.count(((lane.word() >> Lane::kFrameShift) & Lane::kFrameMask) < count) == 0u) break;
             continue;
         }
         if (pending) {  // expensive phase
-            pending = false;
-            if (Rows::kHit) {
-                H.p = unpark3(wave, Rows::kHitP);
-                H.n = unpark3(wave, Rows::kHitN);
-                H.mat = f_bits(wave.unpark(Rows::kHitMat));
-            }
-            if (!surface_vertex(S, pixel, frame, seed_lo, H, P, total, wave)) finish_frame();
+            const uint32_t word = lane.word() & ~Lane::kPending;
+            lane.set_word(word);
+            SurfaceHitWf H;
+            H.p = lane.a();
+            H.n = lane.b();
+            H.mat = lane.mat();
+            H.t = hit_t;
+            H.hair = hit_hair;
+            H.tangent = hit_tangent;
+            if (!surface_vertex(S, frame_of(word), H, lane.dir(), lane, wave)) finish_frame();
         }
     }
-    return vertices;
+    return lane.word() >> Lane::kQueryShift;
 }
 
 }  // namespace wf

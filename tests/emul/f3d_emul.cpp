@@ -1105,7 +1105,11 @@ int emul_wavefront_render(const f3d_wf_scene *scene, uint32_t width, uint32_t he
         for (int64_t p = 0; p < pixels; p++) {
             V3 acc{accum[4 * p], accum[4 * p + 1], accum[4 * p + 2]};
             ArrayPending pend;
-            vertices += wf::trace_frames(S, (uint32_t)p, first_frame, frame_count, wf::SoloWave<ArrayPending>{&pend}, [&](uint32_t, V3 total) { acc = acc + total; });
+            // (a call takes at most kMaxFramesPerCall frames -- the lane state's frame counter; frames are independent of each other)
+            for (uint32_t done = 0u; done < frame_count; done += wf::kMaxFramesPerCall) {
+                wf::SoloWave<ArrayPending> wave{&pend, (uint32_t)p, {}};
+                vertices += wf::trace_frames(S, first_frame + done, std::min(wf::kMaxFramesPerCall, frame_count - done), wave, [&](uint32_t, V3 total) { acc = acc + total; });
+            }
             accum[4 * p] = acc.x;
             accum[4 * p + 1] = acc.y;
             accum[4 * p + 2] = acc.z;
