@@ -638,6 +638,47 @@ struct LaneState {
     }
 };
 
+#if defined(F3D_WF_SHADOW_STREAM)
+template <class Wave>
+struct NeeShadowSource {  // the shadow rays of one vertex as a source of march_stream (-DF3D_WF_SHADOW_STREAM, see surface_vertex)
+    const SceneDev &S;
+    LaneState<Wave> &lane;
+    V3 so, env_wi;
+    uint32_t dir_light, nee_on;
+    F3D_HD bool sphere_blocks(V3 rd) const {  // shadowed()'s sphere loop (any hit in (1e-3, 1e30))
+        for (uint32_t i = 0u; i < S.sphere_count; i++) {
+            const SphereDev sp = S.spheres[i];
+            const V3 oc = so - sp.c;
+            const float b = dot(oc, rd);
+            const float cterm = dot(oc, oc) - sp.r * sp.r;
+            const float disc = b * b - cterm;
+            if (disc <= 0.0f) continue;
+            const float q = f_sqrt(disc);
+            const float t0 = -b - q, t1 = -b + q;
+            if ((t0 > 1e-3f && t0 < 1e30f) || (t1 > 1e-3f && t1 < 1e30f)) return true;
+        }
+        return false;
+    }
+    template <class Ctx>
+    F3D_HD bool refill(bool &have, RayCtx &r, float &t_stop, uint32_t &tag, Ctx &ctx) {
+        while (!have && nee_on != 0u) {
+            const uint32_t k = (uint32_t)__builtin_ctz(nee_on);
+            nee_on &= nee_on - 1u;
+            const V3 wi = k == 0u ? env_wi : S.dir[dir_light].wi;
+            if (sphere_blocks(wi)) continue;  // occluded whatever the terrain says: the contribution is dropped
+            r = make_ray(S.terrain, so, 1e-3f, wi, 1e30f, false);
+            t_stop = 3.0e38f;
+            tag = k;
+            have = true;
+        }
+        return ctx.any(nee_on != 0u);
+    }
+    F3D_HD void verdict(uint32_t tag, bool blocked) {
+        if (!blocked) lane.add(tag == 0u ? lane.a() : lane.b());
+    }
+};
+
+#endif
 // One surface vertex: emission, NEE (environment / directional / area) with its shadow rays, continuation sample,
 // roulette (pt_shade.wgsl main :460-862 + pt_shadow.wgsl main).  Returns true when the path continues in P.
 // H: the hit (position, normal, material -- and, scenes with hair or fog, its distance, hair flag and strand axis);
@@ -844,6 +885,17 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t frame, const SurfaceHitWf
     // the deferred shadow rays (pt_shadow.wgsl main): every lane takes ITS next one, in the order their contributions were
     // added before (environment, directional, area), until no lane of the wave has one left.  The two contributions every
     // scene has wait in rows A and B meanwhile; the directional light's direction is read again from the light table.
+#if defined(F3D_WF_SHADOW_STREAM)
+    // A/B (round 6): in a scene whose only other occluders are spheres, the vertex's shadow rays go through the heightfield as a
+    // STREAM (f3d_march.h march_stream): a lane whose ray is done takes ITS next one while the others still march, so the wave
+    // iterates max over lanes of (env + dir steps) instead of max(env) + max(dir).  Verdicts do not depend on the schedule
+    //  and a lane adds its contributions in the same order: same results.
+    if (Wave::kTerrain && S.has_terrain != 0u && (Wave::kLite || (S.blas_count == 0u && S.inst_count == 0u && S.area_count == 0u))) {
+        NeeShadowSource<Wave> src{S, lane, so, env_wi, dir_light, nee_on & 3u};
+        march_stream<false>(S.terrain, src, *wave.pend, 16u);
+        nee_on = 0u;
+    }
+#endif
     while (wave.count(nee_on != 0u) != 0u) {
         if (nee_on != 0u) {
             const uint32_t k = (uint32_t)__builtin_ctz(nee_on);

@@ -89,6 +89,7 @@ struct ArrayPending {
     }
     bool flush_now(uint32_t queued, bool marching) const { return queued >= kLeafFifo || (!marching && queued != 0u); }
     bool any(bool pred) const { return pred; }
+    unsigned long long ballot(bool pred) const { return pred ? 1ull : 0ull; }  // (march_stream: a wave of one lane)
     void put(uint32_t l, uint32_t v) { w[l] = v; }
     uint32_t get(uint32_t l) const { return w[l]; }
     void band_entry(const TerrainDev &T, uint32_t l, uint32_t &offset, uint32_t &shift) const {
