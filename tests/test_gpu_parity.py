@@ -156,6 +156,37 @@ def test_mixed_scene_mesh_and_terrain(f3d, oracle):
     assert np.allclose(mixed["albedo"][terr], np.array(scenes.ALBEDO), atol=2e-2)
 
 
+def test_mesh_cache_shares_a_mesh_between_sessions_and_tells_meshes_apart(f3d, oracle):
+    """Round 6: the device copy of a mesh and its BVH are cached like the DEM tables (f3d_host_mem.h acquire_mesh).  A second
+    render of the same mesh gives the same image, a mesh that differs in one vertex or one index gives ITS image (the key
+    hashes both arrays), and emptying the caches changes nothing."""
+    import ctypes
+
+    from forge3d_amd import _native
+
+    dem = scenes.golden_dem()
+    kw = scenes.fixed_frames(scenes.scene_kwargs(dem), 4, spp=2)
+    v, i = scenes.box_city(40)
+    first = f3d.hybrid_render_terrain_reference(dem, 96, 72, scenes.CAM, mesh_vertices=v, mesh_indices=i, **kw)
+    again = f3d.hybrid_render_terrain_reference(dem, 96, 72, scenes.CAM, mesh_vertices=v.copy(), mesh_indices=i.copy(), **kw)
+    _same(first, again)
+    _same(first, oracle.render(dem, 96, 72, scenes.CAM, mesh_vertices=v, mesh_indices=i, **kw))
+    v2 = v.copy()
+    v2[5, 1] += 9.0  # one roof corner higher
+    moved = f3d.hybrid_render_terrain_reference(dem, 96, 72, scenes.CAM, mesh_vertices=v2, mesh_indices=i, **kw)
+    _same(moved, oracle.render(dem, 96, 72, scenes.CAM, mesh_vertices=v2, mesh_indices=i, **kw))
+    assert not np.array_equal(moved["depth"], first["depth"], equal_nan=True)
+    i2 = i[:-1].copy()  # the degenerate last triangle dropped: another index array over the same vertices
+    fewer = f3d.hybrid_render_terrain_reference(dem, 96, 72, scenes.CAM, mesh_vertices=v, mesh_indices=i2, **kw)
+    _same(fewer, oracle.render(dem, 96, 72, scenes.CAM, mesh_vertices=v, mesh_indices=i2, **kw))
+    L = _native.lib()
+    L.f3d_scene_cache_limit(ctypes.c_uint32(0))  # both caches emptied and off
+    try:
+        _same(first, f3d.hybrid_render_terrain_reference(dem, 96, 72, scenes.CAM, mesh_vertices=v, mesh_indices=i, **kw))
+    finally:
+        L.f3d_scene_cache_limit(ctypes.c_uint32(2))
+
+
 def test_terrain_trace_batch_matches_oracle_and_kat_gates(f3d, oracle):
     """The reference's production-kernel proof (terrain_heightfield.rs:2129-2285): 10 000
     xorshift rays + 255^2 grazing shadow mask, any-hit with curvature; here the HIP
