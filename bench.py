@@ -234,9 +234,7 @@ def other_configs(dem, cam, kw, args, device):
             for key in kernel:
                 kernel[key] += seq.kernel_seconds[key]
         kernel_ms = {key: v * 1e3 / timed for key, v in kernel.items()}
-        seq._mode = "overlap"
-        list_stats = seq.stats()  # what the sequence holds on the device, and how full the marcher's deferred list was
-        seq._mode = "serial"
+        list_stats = seq.stats()  # what the sequence holds on the device, and how full the marcher's deferred list was (the timing pass above ran the serial schedule)
         out["C5"] = {"value": wall, "unit": "ms/frame (solver step + march + composite, state and images resident on the GPU; RGBA8 frames read back)",
                      "frames": frames5, "frames_per_s": 1e3 / wall, "kernel_ms": kernel_ms,
                      "kernel_ms_note": "device time by kernel group, from 24 further frames with per-call timing, one call after the other "

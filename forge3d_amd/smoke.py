@@ -628,6 +628,7 @@ class SmokeSequence:
 
     def _handle(self, mode=None):
         mode = mode or self._mode
+        self._last_mode = mode
         if mode not in self._handles:
             streams = (self.solver_stream.cuda_stream, self.render_stream.cuda_stream) if mode == "overlap" else (None, None)
             h = C.c_void_p(None)
@@ -640,7 +641,7 @@ class SmokeSequence:
         return self.render_stream if self._mode == "overlap" else self.torch.cuda.default_stream(self.device)
 
     def close(self):
-        """Give the sequence's device scratch back (the library keeps it per handle; about 1.8 GB at 1080p with self-shadowing)."""
+        """Give the sequence's device scratch back (the library keeps it per handle: about 0.5 GB at 1080p with self-shadowing)."""
         for h in self._handles.values():
             _native.lib().f3d_smoke_seq_destroy(h)
         self._handles = {}
@@ -652,14 +653,14 @@ class SmokeSequence:
             pass
 
     def stats(self) -> dict:
-        """f3d_smoke_seq_stats of the current schedule's handle: bytes of scratch held, and the fill of the marcher's deferred
-        self-shadow list in the last render (waits for it)."""
+        """f3d_smoke_seq_stats of the handle the sequence used last (frames() with overlap: the two-stream one): bytes of scratch
+        held, and the fill of the marcher's deferred self-shadow list in its last render (waits for it)."""
         class _Stats(C.Structure):
             _fields_ = [("scratch_bytes", C.c_uint64), ("shadow_list_chunks", C.c_uint32), ("shadow_list_chunks_used", C.c_uint32),
                         ("shadow_list_slots_per_chunk", C.c_uint32), ("reserved", C.c_uint32)]
 
         st = _Stats()
-        self._check(_native.lib().f3d_smoke_seq_stats(self._handle(), C.byref(st), self._err, len(self._err)))
+        self._check(_native.lib().f3d_smoke_seq_stats(self._handle(getattr(self, "_last_mode", None)), C.byref(st), self._err, len(self._err)))
         return {name: int(getattr(st, name)) for name, _ in _Stats._fields_ if name != "reserved"}
 
     def set_terrain(self, terrain_rgba):

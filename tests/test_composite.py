@@ -279,9 +279,7 @@ def test_sequence_handle_owns_its_scratch_and_reports_the_shadow_list():
 
     seq = smoke.SmokeSequence(smoke.SmokeDomain((24, 16, 20)), terrain, **cam)
     first = run(seq, True)
-    seq._mode = "overlap"
-    st = seq.stats()
-    seq._mode = "serial"
+    st = seq.stats()  # (of the handle used last: the two-stream schedule)
     assert st["scratch_bytes"] > 0 and st["shadow_list_slots_per_chunk"] == 1024
     assert 0 < st["shadow_list_chunks_used"] <= st["shadow_list_chunks"]  # smoke was marched and the list held it
     assert set(seq._handles) == {"overlap"}
@@ -312,7 +310,6 @@ def test_a_shadow_list_that_cannot_be_had_changes_nothing(knob, monkeypatch):
     got = [f.copy() for f in seq.frames(4, settings, emitters, steps_per_frame=2)]
     for a, b in zip(want, got):
         assert np.array_equal(a, b)
-    seq._mode = "overlap"
     st = seq.stats()
     assert st["shadow_list_chunks"] == (0 if knob.endswith("OOM") else 1)
 
