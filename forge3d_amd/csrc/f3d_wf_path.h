@@ -157,8 +157,8 @@ struct PathState {
     uint32_t depth, rng_hi;
 };
 
-F3D_HD void camera_ray(const SceneDev &S, uint32_t pixel, uint32_t frame, uint32_t seed_hi, uint32_t seed_lo, PathState &P) {
-    const uint32_t px = pixel % S.width, py = pixel / S.width;
+F3D_HD void camera_ray(const SceneDev &S, uint32_t px, uint32_t py, uint32_t frame, uint32_t seed_hi, uint32_t seed_lo, PathState &P) {
+    const uint32_t pixel = py * S.width + px;
 #if defined(__HIP_DEVICE_COMPILE__)
     const float u1 = (float)__brev(frame) * 2.3283064365386963e-10f;  // radical_inverse_vdc: a bit reversal
 #else
@@ -559,9 +559,14 @@ F3D_HD uint32_t pick(uint32_t count, float sum_imp, uint32_t &rng, Imp imp) {
             }
         }
     } else {
-        idx = sat_u32(f_floor(rng_next(rng) * (float)count));
+        uint32_t c = count;
+        F3D_OPAQUE_UNIFORM(c);  // (a scene constant: its float is formed here, not kept in a vector register across the flat loop)
+        idx = sat_u32(f_floor(rng_next(rng) * (float)c));
     }
-    return idx < count - 1u ? idx : count - 1u;
+    uint32_t last = count;
+    F3D_OPAQUE_UNIFORM(last);
+    last = last - 1u;
+    return idx < last ? idx : last;
 }
 
 // ---- a lane's loop-carried path state (round 6: resident in the lane's LDS column) -------------------------------------------
@@ -755,12 +760,18 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t frame, const SurfaceHitWf
         }
     }
     if (S.dir_count > 0u) {  // delta lights: weight 1
-        const uint32_t idx = pick(S.dir_count, S.dir_sum_imp, rng, [&](uint32_t i) { return S.dir[i].importance; });
+        const uint32_t dir_count = S.dir_count;
+        const float dir_sum_imp = S.dir_sum_imp;
+        const uint32_t idx = pick(dir_count, dir_sum_imp, rng, [&](uint32_t i) { return S.dir[i].importance; });
         const DirLightDev L = S.dir[idx];
         const float cos_surf = f_max(dot(n, L.wi), 0.0f);
         if (cos_surf > 0.0f) {
             const Bsdf br = bsdf_eval(M, wo, L.wi, n);
-            const float p_sel = S.dir_sum_imp > 0.0f ? L.importance / f_max(S.dir_sum_imp, 1e-8f) : 1.0f / (float)S.dir_count;
+            uint32_t n_dir = dir_count;
+            float sum_dir = dir_sum_imp;
+            F3D_OPAQUE_UNIFORM(n_dir);  // (scene constants: their reciprocal / float are formed here, not in front of the flat loop)
+            F3D_OPAQUE_UNIFORM(sum_dir);
+            const float p_sel = sum_dir > 0.0f ? L.importance / f_max(sum_dir, 1e-8f) : 1.0f / (float)n_dir;
             const float k = ((cos_surf / f_max(p_sel, 1e-8f)) * M.imp) * mtrans;
             lane.set_b(((thr_in * br.f) * L.Li) * k);
             dir_light = idx;
@@ -918,10 +929,12 @@ struct SoloWave {
     static constexpr bool kLite = false;
     static constexpr uint32_t kPark = kLaneRows;  // (the host runs the row form of the code, the rows being an array)
     Pend *pend;
-    uint32_t pixel_;
+    uint32_t pixel_, width_;
     mutable uint32_t parked[kLaneRows];
     F3D_HD uint32_t count(bool flag) const { return flag ? 64u : 0u; }
     F3D_HD uint32_t pixel() const { return pixel_; }
+    F3D_HD uint32_t px() const { return pixel_ % width_; }
+    F3D_HD uint32_t py() const { return pixel_ / width_; }
     F3D_HD void park(uint32_t row, float v) const { parked[row] = f_bits(v); }
     F3D_HD float unpark(uint32_t row) const { return f_from_bits(parked[row]); }
 };
@@ -940,6 +953,8 @@ struct HipWave {
         const uint32_t lane = lane_now();
         return (y0 + (lane >> 3)) * width + x0 + (lane & 7u);
     }
+    __device__ uint32_t px() const { return x0 + (lane_now() & 7u); }
+    __device__ uint32_t py() const { return y0 + (lane_now() >> 3); }
     __device__ void park(uint32_t row, float v) const { pend->col[(kPathParkRow0 + row) * kWave] = f_bits(v); }
     __device__ float unpark(uint32_t row) const { return f_from_bits(pend->col[(kPathParkRow0 + row) * kWave]); }
 };
@@ -990,7 +1005,7 @@ F3D_HD uint32_t trace_frames(const SceneDev &S, uint32_t first, uint32_t count, 
                     const uint32_t frame = frame_of(word);
                     const uint32_t seed_hi = splitmix32(S.seed_hi ^ frame), seed_lo = splitmix32(S.seed_lo ^ (frame * 0x00009E3Du));
                     PathState P;
-                    camera_ray(S, wave.pixel(), frame, seed_hi, seed_lo, P);
+                    camera_ray(S, wave.px(), wave.py(), frame, seed_hi, seed_lo, P);  // (the pixel's column and row: no division by the image width)
                     o = P.o;
                     d = P.d;
                     lane.set_dir(d);

@@ -1108,7 +1108,7 @@ int emul_wavefront_render(const f3d_wf_scene *scene, uint32_t width, uint32_t he
             ArrayPending pend;
             // (a call takes at most kMaxFramesPerCall frames -- the lane state's frame counter; frames are independent of each other)
             for (uint32_t done = 0u; done < frame_count; done += wf::kMaxFramesPerCall) {
-                wf::SoloWave<ArrayPending> wave{&pend, (uint32_t)p, {}};
+                wf::SoloWave<ArrayPending> wave{&pend, (uint32_t)p, (uint32_t)width, {}};
                 vertices += wf::trace_frames(S, first_frame + done, std::min(wf::kMaxFramesPerCall, frame_count - done), wave, [&](uint32_t, V3 total) { acc = acc + total; });
             }
             accum[4 * p] = acc.x;
