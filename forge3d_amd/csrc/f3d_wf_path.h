@@ -429,13 +429,8 @@ F3D_HD bool closest(const SceneDev &S, V3 o, V3 d, float tmin, SurfaceHitWf &H, 
     return true;
 }
 
-// pt_shadow.wgsl main, :248-294 (+ the terrain primitive)
-template <class Wave>
-F3D_HD bool shadowed(const SceneDev &S, V3 ro, V3 rd, float tmin, float tmax, Wave &wave) {
-    if (Wave::kTerrain && S.has_terrain != 0u) {  // any hit of the heightfield in (tmin, tmax)
-        const RayCtx r = make_ray(S.terrain, ro, tmin, rd, tmax, false);
-        if (march_terrain<false>(S.terrain, r, true, true, *wave.pend).hit) return true;
-    }
+// the spheres' part of pt_shadow.wgsl main (:248-294): any sphere hit in (tmin, tmax)
+F3D_HD bool sphere_shadow(const SceneDev &S, V3 ro, V3 rd, float tmin, float tmax) {
     for (uint32_t i = 0u; i < S.sphere_count; i++) {
         const SphereDev s = S.spheres[i];
         const V3 oc = ro - s.c;
@@ -447,6 +442,17 @@ F3D_HD bool shadowed(const SceneDev &S, V3 ro, V3 rd, float tmin, float tmax, Wa
         const float t0 = -b - q, t1 = -b + q;
         if ((t0 > tmin && t0 < tmax) || (t1 > tmin && t1 < tmax)) return true;
     }
+    return false;
+}
+
+// pt_shadow.wgsl main, :248-294 (+ the terrain primitive)
+template <class Wave>
+F3D_HD bool shadowed(const SceneDev &S, V3 ro, V3 rd, float tmin, float tmax, Wave &wave) {
+    if (Wave::kTerrain && S.has_terrain != 0u) {  // any hit of the heightfield in (tmin, tmax)
+        const RayCtx r = make_ray(S.terrain, ro, tmin, rd, tmax, false);
+        if (march_terrain<false>(S.terrain, r, true, true, *wave.pend).hit) return true;
+    }
+    if (sphere_shadow(S, ro, rd, tmin, tmax)) return true;
     if (Wave::kLite) return false;
     float t;
     V3 nn;
@@ -650,20 +656,7 @@ struct NeeShadowSource {  // the shadow rays of one vertex as a source of march_
     LaneState<Wave> &lane;
     V3 so, env_wi;
     uint32_t dir_light, nee_on;
-    F3D_HD bool sphere_blocks(V3 rd) const {  // shadowed()'s sphere loop (any hit in (1e-3, 1e30))
-        for (uint32_t i = 0u; i < S.sphere_count; i++) {
-            const SphereDev sp = S.spheres[i];
-            const V3 oc = so - sp.c;
-            const float b = dot(oc, rd);
-            const float cterm = dot(oc, oc) - sp.r * sp.r;
-            const float disc = b * b - cterm;
-            if (disc <= 0.0f) continue;
-            const float q = f_sqrt(disc);
-            const float t0 = -b - q, t1 = -b + q;
-            if ((t0 > 1e-3f && t0 < 1e30f) || (t1 > 1e-3f && t1 < 1e30f)) return true;
-        }
-        return false;
-    }
+    F3D_HD bool sphere_blocks(V3 rd) const { return sphere_shadow(S, so, rd, 1e-3f, 1e30f); }
     template <class Ctx>
     F3D_HD bool refill(bool &have, RayCtx &r, float &t_stop, uint32_t &tag, Ctx &ctx) {
         while (!have && nee_on != 0u) {
@@ -690,8 +683,15 @@ struct NeeShadowSource {  // the shadow rays of one vertex as a source of march_
 // d_in: the direction the path arrived with.  Everything else the vertex reads and leaves is the lane's state L: it adds to
 // the frame's total, and when the path continues it leaves the new throughput, direction, RNG word and depth there and the
 // new ray's origin in rows A.  (`lane`, not L: the light records of the next-event blocks are called L.)
+// The vertex's shadow rays are an OUTPUT (NeeRays): trace_frames traces them (vertex_shadows), in a scene whose occluders are the
+// heightfield and spheres with EVERY lane of the wave in the call, so that lanes without a ray lend themselves to the ray sharing.
+struct NeeRays {
+    V3 so{0.0f, 0.0f, 0.0f}, env_wi{0.0f, 0.0f, 0.0f}, area_wi{0.0f, 0.0f, 0.0f}, area_c{0.0f, 0.0f, 0.0f};
+    float area_tmax = 1e30f;
+    uint32_t on = 0u, dir_light = 0u;  // on: bit 0 environment (contribution in rows A), bit 1 directional (rows B), bit 2 area (area_c)
+};
 template <class Wave>
-F3D_HD bool surface_vertex(const SceneDev &S, uint32_t frame, const SurfaceHitWf &H, V3 d_in, LaneState<Wave> &lane, Wave &wave) {
+F3D_HD bool vertex_shade(const SceneDev &S, uint32_t frame, const SurfaceHitWf &H, V3 d_in, LaneState<Wave> &lane, Wave &wave, NeeRays &nee) {
     using Lane = LaneState<Wave>;
     const uint32_t pixel = wave.pixel();
     const uint32_t depth_in = lane.word() & Lane::kDepthMask;
@@ -893,31 +893,58 @@ F3D_HD bool surface_vertex(const SceneDev &S, uint32_t frame, const SurfaceHitWf
     lane.set_rng(rng);
     return true;
     }();
-    // the deferred shadow rays (pt_shadow.wgsl main): every lane takes ITS next one, in the order their contributions were
-    // added before (environment, directional, area), until no lane of the wave has one left.  The two contributions every
-    // scene has wait in rows A and B meanwhile; the directional light's direction is read again from the light table.
+    nee.so = so;
+    nee.env_wi = env_wi;
+    if (!Wave::kLite) {  // (a LITE scene has no area lights)
+        nee.area_wi = area_wi;
+        nee.area_c = area_c;
+        nee.area_tmax = area_tmax;
+    }
+    nee.on = nee_on;
+    nee.dir_light = dir_light;
+    return go_on;
+}
+
+// The deferred shadow rays of a vertex (pt_shadow.wgsl main): every lane takes ITS next one, in the order their contributions
+// were added before (environment, directional, area), until no lane of the wave has one left.  The two contributions every
+// scene has wait in rows A and B meanwhile; the directional light's direction is read again from the light table.
+// ALL_LANES (wave-uniform call): every lane of the wave goes through the heightfield's march, the ones without a ray with an
+// empty one -- inside the march they are lanes whose ray has ended, which is what the ray sharing of f3d_march.h deals the
+// last rays of a wave to.  Verdicts do not depend on who walks a slice: same results.
+template <bool ALL_LANES, class Wave>
+F3D_HD void vertex_shadows(const SceneDev &S, NeeRays &nee, LaneState<Wave> &lane, Wave &wave) {
 #if defined(F3D_WF_SHADOW_STREAM)
-    // A/B (round 6): in a scene whose only other occluders are spheres, the vertex's shadow rays go through the heightfield as a
-    // STREAM (f3d_march.h march_stream): a lane whose ray is done takes ITS next one while the others still march, so the wave
-    // iterates max over lanes of (env + dir steps) instead of max(env) + max(dir).  Verdicts do not depend on the schedule
-    //  and a lane adds its contributions in the same order: same results.
+    // A/B (round 6): the rays as a STREAM (f3d_march.h march_stream): a lane whose ray is done takes ITS next one while the others
+    // still march -- max over lanes of (env + dir steps) instead of max(env) + max(dir).  Measured: 48.5 ms against 34.4.
     if (Wave::kTerrain && S.has_terrain != 0u && (Wave::kLite || (S.blas_count == 0u && S.inst_count == 0u && S.area_count == 0u))) {
-        NeeShadowSource<Wave> src{S, lane, so, env_wi, dir_light, nee_on & 3u};
+        NeeShadowSource<Wave> src{S, lane, nee.so, nee.env_wi, nee.dir_light, nee.on & 3u};
         march_stream<false>(S.terrain, src, *wave.pend, 16u);
-        nee_on = 0u;
+        nee.on = 0u;
     }
 #endif
-    while (wave.count(nee_on != 0u) != 0u) {
-        if (nee_on != 0u) {
-            const uint32_t k = (uint32_t)__builtin_ctz(nee_on);
-            nee_on &= nee_on - 1u;
-            const V3 wi = k == 0u ? env_wi : (k == 1u ? S.dir[dir_light].wi : area_wi);
-            if (!shadowed(S, so, wi, 1e-3f, k == 2u ? area_tmax : 1e30f, wave))
-                acc_add(k == 0u ? lane.a() : (k == 1u ? lane.b() : area_c));
+    while (wave.count(nee.on != 0u) != 0u) {
+        const bool have = nee.on != 0u;
+        if (ALL_LANES) {
+            uint32_t k = 0u;
+            V3 wi{0.0f, 1.0f, 0.0f};
+            if (have) {
+                k = (uint32_t)__builtin_ctz(nee.on);
+                nee.on &= nee.on - 1u;
+                wi = k == 0u ? nee.env_wi : S.dir[nee.dir_light].wi;
+            }
+            // (tmax < tmin: the root interval of a lane without a ray is empty, it never marches)
+            const RayCtx r = make_ray(S.terrain, nee.so, have ? 1e-3f : 1.0f, wi, have ? 1e30f : 0.0f, false);
+            bool blocked = march_terrain<false>(S.terrain, r, true, true, *wave.pend).hit;
+            if (have && !blocked) blocked = sphere_shadow(S, nee.so, wi, 1e-3f, 1e30f);
+            if (have && !blocked) lane.add(k == 0u ? lane.a() : lane.b());
+        } else if (have) {
+            const uint32_t k = (uint32_t)__builtin_ctz(nee.on);
+            nee.on &= nee.on - 1u;
+            const V3 wi = k == 0u ? nee.env_wi : (k == 1u ? S.dir[nee.dir_light].wi : nee.area_wi);
+            if (!shadowed(S, nee.so, wi, 1e-3f, k == 2u ? nee.area_tmax : 1e30f, wave))
+                lane.add(k == 0u ? lane.a() : (k == 1u ? lane.b() : nee.area_c));
         }
     }
-    if (go_on) lane.set_a(so);
-    return go_on;
 }
 
 // How many lanes of the wave could use another closest-hit attempt (the host "wave" is one lane wide), the rows of the lane's
@@ -1043,7 +1070,10 @@ F3D_HD uint32_t trace_frames(const SceneDev &S, uint32_t first, uint32_t count, 
             if (wave.count(((lane.word() >> Lane::kFrameShift) & Lane::kFrameMask) < count) == 0u) break;
             continue;
         }
-        if (pending) {  // expensive phase
+        // expensive phase: the waiting hits are shaded; then the vertices' shadow rays; then the paths continue or end
+        NeeRays nee;
+        bool go_on = false;
+        if (pending) {
             const uint32_t word = lane.word() & ~Lane::kPending;
             lane.set_word(word);
             SurfaceHitWf H;
@@ -1053,7 +1083,19 @@ F3D_HD uint32_t trace_frames(const SceneDev &S, uint32_t first, uint32_t count, 
             H.t = hit_t;
             H.hair = hit_hair;
             H.tangent = hit_tangent;
-            if (!surface_vertex(S, frame_of(word), H, lane.dir(), lane, wave)) finish_frame();
+            go_on = vertex_shade(S, frame_of(word), H, lane.dir(), lane, wave, nee);
+        }
+#if !defined(F3D_WF_SHADOWS_DIVERGENT)  // A/B: the round-5 form -- only the lanes with a vertex enter the shadow rays' march
+        // (a scene whose occluders are the heightfield and spheres: every lane of the wave goes through the shadow rays' march)
+        // (the LITE kernel is only ever launched for such a scene: no run-time test, and the other form is not in it)
+        if (Wave::kLite || (Wave::kTerrain && S.has_terrain != 0u && S.blas_count == 0u && S.inst_count == 0u && S.area_count == 0u && S.hair_count == 0u)) {
+            vertex_shadows<true>(S, nee, lane, wave);
+        } else
+#endif
+        if (pending) vertex_shadows<false>(S, nee, lane, wave);
+        if (pending) {
+            if (go_on) lane.set_a(nee.so);  // the continuing ray's origin, for the next closest()
+            else finish_frame();
         }
     }
     return lane.word() >> Lane::kQueryShift;
