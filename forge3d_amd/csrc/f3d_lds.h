@@ -30,8 +30,11 @@ constexpr int kBoardRow = kParkRow + kParkHead + 1;  // verdict board of the ray
 constexpr uint32_t kBoardBit = 0x80000000u;
 constexpr int kLdsRows = kParkRow + kParkWords > kMaxLevels ? kParkRow + kParkWords : kMaxLevels;
 constexpr int kLdsWords = kLdsRows * kWave + 4 * kMaxLevels;
-template <int BOARD_ROW, bool MESH_STACK = true>
+template <int BOARD_ROW, bool MESH_STACK = true, bool SHARE_CLOSEST = false>
 struct LdsPendingAt {
+    // closest-hit rays are shared too (f3d_march.h march_shared_closest): the board's row is the board's alone, a lane's whole
+    // word is free for the key of the nearest hit its ray's slices have found
+    static constexpr bool kShareClosest = SHARE_CLOSEST;
     // may the scene hold a mesh?  (closest_hit / occluded, f3d_shade.h: the terrain-only frame kernels are compiled without
     // the mesh walk, so nothing the mesh path needs can move their register allocation -- and the other way round)
     // MESH_STACK = false: the user never walks a mesh 4 wide through stack_put / stack_get (the PBR tracer walks its instanced
@@ -112,6 +115,20 @@ struct LdsPendingAt {
                               __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
     __device__ __forceinline__ bool verdict_get(uint32_t owner) const { return (board()[owner & (kWave - 1u)] & kBoardBit) != 0u; }
+    // nearest hit of a shared closest-hit ray: kBoardBit | the complement of the 27-bit key, so that an atomic MAX keeps the
+    // smallest key and 0 says "none"
+    __device__ __forceinline__ void nearest_post() const {
+        static_assert(SHARE_CLOSEST, "the board's word is shared with other flags in this layout");
+        *(LdsWord *)(col + BOARD_ROW * kWave) = 0u;
+    }
+    __device__ __forceinline__ void nearest_set(uint32_t owner, uint32_t key) const {
+        __hip_atomic_fetch_max((__attribute__((address_space(3))) uint32_t *)(board() + (owner & (kWave - 1u))), kBoardBit | (0x07FFFFFFu - key),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    __device__ __forceinline__ uint32_t nearest_get(uint32_t owner) const {
+        const uint32_t w = board()[owner & (kWave - 1u)];
+        return (w & kBoardBit) != 0u ? 0x07FFFFFFu - (w & 0x07FFFFFFu) : kNoNearest;
+    }
     // wave primitives of march_deal (f3d_march.h)
     __device__ __forceinline__ unsigned long long ballot(bool pred) const { return __ballot(pred); }
     __device__ __forceinline__ float shfl(float v, int src) const { return __shfl(v, src, kWave); }
@@ -147,7 +164,11 @@ constexpr int kPathParkRows = F3D_WF_PARK;
 constexpr int kPathParkRow0 = kParkRow + 1;
 constexpr int kCompactRows = kParkRow + 1 + kPathParkRows;
 constexpr int kCompactLdsWords = kCompactRows * kWave + 4 * kMaxLevels;
-using LdsPendingCompact = LdsPendingAt<kParkRow, false>;
+#if !defined(F3D_WF_NO_SHARE_CLOSEST)  // (A/B: camera and bounce rays marched to their end by their own lanes, the round-5 form)
+using LdsPendingCompact = LdsPendingAt<kParkRow, false, true>;
+#else
+using LdsPendingCompact = LdsPendingAt<kParkRow, false, false>;
+#endif
 // rows: lane-column rows in front of the level table (the occlusion-stream kernels need the leaf FIFO only)
 struct LdsPendingTerrainOnly : LdsPending {
     static constexpr bool kMesh = false;

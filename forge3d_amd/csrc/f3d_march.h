@@ -389,9 +389,20 @@ constexpr bool kVerifyInLoop = true;
 // judged as the reference judges it -- cell range, the zero-length interval [T, T] clipped by the ray's
 // (tmin, tmax), the cell's own (min,max) band (= min / max of its corner record; its ancestors' tests
 // are implied, their intervals contain T and their bands contain the cell's), then the leaf solve.
+// The slab interval of cell (cx, cz) clipped by the ray's (tmin, tmax), by the expressions march_step uses for a level-0 node.
+F3D_HD void march_leaf_interval(const TerrainDev &T, const RayCtx &r, uint32_t cx, uint32_t cz, float &lo, float &hi) {
+    const uint32_t cx1 = cx + 1u < T.cell_w ? cx + 1u : T.cell_w, cz1 = cz + 1u < T.cell_h ? cz + 1u : T.cell_h;
+    const float tx0 = (plane_at(T.origin_x, cx, T.spacing_x) - r.o.x) * r.inv_x;
+    const float tx1 = (plane_at(T.origin_x, cx1, T.spacing_x) - r.o.x) * r.inv_x;
+    const float tz0 = (plane_at(T.origin_z, cz, T.spacing_z) - r.o.z) * r.inv_z;
+    const float tz1 = (plane_at(T.origin_z, cz1, T.spacing_z) - r.o.z) * r.inv_z;
+    lo = f_max(f_max(f_min(tx0, tx1), f_min(tz0, tz1)), r.tmin);
+    hi = f_min(f_min(f_max(tx0, tx1), f_max(tz0, tz1)), r.tmax);
+}
+// hit_cell: the cell (cx | cz << 16) of the hit a closest-hit drain ends with (the sharing of closest-hit rays, march_shared_closest)
 template <class Ctx>
 F3D_HD void march_drain(const TerrainDev &T, const RayCtx &r, bool any_hit, MarchState &m, uint32_t &queued,
-                        TraceHit &res, Ctx &ctx) {
+                        TraceHit &res, Ctx &ctx, uint32_t &hit_cell) {
     uint32_t k = 0u;  // per lane: a tie entry is visited twice
     // (a plain divergent `while (k < queued && !res.hit)` measured 0.5 % slower than this vote per entry)
     while (ctx.any(k < queued && !res.hit)) {
@@ -406,13 +417,7 @@ F3D_HD void march_drain(const TerrainDev &T, const RayCtx &r, bool any_hit, Marc
                 if (tie) {
                     lo = hi = (plane_at(T.origin_x, cell & 0x3FFFu, T.spacing_x) - r.o.x) * r.inv_x;
                 } else {
-                    const uint32_t cx1 = cx + 1u < T.cell_w ? cx + 1u : T.cell_w, cz1 = cz + 1u < T.cell_h ? cz + 1u : T.cell_h;
-                    const float tx0 = (plane_at(T.origin_x, cx, T.spacing_x) - r.o.x) * r.inv_x;
-                    const float tx1 = (plane_at(T.origin_x, cx1, T.spacing_x) - r.o.x) * r.inv_x;
-                    const float tz0 = (plane_at(T.origin_z, cz, T.spacing_z) - r.o.z) * r.inv_z;
-                    const float tz1 = (plane_at(T.origin_z, cz1, T.spacing_z) - r.o.z) * r.inv_z;
-                    lo = f_max(f_max(f_min(tx0, tx1), f_min(tz0, tz1)), r.tmin);
-                    hi = f_min(f_min(f_max(tx0, tx1), f_max(tz0, tz1)), r.tmax);
+                    march_leaf_interval(T, r, cx, cz, lo, hi);
                 }
             }
             if (tie) {
@@ -440,6 +445,7 @@ F3D_HD void march_drain(const TerrainDev &T, const RayCtx &r, bool any_hit, Marc
                     res.hit = true;  // first hit in ray order is final (see the header)
                     res.t = t;
                     res.n = leaf_normal(T, leaf, along(r.o, t, r.d), cx, cz);
+                    hit_cell = cx | (cz << 16);
                 }
             }
         }
@@ -447,6 +453,12 @@ F3D_HD void march_drain(const TerrainDev &T, const RayCtx &r, bool any_hit, Marc
     queued = 0u;
     // (once, here: a second boolean carried through the loop above costs a lane-mask merge per level of nesting -- 1.4 %)
     m.marching = m.marching & !res.hit;
+}
+template <class Ctx>
+F3D_HD void march_drain(const TerrainDev &T, const RayCtx &r, bool any_hit, MarchState &m, uint32_t &queued,
+                        TraceHit &res, Ctx &ctx) {
+    uint32_t hit_cell;  // (nobody reads it: the stores go)
+    march_drain(T, r, any_hit, m, queued, res, ctx, hit_cell);
 }
 
 // ---- the last few rays of a wave, shared by all its lanes -----------------------------------------
@@ -626,6 +638,82 @@ F3D_HD bool march_shared(const TerrainDev &T, const RayCtx &own_ray, MarchState 
     return ctx.verdict_get(ctx.lane());
 }
 
+// ---- the same for CLOSEST-hit rays (round 6; the PBR path tracer's camera and bounce rays, Ctx::kShareClosest) -----------------
+// A closest-hit ray wants the FIRST leaf in ray order that hits (see the header).  Cut into slices, each slice's drain ends with
+// the first hit of its own stretch; the ray's answer is the hit that comes first in ray order among them.  "First in ray order"
+// needs no parameter: consecutive cells along a ray differ by one step in x or in z (or both, through a corner) in the ray's
+// direction, so the PROGRESS p = (x_forward ? cx : 8191 - cx) + (z_forward ? cz : 8191 - cz) grows strictly from one leaf of the
+// march to the next.  A slice that hits posts key = p << 13 | cx on its owner's word of the board (an LDS atomic max of the
+// complement: the smallest key wins; p and cx name the cell, cz follows from them); a slice standing in a node whose smallest
+// progress lies beyond the posted one stops.  When all slices are done the owner solves the winning leaf ITSELF -- the interval by
+// march_step's expressions on its own ray (what the one-word FIFO's drain does), the same leaf_solve / leaf_normal -- so t and the
+// normal are the unshared march's bit for bit (the cut's node is visited by both neighbours: the same leaf gives the same key).
+constexpr uint32_t kNoNearest = 0xFFFFFFFFu;
+F3D_HD uint32_t march_progress_key(const RayCtx &r, uint32_t cx, uint32_t cz) {
+    const uint32_t px = !(r.d.x < 0.0f) ? cx : 8191u - cx, pz = !(r.d.z < 0.0f) ? cz : 8191u - cz;
+    return ((px + pz) << 13) | cx;
+}
+template <bool CURVED, class Ctx>
+F3D_HD TraceHit march_shared_closest(const TerrainDev &T, const RayCtx &own_ray, MarchState m, TraceHit own, Ctx &ctx, float t_stop = 3.0e38f) {
+    MarchSlice s;
+    s.r = own_ray;
+    s.t_stop = t_stop;
+    s.owner = ctx.lane();
+    {
+        float lo;
+        march_root_interval(T, own_ray, lo, s.t_end);
+    }
+    ctx.nearest_post();  // (a lane that has its hit already is not marching: nobody walks a slice for it)
+    uint32_t queued = 0u;
+    TraceHit res;
+    res.n = V3{0.0f, 0.0f, 0.0f};
+    for (uint32_t round = 0u;; round++) {
+        ctx.template deal<CURVED>(T, s, m);
+        if (m.marching) march_fetch(T, m, ctx);
+        march_first_step<CURVED, true>(T, s.r, m, queued, ctx, false, s.t_stop);
+        res.hit = false;
+        res.t = s.r.tmax;
+        uint32_t cell = 0u;  // of this round's hit (a slice stops at its first: later drains of the round post the same key again)
+        bool again = false;
+        for (;;) {
+            if (m.marching) march_step<CURVED, true, kVerifyInLoop>(T, s.r, m, queued, ctx, false, s.t_stop);
+#pragma unroll 1
+            for (uint32_t extra = 1u; extra < kStepsPerVoteShared && m.marching && queued + 2u <= kLeafFifoRows; extra++)
+                march_step<CURVED, true, kVerifyInLoop>(T, s.r, m, queued, ctx, false, s.t_stop);
+            again = round + 1u < kShareRounds && ctx.share_now(m.marching);
+            if (again || ctx.flush_now(queued, m.marching)) {
+                march_drain(T, s.r, false, m, queued, res, ctx, cell);
+                if (res.hit) ctx.nearest_set(s.owner, march_progress_key(s.r, cell & 0xFFFFu, cell >> 16));
+                const uint32_t best = ctx.nearest_get(s.owner);
+                if (m.marching && best != kNoNearest) {  // is everything this slice can still find behind the posted hit?
+                    const uint32_t x0 = m.nx << m.level, z0 = m.nz << m.level;
+                    uint32_t x1 = (m.nx + 1u) << m.level, z1 = (m.nz + 1u) << m.level;
+                    x1 = (x1 < T.cell_w ? x1 : T.cell_w) - 1u;
+                    z1 = (z1 < T.cell_h ? z1 : T.cell_h) - 1u;
+                    const uint32_t p_min = (!(s.r.d.x < 0.0f) ? x0 : 8191u - x1) + (!(s.r.d.z < 0.0f) ? z0 : 8191u - z1);
+                    if ((best >> 13) < p_min) m.marching = false;
+                }
+            }
+            if (again || !ctx.any(m.marching || queued != 0u)) break;
+        }
+        if (!again) break;
+    }
+    const uint32_t best = ctx.nearest_get(ctx.lane());
+    if (best != kNoNearest) {
+        const uint32_t cx = best & 8191u, p = best >> 13;
+        const uint32_t pz = p - (!(own_ray.d.x < 0.0f) ? cx : 8191u - cx), cz = !(own_ray.d.z < 0.0f) ? pz : 8191u - pz;
+        float lo, hi, t;
+        march_leaf_interval(T, own_ray, cx, cz, lo, hi);
+        const LeafRec leaf = T.leaves[tiled_index(cx, cz, T.tiles_x[0])];
+        if (leaf_solve(T, own_ray, leaf, cx, cz, lo, hi, false, t) && t < own.t) {
+            own.hit = true;
+            own.t = t;
+            own.n = leaf_normal(T, leaf, along(own_ray.o, t, own_ray.d), cx, cz);
+        }
+    }
+    return own;
+}
+
 // A camera ray whose pixel holds a certificate (f3d_cone.h primary_start): every ray of the pixel is above every cell it
 // passes up to t_clear, so the nodes before it are exactly those the march would reject without solving a leaf.  The
 // lane starts in the node of `level` that contains the ray at t_clear -- located from the position and validated by
@@ -691,11 +779,15 @@ F3D_HD TraceHit march_terrain_from(const TerrainDev &T, const RayCtx &r, bool an
 #else
         if (!CURVED && any_hit) deal = ctx.share_now(m.marching);  // the last few IBL rays: share them (needs empty FIFOs)
 #endif
+        if (Ctx::kShareClosest && !CURVED && !any_hit) deal = ctx.share_now(m.marching);  // ... and of closest-hit rays (march_shared_closest)
 #endif
         // (Balancing the queued leaf solves of a wave over its lanes -- ceil(sum / lanes) rounds instead of
         // max(queued), the owner's ray fetched by ds_bpermute -- was built and measured: bit-identical, 0.96x.)
         if (deal || ctx.flush_now(queued, m.marching)) march_drain(T, r, any_hit, m, queued, res, ctx);
         if (deal || !ctx.any(m.marching || queued != 0u)) break;
+    }
+    if constexpr (Ctx::kShareClosest) {
+        if (deal && !any_hit) return march_shared_closest<CURVED>(T, r, m, res, ctx, t_stop);
     }
     if (deal) {
         res.hit = march_shared<CURVED>(T, r, m, res.hit, ctx, t_stop);

@@ -338,13 +338,17 @@ F3D_HD bool hair_segment(V3 o, V3 d, float tmin, float tmax, V3 p0, V3 p1, float
 // pt_intersect.wgsl main, :431-558 (+ the terrain primitive)
 // camera_pixel: the pixel whose CAMERA ray this is (its march may start where the pixel's certificate ends); kNoPixel: any other ray
 constexpr uint32_t kNoPixel = 0xFFFFFFFFu;
+// have: the lane has a ray.  trace_frames calls with EVERY lane of the wave in a scene whose primitives are the heightfield and
+// spheres: a lane without a ray goes through the heightfield's march with an empty one (tmax < tmin: it never marches) and is,
+// inside, a lane whose ray has ended -- what the sharing of closest-hit rays deals the last rays of a wave to (f3d_march.h
+// march_shared_closest).
 template <class Wave>
-F3D_HD bool closest(const SceneDev &S, V3 o, V3 d, float tmin, SurfaceHitWf &H, Wave &wave, uint32_t camera_pixel = kNoPixel) {
+F3D_HD bool closest(const SceneDev &S, V3 o, V3 d, float tmin, SurfaceHitWf &H, Wave &wave, uint32_t camera_pixel = kNoPixel, bool have = true) {
     const float tmax = 1e30f;
     float t_best = 1e30f;
     V3 n = V3{0.0f, 1.0f, 0.0f};
     uint32_t mat = 0u;
-    for (uint32_t i = 0u; i < S.sphere_count; i++) {
+    for (uint32_t i = 0u; have && i < S.sphere_count; i++) {
         const SphereDev s = S.spheres[i];
         const V3 oc = o - s.c;
         const float b = dot(oc, d);
@@ -402,12 +406,12 @@ F3D_HD bool closest(const SceneDev &S, V3 o, V3 d, float tmin, SurfaceHitWf &H, 
         }
     }
     if (Wave::kTerrain && S.has_terrain != 0u) {  // terrain_trace(ray with tmax = the closest hit so far), curvature off
-        const RayCtx r = make_ray(S.terrain, o, tmin, d, t_best, false);
+        const RayCtx r = make_ray(S.terrain, o, have ? tmin : 1.0f, d, have ? t_best : 0.0f, false);
         // A camera ray of a pixel with a certificate (round 5: the terrain tracer's, for the same camera -- f3d_cone.h
         // primary_start) starts where the certificate ends: every node before that is one the march would step over without
         // solving a leaf, so the hit is the same; 27 -> 14.5 steps per camera ray on the headline frame.
         MarchState m = march_begin(S.terrain, r, true);
-        if (camera_pixel != kNoPixel && S.primary_start != nullptr) {
+        if (have && camera_pixel != kNoPixel && S.primary_start != nullptr) {
             const uint2 st = S.primary_start[camera_pixel];
             if (f_from_bits(st.x) > 0.0f) m = march_begin_at(S.terrain, r, f_from_bits(st.x), st.y);
         }
@@ -419,7 +423,7 @@ F3D_HD bool closest(const SceneDev &S, V3 o, V3 d, float tmin, SurfaceHitWf &H, 
             hair = false;
         }
     }
-    if (!(t_best < 1e20f)) return false;
+    if (!have || !(t_best < 1e20f)) return false;
     H.p = o + d * t_best;
     H.t = t_best;
     H.n = n;
@@ -1023,12 +1027,22 @@ F3D_HD uint32_t trace_frames(const SceneDev &S, uint32_t first, uint32_t count, 
         lane.set_acc(V3{0.0f, 0.0f, 0.0f});
         lane.set_word(((word & ~Lane::kDepthMask) + (1u << Lane::kFrameShift)) | Lane::kFresh);
     };
+    // a scene whose primitives are the heightfield and spheres: every lane of the wave goes through the marches (the LITE kernel is
+    // only ever launched for such a scene: no run-time test, and the other form is not in it)
+    const bool all_lanes = Wave::kLite || (Wave::kTerrain && S.has_terrain != 0u && S.blas_count == 0u && S.inst_count == 0u &&
+                                           S.area_count == 0u && S.hair_count == 0u);
     for (;;) {
         for (;;) {  // cheap phase
             uint32_t word = lane.word();
-            if (active(word)) {
-                V3 o, d;
-                if (word & Lane::kFresh) {
+            const bool act = active(word);
+#if !defined(F3D_WF_CLOSEST_DIVERGENT)  // A/B: the round-5 form -- only the lanes with a ray enter closest()
+            if (act || all_lanes) {
+#else
+            if (act) {
+#endif
+                V3 o{0.0f, 0.0f, 0.0f}, d{0.0f, 1.0f, 0.0f};
+                if (!act) {
+                } else if (word & Lane::kFresh) {
                     const uint32_t frame = frame_of(word);
                     const uint32_t seed_hi = splitmix32(S.seed_hi ^ frame), seed_lo = splitmix32(S.seed_lo ^ (frame * 0x00009E3Du));
                     PathState P;
@@ -1044,9 +1058,11 @@ F3D_HD uint32_t trace_frames(const SceneDev &S, uint32_t first, uint32_t count, 
                     d = lane.dir();
                 }
                 const uint32_t depth = word & Lane::kDepthMask;
-                word += 1u << Lane::kQueryShift;
+                if (act) word += 1u << Lane::kQueryShift;
                 SurfaceHitWf H;
-                if (closest(S, o, d, depth == 0u ? 1e-4f : 1e-3f, H, wave, depth == 0u ? wave.pixel() : kNoPixel)) {
+                const bool hit = closest(S, o, d, depth == 0u ? 1e-4f : 1e-3f, H, wave, depth == 0u ? wave.pixel() : kNoPixel, act);
+                if (!act) {
+                } else if (hit) {
                     // the hit waits for the expensive phase in the rows, not in registers
                     lane.set_a(H.p);
                     lane.set_b(H.n);
@@ -1088,7 +1104,7 @@ F3D_HD uint32_t trace_frames(const SceneDev &S, uint32_t first, uint32_t count, 
 #if !defined(F3D_WF_SHADOWS_DIVERGENT)  // A/B: the round-5 form -- only the lanes with a vertex enter the shadow rays' march
         // (a scene whose occluders are the heightfield and spheres: every lane of the wave goes through the shadow rays' march)
         // (the LITE kernel is only ever launched for such a scene: no run-time test, and the other form is not in it)
-        if (Wave::kLite || (Wave::kTerrain && S.has_terrain != 0u && S.blas_count == 0u && S.inst_count == 0u && S.area_count == 0u && S.hair_count == 0u)) {
+        if (all_lanes) {
             vertex_shadows<true>(S, nee, lane, wave);
         } else
 #endif

@@ -70,6 +70,10 @@ struct ArrayPending {
     void verdict_post(bool) const {}
     void verdict_set(uint32_t) const {}
     bool verdict_get(uint32_t) const { return false; }
+    static constexpr bool kShareClosest = false;
+    void nearest_post() const {}
+    void nearest_set(uint32_t, uint32_t) const {}
+    uint32_t nearest_get(uint32_t) const { return kNoNearest; }
     // deferred leaf FIFO of the march: a single lane drains only when its FIFO is full or its march
     // has ended, i.e. as LATE as possible -- the opposite extreme of the device's wave vote, so the
     // order-independence the deferral relies on is exercised by every CPU parity test
@@ -235,6 +239,13 @@ struct WavePending : ArrayPending {
     void verdict_post(bool hit) const { wave->board[me] = hit ? 1u : 0u; }
     void verdict_set(uint32_t owner) const { wave->board[owner & 63u] = 1u; }
     bool verdict_get(uint32_t owner) const { return wave->board[owner & 63u] != 0u; }
+    // closest-hit rays shared as well (f3d_march.h march_shared_closest): the board holds the smallest key posted (0xFFFFFFFF: none)
+    static constexpr bool kShareClosest = true;
+    void nearest_post() const { wave->board[me] = kNoNearest; }
+    void nearest_set(uint32_t owner, uint32_t key) const {
+        if (key < wave->board[owner & 63u]) wave->board[owner & 63u] = key;
+    }
+    uint32_t nearest_get(uint32_t owner) const { return wave->board[owner & 63u]; }
 };
 
 struct HostTables {

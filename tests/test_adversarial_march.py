@@ -82,9 +82,10 @@ def test_ray_sharing_on_the_host_wave_matches_the_oracle(share):
         got = emul.terrain_trace_batch_wave(heights, rays, any_hit=mode, share_below=share, **base)
         assert np.array_equal(got["hit"], want_any["hit"]), (mode, share)
         assert got["deals"] > 0  # the dealing code really ran
-    got = emul.terrain_trace_batch_wave(heights, rays, any_hit=3, share_below=share, **base)
-    assert np.array_equal(got["hit"], want_closest["hit"]) and np.array_equal(got["t"], want_closest["t"])
-    assert np.array_equal(got["normal"], want_closest["normal"]) and got["deals"] == 0  # closest-hit rays are never dealt
+    for mode in (3, 7):  # closest-hit rays are dealt too (march_shared_closest; the host wave's context asks for it)
+        got = emul.terrain_trace_batch_wave(heights, rays, any_hit=mode, share_below=share, **base)
+        assert np.array_equal(got["hit"], want_closest["hit"]) and np.array_equal(got["t"], want_closest["t"]), (mode, share)
+        assert np.array_equal(got["normal"], want_closest["normal"]) and got["deals"] > 0, (mode, share)
 
 
 @pytest.mark.parametrize("name", ["diagplane", "ragged", "terrace", "rand_sym_int"])
@@ -100,4 +101,9 @@ def test_lattice_aligned_rays_on_the_host_wave(name):
         for mode in (2, 6):
             got = emul.terrain_trace_batch_wave(dem, rays, any_hit=mode, share_below=share, **base)
             bad = np.nonzero(got["hit"] != want["hit"])[0]
+            assert bad.size == 0, (name, spacing, share, mode, bad.size, rays[bad[:2]].tolist())
+        want = oracle.terrain_trace_batch(dem, rays, any_hit=False, **base)
+        for mode in (3, 7):  # closest-hit rays cut into slices: the first hit in ray order, its parameter and normal
+            got = emul.terrain_trace_batch_wave(dem, rays, any_hit=mode, share_below=share, **base)
+            bad = np.nonzero((got["hit"] != want["hit"]) | (got["t"] != want["t"]) | (got["normal"] != want["normal"]).any(axis=1))[0]
             assert bad.size == 0, (name, spacing, share, mode, bad.size, rays[bad[:2]].tolist())
