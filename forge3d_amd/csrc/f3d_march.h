@@ -745,16 +745,17 @@ F3D_HD MarchState march_begin_at(const TerrainDev &T, const RayCtx &r, float t_c
 // the ray is in (secondary rays) instead of at the root (camera rays entering from outside).
 // Ctx provides: note(), band_entry(), the FIFO storage fifo_put/fifo_get, the wave votes
 // flush_now(queued, marching) / any(pred), and share_now / deal / verdict_* (ray sharing).
+// hit_cell (closest-hit callers that want it, no ray sharing): the cell (cx | cz << 16) of the hit.
 template <bool CURVED, bool STOP = CURVED, class Ctx>
 F3D_HD TraceHit march_terrain_from(const TerrainDev &T, const RayCtx &r, bool any_hit, MarchState m, Ctx &ctx,
-                                   float t_stop = 3.0e38f) {
+                                   float t_stop = 3.0e38f, uint32_t *hit_cell = nullptr) {
     TraceHit res;
     res.hit = false;
     res.t = r.tmax;
     res.n = V3{0.0f, 0.0f, 0.0f};
     ctx.note(2 | (any_hit ? 1 : 0) | (CURVED ? 4 : 0));  // statistics hook: a new ray starts
     ctx.feature(r.d.y);
-    uint32_t queued = 0u;
+    uint32_t queued = 0u, cell = 0u;
     bool deal = false;
     if (m.marching) march_fetch(T, m, ctx);
     march_first_step<CURVED, STOP>(T, r, m, queued, ctx, any_hit, t_stop);
@@ -783,9 +784,10 @@ F3D_HD TraceHit march_terrain_from(const TerrainDev &T, const RayCtx &r, bool an
 #endif
         // (Balancing the queued leaf solves of a wave over its lanes -- ceil(sum / lanes) rounds instead of
         // max(queued), the owner's ray fetched by ds_bpermute -- was built and measured: bit-identical, 0.96x.)
-        if (deal || ctx.flush_now(queued, m.marching)) march_drain(T, r, any_hit, m, queued, res, ctx);
+        if (deal || ctx.flush_now(queued, m.marching)) march_drain(T, r, any_hit, m, queued, res, ctx, cell);
         if (deal || !ctx.any(m.marching || queued != 0u)) break;
     }
+    if (hit_cell) *hit_cell = cell;
     if constexpr (Ctx::kShareClosest) {
         if (deal && !any_hit) return march_shared_closest<CURVED>(T, r, m, res, ctx, t_stop);
     }

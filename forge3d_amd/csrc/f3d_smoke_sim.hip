@@ -249,6 +249,98 @@ __global__ __launch_bounds__(kPhaseBlock) void k_phase(const StepArgs A, const P
     const uint32_t plane = A.G.nx * A.G.ny, z = v / plane, y = (v - z * plane) / A.G.nx, x = v - z * plane - y * A.G.nx;
     phase_voxel<PH>(A, A.G, C, v, x, y, z);
 }
+// ---- K Jacobi sweeps a launch, the tile and its halo in LDS (round 6) ------------------------------------------------------
+// A sweep of the pressure solve (sim_jacobi) is 3 MB in, 3 MB out and ~5 us of launch for BASELINE configs[4]'s grid, thirty times
+// a step: 45 % of the step, issuing 12 % of its vector slots.  Here a workgroup owns a tile of kJacTX x kJacTY x kJacTZ voxels,
+// loads it with a halo of K voxels (y, z; x too when a row does not fit one tile -- otherwise the row's two border voxels) into
+// LDS and runs K sweeps there, each over the voxels whose K-sweep history the halo still covers (the region shrinks by one ring a
+// sweep), the divergence read from L2 each time; the tile's voxels go out after the K-th.  Per voxel and sweep the expression is
+// sim_jacobi's -- the six neighbours added in its order, minus the divergence, divided by 6; 0 on the border -- on the values the
+// one-sweep launches would have read: bit-identical (tests/test_smoke_sim.py runs both).  K = 4: a 98 x 16 x 12 region twice =
+// 150 KB of the CU's 160 KB of LDS, one workgroup of 1 024 lanes a CU, 256 tiles for the 96 x 64 x 128 grid; 20 + 10 sweeps are
+// 5 + 3 launches instead of 30.  Measured slower than the one-sweep launches (see where it is launched): opt-in, F3D_SMOKE_JACOBI=tiled.
+constexpr uint32_t kJacTX = 96u, kJacTY = 8u, kJacTZ = 4u, kJacK = 4u, kJacLanesX = 128u, kJacRows = 8u;
+constexpr uint32_t kJacRegion = (kJacTX + 2u * kJacK) * (kJacTY + 2u * kJacK) * (kJacTZ + 2u * kJacK);  // 104 x 16 x 12
+static_assert(kJacTX + 2u * kJacK <= kJacLanesX, "a lane per voxel of a region row");
+__global__ __launch_bounds__(kJacLanesX * kJacRows) void k_jacobi_tiled(const SimGrid G, const float *cur, const float *div, float *next, uint32_t sweeps,
+                                                                          uint32_t tiles_x, uint32_t tiles_y) {
+    __shared__ float buf[2][kJacRegion];
+    const uint32_t tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, tz = blockIdx.x / (tiles_x * tiles_y);
+    const uint32_t hx = tiles_x == 1u ? 1u : sweeps, h = sweeps;  // halo in x; in y and z
+    const uint32_t ex = kJacTX + 2u * hx, ey = kJacTY + 2u * h, ez = kJacTZ + 2u * h;
+    // region voxel (rx, ry, rz) is grid voxel (x0 + rx, y0 + ry, z0 + rz) (unsigned wrap-around below 0: outside the grid like beyond it)
+    const uint32_t x0 = tx * kJacTX - hx, y0 = ty * kJacTY - h, z0 = tz * kJacTZ - h;
+    // (a wave lies in one row: the row's number and everything derived from it are scalars)
+    const uint32_t rx = threadIdx.x & (kJacLanesX - 1u), row0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kJacLanesX));
+    const uint32_t gx = x0 + rx;
+    const bool col = rx < ex;
+    // sim_interior(G, x, y, z, 1) as one unsigned comparison an axis: x - 1 < nx - 2 (a coordinate "below 0" has wrapped around)
+    const uint32_t inx = G.nx > 2u ? G.nx - 2u : 0u, iny = G.ny > 2u ? G.ny - 2u : 0u, inz = G.nz > 2u ? G.nz - 2u : 0u;
+    // Everything that comes from memory is asked for at once, before the first sweep: the region's pressures (a lane takes the
+    // voxel rx of every kJacRows-th row) and the divergences of the voxels it will update -- the same voxels in every sweep (the
+    // inner rows of the region, numbered once; a sweep skips the rows its ring has given up), so they stay in registers.  (A first
+    // form fetched the divergence inside the sweeps: a trip to L2 per row and sweep, 28 us a launch.)
+    constexpr uint32_t kLoads = ((kJacTY + 2u * kJacK) * (kJacTZ + 2u * kJacK) + kJacRows - 1u) / kJacRows;            // 24
+    constexpr uint32_t kInner = ((kJacTY + 2u * kJacK - 2u) * (kJacTZ + 2u * kJacK - 2u) + kJacRows - 1u) / kJacRows;  // 18
+    float p[kLoads], d[kInner];
+    const uint32_t iy = ey - 2u, iz = ez - 2u;  // the inner rows: ry in [1, ey - 2], rz in [1, ez - 2]
+    // (row -> (y, z) without a division: rows advance by kJacRows <= the rows of a slab, so y wraps at most once a step)
+    static_assert(kJacRows <= kJacTY, "a step of kJacRows rows crosses at most one slab");
+    {
+        uint32_t ry = row0, rz = 0u;
+#pragma unroll
+        for (uint32_t j = 0u; j < kLoads; j++) {
+            const uint32_t gy = y0 + ry, gz = z0 + rz;
+            p[j] = (col && rz < ez && gx < G.nx && gy < G.ny && gz < G.nz) ? cur[sim_index(G, gx, gy, gz)] : 0.0f;
+            ry += kJacRows;
+            if (ry >= ey) ry -= ey, rz++;
+        }
+    }
+    {
+        uint32_t ry = 1u + row0, rz = 1u;
+#pragma unroll
+        for (uint32_t j = 0u; j < kInner; j++) {
+            const uint32_t gy = y0 + ry, gz = z0 + rz;
+            d[j] = (col && rz <= iz && gx - 1u < inx && gy - 1u < iny && gz - 1u < inz) ? div[sim_index(G, gx, gy, gz)] : 0.0f;
+            ry += kJacRows;
+            if (ry > iy) ry -= iy, rz++;
+        }
+    }
+#pragma unroll
+    for (uint32_t j = 0u; j < kLoads; j++) {
+        const uint32_t row = row0 + j * kJacRows;
+        if (col && row < ey * ez) buf[0][row * ex + rx] = p[j];
+    }
+    __syncthreads();
+    for (uint32_t s = 1u; s <= sweeps; s++) {
+        const float *in = buf[(s - 1u) & 1u];
+        float *out = buf[s & 1u];
+        // rows whose y and z are at least s from the region's faces; in x every voxel but the region's first and last (with a
+        // one-voxel x halo those are outside the grid or on its border: 0 either way; with a K-voxel one they are never read again
+        // by a voxel that is still owed a right value)
+        uint32_t ry = 1u + row0, rz = 1u;
+#pragma unroll
+        for (uint32_t j = 0u; j < kInner; j++, ry += kJacRows, ry > iy ? (ry -= iy, rz++) : 0u) {
+            const uint32_t gy = y0 + ry, gz = z0 + rz;
+            if (rz <= iz && ry >= s && ry + s < ey && rz >= s && rz + s < ez && col && rx >= 1u && rx + 1u < ex) {
+                const uint32_t i = (rz * ey + ry) * ex + rx;
+                float v = 0.0f;
+                if (gx - 1u < inx && gy - 1u < iny && gz - 1u < inz) {
+                    const float sum = in[i - 1u] + in[i + 1u] + in[i - ex] + in[i + ex] + in[i - ex * ey] + in[i + ex * ey];
+                    v = (sum - d[j]) / 6.0f;
+                }
+                out[i] = v;
+            }
+        }
+        __syncthreads();
+    }
+    const float *res = buf[sweeps & 1u];
+    for (uint32_t r = row0; r < kJacTY * kJacTZ; r += kJacRows) {  // the tile goes out
+        const uint32_t ry = h + r % kJacTY, rz = h + r / kJacTY, gy = y0 + ry, gz = z0 + rz;
+        if (rx >= hx && rx < hx + kJacTX && gx < G.nx && gy < G.ny && gz < G.nz) next[sim_index(G, gx, gy, gz)] = res[(rz * ey + ry) * ex + rx];
+    }
+}
+
 __global__ __launch_bounds__(64) void k_phase_sum_rows(const StepArgs A, const SumKinds K, const float *density) {
     const uint32_t r = blockIdx.x * 64u + threadIdx.x;
     if (r < A.G.ny * A.G.nz) sums_row(A, A.G, density, K, r);
@@ -690,6 +782,12 @@ extern "C" int f3d_smoke_step(f3d_smoke_state *st, const f3d_smoke_step_settings
                 // cached loads a voxel instead of 2 x 8) -- bit-identical, 15 launches fewer a step, and SLOWER: 0.411-0.416 ms
                 // against 0.386-0.397 (the doubled sweep costs more than the 5-us launch it saves).  F3D_SMOKE_DOUBLE_SWEEPS=1 runs it.
                 const bool single_sweeps = getenv("F3D_SMOKE_DOUBLE_SWEEPS") == nullptr;
+                // MEASURED, NOT ADOPTED (round 6): K sweeps a launch on LDS tiles (k_jacobi_tiled) -- bit-identical, 8 launches instead of
+                // 30 a step, and SLOWER: 0.45 ms a step against 0.33 (a launch of four sweeps takes 43 us, of two 22 us: ~80 vector
+                // instructions per voxel and sweep once the halo's redundancy, the row predicates and the IEEE division are paid by one
+                // workgroup a CU, against 5 us for a sweep that the whole chip shares).  F3D_SMOKE_JACOBI=tiled runs it.
+                const char *jacobi_form = getenv("F3D_SMOKE_JACOBI");
+                const bool jacobi_tiled = single_sweeps && jacobi_form && strcmp(jacobi_form, "tiled") == 0;
                 const size_t slab_lds = ((size_t)s.G.nx * (s.G.ny + 1u) + 4u * (size_t)s.G.ny) * sizeof(float);
                 const bool slab_sums = slab_lds <= 60u * 1024u && 4u * (size_t)s.G.nz * sizeof(float) <= 60u * 1024u &&
                                        getenv("F3D_SMOKE_ROW_SUMS") == nullptr;  // (else: a lane a row from global memory)
@@ -707,6 +805,17 @@ extern "C" int f3d_smoke_step(f3d_smoke_state *st, const f3d_smoke_step_settings
                     C.cur = K.F.pressure;
                     C.next = K.pres_b;
                     uint32_t it = 0;
+                    if (jacobi_tiled) {  // K sweeps a launch in LDS (k_jacobi_tiled)
+                        const uint32_t tiles_x = (s.G.nx + kJacTX - 1u) / kJacTX, tiles_y = (s.G.ny + kJacTY - 1u) / kJacTY,
+                                       tiles_z = (s.G.nz + kJacTZ - 1u) / kJacTZ;
+                        while (it < iterations) {
+                            const uint32_t k = std::min(kJacK, iterations - it);
+                            hipLaunchKernelGGL(k_jacobi_tiled, dim3(tiles_x * tiles_y * tiles_z), dim3(kJacLanesX * kJacRows), 0, call_stream(), K.G,
+                                               (const float *)C.cur, (const float *)K.div, C.next, k, tiles_x, tiles_y);
+                            std::swap(C.cur, C.next);
+                            it += k;
+                        }
+                    }
                     for (; it + 2u <= iterations && !single_sweeps; it += 2u) {  // two sweeps a launch (sim_jacobi_twice)
                         hipLaunchKernelGGL(k_phase<kPhJacobiTwice>, grid, block, 0, call_stream(), K, C);
                         std::swap(C.cur, C.next);

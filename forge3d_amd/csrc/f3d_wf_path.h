@@ -1029,6 +1029,9 @@ F3D_HD uint32_t trace_frames(const SceneDev &S, uint32_t first, uint32_t count, 
     };
     // a scene whose primitives are the heightfield and spheres: every lane of the wave goes through the marches (the LITE kernel is
     // only ever launched for such a scene: no run-time test, and the other form is not in it)
+#if defined(F3D_WF_STATS)
+    uint32_t stat = 0u;
+#endif
     const bool all_lanes = Wave::kLite || (Wave::kTerrain && S.has_terrain != 0u && S.blas_count == 0u && S.inst_count == 0u &&
                                            S.area_count == 0u && S.hair_count == 0u);
     for (;;) {
@@ -1087,6 +1090,12 @@ F3D_HD uint32_t trace_frames(const SceneDev &S, uint32_t first, uint32_t count, 
             continue;
         }
         // expensive phase: the waiting hits are shaded; then the vertices' shadow rays; then the paths continue or end
+#if defined(F3D_WF_STATS)  // statistics build (the image is right, the vertex count is not): how full is the expensive phase?
+        {
+            const uint32_t np = wave.count(pending);
+            stat += F3D_WF_STATS == 1 ? 1u : F3D_WF_STATS == 2 ? np : F3D_WF_STATS == 3 ? (np <= 32u ? 1u : 0u) : (np <= 16u ? 1u : 0u);
+        }
+#endif
         NeeRays nee;
         bool go_on = false;
         if (pending) {
@@ -1114,6 +1123,9 @@ F3D_HD uint32_t trace_frames(const SceneDev &S, uint32_t first, uint32_t count, 
             else finish_frame();
         }
     }
+#if defined(F3D_WF_STATS)
+    return lane_now() == 0u ? stat : 0u;
+#endif
     return lane.word() >> Lane::kQueryShift;
 }
 

@@ -73,6 +73,9 @@ def _cases():
         "six_emitters": (dict(dims=(22, 12, 16)), [dict(center=(4.0 + 2.5 * k, 3.0 + 0.5 * k, 5.0 + 1.5 * k), radius=1.5 + 0.2 * k, density_rate=2.0 + k,
                                                       temperature_rate=1.0 + 0.5 * k, velocity=(0.1 * k, 1.0, -0.05 * k)) for k in range(6)],
                          dict(dt=0.15, pressure_iterations=6), 3),
+        # a row longer than a tile of the K-sweeps-a-launch pressure solve (csrc/f3d_smoke_sim.hip k_jacobi_tiled: 96 voxels): tiles
+        # with a K-voxel halo in x too, ragged in every axis; 7 sweeps = a launch of 4 and one of 3
+        "wide": (dict(dims=(101, 11, 15)), plume[:1], dict(dt=0.2, pressure_iterations=7), 5),
         "bare": (dict(dims=(12, 10, 14)), plume[:1], dict(dt=0.3, diffusion=0.0, vorticity=0.0, velocity_damping=0.0, mass_conservation=False,
                                                           terrain_collision=False, pressure_iterations=1, turbulence_strength=0.3, wind=(0.0, 0.0, 0.0)), 4),
     }
@@ -113,7 +116,7 @@ def test_python_surface_of_the_solver():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["fused", "fused2", "fused-row-sums", "persistent", "launches"])
+@pytest.mark.parametrize("form", ["fused", "fused-single-sweeps", "fused2", "fused-row-sums", "persistent", "launches"])
 @pytest.mark.parametrize("case", sorted(_cases()))
 def test_hip_solver_equals_the_oracle(case, form, monkeypatch):
     """All three drivers of the device solver (csrc/f3d_smoke_sim.hip): the step's phases as one launch each (the default),
@@ -123,6 +126,8 @@ def test_hip_solver_equals_the_oracle(case, form, monkeypatch):
     monkeypatch.setenv("F3D_SMOKE_SOLVER", "fused" if form.startswith("fused") else form)
     if form == "fused-row-sums":  # the grid sums a lane a row from global memory (the default stages each slab in LDS)
         monkeypatch.setenv("F3D_SMOKE_ROW_SUMS", "1")
+    if form == "fused-single-sweeps":  # a Jacobi sweep a launch (round 5; the default runs K sweeps a launch in LDS)
+        monkeypatch.setenv("F3D_SMOKE_JACOBI", "single")
     if form == "fused2":  # two Jacobi sweeps a launch (measured slower, opt-in)
         monkeypatch.setenv("F3D_SMOKE_DOUBLE_SWEEPS", "1")
     geo, emitters, settings, steps = _cases()[case]
