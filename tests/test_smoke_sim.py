@@ -116,7 +116,7 @@ def test_python_surface_of_the_solver():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["fused", "fused-single-sweeps", "fused2", "fused-row-sums", "persistent", "launches"])
+@pytest.mark.parametrize("form", ["fused", "fused-tiled", "fused2", "fused-row-sums", "persistent", "launches"])
 @pytest.mark.parametrize("case", sorted(_cases()))
 def test_hip_solver_equals_the_oracle(case, form, monkeypatch):
     """All three drivers of the device solver (csrc/f3d_smoke_sim.hip): the step's phases as one launch each (the default),
@@ -126,8 +126,8 @@ def test_hip_solver_equals_the_oracle(case, form, monkeypatch):
     monkeypatch.setenv("F3D_SMOKE_SOLVER", "fused" if form.startswith("fused") else form)
     if form == "fused-row-sums":  # the grid sums a lane a row from global memory (the default stages each slab in LDS)
         monkeypatch.setenv("F3D_SMOKE_ROW_SUMS", "1")
-    if form == "fused-single-sweeps":  # a Jacobi sweep a launch (round 5; the default runs K sweeps a launch in LDS)
-        monkeypatch.setenv("F3D_SMOKE_JACOBI", "single")
+    if form == "fused-tiled":  # K Jacobi sweeps a launch on LDS tiles (measured slower, opt-in)
+        monkeypatch.setenv("F3D_SMOKE_JACOBI", "tiled")
     if form == "fused2":  # two Jacobi sweeps a launch (measured slower, opt-in)
         monkeypatch.setenv("F3D_SMOKE_DOUBLE_SWEEPS", "1")
     geo, emitters, settings, steps = _cases()[case]
