@@ -53,6 +53,9 @@ struct WfParams {
 // at 80 registers and 284 bytes of spills beat four at 128 and 92 (C3 GI, 1080p x 32 paths: 4 / 5 / 6 / 7 / 8 waves ->
 // 23.6 / 22.9 / 22.1 / 21.8-22.7 / 22.2-22.4 ms; its LDS block is the compact one of f3d_lds.h so that the waves fit).  Without
 // the primitive the BLAS walk's spills decide: 4 / 5 / 6 -> 137.6 / 178.6 / 203.8 ms at the adjudication gate.
+#ifndef F3D_WF_FRAME_LANES
+#define F3D_WF_FRAME_LANES 4  // lanes a pixel in the kernels with the heightfield primitive (f3d_wf_path.h HipWave)
+#endif
 #ifndef F3D_WF_WAVES_TERRAIN
 #define F3D_WF_WAVES_TERRAIN 6
 #endif
@@ -65,23 +68,26 @@ __global__ __launch_bounds__(64, TERRAIN ? F3D_WF_WAVES_TERRAIN : F3D_WF_WAVES) 
     __shared__ __attribute__((aligned(16))) uint32_t lds[TERRAIN ? kCompactLdsWords : 1];
     LdsPendingCompact pend{};
     if (TERRAIN) pend = make_pending<LdsPendingCompact>(lds, P.S.terrain, kCompactRows);
-    const uint32_t tiles_x = (P.S.width + 7u) / 8u, tiles = tiles_x * ((P.S.height + 7u) / 8u);
+    using Wave = wf::HipWave<LdsPendingCompact, TERRAIN, LITE, TERRAIN ? (uint32_t)F3D_WF_FRAME_LANES : 1u>;
+    constexpr uint32_t kFL = Wave::kFrameStride, kTW = Wave::kTileW, kTH = Wave::kTileH;
+    const uint32_t tiles_x = (P.S.width + kTW - 1u) / kTW, tiles = tiles_x * ((P.S.height + kTH - 1u) / kTH);
     // (all frame groups of a tile together and image rows from the bottom up -- heavy tiles first -- measured 21.3-21.4 against
     // 21.4-21.6 ms on C3 GI: the tail is not what the round waits for; not taken)
     const uint32_t tile = blockIdx.x % tiles, group = blockIdx.x / tiles;
-    const uint32_t x0 = (tile % tiles_x) * 8u, y0 = (tile / tiles_x) * 8u;
-    const uint32_t x = x0 + (threadIdx.x & 7u), y = y0 + (threadIdx.x >> 3);
-    const uint32_t begin = group * P.frames_per_lane;
+    const uint32_t x0 = (tile % tiles_x) * kTW, y0 = (tile / tiles_x) * kTH;
+    const uint32_t turn = threadIdx.x % kFL, x = x0 + (threadIdx.x / kFL) % kTW, y = y0 + threadIdx.x / (kFL * kTW);
+    // the wave's frames: kFL * frames_per_lane consecutive ones, the lanes of a pixel taking them in turns
+    const uint32_t begin = group * (kFL * P.frames_per_lane);
     uint32_t vertices = 0u;
-    if (x < P.S.width && y < P.S.height && begin < P.count) {
-        const uint32_t n = P.count - begin < P.frames_per_lane ? P.count - begin : P.frames_per_lane;
-        const uint32_t first = P.first + begin;
-        const wf::HipWave<LdsPendingCompact, TERRAIN, LITE> wave{&pend, x0, y0, P.S.width};
+    if (x < P.S.width && y < P.S.height && begin + turn < P.count) {
+        const uint32_t all = P.count - begin < kFL * P.frames_per_lane ? P.count - begin : kFL * P.frames_per_lane;
+        const uint32_t n = (all - turn + kFL - 1u) / kFL;
+        const Wave wave{&pend, x0, y0, P.S.width};
         // (the output address is formed from the lane's pixel where a frame ends, like everything else that depends on it:
         // nothing per-lane but the march's own state is alive across a march)
-        vertices = wf::trace_frames(P.S, first, n, wave, [&](uint32_t frame, V3 total) {
+        vertices = wf::trace_frames(P.S, P.first + begin + turn, n, wave, [&](uint32_t frame, V3 total) {
             const size_t pixels = (size_t)P.S.width * P.S.height;
-            P.totals[(size_t)(begin + (frame - first)) * pixels + wave.pixel()] = float4{total.x, total.y, total.z, 0.0f};
+            P.totals[(size_t)(frame - P.first) * pixels + wave.pixel()] = float4{total.x, total.y, total.z, 0.0f};
         });
     }
     unsigned long long total = vertices;
@@ -248,7 +254,10 @@ extern "C" int f3d_wavefront_render(const f3d_wf_scene *scene_in, uint32_t width
         // Rounds: a round traces `round_frames` frames of every pixel into the totals buffer (16 B per pixel-frame, 4 GB
         // by default -- a sliver of the 288 GB) and folds them; lanes take `frames_per_lane` frames each: few enough
         // that a round has tens of thousands of waves, many enough that the lanes of a wave end their batches together.
-        const uint32_t tiles = ((width + 7u) / 8u) * ((height + 7u) / 8u);
+        // (the kernels with the heightfield primitive: F3D_WF_FRAME_LANES lanes a pixel, tiles of 64 / that many pixels -- f3d_wf_path.h HipWave)
+        const uint32_t frame_lanes = S.has_terrain ? (uint32_t)F3D_WF_FRAME_LANES : 1u;
+        const uint32_t tile_w = wf::wf_tile_w(frame_lanes), tile_h = wf::wf_tile_h(frame_lanes);
+        const uint32_t tiles = ((width + tile_w - 1u) / tile_w) * ((height + tile_h - 1u) / tile_h);
         const uint64_t budget = 4ull << 30;
         uint32_t round_frames = frames_per_launch ? frames_per_launch : (uint32_t)std::min<uint64_t>(frame_count, std::max<uint64_t>(1, budget / (pixels * sizeof(float4))));
         round_frames = std::min(round_frames, frame_count);
@@ -256,7 +265,7 @@ extern "C" int f3d_wavefront_render(const f3d_wf_scene *scene_in, uint32_t width
         // (with the heightfield primitive the waves are long and differ more -- sky tiles end at once -- so the tail of a round
         // asks for more, shorter ones: C3 GI at 1080p x 32 frames, 32 / 16 / 8 / 4 / 2 -> 24.4 / 22.3 / 21.4 / 21.9 / 24.1 ms)
         const uint64_t want_waves = S.has_terrain ? 100000ull : 32768ull;
-        while (fpl > 8u && (uint64_t)tiles * ((round_frames + fpl - 1u) / fpl) < want_waves) fpl >>= 1;
+        while (fpl > 8u && (uint64_t)tiles * ((round_frames + frame_lanes * fpl - 1u) / (frame_lanes * fpl)) < want_waves) fpl >>= 1;
         if (const char *e = getenv("F3D_WF_FRAMES_PER_LANE")) fpl = (uint32_t)std::max(1, atoi(e));
         fpl = std::min(std::min(fpl, round_frames), wf::kMaxFramesPerCall);  // (a lane's frame counter has 11 bits: f3d_wf_path.h LaneState)
         P.frames_per_lane = fpl;
@@ -267,7 +276,7 @@ extern "C" int f3d_wavefront_render(const f3d_wf_scene *scene_in, uint32_t width
         for (uint32_t done = 0u; done < frame_count; done += round_frames) {
             P.first = first_frame + done;
             P.count = std::min(round_frames, frame_count - done);
-            const uint32_t groups = (P.count + fpl - 1u) / fpl;
+            const uint32_t groups = (P.count + frame_lanes * fpl - 1u) / (frame_lanes * fpl);
             const bool lite = S.has_terrain && S.blas_count == 0u && S.inst_count == 0u && S.hair_count == 0u && S.area_count == 0u && S.medium_on == 0u &&
                               getenv("F3D_WF_FULL_KERNEL") == nullptr;  // (A/B + test switch: the full instantiation for a lite scene -- same results)
             if (lite) hipLaunchKernelGGL((k_wf_paths<true, true>), dim3(tiles * groups), dim3(64), 0, nullptr, P);

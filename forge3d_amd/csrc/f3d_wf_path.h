@@ -959,6 +959,7 @@ struct SoloWave {
     static constexpr bool kTerrain = true;
     static constexpr bool kLite = false;
     static constexpr uint32_t kPark = kLaneRows;  // (the host runs the row form of the code, the rows being an array)
+    static constexpr uint32_t kFrameStride = 1u;
     Pend *pend;
     uint32_t pixel_, width_;
     mutable uint32_t parked[kLaneRows];
@@ -970,22 +971,27 @@ struct SoloWave {
     F3D_HD float unpark(uint32_t row) const { return f_from_bits(parked[row]); }
 };
 #if defined(__HIPCC__)
-template <class Pend, bool TERRAIN, bool LITE = false>
+// FRAME_LANES (round 6): neighbouring lanes of a wave are the SAME pixel taking its frames in turns (lane % FRAME_LANES = which
+// turn), the wave's tile being 64 / FRAME_LANES pixels -- the terrain tracer's "sample lanes" (DESIGN.md 4.5): their camera rays
+// are almost the same ray, their vertices almost the same point, so their marches are as long as each other and read the same
+// table entries.  Every frame's total goes out under its own frame number and is folded in frame order: same results.
+constexpr uint32_t wf_tile_w(uint32_t frame_lanes) { return frame_lanes <= 2u ? 8u : (frame_lanes <= 8u ? 4u : 2u); }
+constexpr uint32_t wf_tile_h(uint32_t frame_lanes) { return 64u / frame_lanes / wf_tile_w(frame_lanes); }
+template <class Pend, bool TERRAIN, bool LITE = false, uint32_t FRAME_LANES = 1u>
 struct HipWave {
+    static_assert(FRAME_LANES == 1u || FRAME_LANES == 2u || FRAME_LANES == 4u || FRAME_LANES == 8u || FRAME_LANES == 16u, "a power of two up to 16");
     static constexpr bool kTerrain = TERRAIN;
     static constexpr bool kLite = LITE;  // no meshes, hair, area lights, fog in the scene: their code is not in the kernel
     // rows of the lane's LDS column that hold the path's loop-carried state (0: no LDS block, the state lives in registers)
     static constexpr uint32_t kPark = TERRAIN ? (uint32_t)kPathParkRows : 0u;
+    static constexpr uint32_t kFrameStride = FRAME_LANES, kTileW = wf_tile_w(FRAME_LANES), kTileH = wf_tile_h(FRAME_LANES);
     Pend *pend;
-    uint32_t x0, y0, width;  // the wave's 8 x 8 tile (wave-uniform)
+    uint32_t x0, y0, width;  // the wave's tile of kTileW x kTileH pixels (wave-uniform)
     __device__ uint32_t count(bool flag) const { return (uint32_t)__popcll(__ballot(flag)); }
     // the lane's pixel, formed where it is used from the hardware's lane id (f3d_lds.h lane_now: never hoisted, never kept)
-    __device__ uint32_t pixel() const {
-        const uint32_t lane = lane_now();
-        return (y0 + (lane >> 3)) * width + x0 + (lane & 7u);
-    }
-    __device__ uint32_t px() const { return x0 + (lane_now() & 7u); }
-    __device__ uint32_t py() const { return y0 + (lane_now() >> 3); }
+    __device__ uint32_t px() const { return x0 + ((lane_now() / FRAME_LANES) % kTileW); }
+    __device__ uint32_t py() const { return y0 + (lane_now() / (FRAME_LANES * kTileW)); }
+    __device__ uint32_t pixel() const { return py() * width + px(); }
     __device__ void park(uint32_t row, float v) const { pend->col[(kPathParkRow0 + row) * kWave] = f_bits(v); }
     __device__ float unpark(uint32_t row) const { return f_from_bits(pend->col[(kPathParkRow0 + row) * kWave]); }
 };
@@ -1019,7 +1025,8 @@ F3D_HD uint32_t trace_frames(const SceneDev &S, uint32_t first, uint32_t count, 
     float hit_t = 0.0f;
     bool hit_hair = false;
     V3 hit_tangent{0.0f, 0.0f, 0.0f};
-    auto frame_of = [&](uint32_t word) F3D_LAMBDA { return first + ((word >> Lane::kFrameShift) & Lane::kFrameMask); };
+    // (Wave::kFrameStride: the lanes of a pixel take its frames in turns -- the lane's k-th frame is first + k * stride)
+    auto frame_of = [&](uint32_t word) F3D_LAMBDA { return first + Wave::kFrameStride * ((word >> Lane::kFrameShift) & Lane::kFrameMask); };
     auto active = [&](uint32_t word) F3D_LAMBDA { return (word & Lane::kPending) == 0u && ((word >> Lane::kFrameShift) & Lane::kFrameMask) < count; };
     auto finish_frame = [&]() F3D_LAMBDA {  // the frame's total goes out, the next frame starts from zero
         const uint32_t word = lane.word();
