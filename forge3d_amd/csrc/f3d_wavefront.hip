@@ -56,6 +56,9 @@ struct WfParams {
 #ifndef F3D_WF_FRAME_LANES
 #define F3D_WF_FRAME_LANES 4  // lanes a pixel in the kernels with the heightfield primitive (f3d_wf_path.h HipWave)
 #endif
+#ifndef F3D_WF_FRAME_LANES_PLAIN
+#define F3D_WF_FRAME_LANES_PLAIN 4  // ... and in the kernel without it (adjudication gate, 512 x 512 x 4096: 1 / 2 / 4 / 8 lanes -> 139.8 / 139.2 / 135.7 / 134.8 ms)
+#endif
 #ifndef F3D_WF_WAVES_TERRAIN
 #define F3D_WF_WAVES_TERRAIN 6
 #endif
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(64, TERRAIN ? F3D_WF_WAVES_TERRAIN : F3D_WF_WAVES) 
     __shared__ __attribute__((aligned(16))) uint32_t lds[TERRAIN ? kCompactLdsWords : 1];
     LdsPendingCompact pend{};
     if (TERRAIN) pend = make_pending<LdsPendingCompact>(lds, P.S.terrain, kCompactRows);
-    using Wave = wf::HipWave<LdsPendingCompact, TERRAIN, LITE, TERRAIN ? (uint32_t)F3D_WF_FRAME_LANES : 1u>;
+    using Wave = wf::HipWave<LdsPendingCompact, TERRAIN, LITE, TERRAIN ? (uint32_t)F3D_WF_FRAME_LANES : (uint32_t)F3D_WF_FRAME_LANES_PLAIN>;
     constexpr uint32_t kFL = Wave::kFrameStride, kTW = Wave::kTileW, kTH = Wave::kTileH;
     const uint32_t tiles_x = (P.S.width + kTW - 1u) / kTW, tiles = tiles_x * ((P.S.height + kTH - 1u) / kTH);
     // (all frame groups of a tile together and image rows from the bottom up -- heavy tiles first -- measured 21.3-21.4 against
@@ -255,7 +258,7 @@ extern "C" int f3d_wavefront_render(const f3d_wf_scene *scene_in, uint32_t width
         // by default -- a sliver of the 288 GB) and folds them; lanes take `frames_per_lane` frames each: few enough
         // that a round has tens of thousands of waves, many enough that the lanes of a wave end their batches together.
         // (the kernels with the heightfield primitive: F3D_WF_FRAME_LANES lanes a pixel, tiles of 64 / that many pixels -- f3d_wf_path.h HipWave)
-        const uint32_t frame_lanes = S.has_terrain ? (uint32_t)F3D_WF_FRAME_LANES : 1u;
+        const uint32_t frame_lanes = S.has_terrain ? (uint32_t)F3D_WF_FRAME_LANES : (uint32_t)F3D_WF_FRAME_LANES_PLAIN;
         const uint32_t tile_w = wf::wf_tile_w(frame_lanes), tile_h = wf::wf_tile_h(frame_lanes);
         const uint32_t tiles = ((width + tile_w - 1u) / tile_w) * ((height + tile_h - 1u) / tile_h);
         const uint64_t budget = 4ull << 30;
