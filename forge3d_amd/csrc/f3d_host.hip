@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <deque>
 #include <exception>
 #include <memory>
 #include <map>
@@ -24,6 +25,7 @@
 #include "f3d_devmem.h"
 #include "f3d_launch.h"
 #include "f3d_lbvh.h"
+#include "f3d_meshgrid.h"
 #include "f3d_setup.h"
 #include "f3d_tables.h"
 
@@ -301,6 +303,7 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
     P.terrain.leaves = s.tables.leaves;
     P.terrain.nodes = s.tables.nodes;
     P.terrain.bands = s.tables.bands;
+    P.terrain.mesh_bands = s.tables.bands;  // (no mesh grid: the fused march tests the terrain's band twice, f3d_scene.h)
 #if !defined(F3D_NO_IBL_STOP)  // A/B builds (tools/build_variant.sh)
     // Opt-in (F3D_IBL_HORIZON=1): measured on MI355X, the table costs 12.9 ms to build for the 2048^2 headline DEM and
     // saves 0.03 ms per 8-spp 1080p frame (+1.2 %) -- its blocks' lowest points see higher horizons than the hit points
@@ -359,6 +362,21 @@ void session_init(f3d_session &s, const f3d_terrain_ref_desc &d, const f3d_sessi
         s.mesh = acquire_mesh(s.device, d.mesh_vertices, d.mesh_vertex_count, d.mesh_indices, d.mesh_index_count, builder, s.stream);
         s.mem.device_bytes += s.mesh->mem.device_bytes;  // shared, but part of this render's working set
         P.mesh = s.mesh->dev;
+#if defined(F3D_MESH_FUSED)  // A/B build (f3d_shade.h occluded: measured slower, not in the shipped library)
+        // ... and as a second band of the terrain's pyramid for the occlusion rays' march (f3d_meshgrid.h; F3D_MESH_GRID=0: the tree
+        // walk for every ray).  Depends on the mesh AND on where the DEM's cells lie: kept with the cached mesh per grid geometry.
+        if (const char *env = getenv("F3D_MESH_GRID"); !(env && env[0] == '0')) {
+            const CachedMesh::Grid *grid = acquire_mesh_grid(*s.mesh, s.tables.layout, P.terrain, d.mesh_vertices, d.mesh_vertex_count, d.mesh_indices,
+                                                             d.mesh_index_count);
+            if (grid && grid->bands) {
+                P.terrain.mesh_bands = grid->bands;
+                P.terrain.mesh_cell_start = grid->cell_start;
+                P.terrain.mesh_cell_tris = grid->tris;
+                P.terrain.mesh_top = grid->top;
+                s.mem.device_bytes += grid->bytes;
+            }
+        }
+#endif
     }
     if (d.atmosphere) upload_aether(s, *d.atmosphere, d);
     clock.lap(kSetupScene);

@@ -371,6 +371,17 @@ struct CachedMesh {
     Ledger mem;
     MeshDev dev{};
     uint64_t stamp = 0;
+    // the mesh as a second band of a DEM's pyramid (f3d_meshgrid.h), per grid geometry; bands == nullptr: this mesh has none there
+    struct Grid {
+        uint32_t cell_w = 0, cell_h = 0;
+        float origin_x = 0, origin_z = 0, spacing_x = 0, spacing_z = 0;
+        const NodeRec *bands = nullptr;
+        const uint32_t *cell_start = nullptr;
+        const float4 *tris = nullptr;
+        float top = 0;
+        size_t bytes = 0;
+    };
+    std::deque<Grid> grids;  // (a deque: sessions keep pointers to its elements)
     ~CachedMesh() {
         int prev = -1;
         (void)hipGetDevice(&prev);
@@ -458,6 +469,36 @@ std::shared_ptr<CachedMesh> acquire_mesh(int device, const float *vertices, uint
         }
     }
     return e;
+}
+
+// The grid of a cached mesh on this DEM's cells: from the cache entry, or built now (host) and uploaded into its memory.
+const CachedMesh::Grid *acquire_mesh_grid(CachedMesh &mesh, const TableLayout &L, const TerrainDev &T, const float *vertices, uint32_t vertex_count,
+                                          const uint32_t *indices, uint32_t index_count) {
+    std::lock_guard<std::mutex> lock(g_scene_mutex);
+    for (const auto &g : mesh.grids)
+        if (g.cell_w == T.cell_w && g.cell_h == T.cell_h && g.origin_x == T.origin_x && g.origin_z == T.origin_z && g.spacing_x == T.spacing_x &&
+            g.spacing_z == T.spacing_z)
+            return &g;
+    CachedMesh::Grid out;
+    out.cell_w = T.cell_w, out.cell_h = T.cell_h;
+    out.origin_x = T.origin_x, out.origin_z = T.origin_z, out.spacing_x = T.spacing_x, out.spacing_z = T.spacing_z;
+    const MeshGrid g = build_mesh_grid(L, T.origin_x, T.origin_z, T.spacing_x, T.spacing_z, vertices, vertex_count, indices, index_count);
+    if (g.ok) {
+        const size_t before = mesh.mem.device_bytes;
+        NodeRec *db = (NodeRec *)mesh.mem.alloc(g.bands.size() * sizeof(NodeRec), "mesh band tables");
+        uint32_t *dc = (uint32_t *)mesh.mem.alloc(g.cell_start.size() * sizeof(uint32_t), "mesh cell lists");
+        float4 *dt = (float4 *)mesh.mem.alloc(std::max<size_t>(g.tris.size(), 4u) * sizeof(float), "mesh cell triangles");
+        hip_check(hipMemcpy(db, g.bands.data(), g.bands.size() * sizeof(NodeRec), hipMemcpyHostToDevice), "mesh grid upload");
+        hip_check(hipMemcpy(dc, g.cell_start.data(), g.cell_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice), "mesh grid upload");
+        if (!g.tris.empty()) hip_check(hipMemcpy(dt, g.tris.data(), g.tris.size() * sizeof(float), hipMemcpyHostToDevice), "mesh grid upload");
+        out.bands = db;
+        out.cell_start = dc;
+        out.tris = dt;
+        out.top = g.top;
+        out.bytes = mesh.mem.device_bytes - before;
+    }
+    mesh.grids.push_back(out);
+    return &mesh.grids.back();
 }
 
 }  // namespace

@@ -123,6 +123,7 @@ struct MarchState {
     bool marching, unverified_start;
 #if !defined(F3D_NO_BAND_PREFETCH)
     float band_mn, band_mx;  // the (min,max) band of the node the lane stands in, fetched when it moved there
+    float mesh_mn, mesh_mx;  // FUSE: the node's mesh band (f3d_meshgrid.h)
 #endif
 };
 
@@ -130,7 +131,14 @@ struct MarchState {
 // The lane therefore asks for it as soon as it knows where it goes next -- at the END of the previous step -- and the
 // wave votes, the FIFO bookkeeping and the next step's plane arithmetic run while it is on its way
 // (-DF3D_NO_BAND_PREFETCH: fetched where it is needed, the round-2 form; profiles/README.md).
-template <class Ctx>
+// FUSE (the occlusion rays of the kernels compiled for scenes with a mesh, round 6): the scene's mesh is a second (min, max) band
+// of every node (f3d_meshgrid.h) and the march looks for both at once -- it descends where either band passes, and a cell whose
+// mesh band passes is queued with kMeshCell (with kMeshOnly when the terrain's own band rejects it): the drain puts the cell's
+// triangles through the sweep's ray_triangle.  The terrain's verdicts are untouched (its leaves are queued and solved exactly
+// when its own band passes); the mesh's are conservative by the grid's construction and exact in the triangle test.  Measured
+// before it was built: a second band per step costs the configs[3] frame 0.4 ms, the occlusion rays' tree walks 8.9 ms.
+constexpr uint32_t kMeshCell = 0x4000u, kMeshOnly = 0x8000u;  // (cell = cx | cz << 16 with cx, cz < 2^13: bits 13-15 are free)
+template <bool FUSE = false, class Ctx>
 F3D_HD void march_fetch(const TerrainDev &T, MarchState &m, Ctx &ctx) {
 #if !defined(F3D_NO_BAND_PREFETCH)
     uint32_t band_offset, band_shift;
@@ -138,6 +146,13 @@ F3D_HD void march_fetch(const TerrainDev &T, MarchState &m, Ctx &ctx) {
     const NodeRec band = T.bands[band_offset + (m.nz << band_shift) + m.nx];
     m.band_mn = band.mn;
     m.band_mx = band.mx;
+    if (FUSE) {
+        const NodeRec mesh = T.mesh_bands[band_offset + (m.nz << band_shift) + m.nx];
+        m.mesh_mn = mesh.mn;
+        m.mesh_mx = mesh.mx;
+    }
+#else
+    static_assert(!FUSE, "the fused mesh band rides with the band prefetch");
 #endif
 }
 
@@ -184,7 +199,7 @@ F3D_HD MarchState march_begin(const TerrainDev &T, const RayCtx &r, bool start_i
 // VERIFY: the lane may stand in a node that was located from a rounded position (m.unverified_start).  Only the FIRST
 // step of a ray or slice can: the march loops take that step through the verifying instantiation (march_first_step)
 // and every later one through VERIFY = false, which carries neither the flag nor its test.
-template <bool CURVED, bool SLICED, bool VERIFY = true, class Ctx>
+template <bool CURVED, bool SLICED, bool VERIFY = true, bool FUSE = false, class Ctx>
 F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint32_t &queued, Ctx &ctx, bool any_hit,
                        float t_stop = 3.0e38f) {
     ctx.note(0);
@@ -226,7 +241,10 @@ F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint
         ctx.band_entry(T, level, band_offset, band_shift);
         const NodeRec band = T.bands[band_offset + (nz << band_shift) + nx];
 #endif
-        const bool pass = !(lo > hi) & !march_band_rejects<CURVED>(r, lo, hi, band.mn, band.mx);  // :297-304 (bitwise: no branch)
+        const bool terrain_pass = !(lo > hi) & !march_band_rejects<CURVED>(r, lo, hi, band.mn, band.mx);  // :297-304 (bitwise: no branch)
+        // (the mesh is met by the STRAIGHT ray: the curvature policy bends the terrain test only, hybrid_traversal.wgsl:204-259)
+        const bool mesh_pass = FUSE ? (!(lo > hi) & !march_band_rejects<false>(r, lo, hi, m.mesh_mn, m.mesh_mx)) : false;
+        const bool pass = terrain_pass | mesh_pass;
         if (pass) ctx.note(-1);  // statistics hook (host emulator only): the last step whose band test passed
 #if defined(F3D_BRANCHLESS_STEP)
         // A/B (round 6, DESIGN.md 6 "plateau"): the step with NO data-dependent branch but the rare corner ties -- DOWN and ACROSS
@@ -234,6 +252,7 @@ F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint
         // moves only for a leaf; the loops call a step only with two slots free).  Same values by the same expressions as the
         // branching form below.
         {
+            static_assert(!FUSE, "the branch-free A/B form of the step has no fused mesh band");
             const bool down = pass & (level > 0u), leaf = pass & (level == 0u);
             const uint32_t cl = level > 0u ? level - 1u : 0u;
             const uint32_t xm = (2u * nx + 1u) << cl, zm = (2u * nz + 1u) << cl;
@@ -279,7 +298,7 @@ F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint
             const uint32_t qx = nx + ((cross_x && x_forward) ? 1u : 0u) - ((cross_x && !x_forward) ? 1u : 0u);
             const uint32_t qz = nz + ((cross_z && z_forward) ? 1u : 0u) - ((cross_z && !z_forward) ? 1u : 0u);
             const bool left = !(exit < r.tmax) | (SLICED & !(exit < t_stop)) | ((qx << level) >= T.cell_w) |
-                              ((qz << level) >= T.cell_h) | (march_height<CURVED>(r, exit) > r.y_exit);
+                              ((qz << level) >= T.cell_h) | (march_height<CURVED && !FUSE>(r, exit) > r.y_exit);
             const bool up = level < top && (((qx ^ nx) | (qz ^ nz)) > 1u);
             m.nx = down ? 2u * nx + ix : (up ? qx >> 1 : qx);
             m.nz = down ? 2u * nz + iz : (up ? qz >> 1 : qz);
@@ -332,7 +351,7 @@ F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint
         } else {
             if (pass) {  // a leaf to solve: queue it and march on as if it had missed
                 ctx.note(1);
-                ctx.fifo_put(queued, nx | (nz << 16), lo, hi);
+                ctx.fifo_put(queued, nx | (nz << 16) | (FUSE ? (mesh_pass ? kMeshCell : 0u) | (terrain_pass ? 0u : kMeshOnly) : 0u), lo, hi);
                 queued++;
             }
             // ---- across the exit boundary of this node (straight-line: no nested divergence) ----
@@ -355,7 +374,7 @@ F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint
             // above the whole terrain and climbing (RayCtx::y_exit): nothing ahead can pass its band test
             // (bitwise | on purpose: every term is a couple of vector compares, cheaper than the branches of a short-circuit)
             const bool left = !(exit < r.tmax) | (SLICED & !(exit < t_stop)) | ((qx << level) >= T.cell_w) |
-                              ((qz << level) >= T.cell_h) | (march_height<CURVED>(r, exit) > r.y_exit);
+                              ((qz << level) >= T.cell_h) | (march_height<CURVED && !FUSE>(r, exit) > r.y_exit);
             // leaving the parent as well: continue one level up (jumping h > 1 levels when the crossing
             // leaves h ancestors was modelled on the emulator's step logs: fewer IBL steps, but more
             // shadow steps and 7-17 % more wave iterations -- tools/march_model.py)
@@ -369,13 +388,13 @@ F3D_HD void march_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint
 #endif
     }
     if (VERIFY) m.unverified_start = false;
-    if (m.marching) march_fetch(T, m, ctx);
+    if (m.marching) march_fetch<FUSE>(T, m, ctx);
 }
 // The first step of the lanes whose start node still has to be validated (see VERIFY above).
-template <bool CURVED, bool SLICED, class Ctx>
+template <bool CURVED, bool SLICED, bool FUSE = false, class Ctx>
 F3D_HD void march_first_step(const TerrainDev &T, const RayCtx &r, MarchState &m, uint32_t &queued, Ctx &ctx, bool any_hit, float t_stop) {
 #if !defined(F3D_VERIFY_EVERY_STEP)  // (A/B: the round-2 form tests the flag in every step)
-    if (m.marching && m.unverified_start) march_step<CURVED, SLICED, true>(T, r, m, queued, ctx, any_hit, t_stop);
+    if (m.marching && m.unverified_start) march_step<CURVED, SLICED, true, FUSE>(T, r, m, queued, ctx, any_hit, t_stop);
 #endif
 }
 #if !defined(F3D_VERIFY_EVERY_STEP)
@@ -400,7 +419,7 @@ F3D_HD void march_leaf_interval(const TerrainDev &T, const RayCtx &r, uint32_t c
     hi = f_min(f_min(f_max(tx0, tx1), f_max(tz0, tz1)), r.tmax);
 }
 // hit_cell: the cell (cx | cz << 16) of the hit a closest-hit drain ends with (the sharing of closest-hit rays, march_shared_closest)
-template <class Ctx>
+template <bool FUSE = false, class Ctx>
 F3D_HD void march_drain(const TerrainDev &T, const RayCtx &r, bool any_hit, MarchState &m, uint32_t &queued,
                         TraceHit &res, Ctx &ctx, uint32_t &hit_cell) {
     uint32_t k = 0u;  // per lane: a tie entry is visited twice
@@ -410,9 +429,10 @@ F3D_HD void march_drain(const TerrainDev &T, const RayCtx &r, bool any_hit, Marc
             uint32_t cell;
             float lo, hi;
             ctx.fifo_get(k, cell, lo, hi);
-            uint32_t cx = cell & 0xFFFFu, cz = cell >> 16;
-            bool solve = true;
+            uint32_t cx = cell & (FUSE ? 0x1FFFu : 0xFFFFu), cz = cell >> 16;
             const bool tie = any_hit && (cell & kTieFlag) != 0u;
+            bool solve = FUSE ? (tie || (cell & kMeshOnly) == 0u) : true;  // (a cell queued for its triangles only: no leaf to solve)
+            const bool triangles = FUSE && !tie && (cell & kMeshCell) != 0u && T.mesh_cell_start != nullptr;
             if (kFifoWords == 1u) {  // the interval again, as march_step formed it (see kFifoWords)
                 if (tie) {
                     lo = hi = (plane_at(T.origin_x, cell & 0x3FFFu, T.spacing_x) - r.o.x) * r.inv_x;
@@ -448,17 +468,37 @@ F3D_HD void march_drain(const TerrainDev &T, const RayCtx &r, bool any_hit, Marc
                     hit_cell = cx | (cz << 16);
                 }
             }
+#if defined(F3D_NO_CELL_TRIANGLES)  // test of the tests: the fused march without its triangle tests must FAIL the mesh parity tests
+            if (false) {
+#else
+            if (FUSE && triangles && !res.hit) {
+#endif  // the cell's triangles through the sweep's own test (any hit: existence)
+                const uint32_t c = cz * T.cell_w + cx;
+                uint32_t e = T.mesh_cell_start[c];
+                const uint32_t e_end = T.mesh_cell_start[c + 1u];
+                for (; e < e_end; e++) {
+                    const float4 a = T.mesh_cell_tris[3u * e], b = T.mesh_cell_tris[3u * e + 1u], c2 = T.mesh_cell_tris[3u * e + 2u];
+                    float t;
+                    V3 n;
+                    if (ray_triangle(r.o, r.tmin, r.d, r.tmax, V3{a.x, a.y, a.z}, V3{b.x, b.y, b.z}, V3{c2.x, c2.y, c2.z}, t, n)) {
+                        res.hit = true;
+                        res.t = t;
+                        res.n = n;
+                        break;
+                    }
+                }
+            }
         }
     }
     queued = 0u;
     // (once, here: a second boolean carried through the loop above costs a lane-mask merge per level of nesting -- 1.4 %)
     m.marching = m.marching & !res.hit;
 }
-template <class Ctx>
+template <bool FUSE = false, class Ctx>
 F3D_HD void march_drain(const TerrainDev &T, const RayCtx &r, bool any_hit, MarchState &m, uint32_t &queued,
                         TraceHit &res, Ctx &ctx) {
     uint32_t hit_cell;  // (nobody reads it: the stores go)
-    march_drain(T, r, any_hit, m, queued, res, ctx, hit_cell);
+    march_drain<FUSE>(T, r, any_hit, m, queued, res, ctx, hit_cell);
 }
 
 // ---- the last few rays of a wave, shared by all its lanes -----------------------------------------
@@ -593,7 +633,7 @@ F3D_HD void march_deal(const TerrainDev &T, MarchSlice &s, MarchState &m, const 
 
 // Phase 2 of an any-hit march (see above).  `m` holds the lane's position on its own ray, own_hit its
 // verdict so far; returns the final verdict of the lane's OWN ray.
-template <bool CURVED, class Ctx>
+template <bool CURVED, bool FUSE = false, class Ctx>
 F3D_HD bool march_shared(const TerrainDev &T, const RayCtx &own_ray, MarchState m, bool own_hit, Ctx &ctx, float t_stop = 3.0e38f) {
     MarchSlice s;
     s.r = own_ray;
@@ -609,25 +649,25 @@ F3D_HD bool march_shared(const TerrainDev &T, const RayCtx &own_ray, MarchState 
     res.n = V3{0.0f, 0.0f, 0.0f};
     for (uint32_t round = 0u;; round++) {
         ctx.template deal<CURVED>(T, s, m);  // m.marching now says whether this lane got a slice
-        if (m.marching) march_fetch(T, m, ctx);
-        march_first_step<CURVED, true>(T, s.r, m, queued, ctx, true, s.t_stop);  // slices other than a ray's first start in a located node
+        if (m.marching) march_fetch<FUSE>(T, m, ctx);
+        march_first_step<CURVED, true, FUSE>(T, s.r, m, queued, ctx, true, s.t_stop);  // slices other than a ray's first start in a located node
         res.hit = false;
         res.t = s.r.tmax;
         bool again = false;
         for (;;) {
-            if (m.marching) march_step<CURVED, true, kVerifyInLoop>(T, s.r, m, queued, ctx, true, s.t_stop);
+            if (m.marching) march_step<CURVED, true, kVerifyInLoop, FUSE>(T, s.r, m, queued, ctx, true, s.t_stop);
 #if !defined(F3D_STEPS_UNROLLED)
 #pragma unroll 1
             for (uint32_t extra = 1u; extra < kStepsPerVoteShared && m.marching && queued + 2u <= kLeafFifoRows; extra++)
-                march_step<CURVED, true, kVerifyInLoop>(T, s.r, m, queued, ctx, true, s.t_stop);
+                march_step<CURVED, true, kVerifyInLoop, FUSE>(T, s.r, m, queued, ctx, true, s.t_stop);
 #else
 #pragma unroll
             for (uint32_t extra = 1u; extra < kStepsPerVoteShared; extra++)
-                if (m.marching && queued + 2u <= kLeafFifoRows) march_step<CURVED, true, kVerifyInLoop>(T, s.r, m, queued, ctx, true, s.t_stop);
+                if (m.marching && queued + 2u <= kLeafFifoRows) march_step<CURVED, true, kVerifyInLoop, FUSE>(T, s.r, m, queued, ctx, true, s.t_stop);
 #endif
             again = round + 1u < kShareRounds && ctx.share_now(m.marching);
             if (again || ctx.flush_now(queued, m.marching)) {
-                march_drain(T, s.r, true, m, queued, res, ctx);
+                march_drain<FUSE>(T, s.r, true, m, queued, res, ctx);
                 if (res.hit) ctx.verdict_set(s.owner);
                 if (ctx.verdict_get(s.owner)) m.marching = false;  // another slice of this ray has hit
             }
@@ -746,7 +786,7 @@ F3D_HD MarchState march_begin_at(const TerrainDev &T, const RayCtx &r, float t_c
 // Ctx provides: note(), band_entry(), the FIFO storage fifo_put/fifo_get, the wave votes
 // flush_now(queued, marching) / any(pred), and share_now / deal / verdict_* (ray sharing).
 // hit_cell (closest-hit callers that want it, no ray sharing): the cell (cx | cz << 16) of the hit.
-template <bool CURVED, bool STOP = CURVED, class Ctx>
+template <bool CURVED, bool STOP = CURVED, bool FUSE = false, class Ctx>
 F3D_HD TraceHit march_terrain_from(const TerrainDev &T, const RayCtx &r, bool any_hit, MarchState m, Ctx &ctx,
                                    float t_stop = 3.0e38f, uint32_t *hit_cell = nullptr) {
     TraceHit res;
@@ -757,22 +797,22 @@ F3D_HD TraceHit march_terrain_from(const TerrainDev &T, const RayCtx &r, bool an
     ctx.feature(r.d.y);
     uint32_t queued = 0u, cell = 0u;
     bool deal = false;
-    if (m.marching) march_fetch(T, m, ctx);
-    march_first_step<CURVED, STOP>(T, r, m, queued, ctx, any_hit, t_stop);
+    if (m.marching) march_fetch<FUSE>(T, m, ctx);
+    march_first_step<CURVED, STOP, FUSE>(T, r, m, queued, ctx, any_hit, t_stop);
     for (;;) {
         // t_stop (occlusion rays, f3d_cone.h sun_clear_from / ibl_stop): no terrain beyond it, so the lane stops after the node that
         // contains it -- the SLICED rule; node and leaf intervals are NOT clipped by it, every visited node is judged
         // exactly as the unbounded march judges it
-        if (m.marching) march_step<CURVED, STOP, kVerifyInLoop>(T, r, m, queued, ctx, any_hit, t_stop);
+        if (m.marching) march_step<CURVED, STOP, kVerifyInLoop, FUSE>(T, r, m, queued, ctx, any_hit, t_stop);
         // further steps before the wave votes again (kStepsPerVote above)
 #if !defined(F3D_STEPS_UNROLLED)  // a real loop (A/B: unrolled copies of the step -- bigger code, 1-2 % slower)
 #pragma unroll 1
         for (uint32_t extra = 1u; extra < kStepsPerVote && m.marching && queued + 2u <= kLeafFifoRows; extra++)
-            march_step<CURVED, STOP, kVerifyInLoop>(T, r, m, queued, ctx, any_hit, t_stop);
+            march_step<CURVED, STOP, kVerifyInLoop, FUSE>(T, r, m, queued, ctx, any_hit, t_stop);
 #else
 #pragma unroll
         for (uint32_t extra = 1u; extra < kStepsPerVote; extra++)
-            if (m.marching && queued + 2u <= kLeafFifoRows) march_step<CURVED, STOP, kVerifyInLoop>(T, r, m, queued, ctx, any_hit, t_stop);
+            if (m.marching && queued + 2u <= kLeafFifoRows) march_step<CURVED, STOP, kVerifyInLoop, FUSE>(T, r, m, queued, ctx, any_hit, t_stop);
 #endif
 #if !defined(F3D_NO_SHARE)
 #if defined(F3D_SHARE_CURVED)  // A/B: sun rays too, with their own threshold (profiles/README.md)
@@ -784,7 +824,7 @@ F3D_HD TraceHit march_terrain_from(const TerrainDev &T, const RayCtx &r, bool an
 #endif
         // (Balancing the queued leaf solves of a wave over its lanes -- ceil(sum / lanes) rounds instead of
         // max(queued), the owner's ray fetched by ds_bpermute -- was built and measured: bit-identical, 0.96x.)
-        if (deal || ctx.flush_now(queued, m.marching)) march_drain(T, r, any_hit, m, queued, res, ctx, cell);
+        if (deal || ctx.flush_now(queued, m.marching)) march_drain<FUSE>(T, r, any_hit, m, queued, res, ctx, cell);
         if (deal || !ctx.any(m.marching || queued != 0u)) break;
     }
     if (hit_cell) *hit_cell = cell;
@@ -792,16 +832,16 @@ F3D_HD TraceHit march_terrain_from(const TerrainDev &T, const RayCtx &r, bool an
         if (deal && !any_hit) return march_shared_closest<CURVED>(T, r, m, res, ctx, t_stop);
     }
     if (deal) {
-        res.hit = march_shared<CURVED>(T, r, m, res.hit, ctx, t_stop);
+        res.hit = march_shared<CURVED, FUSE>(T, r, m, res.hit, ctx, t_stop);
         res.t = r.tmin;  // any-hit callers read only `hit` (and t < tmax)
     }
     return res;
 }
 
-template <bool CURVED, class Ctx>
+template <bool CURVED, bool FUSE = false, class Ctx>
 F3D_HD TraceHit march_terrain(const TerrainDev &T, const RayCtx &r, bool any_hit, bool start_in_cell, Ctx &ctx,
                               float t_stop = 3.0e38f) {
-    return march_terrain_from<CURVED, true>(T, r, any_hit, march_begin(T, r, start_in_cell), ctx, t_stop);
+    return march_terrain_from<CURVED, true, FUSE>(T, r, any_hit, march_begin(T, r, start_in_cell), ctx, t_stop);
 }
 
 // ---- a STREAM of occlusion rays through the lanes of a wave (wavefront kernels, f3d_kernels.hip k_wf_occl) -----------

@@ -81,6 +81,14 @@ struct TerrainDev {
     uint32_t horizon_level, horizon_bx;
     uint32_t leaf_quorum;   // lanes of a wave that must hold a fat leaf before the leaf body runs
     uint32_t share_below;   // ray sharing (f3d_march.h): deal when at most this many lanes still march; 0 = default
+    // The scene's mesh as a second band of the same pyramid (f3d_meshgrid.h; the occlusion rays' march of the kernels compiled
+    // for scenes with a mesh, f3d_march.h FUSE): mesh_bands has the layout of `bands`; the triangles binned in cell (cx, cz) are
+    // mesh_cell_tris[3 e .. 3 e + 2] for e in [mesh_cell_start[cz * cell_w + cx], mesh_cell_start[.. + 1]).  Without a grid
+    // mesh_cell_start is null and mesh_bands = bands (the march then tests the terrain's band twice and the tree is walked).
+    const NodeRec *mesh_bands;
+    const uint32_t *mesh_cell_start;
+    const float4 *mesh_cell_tris;
+    float mesh_top;  // the root's mesh band maximum
 };
 
 // Threaded BVH node (f3d_bvh.h): preorder layout, enter -> node + 1, miss / subtree done -> skip.

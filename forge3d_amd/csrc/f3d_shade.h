@@ -25,27 +25,7 @@ struct SurfaceHit {
     uint32_t kind;  // 0 miss, 1 terrain (reference hit_type 3), 2 mesh (hit_type 0)
 };
 
-// ray_triangle_intersect, hybrid_traversal.wgsl:86-132
-F3D_HD bool ray_triangle(V3 o, float tmin, V3 d, float tmax, V3 v0, V3 v1, V3 v2, float &t_out, V3 &n_out) {
-    V3 e1 = v1 - v0, e2 = v2 - v0;
-    V3 h = cross(d, e2);
-    float a = dot(e1, h);
-    if (f_abs(a) < 1e-7f) return false;
-    float f = 1.0f / a;
-    V3 s = o - v0;
-    float u = f * dot(s, h);
-    if (u < 0.0f || u > 1.0f) return false;
-    V3 q = cross(s, e1);
-    float v = f * dot(d, q);
-    if (v < 0.0f || u + v > 1.0f) return false;
-    float t = f * dot(e2, q);
-    if (t > tmin && t < tmax) {
-        t_out = t;
-        n_out = normalize(cross(e1, e2));
-        return true;
-    }
-    return false;
-}
+// (ray_triangle, the sweep's triangle test, lives in f3d_trace.h: the march tests a cell's triangles with it too)
 
 // intersect_mesh, hybrid_traversal.wgsl:137-172: the reference sweeps every triangle
 // (its BVH buffer is bound but never read); triangle data is wave-uniform here.
@@ -413,6 +393,26 @@ F3D_HD bool occluded(const FrameParams &P, V3 o, float tmin, V3 d, float tmax, b
     // terrain_tmax: a certificate that no terrain lies beyond it on this ray (f3d_cone.h sun_clear_from): the march stops
     // after the node that contains it (sun rays only: the curved instantiation carries the stop rule)
     RayCtx r = make_ray(P.terrain, o, tmin, d, tmax, apply_curvature);
+    // A/B (round 6, -DF3D_MESH_FUSED; MEASURED SLOWER, not in the shipped library): the kernels compiled for scenes with a mesh
+    // march BOTH at once (f3d_march.h FUSE, f3d_meshgrid.h) -- the mesh is a second band of every node of the terrain's pyramid,
+    // and a cell whose mesh band the ray meets has its triangles put through the sweep's own test by the drain: no second
+    // traversal.  The certificates that promise "no TERRAIN beyond" do not hold for the mesh: no stop parameter, and the climbing
+    // ray leaves only above both the terrain's and the mesh's highest point.  Without a grid (a mesh that reaches beyond the DEM,
+    // lists that explode) the second band is the terrain's own and the tree is walked as before.  Bit-identical (1 000 scenes on
+    // the emulator against the oracle's sweep, the device's mesh tests); on the configs[3] stand-in 36.4 ms a frame against 32.4:
+    // a second band per step would cost 0.4 ms, but rays inside the 60 m building layer descend to the cells wherever a node holds
+    // a building at their height (+7.7 ms of steps, as much as the tree walks they replace) and a cell's triangles have no box
+    // of their own in front of them (+5 ms).
+#if defined(F3D_MESH_FUSED) && !defined(F3D_MESH_FIRST) && !defined(F3D_TRAVERSAL_DESCENT)
+    constexpr bool kFuse = Pending::kMesh;
+#else
+    constexpr bool kFuse = false;
+#endif
+    const bool grid = kFuse && P.terrain.mesh_cell_start != nullptr;
+    if (grid) {
+        if (r.y_exit < 3.0e38f) r.y_exit = f_max(r.y_exit, P.terrain.mesh_top);
+        terrain_tmax = 3.0e38f;
+    }
 #if defined(F3D_TRAVERSAL_DESCENT)
     TraceHit th = trace_terrain(P.terrain, r, true, pend);  // the reference-shaped sorted descent
 #else
@@ -420,8 +420,8 @@ F3D_HD bool occluded(const FrameParams &P, V3 o, float tmin, V3 d, float tmax, b
     // rays carry the curvature policy (apply_curvature is a compile-time constant per call site).
     // (with the curvature policy switched off for the whole render, c2 = 0 and fma(t*t, 0, y) == y: the
     // curved instantiation then computes the flat answers exactly, so there is no third copy of the march)
-    TraceHit th = apply_curvature ? march_terrain<true>(P.terrain, r, true, true, pend, terrain_tmax)
-                                  : march_terrain<false>(P.terrain, r, true, true, pend, terrain_tmax);
+    TraceHit th = apply_curvature ? march_terrain<true, kFuse>(P.terrain, r, true, true, pend, terrain_tmax)
+                                  : march_terrain<false, kFuse>(P.terrain, r, true, true, pend, terrain_tmax);
 #endif
     bool hit = th.hit && th.t < tmax && th.t < 1e30f;
 #if !defined(F3D_MESH_FIRST) && !defined(F3D_TIMING_NO_MESH_ANY)
@@ -429,7 +429,7 @@ F3D_HD bool occluded(const FrameParams &P, V3 o, float tmin, V3 d, float tmax, b
         float t;
         V3 n;
         // (accepted triangles have t < tmax; `t < 1e30` is the reference's own last word on the mesh hit)
-        if (!hit && mesh_any(P.mesh, o, tmin, d, tmax, t, n, pend)) hit = t < 1e30f;
+        if (!hit && !grid && mesh_any(P.mesh, o, tmin, d, tmax, t, n, pend)) hit = t < 1e30f;
     }
 #endif
     return hit;

@@ -92,6 +92,28 @@ F3D_HD T pick4(uint32_t code, T a0, T a1, T a2, T a3) {
     return (code & 2u) ? hi : lo;
 }
 
+// ray_triangle_intersect, hybrid_traversal.wgsl:86-132
+F3D_HD bool ray_triangle(V3 o, float tmin, V3 d, float tmax, V3 v0, V3 v1, V3 v2, float &t_out, V3 &n_out) {
+    V3 e1 = v1 - v0, e2 = v2 - v0;
+    V3 h = cross(d, e2);
+    float a = dot(e1, h);
+    if (f_abs(a) < 1e-7f) return false;
+    float f = 1.0f / a;
+    V3 s = o - v0;
+    float u = f * dot(s, h);
+    if (u < 0.0f || u > 1.0f) return false;
+    V3 q = cross(s, e1);
+    float v = f * dot(d, q);
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float t = f * dot(e2, q);
+    if (t > tmin && t < tmax) {
+        t_out = t;
+        n_out = normalize(cross(e1, e2));
+        return true;
+    }
+    return false;
+}
+
 // Exact ray / bilinear patch solve (terrain_leaf_intersect, :167-235) on a corner record.
 F3D_HD bool leaf_solve(const TerrainDev &T, const RayCtx &r, const LeafRec &h, uint32_t cx, uint32_t cz, float t0,
                        float t1, bool any_hit, float &t_hit) {

@@ -906,6 +906,12 @@ F3D_HD bool vertex_shade(const SceneDev &S, uint32_t frame, const SurfaceHitWf &
     }
     nee.on = nee_on;
     nee.dir_light = dir_light;
+#if defined(F3D_WF_TIMING_NO_SHADOWS)  // timing experiments only (wrong image): where does the kernel's time go?
+    nee.on = 0u;
+#endif
+#if defined(F3D_WF_TIMING_NO_BOUNCE)
+    return false;
+#endif
     return go_on;
 }
 

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../forge3d_amd/csrc/f3d_setup.h"
+#include "../../forge3d_amd/csrc/f3d_meshgrid.h"
 #include "../../forge3d_amd/csrc/f3d_composite.h"
 #include "../../forge3d_amd/csrc/f3d_smoke_sim.h"
 #include "../../forge3d_amd/csrc/f3d_shade.h"
@@ -258,6 +259,23 @@ struct HostTables {
         T.leaves = leaves.data();
         T.nodes = nodes.data();
         T.bands = bands.data();
+        T.mesh_bands = bands.data();  // (no mesh grid: the fused march tests the terrain's band twice)
+        T.mesh_cell_start = nullptr;
+        T.mesh_cell_tris = nullptr;
+        T.mesh_top = 0.0f;
+    }
+    // after attach() and fill_uniforms(): the scene's mesh as a second band of the pyramid (f3d_meshgrid.h), as the product's sessions build it
+    MeshGrid grid;
+    void attach_mesh_grid(TerrainDev &T, const float *vertices, uint32_t vertex_count, const uint32_t *indices, uint32_t index_count) {
+        if (getenv("F3D_EMUL_NO_MESH_GRID")) return;
+        grid = build_mesh_grid(L, T.origin_x, T.origin_z, T.spacing_x, T.spacing_z, vertices, vertex_count, indices, index_count);
+        if (getenv("F3D_EMUL_MESH_GRID_VERBOSE"))
+            fprintf(stderr, "mesh grid: %s, %u triangles, %zu listed in %u x %u cells\n", grid.ok ? "built" : "none", index_count / 3u, grid.tris.size() / 12u, L.cell_w, L.cell_h);
+        if (!grid.ok) return;
+        T.mesh_bands = grid.bands.data();
+        T.mesh_cell_start = grid.cell_start.data();
+        T.mesh_cell_tris = (const float4 *)grid.tris.data();
+        T.mesh_top = grid.top;
     }
     // after attach() and fill_uniforms(): the table depends on the spacing too
     void attach_horizon(TerrainDev &T) {
@@ -591,6 +609,7 @@ int emul_render(const f3d_terrain_ref_desc *d, uint32_t row_begin, uint32_t row_
                     P.mesh.bvh4_nodes = bvh4.data();
                     P.mesh.bvh4_node_count = (uint32_t)bvh4.size();
                 }
+                if (g_use_bvh == 2) t.attach_mesh_grid(P.terrain, d->mesh_vertices, d->mesh_vertex_count, d->mesh_indices, d->mesh_index_count);
             }
         }
         if (row_end == 0) row_end = d->height;
@@ -838,6 +857,8 @@ void *emul_session_create(const f3d_terrain_ref_desc *d, uint32_t row_begin, uin
                     s->P.mesh.bvh4_nodes = s->bvh4.data();
                     s->P.mesh.bvh4_node_count = (uint32_t)s->bvh4.size();
                 }
+                if (g_use_bvh == 2)
+                    s->tables.attach_mesh_grid(s->P.terrain, d->mesh_vertices, d->mesh_vertex_count, d->mesh_indices, d->mesh_index_count);
             }
         }
         if (row_end == 0) row_end = d->height;

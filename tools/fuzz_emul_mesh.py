@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """The mesh walk of csrc/f3d_shade.h on the host emulator against the oracle's sweep over all triangles, on the random scenes
-of tests/scenes.py that carry a mesh (terrain + mesh, every output the same bits): python tools/fuzz_emul_mesh.py first_seed count"""
+of tests/scenes.py that carry a mesh (terrain + mesh, every output the same bits): python tools/fuzz_emul_mesh.py first_seed count [inside]"""
 import sys, time
 import numpy as np
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
@@ -8,10 +8,11 @@ import scenes
 from emul import emul
 from oracle import oracle
 first, count = int(sys.argv[1]), int(sys.argv[2])
+inside = len(sys.argv) > 3 and sys.argv[3] == "inside"  # meshes inside the DEM's footprint: the mesh-band form of the march (csrc/f3d_meshgrid.h)
 bad, done, t0 = [], 0, time.time()
 seed = first
 while done < count and seed < first + 40 * count:
-    dem, size, cam, kw = scenes.random_scene(seed)
+    dem, size, cam, kw = scenes.random_scene_city_inside(seed) if inside else scenes.random_scene(seed)
     seed += 1
     if kw.get("mesh_vertices") is None:
         continue
