@@ -22,9 +22,13 @@ _CSRC = _HERE.parent.parent / "forge3d_amd" / "csrc"
 
 
 def build(force=False):
+    global _LIB
     srcs = [_HERE / "f3d_emul.cpp"] + sorted(_CSRC.glob("*.h"))
+    extra = os.environ.get("F3D_EMUL_CXXFLAGS", "").split()  # experiment switches (-DF3D_...)
+    if extra:  # a library of its own per set of switches: a build with other switches is never taken for this one
+        import hashlib
+        _LIB = _HERE / ("libf3d_emul_%s.so" % hashlib.sha256(" ".join(extra).encode()).hexdigest()[:10])
     if force or not _LIB.exists() or _LIB.stat().st_mtime < max(s.stat().st_mtime for s in srcs):
-        extra = os.environ.get("F3D_EMUL_CXXFLAGS", "").split()  # experiment switches (-DF3D_...)
         tmp = _LIB.with_suffix(f".{os.getpid()}.tmp")  # parallel test workers may all find the library stale: build aside, then rename
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-march=x86-64-v3",
                         "-ffp-contract=off", "-DF3D_HORIZON_LAZY", *extra, str(_HERE / "f3d_emul.cpp"), "-o", str(tmp)],
