@@ -1087,6 +1087,10 @@ int f3d_session_fingerprint(f3d_session *s, uint64_t *out, uint32_t count) {
         t.leaves = nullptr;
         t.nodes = nullptr;
         t.bands = nullptr;
+        t.horizon = nullptr;
+        t.mesh_bands = nullptr;  // (device addresses are not part of what a launch computes with: the tables they name are hashed by content)
+        t.mesh_cell_start = nullptr;
+        t.mesh_cell_tris = nullptr;
         MeshDev m = P.mesh;
         m.vertices = nullptr;
         m.indices = nullptr;

@@ -89,6 +89,7 @@ struct TerrainDev {
     const uint32_t *mesh_cell_start;
     const float4 *mesh_cell_tris;
     float mesh_top;  // the root's mesh band maximum
+    uint32_t mesh_reserved;  // (explicit: the record has no padding, its bytes are hashed by f3d_session_fingerprint)
 };
 
 // Threaded BVH node (f3d_bvh.h): preorder layout, enter -> node + 1, miss / subtree done -> skip.

@@ -157,6 +157,15 @@ F3D_HD bool mesh_bvh4(const MeshDev &M, V3 o, float tmin, V3 d, float tmax, floa
     t_best = tmax;
     const float4 *nodes = reinterpret_cast<const float4 *>(M.bvh4_nodes);
     constexpr uint32_t kDone = 0xFFFFFFFFu;
+    // nearest first is for the rays whose t_best shrinks; an occlusion ray only asks whether there is a triangle at all and mostly
+    // finds none -- -DF3D_BVH4_ANY_SLOT_ORDER (A/B, round 6) walks its children in slot order, without the sort
+#if defined(F3D_BVH4_SLOT_ORDER)
+    constexpr bool kNearestFirst = false;
+#elif defined(F3D_BVH4_ANY_SLOT_ORDER)
+    constexpr bool kNearestFirst = !ANY;
+#else
+    constexpr bool kNearestFirst = true;
+#endif
     uint32_t node = 0u, level = 0u, open = 0u;
     while (node != kDone) {
         const float4 *rec = nodes + 8u * node;
@@ -164,12 +173,8 @@ F3D_HD bool mesh_bvh4(const MeshDev &M, V3 o, float tmin, V3 d, float tmax, floa
         const float4 leaf = rec[6], meta = rec[7];
         F3D_MESH_STAT(0);
         uint32_t hit = 0u;
-#if !defined(F3D_BVH4_SLOT_ORDER)
-        float e0, e1, e2, e3;
-#define F3D_BVH4_KEEP(S, v) e##S = v;
-#else
-#define F3D_BVH4_KEEP(S, v)
-#endif
+        float e0 = 0.0f, e1 = 0.0f, e2 = 0.0f, e3 = 0.0f;
+#define F3D_BVH4_KEEP(S, v) if (kNearestFirst) e##S = v;
 #define F3D_BVH4_SLOT(S, C)                                                                                       \
         {                                                                                                         \
             const float ax = f_fma(lox.C, ix, -oix), bx = f_fma(hix.C, ix, -oix);                                 \
@@ -213,7 +218,7 @@ F3D_HD bool mesh_bvh4(const MeshDev &M, V3 o, float tmin, V3 d, float tmax, floa
             open = 0u;
         }
         uint32_t next = kDone;
-#if !defined(F3D_BVH4_SLOT_ORDER)
+        if constexpr (kNearestFirst) {
         // the next node: the NEAREST inner child entered (the others wait, nearest first, in this level's word:
         // (first_child << 8) | (how many - 1) << 6 | three 2-bit slot numbers), or the next waiting child of the deepest level
         // that holds one.  A near child's triangles shorten t_best before the far children's boxes are tested.
@@ -249,7 +254,7 @@ F3D_HD bool mesh_bvh4(const MeshDev &M, V3 o, float tmin, V3 d, float tmax, floa
             next = (word >> 8) + (word & 3u);
             level = at + 1u;
         }
-#else
+        } else {
         // the next node: the first inner child entered (its siblings wait in this level's word), or the next waiting sibling
         // of the deepest level that holds one, or nothing
         if (inner != 0u) {
@@ -269,7 +274,7 @@ F3D_HD bool mesh_bvh4(const MeshDev &M, V3 o, float tmin, V3 d, float tmax, floa
             next = (word >> 4) + (uint32_t)__builtin_ctz(word & 15u);
             level = at + 1u;
         }
-#endif
+        }
         node = next;
     }
     return best_tri != 0xFFFFFFFFu;
