@@ -394,6 +394,31 @@ def test_hip_terrain_primitive_equals_the_oracle(hip, wfo, seed):
     assert np.array_equal(rest["accum"], want["accum"])
 
 
+def test_emulated_terrain_primitive_on_random_scenes(wfo, emul):
+    """Random DEMs / cameras / suns / sizes (scenes.wavefront_terrain_random_scene, the scenes of tools/gpu_fuzz_wf_terrain.py)."""
+    for seed in range(5000, 5016):
+        scene, w, h, frames = scenes.wavefront_terrain_random_scene(seed)
+        d = scene.as_dict()
+        assert np.array_equal(wfo.render(d, w, h, frames)["accum"], emul.wavefront_render(d, w, h, frames)["accum"]), seed
+
+
+@pytest.mark.gpu
+def test_hip_terrain_primitive_on_random_scenes(hip, wfo):
+    """The heightfield primitive on the device -- closest-hit and shadow rays shared over the wave's lanes, four lanes a pixel --
+    on 60 random scenes (a slice of tools/gpu_fuzz_wf_terrain.py): every output bit for bit, whole and continued."""
+    for seed in range(6000, 6060):
+        scene, w, h, frames = scenes.wavefront_terrain_random_scene(seed)
+        d = scene.as_dict()
+        want = wfo.render(d, w, h, frames)
+        got = hip.render_scene(d, w, h, frames)
+        for key in ("accum", "hdr", "rgba"):
+            assert np.array_equal(got[key], want[key], equal_nan=True), (seed, key)
+        if frames >= 2:
+            part = hip.render_scene(d, w, h, 1, frames_per_launch=1)
+            rest = hip.render_scene(d, w, h, frames - 1, first_frame=1, accum=part["accum"])
+            assert np.array_equal(rest["accum"], want["accum"], equal_nan=True), seed
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(4))
 def test_hip_hair_and_fog_equal_the_oracle(hip, wfo, seed):
