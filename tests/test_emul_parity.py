@@ -287,3 +287,20 @@ def test_four_wide_mesh_walk_is_what_runs_and_equals_the_other_forms():
     for other in images[1:]:
         for key in ("rgba", "albedo", "normal", "depth"):
             assert np.array_equal(images[0][key], other[key], equal_nan=True), key
+
+
+@pytest.mark.parametrize("flags", ["-DF3D_MESH_FUSED", "-DF3D_CLOSEST_TERRAIN_FIRST", "-DF3D_BVH4_ANY_SLOT_ORDER"])
+def test_build_switches_of_the_mesh_path_equal_the_oracle(flags):
+    """The mesh path's A/B builds (round 6: the mesh as a second band of the terrain's pyramid fused into the occlusion rays'
+    march, terrain before mesh for camera rays, occlusion rays walking their children in slot order -- all measured slower and
+    not in the shipped library) stay bit-identical to the oracle's sweep: the emulator compiled with the switch (a library of its
+    own per set of switches, tests/emul/emul.py) on meshes inside the DEM's footprint, in a process of its own."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, F3D_EMUL_CXXFLAGS=flags)
+    out = subprocess.run([sys.executable, str(root / "tools" / "fuzz_emul_mesh.py"), "7000", "24", "inside"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-400:]
+    assert "24 mesh scenes from seed 7000: mismatches []" in out.stdout, out.stdout[-300:]
