@@ -3,7 +3,9 @@
 of tests/scenes.py that carry a mesh (terrain + mesh, every output the same bits): python tools/fuzz_emul_mesh.py first_seed count [inside]"""
 import sys, time
 import numpy as np
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / 'tests'))
 import scenes
 from emul import emul
 from oracle import oracle
